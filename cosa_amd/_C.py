@@ -1,0 +1,109 @@
+"""ctypes binding of libcosa_hip.so -- the only way the Python host code reaches the HIP kernels.
+
+The C ABI is declared in include/cosa_hip.h.  Loading FAILS LOUDLY when the shared library is
+missing: there is no CPU or eager-PyTorch fallback anywhere in the product path.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libcosa_hip.so")
+_lib = None
+
+c_void_p, c_int, c_float, c_size_t = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+
+
+class CosaError(RuntimeError):
+    pass
+
+
+_SIGS = {
+    "cosa_abi_version": (c_int, []),
+    "cosa_last_error": (ctypes.c_char_p, []),
+    "cosa_denormalize_img": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "cosa_cam_minmax_norm": (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    "cosa_cam_flip_merge_upsample": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "cosa_cam2mask_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "cosa_cam2mask": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float,
+                              c_int, c_int, ctypes.POINTER(c_int), c_int, c_int, c_float, c_void_p, c_size_t, c_void_p]),
+    "cosa_par_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "cosa_par_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, ctypes.POINTER(c_int), c_int,
+                                 c_int, c_void_p, c_size_t, c_void_p]),
+    "bilateralfilter": (None, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_float, c_float]),
+    "bilateralfilter_batch": (None, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                     c_float, c_float]),
+    "cosa_bilateral_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "cosa_bilateralfilter_batch_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_float,
+                                               c_void_p, c_void_p, c_size_t, c_void_p]),
+    "cosa_dense_energy_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                          c_int, c_float, c_float, c_void_p, c_size_t, c_void_p]),
+    "cosa_dense_energy_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+}
+
+# entry points added by later translation units register themselves here (vit / gemm / attention)
+EXTRA_SIGS = {}
+
+
+def lib():
+    """Load libcosa_hip.so (once).  Raises CosaError if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise CosaError(
+                f"{LIB_PATH} is missing: build the HIP extension first (python -m cosa_amd.build). "
+                "cosa_amd has no CPU fallback.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in list(_SIGS.items()) + list(EXTRA_SIGS.items()):
+            try:
+                fn = getattr(L, name)
+            except AttributeError as e:
+                raise CosaError(f"libcosa_hip.so does not export {name} (stale build?)") from e
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def declared_symbols():
+    return list(_SIGS) + list(EXTRA_SIGS)
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().cosa_last_error().decode("utf-8", "replace")
+        raise CosaError(f"{what} failed (code {rc}): {msg}")
+
+
+def stream_ptr():
+    """Raw hipStream_t of torch's current stream (so kernels order with torch ops)."""
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise CosaError("cosa_amd operators need device (HIP) tensors; there is no CPU path")
+
+
+_ws_cache = {}
+
+
+def workspace(nbytes, device, tag="default"):
+    """Grow-only per-(device,tag) byte workspace (never freed inside the step: graph-safe)."""
+    key = (str(device), tag)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def int_array(values):
+    arr = (c_int * len(values))(*[int(v) for v in values])
+    return arr

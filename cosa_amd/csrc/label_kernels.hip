@@ -1,0 +1,416 @@
+// label_kernels.hip -- CAM -> pseudo-label path (HBM-bound byte/index work), gfx950.
+//
+// Compiled with -ffp-contract=off: every float op below is one IEEE binary32 operation in the
+// order written and FMAs appear only as __builtin_fmaf(), following DESIGN.md "Arithmetic spec".
+// The label maps are therefore bit-identical to the CPU oracle.
+//
+// Reference: utils/seg_helper.py:232-275 (multi_scale_camseg tail), :547-551 (cam_validation),
+//            :721-797 (cam2mask, _refine_cams), utils/torch_helper.py:354-367 (denormalize_img).
+#include "kernels.hpp"
+
+namespace cosa {
+namespace {
+
+// ---- spec E: deterministic expf --------------------------------------------------------
+__device__ __forceinline__ float cosa_expf(float x)
+{
+    if (x < -87.0f) return 0.0f;
+    if (x > 88.0f) x = 88.0f;
+    float k = __builtin_rintf(x * 1.44269504088896341f);
+    float r = __builtin_fmaf(k, -0.693359375f, x);
+    r = __builtin_fmaf(k, 2.12194440e-4f, r);
+    float p = 1.9875691500E-4f;
+    p = __builtin_fmaf(p, r, 1.3981999507E-3f);
+    p = __builtin_fmaf(p, r, 8.3334519073E-3f);
+    p = __builtin_fmaf(p, r, 4.1665795894E-2f);
+    p = __builtin_fmaf(p, r, 1.6666665459E-1f);
+    p = __builtin_fmaf(p, r, 5.0000001201E-1f);
+    float r2 = r * r;
+    float e = __builtin_fmaf(p, r2, r);
+    e = e + 1.0f;
+    return __builtin_ldexpf(e, (int)k);
+}
+
+// ATen area_pixel_compute_source_index (align_corners=False) + guard, spec U
+__device__ __forceinline__ void src_index(int dst, int in, int out, float scale, int &i0, int &i1, float &l0, float &l1)
+{
+    if (in == out) { i0 = dst; i1 = dst < in - 1 ? dst + 1 : dst; l0 = 1.0f; l1 = 0.0f; return; }
+    float src = scale * ((float)dst + 0.5f) - 0.5f;
+    if (src < 0.0f) src = 0.0f;
+    int i = (int)src;
+    if (i > in - 1) i = in - 1;
+    i0 = i;
+    i1 = i < in - 1 ? i + 1 : i;
+    l1 = src - (float)i;
+    l0 = 1.0f - l1;
+}
+
+__device__ __forceinline__ float bilerp(float p00, float p01, float p10, float p11, float lx0, float lx1, float ly0, float ly1)
+{
+    float r0 = __builtin_fmaf(p00, lx0, p01 * lx1);
+    float r1 = __builtin_fmaf(p10, lx0, p11 * lx1);
+    return __builtin_fmaf(r0, ly0, r1 * ly1);
+}
+
+// ---- denormalize_img ---------------------------------------------------------------------
+__global__ void denorm_kernel(const float *__restrict__ img, float *__restrict__ out, int HW, size_t total)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {
+        int c = (int)((i / HW) % 3);
+        float sd = c == 0 ? 58.395f : (c == 1 ? 57.12f : 57.375f);
+        float mn = c == 0 ? 123.675f : (c == 1 ? 116.28f : 103.53f);
+        float v = img[i] * sd;
+        v = v + mn;
+        int iv = (int)v;
+        unsigned char u = (unsigned char)iv;
+        out[i] = (float)u / 255.0f;
+    }
+}
+
+// ---- block reductions (max) ---------------------------------------------------------------
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+template <int NT>
+__device__ __forceinline__ float block_max(float v, float *sh)
+{
+    v = wave_max(v);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sh[wid] = v;
+    __syncthreads();
+    float r = sh[0];
+#pragma unroll
+    for (int i = 1; i < NT / 64; i++) r = fmaxf(r, sh[i]);
+    return r;
+}
+
+// one 1024-thread block per (b,c) plane; float4 path when HW % 4 == 0
+__global__ __launch_bounds__(1024) void minmax_norm_kernel(float *__restrict__ cam, int HW)
+{
+    __shared__ float sh[16];
+    float *x = cam + (size_t)blockIdx.x * HW;
+    float mneg = -INFINITY;
+    if ((HW & 3) == 0) {
+        const float4 *x4 = reinterpret_cast<const float4 *>(x);
+        for (int i = threadIdx.x; i < HW / 4; i += 1024) {
+            float4 v = x4[i];
+            mneg = fmaxf(mneg, fmaxf(fmaxf(-v.x, -v.y), fmaxf(-v.z, -v.w)));
+        }
+    } else {
+        for (int i = threadIdx.x; i < HW; i += 1024) mneg = fmaxf(mneg, -x[i]);
+    }
+    mneg = block_max<1024>(mneg, sh);
+    float mx = -INFINITY;
+    if ((HW & 3) == 0) {
+        const float4 *x4 = reinterpret_cast<const float4 *>(x);
+        for (int i = threadIdx.x; i < HW / 4; i += 1024) {
+            float4 v = x4[i];
+            mx = fmaxf(mx, fmaxf(fmaxf(v.x + mneg, v.y + mneg), fmaxf(v.z + mneg, v.w + mneg)));
+        }
+    } else {
+        for (int i = threadIdx.x; i < HW; i += 1024) mx = fmaxf(mx, x[i] + mneg);
+    }
+    mx = block_max<1024>(mx, sh);
+    const float den = mx + 1e-5f;
+    if ((HW & 3) == 0) {
+        float4 *x4 = reinterpret_cast<float4 *>(x);
+        for (int i = threadIdx.x; i < HW / 4; i += 1024) {
+            float4 v = x4[i];
+            v.x = (v.x + mneg) / den; v.y = (v.y + mneg) / den; v.z = (v.z + mneg) / den; v.w = (v.w + mneg) / den;
+            x4[i] = v;
+        }
+    } else {
+        for (int i = threadIdx.x; i < HW; i += 1024) x[i] = (x[i] + mneg) / den;
+    }
+}
+
+// ---- multi_scale_camseg tail: upsample + flip-merge (+relu) + accumulate ---------------------
+// thread per output pixel; grid (ceil(S*S/256), C, B)
+__global__ __launch_bounds__(256) void flip_merge_upsample_kernel(const float *__restrict__ src, float *__restrict__ dst,
+                                                                 int B, int C, int h, int w, int S, float sy, float sx,
+                                                                 int mode, int accumulate)
+{
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    if (pix >= S * S) return;
+    const int Y = pix / S, X = pix - Y * S;
+    const int c = blockIdx.y, b = blockIdx.z;
+    int y0, y1, x0, x1, fx0, fx1;
+    float ly0, ly1, lx0, lx1, flx0, flx1;
+    src_index(Y, h, S, sy, y0, y1, ly0, ly1);
+    src_index(X, w, S, sx, x0, x1, lx0, lx1);
+    src_index(S - 1 - X, w, S, sx, fx0, fx1, flx0, flx1);
+    const float *p = src + ((size_t)b * C + c) * h * w;
+    const float *q = src + ((size_t)(b + B) * C + c) * h * w;
+    float u1 = bilerp(p[y0 * w + x0], p[y0 * w + x1], p[y1 * w + x0], p[y1 * w + x1], lx0, lx1, ly0, ly1);
+    float u2 = bilerp(q[y0 * w + fx0], q[y0 * w + fx1], q[y1 * w + fx0], q[y1 * w + fx1], flx0, flx1, ly0, ly1);
+    float v;
+    if (mode == 0) { v = fmaxf(u1, u2); v = v > 0.0f ? v : 0.0f; }
+    else v = u1 + u2;
+    const size_t o = ((size_t)b * C + c) * S * S + pix;
+    dst[o] = accumulate ? dst[o] + v : v;
+}
+
+// ---- active channel list -------------------------------------------------------------------
+__global__ void active_kernel(const float *__restrict__ labels, int *__restrict__ act, int *__restrict__ kcount, int B, int C)
+{
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    int *a = act + (size_t)b * (C + 1);
+    int K = 0;
+    a[K++] = 0;
+    for (int c = 0; c < C; c++)
+        if (labels[(size_t)b * C + c] != 0.0f) a[K++] = c + 1;
+    kcount[b] = K;
+    kcount[B + b] = 2 * K;   // hi+lo stacked plane count, used by the PAR step
+}
+
+// ---- spec L: threshold plane + /2 bilinear + active softmax (hi and lo in one pass) ---------------
+// P layout: [B][2][Kmax][s*s]  (hi planes then lo planes), Kmax = C+1
+template <int DS>
+__device__ __forceinline__ float lowres_value(const float *__restrict__ pl, float lab, int S, int y, int x)
+{
+    if (DS == 2) {
+        const float2 t = *reinterpret_cast<const float2 *>(pl + (size_t)(2 * y) * S + 2 * x);
+        const float2 u = *reinterpret_cast<const float2 *>(pl + (size_t)(2 * y + 1) * S + 2 * x);
+        float a00 = t.x * lab, a01 = t.y * lab, a10 = u.x * lab, a11 = u.y * lab;
+        float r0 = a00 * 0.5f + a01 * 0.5f;
+        float r1 = a10 * 0.5f + a11 * 0.5f;
+        return r0 * 0.5f + r1 * 0.5f;
+    } else {
+        return pl[(size_t)y * S + x] * lab;
+    }
+}
+
+template <int DS>
+__global__ __launch_bounds__(256) void lowres_softmax_kernel(const float *__restrict__ cams, const float *__restrict__ labels,
+                                                            const int *__restrict__ act, const int *__restrict__ kcount,
+                                                            float *__restrict__ P, int C, int S, int s, float thr_hi, float thr_lo, int fold)
+{
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    if (pix >= s * s) return;
+    const int b = blockIdx.y;
+    const int y = pix / s, x = pix - y * s;
+    const int K = kcount[b];
+    const int Kmax = C + 1;
+    const int *a = act + (size_t)b * Kmax;
+    const float *cam = cams + (size_t)b * C * S * S;
+    const float *lab = labels + (size_t)b * C;
+    const size_t ss = (size_t)s * s;
+    float *Phi = P + ((size_t)b * 2 + 0) * Kmax * ss + pix;
+    float *Plo = P + ((size_t)b * 2 + 1) * Kmax * ss + pix;
+
+    float mc = -INFINITY;
+    for (int k = 1; k < K; k++) {
+        const int c = a[k] - 1;
+        float v = lowres_value<DS>(cam + (size_t)c * S * S, fold ? lab[c] : 1.0f, S, y, x);
+        mc = v > mc ? v : mc;
+    }
+    const float mhi = mc > thr_hi ? mc : thr_hi;
+    const float mlo = mc > thr_lo ? mc : thr_lo;
+    float ehi0 = cosa_expf(thr_hi - mhi), elo0 = cosa_expf(thr_lo - mlo);
+    float shi = 0.0f + ehi0, slo = 0.0f + elo0;
+    for (int k = 1; k < K; k++) {
+        const int c = a[k] - 1;
+        float v = lowres_value<DS>(cam + (size_t)c * S * S, fold ? lab[c] : 1.0f, S, y, x);
+        shi = shi + cosa_expf(v - mhi);
+        slo = slo + cosa_expf(v - mlo);
+    }
+    Phi[0] = ehi0 / shi;
+    Plo[0] = elo0 / slo;
+    for (int k = 1; k < K; k++) {
+        const int c = a[k] - 1;
+        float v = lowres_value<DS>(cam + (size_t)c * S * S, fold ? lab[c] : 1.0f, S, y, x);
+        Phi[(size_t)k * ss] = cosa_expf(v - mhi) / shi;
+        Plo[(size_t)k * ss] = cosa_expf(v - mlo) / slo;
+    }
+}
+
+// ---- /2 bilinear of the de-normalised image for the PAR hook (utils/seg_helper.py:735-737) ------
+__global__ __launch_bounds__(256) void halve_image_kernel(const float *__restrict__ img, float *__restrict__ out, int planes, int S)
+{
+    const int s = S / 2;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)planes * s * s) return;
+    const int pl = (int)(i / ((size_t)s * s));
+    const int pix = (int)(i - (size_t)pl * s * s);
+    const int y = pix / s, x = pix - y * s;
+    const float *p = img + (size_t)pl * S * S;
+    const float2 t = *reinterpret_cast<const float2 *>(p + (size_t)(2 * y) * S + 2 * x);
+    const float2 u = *reinterpret_cast<const float2 *>(p + (size_t)(2 * y + 1) * S + 2 * x);
+    float r0 = t.x * 0.5f + t.y * 0.5f;
+    float r1 = u.x * 0.5f + u.y * 0.5f;
+    out[i] = r0 * 0.5f + r1 * 0.5f;
+}
+
+// ---- spec U: upsample + first-max argmax + key gather + box + hi/lo merge ------------------------
+__device__ __forceinline__ int argmax_up(const float *__restrict__ Pb, int K, size_t ss, int s,
+                                         int y0, int y1, int x0, int x1, float ly0, float ly1, float lx0, float lx1)
+{
+    float best = 0.0f;
+    int bi = 0;
+    for (int k = 0; k < K; k++) {
+        const float *pl = Pb + (size_t)k * ss;
+        float v = bilerp(pl[y0 * s + x0], pl[y0 * s + x1], pl[y1 * s + x0], pl[y1 * s + x1], lx0, lx1, ly0, ly1);
+        if (k == 0 || v > best) { best = v; bi = k; }
+    }
+    return bi;
+}
+
+__global__ __launch_bounds__(256) void upsample_argmax_merge_kernel(const float *__restrict__ P, const int *__restrict__ act,
+                                                                   const int *__restrict__ kcount, const int32_t *__restrict__ boxes,
+                                                                   float *__restrict__ mask, int C, int S, int s, float scale,
+                                                                   float ignore_index)
+{
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    if (pix >= S * S) return;
+    const int b = blockIdx.y;
+    const int Y = pix / S, X = pix - Y * S;
+    const int32_t *bx = boxes + b * 4;
+    float r = ignore_index;
+    if (Y >= bx[0] && Y < bx[1] && X >= bx[2] && X < bx[3]) {
+        const int K = kcount[b];
+        const int Kmax = C + 1;
+        const size_t ss = (size_t)s * s;
+        int y0, y1, x0, x1;
+        float ly0, ly1, lx0, lx1;
+        src_index(Y, s, S, scale, y0, y1, ly0, ly1);
+        src_index(X, s, S, scale, x0, x1, lx0, lx1);
+        const int *a = act + (size_t)b * Kmax;
+        const int khi = argmax_up(P + ((size_t)b * 2 + 0) * Kmax * ss, K, ss, s, y0, y1, x0, x1, ly0, ly1, lx0, lx1);
+        const int klo = argmax_up(P + ((size_t)b * 2 + 1) * Kmax * ss, K, ss, s, y0, y1, x0, x1, ly0, ly1, lx0, lx1);
+        const float hi = (float)a[khi], lo = (float)a[klo];
+        r = hi;
+        if (hi == 0.0f) r = ignore_index;
+        if (hi + lo == 0.0f) r = 0.0f;
+    }
+    mask[(size_t)b * S * S + pix] = r;
+}
+
+}  // namespace
+}  // namespace cosa
+
+using namespace cosa;
+
+extern "C" int cosa_denormalize_img(const float *img, float *out, int B, int H, int W, void *stream)
+{
+    COSA_REQUIRE(img && out && B > 0 && H > 0 && W > 0, "cosa_denormalize_img: bad arguments");
+    const size_t total = (size_t)B * 3 * H * W;
+    int grid = (int)((total + 255) / 256);
+    if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(denorm_kernel, dim3(grid), dim3(256), 0, as_stream(stream), img, out, H * W, total);
+    COSA_LAUNCH_CHECK();
+    return COSA_OK;
+}
+
+extern "C" int cosa_cam_minmax_norm(float *cam, int BC, int HW, void *stream)
+{
+    COSA_REQUIRE(cam && BC > 0 && HW > 0, "cosa_cam_minmax_norm: bad arguments");
+    hipLaunchKernelGGL(minmax_norm_kernel, dim3(BC), dim3(1024), 0, as_stream(stream), cam, HW);
+    COSA_LAUNCH_CHECK();
+    return COSA_OK;
+}
+
+extern "C" int cosa_cam_flip_merge_upsample(const float *src, float *dst, int B, int C, int h, int w, int S,
+                                            int mode, int accumulate, void *stream)
+{
+    COSA_REQUIRE(src && dst && B > 0 && C > 0 && h > 0 && w > 0 && S > 0, "cosa_cam_flip_merge_upsample: bad arguments");
+    COSA_REQUIRE(mode == 0 || mode == 1, "cosa_cam_flip_merge_upsample: mode must be 0 or 1");
+    COSA_REQUIRE(C <= 65535 && B <= 65535, "cosa_cam_flip_merge_upsample: grid too large");
+    const float sy = (float)h / (float)S, sx = (float)w / (float)S;
+    dim3 grid((S * S + 255) / 256, C, B);
+    hipLaunchKernelGGL(flip_merge_upsample_kernel, grid, dim3(256), 0, as_stream(stream), src, dst, B, C, h, w, S, sy, sx,
+                       mode, accumulate);
+    COSA_LAUNCH_CHECK();
+    return COSA_OK;
+}
+
+// workspace layout of cam2mask: act[B*(C+1)] | kcount[2B] | P[B][2][C+1][s*s] | P2 (same) | img_lo[B*3*s*s] | aff[B][NN][s*s]
+extern "C" size_t cosa_cam2mask_workspace_bytes(int B, int C, int S, int downscale, int n_dil)
+{
+    const int s = downscale ? S / downscale : S;
+    const size_t ss = (size_t)s * s;
+    size_t bytes = 0;
+    bytes += align_up((size_t)B * (C + 1) * sizeof(int), 256);
+    bytes += align_up((size_t)2 * B * sizeof(int), 256);
+    bytes += align_up((size_t)B * 2 * (C + 1) * ss * sizeof(float), 256);
+    if (n_dil > 0) {
+        bytes += align_up((size_t)B * 2 * (C + 1) * ss * sizeof(float), 256);
+        bytes += align_up((size_t)B * 3 * ss * sizeof(float), 256);
+        bytes += align_up((size_t)B * n_dil * 8 * ss * sizeof(float), 256);
+    }
+    return bytes;
+}
+
+extern "C" int cosa_cam2mask(const float *images, const int32_t *boxes, const float *cams, const float *labels,
+                             float *mask, int B, int C, int S, float thr_hi, float thr_lo, int downscale,
+                             int fold_validation, const int *dilations, int n_dil, int par_iters, float ignore_index,
+                             void *workspace, size_t workspace_bytes, void *stream)
+{
+    COSA_REQUIRE(boxes && cams && labels && mask && workspace, "cosa_cam2mask: null pointer");
+    COSA_REQUIRE(B > 0 && C > 0 && S > 0 && B <= 65535, "cosa_cam2mask: bad shape");
+    COSA_REQUIRE(downscale == 0 || downscale == 2, "cosa_cam2mask: downscale must be 0 or 2");
+    COSA_REQUIRE(!downscale || (S % 2) == 0, "cosa_cam2mask: S must be even when downscale=2");
+    const bool use_par = par_iters > 0;
+    if (!use_par) n_dil = 0;
+    COSA_REQUIRE(!use_par || (images && dilations && n_dil > 0 && n_dil <= kMaxDil), "cosa_cam2mask: PAR needs images and 1..8 dilations");
+    if (workspace_bytes < cosa_cam2mask_workspace_bytes(B, C, S, downscale, n_dil)) {
+        set_error("cosa_cam2mask: workspace too small");
+        return COSA_ENOMEM;
+    }
+    hipStream_t st = as_stream(stream);
+    const int s = downscale ? S / downscale : S;
+    const size_t ss = (size_t)s * s;
+    const int Kmax = C + 1;
+    Carver cv(workspace);
+    int *act = cv.take<int>((size_t)B * Kmax);
+    int *kcount = cv.take<int>((size_t)2 * B);
+    float *P = cv.take<float>((size_t)B * 2 * Kmax * ss);
+
+    hipLaunchKernelGGL(active_kernel, dim3((B + 63) / 64), dim3(64), 0, st, labels, act, kcount, B, C);
+    COSA_LAUNCH_CHECK();
+    dim3 g1((unsigned)((ss + 255) / 256), B);
+    if (downscale == 2)
+        hipLaunchKernelGGL(lowres_softmax_kernel<2>, g1, dim3(256), 0, st, cams, labels, act, kcount, P, C, S, s, thr_hi, thr_lo, fold_validation);
+    else
+        hipLaunchKernelGGL(lowres_softmax_kernel<0>, g1, dim3(256), 0, st, cams, labels, act, kcount, P, C, S, s, thr_hi, thr_lo, fold_validation);
+    COSA_LAUNCH_CHECK();
+
+    const float *Pfinal = P;
+    if (use_par) {
+        float *P2 = cv.take<float>((size_t)B * 2 * Kmax * ss);
+        float *img_lo = cv.take<float>((size_t)B * 3 * ss);
+        float *aff = cv.take<float>((size_t)B * n_dil * 8 * ss);
+        ParPlan plan;
+        int rc = par_make_plan(dilations, n_dil, &plan);
+        if (rc) return rc;
+        const float *im = images;
+        if (downscale == 2) {
+            const size_t tot = (size_t)B * 3 * ss;
+            hipLaunchKernelGGL(halve_image_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, images, img_lo, B * 3, S);
+            COSA_LAUNCH_CHECK();
+            im = img_lo;
+        }
+        rc = par_launch_affinity(im, aff, B, s, s, plan, st);
+        if (rc) return rc;
+        float *src = P, *dst = P2;
+        for (int it = 0; it < par_iters; it++) {
+            // hi and lo stacks are contiguous: treat as 2*Kmax planes, of which [0,K) and [Kmax,Kmax+K) are live
+            rc = par_launch_step(aff, src, dst, B, 2 * Kmax, kcount, (size_t)2 * Kmax * ss, s, s, plan, st);
+            if (rc) return rc;
+            float *t = src; src = dst; dst = t;
+        }
+        Pfinal = src;
+    }
+    dim3 g3((S * S + 255) / 256, B);
+    const float scale = (float)s / (float)S;
+    hipLaunchKernelGGL(upsample_argmax_merge_kernel, g3, dim3(256), 0, st, Pfinal, act, kcount, boxes, mask, C, S, s, scale, ignore_index);
+    COSA_LAUNCH_CHECK();
+    return COSA_OK;
+}

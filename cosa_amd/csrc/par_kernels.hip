@@ -1,0 +1,296 @@
+// par_kernels.hip -- Pixel-Adaptive Refinement (models/PAR.py:26-91) for gfx950.
+//
+// Compiled with -ffp-contract=off; follows DESIGN.md "Arithmetic spec" (spec P) so that the
+// refined masks -- and the label maps cut from them -- are bit-identical to the CPU oracle.
+//
+//   affinity:  per pixel, 8 neighbours x n_dil dilations (replicate border):
+//              aff_n = softmax_n( mean_c( -(|x_n - x| / (std_n(x) + 1e-8) / 0.3)^2 ) ) + 0.01 * posw_n
+//   step:      m'[k] = sum_n aff_n * m[k](neighbour n)        (num_iter times, ping-pong)
+//
+// Layout: aff [B][NN][h*w] (plane per neighbour: coalesced across the wavefront),
+//         masks [B][planes][h*w].
+#include "kernels.hpp"
+#include <cmath>
+
+namespace cosa {
+namespace {
+
+__device__ __forceinline__ float cosa_expf(float x)
+{
+    if (x < -87.0f) return 0.0f;
+    if (x > 88.0f) x = 88.0f;
+    float k = __builtin_rintf(x * 1.44269504088896341f);
+    float r = __builtin_fmaf(k, -0.693359375f, x);
+    r = __builtin_fmaf(k, 2.12194440e-4f, r);
+    float p = 1.9875691500E-4f;
+    p = __builtin_fmaf(p, r, 1.3981999507E-3f);
+    p = __builtin_fmaf(p, r, 8.3334519073E-3f);
+    p = __builtin_fmaf(p, r, 4.1665795894E-2f);
+    p = __builtin_fmaf(p, r, 1.6666665459E-1f);
+    p = __builtin_fmaf(p, r, 5.0000001201E-1f);
+    float r2 = r * r;
+    float e = __builtin_fmaf(p, r2, r);
+    e = e + 1.0f;
+    return __builtin_ldexpf(e, (int)k);
+}
+
+// host twin of the same spec (for the constant position prior)
+inline float host_expf(float x)
+{
+    if (x < -87.0f) return 0.0f;
+    if (x > 88.0f) x = 88.0f;
+    float k = std::rint(x * 1.44269504088896341f);
+    float r = std::fma(k, -0.693359375f, x);
+    r = std::fma(k, 2.12194440e-4f, r);
+    float p = 1.9875691500E-4f;
+    p = std::fma(p, r, 1.3981999507E-3f);
+    p = std::fma(p, r, 8.3334519073E-3f);
+    p = std::fma(p, r, 4.1665795894E-2f);
+    p = std::fma(p, r, 1.6666665459E-1f);
+    p = std::fma(p, r, 5.0000001201E-1f);
+    float r2 = r * r;
+    float e = std::fma(p, r2, r);
+    e = e + 1.0f;
+    return std::ldexp(e, (int)k);
+}
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// neighbour t of get_kernel (models/PAR.py:10-24): (dy,dx) in {-1,0,1}
+__device__ __forceinline__ void nbr_off(int t, int &dy, int &dx)
+{
+    // t: 0 1 2 3 4 5 6 7 -> dy: -1 -1 -1 0 0 1 1 1 ; dx: -1 0 1 -1 1 -1 0 1
+    const int tt = t < 4 ? t : t + 1;   // skip the centre of the 3x3
+    dy = tt / 3 - 1;
+    dx = tt % 3 - 1;
+}
+
+__global__ __launch_bounds__(256) void par_affinity_kernel(const float *__restrict__ imgs, float *__restrict__ aff,
+                                                          int h, int w, ParPlan plan)
+{
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    const int hw = h * w;
+    if (pix >= hw) return;
+    const int b = blockIdx.y;
+    const int y = pix / w, x = pix - y * w;
+    const int NN = plan.n_dil * 8;
+    const float *img = imgs + (size_t)b * 3 * hw;
+    float sd[3], ctr[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float *pl = img + (size_t)c * hw;
+        ctr[c] = pl[pix];
+        float sum = 0.0f;
+        for (int n = 0; n < NN; n++) {
+            int dy, dx;
+            nbr_off(n & 7, dy, dx);
+            const int d = plan.dil[n >> 3];
+            sum = sum + pl[clampi(y + dy * d, 0, h - 1) * w + clampi(x + dx * d, 0, w - 1)];
+        }
+        const float mean = sum / (float)NN;
+        float var = 0.0f;
+        for (int n = 0; n < NN; n++) {
+            int dy, dx;
+            nbr_off(n & 7, dy, dx);
+            const int d = plan.dil[n >> 3];
+            float dl = pl[clampi(y + dy * d, 0, h - 1) * w + clampi(x + dx * d, 0, w - 1)] - mean;
+            var = var + dl * dl;
+        }
+        var = var / (float)(NN - 1);
+        sd[c] = __builtin_sqrtf(var) + 1e-8f;
+    }
+    float *out = aff + (size_t)b * NN * hw + pix;
+    // logits are staged through the output buffer (own slot per thread): pass 1 logits + max
+    float mx = -INFINITY;
+    for (int n = 0; n < NN; n++) {
+        int dy, dx;
+        nbr_off(n & 7, dy, dx);
+        const int d = plan.dil[n >> 3];
+        const int o = clampi(y + dy * d, 0, h - 1) * w + clampi(x + dx * d, 0, w - 1);
+        float acc = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            float a = __builtin_fabsf(img[(size_t)c * hw + o] - ctr[c]);
+            float q = a / sd[c];
+            q = q / 0.3f;
+            acc = acc + (-(q * q));
+        }
+        const float lg = acc / 3.0f;
+        out[(size_t)n * hw] = lg;
+        mx = lg > mx ? lg : mx;
+    }
+    float es = 0.0f;
+    for (int n = 0; n < NN; n++) {
+        const float e = cosa_expf(out[(size_t)n * hw] - mx);
+        out[(size_t)n * hw] = e;
+        es = es + e;
+    }
+    for (int n = 0; n < NN; n++) {
+        const float a = out[(size_t)n * hw] / es;
+        out[(size_t)n * hw] = a + 0.01f * plan.posw[n];
+    }
+}
+
+// one propagation step; each thread owns one pixel of up to CG live planes.
+template <int CG>
+__global__ __launch_bounds__(256) void par_step_kernel(const float *__restrict__ aff, const float *__restrict__ src,
+                                                      float *__restrict__ dst, const int *__restrict__ kcount, int Kfull,
+                                                      int halves, int half_planes, size_t img_stride, int h, int w, ParPlan plan)
+{
+    const int b = blockIdx.z;
+    const int K = kcount ? kcount[b] : Kfull;
+    const int live = K * halves;
+    const int j0 = blockIdx.y * CG;
+    if (j0 >= live) return;
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    const int hw = h * w;
+    if (pix >= hw) return;
+    const int y = pix / w, x = pix - y * w;
+    const int NN = plan.n_dil * 8;
+    const float *sp[CG];
+    float *dp[CG];
+    float acc[CG];
+    bool ok[CG];
+#pragma unroll
+    for (int i = 0; i < CG; i++) {
+        int j = j0 + i;
+        ok[i] = j < live;
+        if (!ok[i]) j = j0;
+        const int half = j / K;
+        const int plane = half * half_planes + (j - half * K);
+        sp[i] = src + (size_t)b * img_stride + (size_t)plane * hw;
+        dp[i] = dst + (size_t)b * img_stride + (size_t)plane * hw;
+        acc[i] = 0.0f;
+    }
+    const float *ab = aff + (size_t)b * NN * hw + pix;
+    for (int n = 0; n < NN; n++) {
+        int dy, dx;
+        nbr_off(n & 7, dy, dx);
+        const int d = plan.dil[n >> 3];
+        const int o = clampi(y + dy * d, 0, h - 1) * w + clampi(x + dx * d, 0, w - 1);
+        const float a = ab[(size_t)n * hw];
+#pragma unroll
+        for (int i = 0; i < CG; i++) acc[i] = acc[i] + sp[i][o] * a;
+    }
+#pragma unroll
+    for (int i = 0; i < CG; i++)
+        if (ok[i]) dp[i][pix] = acc[i];
+}
+
+}  // namespace
+
+int par_make_plan(const int *dilations, int n_dil, ParPlan *plan)
+{
+    COSA_REQUIRE(dilations && n_dil > 0 && n_dil <= kMaxDil, "PAR: 1..%d dilations supported", kMaxDil);
+    plan->n_dil = n_dil;
+    const int NN = n_dil * 8;
+    float pos[kMaxDil * 8];
+    const float sq2 = (float)std::sqrt(2.0);
+    for (int di = 0; di < n_dil; di++) {
+        COSA_REQUIRE(dilations[di] > 0, "PAR: dilation must be positive");
+        plan->dil[di] = dilations[di];
+        for (int t = 0; t < 8; t++) {
+            const float kk = (t == 0 || t == 2 || t == 5 || t == 7) ? sq2 : 1.0f;
+            pos[di * 8 + t] = kk * (float)dilations[di];
+        }
+    }
+    for (int di = n_dil; di < kMaxDil; di++) plan->dil[di] = 1;
+    // spec P (position prior): every op one binary32 operation, same order as the oracle
+    volatile float sum = 0.0f;
+    for (int n = 0; n < NN; n++) sum = sum + pos[n];
+    volatile float mean = sum / (float)NN;
+    volatile float var = 0.0f;
+    for (int n = 0; n < NN; n++) {
+        volatile float dl = pos[n] - mean;
+        volatile float sq = dl * dl;
+        var = var + sq;
+    }
+    var = var / (float)(NN - 1);
+    volatile float sd = std::sqrt((float)var);
+    float mx = -INFINITY;
+    for (int n = 0; n < NN; n++) {
+        volatile float q = pos[n] / (sd + 1e-8f);
+        q = q / 0.3f;
+        volatile float qq = q * q;
+        pos[n] = -qq;
+        if (pos[n] > mx) mx = pos[n];
+    }
+    volatile float es = 0.0f;
+    for (int n = 0; n < NN; n++) {
+        plan->posw[n] = host_expf(pos[n] - mx);
+        es = es + plan->posw[n];
+    }
+    for (int n = 0; n < NN; n++) plan->posw[n] = plan->posw[n] / es;
+    for (int n = NN; n < kMaxDil * 8; n++) plan->posw[n] = 0.0f;
+    return COSA_OK;
+}
+
+int par_launch_affinity(const float *imgs, float *aff, int B, int h, int w, const ParPlan &plan, hipStream_t st)
+{
+    dim3 grid((h * w + 255) / 256, B);
+    hipLaunchKernelGGL(par_affinity_kernel, grid, dim3(256), 0, st, imgs, aff, h, w, plan);
+    COSA_LAUNCH_CHECK();
+    return COSA_OK;
+}
+
+// planes per image = Kmax; when kcount != null the live planes of image b are the first kcount[b] planes of each of
+// `halves` equal halves of the stack (cam2mask: hi stack then lo stack).
+int par_launch_step(const float *aff, const float *src, float *dst, int B, int Kmax, const int *kcount,
+                    size_t plane_stride, int h, int w, const ParPlan &plan, hipStream_t st)
+{
+    constexpr int CG = 4;
+    const int halves = kcount ? 2 : 1;
+    const int half_planes = Kmax / halves;
+    dim3 grid((h * w + 255) / 256, (Kmax + CG - 1) / CG, B);
+    hipLaunchKernelGGL(par_step_kernel<CG>, grid, dim3(256), 0, st, aff, src, dst, kcount, Kmax, halves, half_planes,
+                       plane_stride, h, w, plan);
+    COSA_LAUNCH_CHECK();
+    return COSA_OK;
+}
+
+}  // namespace cosa
+
+using namespace cosa;
+
+extern "C" size_t cosa_par_workspace_bytes(int B, int K, int h, int w, int n_dil)
+{
+    const size_t hw = (size_t)h * w;
+    return align_up((size_t)B * n_dil * 8 * hw * sizeof(float), 256) + align_up((size_t)B * K * hw * sizeof(float), 256);
+}
+
+extern "C" int cosa_par_forward(const float *imgs, const float *masks, float *out, int B, int K, int h, int w,
+                                const int *dilations, int n_dil, int num_iter,
+                                void *workspace, size_t workspace_bytes, void *stream)
+{
+    COSA_REQUIRE(imgs && masks && out && workspace, "cosa_par_forward: null pointer");
+    COSA_REQUIRE(B > 0 && K > 0 && h > 0 && w > 0 && B <= 65535, "cosa_par_forward: bad shape");
+    COSA_REQUIRE(num_iter >= 0, "cosa_par_forward: num_iter < 0");
+    COSA_REQUIRE(out != masks, "cosa_par_forward: out must not alias masks");
+    ParPlan plan;
+    int rc = par_make_plan(dilations, n_dil, &plan);
+    if (rc) return rc;
+    if (workspace_bytes < cosa_par_workspace_bytes(B, K, h, w, n_dil)) {
+        set_error("cosa_par_forward: workspace too small");
+        return COSA_ENOMEM;
+    }
+    hipStream_t st = as_stream(stream);
+    const size_t hw = (size_t)h * w;
+    Carver cv(workspace);
+    float *aff = cv.take<float>((size_t)B * n_dil * 8 * hw);
+    float *tmp = cv.take<float>((size_t)B * K * hw);
+    if (num_iter == 0) {
+        if (out != masks) COSA_HIP_CHECK(hipMemcpyAsync(out, masks, (size_t)B * K * hw * sizeof(float), hipMemcpyDeviceToDevice, st));
+        return COSA_OK;
+    }
+    rc = par_launch_affinity(imgs, aff, B, h, w, plan, st);
+    if (rc) return rc;
+    // ping-pong so that the last step lands in `out`: steps alternate tmp/out
+    const float *src = masks;
+    for (int it = 0; it < num_iter; it++) {
+        float *dst = ((num_iter - 1 - it) & 1) ? tmp : out;
+        rc = par_launch_step(aff, src, dst, B, K, nullptr, (size_t)K * hw, h, w, plan, st);
+        if (rc) return rc;
+        src = dst;
+    }
+    return COSA_OK;
+}

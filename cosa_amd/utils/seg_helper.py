@@ -1,0 +1,239 @@
+"""utils.seg_helper -- hot-path functions of the reference module, backed by the HIP kernels.
+
+Same names, arguments and error behaviour as the reference (utils/seg_helper.py); every function
+cites the lines it replaces.  All tensors live on the GPU; nothing here falls back to the CPU.
+"""
+import torch
+import torch.nn.functional as F
+from torch.autograd import Function
+
+from .. import _C
+from ..models.PAR import PAR
+
+
+# --------------------------------------------------------------------------------------------
+# multi_scale_camseg  (utils/seg_helper.py:232-275)
+# --------------------------------------------------------------------------------------------
+def _flip_merge_upsample(src, dst, B, S, mode, accumulate):
+    src = src.contiguous().float()
+    _, C, h, w = src.shape
+    _C.check(_C.lib().cosa_cam_flip_merge_upsample(_C.ptr(src), _C.ptr(dst), B, C, h, w, S, mode, int(accumulate),
+                                                   _C.stream_ptr()), "cosa_cam_flip_merge_upsample")
+
+
+def cam_minmax_norm_(cam):
+    """In place x -= min; x /= max + 1e-5 per (b,c) plane (utils/seg_helper.py:265-266,269-270)."""
+    b, c, h, w = cam.shape
+    _C.check(_C.lib().cosa_cam_minmax_norm(_C.ptr(cam), b * c, h * w, _C.stream_ptr()), "cosa_cam_minmax_norm")
+    return cam
+
+
+def multi_scale_camseg(model, imgs, scales):
+    """Teacher forward over scales x {orig, flip}; returns (cam, cam_aux, seg) at input size.
+
+    utils/seg_helper.py:232-275.  Per scale one fused kernel does bilinear-up + un-flip + max/sum
+    (+ReLU) + accumulation; the reference's quirk that cam_aux keeps ONLY the last scale
+    (`cam_aux_list = [...]`, :258) is reproduced.
+    """
+    b, c, h, w = imgs.shape
+    assert 1.0 in scales, 'scale 1.0 must be in scales'
+    assert h == w, "square crops only"
+    _C.require_cuda(imgs)
+    cam = cam_aux = seg = None
+    with torch.no_grad():
+        for si, s in enumerate(scales):
+            if s != 1.0:
+                imgs_ = F.interpolate(imgs, size=(int(s * h), int(s * w)), mode='bilinear', align_corners=False)
+            else:
+                imgs_ = imgs
+            imgs_cat = torch.cat([imgs_, imgs_.flip(-1)], dim=0)
+            _, _, _, _seg, _cam, _cam_aux = model(imgs_cat, cam_only=False)
+            if cam is None:
+                cam = torch.empty((b, _cam.shape[1], h, w), device=imgs.device, dtype=torch.float32)
+                cam_aux = torch.empty_like(cam)
+                seg = torch.empty((b, _seg.shape[1], h, w), device=imgs.device, dtype=torch.float32)
+            _flip_merge_upsample(_cam, cam, b, h, 0, si > 0)
+            _flip_merge_upsample(_cam_aux, cam_aux, b, h, 0, False)     # last scale wins (:258)
+            _flip_merge_upsample(_seg, seg, b, h, 1, si > 0)
+        cam_minmax_norm_(cam)
+        cam_minmax_norm_(cam_aux)
+    return cam, cam_aux, seg
+
+
+# --------------------------------------------------------------------------------------------
+# cam_validation / cam2mask  (utils/seg_helper.py:547-551, 721-797)
+# --------------------------------------------------------------------------------------------
+def cam_validation(cam, cls_label):
+    """utils/seg_helper.py:547-551 (broadcast multiply; no materialised repeat)."""
+    return cam * cls_label[:, :, None, None]
+
+
+def _boxes_to_device(img_boxes, device):
+    if not torch.is_tensor(img_boxes):
+        img_boxes = torch.as_tensor(img_boxes)
+    return img_boxes.to(device=device, dtype=torch.int32, non_blocking=True).contiguous()
+
+
+def cam2mask(images, img_boxes, cams, cls_labels, threshold_high, threshold_low, refine_model=None, ignore_index=255,
+             downscale=2, _fold_validation=False):
+    """CAM -> {0..C, 255} label mask [b,h,w] (float32), one fused launch sequence for the whole batch.
+
+    utils/seg_helper.py:721-785 (+ _refine_cams :787-797).  `refine_model` may be None (reference
+    default) or a cosa_amd.models.PAR.PAR instance (the reference's only refine model).
+    `cams` are the validated CAMs as in the reference call order (main.py:137,158-166);
+    `_fold_validation=True` lets the training loop pass raw CAMs and skip cam_validation's pass.
+    """
+    _C.require_cuda(cams, cls_labels)
+    b, _, h, w = images.shape
+    if h != w:
+        raise ValueError("cam2mask: square crops only")
+    if downscale not in (0, 2, None, False):
+        raise NotImplementedError("cam2mask: downscale must be 0 or 2 (reference default 2)")
+    downscale = 2 if downscale == 2 else 0
+    if refine_model is not None and not isinstance(refine_model, PAR):
+        raise TypeError("cam2mask: refine_model must be None or cosa_amd.models.PAR.PAR")
+    cams = cams.contiguous().float()
+    cls_labels = cls_labels.contiguous().float()
+    C = cams.shape[1]
+    if cams.shape != (b, C, h, w) or cls_labels.shape != (b, C):
+        raise ValueError("cam2mask: cams must be [b,C,h,w] at image size and cls_labels [b,C]")
+    boxes = _boxes_to_device(img_boxes, cams.device)
+    if boxes.shape != (b, 4):
+        raise ValueError("cam2mask: img_boxes must be [b,4]")
+    mask = torch.empty((b, h, w), device=cams.device, dtype=torch.float32)
+    L = _C.lib()
+    if refine_model is not None:
+        _C.require_cuda(images)
+        images = images.contiguous().float()
+        dil, nd, iters = _C.int_array(refine_model.dilations), len(refine_model.dilations), refine_model.num_iter
+    else:
+        dil, nd, iters = _C.int_array([1]), 0, 0
+    ws = _C.workspace(L.cosa_cam2mask_workspace_bytes(b, C, h, downscale, nd if iters > 0 else 0), cams.device, "cam2mask")
+    _C.check(L.cosa_cam2mask(_C.ptr(images if iters > 0 else None), _C.ptr(boxes), _C.ptr(cams), _C.ptr(cls_labels),
+                             _C.ptr(mask), b, C, h, float(threshold_high), float(threshold_low), downscale,
+                             int(bool(_fold_validation)), dil, nd, iters, float(ignore_index), _C.ptr(ws), ws.numel(),
+                             _C.stream_ptr()), "cosa_cam2mask")
+    return mask
+
+
+# --------------------------------------------------------------------------------------------
+# seg_loss  (utils/seg_helper.py:800-813)
+# --------------------------------------------------------------------------------------------
+def seg_loss(seg_pred, mask_label, fg_alpha=0.5, ignore_index=255):
+    assert fg_alpha >= 0 and fg_alpha <= 1, "fg_alpha should be in [0,1]"
+    lab = mask_label.long()
+    bg_label = torch.where(lab != 0, torch.full_like(lab, ignore_index), lab)
+    fg_label = torch.where(lab == 0, torch.full_like(lab, ignore_index), lab)
+    # one log-softmax pass shared by the two class-balanced terms
+    logp = F.log_softmax(seg_pred.float(), dim=1)
+    bg_loss = F.nll_loss(logp, bg_label, ignore_index=ignore_index, reduction='sum') / ((bg_label != ignore_index).sum() + 1e-6)
+    fg_loss = F.nll_loss(logp, fg_label, ignore_index=ignore_index, reduction='sum') / ((fg_label != ignore_index).sum() + 1e-6)
+    return (1 - fg_alpha) * bg_loss + fg_alpha * fg_loss
+
+
+# --------------------------------------------------------------------------------------------
+# DenseEnergyLoss  (utils/seg_helper.py:191-230, 864-903)
+# --------------------------------------------------------------------------------------------
+class DenseEnergyLossFunction(Function):
+    """utils/seg_helper.py:864-903 with the bilateral filter, gate, dot product and the backward
+    scaling all on the device (no D2H/H2D hops, no host-side AS)."""
+
+    @staticmethod
+    def forward(ctx, images, segmentations, sigma_rgb, sigma_xy, ROIs, unlabel_region):
+        _C.require_cuda(images, segmentations, ROIs, unlabel_region)
+        N, K, H, W = segmentations.shape
+        images = images.contiguous().float()
+        seg = segmentations.contiguous().float()
+        roi = ROIs.contiguous().float()
+        unl = unlabel_region.contiguous().to(torch.uint8)
+        AS = torch.empty_like(seg)
+        loss = torch.empty(1, device=seg.device, dtype=torch.float32)
+        L = _C.lib()
+        ws = _C.workspace(L.cosa_bilateral_workspace_bytes(N, K, H, W), seg.device, "bilateral")
+        _C.check(L.cosa_dense_energy_forward(_C.ptr(images), _C.ptr(seg), _C.ptr(roi), _C.ptr(unl), _C.ptr(AS), _C.ptr(loss),
+                                             N, K, H, W, float(sigma_rgb), float(sigma_xy), _C.ptr(ws), ws.numel(),
+                                             _C.stream_ptr()), "cosa_dense_energy_forward")
+        ctx.save_for_backward(AS, roi)
+        ctx.shape = (N, K, H, W)
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        AS, roi = ctx.saved_tensors
+        N, K, H, W = ctx.shape
+        g = grad_output.contiguous().float()
+        grad_seg = torch.empty_like(AS)
+        _C.check(_C.lib().cosa_dense_energy_backward(_C.ptr(AS), _C.ptr(roi), _C.ptr(g), _C.ptr(grad_seg), N, K, H, W,
+                                                     _C.stream_ptr()), "cosa_dense_energy_backward")
+        return None, grad_seg, None, None, None, None
+
+
+class DenseEnergyLoss(torch.nn.Module):
+    """utils/seg_helper.py:191-208"""
+
+    def __init__(self, weight, sigma_rgb, sigma_xy, scale_factor):
+        super().__init__()
+        self.weight = weight
+        self.sigma_rgb = sigma_rgb
+        self.sigma_xy = sigma_xy
+        self.scale_factor = scale_factor
+
+    def forward(self, images, segmentations, ROIs, seg_label):
+        sf = self.scale_factor
+        scaled_images = F.interpolate(images, scale_factor=sf, recompute_scale_factor=True)
+        scaled_segs = F.interpolate(segmentations, scale_factor=sf, mode='bilinear', align_corners=False,
+                                    recompute_scale_factor=True)
+        scaled_ROIs = F.interpolate(ROIs.unsqueeze(1), scale_factor=sf, recompute_scale_factor=True).squeeze(1)
+        scaled_seg_label = F.interpolate(seg_label.float(), scale_factor=sf, mode='nearest', recompute_scale_factor=True)
+        unlabel_region = (scaled_seg_label.long() == 255).squeeze(1)
+        return self.weight * DenseEnergyLossFunction.apply(scaled_images, scaled_segs, self.sigma_rgb,
+                                                           self.sigma_xy * self.scale_factor, scaled_ROIs, unlabel_region)
+
+    def extra_repr(self):
+        return 'sigma_rgb={}, sigma_xy={}, weight={}, scale_factor={}'.format(
+            self.sigma_rgb, self.sigma_xy, self.weight, self.scale_factor)
+
+
+def _crop_mask_from_boxes(img_box, b, h, w, device):
+    boxes = _boxes_to_device(img_box, device)
+    ys = torch.arange(h, device=device, dtype=torch.int32)[None, :, None]
+    xs = torch.arange(w, device=device, dtype=torch.int32)[None, None, :]
+    inside = (ys >= boxes[:, 0, None, None]) & (ys < boxes[:, 1, None, None]) & \
+             (xs >= boxes[:, 2, None, None]) & (xs < boxes[:, 3, None, None])
+    return inside.float()
+
+
+def get_energy_loss(img, logit, label, img_box, loss_layer, mean=[123.675, 116.28, 103.53], std=[58.395, 57.12, 57.375]):
+    """utils/seg_helper.py:210-230 (box mask built with one broadcast compare instead of a Python loop)."""
+    pred_prob = F.softmax(logit.float(), dim=1)
+    b, _, h, w = pred_prob.shape
+    crop_mask = _crop_mask_from_boxes(img_box, b, h, w, pred_prob.device)
+    mean_t = torch.tensor(mean, device=img.device, dtype=torch.float32)[None, :, None, None]
+    std_t = torch.tensor(std, device=img.device, dtype=torch.float32)[None, :, None, None]
+    _img = img * std_t + mean_t
+    loss = loss_layer(_img, pred_prob, crop_mask, label.type(torch.uint8).unsqueeze(1))
+    return loss
+
+
+# --------------------------------------------------------------------------------------------
+# seg_refine_by_label / cam_loss  (utils/seg_helper.py:553-568, 593-602)
+# --------------------------------------------------------------------------------------------
+def seg_refine_by_label(seg, cls_label, softmaxtemp, after_softmax=False):
+    b, c, h, w = seg.shape
+    cls_label_bk = torch.cat([torch.ones(b, 1, device=cls_label.device, dtype=cls_label.dtype), cls_label], dim=1)
+    if after_softmax:
+        seg = F.softmax(seg / softmaxtemp, dim=1)
+        return cls_label_bk[:, :, None, None] * seg
+    valid_seg = torch.where((cls_label_bk == 0)[:, :, None, None], torch.full_like(seg, -1e5), seg)
+    return F.softmax(valid_seg / softmaxtemp, dim=1)
+
+
+def cam_loss(cam, seg_ps, is_relu=True):
+    B, C, H, W = cam.shape
+    seg_ps_fg = seg_ps[:, 1:, ...]
+    seg_ps_fg = F.interpolate(seg_ps_fg, size=[H, W], mode='bilinear', align_corners=False)
+    seg_ps_fg_flat = seg_ps_fg.permute(0, 2, 3, 1).reshape(B * H * W, C)
+    if is_relu:
+        cam = F.relu(cam)
+    cam_flat = cam.float().permute(0, 2, 3, 1).reshape(B * H * W, C)
+    return F.multilabel_soft_margin_loss(cam_flat, seg_ps_fg_flat)

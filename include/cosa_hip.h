@@ -1,0 +1,121 @@
+/*
+ * cosa_hip.h -- C ABI of libcosa_hip.so: the MI355X (gfx950) implementation of CoSA's
+ * per-iteration training hot path.  Plain pointers and sizes only; no torch types.
+ *
+ * Conventions
+ *   - every *_dev / device entry point takes DEVICE pointers and a `void *stream`
+ *     (a hipStream_t; NULL = the null stream), enqueues work and returns without
+ *     synchronising.  Return value: COSA_OK or a COSA_E* code; cosa_last_error()
+ *     gives the message for the calling thread.
+ *   - tensors are dense row-major ("NCHW") float32 unless a parameter says otherwise.
+ *   - workspaces are caller-allocated; *_workspace_bytes() tells the size.  Nothing in the
+ *     launch path calls hipMalloc/hipFree/hipDeviceSynchronize (graph-capturable).
+ *   - reference file:line citations are relative to the CoSA repository root.
+ */
+#ifndef COSA_HIP_H
+#define COSA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define COSA_OK 0
+#define COSA_EINVAL 1   /* bad argument / unsupported shape            */
+#define COSA_EHIP 2     /* a HIP runtime call failed                    */
+#define COSA_ERANGE 3   /* lattice key left the packable range          */
+#define COSA_ENOMEM 4   /* workspace too small                          */
+
+int cosa_abi_version(void);
+const char *cosa_last_error(void);
+
+/* ---------------------------------------------------------------------------------------
+ * utils/torch_helper.py:354-367  denormalize_img
+ *   out = float(uint8(img*std+mean)) / 255      img,out [B,3,H,W]
+ * ------------------------------------------------------------------------------------- */
+int cosa_denormalize_img(const float *img, float *out, int B, int H, int W, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * utils/seg_helper.py:264-270  per-(b,c) plane  x -= min(x); x /= max(x) + 1e-5  (in place)
+ *   cam [BC, HW]
+ * ------------------------------------------------------------------------------------- */
+int cosa_cam_minmax_norm(float *cam, int BC, int HW, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * utils/seg_helper.py:252-270  fused tail of multi_scale_camseg for ONE scale:
+ *   up   = bilinear(src[2b,C,h,w] -> (S,S), align_corners=False)
+ *   v    = mode 0: relu(max(up[:b], flip_w(up[b:])))          (cam / cam_aux, :253-258)
+ *          mode 1: up[:b] + flip_w(up[b:])                    (seg,           :260-262)
+ *   dst  = accumulate ? dst + v : v                           (sum over scales, :264,273)
+ *   src [2*B, C, h, w]   dst [B, C, S, S]
+ * ------------------------------------------------------------------------------------- */
+int cosa_cam_flip_merge_upsample(const float *src, float *dst, int B, int C, int h, int w, int S,
+                                 int mode, int accumulate, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * utils/seg_helper.py:721-797  cam2mask (+ _refine_cams), with cam_validation (:547-551)
+ * folded in and, optionally, models/PAR.py:64-91 as the refine_model.
+ *
+ *   images  [B,3,S,S]  de-normalised image in [0,1] (read only when par_iters > 0)
+ *   boxes   [B,4] int32 device (h0,h1,w0,w1)
+ *   cams    [B,C,S,S]  cams; fold_validation=1: raw cams, multiplied by labels here
+ *                      (cam_validation); 0: the caller already did (reference call order)
+ *   labels  [B,C]      {0,1}
+ *   mask    [B,S,S]    float32 out: {0..C, ignore_index}
+ *   downscale 2 or 0;  par_iters 0 => refine_model=None;  dilations host int[n_dil]
+ * ------------------------------------------------------------------------------------- */
+size_t cosa_cam2mask_workspace_bytes(int B, int C, int S, int downscale, int n_dil);
+int cosa_cam2mask(const float *images, const int32_t *boxes, const float *cams, const float *labels,
+                  float *mask, int B, int C, int S, float thr_hi, float thr_lo, int downscale,
+                  int fold_validation, const int *dilations, int n_dil, int par_iters, float ignore_index,
+                  void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * models/PAR.py:64-91  PAR.forward for a batch of same-sized images / mask stacks.
+ *   imgs [B,3,h,w]   masks [B,K,h,w] (in)   out [B,K,h,w]
+ * ------------------------------------------------------------------------------------- */
+size_t cosa_par_workspace_bytes(int B, int K, int h, int w, int n_dil);
+int cosa_par_forward(const float *imgs, const float *masks, float *out, int B, int K, int h, int w,
+                     const int *dilations, int n_dil, int num_iter,
+                     void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * utils/bilateralfilter/bilateralfilter.hpp:10-12 (SWIG module `bilateralfilter`,
+ * bilateralfilter.i:21-25).  HOST-pointer drop-ins with the reference's exact argument list
+ * (the SWIG typemaps turn each (ptr,len) pair into one NumPy array); they stage through the
+ * GPU and synchronise.  `out(s)` is written in place.
+ * ------------------------------------------------------------------------------------- */
+void bilateralfilter(float *image, int len_image, float *in, int len_in, float *out, int len_out,
+                     int H, int W, float sigmargb, float sigmaxy);
+void bilateralfilter_batch(float *images, int len_images, float *ins, int len_ins, float *outs, int len_outs,
+                           int N, int K, int H, int W, float sigmargb, float sigmaxy);
+
+/* Device-resident form of the same filter (utils/bilateralfilter/permutohedral.cpp:115-297
+ * init, :507-571 compute): images [N,3,H,W] (0..255), in/out [N,K,H,W].                     */
+size_t cosa_bilateral_workspace_bytes(int N, int K, int H, int W);
+int cosa_bilateralfilter_batch_dev(const float *images, const float *ins, float *outs,
+                                   int N, int K, int H, int W, float sigmargb, float sigmaxy,
+                                   int32_t *lattice_sizes /* [N] device, may be NULL */,
+                                   void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * utils/seg_helper.py:864-903  DenseEnergyLossFunction, device resident.
+ *   forward:  Gate = clamp(ROI - max_k seg, 0); Gate[unlabel] = 1; segm = seg*ROI;
+ *             AS = BF(images, segm) * Gate;  loss = -<segm, AS> / N
+ *   backward: grad_seg = -2 * grad_out * AS / N * ROI
+ *   images [N,3,H,W] 0..255, seg [N,K,H,W], roi [N,H,W], unlabel [N,H,W] uint8
+ *   AS [N,K,H,W] out (kept for backward), loss: 1 float (device)
+ * ------------------------------------------------------------------------------------- */
+int cosa_dense_energy_forward(const float *images, const float *seg, const float *roi, const uint8_t *unlabel,
+                              float *AS, float *loss, int N, int K, int H, int W,
+                              float sigmargb, float sigmaxy,
+                              void *workspace, size_t workspace_bytes, void *stream);
+int cosa_dense_energy_backward(const float *AS, const float *roi, const float *grad_out /* 1 float, device */,
+                               float *grad_seg, int N, int K, int H, int W, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COSA_HIP_H */

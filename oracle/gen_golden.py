@@ -1,0 +1,206 @@
+"""Generate tests/golden/*.npz from the REFERENCE itself (authoring container only).
+
+    python -m oracle.gen_golden
+
+Every vector is produced by the reference's own code: its Python modules loaded by path
+(oracle/ref_loader.py) and its C++ bilateral filter compiled from its sources into oracle/_ref/.
+Only inputs and expected outputs are stored -- no reference source text.  TEST INFRASTRUCTURE.
+"""
+import os
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import c_oracle, ref_loader
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+DIL = [1, 2, 4, 8, 12, 24]
+
+
+def smooth_field(rng, n, h, w, lo=0.0, hi=1.0, waves=4):
+    """sum of a few low-frequency sinusoids, rescaled to [lo,hi] per plane"""
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    out = np.zeros((n, h, w))
+    for i in range(n):
+        acc = np.zeros((h, w))
+        for _ in range(waves):
+            fx, fy = rng.uniform(0.02, 0.25, 2)
+            ph = rng.uniform(0, 2 * np.pi, 2)
+            acc += rng.uniform(0.3, 1.0) * np.sin(xx * fx + ph[0]) * np.cos(yy * fy + ph[1])
+        acc = (acc - acc.min()) / (acc.max() - acc.min() + 1e-12)
+        out[i] = lo + (hi - lo) * acc
+    return out.astype(np.float32)
+
+
+def synth_image255(rng, n, h, w, noise=2.0):
+    base = smooth_field(rng, n * 3, h, w, 0, 255).reshape(n, 3, h, w)
+    img = np.clip(np.floor(base + rng.normal(0, noise, base.shape)), 0, 255)
+    return img.astype(np.float32)
+
+
+def gen_par(rng):
+    par_mod = ref_loader.par_module()
+    out = {}
+    for tag, (K, h, w) in {"k2": (2, 48, 40), "k4": (4, 40, 56)}.items():
+        img = torch.from_numpy(synth_image255(rng, 1, h, w) / 255.0)
+        masks = torch.from_numpy(smooth_field(rng, K, h, w))[None].softmax(1)
+        par = par_mod.PAR(num_iter=10, dilations=DIL)
+        with torch.no_grad():
+            ref = par(img, masks)
+        out[f"{tag}_img"] = img.numpy()
+        out[f"{tag}_masks"] = masks.numpy()
+        out[f"{tag}_out"] = ref.numpy()
+    # short propagation / other dilation set
+    img = torch.from_numpy(synth_image255(rng, 2, 24, 24) / 255.0)
+    masks = torch.from_numpy(smooth_field(rng, 6, 24, 24)).reshape(2, 3, 24, 24).softmax(1)
+    par = par_mod.PAR(num_iter=3, dilations=[1, 2, 4])
+    with torch.no_grad():
+        ref = torch.cat([par(img[i:i + 1], masks[i:i + 1]) for i in range(2)])
+    out.update(b2_img=img.numpy(), b2_masks=masks.numpy(), b2_out=ref.numpy(), b2_dil=np.array([1, 2, 4]), b2_iter=3)
+    np.savez_compressed(os.path.join(OUT, "par.npz"), **out)
+
+
+def gen_cam2mask(rng):
+    sh = ref_loader.seg_helper()
+    par_mod = ref_loader.par_module()
+    B, C, S = 4, 6, 64
+    cams = smooth_field(rng, B * C, S, S).reshape(B, C, S, S)
+    cams = np.maximum(cams * 1.3 - 0.15, 0).astype(np.float32)
+    labels = np.zeros((B, C), np.float32)
+    labels[0, [1, 4]] = 1
+    labels[1, [0]] = 1
+    labels[2, [2, 3, 5]] = 1
+    labels[3, [0, 1, 2, 3, 4, 5]] = 1
+    boxes = np.array([[0, S, 0, S], [3, 60, 5, 50], [0, S, 10, S], [7, 33, 0, 64]], np.int16)
+    images = synth_image255(rng, B, S, S) / 255.0
+    t = torch.from_numpy
+    vc = sh.cam_validation(t(cams), t(labels))
+    out = dict(cams=cams, labels=labels, boxes=boxes, images=images.astype(np.float32), valid_cams=vc.numpy(),
+               thr=np.array([0.7, 0.25], np.float32))
+    with torch.no_grad():
+        out["mask_none"] = sh.cam2mask(t(images), t(boxes), vc, t(labels), 0.7, 0.25, downscale=2).numpy()
+        out["mask_none_ds0"] = sh.cam2mask(t(images), t(boxes), vc, t(labels), 0.7, 0.25, downscale=0).numpy()
+        par = par_mod.PAR(num_iter=10, dilations=DIL)
+        out["mask_par"] = sh.cam2mask(t(images), t(boxes), vc, t(labels), 0.7, 0.25, refine_model=par, downscale=2).numpy()
+        out["mask_par_coco_thr"] = sh.cam2mask(t(images), t(boxes), vc, t(labels), 0.65, 0.25, refine_model=par,
+                                               downscale=2).numpy()
+    np.savez_compressed(os.path.join(OUT, "cam2mask.npz"), **out)
+
+
+class _StubModel:
+    """deterministic stand-in network for multi_scale_camseg: returns smooth functions of the input so that the
+    flip / scale / 'last-scale-only' bookkeeping is what the golden pins."""
+
+    def __init__(self, C):
+        self.C = C
+
+    def __call__(self, x, cam_only=False):
+        B, _, H, W = x.shape
+        f = F.avg_pool2d(x, 8)                                   # [B,3,H/8,W/8]
+        w_cam = torch.linspace(-1.0, 1.5, self.C * 3).reshape(self.C, 3, 1, 1)
+        w_aux = torch.linspace(1.2, -0.8, self.C * 3).reshape(self.C, 3, 1, 1)
+        w_seg = torch.linspace(-0.5, 0.9, (self.C + 1) * 3).reshape(self.C + 1, 3, 1, 1)
+        cam = F.conv2d(f, w_cam) + 0.1 * f[:, :1].roll(1, -1)
+        cam_aux = F.conv2d(f, w_aux) - 0.05 * f[:, 1:2].roll(1, -2)
+        seg = F.conv2d(f, w_seg)
+        return None, None, None, seg, cam, cam_aux
+
+
+def stub_outputs(x, C):
+    return _StubModel(C)(x)
+
+
+def gen_camseg(rng):
+    sh = ref_loader.seg_helper()
+    b, S, C = 2, 64, 5
+    imgs = torch.from_numpy(smooth_field(rng, b * 3, S, S, -2, 2).reshape(b, 3, S, S))
+    cam, cam_aux, seg = sh.multi_scale_camseg(_StubModel(C), imgs, [1.0, 0.5, 1.5])
+    np.savez_compressed(os.path.join(OUT, "camseg_tail.npz"), imgs=imgs.numpy(), cam=cam.numpy(), cam_aux=cam_aux.numpy(),
+                        seg=seg.numpy(), C=C)
+
+
+def gen_bilateral(rng):
+    sh = ref_loader.seg_helper()
+    out = {}
+    for tag, (N, K, H, W, kind) in {"smooth": (2, 3, 32, 32, "s"), "noise": (2, 3, 32, 32, "n"), "odd": (1, 2, 30, 37, "s")}.items():
+        img = synth_image255(rng, N, H, W) if kind == "s" else rng.uniform(0, 255, (N, 3, H, W)).astype(np.float32)
+        seg = torch.from_numpy(smooth_field(rng, N * K, H, W).reshape(N, K, H, W)).softmax(1).numpy()
+        ref = np.zeros_like(seg).reshape(-1)
+        c_oracle.ref_bilateralfilter_batch(img, seg, ref, N, K, H, W, 15.0, 50.0)
+        out[f"{tag}_img"] = img
+        out[f"{tag}_seg"] = seg
+        out[f"{tag}_out"] = ref.reshape(N, K, H, W)
+    # DenseEnergyLoss through the reference's own autograd Function (forward value + gradient)
+    N, K, S = 2, 4, 64
+    img = synth_image255(rng, N, S, S)
+    logits = torch.from_numpy(smooth_field(rng, N * K, S, S, -2, 2).reshape(N, K, S, S)).requires_grad_(True)
+    probs = logits.softmax(1)
+    roi = torch.zeros(N, S, S)
+    roi[0] = 1
+    roi[1, 4:60, 8:50] = 1
+    label = torch.from_numpy(rng.choice([0, 1, 2, 255], size=(N, 1, S, S), p=[0.4, 0.2, 0.2, 0.2]).astype(np.uint8))
+    layer = sh.DenseEnergyLoss(weight=1e-7, sigma_rgb=15, sigma_xy=100, scale_factor=0.5)
+    loss = layer(torch.from_numpy(img), probs, roi.clone(), label)
+    loss.backward()
+    out.update(del_img=img, del_logits=logits.detach().numpy(), del_roi=roi.numpy(), del_label=label.numpy(),
+               del_loss=loss.detach().numpy(), del_grad=logits.grad.numpy())
+    np.savez_compressed(os.path.join(OUT, "bilateral.npz"), **out)
+
+
+def gen_misc(rng):
+    sh = ref_loader.seg_helper()
+    th = ref_loader.torch_helper_fns()
+    out = {}
+    x = torch.from_numpy(rng.normal(0, 1.2, (2, 3, 16, 16)).astype(np.float32))
+    out["denorm_in"] = x.numpy()
+    out["denorm_out"] = th.denormalize_img(x).numpy()
+    # LR schedule of PolyWarmupAdamW
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = th.PolyWarmupAdamW([{"params": [p], "lr": 6e-5}], lr=6e-5, weight_decay=1e-2, betas=(0.9, 0.999), warmup_iter=1500,
+                             max_iter=32000, warmup_ratio=1e-6, power=0.9, min_mult=0.0)
+    steps = [0, 1, 2, 750, 1499, 1500, 1501, 16000, 31999]
+    lrs = []
+    for st in steps:
+        opt.global_step = st
+        p.grad = torch.zeros(1)
+        opt.step()
+        lrs.append(opt.param_groups[0]["lr"])
+    out["lr_steps"] = np.array(steps)
+    out["lr_values"] = np.array(lrs, np.float64)
+    # losses
+    B, C, S = 2, 5, 32
+    seg_pred = torch.from_numpy(rng.normal(0, 1, (B, C + 1, S, S)).astype(np.float32))
+    mask = torch.from_numpy(rng.choice([0, 1, 3, 5, 255], size=(B, S, S)).astype(np.float32))
+    out["segloss_pred"] = seg_pred.numpy()
+    out["segloss_mask"] = mask.numpy()
+    out["segloss_out"] = sh.seg_loss(seg_pred, mask, fg_alpha=0.5).numpy()
+    labels = torch.tensor([[1, 0, 0, 1, 0], [0, 1, 1, 0, 0]], dtype=torch.float32)
+    seg = torch.from_numpy(rng.normal(0, 1, (B, C + 1, S, S)).astype(np.float32))
+    ref = sh.seg_refine_by_label(seg, labels, softmaxtemp=0.01)
+    out["refine_seg"] = seg.numpy()
+    out["refine_labels"] = labels.numpy()
+    out["refine_out"] = ref.numpy()
+    cam = torch.from_numpy(rng.normal(0, 1, (B, C, 4, 4)).astype(np.float32))
+    out["camloss_cam"] = cam.numpy()
+    out["camloss_out"] = sh.cam_loss(cam, ref).numpy()
+    np.savez_compressed(os.path.join(OUT, "misc.npz"), **out)
+
+
+def main():
+    assert ref_loader.available(), "reference tree not present"
+    os.makedirs(OUT, exist_ok=True)
+    c_oracle.build()
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    gen_par(np.random.default_rng(11))
+    gen_cam2mask(np.random.default_rng(12))
+    gen_camseg(np.random.default_rng(13))
+    gen_bilateral(np.random.default_rng(14))
+    gen_misc(np.random.default_rng(15))
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()

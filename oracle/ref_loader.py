@@ -91,5 +91,9 @@ def torch_helper_fns():
     """denormalize_img / PolyWarmupAdamW live in utils/torch_helper.py which imports sklearn+texttable."""
     if "th" not in _cache:
         _stub("texttable", Texttable=object)
-        _cache["th"] = _load("_cosa_ref_torch_helper", "utils/torch_helper.py")
+        # the file does `from . import misc` (distributed helpers, unused here): give it an empty parent package
+        pkg = _stub("_cosa_ref_utils")
+        pkg.__path__ = []
+        pkg.misc = _stub("_cosa_ref_utils.misc")
+        _cache["th"] = _load("_cosa_ref_utils.torch_helper", "utils/torch_helper.py")
     return _cache["th"]

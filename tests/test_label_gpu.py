@@ -1,0 +1,222 @@
+"""GPU parity: HIP label / PAR / CAM-tail / bilateral kernels (through the C ABI) vs the CPU oracle and the goldens."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DIL = [1, 2, 4, 8, 12, 24]
+
+
+def dev(a, dtype=torch.float32):
+    return torch.as_tensor(np.asarray(a)).to("cuda", dtype=dtype)
+
+
+def smooth(rng, n, h, w):
+    from oracle.gen_golden import smooth_field
+    return smooth_field(rng, n, h, w)
+
+
+def test_library_is_loaded_native():
+    from cosa_amd import _C
+    assert _C.lib().cosa_abi_version() >= 1
+
+
+def test_denorm_bit_exact(oracle_c, golden):
+    from cosa_amd.utils import torch_helper
+    g = golden("misc")
+    out = torch_helper.denormalize_img(dev(g["denorm_in"])).cpu().numpy()
+    assert np.array_equal(out, g["denorm_out"])
+    x = np.random.default_rng(0).normal(0, 1.5, (3, 3, 50, 70)).astype(np.float32)
+    assert np.array_equal(torch_helper.denormalize_img(dev(x)).cpu().numpy(), oracle_c.denormalize_img(x))
+
+
+def test_minmax_norm_bit_exact(oracle_c):
+    from cosa_amd.utils import seg_helper
+    rng = np.random.default_rng(1)
+    for shape in [(2, 3, 17, 19), (2, 20, 448, 448)]:
+        x = np.maximum(rng.normal(0.2, 1, shape), 0).astype(np.float32)
+        out = seg_helper.cam_minmax_norm_(dev(x).clone()).cpu().numpy()
+        assert np.array_equal(out, oracle_c.cam_minmax_norm(x))
+
+
+def test_par_vs_golden_and_oracle_bit_exact(oracle_c, golden):
+    from cosa_amd.models.PAR import PAR
+    g = golden("par")
+    par = PAR(num_iter=10, dilations=DIL)
+    for tag in ("k2", "k4"):
+        out = par(dev(g[f"{tag}_img"]), dev(g[f"{tag}_masks"])).cpu().numpy()
+        ref = g[f"{tag}_out"]
+        assert np.max(np.abs(out - ref) / np.maximum(np.abs(ref), 1e-6)) < 2e-5          # vs the reference
+        orc = oracle_c.par_forward(g[f"{tag}_img"][0], g[f"{tag}_masks"][0], DIL, 10)
+        assert np.array_equal(out[0], orc)                                               # vs the oracle: every bit
+    par3 = PAR(num_iter=int(g["b2_iter"]), dilations=list(g["b2_dil"]))
+    out = par3(dev(g["b2_img"]), dev(g["b2_masks"])).cpu().numpy()
+    np.testing.assert_allclose(out, g["b2_out"], rtol=2e-5, atol=1e-7)
+
+
+def test_par_affinity_rows_sum(oracle_c):
+    """size-independent property: every affinity row sums to 1 + w2 => a constant mask stays constant * 1.01^T."""
+    from cosa_amd.models.PAR import PAR
+    rng = np.random.default_rng(2)
+    img = dev(rng.uniform(0, 1, (2, 3, 224, 224)).astype(np.float32))
+    masks = torch.full((2, 3, 224, 224), 0.5, device="cuda")
+    out = PAR(num_iter=10, dilations=DIL)(img, masks)
+    assert torch.allclose(out, torch.full_like(out, 0.5 * 1.01 ** 10), rtol=1e-5)
+
+
+@pytest.mark.parametrize("key,ds,use_par,thr_hi", [("mask_none", 2, False, 0.7), ("mask_none_ds0", 0, False, 0.7),
+                                                  ("mask_par", 2, True, 0.7), ("mask_par_coco_thr", 2, True, 0.65)])
+def test_cam2mask_golden_bit_exact(golden, key, ds, use_par, thr_hi):
+    from cosa_amd.models.PAR import PAR
+    from cosa_amd.utils import seg_helper
+    g = golden("cam2mask")
+    par = PAR(num_iter=10, dilations=DIL) if use_par else None
+    vc = seg_helper.cam_validation(dev(g["cams"]), dev(g["labels"]))
+    m = seg_helper.cam2mask(dev(g["images"]), torch.from_numpy(g["boxes"]), vc, dev(g["labels"]), thr_hi, 0.25,
+                            refine_model=par, downscale=ds)
+    assert np.array_equal(m.cpu().numpy(), g[key])
+    # raw cams + folded validation give the same labels
+    m2 = seg_helper.cam2mask(dev(g["images"]), torch.from_numpy(g["boxes"]), dev(g["cams"]), dev(g["labels"]), thr_hi, 0.25,
+                             refine_model=par, downscale=ds, _fold_validation=True)
+    assert torch.equal(m, m2)
+
+
+@pytest.mark.parametrize("use_par", [False, True])
+def test_cam2mask_full_size_vs_oracle(oracle_c, use_par):
+    """BASELINE config shape (448x448, 20 classes), a few images; ragged label counts incl. an image with no fg."""
+    from cosa_amd.models.PAR import PAR
+    from cosa_amd.utils import seg_helper
+    rng = np.random.default_rng(7)
+    B, C, S = 3, 20, 448
+    cams = np.maximum(smooth(rng, B * C, S, S).reshape(B, C, S, S) * 1.3 - 0.15, 0).astype(np.float32)
+    labels = np.zeros((B, C), np.float32)
+    labels[0, [3]] = 1
+    labels[1, [0, 7, 19]] = 1          # image 2: no foreground class at all
+    boxes = np.array([[0, S, 0, S], [10, 400, 33, 448], [0, 448, 0, 100]], np.int32)
+    images = smooth(rng, B * 3, S, S).reshape(B, 3, S, S)
+    par = PAR(num_iter=10, dilations=DIL) if use_par else None
+    m = seg_helper.cam2mask(dev(images), torch.from_numpy(boxes), dev(cams), dev(labels), 0.7, 0.25, refine_model=par,
+                            _fold_validation=True).cpu().numpy()
+    ref = oracle_c.cam2mask(images, boxes, cams, labels, 0.7, 0.25, 2, par=(DIL, 10) if use_par else None)
+    assert np.array_equal(m, ref), f"{(m != ref).sum()} labels differ"
+    assert np.all(m[2][:, 100:] == 255) and set(np.unique(m[2][:, :100])) == {0.0}
+
+
+def test_cam2mask_properties_at_bench_size():
+    """size-independent checks at b=16: outside-box = 255; values in {0, active classes, 255}; hi/lo merge rule."""
+    from cosa_amd.utils import seg_helper
+    rng = np.random.default_rng(8)
+    B, C, S = 16, 20, 448
+    cams = torch.rand(B, C, S // 8, S // 8, device="cuda")
+    cams = torch.nn.functional.interpolate(cams, size=(S, S), mode="bilinear")
+    labels = torch.zeros(B, C, device="cuda")
+    for b in range(B):
+        labels[b, rng.choice(C, size=rng.integers(1, 4), replace=False)] = 1
+    boxes = torch.tensor([[0, S, 0, S]] * 8 + [[16, 400, 32, 432]] * 8, dtype=torch.int16)
+    m = seg_helper.cam2mask(torch.zeros(B, 3, S, S, device="cuda"), boxes, cams, labels, 0.7, 0.25, _fold_validation=True)
+    assert torch.all(m[8:, :16] == 255) and torch.all(m[8:, :, 432:] == 255)
+    for b in range(B):
+        allowed = {0.0, 255.0} | {float(c + 1) for c in torch.nonzero(labels[b])[:, 0].tolist()}
+        assert set(torch.unique(m[b]).tolist()) <= allowed
+    # thresholds: raising the high threshold can only turn fg into ignore, never into another class
+    m2 = seg_helper.cam2mask(torch.zeros(B, 3, S, S, device="cuda"), boxes, cams, labels, 0.9, 0.25, _fold_validation=True)
+    changed = m != m2
+    assert torch.all((m2[changed] == 255) | (m2[changed] == 0))
+
+
+def test_camseg_tail_vs_golden(golden):
+    from cosa_amd.utils import seg_helper
+    from oracle.gen_golden import _StubModel
+    g = golden("camseg_tail")
+    C = int(g["C"])
+    stub = _StubModel(C)
+
+    def model(x, cam_only=False):
+        outs = stub(x.cpu())
+        return tuple(o.cuda() if o is not None else None for o in outs)
+
+    cam, aux, seg = seg_helper.multi_scale_camseg(model, dev(g["imgs"]), [1.0, 0.5, 1.5])
+    np.testing.assert_allclose(cam.cpu().numpy(), g["cam"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(aux.cpu().numpy(), g["cam_aux"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(seg.cpu().numpy(), g["seg"], rtol=1e-6, atol=1e-6)
+
+
+def test_bilateral_vs_golden(oracle_c, golden):
+    from cosa_amd import _C
+    g = golden("bilateral")
+    L = _C.lib()
+    for tag in ("smooth", "noise", "odd"):
+        img, seg, ref = dev(g[f"{tag}_img"]), dev(g[f"{tag}_seg"]), g[f"{tag}_out"]
+        N, K, H, W = seg.shape
+        out = torch.empty_like(seg)
+        Ms = torch.zeros(N, dtype=torch.int32, device="cuda")
+        ws = _C.workspace(L.cosa_bilateral_workspace_bytes(N, K, H, W), "cuda", "t")
+        _C.check(L.cosa_bilateralfilter_batch_dev(_C.ptr(img), _C.ptr(seg), _C.ptr(out), N, K, H, W, 15.0, 50.0, _C.ptr(Ms),
+                                                  _C.ptr(ws), ws.numel(), _C.stream_ptr()))
+        _, M_ref = oracle_c.bilateralfilter_batch(g[f"{tag}_img"], g[f"{tag}_seg"], N, K, H, W, 15.0, 50.0)
+        assert np.array_equal(Ms.cpu().numpy(), M_ref)               # identical lattice (integer work): exact
+        np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=2e-5, atol=1e-6)   # float atomics: order differs
+
+
+def test_bilateralfilter_module_numpy_signature(golden):
+    from cosa_amd import bilateralfilter as bf
+    g = golden("bilateral")
+    img, seg, ref = g["noise_img"], g["noise_seg"], g["noise_out"]
+    N, K, H, W = seg.shape
+    out = np.zeros(seg.size, np.float32)
+    bf.bilateralfilter_batch(img.flatten(), seg.flatten(), out, N, K, H, W, 15.0, 50.0)
+    np.testing.assert_allclose(out.reshape(ref.shape), ref, rtol=2e-5, atol=1e-6)
+    out1 = np.zeros(K * H * W, np.float32)
+    bf.bilateralfilter(img[0].flatten(), seg[0].flatten(), out1, H, W, 15.0, 50.0)
+    np.testing.assert_allclose(out1.reshape(ref[0].shape), ref[0], rtol=2e-5, atol=1e-6)
+    with pytest.raises(TypeError):
+        bf.bilateralfilter_batch(img, seg, np.zeros(3, np.float64), N, K, H, W, 15.0, 50.0)
+
+
+def test_dense_energy_loss_and_grad_vs_golden(golden):
+    from cosa_amd.utils import seg_helper, rrm_utils
+    assert rrm_utils.DenseEnergyLoss is seg_helper.DenseEnergyLoss
+    g = golden("bilateral")
+    logits = dev(g["del_logits"]).requires_grad_(True)
+    layer = seg_helper.DenseEnergyLoss(weight=1e-7, sigma_rgb=15, sigma_xy=100, scale_factor=0.5)
+    loss = layer(dev(g["del_img"]), logits.softmax(1), dev(g["del_roi"]), dev(g["del_label"], torch.uint8))
+    loss.backward()
+    np.testing.assert_allclose(loss.detach().cpu().numpy(), g["del_loss"], rtol=1e-4)
+    np.testing.assert_allclose(logits.grad.cpu().numpy(), g["del_grad"], rtol=1e-3, atol=1e-11)
+
+
+def test_dense_energy_full_size_vs_oracle(oracle_c):
+    """224x224 (the size the training step filters at), K=21, smooth image + noise image."""
+    from cosa_amd import _C
+    from oracle.gen_golden import synth_image255
+    rng = np.random.default_rng(9)
+    N, K, H, W = 2, 21, 224, 224
+    img = synth_image255(rng, N, H, W)
+    img[1] = rng.uniform(0, 255, (3, H, W)).astype(np.float32)
+    seg = torch.from_numpy(smooth(rng, N * K, H, W).reshape(N, K, H, W) * 4).softmax(1).numpy()
+    roi = np.ones((N, H, W), np.float32)
+    roi[1, :20] = 0
+    unl = (rng.uniform(size=(N, H, W)) < 0.3).astype(np.uint8)
+    loss_ref, AS_ref = oracle_c.dense_energy_forward(img, seg, roi, unl, 15.0, 50.0)
+    L = _C.lib()
+    AS = torch.empty(N, K, H, W, device="cuda")
+    loss = torch.empty(1, device="cuda")
+    ws = _C.workspace(L.cosa_bilateral_workspace_bytes(N, K, H, W), "cuda", "t")
+    _C.check(L.cosa_dense_energy_forward(_C.ptr(dev(img)), _C.ptr(dev(seg)), _C.ptr(dev(roi)), _C.ptr(dev(unl, torch.uint8)),
+                                         _C.ptr(AS), _C.ptr(loss), N, K, H, W, 15.0, 50.0, _C.ptr(ws), ws.numel(),
+                                         _C.stream_ptr()))
+    np.testing.assert_allclose(AS.cpu().numpy(), AS_ref, rtol=1e-4, atol=1e-5)
+    assert loss.item() == pytest.approx(loss_ref, rel=1e-4)
+
+
+def test_errors_are_loud():
+    from cosa_amd import _C
+    from cosa_amd.utils import seg_helper
+    with pytest.raises(NotImplementedError):
+        seg_helper.cam2mask(torch.zeros(1, 3, 8, 8, device="cuda"), torch.tensor([[0, 8, 0, 8]]), torch.zeros(1, 2, 8, 8, device="cuda"),
+                            torch.ones(1, 2, device="cuda"), 0.7, 0.25, downscale=4)
+    with pytest.raises(TypeError):
+        seg_helper.cam2mask(torch.zeros(1, 3, 8, 8, device="cuda"), torch.tensor([[0, 8, 0, 8]]), torch.zeros(1, 2, 8, 8, device="cuda"),
+                            torch.ones(1, 2, device="cuda"), 0.7, 0.25, refine_model=lambda a, b: b)
+    with pytest.raises(_C.CosaError):
+        _C.check(_C.lib().cosa_cam_minmax_norm(None, 0, 0, None), "bad call")

@@ -1,0 +1,110 @@
+"""CPU suite: the oracle (oracle/) against the golden vectors produced by the reference itself."""
+import numpy as np
+import pytest
+import torch
+
+DIL = [1, 2, 4, 8, 12, 24]
+
+
+def test_expf_accuracy(oracle_c):
+    xs = np.linspace(-30, 10, 4001).astype(np.float32)
+    e = np.array([oracle_c.expf(x) for x in xs], np.float64)
+    ref = np.exp(xs.astype(np.float64))
+    assert np.max(np.abs(e - ref) / ref) < 2e-7
+    assert oracle_c.expf(-100.0) == 0.0 and oracle_c.expf(0.0) == 1.0
+
+
+def test_par_vs_reference(oracle_c, golden):
+    g = golden("par")
+    for tag in ("k2", "k4"):
+        out = oracle_c.par_forward(g[f"{tag}_img"][0], g[f"{tag}_masks"][0], DIL, 10)
+        ref = g[f"{tag}_out"][0]
+        assert np.max(np.abs(out - ref) / np.maximum(np.abs(ref), 1e-6)) < 2e-5
+    for i in range(2):
+        out = oracle_c.par_forward(g["b2_img"][i], g["b2_masks"][i], g["b2_dil"], int(g["b2_iter"]))
+        np.testing.assert_allclose(out, g["b2_out"][i], rtol=2e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("key,ds,par,thr_hi", [("mask_none", 2, None, 0.7), ("mask_none_ds0", 0, None, 0.7),
+                                              ("mask_par", 2, (DIL, 10), 0.7), ("mask_par_coco_thr", 2, (DIL, 10), 0.65)])
+def test_cam2mask_bit_exact_vs_reference(oracle_c, golden, key, ds, par, thr_hi):
+    g = golden("cam2mask")
+    m = oracle_c.cam2mask(g["images"], g["boxes"], g["cams"], g["labels"], thr_hi, 0.25, ds, par=par)
+    ref = g[key]
+    assert m.shape == ref.shape
+    assert set(np.unique(ref)) <= set([0, 1, 2, 3, 4, 5, 6, 255])
+    assert np.array_equal(m, ref), f"{(m != ref).sum()} of {m.size} labels differ"
+
+
+def test_cam2mask_golden_is_nontrivial(golden):
+    g = golden("cam2mask")
+    for key in ("mask_none", "mask_par"):
+        vals, cnt = np.unique(g[key], return_counts=True)
+        assert len(vals) >= 5 and (cnt > 50).sum() >= 4      # several classes, bg and ignore all present
+
+
+def test_bilateral_bit_exact_vs_reference_cpp(oracle_c, golden):
+    g = golden("bilateral")
+    for tag in ("smooth", "noise", "odd"):
+        img, seg, ref = g[f"{tag}_img"], g[f"{tag}_seg"], g[f"{tag}_out"]
+        N, K, H, W = seg.shape
+        out, M = oracle_c.bilateralfilter_batch(img, seg, N, K, H, W, 15.0, 50.0)
+        assert np.array_equal(out, ref)
+        assert (M > 0).all()
+
+
+def test_bilateral_against_compiled_reference_live(oracle_c):
+    """oracle/_ref (the reference's own C++) on a fresh input, when it has been built."""
+    if oracle_c.ref_lib() is None:
+        pytest.skip("oracle/_ref not built here")
+    rng = np.random.default_rng(5)
+    N, K, H, W = 1, 2, 24, 40
+    img = rng.uniform(0, 255, (N, 3, H, W)).astype(np.float32)
+    seg = rng.uniform(0, 1, (N, K, H, W)).astype(np.float32)
+    ref = np.zeros(seg.size, np.float32)
+    oracle_c.ref_bilateralfilter_batch(img, seg, ref, N, K, H, W, 15.0, 50.0)
+    out, _ = oracle_c.bilateralfilter_batch(img, seg, N, K, H, W, 15.0, 50.0)
+    assert np.array_equal(out.reshape(-1), ref)
+
+
+def test_dense_energy_loss_and_grad_vs_reference(golden):
+    from oracle import torch_oracle as to
+    g = golden("bilateral")
+    logits = torch.from_numpy(g["del_logits"]).requires_grad_(True)
+    prob = logits.softmax(1)
+    loss, grad = to.dense_energy(torch.from_numpy(g["del_img"]), prob, torch.from_numpy(g["del_roi"]),
+                                 torch.from_numpy(g["del_label"]), 1e-7, 15.0, 100.0, 0.5, leaf=logits)
+    np.testing.assert_allclose(loss.numpy(), g["del_loss"], rtol=1e-5)
+    np.testing.assert_allclose(grad.numpy(), g["del_grad"], rtol=1e-4, atol=1e-12)
+
+
+def test_camseg_tail_vs_reference(golden):
+    from oracle import torch_oracle as to
+    from oracle.gen_golden import _StubModel
+    g = golden("camseg_tail")
+    cam, aux, seg = to.multi_scale_camseg(_StubModel(int(g["C"])), torch.from_numpy(g["imgs"]), [1.0, 0.5, 1.5])
+    np.testing.assert_allclose(cam.numpy(), g["cam"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(aux.numpy(), g["cam_aux"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(seg.numpy(), g["seg"], rtol=1e-6, atol=1e-6)
+
+
+def test_cam_minmax_norm_c_vs_torch(oracle_c):
+    rng = np.random.default_rng(3)
+    x = np.maximum(rng.normal(0.3, 1, (2, 3, 17, 19)), 0).astype(np.float32)
+    t = torch.from_numpy(x)
+    t = t - t.amin(dim=(2, 3), keepdim=True)
+    t = t / (t.amax(dim=(2, 3), keepdim=True) + 1e-5)
+    assert np.array_equal(oracle_c.cam_minmax_norm(x), t.numpy())
+
+
+def test_misc_vs_reference(oracle_c, golden):
+    from oracle import torch_oracle as to
+    g = golden("misc")
+    assert np.array_equal(oracle_c.denormalize_img(g["denorm_in"]), g["denorm_out"])
+    for st, lr in zip(g["lr_steps"], g["lr_values"]):
+        assert to.poly_warmup_lr(int(st), 6e-5) == pytest.approx(lr, rel=1e-12)
+    t = torch.from_numpy
+    np.testing.assert_allclose(to.seg_loss(t(g["segloss_pred"]), t(g["segloss_mask"])).numpy(), g["segloss_out"], rtol=1e-6)
+    ref = to.seg_refine_by_label(t(g["refine_seg"]), t(g["refine_labels"]), 0.01)
+    np.testing.assert_allclose(ref.numpy(), g["refine_out"], rtol=1e-6, atol=1e-30)
+    np.testing.assert_allclose(to.cam_loss(t(g["camloss_cam"]), ref).numpy(), g["camloss_out"], rtol=1e-6)
