@@ -1,0 +1,154 @@
+#!/usr/bin/env python
+"""bench.py -- training images/sec of the CoSA hot path on N MI355X GPUs (one process per GPU, RCCL).
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one full training iteration (main.py:106-252): teacher 3 scales x 2 flips forward,
+student forward+backward, CAM -> label maps (x2), the five losses incl. the bilateral dense-energy
+regulariser, AdamW, EMA -- on one synthetic batch per rank, post-warm-up loss
+weights so every loss is live.  Workload = BASELINE.json configs[1]: VOC 21-class, ViT-B bf16,
+batch 16 x 448 x 448 per GPU (weak scaling).
+
+Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
+  roofline      the dominant hand-written kernel, timed with HIP events inside the timed steps
+  cpu_baseline  the CPU oracle's step on a bounded sample (N=1 only), timed on the host cores
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FLOP_PER_IMG_448 = 1.782e12        # teacher 1282.9 G + student fwd+bwd 498.9 G
+PEAK_BF16 = 2.5e15                 # dense bf16 MFMA peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=16, help="per-GPU batch (BASELINE configs[1]: 16)")
+    ap.add_argument("--crop", type=int, default=448)
+    ap.add_argument("--dataset", default="VOC12", choices=["VOC12", "COCO"])
+    ap.add_argument("--usepar", action="store_true", help="PAR(T=10, 6 dilations) as cam2mask's refine_model")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=2, help="batch of the CPU-baseline sample (configs[0]: 2)")
+    return ap.parse_args()
+
+
+def cpu_baseline(opt, state_dict, C):
+    """one step of the CPU oracle at configs[0] (b=2, 448^2, fp32) on all host cores"""
+    from oracle import c_oracle
+    from oracle.cpu_step import CpuStep
+    from cosa_amd.train_step import synthetic_batch
+    c_oracle.build()
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    sd = {k: v.detach().float().cpu() for k, v in state_dict.items()}
+    step = CpuStep(sd, num_classes=C + 1, aux_layer=-4 if opt.dataset == "VOC12" else -3,
+                   args=dict(max_iters=32000 if opt.dataset == "VOC12" else 60000, par=([1, 2, 4, 8, 12, 24], 10) if opt.usepar else None))
+    b = opt.cpu_batch
+    wimg, simg, lab, box = synthetic_batch(b, opt.crop, C, torch.device("cpu"), seed=1234, dataset=opt.dataset)
+    timers = {}
+    t0 = time.perf_counter()
+    step.step(wimg, simg, lab, box.numpy(), n_iter=10 ** 6, timers=timers)
+    dt = time.perf_counter() - t0
+    return {"value": round(b / dt, 4), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"1 full training step, batch {b} x {opt.crop}x{opt.crop}, fp32, oracle/cpu_step.py ({dt:.1f} s)",
+            "stage_s": {k: round(v, 2) for k, v in timers.items()}}
+
+
+def main():
+    opt = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)          # "nccl" == RCCL on ROCm
+
+    from cosa_amd import _C, nn_ops
+    from cosa_amd.train_step import CoSATrainer, default_args, synthetic_batch
+
+    C = 20 if opt.dataset == "VOC12" else 80
+    args = default_args(opt.dataset, crop_size=opt.crop, batch_size=opt.batch, usepar=opt.usepar)
+    trainer = CoSATrainer(args, dev, ddp=world > 1, seed=0)
+    wimg, simg, lab, box = synthetic_batch(opt.batch, opt.crop, C, dev, seed=1234 + rank, dataset=opt.dataset)
+    n_iter = args.warmup_iters + 1            # post-warm-up: all five losses are live
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(opt.warmup):
+        trainer.step(wimg, simg, lab, box, n_iter)
+    sync()
+    nn_ops._flops.clear()
+    _C.profile_start()
+    t0 = time.perf_counter()
+    for _ in range(opt.steps):
+        logs = trainer.step(wimg, simg, lab, box, n_iter)
+    sync()
+    dt = time.perf_counter() - t0
+    prof = _C.profile_stop()
+    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    loss = float(logs["overall_loss"])
+
+    if rank == 0:
+        imgs = opt.batch * world * opt.steps
+        ips = imgs / dt
+        flop_img = FLOP_PER_IMG_448 if opt.crop == 448 else None
+        # dominant hand-written kernel: the fused attention forward (HIP events on the launch stream)
+        n_launch, ms = prof.get("attn_fwd", (0, 0.0))
+        roof = None
+        if n_launch:
+            flops = nn_ops._flops.get("attn_fwd", 0.0)
+            ach = flops / (ms * 1e-3) / 1e12
+            roof = {"kernel": "attn_fwd_kernel", "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16 / 1e12,
+                    "unit": "TFLOP/s", "frac": round(ach * 1e12 / PEAK_BF16, 4), "traffic": None,
+                    "launches": n_launch, "avg_launch_ms": round(ms / n_launch, 4),
+                    "share_of_step": round(ms * 1e-3 / dt, 4)}
+        out = {
+            "metric": "training images/sec at 448x448 ViT-B", "value": round(ips, 3), "unit": "images/s", "n_gpus": world,
+            "steps": opt.steps, "warmup": opt.warmup, "ms_per_step": round(dt / opt.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"{opt.dataset} {C + 1}-class, ViT-B/16 bf16, batch {opt.batch}/GPU x {opt.crop}x{opt.crop}, "
+                                   f"teacher 3 scales x 2 flips + student fwd/bwd + cam2mask x2 + 5 losses + AdamW + EMA"
+                                   f"{' + PAR' if opt.usepar else ''}",
+                       "global_batch": opt.batch * world, "parallelism": f"dp{world}", "final_loss": round(loss, 5)},
+            "roofline": roof,
+        }
+        if flop_img:
+            out["step_mfma"] = {"achieved_TFLOPs": round(ips * flop_img / 1e12, 2), "peak_TFLOPs": PEAK_BF16 / 1e12 * world,
+                                "frac": round(ips * flop_img / (PEAK_BF16 * world), 4), "flop_per_img": flop_img}
+        if world == 1 and not opt.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(opt, trainer.student.state_dict(), C)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -40,6 +40,10 @@ _SIGS = {
     "cosa_dense_energy_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                           c_int, c_float, c_float, c_void_p, c_size_t, c_void_p]),
     "cosa_dense_energy_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "cosa_attn_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "cosa_attn_prepare_vt": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "cosa_attn_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p, c_size_t,
+                      c_void_p]),
 }
 
 # entry points added by later translation units register themselves here (vit / gemm / attention)
@@ -102,6 +106,42 @@ def workspace(nbytes, device, tag="default"):
         buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
         _ws_cache[key] = buf
     return buf
+
+
+# ---- optional per-kernel HIP-event timing (bench.py's roofline leg) ------------------------------------
+_prof = None
+
+
+def profile_start():
+    """Record a HIP event pair around every profiled() region on torch's current stream (= the launch stream)."""
+    global _prof
+    _prof = {}
+
+
+def profile_stop():
+    """-> {name: (n_launches, total_ms)}; synchronises."""
+    global _prof
+    p, _prof = _prof, None
+    torch.cuda.synchronize()
+    return {k: (len(v), sum(a.elapsed_time(b) for a, b in v)) for k, v in (p or {}).items()}
+
+
+class profiled:
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if _prof is not None:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.b = torch.cuda.Event(enable_timing=True)
+            self.a.record()
+        return self
+
+    def __exit__(self, *exc):
+        if _prof is not None:
+            self.b.record()
+            _prof.setdefault(self.name, []).append((self.a, self.b))
+        return False
 
 
 def int_array(values):

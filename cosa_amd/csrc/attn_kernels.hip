@@ -1,0 +1,240 @@
+// attn_kernels.hip -- ViT patch attention for gfx950 (CDNA4): LDS-tiled, MFMA, online softmax.
+//
+// Reference: models/vit/vit.py:119-137 (Attention.forward): softmax(q k^T * hd^-0.5) v, 12 heads x 64,
+// sequence lengths 197 / 785 / 1765 (+3601 at 640 crops).  The reference materialises the
+// [B,12,N,N] score tensor; here it never leaves the CU.
+//
+// Layouts (bf16):  qkv [B, N, 3, H, 64]  (straight out of the qkv projection, no permute copy)
+//                  vt  [B, H, 64, Npad]  V transposed per head, keys zero-padded to Npad % 64 == 0
+//                  out [B, N, H*64]      (what the output projection consumes)
+//                  lse [B, H, N] f32     natural-log sum-exp of the scaled scores (for backward)
+//
+// Wave64 tiling: a workgroup = 4 waves = 128 queries; each wave owns 32 queries and walks the keys
+// in tiles of 64.  Scores are computed TRANSPOSED (S^T = K Q^T, v_mfma_f32_32x32x16_bf16) so that
+// the query sits on the lane: row max / row sum are in-lane plus one cross-half exchange, the
+// exponentiated tile is already the B operand of O^T = V^T P^T (no LDS round trip, no shuffles),
+// and the O rescale / final 1/l are lane-local.
+#include "kernels.hpp"
+
+namespace cosa {
+namespace {
+
+typedef __bf16 bf16;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int HD = 64;           // head dim
+constexpr int BQ = 128;          // queries per workgroup
+constexpr int BK = 64;           // keys per tile
+constexpr int VS = 136;          // bytes per row of the V^T LDS image (64 keys * 2 B + 8 pad: conflict-free b64 reads)
+
+__device__ __forceinline__ int crow(int i, int hh) { return (i & 3) + 8 * (i >> 2) + 4 * hh; }
+
+// ---- V transpose: qkv[...,2,h,:] -> vt[b,h,d,key] ------------------------------------------------
+__global__ __launch_bounds__(256) void attn_vt_kernel(const bf16 *__restrict__ qkv, bf16 *__restrict__ vt, int N, int Npad, int H)
+{
+    __shared__ unsigned short tile[BK][HD + 2];
+    const int b = blockIdx.z, h = blockIdx.y, k0 = blockIdx.x * BK;
+    const int tid = threadIdx.x;
+    for (int c = tid; c < BK * 8; c += 256) {
+        const int key = c >> 3, s = c & 7;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (k0 + key < N)
+            v = *reinterpret_cast<const uint4 *>(qkv + (((size_t)b * N + k0 + key) * 3 + 2) * H * HD + h * HD + s * 8);
+        unsigned *dst = reinterpret_cast<unsigned *>(&tile[key][s * 8]);
+        dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+    }
+    __syncthreads();
+    for (int c = tid; c < HD * 8; c += 256) {
+        const int d = c >> 3, kc = c & 7;
+        unsigned short e[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) e[i] = tile[kc * 8 + i][d];
+        uint4 v;
+        v.x = e[0] | ((unsigned)e[1] << 16); v.y = e[2] | ((unsigned)e[3] << 16);
+        v.z = e[4] | ((unsigned)e[5] << 16); v.w = e[6] | ((unsigned)e[7] << 16);
+        *reinterpret_cast<uint4 *>(vt + (((size_t)b * H + h) * HD + d) * Npad + k0 + kc * 8) = v;
+    }
+}
+
+// ---- forward -----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16 *__restrict__ qkv, const bf16 *__restrict__ vt,
+                                                      bf16 *__restrict__ out, float *__restrict__ lse,
+                                                      int N, int Npad, int H, float scale_log2e)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char smem[BK * 128 + HD * VS];
+    unsigned char *Ks = smem;
+    unsigned char *Vs = smem + BK * 128;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int q0 = blockIdx.x * BQ + wave * 32;
+    const size_t rs = (size_t)3 * H * HD;          // elements per token row of qkv
+
+    // Q fragments: B operand of S^T = K Q^T  (lane: query r, d = 16s + 8hh + j)
+    const int qrow = min(q0 + r, N - 1);
+    const bf16 *qp = qkv + ((size_t)b * N + qrow) * rs + h * HD + 8 * hh;
+    bf16x8 qf[4];
+#pragma unroll
+    for (int s = 0; s < 4; s++) qf[s] = *reinterpret_cast<const bf16x8 *>(qp + 16 * s);
+
+    f32x16 o0, o1;
+#pragma unroll
+    for (int i = 0; i < 16; i++) { o0[i] = 0.f; o1[i] = 0.f; }
+    float m = -INFINITY, l = 0.f;
+
+    const bf16 *kbase = qkv + (size_t)b * N * rs + (size_t)H * HD + h * HD;      // k part
+    const bf16 *vbase = vt + ((size_t)b * H + h) * HD * Npad;
+    const int swz = (r >> 1) & 7;
+
+    for (int k0 = 0; k0 < N; k0 += BK) {
+        __syncthreads();
+        // stage K tile [64 keys][64 d], 16-B slots XOR-swizzled by (key>>1)&7 (conflict-free ds_read_b128)
+#pragma unroll
+        for (int c = tid; c < BK * 8; c += 256) {
+            const int key = c >> 3, s = c & 7;
+            const int gk = min(k0 + key, N - 1);
+            const uint4 v = *reinterpret_cast<const uint4 *>(kbase + (size_t)gk * rs + s * 8);
+            *reinterpret_cast<uint4 *>(Ks + key * 128 + ((s ^ ((key >> 1) & 7)) << 4)) = v;
+        }
+        // stage V^T tile [64 d][64 keys] (already transposed + zero padded in global memory)
+#pragma unroll
+        for (int c = tid; c < HD * 8; c += 256) {
+            const int d = c >> 3, kc = c & 7;
+            const uint4 v = *reinterpret_cast<const uint4 *>(vbase + (size_t)d * Npad + k0 + kc * 8);
+            uint2 *dst = reinterpret_cast<uint2 *>(Vs + d * VS + kc * 16);
+            dst[0] = make_uint2(v.x, v.y);
+            dst[1] = make_uint2(v.z, v.w);
+        }
+        __syncthreads();
+
+        // S^T[key][query] for two 32-key blocks
+        f32x16 s0, s1;
+#pragma unroll
+        for (int i = 0; i < 16; i++) { s0[i] = 0.f; s1[i] = 0.f; }
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            const int slot = ((2 * s + hh) ^ swz) << 4;
+            const bf16x8 a0 = *reinterpret_cast<const bf16x8 *>(Ks + r * 128 + slot);
+            const bf16x8 a1 = *reinterpret_cast<const bf16x8 *>(Ks + (r + 32) * 128 + slot);
+            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, qf[s], s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, qf[s], s1, 0, 0, 0);
+        }
+        // scale (log2 domain), mask the key tail, online softmax with the query on the lane
+        float mt = -INFINITY;
+        const bool tail = k0 + BK > N;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            float a = s0[i] * scale_log2e, c = s1[i] * scale_log2e;
+            if (tail) {
+                if (k0 + crow(i, hh) >= N) a = -INFINITY;
+                if (k0 + 32 + crow(i, hh) >= N) c = -INFINITY;
+            }
+            s0[i] = a; s1[i] = c;
+            mt = fmaxf(mt, fmaxf(a, c));
+        }
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        const float mnew = fmaxf(m, mt);
+        const float alpha = __builtin_amdgcn_exp2f(m - mnew);
+        m = mnew;
+        float ls = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            s0[i] = __builtin_amdgcn_exp2f(s0[i] - mnew);
+            s1[i] = __builtin_amdgcn_exp2f(s1[i] - mnew);
+            ls += s0[i] + s1[i];
+        }
+        l = l * alpha + ls;
+#pragma unroll
+        for (int i = 0; i < 16; i++) { o0[i] *= alpha; o1[i] *= alpha; }
+
+        // O^T[d][query] += V^T[d][key] P^T[key][query]; the exponentiated accumulators ARE the B operand
+#pragma unroll
+        for (int kb = 0; kb < 2; kb++) {
+#pragma unroll
+            for (int sp = 0; sp < 2; sp++) {
+                bf16x8 pf;
+#pragma unroll
+                for (int j = 0; j < 8; j++) pf[j] = (bf16)(kb == 0 ? s0[8 * sp + j] : s1[8 * sp + j]);
+                const int keyb = kb * 32 + 16 * sp + 4 * hh;
+                {
+                    const uint2 lo = *reinterpret_cast<const uint2 *>(Vs + r * VS + keyb * 2);
+                    const uint2 hi = *reinterpret_cast<const uint2 *>(Vs + r * VS + (keyb + 8) * 2);
+                    uint4 av = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                    o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8 *>(&av), pf, o0, 0, 0, 0);
+                }
+                {
+                    const uint2 lo = *reinterpret_cast<const uint2 *>(Vs + (r + 32) * VS + keyb * 2);
+                    const uint2 hi = *reinterpret_cast<const uint2 *>(Vs + (r + 32) * VS + (keyb + 8) * 2);
+                    uint4 av = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                    o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8 *>(&av), pf, o1, 0, 0, 0);
+                }
+            }
+        }
+    }
+    // finish: combine the two half-lane partial sums, normalise, store O (d = db*32 + crow(i,hh)) and LSE
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+    const int q = q0 + r;
+    if (q < N) {
+        bf16 *op = out + ((size_t)b * N + q) * H * HD + h * HD;
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            bf16x4 v0, v1;
+#pragma unroll
+            for (int j = 0; j < 4; j++) { v0[j] = (bf16)(o0[4 * g + j] * inv); v1[j] = (bf16)(o1[4 * g + j] * inv); }
+            *reinterpret_cast<bf16x4 *>(op + 8 * g + 4 * hh) = v0;
+            *reinterpret_cast<bf16x4 *>(op + 32 + 8 * g + 4 * hh) = v1;
+        }
+        if (hh == 0) lse[((size_t)b * H + h) * N + q] = (m + __builtin_amdgcn_logf(l)) * 0.6931471805599453f;
+    }
+}
+
+}  // namespace
+}  // namespace cosa
+
+using namespace cosa;
+
+/* vt scratch size in bytes for cosa_attn_fwd */
+extern "C" size_t cosa_attn_workspace_bytes(int B, int N, int H)
+{
+    const size_t Npad = (size_t)(N + BK - 1) / BK * BK;
+    return align_up((size_t)B * H * HD * Npad * sizeof(bf16), 256);
+}
+
+extern "C" int cosa_attn_prepare_vt(const void *qkv, int B, int N, int H, void *workspace, size_t workspace_bytes, void *stream)
+{
+    COSA_REQUIRE(qkv && workspace && B > 0 && N > 0 && H > 0 && B <= 65535 && H <= 65535, "cosa_attn_prepare_vt: bad arguments");
+    if (workspace_bytes < cosa_attn_workspace_bytes(B, N, H)) {
+        set_error("cosa_attn_prepare_vt: workspace too small");
+        return COSA_ENOMEM;
+    }
+    const int Npad = (N + BK - 1) / BK * BK;
+    hipLaunchKernelGGL(attn_vt_kernel, dim3(Npad / BK, H, B), dim3(256), 0, as_stream(stream), static_cast<const bf16 *>(qkv),
+                       static_cast<bf16 *>(workspace), N, Npad, H);
+    COSA_LAUNCH_CHECK();
+    return COSA_OK;
+}
+
+extern "C" int cosa_attn_fwd(const void *qkv, void *out, float *lse, int B, int N, int H, int head_dim, float scale,
+                             int flags, void *workspace, size_t workspace_bytes, void *stream)
+{
+    COSA_REQUIRE(qkv && out && lse && workspace, "cosa_attn_fwd: null pointer");
+    COSA_REQUIRE(head_dim == HD, "cosa_attn_fwd: head_dim must be 64");
+    COSA_REQUIRE(B > 0 && N > 0 && H > 0 && B <= 65535 && H <= 65535, "cosa_attn_fwd: bad shape");
+    if (workspace_bytes < cosa_attn_workspace_bytes(B, N, H)) {
+        set_error("cosa_attn_fwd: workspace too small");
+        return COSA_ENOMEM;
+    }
+    hipStream_t st = as_stream(stream);
+    const int Npad = (N + BK - 1) / BK * BK;
+    bf16 *vt = static_cast<bf16 *>(workspace);
+    if (!(flags & 1)) {   // bit 0: V^T already prepared in the workspace by cosa_attn_prepare_vt
+        hipLaunchKernelGGL(attn_vt_kernel, dim3(Npad / BK, H, B), dim3(256), 0, st, static_cast<const bf16 *>(qkv), vt, N, Npad, H);
+        COSA_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3((N + BQ - 1) / BQ, H, B), dim3(256), 0, st, static_cast<const bf16 *>(qkv), vt,
+                       static_cast<bf16 *>(out), lse, N, Npad, H, scale * 1.4426950408889634f);
+    COSA_LAUNCH_CHECK();
+    return COSA_OK;
+}

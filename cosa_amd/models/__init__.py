@@ -1,0 +1,117 @@
+"""models -- `build_model(args)` / `VITNetwork` with the reference's call surface.
+
+Reference: models/__init__.py:13-79 (build_model), :82-206 (VITNetwork), models/decoder/conv_head.py:11-41
+(LargeFOV).  state_dict keys are identical to the reference: encoder.* (timm ViT names),
+decoder.conv6/7/8.weight, classifier.weight, aux_classifier.weight.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import _C, nn_ops
+from . import vit as vitencoder
+from .PAR import PAR  # noqa: F401
+
+
+class LargeFOV(nn.Module):
+    """models/decoder/conv_head.py:11-41: 3x3 d5 (768->512) ReLU, 3x3 d5 (512->512) ReLU, 1x1 -> classes; no bias."""
+
+    def __init__(self, in_planes, out_planes, dilation=5):
+        super().__init__()
+        self.embed_dim = 512
+        self.dilation = dilation
+        self.conv6 = nn.Conv2d(in_planes, self.embed_dim, 3, padding=dilation, dilation=dilation, bias=False)
+        self.conv7 = nn.Conv2d(self.embed_dim, self.embed_dim, 3, padding=dilation, dilation=dilation, bias=False)
+        self.conv8 = nn.Conv2d(self.embed_dim, out_planes, 1, bias=False)
+
+    def forward_nhwc(self, x, dt):
+        """x: [B,C,h,w] view with channels-last strides (tokens are NHWC already)."""
+        c = nn_ops.cast_param
+        x = F.relu(F.conv2d(x, c(self.conv6.weight, dt).contiguous(memory_format=torch.channels_last), padding=self.dilation,
+                            dilation=self.dilation))
+        x = F.relu(F.conv2d(x, c(self.conv7.weight, dt).contiguous(memory_format=torch.channels_last), padding=self.dilation,
+                            dilation=self.dilation))
+        return F.conv2d(x, c(self.conv8.weight, dt))
+
+
+class VITNetwork(nn.Module):
+    """models/__init__.py:82-206"""
+
+    def __init__(self, backbone, num_classes, pretrained=True, aux_layer=-3, isgap=False, decoder='LargeFOV',
+                 compute_dtype=torch.bfloat16):
+        super().__init__()
+        assert decoder in ['LargeFOV'], "cosa_amd builds the LargeFOV decoder (the run scripts' default)"
+        self.num_classes = num_classes
+        self.encoder = getattr(vitencoder, backbone)(pretrained=pretrained, aux_layer=aux_layer, compute_dtype=compute_dtype)
+        self.in_channels = [self.encoder.embed_dim] * 4
+        self.isgap = isgap
+        self.decoder = LargeFOV(in_planes=self.in_channels[-1], out_planes=self.num_classes)
+        self.isdecoder_trans = False
+        self.classifier = nn.Conv2d(self.in_channels[-1], self.num_classes - 1, kernel_size=1, bias=False)
+        self.aux_classifier = nn.Conv2d(self.in_channels[-1], self.num_classes - 1, kernel_size=1, bias=False)
+        self.compute_dtype = compute_dtype
+
+    def set_compute_dtype(self, dt):
+        self.compute_dtype = dt
+        self.encoder.compute_dtype = dt
+        return self
+
+    def get_param_groups(self):
+        """models/__init__.py:126-144: backbone; backbone norms; cls heads; decoder"""
+        groups = [[], [], [], []]
+        for name, param in self.encoder.named_parameters():
+            groups[1 if "norm" in name else 0].append(param)
+        groups[2].append(self.classifier.weight)
+        groups[2].append(self.aux_classifier.weight)
+        groups[3].extend(self.decoder.parameters())
+        return groups
+
+    def _pool(self, tok):
+        return tok.mean(dim=1) if self.isgap else tok.amax(dim=1)
+
+    def _cam(self, tok, weight, B, h, w, detach_feat, detach_w):
+        """1x1 conv over tokens == tokens @ W^T; returned as fp32 NCHW [B,C,h,w] (models/__init__.py:190-192)."""
+        dt = self.compute_dtype
+        wgt = nn_ops.cast_param(weight, dt).reshape(weight.shape[0], -1)
+        if detach_w:
+            wgt = wgt.detach()
+        if detach_feat:
+            tok = tok.detach()
+        cam = F.linear(tok, wgt).float()
+        return cam.reshape(B, h, w, -1).permute(0, 3, 1, 2).contiguous()
+
+    def forward(self, x, cam_only=False, seg_only=False, detach='none'):
+        """models/__init__.py:163-206 -> (cls, cls_aux, feat[B,768,h,w], seg, cam, cam_aux)"""
+        assert detach in ['all', 'feat', 'none', 'cls']
+        _C.require_cuda(x)                                            # MI355X only: there is no CPU path
+        dt = self.compute_dtype
+        B = x.shape[0]
+        _, tok, tok_aux = self.encoder.forward_features(x)
+        p = self.encoder.patch_size
+        h, w = x.shape[-2] // p, x.shape[-1] // p
+        x4 = tok.reshape(B, h, w, -1).permute(0, 3, 1, 2)            # NCHW view, channels-last strides (no copy)
+        seg = self.decoder.forward_nhwc(x4, dt).float().contiguous()
+        if seg_only:
+            return seg
+        cam = self._cam(tok, self.classifier.weight, B, h, w, detach == 'feat', detach == 'cls')
+        cam_aux = self._cam(tok_aux, self.aux_classifier.weight, B, h, w, detach == 'feat', detach == 'cls')
+        if detach == 'all':
+            cam, cam_aux = cam.detach(), cam_aux.detach()
+        if cam_only:
+            return cam, cam_aux
+        wc = nn_ops.cast_param(self.classifier.weight, dt).reshape(self.num_classes - 1, -1)
+        wa = nn_ops.cast_param(self.aux_classifier.weight, dt).reshape(self.num_classes - 1, -1)
+        cls_x4 = F.linear(self._pool(tok), wc).float()
+        cls_aux = F.linear(self._pool(tok_aux), wa).float()
+        return cls_x4, cls_aux, x4, seg, cam, cam_aux
+
+
+def build_model(args):
+    """models/__init__.py:13-24 (the `vit` branch; the other zoos are commented out in the reference too)."""
+    model = getattr(args, "model", "vit")
+    if model != 'vit':
+        raise NotImplementedError("cosa_amd builds args.model == 'vit' (the only live branch of the reference)")
+    dt = getattr(args, "compute_dtype", torch.bfloat16)
+    return VITNetwork(backbone=args.backbone, num_classes=args.num_classes, pretrained=getattr(args, "pretrained", False),
+                      aux_layer=args.aux_layer, isgap=getattr(args, "isgap", False),
+                      decoder=getattr(args, "decoder", "LargeFOV"), compute_dtype=dt)

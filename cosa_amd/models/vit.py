@@ -1,0 +1,159 @@
+"""ViT-B/16 encoder of the CoSA network, MI355X-native execution.
+
+Reference: models/vit/vit.py:86-181 (Mlp/Attention/Block/PatchEmbed), :219-330 (VisionTransformer,
+prepare_tokens, forward_features), :365-377 (vit_base_patch16_224).  Module / parameter names are
+kept so the reference's state_dict (and the released checkpoints) load unchanged.
+
+Execution differs from the reference on purpose:
+  * tokens stay [B, N, 768] (== NHWC) end to end; no NCHW transposes
+  * patch embedding is an im2col view + one GEMM (the 16x16/16 conv is exactly that)
+  * attention is the fused HIP kernel on the packed qkv buffer (no [B,12,N,N] tensor, no permutes)
+  * the bicubic position-embedding resize is cached per token grid (pos_embed is frozen)
+  * bf16 compute with fp32 master weights (compute_dtype=torch.float32 is the parity mode)
+"""
+from functools import partial
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import nn_ops
+
+
+class Mlp(nn.Module):
+    def __init__(self, in_features, hidden_features):
+        super().__init__()
+        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.fc2 = nn.Linear(hidden_features, in_features)
+
+
+class Attention(nn.Module):
+    def __init__(self, dim, num_heads, qkv_bias=True):
+        super().__init__()
+        self.num_heads = num_heads
+        self.scale = (dim // num_heads) ** -0.5
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.proj = nn.Linear(dim, dim)
+
+
+class Block(nn.Module):
+    def __init__(self, dim, num_heads, mlp_ratio=4.0, qkv_bias=True, eps=1e-6):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim, eps=eps)
+        self.attn = Attention(dim, num_heads, qkv_bias)
+        self.norm2 = nn.LayerNorm(dim, eps=eps)
+        self.mlp = Mlp(dim, int(dim * mlp_ratio))
+
+
+class PatchEmbed(nn.Module):
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=768):
+        super().__init__()
+        self.img_size = (img_size, img_size)
+        self.patch_size = (patch_size, patch_size)
+        self.num_patches = (img_size // patch_size) ** 2
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size)
+
+
+def _trunc_normal_(t, std=0.02):
+    return nn.init.trunc_normal_(t, std=std)
+
+
+class VisionTransformer(nn.Module):
+    """models/vit/vit.py:219-330"""
+
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, num_classes=1000, embed_dim=768, depth=12, num_heads=12,
+                 mlp_ratio=4.0, qkv_bias=True, aux_layer=-3, eps=1e-6, compute_dtype=torch.bfloat16):
+        super().__init__()
+        self.num_classes = num_classes
+        self.num_features = self.embed_dim = embed_dim
+        self.patch_embed = PatchEmbed(img_size, patch_size, in_chans, embed_dim)
+        num_patches = self.patch_embed.num_patches
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.pos_embed = nn.Parameter(torch.zeros(1, num_patches + 1, embed_dim))
+        self.pos_embed.requires_grad = False                      # vit.py:237
+        self._size = img_size // patch_size
+        self.patch_size = patch_size
+        self.aux_layer = aux_layer
+        self.num_heads = num_heads
+        self.blocks = nn.ModuleList([Block(embed_dim, num_heads, mlp_ratio, qkv_bias, eps) for _ in range(depth)])
+        self.norm = nn.LayerNorm(embed_dim, eps=eps)
+        self.head = nn.Linear(embed_dim, num_classes) if num_classes > 0 else nn.Identity()   # unused by the path (vit.py:257,325)
+        self.compute_dtype = compute_dtype
+        self._pos_cache = {}
+        _trunc_normal_(self.pos_embed)
+        _trunc_normal_(self.cls_token)
+        self.apply(self._init_weights)
+
+    @staticmethod
+    def _init_weights(m):
+        if isinstance(m, nn.Linear):
+            _trunc_normal_(m.weight)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+
+    # -- vit.py:283-300 ---------------------------------------------------------------------------
+    def _pos_for_grid(self, h, w, dtype):
+        pe = self.pos_embed
+        key = (h, w, dtype, pe.device)
+        ent = self._pos_cache.get(key)
+        if ent is None or ent[0] != pe._version:
+            with torch.no_grad():
+                grid = pe[:, 1:, :].reshape(1, self._size, self._size, -1).permute(0, 3, 1, 2).float()
+                grid = F.interpolate(grid, size=(h, w), mode="bicubic", align_corners=False)
+                grid = grid.reshape(1, -1, h * w).permute(0, 2, 1)
+                full = torch.cat((pe[:, :1, :].float(), grid), dim=1).to(dtype).contiguous()
+            ent = (pe._version, full)
+            self._pos_cache[key] = ent
+        return ent[1]
+
+    def prepare_tokens(self, x):
+        B, nc, H, W = x.shape
+        p = self.patch_size
+        h, w = H // p, W // p
+        dt = self.compute_dtype
+        # im2col view of the stride-16 conv: [B, h*w, 3*16*16] @ W^T
+        cols = x.to(dt).reshape(B, nc, h, p, w, p).permute(0, 2, 4, 1, 3, 5).reshape(B, h * w, nc * p * p)
+        wgt = nn_ops.cast_param(self.patch_embed.proj.weight, dt).reshape(self.embed_dim, -1)
+        tok = F.linear(cols, wgt, nn_ops.cast_param(self.patch_embed.proj.bias, dt))
+        cls = nn_ops.cast_param(self.cls_token, dt).expand(B, -1, -1)
+        tok = torch.cat((cls, tok), dim=1)
+        return tok + self._pos_for_grid(h, w, dt), h, w
+
+    def _block(self, blk, x):
+        dt = self.compute_dtype
+        c = nn_ops.cast_param
+        y = F.layer_norm(x, (self.embed_dim,), c(blk.norm1.weight, dt), c(blk.norm1.bias, dt), blk.norm1.eps)
+        qkv = F.linear(y, c(blk.attn.qkv.weight, dt), c(blk.attn.qkv.bias, dt))
+        y = nn_ops.attention(qkv, self.num_heads)
+        x = x + F.linear(y, c(blk.attn.proj.weight, dt), c(blk.attn.proj.bias, dt))
+        y = F.layer_norm(x, (self.embed_dim,), c(blk.norm2.weight, dt), c(blk.norm2.bias, dt), blk.norm2.eps)
+        y = nn_ops.gelu(F.linear(y, c(blk.mlp.fc1.weight, dt), c(blk.mlp.fc1.bias, dt)))
+        return x + F.linear(y, c(blk.mlp.fc2.weight, dt), c(blk.mlp.fc2.bias, dt))
+
+    # -- vit.py:302-321: returns cls token, final tokens, aux-layer tokens (pre final norm unless aux is the last) --
+    def forward_features(self, x):
+        x, h, w = self.prepare_tokens(x)
+        depth = len(self.blocks)
+        aux_idx = self.aux_layer % depth
+        aux = None
+        for i, blk in enumerate(self.blocks):
+            x = self._block(blk, x)
+            if i == aux_idx:
+                aux = x
+        dt = self.compute_dtype
+        x = F.layer_norm(x, (self.embed_dim,), nn_ops.cast_param(self.norm.weight, dt), nn_ops.cast_param(self.norm.bias, dt),
+                         self.norm.eps)
+        if aux_idx == depth - 1:
+            aux = x
+        return x[:, 0], x[:, 1:], aux[:, 1:]
+
+
+def vit_base_patch16_224(pretrained=False, **kwargs):
+    """models/vit/vit.py:365-377 (pretrained ImageNet weights need network access: load a state_dict instead)."""
+    if pretrained:
+        print("cosa_amd: pretrained=True ignored here (no network); load weights with load_state_dict()")
+    return VisionTransformer(patch_size=16, embed_dim=768, depth=12, num_heads=12, mlp_ratio=4, qkv_bias=True, eps=1e-6,
+                             **kwargs)

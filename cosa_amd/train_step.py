@@ -1,0 +1,176 @@
+"""One CoSA training iteration on MI355X (the hot path of main.py:106-252), data-parallel over RCCL.
+
+`CoSATrainer.step()` is the reference loop body with the same call surface underneath
+(models.build_model, utils.seg_helper.*, utils.torch_helper.PolyWarmupAdamW) and these deliberate
+differences, none of which change the maths:
+  * no per-iteration host syncs (the reference does 8 .item() + sklearn mAP per step, main.py:257-268);
+    losses come back as device tensors
+  * cam_validation is folded into the cam2mask kernel; the box ROI is one broadcast compare
+  * EMA teacher update is two foreach launches instead of a ~150-tensor Python loop
+  * the per-iteration barrier (main.py:385) is dropped: the gradient all-reduce already orders ranks
+  * encoder.head (never used, vit.py:257,325) is frozen so DDP needs no find_unused_parameters
+"""
+import math
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from .models import build_model
+from .models.PAR import PAR
+from .utils import seg_helper, torch_helper
+
+IMAGENET_MEAN = (123.675, 116.28, 103.53)
+IMAGENET_STD = (58.395, 57.12, 57.375)
+
+
+def default_args(dataset="VOC12", **over):
+    """Hot-path subset of args.py:3-79 / args_coco.py (values, not the argparse plumbing)."""
+    a = dict(model='vit', backbone='vit_base_patch16_224', decoder='LargeFOV', pretrained=False, aux_layer=-3, isgap=False,
+             crop_size=448, ignore_index=255, num_classes=21, batch_size=2, max_iters=40000, warmup_iters=6000, lr=6e-5,
+             min_mult=0.0, wt_dec=1e-2, wt_dec_mult=1.0, lrscale=10.0, freeze_norm=False, momentum=0.9994, seg_weight=0.1,
+             segfg_alpha=0.5, cam_weight=0.05, seg_softmaxtemp=0.01, reg_weight=0.05, pseudo_scales=[1.0, 0.5, 1.5],
+             high_thre=0.7, high_thre_aux=0.7, low_thre=0.25, low_thre_aux=0.25, par_downscale=2, usepar=False,
+             aux_cam2seg=True, aux_cam2seg_alpha=0.5, aux_seg2cam=False, aux_seg2cam_alpha=0.5, after_softmax=False,
+             detach='none', use_cammix=False, compute_dtype=torch.bfloat16)
+    if dataset == "VOC12":
+        a.update(aux_layer=-4, max_iters=32000)            # run_voc.sh:9-11
+    elif dataset == "COCO":
+        a.update(num_classes=81, batch_size=4, max_iters=60000, warmup_iters=10000, high_thre=0.65)   # args_coco.py
+    a.update(over)
+    return SimpleNamespace(**a)
+
+
+class CoSATrainer:
+    def __init__(self, args, device, ddp=False, seed=0):
+        self.args = args
+        self.device = device
+        torch_helper.setup_seed(seed)
+        self.model_ON = build_model(args).to(device)
+        self.model_AN = build_model(args).to(device)
+        # same weights in student and teacher at step 0 (SURVEY d-2; the reference gets there through identical seeding)
+        self.model_AN.load_state_dict(self.model_ON.state_dict())
+        for m in (self.model_ON, self.model_AN):
+            for p in m.encoder.head.parameters():
+                p.requires_grad = False
+        for p in self.model_AN.parameters():
+            p.requires_grad = False
+        groups = self.model_ON.get_param_groups()
+        self.student = self.model_ON
+        if ddp:
+            self.model_ON = torch.nn.parallel.DistributedDataParallel(
+                self.model_ON, device_ids=[device.index], gradient_as_bucket_view=True, bucket_cap_mb=64)
+        self.optimizer = torch_helper.PolyWarmupAdamW(
+            params=[
+                {'params': [p for p in groups[0] if p.requires_grad], 'lr': args.lr, 'weight_decay': args.wt_dec},
+                {'params': groups[1], 'lr': args.lr if not args.freeze_norm else 0,
+                 'weight_decay': args.wt_dec * args.wt_dec_mult if not args.freeze_norm else 0},
+                {'params': groups[2], 'lr': args.lrscale * args.lr, 'weight_decay': args.wt_dec},
+                {'params': groups[3], 'lr': args.lrscale * args.lr, 'weight_decay': args.wt_dec},
+            ],
+            lr=args.lr, weight_decay=args.wt_dec, betas=(0.9, 0.999), warmup_iter=1500, max_iter=args.max_iters,
+            warmup_ratio=1e-6, power=0.9, min_mult=args.min_mult)
+        self.reg_layer = seg_helper.DenseEnergyLoss(weight=1e-7, sigma_rgb=15, sigma_xy=100, scale_factor=0.5)
+        self.refine_model = PAR(num_iter=10, dilations=[1, 2, 4, 8, 12, 24]) if args.usepar else None
+        self._ema_pairs = (list(self.model_AN.parameters()), list(self.student.parameters()))
+
+    # main.py:114-252 -------------------------------------------------------------------------------
+    def forward_losses(self, wimg, simg, cls_label, img_box, n_iter):
+        args = self.args
+        img_denorm = torch_helper.denormalize_img(simg) if self.refine_model is not None else simg
+        cam_ps, cam_aux_ps, seg_ps = seg_helper.multi_scale_camseg(self.model_AN, wimg, args.pseudo_scales)
+        cls_final, cls_aux, _feat, seg_pred, cam_pred, cam_aux_pred = self.model_ON(simg, cam_only=False, detach=args.detach)
+        cls_loss = F.multilabel_soft_margin_loss(cls_final, cls_label)
+        cls_loss_aux = F.multilabel_soft_margin_loss(cls_aux, cls_label)
+        with torch.no_grad():
+            if args.use_cammix:
+                cam_ps = (cam_ps + cam_aux_ps) / 2
+            refine_mask_label = seg_helper.cam2mask(img_denorm, img_box, cam_ps, cls_label, args.high_thre, args.low_thre,
+                                                    refine_model=self.refine_model, downscale=args.par_downscale,
+                                                    _fold_validation=True)
+        seg_pred = F.interpolate(seg_pred, size=refine_mask_label.shape[1:], mode='bilinear', align_corners=False)
+        seg_loss = seg_helper.seg_loss(seg_pred, refine_mask_label, fg_alpha=args.segfg_alpha)
+        if args.aux_cam2seg:
+            with torch.no_grad():
+                refine_mask_label_aux = seg_helper.cam2mask(img_denorm, img_box, cam_aux_ps, cls_label, args.high_thre_aux,
+                                                            args.low_thre_aux, refine_model=self.refine_model,
+                                                            downscale=args.par_downscale, _fold_validation=True)
+            seg_loss_aux = seg_helper.seg_loss(seg_pred, refine_mask_label_aux, fg_alpha=args.segfg_alpha)
+            seg_loss = (1 - args.aux_cam2seg_alpha) * seg_loss + args.aux_cam2seg_alpha * seg_loss_aux
+        reg_loss = seg_helper.get_energy_loss(img=simg, logit=seg_pred, label=refine_mask_label, img_box=img_box,
+                                              loss_layer=self.reg_layer)
+        with torch.no_grad():
+            valid_seg_ps = seg_helper.seg_refine_by_label(seg_ps, cls_label, softmaxtemp=args.seg_softmaxtemp,
+                                                          after_softmax=args.after_softmax)
+        cam_loss = seg_helper.cam_loss(cam_pred, valid_seg_ps)
+        if args.aux_seg2cam:
+            cam_aux_loss = seg_helper.cam_loss(cam_aux_pred, valid_seg_ps)
+            cam_loss = (1 - args.aux_seg2cam_alpha) * cam_loss + args.aux_seg2cam_alpha * cam_aux_loss
+        if n_iter <= args.warmup_iters:
+            loss = 1.0 * cls_loss + 1.0 * cls_loss_aux + 0.0 * seg_loss + 0.0 * cam_loss + 0.0 * reg_loss
+        else:
+            loss = 1.0 * cls_loss + 1.0 * cls_loss_aux + args.seg_weight * seg_loss + args.cam_weight * cam_loss \
+                + args.reg_weight * reg_loss
+        return loss, dict(overall_loss=loss.detach(), cls_loss=cls_loss.detach(), cls_aux_loss=cls_loss_aux.detach(),
+                          seg_loss=seg_loss.detach(), cam_loss=cam_loss.detach(), reg_loss=reg_loss.detach(),
+                          mask=refine_mask_label)
+
+    def step(self, wimg, simg, cls_label, img_box, n_iter):
+        loss, logs = self.forward_losses(wimg, simg, cls_label, img_box, n_iter)
+        self.optimizer.zero_grad(set_to_none=True)
+        loss.backward()
+        self.optimizer.step()
+        torch_helper.ema_update(self._ema_pairs[0], self._ema_pairs[1], self.args.momentum)
+        return logs
+
+
+# ---- synthetic batches --------------------------------------------------------------------
+def synthetic_batch(b, S, C, device, seed=1234, dataset="VOC12"):
+    """(wimg, simg, cls_label, img_box) with the loader's contract (dataloaders/voc.py:295-305):
+    smooth sinusoid images + sigma=2 noise, uint8-quantised then ImageNet-normalised; VOC-empirical label counts;
+    half the boxes full, half cropped."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    yy, xx = torch.meshgrid(torch.arange(S, dtype=torch.float32), torch.arange(S, dtype=torch.float32), indexing="ij")
+    base = torch.zeros(b, 3, S, S)
+    for _ in range(6):
+        per = 64 + (400 - 64) * torch.rand(b, 3, 2, generator=g)
+        ph = 2 * math.pi * torch.rand(b, 3, 2, generator=g)
+        base += torch.sin(2 * math.pi * xx[None, None] / per[..., 0, None, None] + ph[..., 0, None, None]) * \
+            torch.cos(2 * math.pi * yy[None, None] / per[..., 1, None, None] + ph[..., 1, None, None])
+    mn, mx = base.amin(dim=(2, 3), keepdim=True), base.amax(dim=(2, 3), keepdim=True)
+    img = (base - mn) / (mx - mn) * 255.0 + 2.0 * torch.randn(b, 3, S, S, generator=g)
+    img = img.clamp(0, 255).floor()
+    mean = torch.tensor(IMAGENET_MEAN)[None, :, None, None]
+    std = torch.tensor(IMAGENET_STD)[None, :, None, None]
+    wimg = (img - mean) / std
+    contrast = 0.5 + torch.rand(b, 1, 1, 1, generator=g)
+    simg = (((img - 127.5) * contrast + 127.5).clamp(0, 255).floor() - mean) / std
+    labels = torch.zeros(b, C)
+    for i in range(b):
+        if dataset == "COCO":
+            n_fg = int(min(7, 1 + torch.poisson(torch.tensor(1.9), generator=g).item()))
+        else:
+            n_fg = int(torch.multinomial(torch.tensor([0.60, 0.29, 0.09, 0.02]), 1, generator=g).item()) + 1
+        labels[i, torch.randperm(C, generator=g)[:n_fg]] = 1
+    boxes = torch.zeros(b, 4, dtype=torch.int16)
+    for i in range(b):
+        if i % 2 == 0:
+            boxes[i] = torch.tensor([0, S, 0, S])
+        else:
+            r = torch.randint(0, S // 8 + 1, (4,), generator=g)
+            boxes[i] = torch.tensor([int(r[0]), S - int(r[1]), int(r[2]), S - int(r[3])])
+    return wimg.to(device), simg.to(device), labels.to(device), boxes
+
+
+def smoke():
+    """one tiny forward+backward of the flagship step on cuda:0 (reduced crop, same code path)."""
+    dev = torch.device("cuda", 0)
+    args = default_args("VOC12", crop_size=128)
+    tr = CoSATrainer(args, dev)
+    wimg, simg, lab, box = synthetic_batch(2, 128, 20, dev, seed=1)
+    logs = tr.step(wimg, simg, lab, box, n_iter=args.warmup_iters + 1)
+    torch.cuda.synchronize()
+    vals = {k: float(v) for k, v in logs.items() if k != "mask"}
+    assert all(math.isfinite(v) for v in vals.values()), vals
+    print("train_step smoke:", {k: round(v, 5) for k, v in vals.items()})

@@ -115,6 +115,19 @@ int cosa_dense_energy_forward(const float *images, const float *seg, const float
 int cosa_dense_energy_backward(const float *AS, const float *roi, const float *grad_out /* 1 float, device */,
                                float *grad_seg, int N, int K, int H, int W, void *stream);
 
+/* ---------------------------------------------------------------------------------------
+ * models/vit/vit.py:119-137  Attention core: softmax(q k^T * scale) v per head, fused (the
+ * [B,H,N,N] score tensor is never materialised).  bf16 in/out, fp32 softmax and accumulation.
+ *   qkv [B,N,3,H,64] bf16 (output of the qkv projection)   out [B,N,H*64] bf16
+ *   lse [B,H,N] f32 (log-sum-exp of the scaled scores, kept for the backward pass)
+ *   workspace holds V transposed per head ([B,H,64,Npad]); flags bit0 = it was already filled by
+ *   cosa_attn_prepare_vt (lets a profiler time the main kernel alone).
+ * ------------------------------------------------------------------------------------- */
+size_t cosa_attn_workspace_bytes(int B, int N, int H);
+int cosa_attn_prepare_vt(const void *qkv, int B, int N, int H, void *workspace, size_t workspace_bytes, void *stream);
+int cosa_attn_fwd(const void *qkv, void *out, float *lse, int B, int N, int H, int head_dim, float scale,
+                  int flags, void *workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

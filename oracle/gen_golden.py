@@ -187,6 +187,55 @@ def gen_misc(rng):
     np.savez_compressed(os.path.join(OUT, "misc.npz"), **out)
 
 
+def gen_vit(rng):
+    """tiny ViT (embed 128, 2 heads x 64, depth 3) from the reference's own VisionTransformer + LargeFOV classes,
+    composed the way models/__init__.py:163-206 composes them."""
+    vit = ref_loader.vit_module()
+    head = ref_loader.conv_head_module()
+    from functools import partial
+    torch.manual_seed(3)
+    C1, E = 7, 128
+    enc = vit.VisionTransformer(patch_size=16, embed_dim=E, depth=3, num_heads=2, mlp_ratio=4, qkv_bias=True,
+                                norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), aux_layer=-2, num_classes=10)
+    dec = head.LargeFOV(in_planes=E, out_planes=C1)
+    cls_w = torch.nn.Conv2d(E, C1 - 1, 1, bias=False)
+    aux_w = torch.nn.Conv2d(E, C1 - 1, 1, bias=False)
+    with torch.no_grad():   # non-trivial biases / norms so every term is exercised
+        for n_, p_ in enc.named_parameters():
+            if p_.ndim == 1:
+                p_.add_(torch.randn_like(p_) * 0.1)
+        # LargeFOV is hard-wired to 512 channels (conv_head.py:14): keep the fixture small by giving the decoder
+        # sparse int8-valued weights (stored as int8, value = q / 256)
+        qstore = {}
+        for n_, p_ in dec.named_parameters():
+            q = rng.integers(-24, 25, size=tuple(p_.shape)).astype(np.int8)
+            if p_.numel() > 1_000_000:
+                q[rng.uniform(size=q.shape) > 0.06] = 0
+            qstore["decoder." + n_] = q
+            p_.copy_(torch.from_numpy(q.astype(np.float32) / 256.0))
+    enc.eval(); dec.eval()
+    x = torch.from_numpy(rng.normal(0, 1, (2, 3, 96, 64)).astype(np.float32))
+    with torch.no_grad():
+        cls_tok, tok, tok_aux = enc.forward_features(x)
+        h, w = x.shape[-2] // 16, x.shape[-1] // 16
+        to2d = lambda t: t.transpose(1, 2).reshape(t.shape[0], E, h, w)
+        x4, xa = to2d(tok), to2d(tok_aux)
+        seg = dec(x4)
+        cam = F.conv2d(x4, cls_w.weight)
+        cam_aux = F.conv2d(xa, aux_w.weight)
+        cls = cls_w(F.adaptive_max_pool2d(x4, (1, 1))).view(-1, C1 - 1)
+        cls_aux = aux_w(F.adaptive_max_pool2d(xa, (1, 1))).view(-1, C1 - 1)
+    out = {"x": x.numpy(), "cls": cls.numpy(), "cls_aux": cls_aux.numpy(), "x4": x4.numpy(), "seg": seg.numpy(),
+           "cam": cam.numpy(), "cam_aux": cam_aux.numpy()}
+    for k, v in enc.state_dict().items():
+        out["sd/encoder." + k] = v.numpy()
+    for k, q in qstore.items():
+        out["sdq/" + k] = q
+    out["sd/classifier.weight"] = cls_w.weight.detach().numpy()
+    out["sd/aux_classifier.weight"] = aux_w.weight.detach().numpy()
+    np.savez_compressed(os.path.join(OUT, "vit_tiny.npz"), **out)
+
+
 def main():
     assert ref_loader.available(), "reference tree not present"
     os.makedirs(OUT, exist_ok=True)
@@ -198,6 +247,7 @@ def main():
     gen_camseg(np.random.default_rng(13))
     gen_bilateral(np.random.default_rng(14))
     gen_misc(np.random.default_rng(15))
+    gen_vit(np.random.default_rng(16))
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")
 

@@ -202,7 +202,8 @@ def test_dense_energy_full_size_vs_oracle(oracle_c):
     AS = torch.empty(N, K, H, W, device="cuda")
     loss = torch.empty(1, device="cuda")
     ws = _C.workspace(L.cosa_bilateral_workspace_bytes(N, K, H, W), "cuda", "t")
-    _C.check(L.cosa_dense_energy_forward(_C.ptr(dev(img)), _C.ptr(dev(seg)), _C.ptr(dev(roi)), _C.ptr(dev(unl, torch.uint8)),
+    d_img, d_seg, d_roi, d_unl = dev(img), dev(seg), dev(roi), dev(unl, torch.uint8)     # keep alive across the launch
+    _C.check(L.cosa_dense_energy_forward(_C.ptr(d_img), _C.ptr(d_seg), _C.ptr(d_roi), _C.ptr(d_unl),
                                          _C.ptr(AS), _C.ptr(loss), N, K, H, W, 15.0, 50.0, _C.ptr(ws), ws.numel(),
                                          _C.stream_ptr()))
     np.testing.assert_allclose(AS.cpu().numpy(), AS_ref, rtol=1e-4, atol=1e-5)
