@@ -1,0 +1,265 @@
+// gemm_kernels.hip -- bf16 MFMA GEMM with fused epilogues for the ViT projections (gfx950).
+//
+//   Y[M,N] = X[M,K] * W[N,K]^T + bias[N]      (nn.Linear layout: both operands K-contiguous)
+//   epilogues:  EPI_BIAS      -> bf16 Y                       (qkv projection,          vit.py:121)
+//               EPI_GELU      -> bf16 gelu_erf(Y)             (mlp.fc1 + GELU,          vit.py:97-98)
+//               EPI_RESIDUAL  -> fp32 Yres = R + Y            (attn.proj / mlp.fc2 + residual, vit.py:156-157)
+//
+// CDNA4 structure: 128x128 output tile per 256-thread workgroup (4 wave64 as 2x2, each 64x64 =
+// 4x4 v_mfma_f32_16x16x32_bf16 accumulators), BK = 64, two LDS stages filled by
+// global_load_lds_dwordx4 (no VGPR round trip): the LDS image is lane-linear, so the XOR swizzle
+// (16-B slot ^ (row & 7), conflict-free ds_read_b128) is applied to the per-lane SOURCE address.
+// W rows feed the MFMA A operand and X rows the B operand, so each lane ends up with four
+// consecutive output features of one token; the tile is staged through LDS once and leaves as
+// whole 256-B rows.  Workgroup ids are remapped so that the tiles sharing an X panel run on the
+// same XCD (private L2).
+#include "kernels.hpp"
+
+namespace cosa {
+namespace {
+
+typedef __bf16 bf16;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = 128 * BK * 2;          // one operand tile: 128 rows x 128 B
+constexpr int STAGE_BYTES = 2 * TILE_BYTES;       // W tile + X tile
+constexpr int CT_LD = 272;                        // bytes per row of the epilogue tile (256 + 16 pad)
+
+enum { EPI_BIAS = 0, EPI_GELU = 1, EPI_RESIDUAL = 2 };
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
+// one operand tile (128 rows x 64 k) -> LDS, 16 B per lane, 4 wave-instructions per wave
+__device__ __forceinline__ void stage_tile(const bf16 *__restrict__ src, int row0, int nrows, int ld, int k0,
+                                           unsigned char *lds_tile, int wave, int lane)
+{
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int q = wave * 4 + i;                  // 1-KiB piece: rows 8q .. 8q+7
+        const int row = 8 * q + (lane >> 3);
+        const int s = (lane & 7) ^ (row & 7);        // logical 16-B slot that lands in physical slot lane&7
+        int grow = row0 + row;
+        grow = grow < nrows ? grow : nrows - 1;      // clamp the M tail (masked at the store)
+        const bf16 *g = src + (size_t)grow * ld + k0 + s * 8;
+        __builtin_amdgcn_global_load_lds((gbl_void *)g, (lds_void *)(lds_tile + q * 1024), 16, 0, 0);
+    }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const bf16 *__restrict__ X, const bf16 *__restrict__ W,
+                                                          const bf16 *__restrict__ bias, const float *__restrict__ R,
+                                                          void *__restrict__ Yv, int M, int N, int K, int tiles_m, int tiles_n)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    // XCD-aware remap (bijective): consecutive ids of one XCD walk the n-tiles of one m-panel
+    const int nwg = tiles_m * tiles_n;
+    int wg = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7, idx = wg >> 3;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tm = wg / tiles_n, tn = wg - tm * tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int wr = wave >> 1, wc = wave & 1;        // wave tile: n-rows [wr*64,+64) x m-cols [wc*64,+64)
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = K / BK;
+    stage_tile(W, n0, N, K, 0, smem, wave, lane);
+    stage_tile(X, m0, M, K, 0, smem + TILE_BYTES, wave, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int frow = lane & 15, fq = lane >> 4;
+    for (int kt = 0; kt < nk; kt++) {
+        unsigned char *cur = smem + (kt & 1) * STAGE_BYTES;
+        unsigned char *nxt = smem + ((kt + 1) & 1) * STAGE_BYTES;
+        if (kt + 1 < nk) {
+            stage_tile(W, n0, N, K, (kt + 1) * BK, nxt, wave, lane);
+            stage_tile(X, m0, M, K, (kt + 1) * BK, nxt + TILE_BYTES, wave, lane);
+        }
+        const unsigned char *At = cur + (wr * 64) * 128;
+        const unsigned char *Bt = cur + TILE_BYTES + (wc * 64) * 128;
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            bf16x8 a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int row = i * 16 + frow;
+                const int slot = ((fq + 4 * ks) ^ (row & 7)) << 4;
+                a[i] = *reinterpret_cast<const bf16x8 *>(At + row * 128 + slot);
+                b[i] = *reinterpret_cast<const bf16x8 *>(Bt + row * 128 + slot);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // ---- epilogue: bias (+GELU) in registers -> LDS tile [m][n] -> whole-row stores (+fp32 residual) ----
+    // acc[i][j][r]: n = wr*64 + 16i + 4*fq + r,  m = wc*64 + 16j + frow
+    unsigned char *Ct = smem;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int nl = wr * 64 + 16 * i + 4 * fq;
+        float bv[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) bv[r] = (float)bias[n0 + nl + r];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int ml = wc * 64 + 16 * j + frow;
+            if (EPI == EPI_RESIDUAL) {
+                // keep fp32: two 128x64 fp32 halves would not fit the 2-stage LDS at once -> write bf16x... use f32 tile rows of 128 n
+                f32x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; r++) v[r] = acc[i][j][r] + bv[r];
+                *reinterpret_cast<f32x4 *>(Ct + ml * (BN * 4 + 16) + nl * 4) = v;
+            } else {
+                bf16x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    float t = acc[i][j][r] + bv[r];
+                    if (EPI == EPI_GELU) t = gelu_erf(t);
+                    v[r] = (bf16)t;
+                }
+                *reinterpret_cast<bf16x4 *>(Ct + ml * CT_LD + nl * 2) = v;
+            }
+        }
+    }
+    __syncthreads();
+    if (EPI == EPI_RESIDUAL) {
+        float *Y = static_cast<float *>(Yv);
+        // 128 rows x 512 B: 4096 16-B chunks, 16 per thread
+#pragma unroll
+        for (int c = tid; c < BM * 32; c += 256) {
+            const int ml = c >> 5, s = c & 31;
+            if (m0 + ml < M) {
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(Ct + ml * (BN * 4 + 16) + s * 16);
+                const size_t o = (size_t)(m0 + ml) * N + n0 + s * 4;
+                const f32x4 rv = *reinterpret_cast<const f32x4 *>(R + o);
+                *reinterpret_cast<f32x4 *>(Y + o) = v + rv;
+            }
+        }
+    } else {
+        bf16 *Y = static_cast<bf16 *>(Yv);
+#pragma unroll
+        for (int c = tid; c < BM * 16; c += 256) {
+            const int ml = c >> 4, s = c & 15;
+            if (m0 + ml < M)
+                *reinterpret_cast<uint4 *>(Y + (size_t)(m0 + ml) * N + n0 + s * 8) =
+                    *reinterpret_cast<const uint4 *>(Ct + ml * CT_LD + s * 16);
+        }
+    }
+}
+
+constexpr size_t kLdsBytes = 128 * (BN * 4 + 16) > 2 * STAGE_BYTES ? 128 * (BN * 4 + 16) : 2 * STAGE_BYTES;
+
+// ---- LayerNorm: fp32 residual stream in, bf16 out; one wave per 768-wide row ---------------------------
+template <int D>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict__ x, const bf16 *__restrict__ g,
+                                                       const bf16 *__restrict__ b, bf16 *__restrict__ y, float *__restrict__ y32,
+                                                       int rows, float eps)
+{
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    constexpr int PER = D / 64 / 4;               // float4 per lane
+    const float4 *xr = reinterpret_cast<const float4 *>(x + (size_t)row * D);
+    float4 v[PER];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < PER; i++) { v[i] = xr[lane + 64 * i]; s += v[i].x + v[i].y + v[i].z + v[i].w; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float mean = s * (1.0f / D);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+        const float a = v[i].x - mean, c = v[i].y - mean, d = v[i].z - mean, e = v[i].w - mean;
+        q += a * a + c * c + d * d + e * e;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+    const float rstd = rsqrtf(q * (1.0f / D) + eps);
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+        const int c0 = (lane + 64 * i) * 4;
+        const bf16x4 gg = *reinterpret_cast<const bf16x4 *>(g + c0);
+        const bf16x4 bb = *reinterpret_cast<const bf16x4 *>(b + c0);
+        float o0 = (v[i].x - mean) * rstd * (float)gg[0] + (float)bb[0];
+        float o1 = (v[i].y - mean) * rstd * (float)gg[1] + (float)bb[1];
+        float o2 = (v[i].z - mean) * rstd * (float)gg[2] + (float)bb[2];
+        float o3 = (v[i].w - mean) * rstd * (float)gg[3] + (float)bb[3];
+        if (y) {
+            bf16x4 ov;
+            ov[0] = (bf16)o0; ov[1] = (bf16)o1; ov[2] = (bf16)o2; ov[3] = (bf16)o3;
+            *reinterpret_cast<bf16x4 *>(y + (size_t)row * D + c0) = ov;
+        }
+        if (y32) *reinterpret_cast<float4 *>(y32 + (size_t)row * D + c0) = make_float4(o0, o1, o2, o3);
+    }
+}
+
+}  // namespace
+}  // namespace cosa
+
+using namespace cosa;
+
+extern "C" int cosa_gemm_bf16(const void *X, const void *W, const void *bias, const float *residual, void *Y,
+                              int M, int N, int K, int epilogue, void *stream)
+{
+    COSA_REQUIRE(X && W && bias && Y, "cosa_gemm_bf16: null pointer");
+    COSA_REQUIRE(M > 0 && N > 0 && K > 0, "cosa_gemm_bf16: bad shape");
+    COSA_REQUIRE(N % BN == 0 && K % BK == 0, "cosa_gemm_bf16: N must be a multiple of 128 and K of 64 (got N=%d K=%d)", N, K);
+    COSA_REQUIRE(epilogue >= 0 && epilogue <= 2, "cosa_gemm_bf16: unknown epilogue");
+    COSA_REQUIRE(epilogue != EPI_RESIDUAL || residual, "cosa_gemm_bf16: residual epilogue needs the residual pointer");
+    const int tiles_m = (M + BM - 1) / BM, tiles_n = N / BN;
+    const dim3 grid(tiles_m * tiles_n), blk(256);
+    hipStream_t st = as_stream(stream);
+    const bf16 *x = static_cast<const bf16 *>(X), *w = static_cast<const bf16 *>(W), *b = static_cast<const bf16 *>(bias);
+    static bool attr_done = false;
+    if (!attr_done) {
+        COSA_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_bf16_kernel<EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes));
+        COSA_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_bf16_kernel<EPI_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes));
+        COSA_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_bf16_kernel<EPI_RESIDUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes));
+        attr_done = true;
+    }
+    switch (epilogue) {
+    case EPI_BIAS:
+        hipLaunchKernelGGL(gemm_bf16_kernel<EPI_BIAS>, grid, blk, kLdsBytes, st, x, w, b, residual, Y, M, N, K, tiles_m, tiles_n);
+        break;
+    case EPI_GELU:
+        hipLaunchKernelGGL(gemm_bf16_kernel<EPI_GELU>, grid, blk, kLdsBytes, st, x, w, b, residual, Y, M, N, K, tiles_m, tiles_n);
+        break;
+    default:
+        hipLaunchKernelGGL(gemm_bf16_kernel<EPI_RESIDUAL>, grid, blk, kLdsBytes, st, x, w, b, residual, Y, M, N, K, tiles_m, tiles_n);
+        break;
+    }
+    COSA_LAUNCH_CHECK();
+    return COSA_OK;
+}
+
+extern "C" int cosa_layernorm(const float *x, const void *gamma, const void *beta, void *y_bf16, float *y_f32,
+                              int rows, int dim, float eps, void *stream)
+{
+    COSA_REQUIRE(x && gamma && beta && (y_bf16 || y_f32) && rows > 0, "cosa_layernorm: bad arguments");
+    COSA_REQUIRE(dim == 768, "cosa_layernorm: dim must be 768 (ViT-B)");
+    hipLaunchKernelGGL(layernorm_kernel<768>, dim3((rows + 3) / 4), dim3(256), 0, as_stream(stream), x,
+                       static_cast<const bf16 *>(gamma), static_cast<const bf16 *>(beta), static_cast<bf16 *>(y_bf16), y_f32, rows, eps);
+    COSA_LAUNCH_CHECK();
+    return COSA_OK;
+}
