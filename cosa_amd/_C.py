@@ -41,6 +41,11 @@ _SIGS = {
                                           c_int, c_float, c_float, c_void_p, c_size_t, c_void_p]),
     "cosa_dense_energy_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "cosa_attn_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "cosa_attn_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "cosa_attn_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p,
+                      c_size_t, c_void_p]),
+    "cosa_gemm_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "cosa_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     "cosa_attn_prepare_vt": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "cosa_attn_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p, c_size_t,
                       c_void_p]),

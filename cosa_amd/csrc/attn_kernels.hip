@@ -190,6 +190,296 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16 *__restrict__ 
     }
 }
 
+
+// =====================================================================================================
+// backward (student pass).  Two MFMA kernels, no atomics, deterministic:
+//   attn_bwd_dq_kernel   workgroup owns 128 queries (query on the lane), walks the keys:
+//        S^T = K Q^T,  P^T = exp(S^T - lse),  dP^T = V dO^T,  dS^T = P^T o (dP^T - delta) * scale,
+//        dQ^T += K^T dS^T
+//   attn_bwd_dkv_kernel  workgroup owns 128 keys (key on the lane), walks the queries:
+//        S = Q K^T,  P,  dP = dO V^T,  dS,   dV^T += dO^T P,   dK^T += Q^T dS
+// In both, the exponentiated / gradient score tile is consumed straight from the accumulator registers
+// as the B operand of the next MFMA (rows of the tile are the contraction index).  The operands that
+// must be contraction-contiguous along tokens (K^T, Q^T, dO^T) come from a transposing prep kernel,
+// which also produces delta = rowsum(dO o O).
+// =====================================================================================================
+
+// [64 tokens][64 d] -> swizzled LDS tile (rows clamped to N-1)
+__device__ __forceinline__ void stage_rows(unsigned char *dst, const bf16 *__restrict__ base, size_t row_stride, int row0,
+                                           int N, int tid)
+{
+#pragma unroll
+    for (int c = tid; c < BK * 8; c += 256) {
+        const int row = c >> 3, s = c & 7;
+        const int g = min(row0 + row, N - 1);
+        const uint4 v = *reinterpret_cast<const uint4 *>(base + (size_t)g * row_stride + s * 8);
+        *reinterpret_cast<uint4 *>(dst + row * 128 + ((s ^ ((row >> 1) & 7)) << 4)) = v;
+    }
+}
+
+// transposed global [64 d][Npad] -> LDS [64 d][VS bytes]
+__device__ __forceinline__ void stage_cols(unsigned char *dst, const bf16 *__restrict__ tbase, int Npad, int col0, int tid)
+{
+#pragma unroll
+    for (int c = tid; c < HD * 8; c += 256) {
+        const int d = c >> 3, kc = c & 7;
+        const uint4 v = *reinterpret_cast<const uint4 *>(tbase + (size_t)d * Npad + col0 + kc * 8);
+        uint2 *p = reinterpret_cast<uint2 *>(dst + d * VS + kc * 16);
+        p[0] = make_uint2(v.x, v.y);
+        p[1] = make_uint2(v.z, v.w);
+    }
+}
+
+__device__ __forceinline__ bf16x8 frag_rows(const unsigned char *tile, int row, int s, int hh)
+{
+    return *reinterpret_cast<const bf16x8 *>(tile + row * 128 + (((2 * s + hh) ^ ((row >> 1) & 7)) << 4));
+}
+
+__device__ __forceinline__ bf16x8 frag_cols(const unsigned char *tile, int d, int tokb)
+{
+    const uint2 lo = *reinterpret_cast<const uint2 *>(tile + d * VS + tokb * 2);
+    const uint2 hi = *reinterpret_cast<const uint2 *>(tile + d * VS + (tokb + 8) * 2);
+    uint4 av = make_uint4(lo.x, lo.y, hi.x, hi.y);
+    return *reinterpret_cast<bf16x8 *>(&av);
+}
+
+// prep: which = 0 (q), 1 (k) of qkv and dO  ->  qt, kt, dot [B,H,64,Npad];  delta [B,H,N]
+__global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const bf16 *__restrict__ qkv, const bf16 *__restrict__ dO,
+                                                           const bf16 *__restrict__ O, bf16 *__restrict__ qt, bf16 *__restrict__ kt,
+                                                           bf16 *__restrict__ dot, float *__restrict__ delta, int N, int Npad, int H)
+{
+    __shared__ unsigned short tile[BK][HD + 2];
+    const int b = blockIdx.z, h = blockIdx.y, t0 = blockIdx.x * BK;
+    const int tid = threadIdx.x;
+    const size_t rs = (size_t)3 * H * HD;
+#pragma unroll 1
+    for (int which = 0; which < 3; which++) {
+        __syncthreads();
+        for (int c = tid; c < BK * 8; c += 256) {
+            const int tok = c >> 3, s = c & 7;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (t0 + tok < N) {
+                const bf16 *src = which < 2 ? qkv + ((size_t)b * N + t0 + tok) * rs + (size_t)which * H * HD + h * HD + s * 8
+                                            : dO + ((size_t)b * N + t0 + tok) * H * HD + h * HD + s * 8;
+                v = *reinterpret_cast<const uint4 *>(src);
+            }
+            unsigned *dst = reinterpret_cast<unsigned *>(&tile[tok][s * 8]);
+            dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+        }
+        __syncthreads();
+        bf16 *outp = which == 0 ? qt : (which == 1 ? kt : dot);
+        for (int c = tid; c < HD * 8; c += 256) {
+            const int d = c >> 3, kc = c & 7;
+            unsigned short e[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) e[i] = tile[kc * 8 + i][d];
+            uint4 v;
+            v.x = e[0] | ((unsigned)e[1] << 16); v.y = e[2] | ((unsigned)e[3] << 16);
+            v.z = e[4] | ((unsigned)e[5] << 16); v.w = e[6] | ((unsigned)e[7] << 16);
+            *reinterpret_cast<uint4 *>(outp + (((size_t)b * H + h) * HD + d) * Npad + t0 + kc * 8) = v;
+        }
+    }
+    // delta[q] = sum_d dO[q,d] * O[q,d]: 4 lanes per token, 16 d each
+    {
+        const int tok = tid >> 2, part = tid & 3;
+        float acc = 0.f;
+        if (t0 + tok < N) {
+            const size_t o = ((size_t)b * N + t0 + tok) * H * HD + h * HD + part * 16;
+#pragma unroll
+            for (int i = 0; i < 16; i++) acc += (float)dO[o + i] * (float)O[o + i];
+        }
+        acc += __shfl_xor(acc, 1, 64);
+        acc += __shfl_xor(acc, 2, 64);
+        if (part == 0 && t0 + tok < N) delta[((size_t)b * H + h) * N + t0 + tok] = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16 *__restrict__ qkv, const bf16 *__restrict__ dO,
+                                                         const bf16 *__restrict__ kt, const float *__restrict__ lse,
+                                                         const float *__restrict__ delta, bf16 *__restrict__ dqkv,
+                                                         int N, int Npad, int H, float scale)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BK * 128 + HD * VS];
+    unsigned char *Ks = smem, *Vsr = smem + BK * 128, *Kts = smem + 2 * BK * 128;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int q0 = blockIdx.x * BQ + wave * 32;
+    const size_t rs = (size_t)3 * H * HD;
+    const int qrow = min(q0 + r, N - 1);
+    const bf16 *qp = qkv + ((size_t)b * N + qrow) * rs + h * HD + 8 * hh;
+    const bf16 *dop = dO + ((size_t)b * N + qrow) * H * HD + h * HD + 8 * hh;
+    bf16x8 qf[4], dof[4];
+#pragma unroll
+    for (int s = 0; s < 4; s++) { qf[s] = *reinterpret_cast<const bf16x8 *>(qp + 16 * s); dof[s] = *reinterpret_cast<const bf16x8 *>(dop + 16 * s); }
+    const float scale_log2e = scale * 1.4426950408889634f;
+    const float lse2 = lse[((size_t)b * H + h) * N + qrow] * 1.4426950408889634f;
+    const float dl = delta[((size_t)b * H + h) * N + qrow];
+    f32x16 g0, g1;
+#pragma unroll
+    for (int i = 0; i < 16; i++) { g0[i] = 0.f; g1[i] = 0.f; }
+    const bf16 *kbase = qkv + (size_t)b * N * rs + (size_t)H * HD + h * HD;
+    const bf16 *vbase = qkv + (size_t)b * N * rs + (size_t)2 * H * HD + h * HD;
+    const bf16 *ktbase = kt + ((size_t)b * H + h) * HD * Npad;
+
+    for (int k0 = 0; k0 < N; k0 += BK) {
+        __syncthreads();
+        stage_rows(Ks, kbase, rs, k0, N, tid);
+        stage_rows(Vsr, vbase, rs, k0, N, tid);
+        stage_cols(Kts, ktbase, Npad, k0, tid);
+        __syncthreads();
+        f32x16 s0, s1, p0, p1;
+#pragma unroll
+        for (int i = 0; i < 16; i++) { s0[i] = 0.f; s1[i] = 0.f; p0[i] = 0.f; p1[i] = 0.f; }
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Ks, r, s, hh), qf[s], s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Ks, r + 32, s, hh), qf[s], s1, 0, 0, 0);
+            p0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Vsr, r, s, hh), dof[s], p0, 0, 0, 0);
+            p1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Vsr, r + 32, s, hh), dof[s], p1, 0, 0, 0);
+        }
+        const bool tail = k0 + BK > N;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            float a = __builtin_amdgcn_exp2f(s0[i] * scale_log2e - lse2);
+            float c = __builtin_amdgcn_exp2f(s1[i] * scale_log2e - lse2);
+            if (tail) {
+                if (k0 + crow(i, hh) >= N) a = 0.f;
+                if (k0 + 32 + crow(i, hh) >= N) c = 0.f;
+            }
+            s0[i] = a * (p0[i] - dl) * scale;        // dS^T
+            s1[i] = c * (p1[i] - dl) * scale;
+        }
+#pragma unroll
+        for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+            for (int sp = 0; sp < 2; sp++) {
+                bf16x8 df;
+#pragma unroll
+                for (int j = 0; j < 8; j++) df[j] = (bf16)(kb == 0 ? s0[8 * sp + j] : s1[8 * sp + j]);
+                const int keyb = kb * 32 + 16 * sp + 4 * hh;
+                g0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(Kts, r, keyb), df, g0, 0, 0, 0);
+                g1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(Kts, r + 32, keyb), df, g1, 0, 0, 0);
+            }
+    }
+    const int q = q0 + r;
+    if (q < N) {
+        bf16 *op = dqkv + ((size_t)b * N + q) * rs + h * HD;
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            bf16x4 v0, v1;
+#pragma unroll
+            for (int j = 0; j < 4; j++) { v0[j] = (bf16)g0[4 * g + j]; v1[j] = (bf16)g1[4 * g + j]; }
+            *reinterpret_cast<bf16x4 *>(op + 8 * g + 4 * hh) = v0;
+            *reinterpret_cast<bf16x4 *>(op + 32 + 8 * g + 4 * hh) = v1;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16 *__restrict__ qkv, const bf16 *__restrict__ dO,
+                                                          const bf16 *__restrict__ qt, const bf16 *__restrict__ dot,
+                                                          const float *__restrict__ lse, const float *__restrict__ delta,
+                                                          bf16 *__restrict__ dqkv, int N, int Npad, int H, float scale)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BK * 128 + 2 * HD * VS + 2 * BK * 4];
+    unsigned char *Qs = smem, *dOs = smem + BK * 128, *Qts = smem + 2 * BK * 128, *dOts = Qts + HD * VS;
+    float *lse_s = reinterpret_cast<float *>(dOts + HD * VS);
+    float *dl_s = lse_s + BK;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int key0 = blockIdx.x * BQ + wave * 32;
+    const size_t rs = (size_t)3 * H * HD;
+    const int krow = min(key0 + r, N - 1);
+    const bf16 *kp = qkv + ((size_t)b * N + krow) * rs + (size_t)H * HD + h * HD + 8 * hh;
+    const bf16 *vp = qkv + ((size_t)b * N + krow) * rs + (size_t)2 * H * HD + h * HD + 8 * hh;
+    bf16x8 kf[4], vf[4];
+#pragma unroll
+    for (int s = 0; s < 4; s++) { kf[s] = *reinterpret_cast<const bf16x8 *>(kp + 16 * s); vf[s] = *reinterpret_cast<const bf16x8 *>(vp + 16 * s); }
+    const float scale_log2e = scale * 1.4426950408889634f;
+    f32x16 dk0, dk1, dv0, dv1;
+#pragma unroll
+    for (int i = 0; i < 16; i++) { dk0[i] = 0.f; dk1[i] = 0.f; dv0[i] = 0.f; dv1[i] = 0.f; }
+    const bf16 *qbase = qkv + (size_t)b * N * rs + h * HD;
+    const bf16 *dobase = dO + (size_t)b * N * H * HD + h * HD;
+    const bf16 *qtbase = qt + ((size_t)b * H + h) * HD * Npad;
+    const bf16 *dotbase = dot + ((size_t)b * H + h) * HD * Npad;
+    const float *lseb = lse + ((size_t)b * H + h) * N;
+    const float *dlb = delta + ((size_t)b * H + h) * N;
+
+    for (int q0 = 0; q0 < N; q0 += BK) {
+        __syncthreads();
+        stage_rows(Qs, qbase, rs, q0, N, tid);
+        stage_rows(dOs, dobase, (size_t)H * HD, q0, N, tid);
+        stage_cols(Qts, qtbase, Npad, q0, tid);
+        stage_cols(dOts, dotbase, Npad, q0, tid);
+        if (tid < BK) {
+            const int q = q0 + tid;
+            lse_s[tid] = q < N ? lseb[q] * 1.4426950408889634f : 0.f;
+            dl_s[tid] = q < N ? dlb[q] : 0.f;
+        }
+        __syncthreads();
+        // S[q][key], dP[q][key] for two 32-query blocks (rows = queries in registers, key on the lane)
+        f32x16 s0, s1, p0, p1;
+#pragma unroll
+        for (int i = 0; i < 16; i++) { s0[i] = 0.f; s1[i] = 0.f; p0[i] = 0.f; p1[i] = 0.f; }
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Qs, r, s, hh), kf[s], s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Qs, r + 32, s, hh), kf[s], s1, 0, 0, 0);
+            p0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(dOs, r, s, hh), vf[s], p0, 0, 0, 0);
+            p1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(dOs, r + 32, s, hh), vf[s], p1, 0, 0, 0);
+        }
+        const bool tail = q0 + BK > N;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int qa = crow(i, hh), qc = 32 + crow(i, hh);
+            float a = __builtin_amdgcn_exp2f(s0[i] * scale_log2e - lse_s[qa]);
+            float c = __builtin_amdgcn_exp2f(s1[i] * scale_log2e - lse_s[qc]);
+            if (tail) {
+                if (q0 + qa >= N) a = 0.f;
+                if (q0 + qc >= N) c = 0.f;
+            }
+            s0[i] = a;                                 // P
+            s1[i] = c;
+            p0[i] = a * (p0[i] - dl_s[qa]) * scale;    // dS
+            p1[i] = c * (p1[i] - dl_s[qc]) * scale;
+        }
+#pragma unroll
+        for (int qb = 0; qb < 2; qb++)
+#pragma unroll
+            for (int sp = 0; sp < 2; sp++) {
+                bf16x8 pf, df;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    pf[j] = (bf16)(qb == 0 ? s0[8 * sp + j] : s1[8 * sp + j]);
+                    df[j] = (bf16)(qb == 0 ? p0[8 * sp + j] : p1[8 * sp + j]);
+                }
+                const int tokb = qb * 32 + 16 * sp + 4 * hh;
+                dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(dOts, r, tokb), pf, dv0, 0, 0, 0);
+                dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(dOts, r + 32, tokb), pf, dv1, 0, 0, 0);
+                dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(Qts, r, tokb), df, dk0, 0, 0, 0);
+                dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(Qts, r + 32, tokb), df, dk1, 0, 0, 0);
+            }
+    }
+    const int key = key0 + r;
+    if (key < N) {
+        bf16 *okp = dqkv + ((size_t)b * N + key) * rs + (size_t)H * HD + h * HD;
+        bf16 *ovp = dqkv + ((size_t)b * N + key) * rs + (size_t)2 * H * HD + h * HD;
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            bf16x4 a0, a1, c0, c1;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                a0[j] = (bf16)dk0[4 * g + j]; a1[j] = (bf16)dk1[4 * g + j];
+                c0[j] = (bf16)dv0[4 * g + j]; c1[j] = (bf16)dv1[4 * g + j];
+            }
+            *reinterpret_cast<bf16x4 *>(okp + 8 * g + 4 * hh) = a0;
+            *reinterpret_cast<bf16x4 *>(okp + 32 + 8 * g + 4 * hh) = a1;
+            *reinterpret_cast<bf16x4 *>(ovp + 8 * g + 4 * hh) = c0;
+            *reinterpret_cast<bf16x4 *>(ovp + 32 + 8 * g + 4 * hh) = c1;
+        }
+    }
+}
+
 }  // namespace
 }  // namespace cosa
 
@@ -235,6 +525,41 @@ extern "C" int cosa_attn_fwd(const void *qkv, void *out, float *lse, int B, int 
     }
     hipLaunchKernelGGL(attn_fwd_kernel, dim3((N + BQ - 1) / BQ, H, B), dim3(256), 0, st, static_cast<const bf16 *>(qkv), vt,
                        static_cast<bf16 *>(out), lse, N, Npad, H, scale * 1.4426950408889634f);
+    COSA_LAUNCH_CHECK();
+    return COSA_OK;
+}
+
+/* backward workspace: qt | kt | dot ([B,H,64,Npad] bf16 each) | delta [B,H,N] f32 */
+extern "C" size_t cosa_attn_bwd_workspace_bytes(int B, int N, int H)
+{
+    const size_t Npad = (size_t)(N + BK - 1) / BK * BK;
+    return 3 * align_up((size_t)B * H * HD * Npad * sizeof(bf16), 256) + align_up((size_t)B * H * N * sizeof(float), 256);
+}
+
+extern "C" int cosa_attn_bwd(const void *qkv, const void *out, const void *dout, const float *lse, void *dqkv,
+                             int B, int N, int H, int head_dim, float scale, void *workspace, size_t workspace_bytes, void *stream)
+{
+    COSA_REQUIRE(qkv && out && dout && lse && dqkv && workspace, "cosa_attn_bwd: null pointer");
+    COSA_REQUIRE(head_dim == HD, "cosa_attn_bwd: head_dim must be 64");
+    COSA_REQUIRE(B > 0 && N > 0 && H > 0 && B <= 65535 && H <= 65535, "cosa_attn_bwd: bad shape");
+    if (workspace_bytes < cosa_attn_bwd_workspace_bytes(B, N, H)) {
+        set_error("cosa_attn_bwd: workspace too small");
+        return COSA_ENOMEM;
+    }
+    hipStream_t st = as_stream(stream);
+    const int Npad = (N + BK - 1) / BK * BK;
+    Carver cv(workspace);
+    bf16 *qt = cv.take<bf16>((size_t)B * H * HD * Npad);
+    bf16 *kt = cv.take<bf16>((size_t)B * H * HD * Npad);
+    bf16 *dot = cv.take<bf16>((size_t)B * H * HD * Npad);
+    float *delta = cv.take<float>((size_t)B * H * N);
+    const bf16 *q = static_cast<const bf16 *>(qkv), *o = static_cast<const bf16 *>(out), *d_o = static_cast<const bf16 *>(dout);
+    hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3(Npad / BK, H, B), dim3(256), 0, st, q, d_o, o, qt, kt, dot, delta, N, Npad, H);
+    COSA_LAUNCH_CHECK();
+    const dim3 grid((N + BQ - 1) / BQ, H, B);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, st, q, d_o, kt, lse, delta, static_cast<bf16 *>(dqkv), N, Npad, H, scale);
+    COSA_LAUNCH_CHECK();
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, st, q, d_o, qt, dot, lse, delta, static_cast<bf16 *>(dqkv), N, Npad, H, scale);
     COSA_LAUNCH_CHECK();
     return COSA_OK;
 }

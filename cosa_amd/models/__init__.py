@@ -71,7 +71,7 @@ class VITNetwork(nn.Module):
 
     def _cam(self, tok, weight, B, h, w, detach_feat, detach_w):
         """1x1 conv over tokens == tokens @ W^T; returned as fp32 NCHW [B,C,h,w] (models/__init__.py:190-192)."""
-        dt = self.compute_dtype
+        dt = tok.dtype                      # fp32 tokens (fused teacher path) keep the CAM head in fp32
         wgt = nn_ops.cast_param(weight, dt).reshape(weight.shape[0], -1)
         if detach_w:
             wgt = wgt.detach()
@@ -86,14 +86,14 @@ class VITNetwork(nn.Module):
         _C.require_cuda(x)                                            # MI355X only: there is no CPU path
         dt = self.compute_dtype
         B = x.shape[0]
-        _, tok, tok_aux = self.encoder.forward_features(x)
+        _, tok, tok_aux, tok32 = self.encoder.features_ex(x)
         p = self.encoder.patch_size
         h, w = x.shape[-2] // p, x.shape[-1] // p
         x4 = tok.reshape(B, h, w, -1).permute(0, 3, 1, 2)            # NCHW view, channels-last strides (no copy)
         seg = self.decoder.forward_nhwc(x4, dt).float().contiguous()
         if seg_only:
             return seg
-        cam = self._cam(tok, self.classifier.weight, B, h, w, detach == 'feat', detach == 'cls')
+        cam = self._cam(tok if tok32 is None else tok32, self.classifier.weight, B, h, w, detach == 'feat', detach == 'cls')
         cam_aux = self._cam(tok_aux, self.aux_classifier.weight, B, h, w, detach == 'feat', detach == 'cls')
         if detach == 'all':
             cam, cam_aux = cam.detach(), cam_aux.detach()
@@ -101,8 +101,8 @@ class VITNetwork(nn.Module):
             return cam, cam_aux
         wc = nn_ops.cast_param(self.classifier.weight, dt).reshape(self.num_classes - 1, -1)
         wa = nn_ops.cast_param(self.aux_classifier.weight, dt).reshape(self.num_classes - 1, -1)
-        cls_x4 = F.linear(self._pool(tok), wc).float()
-        cls_aux = F.linear(self._pool(tok_aux), wa).float()
+        cls_x4 = F.linear(self._pool(tok).to(dt), wc).float()
+        cls_aux = F.linear(self._pool(tok_aux).to(dt), wa).float()
         return cls_x4, cls_aux, x4, seg, cam, cam_aux
 
 

@@ -96,18 +96,27 @@ class VisionTransformer(nn.Module):
 
     # -- vit.py:283-300 ---------------------------------------------------------------------------
     def _pos_for_grid(self, h, w, dtype):
+        """bicubic resize of the 14x14 position grid (vit.py:288-291).  The resize is linear in pos_embed, so it is
+        applied as a cached [h*w,196] interpolation matrix (built once per grid with the same bicubic kernel) times
+        the current pos_embed -- the teacher's pos_embed is EMA-touched every step, so caching the RESULT would go
+        stale, and torch's bicubic kernel costs ~3 ms per call on this shape."""
         pe = self.pos_embed
-        key = (h, w, dtype, pe.device)
+        key = (h, w, pe.device)
         ent = self._pos_cache.get(key)
-        if ent is None or ent[0] != pe._version:
+        if ent is None:
+            n0 = self._size * self._size
             with torch.no_grad():
-                grid = pe[:, 1:, :].reshape(1, self._size, self._size, -1).permute(0, 3, 1, 2).float()
-                grid = F.interpolate(grid, size=(h, w), mode="bicubic", align_corners=False)
-                grid = grid.reshape(1, -1, h * w).permute(0, 2, 1)
-                full = torch.cat((pe[:, :1, :].float(), grid), dim=1).to(dtype).contiguous()
-            ent = (pe._version, full)
+                eye = torch.eye(n0, device=pe.device, dtype=torch.float32).reshape(1, n0, self._size, self._size)
+                mat = F.interpolate(eye, size=(h, w), mode="bicubic", align_corners=False).reshape(n0, h * w).t().contiguous()
+            ent = {"mat": mat, "ver": None, "val": {}}
             self._pos_cache[key] = ent
-        return ent[1]
+        if ent["ver"] != pe._version:
+            ent["ver"], ent["val"] = pe._version, {}
+        if dtype not in ent["val"]:
+            with torch.no_grad():
+                grid = ent["mat"] @ pe[0, 1:, :].float()
+                ent["val"][dtype] = torch.cat((pe[0, :1, :].float(), grid), dim=0).unsqueeze(0).to(dtype).contiguous()
+        return ent["val"][dtype]
 
     def prepare_tokens(self, x):
         B, nc, H, W = x.shape
@@ -133,8 +142,43 @@ class VisionTransformer(nn.Module):
         y = nn_ops.gelu(F.linear(y, c(blk.mlp.fc1.weight, dt), c(blk.mlp.fc1.bias, dt)))
         return x + F.linear(y, c(blk.mlp.fc2.weight, dt), c(blk.mlp.fc2.bias, dt))
 
+    # -- fused no-grad path (the teacher's 6 passes): fp32 residual stream, HIP GEMM/LN/attention kernels -------
+    def _forward_features_fused(self, x):
+        tok, h, w = self.prepare_tokens(x)                      # bf16 [B,N,768]
+        B, N, D = tok.shape
+        c = lambda p_: nn_ops.cast_param(p_, torch.bfloat16)
+        xr = tok.float().reshape(B * N, D).contiguous()          # fp32 residual stream
+        depth = len(self.blocks)
+        aux_idx = self.aux_layer % depth
+        aux = None
+        for i, blk in enumerate(self.blocks):
+            y, _ = nn_ops.layernorm_f32(xr, c(blk.norm1.weight), c(blk.norm1.bias), blk.norm1.eps)
+            qkv = nn_ops.gemm_bf16(y, c(blk.attn.qkv.weight), c(blk.attn.qkv.bias), nn_ops.EPI_BIAS)
+            o, _ = nn_ops._attn_fwd(qkv.view(B, N, 3 * D), B, N, self.num_heads)
+            nn_ops.gemm_bf16(o.view(B * N, D), c(blk.attn.proj.weight), c(blk.attn.proj.bias), nn_ops.EPI_RESIDUAL, residual=xr,
+                             out=xr)
+            y, _ = nn_ops.layernorm_f32(xr, c(blk.norm2.weight), c(blk.norm2.bias), blk.norm2.eps)
+            hmid = nn_ops.gemm_bf16(y, c(blk.mlp.fc1.weight), c(blk.mlp.fc1.bias), nn_ops.EPI_GELU)
+            nn_ops.gemm_bf16(hmid, c(blk.mlp.fc2.weight), c(blk.mlp.fc2.bias), nn_ops.EPI_RESIDUAL, residual=xr, out=xr)
+            if i == aux_idx and aux_idx != depth - 1:
+                aux = xr.clone()
+        xn16, xn32 = nn_ops.layernorm_f32(xr, c(self.norm.weight), c(self.norm.bias), self.norm.eps, True, True)
+        if aux is None:
+            aux = xn32
+        xn16, xn32, aux = xn16.view(B, N, D), xn32.view(B, N, D), aux.view(B, N, D)
+        return xn32[:, 0], xn16[:, 1:], aux[:, 1:], xn32[:, 1:]
+
+    def use_fused(self, x):
+        return (not torch.is_grad_enabled()) and self.compute_dtype == torch.bfloat16 and x.is_cuda and self.embed_dim == 768
+
     # -- vit.py:302-321: returns cls token, final tokens, aux-layer tokens (pre final norm unless aux is the last) --
     def forward_features(self, x):
+        return self.features_ex(x)[:3]
+
+    def features_ex(self, x):
+        """-> (cls, tokens, aux tokens, fp32 tokens or None).  No-grad bf16 passes take the fused HIP path."""
+        if self.use_fused(x):
+            return self._forward_features_fused(x)
         x, h, w = self.prepare_tokens(x)
         depth = len(self.blocks)
         aux_idx = self.aux_layer % depth
@@ -148,7 +192,7 @@ class VisionTransformer(nn.Module):
                          self.norm.eps)
         if aux_idx == depth - 1:
             aux = x
-        return x[:, 0], x[:, 1:], aux[:, 1:]
+        return x[:, 0], x[:, 1:], aux[:, 1:], None
 
 
 def vit_base_patch16_224(pretrained=False, **kwargs):

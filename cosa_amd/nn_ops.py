@@ -35,9 +35,8 @@ def _attn_fwd(qkv, B, N, H):
 class FusedAttention(Function):
     """softmax(q k^T / sqrt(64)) v over packed qkv [B,N,3*H*64] (bf16) -> [B,N,H*64].
 
-    Forward is the LDS-tiled MFMA kernel (cosa_attn_fwd).  Backward recomputes P from the saved
-    log-sum-exp per head with batched GEMMs (rocBLAS/hipBLASLt) -- the student pass is 3 % of the
-    step's attention FLOPs; a fused backward kernel is the next kernel on the list."""
+    Forward is the LDS-tiled MFMA kernel (cosa_attn_fwd); backward is the pair of MFMA kernels behind
+    cosa_attn_bwd (P recomputed from the saved log-sum-exp, nothing of size N^2 in HBM, no atomics)."""
 
     @staticmethod
     def forward(ctx, qkv, H):
@@ -54,21 +53,14 @@ class FusedAttention(Function):
         qkv, out, lse = ctx.saved_tensors
         H = ctx.H
         B, N, _ = qkv.shape
-        q, k, v = qkv.view(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)          # [B,H,N,64] views
-        do = dout.reshape(B, N, H, 64).permute(0, 2, 1, 3)
-        o = out.view(B, N, H, 64).permute(0, 2, 1, 3)
-        s = torch.matmul(q, k.transpose(-1, -2)).float().mul_(0.125)        # [B,H,N,N]
-        p = torch.exp(s - lse.unsqueeze(-1))
-        del s
-        delta = (do.float() * o.float()).sum(-1, keepdim=True)
-        pb = p.to(torch.bfloat16)
-        dv = torch.matmul(pb.transpose(-1, -2), do)
-        dp = torch.matmul(do, v.transpose(-1, -2)).float()
-        ds = (p * (dp - delta)).mul_(0.125).to(torch.bfloat16)
-        del p, dp
-        dq = torch.matmul(ds, k)
-        dk = torch.matmul(ds.transpose(-1, -2), q)
-        dqkv = torch.stack([dq, dk, dv], 0).permute(1, 3, 0, 2, 4).reshape(B, N, 3 * H * 64)
+        dout = dout.contiguous()
+        dqkv = torch.empty_like(qkv)
+        L = _C.lib()
+        ws = _C.workspace(L.cosa_attn_bwd_workspace_bytes(B, N, H), qkv.device, "attn_bwd")
+        with _C.profiled("attn_bwd"):
+            _C.check(L.cosa_attn_bwd(_C.ptr(qkv), _C.ptr(out), _C.ptr(dout), _C.ptr(lse), _C.ptr(dqkv), B, N, H, 64, 0.125,
+                                     _C.ptr(ws), ws.numel(), _C.stream_ptr()), "cosa_attn_bwd")
+        _flops["attn_bwd"] = _flops.get("attn_bwd", 0) + 10.0 * B * H * N * N * 64
         return dqkv, None
 
 
@@ -80,6 +72,35 @@ def attention(qkv, H):
     q, k, v = qkv.view(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
     att = torch.matmul(q, k.transpose(-1, -2)) * 0.125
     return torch.matmul(att.softmax(-1), v).transpose(1, 2).reshape(B, N, H * 64)
+
+
+# --------------------------------------------------------------------------------------------
+# fused projections / LayerNorm (inference-side: the teacher's six passes per step)
+# --------------------------------------------------------------------------------------------
+EPI_BIAS, EPI_GELU, EPI_RESIDUAL = 0, 1, 2
+
+
+def gemm_bf16(x, w, b, epilogue=EPI_BIAS, residual=None, out=None):
+    """x [M,K] bf16, w [N,K] bf16, b [N] bf16 -> [M,N] (bf16, or fp32 for the residual epilogue; may be in place)."""
+    M, K = x.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty((M, N), device=x.device, dtype=torch.float32 if epilogue == EPI_RESIDUAL else torch.bfloat16)
+    with _C.profiled("gemm_bf16"):
+        _C.check(_C.lib().cosa_gemm_bf16(_C.ptr(x), _C.ptr(w), _C.ptr(b), _C.ptr(residual), _C.ptr(out), M, N, K, epilogue,
+                                         _C.stream_ptr()), "cosa_gemm_bf16")
+    _flops["gemm_bf16"] = _flops.get("gemm_bf16", 0) + 2.0 * M * N * K
+    return out
+
+
+def layernorm_f32(x, g, b, eps, want_bf16=True, want_f32=False):
+    """x [rows,768] fp32 -> (bf16 | None, fp32 | None)"""
+    rows, D = x.shape
+    y16 = torch.empty((rows, D), device=x.device, dtype=torch.bfloat16) if want_bf16 else None
+    y32 = torch.empty((rows, D), device=x.device, dtype=torch.float32) if want_f32 else None
+    _C.check(_C.lib().cosa_layernorm(_C.ptr(x), _C.ptr(g), _C.ptr(b), _C.ptr(y16), _C.ptr(y32), rows, D, float(eps),
+                                     _C.stream_ptr()), "cosa_layernorm")
+    return y16, y32
 
 
 # --------------------------------------------------------------------------------------------

@@ -128,6 +128,28 @@ int cosa_attn_prepare_vt(const void *qkv, int B, int N, int H, void *workspace, 
 int cosa_attn_fwd(const void *qkv, void *out, float *lse, int B, int N, int H, int head_dim, float scale,
                   int flags, void *workspace, size_t workspace_bytes, void *stream);
 
+/* Backward of the same attention (autograd of vit.py:128-134): dqkv [B,N,3,H,64] bf16 from
+ * dout [B,N,H*64]; P is recomputed from lse, nothing of size N^2 touches HBM; no atomics
+ * (one kernel owns query blocks for dQ, one owns key blocks for dK/dV).                       */
+size_t cosa_attn_bwd_workspace_bytes(int B, int N, int H);
+int cosa_attn_bwd(const void *qkv, const void *out, const void *dout, const float *lse, void *dqkv,
+                  int B, int N, int H, int head_dim, float scale, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * models/vit/vit.py:96-102,119-137,154-158  the nn.Linear projections of a ViT block with their
+ * element-wise tails fused:   Y = X[M,K] * W[N,K]^T + bias[N]   (bf16 operands, fp32 accumulate)
+ *   epilogue 0: Y bf16                      (attn.qkv)
+ *   epilogue 1: Y bf16 = gelu_erf(.)        (mlp.fc1 + nn.GELU)
+ *   epilogue 2: Y fp32 = residual fp32 + .  (attn.proj / mlp.fc2 + the block's residual add;
+ *                                            Y may alias residual)
+ *   N % 128 == 0, K % 64 == 0.
+ * cosa_layernorm: nn.LayerNorm(768, eps) over the fp32 residual stream -> bf16 (and/or fp32).
+ * ------------------------------------------------------------------------------------- */
+int cosa_gemm_bf16(const void *X, const void *W, const void *bias, const float *residual, void *Y,
+                   int M, int N, int K, int epilogue, void *stream);
+int cosa_layernorm(const float *x, const void *gamma, const void *beta, void *y_bf16, float *y_f32,
+                   int rows, int dim, float eps, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
