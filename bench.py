@@ -85,12 +85,12 @@ def main():
         dist.init_process_group("nccl", device_id=dev)          # "nccl" == RCCL on ROCm
 
     from cosa_amd import _C, nn_ops
-    from cosa_amd.train_step import CoSATrainer, default_args, synthetic_batch
+    from cosa_amd.train_step import CoSATrainer, default_args, rank_seed, synthetic_batch
 
     C = 20 if opt.dataset == "VOC12" else 80
     args = default_args(opt.dataset, crop_size=opt.crop, batch_size=opt.batch, usepar=opt.usepar)
     trainer = CoSATrainer(args, dev, ddp=world > 1, seed=0)
-    wimg, simg, lab, box = synthetic_batch(opt.batch, opt.crop, C, dev, seed=1234 + rank, dataset=opt.dataset)
+    wimg, simg, lab, box = synthetic_batch(opt.batch, opt.crop, C, dev, seed=rank_seed(1234, rank), dataset=opt.dataset)
     n_iter = args.warmup_iters + 1            # post-warm-up: all five losses are live
 
     def sync():

@@ -87,26 +87,30 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16 *__restrict__ 
     const bf16 *vbase = vt + ((size_t)b * H + h) * HD * Npad;
     const int swz = (r >> 1) & 7;
 
+    // register-staged software pipeline: the next tile's global loads are in flight while this tile computes
+    uint4 kreg0, kreg1, vreg0, vreg1;
+    const int row_a = tid >> 3, row_b = (tid + 256) >> 3, slot_s = tid & 7;     // chunk -> (row, 16-B slot)
+#define COSA_LOAD_TILE(K0)                                                                                           \
+    do {                                                                                                             \
+        kreg0 = *reinterpret_cast<const uint4 *>(kbase + (size_t)min((K0) + row_a, N - 1) * rs + slot_s * 8);       \
+        kreg1 = *reinterpret_cast<const uint4 *>(kbase + (size_t)min((K0) + row_b, N - 1) * rs + slot_s * 8);       \
+        vreg0 = *reinterpret_cast<const uint4 *>(vbase + (size_t)row_a * Npad + (K0) + slot_s * 8);                  \
+        vreg1 = *reinterpret_cast<const uint4 *>(vbase + (size_t)row_b * Npad + (K0) + slot_s * 8);                  \
+    } while (0)
+    COSA_LOAD_TILE(0);
+    const float NEG_INF = -INFINITY;
     for (int k0 = 0; k0 < N; k0 += BK) {
         __syncthreads();
-        // stage K tile [64 keys][64 d], 16-B slots XOR-swizzled by (key>>1)&7 (conflict-free ds_read_b128)
-#pragma unroll
-        for (int c = tid; c < BK * 8; c += 256) {
-            const int key = c >> 3, s = c & 7;
-            const int gk = min(k0 + key, N - 1);
-            const uint4 v = *reinterpret_cast<const uint4 *>(kbase + (size_t)gk * rs + s * 8);
-            *reinterpret_cast<uint4 *>(Ks + key * 128 + ((s ^ ((key >> 1) & 7)) << 4)) = v;
-        }
-        // stage V^T tile [64 d][64 keys] (already transposed + zero padded in global memory)
-#pragma unroll
-        for (int c = tid; c < HD * 8; c += 256) {
-            const int d = c >> 3, kc = c & 7;
-            const uint4 v = *reinterpret_cast<const uint4 *>(vbase + (size_t)d * Npad + k0 + kc * 8);
-            uint2 *dst = reinterpret_cast<uint2 *>(Vs + d * VS + kc * 16);
-            dst[0] = make_uint2(v.x, v.y);
-            dst[1] = make_uint2(v.z, v.w);
+        *reinterpret_cast<uint4 *>(Ks + row_a * 128 + ((slot_s ^ ((row_a >> 1) & 7)) << 4)) = kreg0;
+        *reinterpret_cast<uint4 *>(Ks + row_b * 128 + ((slot_s ^ ((row_b >> 1) & 7)) << 4)) = kreg1;
+        {
+            uint2 *d0 = reinterpret_cast<uint2 *>(Vs + row_a * VS + slot_s * 16);
+            d0[0] = make_uint2(vreg0.x, vreg0.y); d0[1] = make_uint2(vreg0.z, vreg0.w);
+            uint2 *d1 = reinterpret_cast<uint2 *>(Vs + row_b * VS + slot_s * 16);
+            d1[0] = make_uint2(vreg1.x, vreg1.y); d1[1] = make_uint2(vreg1.z, vreg1.w);
         }
         __syncthreads();
+        if (k0 + BK < N) COSA_LOAD_TILE(k0 + BK);
 
         // S^T[key][query] for two 32-key blocks
         f32x16 s0, s1;
@@ -120,33 +124,34 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16 *__restrict__ 
             s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, qf[s], s0, 0, 0, 0);
             s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, qf[s], s1, 0, 0, 0);
         }
-        // scale (log2 domain), mask the key tail, online softmax with the query on the lane
-        float mt = -INFINITY;
-        const bool tail = k0 + BK > N;
+        // online softmax with the query on the lane; raw-score max, scale folded into the exp2 argument (one fma)
+        if (k0 + BK > N) {
 #pragma unroll
-        for (int i = 0; i < 16; i++) {
-            float a = s0[i] * scale_log2e, c = s1[i] * scale_log2e;
-            if (tail) {
-                if (k0 + crow(i, hh) >= N) a = -INFINITY;
-                if (k0 + 32 + crow(i, hh) >= N) c = -INFINITY;
+            for (int i = 0; i < 16; i++) {
+                if (k0 + crow(i, hh) >= N) s0[i] = NEG_INF;
+                if (k0 + 32 + crow(i, hh) >= N) s1[i] = NEG_INF;
             }
-            s0[i] = a; s1[i] = c;
-            mt = fmaxf(mt, fmaxf(a, c));
         }
+        float mt = fmaxf(s0[0], s1[0]);
+#pragma unroll
+        for (int i = 1; i < 16; i++) mt = fmaxf(mt, fmaxf(s0[i], s1[i]));
         mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-        const float mnew = fmaxf(m, mt);
-        const float alpha = __builtin_amdgcn_exp2f(m - mnew);
-        m = mnew;
+        const float mnew = fmaxf(m, mt * scale_log2e);
+        if (__any(mnew != m)) {                       // wave-uniform: rescale only when some row's max moved
+            const float alpha = __builtin_amdgcn_exp2f(m - mnew);
+            l *= alpha;
+#pragma unroll
+            for (int i = 0; i < 16; i++) { o0[i] *= alpha; o1[i] *= alpha; }
+            m = mnew;
+        }
         float ls = 0.f;
 #pragma unroll
         for (int i = 0; i < 16; i++) {
-            s0[i] = __builtin_amdgcn_exp2f(s0[i] - mnew);
-            s1[i] = __builtin_amdgcn_exp2f(s1[i] - mnew);
+            s0[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[i], scale_log2e, -m));
+            s1[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[i], scale_log2e, -m));
             ls += s0[i] + s1[i];
         }
-        l = l * alpha + ls;
-#pragma unroll
-        for (int i = 0; i < 16; i++) { o0[i] *= alpha; o1[i] *= alpha; }
+        l += ls;
 
         // O^T[d][query] += V^T[d][key] P^T[key][query]; the exponentiated accumulators ARE the B operand
 #pragma unroll
@@ -172,6 +177,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16 *__restrict__ 
             }
         }
     }
+#undef COSA_LOAD_TILE
     // finish: combine the two half-lane partial sums, normalise, store O (d = db*32 + crow(i,hh)) and LSE
     l += __shfl_xor(l, 32, 64);
     const float inv = 1.0f / l;

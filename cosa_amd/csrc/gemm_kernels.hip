@@ -30,7 +30,22 @@ constexpr int CT_LD = 272;                        // bytes per row of the epilog
 
 enum { EPI_BIAS = 0, EPI_GELU = 1, EPI_RESIDUAL = 2 };
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// erf-GELU (nn.GELU default).  erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, far below bf16 resolution) on the
+// hardware exp2 / rcp units: ~14 VALU ops instead of libm erff's ~40 with branches.
+__device__ __forceinline__ float gelu_erf(float x)
+{
+    const float z = __builtin_fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.0f));
+    float p = __builtin_fmaf(1.061405429f, t, -1.453152027f);
+    p = __builtin_fmaf(p, t, 1.421413741f);
+    p = __builtin_fmaf(p, t, -0.284496736f);
+    p = __builtin_fmaf(p, t, 0.254829592f);
+    p = p * t;
+    const float e = __builtin_amdgcn_exp2f(-z * z * 1.4426950408889634f);
+    const float erf_abs = __builtin_fmaf(-p, e, 1.0f);
+    const float erfx = __builtin_copysignf(erf_abs, x);
+    return 0.5f * x * (1.0f + erfx);
+}
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;

@@ -92,9 +92,10 @@ __device__ __forceinline__ float block_max(float v, float *sh)
 }
 
 // one 1024-thread block per (b,c) plane; float4 path when HW % 4 == 0
-__global__ __launch_bounds__(1024) void minmax_norm_kernel(float *__restrict__ cam, int HW)
+__global__ __launch_bounds__(1024) void minmax_norm_kernel(float *__restrict__ cam, int HW, const float *__restrict__ active)
 {
     __shared__ float sh[16];
+    if (active && active[blockIdx.x] == 0.0f) return;   // all-zero plane stays all-zero
     float *x = cam + (size_t)blockIdx.x * HW;
     float mneg = -INFINITY;
     if ((HW & 3) == 0) {
@@ -135,12 +136,16 @@ __global__ __launch_bounds__(1024) void minmax_norm_kernel(float *__restrict__ c
 // thread per output pixel; grid (ceil(S*S/256), C, B)
 __global__ __launch_bounds__(256) void flip_merge_upsample_kernel(const float *__restrict__ src, float *__restrict__ dst,
                                                                  int B, int C, int h, int w, int S, float sy, float sx,
-                                                                 int mode, int accumulate)
+                                                                 int mode, int accumulate, const float *__restrict__ active)
 {
     const int pix = blockIdx.x * 256 + threadIdx.x;
     if (pix >= S * S) return;
     const int Y = pix / S, X = pix - Y * S;
     const int c = blockIdx.y, b = blockIdx.z;
+    if (active && active[b * C + c] == 0.0f) {          // class absent from the image: cam_validation zeroes it anyway
+        if (!accumulate) dst[((size_t)b * C + c) * S * S + pix] = 0.0f;
+        return;
+    }
     int y0, y1, x0, x1, fx0, fx1;
     float ly0, ly1, lx0, lx1, flx0, flx1;
     src_index(Y, h, S, sy, y0, y1, ly0, ly1);
@@ -309,16 +314,16 @@ extern "C" int cosa_denormalize_img(const float *img, float *out, int B, int H, 
     return COSA_OK;
 }
 
-extern "C" int cosa_cam_minmax_norm(float *cam, int BC, int HW, void *stream)
+extern "C" int cosa_cam_minmax_norm(float *cam, int BC, int HW, const float *active, void *stream)
 {
     COSA_REQUIRE(cam && BC > 0 && HW > 0, "cosa_cam_minmax_norm: bad arguments");
-    hipLaunchKernelGGL(minmax_norm_kernel, dim3(BC), dim3(1024), 0, as_stream(stream), cam, HW);
+    hipLaunchKernelGGL(minmax_norm_kernel, dim3(BC), dim3(1024), 0, as_stream(stream), cam, HW, active);
     COSA_LAUNCH_CHECK();
     return COSA_OK;
 }
 
 extern "C" int cosa_cam_flip_merge_upsample(const float *src, float *dst, int B, int C, int h, int w, int S,
-                                            int mode, int accumulate, void *stream)
+                                            int mode, int accumulate, const float *active, void *stream)
 {
     COSA_REQUIRE(src && dst && B > 0 && C > 0 && h > 0 && w > 0 && S > 0, "cosa_cam_flip_merge_upsample: bad arguments");
     COSA_REQUIRE(mode == 0 || mode == 1, "cosa_cam_flip_merge_upsample: mode must be 0 or 1");
@@ -326,7 +331,7 @@ extern "C" int cosa_cam_flip_merge_upsample(const float *src, float *dst, int B,
     const float sy = (float)h / (float)S, sx = (float)w / (float)S;
     dim3 grid((S * S + 255) / 256, C, B);
     hipLaunchKernelGGL(flip_merge_upsample_kernel, grid, dim3(256), 0, as_stream(stream), src, dst, B, C, h, w, S, sy, sx,
-                       mode, accumulate);
+                       mode, accumulate, active);
     COSA_LAUNCH_CHECK();
     return COSA_OK;
 }

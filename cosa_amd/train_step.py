@@ -42,6 +42,18 @@ def default_args(dataset="VOC12", **over):
     return SimpleNamespace(**a)
 
 
+def wrap_ddp(module, device):
+    """Student-only DDP (main.py:49-50): RCCL all-reduce of ~92.5 M fp32 grads, 64 MB buckets as gradient views,
+    overlapped with backward.  find_unused_parameters is not needed (the dead encoder.head is frozen)."""
+    ids = [device.index] if device.type == "cuda" else None
+    return torch.nn.parallel.DistributedDataParallel(module, device_ids=ids, gradient_as_bucket_view=True, bucket_cap_mb=64)
+
+
+def rank_seed(base, rank):
+    """per-rank synthetic-data seed (SURVEY d-2): distinct shards, no data-path collective"""
+    return base + rank
+
+
 class CoSATrainer:
     def __init__(self, args, device, ddp=False, seed=0):
         self.args = args
@@ -59,8 +71,7 @@ class CoSATrainer:
         groups = self.model_ON.get_param_groups()
         self.student = self.model_ON
         if ddp:
-            self.model_ON = torch.nn.parallel.DistributedDataParallel(
-                self.model_ON, device_ids=[device.index], gradient_as_bucket_view=True, bucket_cap_mb=64)
+            self.model_ON = wrap_ddp(self.model_ON, device)
         self.optimizer = torch_helper.PolyWarmupAdamW(
             params=[
                 {'params': [p for p in groups[0] if p.requires_grad], 'lr': args.lr, 'weight_decay': args.wt_dec},
@@ -79,7 +90,8 @@ class CoSATrainer:
     def forward_losses(self, wimg, simg, cls_label, img_box, n_iter):
         args = self.args
         img_denorm = torch_helper.denormalize_img(simg) if self.refine_model is not None else simg
-        cam_ps, cam_aux_ps, seg_ps = seg_helper.multi_scale_camseg(self.model_AN, wimg, args.pseudo_scales)
+        cam_ps, cam_aux_ps, seg_ps = seg_helper.multi_scale_camseg(self.model_AN, wimg, args.pseudo_scales,
+                                                                   _active_labels=None if args.use_cammix else cls_label)
         cls_final, cls_aux, _feat, seg_pred, cam_pred, cam_aux_pred = self.model_ON(simg, cam_only=False, detach=args.detach)
         cls_loss = F.multilabel_soft_margin_loss(cls_final, cls_label)
         cls_loss_aux = F.multilabel_soft_margin_loss(cls_aux, cls_label)

@@ -14,32 +14,35 @@ from ..models.PAR import PAR
 # --------------------------------------------------------------------------------------------
 # multi_scale_camseg  (utils/seg_helper.py:232-275)
 # --------------------------------------------------------------------------------------------
-def _flip_merge_upsample(src, dst, B, S, mode, accumulate):
+def _flip_merge_upsample(src, dst, B, S, mode, accumulate, active=None):
     src = src.contiguous().float()
     _, C, h, w = src.shape
     _C.check(_C.lib().cosa_cam_flip_merge_upsample(_C.ptr(src), _C.ptr(dst), B, C, h, w, S, mode, int(accumulate),
-                                                   _C.stream_ptr()), "cosa_cam_flip_merge_upsample")
+                                                   _C.ptr(active), _C.stream_ptr()), "cosa_cam_flip_merge_upsample")
 
 
-def cam_minmax_norm_(cam):
+def cam_minmax_norm_(cam, active=None):
     """In place x -= min; x /= max + 1e-5 per (b,c) plane (utils/seg_helper.py:265-266,269-270)."""
     b, c, h, w = cam.shape
-    _C.check(_C.lib().cosa_cam_minmax_norm(_C.ptr(cam), b * c, h * w, _C.stream_ptr()), "cosa_cam_minmax_norm")
+    _C.check(_C.lib().cosa_cam_minmax_norm(_C.ptr(cam), b * c, h * w, _C.ptr(active), _C.stream_ptr()), "cosa_cam_minmax_norm")
     return cam
 
 
-def multi_scale_camseg(model, imgs, scales):
+def multi_scale_camseg(model, imgs, scales, _active_labels=None):
     """Teacher forward over scales x {orig, flip}; returns (cam, cam_aux, seg) at input size.
 
     utils/seg_helper.py:232-275.  Per scale one fused kernel does bilinear-up + un-flip + max/sum
     (+ReLU) + accumulation; the reference's quirk that cam_aux keeps ONLY the last scale
-    (`cam_aux_list = [...]`, :258) is reproduced.
+    (`cam_aux_list = [...]`, :258) is reproduced.  `_active_labels` ([b,C] image-level labels, optional): the CAM
+    planes of absent classes are returned as zeros -- exactly what cam_validation makes of them in the very next
+    call of the training loop (main.py:137) -- so the tail only touches the 1-4 live planes per image.
     """
     b, c, h, w = imgs.shape
     assert 1.0 in scales, 'scale 1.0 must be in scales'
     assert h == w, "square crops only"
     _C.require_cuda(imgs)
     cam = cam_aux = seg = None
+    act = _active_labels.contiguous().float() if _active_labels is not None else None
     with torch.no_grad():
         for si, s in enumerate(scales):
             if s != 1.0:
@@ -52,11 +55,12 @@ def multi_scale_camseg(model, imgs, scales):
                 cam = torch.empty((b, _cam.shape[1], h, w), device=imgs.device, dtype=torch.float32)
                 cam_aux = torch.empty_like(cam)
                 seg = torch.empty((b, _seg.shape[1], h, w), device=imgs.device, dtype=torch.float32)
-            _flip_merge_upsample(_cam, cam, b, h, 0, si > 0)
-            _flip_merge_upsample(_cam_aux, cam_aux, b, h, 0, False)     # last scale wins (:258)
+            _flip_merge_upsample(_cam, cam, b, h, 0, si > 0, act)
+            if si == len(scales) - 1:                                   # only the last scale survives (:258)
+                _flip_merge_upsample(_cam_aux, cam_aux, b, h, 0, False, act)
             _flip_merge_upsample(_seg, seg, b, h, 1, si > 0)
-        cam_minmax_norm_(cam)
-        cam_minmax_norm_(cam_aux)
+        cam_minmax_norm_(cam, act)
+        cam_minmax_norm_(cam_aux, act)
     return cam, cam_aux, seg
 
 

@@ -39,9 +39,9 @@ int cosa_denormalize_img(const float *img, float *out, int B, int H, int W, void
 
 /* ---------------------------------------------------------------------------------------
  * utils/seg_helper.py:264-270  per-(b,c) plane  x -= min(x); x /= max(x) + 1e-5  (in place)
- *   cam [BC, HW]
+ *   cam [BC, HW]; `active` (optional, [BC]): planes whose entry is 0 are known all-zero and skipped
  * ------------------------------------------------------------------------------------- */
-int cosa_cam_minmax_norm(float *cam, int BC, int HW, void *stream);
+int cosa_cam_minmax_norm(float *cam, int BC, int HW, const float *active /* [BC] or NULL */, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * utils/seg_helper.py:252-270  fused tail of multi_scale_camseg for ONE scale:
@@ -50,9 +50,11 @@ int cosa_cam_minmax_norm(float *cam, int BC, int HW, void *stream);
  *          mode 1: up[:b] + flip_w(up[b:])                    (seg,           :260-262)
  *   dst  = accumulate ? dst + v : v                           (sum over scales, :264,273)
  *   src [2*B, C, h, w]   dst [B, C, S, S]
+ *   active (optional, the image-level labels): channels with active[b,c]==0 are written as 0 --
+ *   what cam_validation (:547-551) makes of them one call later -- and cost nothing.
  * ------------------------------------------------------------------------------------- */
 int cosa_cam_flip_merge_upsample(const float *src, float *dst, int B, int C, int h, int w, int S,
-                                 int mode, int accumulate, void *stream);
+                                 int mode, int accumulate, const float *active /* [B,C] or NULL */, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * utils/seg_helper.py:721-797  cam2mask (+ _refine_cams), with cam_validation (:547-551)

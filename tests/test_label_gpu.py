@@ -220,4 +220,4 @@ def test_errors_are_loud():
         seg_helper.cam2mask(torch.zeros(1, 3, 8, 8, device="cuda"), torch.tensor([[0, 8, 0, 8]]), torch.zeros(1, 2, 8, 8, device="cuda"),
                             torch.ones(1, 2, device="cuda"), 0.7, 0.25, refine_model=lambda a, b: b)
     with pytest.raises(_C.CosaError):
-        _C.check(_C.lib().cosa_cam_minmax_norm(None, 0, 0, None), "bad call")
+        _C.check(_C.lib().cosa_cam_minmax_norm(None, 0, 0, None, None), "bad call")
