@@ -48,8 +48,8 @@ _SIGS = {
     "cosa_gemm_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "cosa_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     "cosa_attn_prepare_vt": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
-    "cosa_attn_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p, c_size_t,
-                      c_void_p]),
+    "cosa_attn_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p,
+                      c_size_t, c_void_p]),
 }
 
 # entry points added by later translation units register themselves here (vit / gemm / attention)

@@ -61,9 +61,13 @@ __global__ __launch_bounds__(256) void attn_vt_kernel(const bf16 *__restrict__ q
 // ---- forward -----------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16 *__restrict__ qkv, const bf16 *__restrict__ vt,
                                                       bf16 *__restrict__ out, float *__restrict__ lse,
-                                                      int N, int Npad, int H, float scale_log2e)
+                                                      int N, int Npad, int H, float scale_log2e,
+                                                      unsigned long long *__restrict__ stamps)
 {
     __shared__ __attribute__((aligned(16))) unsigned char smem[BK * 128 + HD * VS];
+    // optional device-side span of this launch (100 MHz wall clock): min start / max end over workgroups.
+    // HIP events cannot be recorded inside a captured hipGraph on ROCm, so bench.py reads these instead.
+    if (stamps && threadIdx.x == 0) atomicMin(&stamps[0], __builtin_amdgcn_s_memrealtime());
     unsigned char *Ks = smem;
     unsigned char *Vs = smem + BK * 128;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
@@ -193,6 +197,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16 *__restrict__ 
             *reinterpret_cast<bf16x4 *>(op + 32 + 8 * g + 4 * hh) = v1;
         }
         if (hh == 0) lse[((size_t)b * H + h) * N + q] = (m + __builtin_amdgcn_logf(l)) * 0.6931471805599453f;
+    }
+    if (stamps) {
+        __syncthreads();
+        if (threadIdx.x == 0) atomicMax(&stamps[1], __builtin_amdgcn_s_memrealtime());
     }
 }
 
@@ -513,7 +521,7 @@ extern "C" int cosa_attn_prepare_vt(const void *qkv, int B, int N, int H, void *
 }
 
 extern "C" int cosa_attn_fwd(const void *qkv, void *out, float *lse, int B, int N, int H, int head_dim, float scale,
-                             int flags, void *workspace, size_t workspace_bytes, void *stream)
+                             int flags, uint64_t *stamps, void *workspace, size_t workspace_bytes, void *stream)
 {
     COSA_REQUIRE(qkv && out && lse && workspace, "cosa_attn_fwd: null pointer");
     COSA_REQUIRE(head_dim == HD, "cosa_attn_fwd: head_dim must be 64");
@@ -530,7 +538,8 @@ extern "C" int cosa_attn_fwd(const void *qkv, void *out, float *lse, int B, int 
         COSA_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(attn_fwd_kernel, dim3((N + BQ - 1) / BQ, H, B), dim3(256), 0, st, static_cast<const bf16 *>(qkv), vt,
-                       static_cast<bf16 *>(out), lse, N, Npad, H, scale * 1.4426950408889634f);
+                       static_cast<bf16 *>(out), lse, N, Npad, H, scale * 1.4426950408889634f,
+                       reinterpret_cast<unsigned long long *>(stamps));
     COSA_LAUNCH_CHECK();
     return COSA_OK;
 }

@@ -108,15 +108,11 @@ class VisionTransformer(nn.Module):
             with torch.no_grad():
                 eye = torch.eye(n0, device=pe.device, dtype=torch.float32).reshape(1, n0, self._size, self._size)
                 mat = F.interpolate(eye, size=(h, w), mode="bicubic", align_corners=False).reshape(n0, h * w).t().contiguous()
-            ent = {"mat": mat, "ver": None, "val": {}}
+            ent = {"mat": mat}
             self._pos_cache[key] = ent
-        if ent["ver"] != pe._version:
-            ent["ver"], ent["val"] = pe._version, {}
-        if dtype not in ent["val"]:
-            with torch.no_grad():
-                grid = ent["mat"] @ pe[0, 1:, :].float()
-                ent["val"][dtype] = torch.cat((pe[0, :1, :].float(), grid), dim=0).unsqueeze(0).to(dtype).contiguous()
-        return ent["val"][dtype]
+        with torch.no_grad():      # three tiny kernels; recomputed every pass so a captured graph never holds a stale value
+            grid = ent["mat"] @ pe[0, 1:, :].float()
+            return torch.cat((pe[0, :1, :].float(), grid), dim=0).unsqueeze(0).to(dtype)
 
     def prepare_tokens(self, x):
         B, nc, H, W = x.shape

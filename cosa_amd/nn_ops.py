@@ -4,6 +4,7 @@ Every op here is an explicit torch.autograd.Function around C-ABI calls (no trac
 Triton).  Plain library GEMMs (F.linear -> hipBLASLt) are used only where a bare GEMM is all
 there is to do; everything fused or attention-shaped is hand-written HIP.
 """
+import ctypes
 import math
 
 import torch
@@ -19,16 +20,52 @@ from . import _C
 _flops = {}   # algorithmic FLOPs issued per profiled kernel (read by bench.py)
 
 
+class KernelStamps:
+    """Device-side launch spans for the dominant kernel (bench.py's roofline leg).
+
+    HIP events cannot be recorded inside a captured hipGraph on ROCm ("External events are disallowed"), so the attention
+    forward kernel can stamp the 100 MHz device wall clock itself: min start / max end over its workgroups, into a slot
+    fixed at launch-issue (= capture) time.  `reset()` is a device op, so it is captured too and re-arms every replay."""
+
+    def __init__(self, device, max_launches=4096):
+        self.buf = torch.zeros((max_launches, 2), dtype=torch.int64, device=device)
+        self.n = 0
+        self.flops = []
+
+    def reset(self):
+        self.buf[:, 0] = torch.iinfo(torch.int64).max
+        self.buf[:, 1] = 0
+
+    def next_slot(self, flops):
+        i = self.n
+        self.n += 1
+        self.flops.append(flops)
+        return ctypes.c_void_p(self.buf.data_ptr() + 16 * i)
+
+    def read(self):
+        """-> (n_launches, total_seconds, total_flops) of the launches stamped since the last reset (after a sync)"""
+        b = self.buf[: self.n].cpu()
+        ok = b[:, 1] > 0
+        ticks = (b[:, 1] - b[:, 0])[ok]
+        fl = sum(f for f, k in zip(self.flops, ok.tolist()) if k)
+        return int(ok.sum()), float(ticks.sum()) * 1e-8, fl
+
+
+stamps = None     # set by bench.py to a KernelStamps to switch the stamping on
+
+
 def _attn_fwd(qkv, B, N, H):
     out = torch.empty((B, N, H * 64), device=qkv.device, dtype=torch.bfloat16)
     lse = torch.empty((B, H, N), device=qkv.device, dtype=torch.float32)
     L = _C.lib()
     ws = _C.workspace(L.cosa_attn_workspace_bytes(B, N, H), qkv.device, "attn")
     _C.check(L.cosa_attn_prepare_vt(_C.ptr(qkv), B, N, H, _C.ptr(ws), ws.numel(), _C.stream_ptr()), "cosa_attn_prepare_vt")
+    fl = 4.0 * B * H * N * N * 64
+    st = stamps.next_slot(fl) if stamps is not None else None
     with _C.profiled("attn_fwd"):
-        _C.check(L.cosa_attn_fwd(_C.ptr(qkv), _C.ptr(out), _C.ptr(lse), B, N, H, 64, 0.125, 1, _C.ptr(ws), ws.numel(),
+        _C.check(L.cosa_attn_fwd(_C.ptr(qkv), _C.ptr(out), _C.ptr(lse), B, N, H, 64, 0.125, 1, st, _C.ptr(ws), ws.numel(),
                                  _C.stream_ptr()), "cosa_attn_fwd")
-    _flops["attn_fwd"] = _flops.get("attn_fwd", 0) + 4.0 * B * H * N * N * 64
+    _flops["attn_fwd"] = _flops.get("attn_fwd", 0) + fl
     return out, lse
 
 
@@ -107,13 +144,36 @@ def layernorm_f32(x, g, b, eps, want_bf16=True, want_f32=False):
 # small helpers
 # --------------------------------------------------------------------------------------------
 _cast_cache = {}
+_shadows = {}          # id(param) -> persistent bf16 shadow (teacher weights; refreshed explicitly, hipGraph-safe)
+
+
+class ShadowSet:
+    """Persistent bf16 copies of a module's fp32 parameters, refreshed with ONE multi-tensor copy.
+
+    The teacher is read 6x per step and written once (EMA).  Keeping fixed-address bf16 shadows (a) casts every weight
+    exactly once per step and (b) makes the whole teacher pass capturable in a hipGraph: the refresh is the first node
+    of the graph, the kernels after it read fixed addresses."""
+
+    def __init__(self, module, dtype=torch.bfloat16):
+        self.params = [p for p in module.parameters()]
+        self.shadows = [torch.empty_like(p, dtype=dtype) for p in self.params]
+        for p, s in zip(self.params, self.shadows):
+            _shadows[id(p)] = (p, s)
+        self.refresh()
+
+    @torch.no_grad()
+    def refresh(self):
+        torch._foreach_copy_(self.shadows, self.params)
 
 
 def cast_param(p, dtype):
-    """bf16 view of an fp32 master parameter.  With grad: differentiable cast.  Without grad
-    (teacher passes): cached per parameter version, so 6 teacher forwards cast each weight once."""
+    """bf16 view of an fp32 master parameter.  Registered shadows (teacher) are returned as they are; with grad the
+    cast is differentiable (student); otherwise cached per parameter version."""
     if p.dtype == dtype:
         return p
+    ent = _shadows.get(id(p))
+    if ent is not None and ent[0] is p and ent[1].dtype == dtype and not (torch.is_grad_enabled() and p.requires_grad):
+        return ent[1]
     if torch.is_grad_enabled() and p.requires_grad:
         return p.to(dtype)
     key = id(p)

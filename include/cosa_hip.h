@@ -128,7 +128,8 @@ int cosa_dense_energy_backward(const float *AS, const float *roi, const float *g
 size_t cosa_attn_workspace_bytes(int B, int N, int H);
 int cosa_attn_prepare_vt(const void *qkv, int B, int N, int H, void *workspace, size_t workspace_bytes, void *stream);
 int cosa_attn_fwd(const void *qkv, void *out, float *lse, int B, int N, int H, int head_dim, float scale,
-                  int flags, void *workspace, size_t workspace_bytes, void *stream);
+                  int flags, uint64_t *stamps /* NULL, or {min start, max end} 100 MHz device ticks of this launch */,
+                  void *workspace, size_t workspace_bytes, void *stream);
 
 /* Backward of the same attention (autograd of vit.py:128-134): dqkv [B,N,3,H,64] bf16 from
  * dout [B,N,H*64]; P is recomputed from lse, nothing of size N^2 touches HBM; no atomics
