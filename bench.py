@@ -35,8 +35,8 @@ PEAK_BF16 = 2.5e15                 # dense bf16 MFMA peak (MI355X_MICROARCH.md)
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=16, help="per-GPU batch (BASELINE configs[1]: 16)")
     ap.add_argument("--crop", type=int, default=448)
     ap.add_argument("--dataset", default="VOC12", choices=["VOC12", "COCO"])
@@ -46,17 +46,28 @@ def parse():
     return ap.parse_args()
 
 
+def usable_cores():
+    """host cores this process may really use: min(affinity mask, cgroup CPU quota, the pool's 16-core share per GPU box)"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get("COSA_CPU_THREADS", "16"))))
+
+
 def cpu_baseline(opt, state_dict, C):
     """one step of the CPU oracle at configs[0] (b=2, 448^2, fp32) on all host cores"""
     from oracle import c_oracle
     from oracle.cpu_step import CpuStep
     from cosa_amd.train_step import synthetic_batch
     c_oracle.build()
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
+    cores = usable_cores()
     torch.set_num_threads(cores)
     sd = {k: v.detach().float().cpu() for k, v in state_dict.items()}
     step = CpuStep(sd, num_classes=C + 1, aux_layer=-4 if opt.dataset == "VOC12" else -3,
@@ -64,12 +75,45 @@ def cpu_baseline(opt, state_dict, C):
     b = opt.cpu_batch
     wimg, simg, lab, box = synthetic_batch(b, opt.crop, C, torch.device("cpu"), seed=1234, dataset=opt.dataset)
     timers = {}
+    n_steps = 2
     t0 = time.perf_counter()
-    step.step(wimg, simg, lab, box.numpy(), n_iter=10 ** 6, timers=timers)
+    for _ in range(n_steps):
+        step.step(wimg, simg, lab, box.numpy(), n_iter=10 ** 6, timers=timers)
     dt = time.perf_counter() - t0
-    return {"value": round(b / dt, 4), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"1 full training step, batch {b} x {opt.crop}x{opt.crop}, fp32, oracle/cpu_step.py ({dt:.1f} s)",
+    return {"value": round(n_steps * b / dt, 4), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"{n_steps} full training steps, batch {b} x {opt.crop}x{opt.crop}, fp32, oracle/cpu_step.py ({dt:.1f} s)",
             "stage_s": {k: round(v, 2) for k, v in timers.items()}}
+
+
+def par_refine_ms_per_img(trainer, simg, lab, box, dev, opt, C):
+    """second half of BASELINE.json's metric: PAR refine ms/img = time of the hi+lo refinement of main+aux CAMs
+    (4 PAR(T=10, dilations 1,2,4,8,12,24) calls per image at S/2) / images (SURVEY d-1), HIP events, resident inputs."""
+    from cosa_amd.models.PAR import PAR
+    from cosa_amd.utils import seg_helper, torch_helper
+    b, S = opt.batch, opt.crop
+    g = torch.Generator(device="cpu").manual_seed(7)
+    cams = torch.nn.functional.interpolate(torch.rand(b, C, S // 8, S // 8, generator=g).to(dev), size=(S, S), mode="bilinear")
+    den = torch_helper.denormalize_img(simg)
+    par = PAR(num_iter=10, dilations=[1, 2, 4, 8, 12, 24])
+
+    def timed(refine, n=10):
+        f = lambda: seg_helper.cam2mask(den, box, cams, lab, 0.7, 0.25, refine_model=refine, _fold_validation=True)
+        f()
+        a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(n):
+            f()
+        e.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(e) / n
+    t0, t1 = timed(None), timed(par)
+    K = float((lab.sum(1) + 1).mean())
+    s = S // 2
+    alg = 4.0 * s * s * (3 + 2 * K * 10) * 2 * b            # bytes per cam2mask call (hi + lo stacks), BASELINE.md §2
+    per_call = (t1 - t0) * 1e-3
+    return {"ms_per_img": round(2 * (t1 - t0) / b, 5), "cam2mask_no_par_ms_per_img": round(t0 / b, 5), "mean_K": round(K, 2),
+            "roofline": {"bound": "hbm", "achieved": round(alg / per_call / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                         "frac": round(alg / per_call / 8e12, 4), "algorithmic_MB_per_call": round(alg / 1e6, 1)}}
 
 
 def main():
@@ -146,6 +190,7 @@ def main():
         if flop_img:
             out["step_mfma"] = {"achieved_TFLOPs": round(ips * flop_img / 1e12, 2), "peak_TFLOPs": PEAK_BF16 / 1e12 * world,
                                 "frac": round(ips * flop_img / (PEAK_BF16 * world), 4), "flop_per_img": flop_img}
+        out["par_refine"] = par_refine_ms_per_img(trainer, simg, lab, box, dev, opt, C)
         if world == 1 and not opt.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(opt, trainer.student.state_dict(), C)
         print(json.dumps(out), flush=True)

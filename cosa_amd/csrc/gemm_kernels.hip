@@ -182,6 +182,147 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const bf16 *__restric
     }
 }
 
+
+// =====================================================================================================
+// v2: 256 (tokens) x 128 (features) x 64 tile, 8 waves (4 x 2, each 64 x 64), THREE LDS stages.
+// One raw s_barrier per K-step and a counted s_waitcnt: the global_load_lds of the next stage stays in
+// flight across the barrier (the 2-stage kernel above drains vmcnt(0) every step).  One workgroup per CU
+// (144 KB LDS), two waves per SIMD.
+// =====================================================================================================
+constexpr int V2_BM = 256, V2_BN = 128;
+constexpr int V2_STAGE = (V2_BM + V2_BN) * 128;        // 48 KB: W tile (128 rows) then X tile (256 rows), 128 B per row
+constexpr int V2_CT_LD_BF16 = 272, V2_CT_LD_F32 = 528;
+
+__device__ __forceinline__ void stage_v2(const bf16 *__restrict__ W, const bf16 *__restrict__ X, int n0, int m0, int M, int K,
+                                         int k0, unsigned char *stage, int wave, int lane)
+{
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        const int q = wave * 6 + i;                    // 48 one-KiB pieces: 0..15 -> W rows, 16..47 -> X rows
+        const int row = 8 * q + (lane >> 3);           // row inside the 384-row stage image
+        const int s = (lane & 7) ^ (row & 7);
+        const bf16 *g;
+        if (q < 16) g = W + (size_t)(n0 + row) * K + k0 + s * 8;
+        else {
+            int gm = m0 + row - 128;
+            gm = gm < M ? gm : M - 1;
+            g = X + (size_t)gm * K + k0 + s * 8;
+        }
+        __builtin_amdgcn_global_load_lds((gbl_void *)g, (lds_void *)(stage + q * 1024), 16, 0, 0);
+    }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512, 1) void gemm_bf16_v2_kernel(const bf16 *__restrict__ X, const bf16 *__restrict__ W,
+                                                             const bf16 *__restrict__ bias, const float *__restrict__ R,
+                                                             void *__restrict__ Yv, int M, int N, int K, int tiles_m, int tiles_n)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int nwg = tiles_m * tiles_n;
+    int wg = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7, idx = wg >> 3;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tm = wg / tiles_n, tn = wg - tm * tiles_n;
+    const int m0 = tm * V2_BM, n0 = tn * V2_BN;
+    const int wm = wave >> 1, wn = wave & 1;           // wave tile: tokens [wm*64,+64) x features [wn*64,+64)
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = K / BK;
+    stage_v2(W, X, n0, m0, M, K, 0, smem, wave, lane);
+    if (nk > 1) stage_v2(W, X, n0, m0, M, K, BK, smem + V2_STAGE, wave, lane);
+
+    const int frow = lane & 15, fq = lane >> 4;
+    for (int kt = 0; kt < nk; kt++) {
+        // stage kt has landed once at most the 6 loads of stage kt+1 are still outstanding
+        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + 2 < nk) stage_v2(W, X, n0, m0, M, K, (kt + 2) * BK, smem + ((kt + 2) % 3) * V2_STAGE, wave, lane);
+        const unsigned char *cur = smem + (kt % 3) * V2_STAGE;
+        const unsigned char *At = cur + (wn * 64) * 128;              // W rows (features)
+        const unsigned char *Bt = cur + 128 * 128 + (wm * 64) * 128;  // X rows (tokens)
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            bf16x8 a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int row = i * 16 + frow;
+                const int slot = ((fq + 4 * ks) ^ (row & 7)) << 4;
+                a[i] = *reinterpret_cast<const bf16x8 *>(At + row * 128 + slot);
+                b[i] = *reinterpret_cast<const bf16x8 *>(Bt + row * 128 + slot);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();      // every wave is done reading the last stage before the tile image is overwritten
+
+    // epilogue: acc[i][j][r] -> feature n = wn*64 + 16i + 4fq + r, token m = wm*64 + 16j + frow
+    unsigned char *Ct = smem;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int nl = wn * 64 + 16 * i + 4 * fq;
+        float bv[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) bv[r] = (float)bias[n0 + nl + r];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int ml = wm * 64 + 16 * j + frow;
+            if (EPI == EPI_RESIDUAL) {
+                f32x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; r++) v[r] = acc[i][j][r] + bv[r];
+                *reinterpret_cast<f32x4 *>(Ct + ml * V2_CT_LD_F32 + nl * 4) = v;
+            } else {
+                bf16x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    float t = acc[i][j][r] + bv[r];
+                    if (EPI == EPI_GELU) t = gelu_erf(t);
+                    v[r] = (bf16)t;
+                }
+                *reinterpret_cast<bf16x4 *>(Ct + ml * V2_CT_LD_BF16 + nl * 2) = v;
+            }
+        }
+    }
+    __syncthreads();
+    if (EPI == EPI_RESIDUAL) {
+        float *Y = static_cast<float *>(Yv);
+#pragma unroll
+        for (int c = tid; c < V2_BM * 32; c += 512) {
+            const int ml = c >> 5, s = c & 31;
+            if (m0 + ml < M) {
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(Ct + ml * V2_CT_LD_F32 + s * 16);
+                const size_t o = (size_t)(m0 + ml) * N + n0 + s * 4;
+                const f32x4 rv = *reinterpret_cast<const f32x4 *>(R + o);
+                *reinterpret_cast<f32x4 *>(Y + o) = v + rv;
+            }
+        }
+    } else {
+        bf16 *Y = static_cast<bf16 *>(Yv);
+#pragma unroll
+        for (int c = tid; c < V2_BM * 16; c += 512) {
+            const int ml = c >> 4, s = c & 15;
+            if (m0 + ml < M)
+                *reinterpret_cast<uint4 *>(Y + (size_t)(m0 + ml) * N + n0 + s * 8) =
+                    *reinterpret_cast<const uint4 *>(Ct + ml * V2_CT_LD_BF16 + s * 16);
+        }
+    }
+}
+
+constexpr size_t kLdsBytesV2 = 3 * V2_STAGE;      // 147456 >= 256*528 (fp32 epilogue tile)
+
 constexpr size_t kLdsBytes = 128 * (BN * 4 + 16) > 2 * STAGE_BYTES ? 128 * (BN * 4 + 16) : 2 * STAGE_BYTES;
 
 // ---- LayerNorm: fp32 residual stream in, bf16 out; one wave per 768-wide row ---------------------------
@@ -234,6 +375,24 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
 
 using namespace cosa;
 
+static int g_gemm_variant = 1;   // measured: the 2-stage 128x128 kernel at 2 workgroups/CU beats the 3-stage 256x128 one (profiles/)
+extern "C" void cosa_gemm_set_variant(int v) { g_gemm_variant = v; }
+
+template <int EPI>
+static int launch_v2(const bf16 *x, const bf16 *w, const bf16 *b, const float *residual, void *Y, int M, int N, int K, hipStream_t st)
+{
+    static bool attr_done = false;
+    if (!attr_done) {
+        COSA_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_bf16_v2_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytesV2));
+        attr_done = true;
+    }
+    const int tiles_m = (M + V2_BM - 1) / V2_BM, tiles_n = N / V2_BN;
+    hipLaunchKernelGGL(gemm_bf16_v2_kernel<EPI>, dim3(tiles_m * tiles_n), dim3(512), kLdsBytesV2, st, x, w, b, residual, Y, M, N, K,
+                       tiles_m, tiles_n);
+    COSA_LAUNCH_CHECK();
+    return COSA_OK;
+}
+
 extern "C" int cosa_gemm_bf16(const void *X, const void *W, const void *bias, const float *residual, void *Y,
                               int M, int N, int K, int epilogue, void *stream)
 {
@@ -246,6 +405,13 @@ extern "C" int cosa_gemm_bf16(const void *X, const void *W, const void *bias, co
     const dim3 grid(tiles_m * tiles_n), blk(256);
     hipStream_t st = as_stream(stream);
     const bf16 *x = static_cast<const bf16 *>(X), *w = static_cast<const bf16 *>(W), *b = static_cast<const bf16 *>(bias);
+    if (g_gemm_variant == 2 && M >= 1024) {
+        switch (epilogue) {
+        case EPI_BIAS: return launch_v2<EPI_BIAS>(x, w, b, residual, Y, M, N, K, st);
+        case EPI_GELU: return launch_v2<EPI_GELU>(x, w, b, residual, Y, M, N, K, st);
+        default: return launch_v2<EPI_RESIDUAL>(x, w, b, residual, Y, M, N, K, st);
+        }
+    }
     static bool attr_done = false;
     if (!attr_done) {
         COSA_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_bf16_kernel<EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes));

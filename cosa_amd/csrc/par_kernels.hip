@@ -131,6 +131,86 @@ __global__ __launch_bounds__(256) void par_affinity_kernel(const float *__restri
     }
 }
 
+// affinity, fast form: the dilation count is a template parameter so all neighbour offsets unroll to constants, the 8 taps
+// of a dilation are issued as independent loads, and the ND*8 logits stay in registers (the generic kernel above stages them
+// through the output buffer).  Same arithmetic, same order: bit-identical to the generic kernel and to the oracle.
+template <int ND>
+__global__ __launch_bounds__(256) void par_affinity_fast_kernel(const float *__restrict__ imgs, float *__restrict__ aff,
+                                                               int h, int w, ParPlan plan)
+{
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    const int hw = h * w;
+    if (pix >= hw) return;
+    const int b = blockIdx.y;
+    const int y = pix / w, x = pix - y * w;
+    constexpr int NN = ND * 8;
+    const float *img = imgs + (size_t)b * 3 * hw;
+    int off[ND][8];
+#pragma unroll
+    for (int di = 0; di < ND; di++) {
+        const int d = plan.dil[di];
+        const int ym = clampi(y - d, 0, h - 1) * w, y0 = y * w, yp = clampi(y + d, 0, h - 1) * w;
+        const int xm = clampi(x - d, 0, w - 1), xp = clampi(x + d, 0, w - 1);
+        off[di][0] = ym + xm; off[di][1] = ym + x; off[di][2] = ym + xp;
+        off[di][3] = y0 + xm; off[di][4] = y0 + xp;
+        off[di][5] = yp + xm; off[di][6] = yp + x; off[di][7] = yp + xp;
+    }
+    float lg[ND][8];
+#pragma unroll
+    for (int di = 0; di < ND; di++)
+#pragma unroll
+        for (int t = 0; t < 8; t++) lg[di][t] = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float *pl = img + (size_t)c * hw;
+        const float ctr = pl[pix];
+        float v[ND][8];
+#pragma unroll
+        for (int di = 0; di < ND; di++)
+#pragma unroll
+            for (int t = 0; t < 8; t++) v[di][t] = pl[off[di][t]];
+        float sum = 0.0f;
+#pragma unroll
+        for (int di = 0; di < ND; di++)
+#pragma unroll
+            for (int t = 0; t < 8; t++) sum = sum + v[di][t];
+        const float mean = sum / (float)NN;
+        float var = 0.0f;
+#pragma unroll
+        for (int di = 0; di < ND; di++)
+#pragma unroll
+            for (int t = 0; t < 8; t++) { const float dl = v[di][t] - mean; var = var + dl * dl; }
+        var = var / (float)(NN - 1);
+        const float sd = __builtin_sqrtf(var) + 1e-8f;
+#pragma unroll
+        for (int di = 0; di < ND; di++)
+#pragma unroll
+            for (int t = 0; t < 8; t++) {
+                float q = __builtin_fabsf(v[di][t] - ctr) / sd;
+                q = q / 0.3f;
+                lg[di][t] = lg[di][t] + (-(q * q));          // acc over c = 0,1,2 starting from 0.0f, as the spec
+            }
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int di = 0; di < ND; di++)
+#pragma unroll
+        for (int t = 0; t < 8; t++) { lg[di][t] = lg[di][t] / 3.0f; mx = lg[di][t] > mx ? lg[di][t] : mx; }
+    float es = 0.0f;
+#pragma unroll
+    for (int di = 0; di < ND; di++)
+#pragma unroll
+        for (int t = 0; t < 8; t++) { lg[di][t] = cosa_expf(lg[di][t] - mx); es = es + lg[di][t]; }
+    float *out = aff + (size_t)b * NN * hw + pix;
+#pragma unroll
+    for (int di = 0; di < ND; di++)
+#pragma unroll
+        for (int t = 0; t < 8; t++) {
+            const float a = lg[di][t] / es;
+            out[(size_t)(di * 8 + t) * hw] = a + 0.01f * plan.posw[di * 8 + t];
+        }
+}
+
 // one propagation step; each thread owns one pixel of up to CG live planes.
 template <int CG>
 __global__ __launch_bounds__(256) void par_step_kernel(const float *__restrict__ aff, const float *__restrict__ src,
@@ -175,6 +255,108 @@ __global__ __launch_bounds__(256) void par_step_kernel(const float *__restrict__
 #pragma unroll
     for (int i = 0; i < CG; i++)
         if (ok[i]) dp[i][pix] = acc[i];
+}
+
+
+// v2 propagation step: each thread owns FOUR consecutive pixels of up to PG live planes.  The affinity row is read once
+// per neighbour as a float4 and shared by all planes.  Interior quads (every tap stays inside the row) take a
+// branch-free path: every neighbour quad is ONE 16-byte load (4-byte aligned; gfx950 global loads do not need more), the
+// 8 taps of a dilation are unrolled so ~8*(1+planes) loads are in flight per thread.  Border quads use clamped scalar
+// taps.  Per pixel the operation order is that of the scalar kernel (acc = acc + m*a, n ascending): bit-identical.
+struct __attribute__((packed, aligned(4))) f4u { float x, y, z, w; };
+
+template <int PG>
+__global__ __launch_bounds__(256) void par_step4_kernel(const float *__restrict__ aff, const float *__restrict__ src,
+                                                       float *__restrict__ dst, const int *__restrict__ kcount, int Kfull,
+                                                       int halves, int half_planes, size_t img_stride, int h, int w, ParPlan plan)
+{
+    const int b = blockIdx.z;
+    const int K = kcount ? kcount[b] : Kfull;
+    const int live = K * halves;
+    const int j0 = blockIdx.y * PG;
+    if (j0 >= live) return;
+    const int w4 = w >> 2;
+    const int q = blockIdx.x * 256 + threadIdx.x;       // quad index
+    if (q >= h * w4) return;
+    const int y = q / w4, x0 = (q - y * w4) << 2;
+    const int hw = h * w;
+    const float *sp[PG];
+    float acc[PG][4];
+    int nlive = live - j0;
+    nlive = nlive > PG ? PG : nlive;
+#pragma unroll
+    for (int i = 0; i < PG; i++) {
+        int j = j0 + (i < nlive ? i : 0);
+        const int half = j / K;
+        const int plane = half * half_planes + (j - half * K);
+        sp[i] = src + (size_t)b * img_stride + (size_t)plane * hw;
+#pragma unroll
+        for (int e = 0; e < 4; e++) acc[i][e] = 0.0f;
+    }
+    const float *ab = aff + (size_t)b * plan.n_dil * 8 * hw + (size_t)y * w + x0;
+    int dmax = 0;
+    for (int di = 0; di < plan.n_dil; di++) dmax = plan.dil[di] > dmax ? plan.dil[di] : dmax;
+    const bool interior = __all(x0 - dmax >= 0 && x0 + 3 + dmax < w);     // wave-uniform
+    if (interior) {
+        // planes beyond nlive alias plane 0 of the group: their loads hit L1 and their sums are never stored, which keeps
+        // this loop free of control flow so the loads of a whole dilation are issued together
+        for (int di = 0; di < plan.n_dil; di++) {
+            const int d = plan.dil[di];
+            const int rm = clampi(y - d, 0, h - 1) * w + x0, r0 = y * w + x0, rp = clampi(y + d, 0, h - 1) * w + x0;
+#pragma unroll
+            for (int t = 0; t < 8; t++) {
+                const int tt = t < 4 ? t : t + 1;
+                const int dy = tt / 3 - 1, dx = tt % 3 - 1;     // compile-time after unrolling
+                const int o = (dy < 0 ? rm : (dy > 0 ? rp : r0)) + dx * d;
+                const float4 a = *reinterpret_cast<const float4 *>(ab + (size_t)(di * 8 + t) * hw);
+#pragma unroll
+                for (int i = 0; i < PG; i++) {
+                    const f4u v = *reinterpret_cast<const f4u *>(sp[i] + o);
+                    acc[i][0] = acc[i][0] + v.x * a.x;
+                    acc[i][1] = acc[i][1] + v.y * a.y;
+                    acc[i][2] = acc[i][2] + v.z * a.z;
+                    acc[i][3] = acc[i][3] + v.w * a.w;
+                }
+            }
+        }
+    } else {
+        // border quads, still branch-free: ONE 16-byte load at the clamped window start, then each of the 4 taps picks
+        // its replicate-clamped column out of the loaded quad (select indices are per tap, shared by all planes)
+        for (int di = 0; di < plan.n_dil; di++) {
+            const int d = plan.dil[di];
+            const int rm = clampi(y - d, 0, h - 1) * w, r0 = y * w, rp = clampi(y + d, 0, h - 1) * w;
+#pragma unroll
+            for (int t = 0; t < 8; t++) {
+                const int tt = t < 4 ? t : t + 1;
+                const int dy = tt / 3 - 1, dx = tt % 3 - 1;
+                const int xs = x0 + dx * d;
+                const int xc = clampi(xs, 0, w - 4);
+                const int i0 = clampi(xs, 0, w - 1) - xc, i1 = clampi(xs + 1, 0, w - 1) - xc;
+                const int i2 = clampi(xs + 2, 0, w - 1) - xc, i3 = clampi(xs + 3, 0, w - 1) - xc;
+                const int o = (dy < 0 ? rm : (dy > 0 ? rp : r0)) + xc;
+                const float4 a = *reinterpret_cast<const float4 *>(ab + (size_t)(di * 8 + t) * hw);
+#pragma unroll
+                for (int i = 0; i < PG; i++) {
+                    const f4u v = *reinterpret_cast<const f4u *>(sp[i] + o);
+                    const float e0 = i0 == 0 ? v.x : (i0 == 1 ? v.y : (i0 == 2 ? v.z : v.w));
+                    const float e1 = i1 == 0 ? v.x : (i1 == 1 ? v.y : (i1 == 2 ? v.z : v.w));
+                    const float e2 = i2 == 0 ? v.x : (i2 == 1 ? v.y : (i2 == 2 ? v.z : v.w));
+                    const float e3 = i3 == 0 ? v.x : (i3 == 1 ? v.y : (i3 == 2 ? v.z : v.w));
+                    acc[i][0] = acc[i][0] + e0 * a.x;
+                    acc[i][1] = acc[i][1] + e1 * a.y;
+                    acc[i][2] = acc[i][2] + e2 * a.z;
+                    acc[i][3] = acc[i][3] + e3 * a.w;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < PG; i++) {
+        if (i < nlive) {
+            const size_t off = (size_t)(sp[i] - src);
+            *reinterpret_cast<float4 *>(dst + off + (size_t)y * w + x0) = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
+        }
+    }
 }
 
 }  // namespace
@@ -228,7 +410,9 @@ int par_make_plan(const int *dilations, int n_dil, ParPlan *plan)
 int par_launch_affinity(const float *imgs, float *aff, int B, int h, int w, const ParPlan &plan, hipStream_t st)
 {
     dim3 grid((h * w + 255) / 256, B);
-    hipLaunchKernelGGL(par_affinity_kernel, grid, dim3(256), 0, st, imgs, aff, h, w, plan);
+    if (plan.n_dil == 6) hipLaunchKernelGGL(par_affinity_fast_kernel<6>, grid, dim3(256), 0, st, imgs, aff, h, w, plan);
+    else if (plan.n_dil == 3) hipLaunchKernelGGL(par_affinity_fast_kernel<3>, grid, dim3(256), 0, st, imgs, aff, h, w, plan);
+    else hipLaunchKernelGGL(par_affinity_kernel, grid, dim3(256), 0, st, imgs, aff, h, w, plan);
     COSA_LAUNCH_CHECK();
     return COSA_OK;
 }
@@ -238,9 +422,17 @@ int par_launch_affinity(const float *imgs, float *aff, int B, int h, int w, cons
 int par_launch_step(const float *aff, const float *src, float *dst, int B, int Kmax, const int *kcount,
                     size_t plane_stride, int h, int w, const ParPlan &plan, hipStream_t st)
 {
-    constexpr int CG = 4;
     const int halves = kcount ? 2 : 1;
     const int half_planes = Kmax / halves;
+    if ((w & 3) == 0) {     // rows are float4-aligned: the 4-pixel kernel (all live planes of an image in one thread for K <= 4)
+        constexpr int PG = 4;
+        dim3 grid4((h * (w >> 2) + 255) / 256, (Kmax + PG - 1) / PG, B);
+        hipLaunchKernelGGL(par_step4_kernel<PG>, grid4, dim3(256), 0, st, aff, src, dst, kcount, Kmax, halves, half_planes,
+                           plane_stride, h, w, plan);
+        COSA_LAUNCH_CHECK();
+        return COSA_OK;
+    }
+    constexpr int CG = 4;
     dim3 grid((h * w + 255) / 256, (Kmax + CG - 1) / CG, B);
     hipLaunchKernelGGL(par_step_kernel<CG>, grid, dim3(256), 0, st, aff, src, dst, kcount, Kmax, halves, half_planes,
                        plane_stride, h, w, plan);
