@@ -323,6 +323,153 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v2_kernel(const bf16 *__rest
 
 constexpr size_t kLdsBytesV2 = 3 * V2_STAGE;      // 147456 >= 256*528 (fp32 epilogue tile)
 
+
+// =====================================================================================================
+// v3: 256 (features) x 256 (tokens) x 64 tile, 8 waves as 2 x 4, each wave 128 features x 64 tokens
+// (8 x 4 MFMA 16x16x32 accumulators).  Compared with the 128x128 kernel this halves the global->LDS
+// staging per flop and cuts LDS fragment reads per MFMA from 0.5 to 0.375 (12 ds_read_b128 per 32 MFMAs):
+// the 128^2 kernel sits at 37 % MFMA-busy with the LDS pipe about as busy as the matrix pipe.
+// Two LDS stages of 64 KB; one workgroup per CU; used for N >= 2304 where the tile count quantises well.
+// =====================================================================================================
+constexpr int V3_T = 256;
+constexpr int V3_STAGE = 2 * V3_T * 128;               // 64 KB: W tile (256 rows) then X tile (256 rows)
+
+__device__ __forceinline__ void stage_v3(const bf16 *__restrict__ W, const bf16 *__restrict__ X, int n0, int m0, int M, int K,
+                                         int k0, unsigned char *stage, int wave, int lane)
+{
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int q = wave * 8 + i;                    // 64 one-KiB pieces: 0..31 -> W rows, 32..63 -> X rows
+        const int row = 8 * q + (lane >> 3);
+        const int s = (lane & 7) ^ (row & 7);
+        const bf16 *g;
+        if (q < 32) g = W + (size_t)(n0 + row) * K + k0 + s * 8;
+        else {
+            int gm = m0 + row - V3_T;
+            gm = gm < M ? gm : M - 1;
+            g = X + (size_t)gm * K + k0 + s * 8;
+        }
+        __builtin_amdgcn_global_load_lds((gbl_void *)g, (lds_void *)(stage + q * 1024), 16, 0, 0);
+    }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512, 1) void gemm_bf16_v3_kernel(const bf16 *__restrict__ X, const bf16 *__restrict__ W,
+                                                             const bf16 *__restrict__ bias, const float *__restrict__ R,
+                                                             void *__restrict__ Yv, int M, int N, int K, int tiles_m, int tiles_n)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int nwg = tiles_m * tiles_n;
+    int wg = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7, idx = wg >> 3;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tm = wg / tiles_n, tn = wg - tm * tiles_n;
+    const int m0 = tm * V3_T, n0 = tn * V3_T;
+    const int wa = wave >> 2, wb = wave & 3;           // features [wa*128,+128) x tokens [wb*64,+64)
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = K / BK;
+    stage_v3(W, X, n0, m0, M, K, 0, smem, wave, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int frow = lane & 15, fq = lane >> 4;
+    for (int kt = 0; kt < nk; kt++) {
+        const unsigned char *cur = smem + (kt & 1) * V3_STAGE;
+        if (kt + 1 < nk) stage_v3(W, X, n0, m0, M, K, (kt + 1) * BK, smem + ((kt + 1) & 1) * V3_STAGE, wave, lane);
+        const unsigned char *At = cur + (wa * 128) * 128;
+        const unsigned char *Bt = cur + V3_T * 128 + (wb * 64) * 128;
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            bf16x8 a[8], b[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int row = j * 16 + frow;
+                b[j] = *reinterpret_cast<const bf16x8 *>(Bt + row * 128 + (((fq + 4 * ks) ^ (row & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int row = i * 16 + frow;
+                a[i] = *reinterpret_cast<const bf16x8 *>(At + row * 128 + (((fq + 4 * ks) ^ (row & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // epilogue.  acc[i][j][r]: feature n = wa*128 + 16i + 4fq + r, token m = wb*64 + 16j + frow.
+    if (EPI == EPI_RESIDUAL) {
+        // fp32 out: each lane holds 4 consecutive features of a token = one 16-byte residual load + store, no LDS round trip
+        float *Y = static_cast<float *>(Yv);
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int n = n0 + wa * 128 + 16 * i + 4 * fq;
+            const f32x4 bv = {(float)bias[n], (float)bias[n + 1], (float)bias[n + 2], (float)bias[n + 3]};
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int m = m0 + wb * 64 + 16 * j + frow;
+                if (m < M) {
+                    const size_t o = (size_t)m * N + n;
+                    const f32x4 rv = *reinterpret_cast<const f32x4 *>(R + o);
+                    *reinterpret_cast<f32x4 *>(Y + o) = acc[i][j] + bv + rv;
+                }
+            }
+        }
+    } else {
+        // bf16 out through LDS in two 128-feature halves (the wave row wa owns one half each)
+        bf16 *Y = static_cast<bf16 *>(Yv);
+        unsigned char *Ct = smem;
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            if (wa == half) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const int nl = 16 * i + 4 * fq;
+                    float bv[4];
+#pragma unroll
+                    for (int r = 0; r < 4; r++) bv[r] = (float)bias[n0 + half * 128 + nl + r];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const int ml = wb * 64 + 16 * j + frow;
+                        bf16x4 v;
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            float t = acc[i][j][r] + bv[r];
+                            if (EPI == EPI_GELU) t = gelu_erf(t);
+                            v[r] = (bf16)t;
+                        }
+                        *reinterpret_cast<bf16x4 *>(Ct + ml * CT_LD + nl * 2) = v;
+                    }
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int c = tid; c < V3_T * 16; c += 512) {
+                const int ml = c >> 4, s = c & 15;
+                if (m0 + ml < M)
+                    *reinterpret_cast<uint4 *>(Y + (size_t)(m0 + ml) * N + n0 + half * 128 + s * 8) =
+                        *reinterpret_cast<const uint4 *>(Ct + ml * CT_LD + s * 16);
+            }
+            __syncthreads();
+        }
+    }
+}
+
+constexpr size_t kLdsBytesV3 = 2 * V3_STAGE;      // 131072 >= 256*272 epilogue half
+
 constexpr size_t kLdsBytes = 128 * (BN * 4 + 16) > 2 * STAGE_BYTES ? 128 * (BN * 4 + 16) : 2 * STAGE_BYTES;
 
 // ---- LayerNorm: fp32 residual stream in, bf16 out; one wave per 768-wide row ---------------------------
@@ -375,7 +522,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
 
 using namespace cosa;
 
-static int g_gemm_variant = 1;   // measured: the 2-stage 128x128 kernel at 2 workgroups/CU beats the 3-stage 256x128 one (profiles/)
+static int g_gemm_variant = 0;   // 0 = pick per shape (measured, tools/bench_gemm.py); 1/2/3 force a kernel
 extern "C" void cosa_gemm_set_variant(int v) { g_gemm_variant = v; }
 
 template <int EPI>
@@ -393,6 +540,21 @@ static int launch_v2(const bf16 *x, const bf16 *w, const bf16 *b, const float *r
     return COSA_OK;
 }
 
+template <int EPI>
+static int launch_v3(const bf16 *x, const bf16 *w, const bf16 *b, const float *residual, void *Y, int M, int N, int K, hipStream_t st)
+{
+    static bool attr_done = false;
+    if (!attr_done) {
+        COSA_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_bf16_v3_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytesV3));
+        attr_done = true;
+    }
+    const int tiles_m = (M + V3_T - 1) / V3_T, tiles_n = N / V3_T;
+    hipLaunchKernelGGL(gemm_bf16_v3_kernel<EPI>, dim3(tiles_m * tiles_n), dim3(512), kLdsBytesV3, st, x, w, b, residual, Y, M, N, K,
+                       tiles_m, tiles_n);
+    COSA_LAUNCH_CHECK();
+    return COSA_OK;
+}
+
 extern "C" int cosa_gemm_bf16(const void *X, const void *W, const void *bias, const float *residual, void *Y,
                               int M, int N, int K, int epilogue, void *stream)
 {
@@ -405,6 +567,17 @@ extern "C" int cosa_gemm_bf16(const void *X, const void *W, const void *bias, co
     const dim3 grid(tiles_m * tiles_n), blk(256);
     hipStream_t st = as_stream(stream);
     const bf16 *x = static_cast<const bf16 *>(X), *w = static_cast<const bf16 *>(W), *b = static_cast<const bf16 *>(bias);
+    // shape rule from the measurements in profiles/r01_gemm_variants.txt: the 256x256 tile wins whenever its tile count
+    // quantises well on 256 CUs (wide N, or >= 2 full rounds of tiles); otherwise the 128x128 kernel at 2 workgroups/CU
+    const long tiles256 = (long)((M + V3_T - 1) / V3_T) * (N / V3_T);
+    const bool pick_v3 = g_gemm_variant == 3 || (g_gemm_variant == 0 && M >= 4096 && (N >= 2304 || tiles256 >= 512));
+    if (pick_v3 && M >= 1024 && N % V3_T == 0) {
+        switch (epilogue) {
+        case EPI_BIAS: return launch_v3<EPI_BIAS>(x, w, b, residual, Y, M, N, K, st);
+        case EPI_GELU: return launch_v3<EPI_GELU>(x, w, b, residual, Y, M, N, K, st);
+        default: return launch_v3<EPI_RESIDUAL>(x, w, b, residual, Y, M, N, K, st);
+        }
+    }
     if (g_gemm_variant == 2 && M >= 1024) {
         switch (epilogue) {
         case EPI_BIAS: return launch_v2<EPI_BIAS>(x, w, b, residual, Y, M, N, K, st);
