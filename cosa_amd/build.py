@@ -31,6 +31,7 @@ SOURCES = {
     "vit_kernels.hip": FAST,
     "gemm_kernels.hip": FAST,
     "attn_kernels.hip": FAST,
+    "loss_kernels.hip": FAST,
 }
 
 

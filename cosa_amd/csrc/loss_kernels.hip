@@ -1,0 +1,283 @@
+// loss_kernels.hip -- the student's dense losses without full-resolution intermediates (gfx950).
+//
+// Reference chain (main.py:167-212, utils/seg_helper.py:800-813, 210-230, 199-208):
+//   seg_pred [b,K,h,w] --bilinear--> [b,K,S,S] --+-- seg_loss(mask_main), seg_loss(mask_aux)   (class-balanced CE, ignore 255)
+//                                               +-- softmax -> DenseEnergyLoss: x0.5 (2x2 mean), ROI, nearest image/label
+// The reference materialises the [b,K,S,S] logits, their log-softmax, softmax and all the gradients of those (>= 10 passes
+// over 270 MB at b=16, K=21, S=448).  Here one forward kernel reads the low-res logits (LDS tile), the two label maps and
+// the image, and emits only the 8 CE sums/counts and the S/2 energy inputs; one backward kernel recomputes the per-pixel
+// softmax and scatters d loss / d logits straight into the [b,K,h,w] gradient (LDS-privatised float atomics).
+//
+// Thread = one 2x2 full-res quad (= one pixel of the energy grid); block = 16x16 quads = 32x32 pixels.
+#include "kernels.hpp"
+
+namespace cosa {
+namespace {
+
+constexpr int TC = 6;     // low-res cells per block edge held in LDS (32 px / (S/h >= 8) + 2)
+
+__device__ __forceinline__ void src_index(int dst, int in, float scale, int &i0, int &i1, float &l0, float &l1)
+{
+    float src = scale * ((float)dst + 0.5f) - 0.5f;
+    if (src < 0.0f) src = 0.0f;
+    int i = (int)src;
+    if (i > in - 1) i = in - 1;
+    i0 = i;
+    i1 = i < in - 1 ? i + 1 : i;
+    l1 = src - (float)i;
+    l0 = 1.0f - l1;
+}
+
+struct Tap { int o00, o01, o10, o11; float w00, w01, w10, w11; };   // offsets inside the LDS tile plane + bilinear weights
+
+__device__ __forceinline__ float tap(const float *pl, const Tap &t)
+{
+    return (pl[t.o00] * t.w00 + pl[t.o01] * t.w01) + (pl[t.o10] * t.w10 + pl[t.o11] * t.w11);
+}
+
+// common prologue: stage the low-res logits of this block into LDS, build the 4 pixel taps of this thread's quad
+struct QuadCtx {
+    Tap t[4];
+    int Y, X;          // top-left full-res pixel
+    bool valid;
+    int cy0, cx0;      // first low-res cell row/col of the tile
+};
+
+__device__ __forceinline__ QuadCtx setup(const float *__restrict__ seg_lr, float *tile, int K, int hs, int ws, int S, float sy, float sx,
+                                         int b)
+{
+    QuadCtx c;
+    const int by = blockIdx.y * 32, bx = blockIdx.x * 32;
+    int a0, a1, d0, d1;
+    float u0, u1;
+    src_index(by, hs, sy, a0, a1, u0, u1);
+    c.cy0 = a0;
+    src_index(bx, ws, sx, d0, d1, u0, u1);
+    c.cx0 = d0;
+    const int tid = threadIdx.y * 16 + threadIdx.x;
+    for (int e = tid; e < K * TC * TC; e += 256) {
+        const int k = e / (TC * TC), r = e - k * TC * TC;
+        const int cy = min(c.cy0 + r / TC, hs - 1), cx = min(c.cx0 + r % TC, ws - 1);
+        tile[e] = seg_lr[(((size_t)b * K + k) * hs + cy) * ws + cx];
+    }
+    __syncthreads();
+    c.Y = by + 2 * threadIdx.y;
+    c.X = bx + 2 * threadIdx.x;
+    c.valid = c.Y < S && c.X < S;
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        int y0, y1, x0, x1;
+        float ly0, ly1, lx0, lx1;
+        src_index(min(c.Y + (p >> 1), S - 1), hs, sy, y0, y1, ly0, ly1);
+        src_index(min(c.X + (p & 1), S - 1), ws, sx, x0, x1, lx0, lx1);
+        y0 -= c.cy0; y1 -= c.cy0; x0 -= c.cx0; x1 -= c.cx0;
+        c.t[p].o00 = y0 * TC + x0; c.t[p].o01 = y0 * TC + x1; c.t[p].o10 = y1 * TC + x0; c.t[p].o11 = y1 * TC + x1;
+        c.t[p].w00 = ly0 * lx0; c.t[p].w01 = ly0 * lx1; c.t[p].w10 = ly1 * lx0; c.t[p].w11 = ly1 * lx1;
+    }
+    return c;
+}
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ---- forward ---------------------------------------------------------------------------------------------------
+// sums[8] = {bgA_sum, bgA_cnt, fgA_sum, fgA_cnt, bgB_sum, bgB_cnt, fgB_sum, fgB_cnt}
+__global__ __launch_bounds__(256) void seg_loss_fwd_kernel(const float *__restrict__ seg_lr, const float *__restrict__ maskA,
+                                                          const float *__restrict__ maskB, const float *__restrict__ simg,
+                                                          const int32_t *__restrict__ boxes, float *__restrict__ sums,
+                                                          float *__restrict__ s_seg, float *__restrict__ s_img,
+                                                          float *__restrict__ roi, unsigned char *__restrict__ unlabel,
+                                                          int K, int hs, int ws, int S, float sy, float sx)
+{
+    extern __shared__ __attribute__((aligned(16))) float tile[];
+    __shared__ float red[4][8];
+    const int b = blockIdx.z;
+    const QuadCtx c = setup(seg_lr, tile, K, hs, ws, S, sy, sx, b);
+    const int Sq = S >> 1;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float m[4], inv[4];
+    if (c.valid) {
+        const size_t SS = (size_t)S * S;
+        // pass 1+2: per-pixel max and sum-exp; CE terms
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            float mx = -INFINITY;
+            for (int k = 0; k < K; k++) mx = fmaxf(mx, tap(tile + k * TC * TC, c.t[p]));
+            float se = 0.f;
+            for (int k = 0; k < K; k++) se += __expf(tap(tile + k * TC * TC, c.t[p]) - mx);
+            m[p] = mx;
+            inv[p] = 1.0f / se;
+            const float lse = mx + __logf(se);
+            const size_t pix = (size_t)(c.Y + (p >> 1)) * S + c.X + (p & 1);
+            const int la = (int)maskA[(size_t)b * SS + pix], lb = (int)maskB[(size_t)b * SS + pix];
+            if (la == 0) { acc[0] += lse - tap(tile, c.t[p]); acc[1] += 1.f; }
+            else if (la != 255) { acc[2] += lse - tap(tile + la * TC * TC, c.t[p]); acc[3] += 1.f; }
+            if (lb == 0) { acc[4] += lse - tap(tile, c.t[p]); acc[5] += 1.f; }
+            else if (lb != 255) { acc[6] += lse - tap(tile + lb * TC * TC, c.t[p]); acc[7] += 1.f; }
+        }
+        // pass 3: probabilities, 2x2 mean (the exact x0.5 bilinear), energy-grid outputs
+        const int qy = c.Y >> 1, qx = c.X >> 1;
+        const size_t q = (size_t)qy * Sq + qx, QQ = (size_t)Sq * Sq;
+        for (int k = 0; k < K; k++) {
+            const float *pl = tile + k * TC * TC;
+            const float p0 = __expf(tap(pl, c.t[0]) - m[0]) * inv[0], p1 = __expf(tap(pl, c.t[1]) - m[1]) * inv[1];
+            const float p2 = __expf(tap(pl, c.t[2]) - m[2]) * inv[2], p3 = __expf(tap(pl, c.t[3]) - m[3]) * inv[3];
+            s_seg[((size_t)b * K + k) * QQ + q] = (p0 * 0.5f + p1 * 0.5f) * 0.5f + (p2 * 0.5f + p3 * 0.5f) * 0.5f;
+        }
+        const size_t pix0 = (size_t)c.Y * S + c.X;
+        const float mean[3] = {123.675f, 116.28f, 103.53f}, sd[3] = {58.395f, 57.12f, 57.375f};
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) s_img[((size_t)b * 3 + ch) * QQ + q] = simg[((size_t)b * 3 + ch) * SS + pix0] * sd[ch] + mean[ch];
+        const int32_t *bx = boxes + b * 4;
+        roi[(size_t)b * QQ + q] = (c.Y >= bx[0] && c.Y < bx[1] && c.X >= bx[2] && c.X < bx[3]) ? 1.0f : 0.0f;
+        unlabel[(size_t)b * QQ + q] = ((int)maskA[(size_t)b * SS + pix0] == 255) ? 1 : 0;
+    }
+    const int tid = threadIdx.y * 16 + threadIdx.x, wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const float v = wave_sum(acc[i]);
+        if (lane == 0) red[wave][i] = v;
+    }
+    __syncthreads();
+    if (tid < 8) atomicAdd(&sums[tid], red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid]);
+}
+
+// ---- backward ---------------------------------------------------------------------------------------------------
+// d/dz_k(pixel) = g_seg * [cA(pix) (p_k - [k==lA]) + cB(pix) (p_k - [k==lB])] + p_k (dP_k - sum_j p_j dP_j),
+//   dP_k = 0.25 * G_k(quad),  G = -2 * g_regw * AS / N * roi   (utils/seg_helper.py:899-902 + the x0.5 mean's adjoint)
+__global__ __launch_bounds__(256) void seg_loss_bwd_kernel(const float *__restrict__ seg_lr, const float *__restrict__ maskA,
+                                                          const float *__restrict__ maskB, const float *__restrict__ sums,
+                                                          const float *__restrict__ AS, const float *__restrict__ roi,
+                                                          const float *__restrict__ g_seg, const float *__restrict__ g_regw,
+                                                          float *__restrict__ grad, int B, int K, int hs, int ws, int S,
+                                                          float sy, float sx)
+{
+    extern __shared__ __attribute__((aligned(16))) float tile[];       // [K][TC][TC] logits, then [K][TC][TC] gradient
+    const int b = blockIdx.z;
+    const QuadCtx c = setup(seg_lr, tile, K, hs, ws, S, sy, sx, b);
+    float *gt = tile + K * TC * TC;
+    const int tid = threadIdx.y * 16 + threadIdx.x;
+    for (int e = tid; e < K * TC * TC; e += 256) gt[e] = 0.f;
+    __syncthreads();
+    if (c.valid) {
+        const size_t SS = (size_t)S * S;
+        const int Sq = S >> 1;
+        const size_t QQ = (size_t)Sq * Sq, q = (size_t)(c.Y >> 1) * Sq + (c.X >> 1);
+        const float gs = g_seg[0];
+        // fg_alpha = 0.5 and aux blend 0.5 (main.py:200-203, seg_helper.py:813): each of the four terms carries 0.25
+        const float cbgA = 0.25f * gs / (sums[1] + 1e-6f), cfgA = 0.25f * gs / (sums[3] + 1e-6f);
+        const float cbgB = 0.25f * gs / (sums[5] + 1e-6f), cfgB = 0.25f * gs / (sums[7] + 1e-6f);
+        const float ge = -2.0f * g_regw[0] / (float)B * roi[(size_t)b * QQ + q] * 0.25f;
+        float m[4], inv[4], dot[4], ca[4], cb[4];
+        int la[4], lb[4];
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            float mx = -INFINITY;
+            for (int k = 0; k < K; k++) mx = fmaxf(mx, tap(tile + k * TC * TC, c.t[p]));
+            float se = 0.f;
+            for (int k = 0; k < K; k++) se += __expf(tap(tile + k * TC * TC, c.t[p]) - mx);
+            m[p] = mx;
+            inv[p] = 1.0f / se;
+            const size_t pix = (size_t)(c.Y + (p >> 1)) * S + c.X + (p & 1);
+            la[p] = (int)maskA[(size_t)b * SS + pix];
+            lb[p] = (int)maskB[(size_t)b * SS + pix];
+            ca[p] = la[p] == 0 ? cbgA : (la[p] != 255 ? cfgA : 0.f);
+            cb[p] = lb[p] == 0 ? cbgB : (lb[p] != 255 ? cfgB : 0.f);
+            dot[p] = 0.f;
+        }
+        if (ge != 0.f) {
+            for (int k = 0; k < K; k++) {
+                const float dP = ge * AS[((size_t)b * K + k) * QQ + q];
+                const float *pl = tile + k * TC * TC;
+#pragma unroll
+                for (int p = 0; p < 4; p++) dot[p] += __expf(tap(pl, c.t[p]) - m[p]) * inv[p] * dP;
+            }
+        }
+        const bool same = c.t[0].o00 == c.t[3].o00 && c.t[0].o11 == c.t[3].o11 && c.t[0].o01 == c.t[3].o01 && c.t[0].o10 == c.t[3].o10;
+        for (int k = 0; k < K; k++) {
+            const float *pl = tile + k * TC * TC;
+            const float dP = ge != 0.f ? ge * AS[((size_t)b * K + k) * QQ + q] : 0.f;
+            float dz[4];
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+                const float pk = __expf(tap(pl, c.t[p]) - m[p]) * inv[p];
+                dz[p] = ca[p] * (pk - (la[p] == k ? 1.f : 0.f)) + cb[p] * (pk - (lb[p] == k ? 1.f : 0.f)) + pk * (dP - dot[p]);
+            }
+            float *gp = gt + k * TC * TC;
+            if (same) {       // the quad's four pixels share their four low-res cells (always true for S = 16 h)
+                atomicAdd(gp + c.t[0].o00, dz[0] * c.t[0].w00 + dz[1] * c.t[1].w00 + dz[2] * c.t[2].w00 + dz[3] * c.t[3].w00);
+                atomicAdd(gp + c.t[0].o01, dz[0] * c.t[0].w01 + dz[1] * c.t[1].w01 + dz[2] * c.t[2].w01 + dz[3] * c.t[3].w01);
+                atomicAdd(gp + c.t[0].o10, dz[0] * c.t[0].w10 + dz[1] * c.t[1].w10 + dz[2] * c.t[2].w10 + dz[3] * c.t[3].w10);
+                atomicAdd(gp + c.t[0].o11, dz[0] * c.t[0].w11 + dz[1] * c.t[1].w11 + dz[2] * c.t[2].w11 + dz[3] * c.t[3].w11);
+            } else {
+#pragma unroll
+                for (int p = 0; p < 4; p++) {
+                    atomicAdd(gp + c.t[p].o00, dz[p] * c.t[p].w00);
+                    atomicAdd(gp + c.t[p].o01, dz[p] * c.t[p].w01);
+                    atomicAdd(gp + c.t[p].o10, dz[p] * c.t[p].w10);
+                    atomicAdd(gp + c.t[p].o11, dz[p] * c.t[p].w11);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < K * TC * TC; e += 256) {
+        const float v = gt[e];
+        if (v != 0.f) {
+            const int k = e / (TC * TC), r = e - k * TC * TC;
+            const int cy = c.cy0 + r / TC, cx = c.cx0 + r % TC;
+            if (cy < hs && cx < ws) atomicAdd(&grad[(((size_t)b * K + k) * hs + cy) * ws + cx], v);
+        }
+    }
+}
+
+}  // namespace
+}  // namespace cosa
+
+using namespace cosa;
+
+static int check_shapes(int B, int K, int hs, int ws, int S)
+{
+    COSA_REQUIRE(B > 0 && K > 0 && hs > 0 && ws > 0 && S > 0 && (S & 1) == 0 && B <= 65535, "seg_loss: bad shape");
+    COSA_REQUIRE(S >= 8 * hs && S >= 8 * ws, "seg_loss: needs an up-sampling factor >= 8 (got %d -> %d)", hs, S);
+    COSA_REQUIRE(K <= 255, "seg_loss: at most 255 classes (labels are stored with 255 = ignore)");
+    return COSA_OK;
+}
+
+extern "C" int cosa_seg_loss_forward(const float *seg_lr, const float *maskA, const float *maskB, const float *simg,
+                                     const int32_t *boxes, float *sums, float *s_seg, float *s_img, float *roi, uint8_t *unlabel,
+                                     int B, int K, int hs, int ws, int S, void *stream)
+{
+    COSA_REQUIRE(seg_lr && maskA && maskB && simg && boxes && sums && s_seg && s_img && roi && unlabel, "cosa_seg_loss_forward: null pointer");
+    int rc = check_shapes(B, K, hs, ws, S);
+    if (rc) return rc;
+    hipStream_t st = as_stream(stream);
+    COSA_HIP_CHECK(hipMemsetAsync(sums, 0, 8 * sizeof(float), st));
+    const dim3 grid((S + 31) / 32, (S + 31) / 32, B), blk(16, 16);
+    const size_t lds = (size_t)K * TC * TC * sizeof(float);
+    hipLaunchKernelGGL(seg_loss_fwd_kernel, grid, blk, lds, st, seg_lr, maskA, maskB, simg, boxes, sums, s_seg, s_img, roi, unlabel, K,
+                       hs, ws, S, (float)hs / (float)S, (float)ws / (float)S);
+    COSA_LAUNCH_CHECK();
+    return COSA_OK;
+}
+
+extern "C" int cosa_seg_loss_backward(const float *seg_lr, const float *maskA, const float *maskB, const float *sums, const float *AS,
+                                      const float *roi, const float *g_seg, const float *g_regw, float *grad_seg_lr,
+                                      int B, int K, int hs, int ws, int S, void *stream)
+{
+    COSA_REQUIRE(seg_lr && maskA && maskB && sums && AS && roi && g_seg && g_regw && grad_seg_lr, "cosa_seg_loss_backward: null pointer");
+    int rc = check_shapes(B, K, hs, ws, S);
+    if (rc) return rc;
+    hipStream_t st = as_stream(stream);
+    COSA_HIP_CHECK(hipMemsetAsync(grad_seg_lr, 0, (size_t)B * K * hs * ws * sizeof(float), st));
+    const dim3 grid((S + 31) / 32, (S + 31) / 32, B), blk(16, 16);
+    const size_t lds = (size_t)2 * K * TC * TC * sizeof(float);
+    hipLaunchKernelGGL(seg_loss_bwd_kernel, grid, blk, lds, st, seg_lr, maskA, maskB, sums, AS, roi, g_seg, g_regw, grad_seg_lr, B, K, hs,
+                       ws, S, (float)hs / (float)S, (float)ws / (float)S);
+    COSA_LAUNCH_CHECK();
+    return COSA_OK;
+}

@@ -34,7 +34,7 @@ def default_args(dataset="VOC12", **over):
              segfg_alpha=0.5, cam_weight=0.05, seg_softmaxtemp=0.01, reg_weight=0.05, pseudo_scales=[1.0, 0.5, 1.5],
              high_thre=0.7, high_thre_aux=0.7, low_thre=0.25, low_thre_aux=0.25, par_downscale=2, usepar=False,
              aux_cam2seg=True, aux_cam2seg_alpha=0.5, aux_seg2cam=False, aux_seg2cam_alpha=0.5, after_softmax=False,
-             detach='none', use_cammix=False, compute_dtype=torch.bfloat16, teacher_graph=True)
+             detach='none', use_cammix=False, compute_dtype=torch.bfloat16, teacher_graph=True, fused_losses=True)
     if dataset == "VOC12":
         a.update(aux_layer=-4, max_iters=32000)            # run_voc.sh:9-11
     elif dataset == "COCO":
@@ -140,17 +140,28 @@ class CoSATrainer:
             refine_mask_label = seg_helper.cam2mask(img_denorm, img_box, cam_ps, cls_label, args.high_thre, args.low_thre,
                                                     refine_model=self.refine_model, downscale=args.par_downscale,
                                                     _fold_validation=True)
-        seg_pred = F.interpolate(seg_pred, size=refine_mask_label.shape[1:], mode='bilinear', align_corners=False)
-        seg_loss = seg_helper.seg_loss(seg_pred, refine_mask_label, fg_alpha=args.segfg_alpha)
-        if args.aux_cam2seg:
+        fused = (getattr(args, "fused_losses", True) and args.aux_cam2seg and args.segfg_alpha == 0.5
+                 and args.aux_cam2seg_alpha == 0.5 and seg_pred.is_cuda)
+        if fused:
+            # one forward + one backward kernel instead of ~10 full-resolution passes (same maths, main.py:167-212)
             with torch.no_grad():
                 refine_mask_label_aux = seg_helper.cam2mask(img_denorm, img_box, cam_aux_ps, cls_label, args.high_thre_aux,
                                                             args.low_thre_aux, refine_model=self.refine_model,
                                                             downscale=args.par_downscale, _fold_validation=True)
-            seg_loss_aux = seg_helper.seg_loss(seg_pred, refine_mask_label_aux, fg_alpha=args.segfg_alpha)
-            seg_loss = (1 - args.aux_cam2seg_alpha) * seg_loss + args.aux_cam2seg_alpha * seg_loss_aux
-        reg_loss = seg_helper.get_energy_loss(img=simg, logit=seg_pred, label=refine_mask_label, img_box=img_box,
-                                              loss_layer=self.reg_layer)
+            seg_loss, reg_loss = seg_helper.fused_seg_and_energy_loss(seg_pred, refine_mask_label, refine_mask_label_aux, simg,
+                                                                      img_box, self.reg_layer)
+        else:
+            seg_pred = F.interpolate(seg_pred, size=refine_mask_label.shape[1:], mode='bilinear', align_corners=False)
+            seg_loss = seg_helper.seg_loss(seg_pred, refine_mask_label, fg_alpha=args.segfg_alpha)
+            if args.aux_cam2seg:
+                with torch.no_grad():
+                    refine_mask_label_aux = seg_helper.cam2mask(img_denorm, img_box, cam_aux_ps, cls_label, args.high_thre_aux,
+                                                                args.low_thre_aux, refine_model=self.refine_model,
+                                                                downscale=args.par_downscale, _fold_validation=True)
+                seg_loss_aux = seg_helper.seg_loss(seg_pred, refine_mask_label_aux, fg_alpha=args.segfg_alpha)
+                seg_loss = (1 - args.aux_cam2seg_alpha) * seg_loss + args.aux_cam2seg_alpha * seg_loss_aux
+            reg_loss = seg_helper.get_energy_loss(img=simg, logit=seg_pred, label=refine_mask_label, img_box=img_box,
+                                                  loss_layer=self.reg_layer)
         with torch.no_grad():
             valid_seg_ps = seg_helper.seg_refine_by_label(seg_ps, cls_label, softmaxtemp=args.seg_softmaxtemp,
                                                           after_softmax=args.after_softmax)

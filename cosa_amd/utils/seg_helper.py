@@ -198,6 +198,66 @@ class DenseEnergyLoss(torch.nn.Module):
             self.sigma_rgb, self.sigma_xy, self.weight, self.scale_factor)
 
 
+class FusedSegRegLoss(Function):
+    """seg_loss(main) / seg_loss(aux) blend + dense-energy regulariser of the SAME low-res logits in two launches.
+
+    Equivalent to main.py:167-212 (F.interpolate -> seg_loss x2 -> get_energy_loss) with fg_alpha = 0.5 and
+    aux_cam2seg_alpha = 0.5 (the reference defaults), but nothing of size [b,K,S,S] is ever written: the kernels
+    re-derive the per-pixel softmax from an LDS tile of the low-res logits.  Returns (seg_loss, reg_loss)."""
+
+    @staticmethod
+    def forward(ctx, seg_lr, maskA, maskB, simg, boxes, weight, sigma_rgb, sigma_xy):
+        _C.require_cuda(seg_lr, maskA, maskB, simg, boxes)
+        seg_lr = seg_lr.contiguous().float()
+        B, K, hs, ws = seg_lr.shape
+        S = maskA.shape[-1]
+        Sq = S // 2
+        dev = seg_lr.device
+        sums = torch.empty(8, device=dev)
+        s_seg = torch.empty((B, K, Sq, Sq), device=dev)
+        s_img = torch.empty((B, 3, Sq, Sq), device=dev)
+        roi = torch.empty((B, Sq, Sq), device=dev)
+        unl = torch.empty((B, Sq, Sq), device=dev, dtype=torch.uint8)
+        L = _C.lib()
+        maskA, maskB, simg = maskA.contiguous().float(), maskB.contiguous().float(), simg.contiguous().float()
+        _C.check(L.cosa_seg_loss_forward(_C.ptr(seg_lr), _C.ptr(maskA), _C.ptr(maskB), _C.ptr(simg), _C.ptr(boxes), _C.ptr(sums),
+                                         _C.ptr(s_seg), _C.ptr(s_img), _C.ptr(roi), _C.ptr(unl), B, K, hs, ws, S, _C.stream_ptr()),
+                 "cosa_seg_loss_forward")
+        AS = torch.empty_like(s_seg)
+        energy = torch.empty(1, device=dev)
+        wsb = _C.workspace(L.cosa_bilateral_workspace_bytes(B, K, Sq, Sq), dev, "bilateral")
+        _C.check(L.cosa_dense_energy_forward(_C.ptr(s_img), _C.ptr(s_seg), _C.ptr(roi), _C.ptr(unl), _C.ptr(AS), _C.ptr(energy), B, K,
+                                             Sq, Sq, float(sigma_rgb), float(sigma_xy), _C.ptr(wsb), wsb.numel(), _C.stream_ptr()),
+                 "cosa_dense_energy_forward")
+        lossA = 0.5 * sums[0] / (sums[1] + 1e-6) + 0.5 * sums[2] / (sums[3] + 1e-6)
+        lossB = 0.5 * sums[4] / (sums[5] + 1e-6) + 0.5 * sums[6] / (sums[7] + 1e-6)
+        ctx.save_for_backward(seg_lr, maskA, maskB, sums, AS, roi)
+        ctx.weight = float(weight)
+        ctx.S = S
+        return 0.5 * lossA + 0.5 * lossB, energy * float(weight)
+
+    @staticmethod
+    def backward(ctx, g_seg, g_reg):
+        seg_lr, maskA, maskB, sums, AS, roi = ctx.saved_tensors
+        B, K, hs, ws = seg_lr.shape
+        grad = torch.empty_like(seg_lr)
+        gs = g_seg.reshape(1).float().contiguous()
+        gr = (g_reg.reshape(1).float() * ctx.weight).contiguous()
+        _C.check(_C.lib().cosa_seg_loss_backward(_C.ptr(seg_lr), _C.ptr(maskA), _C.ptr(maskB), _C.ptr(sums), _C.ptr(AS), _C.ptr(roi),
+                                                 _C.ptr(gs), _C.ptr(gr), _C.ptr(grad), B, K, hs, ws, ctx.S, _C.stream_ptr()),
+                 "cosa_seg_loss_backward")
+        return grad, None, None, None, None, None, None, None
+
+
+def fused_seg_and_energy_loss(seg_pred_lr, mask_main, mask_aux, img, img_box, loss_layer):
+    """(seg_loss, reg_loss) of main.py:167-212 for the reference defaults (fg_alpha 0.5, aux blend 0.5, scale_factor 0.5)."""
+    if loss_layer.scale_factor != 0.5:
+        raise NotImplementedError("fused losses are built for DenseEnergyLoss(scale_factor=0.5) (main.py:77)")
+    boxes = _boxes_to_device(img_box, seg_pred_lr.device)
+    return FusedSegRegLoss.apply(seg_pred_lr, mask_main, mask_aux, img, boxes, loss_layer.weight, loss_layer.sigma_rgb,
+                                 loss_layer.sigma_xy * loss_layer.scale_factor)
+
+
 def _crop_mask_from_boxes(img_box, b, h, w, device):
     boxes = _boxes_to_device(img_box, device)
     ys = torch.arange(h, device=device, dtype=torch.int32)[None, :, None]

@@ -154,6 +154,24 @@ void cosa_gemm_set_variant(int v);   /* 0 (default): per-shape choice; 1: 128x12
 int cosa_layernorm(const float *x, const void *gamma, const void *beta, void *y_bf16, float *y_f32,
                    int rows, int dim, float eps, void *stream);
 
+/* ---------------------------------------------------------------------------------------
+ * main.py:167-212 + utils/seg_helper.py:800-813,199-230  the student's dense losses, fused:
+ *   seg_loss(main) and seg_loss(aux) of the bilinearly up-sampled logits, and the inputs of the
+ *   dense-energy regulariser (softmax -> x0.5, ROI from boxes, nearest image / label), without
+ *   materialising anything at [B,K,S,S].
+ *   seg_lr [B,K,hs,ws] logits; maskA/maskB [B,S,S] labels {0..K-1,255}; simg [B,3,S,S] normalised image
+ *   forward  -> sums[8] = {bgA_sum,bgA_cnt,fgA_sum,fgA_cnt,bgB_...}; s_seg [B,K,S/2,S/2]; s_img [B,3,S/2,S/2] (0..255);
+ *               roi [B,S/2,S/2]; unlabel [B,S/2,S/2] u8   (then cosa_dense_energy_forward on these)
+ *   backward -> grad_seg_lr [B,K,hs,ws] for  g_seg * (0.5*seg_loss_A + 0.5*seg_loss_B)  +  g_regw * energy
+ *               (AS = the gated filter output kept by cosa_dense_energy_forward)
+ * ------------------------------------------------------------------------------------- */
+int cosa_seg_loss_forward(const float *seg_lr, const float *maskA, const float *maskB, const float *simg,
+                          const int32_t *boxes, float *sums, float *s_seg, float *s_img, float *roi, uint8_t *unlabel,
+                          int B, int K, int hs, int ws, int S, void *stream);
+int cosa_seg_loss_backward(const float *seg_lr, const float *maskA, const float *maskB, const float *sums, const float *AS,
+                           const float *roi, const float *g_seg, const float *g_regw, float *grad_seg_lr,
+                           int B, int K, int hs, int ws, int S, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -155,3 +155,34 @@ def test_training_step_bf16_runs_and_learns():
     assert v < first                         # same batch six times: the classification loss must go down
     t0 = next(tr.model_AN.parameters()).detach().clone()
     assert set(torch.unique(logs["mask"]).tolist()) <= set(range(21)) | {255}
+
+
+def test_fused_seg_and_energy_loss_vs_unfused():
+    """fused forward/backward kernels vs the op-by-op path (F.interpolate -> seg_loss x2 -> get_energy_loss), fp32:
+    losses 1e-4 relative, gradient wrt the low-res logits 2e-3 of its max."""
+    import torch.nn.functional as F
+    from cosa_amd.utils import seg_helper
+    torch.manual_seed(0)
+    B, K, hs, S = 3, 21, 12, 192
+    seg_lr = (torch.randn(B, K, hs, hs, device="cuda") * 2).requires_grad_(True)
+    rng = np.random.default_rng(0)
+    mk = lambda: torch.from_numpy(rng.choice([0, 1, 5, 20, 255], size=(B, S, S), p=[0.4, 0.15, 0.15, 0.1, 0.2]).astype(np.float32)).cuda()
+    mA, mB = mk(), mk()
+    mA[2] = 255                                    # an image with nothing labelled in the main mask
+    simg = torch.randn(B, 3, S, S, device="cuda")
+    box = torch.tensor([[0, S, 0, S], [10, 150, 20, 190], [0, S, 0, 100]], dtype=torch.int16)
+    layer = seg_helper.DenseEnergyLoss(weight=1e-7, sigma_rgb=15, sigma_xy=100, scale_factor=0.5)
+    w_seg, w_reg = 0.1, 0.05
+    # reference path
+    up = F.interpolate(seg_lr, size=(S, S), mode="bilinear", align_corners=False)
+    l_seg = 0.5 * seg_helper.seg_loss(up, mA) + 0.5 * seg_helper.seg_loss(up, mB)
+    l_reg = seg_helper.get_energy_loss(img=simg, logit=up, label=mA, img_box=box, loss_layer=layer)
+    (w_seg * l_seg + w_reg * l_reg).sum().backward()
+    g_ref = seg_lr.grad.clone()
+    seg_lr.grad = None
+    f_seg, f_reg = seg_helper.fused_seg_and_energy_loss(seg_lr, mA, mB, simg, box, layer)
+    (w_seg * f_seg + w_reg * f_reg).sum().backward()
+    assert float(f_seg) == pytest.approx(float(l_seg), rel=1e-4)
+    assert float(f_reg) == pytest.approx(float(l_reg), rel=1e-3)
+    err = (seg_lr.grad - g_ref).abs().max().item()
+    assert err <= 2e-3 * g_ref.abs().max().item(), (err, g_ref.abs().max().item())
