@@ -235,6 +235,71 @@ __global__ __launch_bounds__(256) void seg_loss_bwd_kernel(const float *__restri
     }
 }
 
+
+// ---- cam_loss targets without the full-resolution teacher seg ----------------------------------------------------
+// main.py:227-228 + seg_helper.py:553-568,593-597: seg_ps (sum over scales of up(seg)+unflip(up(seg_flip)), [b,K,S,S]) ->
+// mask absent classes with -1e5 -> softmax(x / T) -> foreground channels -> bilinear down to the CAM grid.  The
+// down-sampling reads only 4 pixels of every (S/h)^2 block, so only those pixels are ever evaluated: each thread owns one
+// (image, cell), evaluates the <=4 source pixels straight from the per-scale LOW-RES teacher outputs and blends them.
+struct SegScales {
+    const float *p[4];      // [2B, K, h_i, w_i] per scale (original batch then flipped batch)
+    int h[4], w[4];
+    int n;
+};
+
+__device__ __forceinline__ float bilerp_fma(const float *pl, int w, int y0, int y1, int x0, int x1, float ly0, float ly1, float lx0, float lx1)
+{
+    const float r0 = __builtin_fmaf(pl[y0 * w + x0], lx0, pl[y0 * w + x1] * lx1);
+    const float r1 = __builtin_fmaf(pl[y1 * w + x0], lx0, pl[y1 * w + x1] * lx1);
+    return __builtin_fmaf(r0, ly0, r1 * ly1);
+}
+
+__global__ __launch_bounds__(256) void cam_target_kernel(SegScales sc, const float *__restrict__ labels, float *__restrict__ out,
+                                                        int B, int K, int S, int oh, int ow, float inv_temp)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= B * oh * ow) return;
+    const int b = idx / (oh * ow), cell = idx - b * oh * ow;
+    const int oy = cell / ow, ox = cell - oy * ow;
+    int Y[2], X[2];
+    float wy[2], wx[2];
+    src_index(oy, S, (float)S / (float)oh, Y[0], Y[1], wy[0], wy[1]);
+    src_index(ox, S, (float)S / (float)ow, X[0], X[1], wx[0], wx[1]);
+    const int C = K - 1;
+    // per source pixel: softmax statistics (two passes over k recomputing the summed logits), then the blended output
+    float m[4], inv[4];
+#pragma unroll
+    for (int p = 0; p < 4; p++) { m[p] = -INFINITY; inv[p] = 0.f; }
+    for (int pass = 0; pass < 3; pass++) {
+        for (int k = 0; k < K; k++) {
+            const bool present = k == 0 || labels[(size_t)b * C + k - 1] != 0.0f;
+            float acc_out = 0.f;
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+                const int py = Y[p >> 1], px = X[p & 1];
+                float z = 0.f;
+                for (int s = 0; s < sc.n; s++) {
+                    const int h = sc.h[s], w = sc.w[s];
+                    int y0, y1, x0, x1, f0, f1;
+                    float ly0, ly1, lx0, lx1, fl0, fl1;
+                    src_index(py, h, (float)h / (float)S, y0, y1, ly0, ly1);
+                    src_index(px, w, (float)w / (float)S, x0, x1, lx0, lx1);
+                    src_index(S - 1 - px, w, (float)w / (float)S, f0, f1, fl0, fl1);
+                    const float *a = sc.p[s] + ((size_t)b * K + k) * h * w;
+                    const float *f = sc.p[s] + ((size_t)(b + B) * K + k) * h * w;
+                    const float v = bilerp_fma(a, w, y0, y1, x0, x1, ly0, ly1, lx0, lx1) + bilerp_fma(f, w, y0, y1, f0, f1, ly0, ly1, fl0, fl1);
+                    z = s == 0 ? v : z + v;
+                }
+                z = (present ? z : -1e5f) * inv_temp;
+                if (pass == 0) m[p] = fmaxf(m[p], z);
+                else if (pass == 1) inv[p] += __expf(z - m[p]);
+                else acc_out += wy[p >> 1] * wx[p & 1] * (__expf(z - m[p]) / inv[p]);
+            }
+            if (pass == 2 && k > 0) out[(((size_t)b * C + k - 1) * oh + oy) * ow + ox] = acc_out;
+        }
+    }
+}
+
 }  // namespace
 }  // namespace cosa
 
@@ -278,6 +343,25 @@ extern "C" int cosa_seg_loss_backward(const float *seg_lr, const float *maskA, c
     const size_t lds = (size_t)2 * K * TC * TC * sizeof(float);
     hipLaunchKernelGGL(seg_loss_bwd_kernel, grid, blk, lds, st, seg_lr, maskA, maskB, sums, AS, roi, g_seg, g_regw, grad_seg_lr, B, K, hs,
                        ws, S, (float)hs / (float)S, (float)ws / (float)S);
+    COSA_LAUNCH_CHECK();
+    return COSA_OK;
+}
+
+extern "C" int cosa_cam_loss_targets(const float *const *seg_scales, const int *hs, const int *ws, int n_scales, const float *labels,
+                                     float *out, int B, int K, int S, int oh, int ow, float temperature, void *stream)
+{
+    COSA_REQUIRE(seg_scales && hs && ws && labels && out && n_scales >= 1 && n_scales <= 4, "cosa_cam_loss_targets: bad arguments");
+    COSA_REQUIRE(B > 0 && K > 1 && S > 0 && oh > 0 && ow > 0 && temperature > 0.f, "cosa_cam_loss_targets: bad shape");
+    SegScales sc;
+    sc.n = n_scales;
+    for (int i = 0; i < 4; i++) {
+        sc.p[i] = i < n_scales ? seg_scales[i] : nullptr;
+        sc.h[i] = i < n_scales ? hs[i] : 1;
+        sc.w[i] = i < n_scales ? ws[i] : 1;
+    }
+    const int total = B * oh * ow;
+    hipLaunchKernelGGL(cam_target_kernel, dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), sc, labels, out, B, K, S, oh, ow,
+                       1.0f / temperature);
     COSA_LAUNCH_CHECK();
     return COSA_OK;
 }

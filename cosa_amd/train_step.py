@@ -89,6 +89,7 @@ class CoSATrainer:
         # teacher: fixed-address bf16 shadow weights + (optionally) the whole multi-scale pass as one hipGraph
         self._shadows = nn_ops.ShadowSet(self.model_AN) if args.compute_dtype == torch.bfloat16 and device.type == "cuda" else None
         self.use_graph = bool(getattr(args, "teacher_graph", True)) and self._shadows is not None
+        self.fused_losses = bool(getattr(args, "fused_losses", True)) and device.type == "cuda" and not args.after_softmax
         self._graph = None
         self._graph_calls = 0
 
@@ -105,7 +106,8 @@ class CoSATrainer:
                 st.reset()
             if self._shadows is not None:
                 self._shadows.refresh()
-            return seg_helper.multi_scale_camseg(self.model_AN, wimg, args.pseudo_scales, _active_labels=act)
+            return seg_helper.multi_scale_camseg(self.model_AN, wimg, args.pseudo_scales, _active_labels=act,
+                                                  _seg_scales=self.fused_losses)
         if self._graph is None:
             self._s_wimg = wimg.clone()
             self._s_lab = cls_label.clone()
@@ -116,7 +118,8 @@ class CoSATrainer:
                     st.reset()
                 self._shadows.refresh()
                 self._s_out = seg_helper.multi_scale_camseg(self.model_AN, self._s_wimg, args.pseudo_scales,
-                                                            _active_labels=None if args.use_cammix else self._s_lab)
+                                                            _active_labels=None if args.use_cammix else self._s_lab,
+                                                            _seg_scales=self.fused_losses)
             self._graph = g
             self._g_stamps = (st.n, list(st.flops)) if st is not None else None
         self._s_wimg.copy_(wimg)
@@ -140,8 +143,7 @@ class CoSATrainer:
             refine_mask_label = seg_helper.cam2mask(img_denorm, img_box, cam_ps, cls_label, args.high_thre, args.low_thre,
                                                     refine_model=self.refine_model, downscale=args.par_downscale,
                                                     _fold_validation=True)
-        fused = (getattr(args, "fused_losses", True) and args.aux_cam2seg and args.segfg_alpha == 0.5
-                 and args.aux_cam2seg_alpha == 0.5 and seg_pred.is_cuda)
+        fused = self.fused_losses and args.aux_cam2seg and args.segfg_alpha == 0.5 and args.aux_cam2seg_alpha == 0.5
         if fused:
             # one forward + one backward kernel instead of ~10 full-resolution passes (same maths, main.py:167-212)
             with torch.no_grad():
@@ -162,13 +164,21 @@ class CoSATrainer:
                 seg_loss = (1 - args.aux_cam2seg_alpha) * seg_loss + args.aux_cam2seg_alpha * seg_loss_aux
             reg_loss = seg_helper.get_energy_loss(img=simg, logit=seg_pred, label=refine_mask_label, img_box=img_box,
                                                   loss_layer=self.reg_layer)
-        with torch.no_grad():
-            valid_seg_ps = seg_helper.seg_refine_by_label(seg_ps, cls_label, softmaxtemp=args.seg_softmaxtemp,
-                                                          after_softmax=args.after_softmax)
-        cam_loss = seg_helper.cam_loss(cam_pred, valid_seg_ps)
-        if args.aux_seg2cam:
-            cam_aux_loss = seg_helper.cam_loss(cam_aux_pred, valid_seg_ps)
-            cam_loss = (1 - args.aux_seg2cam_alpha) * cam_loss + args.aux_seg2cam_alpha * cam_aux_loss
+        if self.fused_losses:
+            with torch.no_grad():      # seg_ps is the list of per-scale low-res teacher segs here
+                tgt = seg_helper.cam_loss_targets(seg_ps, cls_label, wimg.shape[-1], cam_pred.shape[-2:], args.seg_softmaxtemp)
+            cam_loss = seg_helper.cam_loss_from_targets(cam_pred, tgt)
+            if args.aux_seg2cam:
+                cam_loss = (1 - args.aux_seg2cam_alpha) * cam_loss + \
+                    args.aux_seg2cam_alpha * seg_helper.cam_loss_from_targets(cam_aux_pred, tgt)
+        else:
+            with torch.no_grad():
+                valid_seg_ps = seg_helper.seg_refine_by_label(seg_ps, cls_label, softmaxtemp=args.seg_softmaxtemp,
+                                                              after_softmax=args.after_softmax)
+            cam_loss = seg_helper.cam_loss(cam_pred, valid_seg_ps)
+            if args.aux_seg2cam:
+                cam_aux_loss = seg_helper.cam_loss(cam_aux_pred, valid_seg_ps)
+                cam_loss = (1 - args.aux_seg2cam_alpha) * cam_loss + args.aux_seg2cam_alpha * cam_aux_loss
         if n_iter <= args.warmup_iters:
             loss = 1.0 * cls_loss + 1.0 * cls_loss_aux + 0.0 * seg_loss + 0.0 * cam_loss + 0.0 * reg_loss
         else:

@@ -3,6 +3,8 @@
 Same names, arguments and error behaviour as the reference (utils/seg_helper.py); every function
 cites the lines it replaces.  All tensors live on the GPU; nothing here falls back to the CPU.
 """
+import ctypes
+
 import torch
 import torch.nn.functional as F
 from torch.autograd import Function
@@ -28,7 +30,7 @@ def cam_minmax_norm_(cam, active=None):
     return cam
 
 
-def multi_scale_camseg(model, imgs, scales, _active_labels=None):
+def multi_scale_camseg(model, imgs, scales, _active_labels=None, _seg_scales=False):
     """Teacher forward over scales x {orig, flip}; returns (cam, cam_aux, seg) at input size.
 
     utils/seg_helper.py:232-275.  Per scale one fused kernel does bilinear-up + un-flip + max/sum
@@ -36,12 +38,16 @@ def multi_scale_camseg(model, imgs, scales, _active_labels=None):
     (`cam_aux_list = [...]`, :258) is reproduced.  `_active_labels` ([b,C] image-level labels, optional): the CAM
     planes of absent classes are returned as zeros -- exactly what cam_validation makes of them in the very next
     call of the training loop (main.py:137) -- so the tail only touches the 1-4 live planes per image.
+    `_seg_scales=True` returns the per-scale low-res seg outputs (a list of [2b,K,h_s,w_s]) in place of the summed
+    full-resolution seg: the only consumer in the loop (cam_loss's targets) reads 4 pixels per 16x16 block of it
+    (see cam_loss_targets), so the [b,K,S,S] tensor need not exist.
     """
     b, c, h, w = imgs.shape
     assert 1.0 in scales, 'scale 1.0 must be in scales'
     assert h == w, "square crops only"
     _C.require_cuda(imgs)
     cam = cam_aux = seg = None
+    seg_list = []
     act = _active_labels.contiguous().float() if _active_labels is not None else None
     with torch.no_grad():
         for si, s in enumerate(scales):
@@ -58,10 +64,13 @@ def multi_scale_camseg(model, imgs, scales, _active_labels=None):
             _flip_merge_upsample(_cam, cam, b, h, 0, si > 0, act)
             if si == len(scales) - 1:                                   # only the last scale survives (:258)
                 _flip_merge_upsample(_cam_aux, cam_aux, b, h, 0, False, act)
-            _flip_merge_upsample(_seg, seg, b, h, 1, si > 0)
+            if _seg_scales:
+                seg_list.append(_seg.contiguous().float())
+            else:
+                _flip_merge_upsample(_seg, seg, b, h, 1, si > 0)
         cam_minmax_norm_(cam, act)
         cam_minmax_norm_(cam_aux, act)
-    return cam, cam_aux, seg
+    return cam, cam_aux, (seg_list if _seg_scales else seg)
 
 
 # --------------------------------------------------------------------------------------------
@@ -290,6 +299,33 @@ def seg_refine_by_label(seg, cls_label, softmaxtemp, after_softmax=False):
         return cls_label_bk[:, :, None, None] * seg
     valid_seg = torch.where((cls_label_bk == 0)[:, :, None, None], torch.full_like(seg, -1e5), seg)
     return F.softmax(valid_seg / softmaxtemp, dim=1)
+
+
+def cam_loss_targets(seg_scales, cls_label, S, out_hw, softmaxtemp):
+    """seg_refine_by_label(sum_scales seg, T)[:, 1:] bilinearly resized to `out_hw` (main.py:227-228, seg_helper.py:553-568,
+    595-597), computed from the per-scale low-res teacher segs without building the [b,K,S,S] tensor."""
+    b2, K = seg_scales[0].shape[:2]
+    B = b2 // 2
+    oh, ow = out_hw
+    out = torch.empty((B, K - 1, oh, ow), device=seg_scales[0].device, dtype=torch.float32)
+    n = len(seg_scales)
+    ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in seg_scales])
+    hs = _C.int_array([t.shape[2] for t in seg_scales])
+    ws = _C.int_array([t.shape[3] for t in seg_scales])
+    lab = cls_label.contiguous().float()
+    _C.check(_C.lib().cosa_cam_loss_targets(ptrs, hs, ws, n, _C.ptr(lab), _C.ptr(out), B, K, int(S), oh, ow, float(softmaxtemp),
+                                            _C.stream_ptr()), "cosa_cam_loss_targets")
+    return out
+
+
+def cam_loss_from_targets(cam, targets, is_relu=True):
+    """cam_loss (seg_helper.py:593-602) given pre-resized targets [B,C,H,W]"""
+    B, C, H, W = cam.shape
+    if is_relu:
+        cam = F.relu(cam)
+    cam_flat = cam.float().permute(0, 2, 3, 1).reshape(B * H * W, C)
+    tgt_flat = targets.permute(0, 2, 3, 1).reshape(B * H * W, C)
+    return F.multilabel_soft_margin_loss(cam_flat, tgt_flat)
 
 
 def cam_loss(cam, seg_ps, is_relu=True):

@@ -172,6 +172,13 @@ int cosa_seg_loss_backward(const float *seg_lr, const float *maskA, const float 
                            const float *roi, const float *g_seg, const float *g_regw, float *grad_seg_lr,
                            int B, int K, int hs, int ws, int S, void *stream);
 
+/* main.py:227-228 + utils/seg_helper.py:553-568,593-597: targets of cam_loss -- seg_refine_by_label(teacher seg, T) foreground
+ * channels, bilinearly down-sampled to the CAM grid -- evaluated only at the pixels the down-sampling reads, straight from the
+ * per-scale low-res teacher seg outputs seg_scales[i] [2B,K,hs[i],ws[i]] (original batch, then the flipped batch).
+ *   out [B, K-1, oh, ow]                                                                                                      */
+int cosa_cam_loss_targets(const float *const *seg_scales, const int *hs, const int *ws, int n_scales, const float *labels,
+                          float *out, int B, int K, int S, int oh, int ow, float temperature, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

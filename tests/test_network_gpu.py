@@ -186,3 +186,28 @@ def test_fused_seg_and_energy_loss_vs_unfused():
     assert float(f_reg) == pytest.approx(float(l_reg), rel=1e-3)
     err = (seg_lr.grad - g_ref).abs().max().item()
     assert err <= 2e-3 * g_ref.abs().max().item(), (err, g_ref.abs().max().item())
+
+
+def test_cam_loss_targets_vs_unfused():
+    """cam_loss targets from per-scale low-res teacher segs == seg_refine_by_label(full-res seg) resized (tolerance: the
+    temperature 0.01 amplifies 1e-7 logit noise by 100)."""
+    import torch.nn.functional as F
+    from cosa_amd.utils import seg_helper
+    torch.manual_seed(4)
+    B, K, S = 3, 21, 128
+    sizes = [8, 4, 12]
+    segs = [torch.randn(2 * B, K, n, n, device="cuda") * 0.05 for n in sizes]
+    labels = torch.zeros(B, K - 1, device="cuda")
+    labels[0, [2, 7]] = 1
+    labels[1, [0]] = 1
+    full = None
+    for t in segs:
+        up = F.interpolate(t, size=(S, S), mode="bilinear", align_corners=False)
+        v = up[:B] + up[B:].flip(-1)
+        full = v if full is None else full + v
+    ref = seg_helper.seg_refine_by_label(full, labels, softmaxtemp=0.01)
+    ref = F.interpolate(ref[:, 1:], size=(8, 8), mode="bilinear", align_corners=False)
+    out = seg_helper.cam_loss_targets(segs, labels, S, (8, 8), 0.01)
+    assert torch.allclose(out, ref, atol=2e-4, rtol=1e-3), (out - ref).abs().max().item()
+    cam = torch.randn(B, K - 1, 8, 8, device="cuda")
+    assert float(seg_helper.cam_loss_from_targets(cam, out)) == pytest.approx(float(seg_helper.cam_loss(cam, seg_helper.seg_refine_by_label(full, labels, 0.01))), rel=1e-4)
