@@ -468,6 +468,115 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v3_kernel(const bf16 *__rest
     }
 }
 
+
+// =====================================================================================================
+// v4: the v3 tile (256 x 256 x 64, 8 waves of 128 x 64) as a PERSISTENT kernel: one workgroup per CU walks its
+// tiles, and the first K-stage of the next tile is fetched (global_load_lds) during the last K-step of the
+// current one, so neither the first-stage latency nor the tile index arithmetic sits between two tiles.  The
+// epilogue goes straight from the accumulators to memory (each lane owns 4 consecutive features of a token:
+// 8-byte bf16 / 16-byte fp32 stores), which leaves LDS free for that prefetch.  With K = 768 a tile is only
+// 12 K-steps long, and the non-persistent kernels spend ~25 % of their time in pro/epilogue.
+// =====================================================================================================
+template <int EPI>
+__global__ __launch_bounds__(512, 1) void gemm_bf16_v4_kernel(const bf16 *__restrict__ X, const bf16 *__restrict__ W,
+                                                             const bf16 *__restrict__ bias, const float *__restrict__ R,
+                                                             void *__restrict__ Yv, int M, int N, int K, int tiles_m, int tiles_n)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int ntiles = tiles_m * tiles_n;
+    const int G = gridDim.x;
+    const int wa = wave >> 2, wb = wave & 3;
+    const int frow = lane & 15, fq = lane >> 4;
+    const int nk = K / BK;
+    // tile order: every XCD (blockIdx & 7) walks a contiguous chunk of the (m-panel major) tile list
+    const int cq = ntiles >> 3, cr = ntiles & 7;
+    auto tile_of = [&](int o, int &m0, int &n0) {
+        const int xcd = o & 7, idx = o >> 3;
+        const int t = (xcd < cr ? xcd * (cq + 1) : cr * (cq + 1) + (xcd - cr) * cq) + idx;
+        const int tm = t / tiles_n;
+        m0 = tm * V3_T;
+        n0 = (t - tm * tiles_n) * V3_T;
+    };
+    int o = blockIdx.x;
+    if (o >= ntiles) return;
+    int m0, n0;
+    tile_of(o, m0, n0);
+    int g = 0;                                           // LDS stage that holds the K-step about to be consumed
+    stage_v3(W, X, n0, m0, M, K, 0, smem, wave, lane);
+    while (true) {
+        f32x4 acc[8][4];
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int o_next = o + G;
+        int m1 = 0, n1 = 0;
+        const bool has_next = o_next < ntiles;
+        if (has_next) tile_of(o_next, m1, n1);
+        for (int kt = 0; kt < nk; kt++) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            unsigned char *nxt = smem + (g ^ 1) * V3_STAGE;
+            if (kt + 1 < nk) stage_v3(W, X, n0, m0, M, K, (kt + 1) * BK, nxt, wave, lane);
+            else if (has_next) stage_v3(W, X, n1, m1, M, K, 0, nxt, wave, lane);
+            const unsigned char *cur = smem + g * V3_STAGE;
+            const unsigned char *At = cur + (wa * 128) * 128;
+            const unsigned char *Bt = cur + V3_T * 128 + (wb * 64) * 128;
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++) {
+                bf16x8 a[8], b[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int row = j * 16 + frow;
+                    b[j] = *reinterpret_cast<const bf16x8 *>(Bt + row * 128 + (((fq + 4 * ks) ^ (row & 7)) << 4));
+                }
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const int row = i * 16 + frow;
+                    a[i] = *reinterpret_cast<const bf16x8 *>(At + row * 128 + (((fq + 4 * ks) ^ (row & 7)) << 4));
+                }
+#pragma unroll
+                for (int i = 0; i < 8; i++)
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+            g ^= 1;
+        }
+        // epilogue from registers: acc[i][j][r] -> feature n0 + wa*128 + 16i + 4fq + r, token m0 + wb*64 + 16j + frow
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int n = n0 + wa * 128 + 16 * i + 4 * fq;
+            const f32x4 bv = {(float)bias[n], (float)bias[n + 1], (float)bias[n + 2], (float)bias[n + 3]};
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int m = m0 + wb * 64 + 16 * j + frow;
+                if (m < M) {
+                    const size_t off = (size_t)m * N + n;
+                    if (EPI == EPI_RESIDUAL) {
+                        float *Y = static_cast<float *>(Yv);
+                        const f32x4 rv = *reinterpret_cast<const f32x4 *>(R + off);
+                        *reinterpret_cast<f32x4 *>(Y + off) = acc[i][j] + bv + rv;
+                    } else {
+                        bf16 *Y = static_cast<bf16 *>(Yv);
+                        bf16x4 v;
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            float t = acc[i][j][r] + bv[r];
+                            if (EPI == EPI_GELU) t = gelu_erf(t);
+                            v[r] = (bf16)t;
+                        }
+                        *reinterpret_cast<bf16x4 *>(Y + off) = v;
+                    }
+                }
+            }
+        }
+        if (!has_next) break;
+        o = o_next; m0 = m1; n0 = n1;
+    }
+}
+
 constexpr size_t kLdsBytesV3 = 2 * V3_STAGE;      // 131072 >= 256*272 epilogue half
 
 constexpr size_t kLdsBytes = 128 * (BN * 4 + 16) > 2 * STAGE_BYTES ? 128 * (BN * 4 + 16) : 2 * STAGE_BYTES;
@@ -555,6 +664,22 @@ static int launch_v3(const bf16 *x, const bf16 *w, const bf16 *b, const float *r
     return COSA_OK;
 }
 
+template <int EPI>
+static int launch_v4(const bf16 *x, const bf16 *w, const bf16 *b, const float *residual, void *Y, int M, int N, int K, hipStream_t st)
+{
+    static bool attr_done = false;
+    if (!attr_done) {
+        COSA_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_bf16_v4_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytesV3));
+        attr_done = true;
+    }
+    const int tiles_m = (M + V3_T - 1) / V3_T, tiles_n = N / V3_T;
+    const int ntiles = tiles_m * tiles_n;
+    const int grid = ntiles < 256 ? ntiles : 256;          // one persistent workgroup per CU
+    hipLaunchKernelGGL(gemm_bf16_v4_kernel<EPI>, dim3(grid), dim3(512), kLdsBytesV3, st, x, w, b, residual, Y, M, N, K, tiles_m, tiles_n);
+    COSA_LAUNCH_CHECK();
+    return COSA_OK;
+}
+
 extern "C" int cosa_gemm_bf16(const void *X, const void *W, const void *bias, const float *residual, void *Y,
                               int M, int N, int K, int epilogue, void *stream)
 {
@@ -570,6 +695,13 @@ extern "C" int cosa_gemm_bf16(const void *X, const void *W, const void *bias, co
     // shape rule from the measurements in profiles/r01_gemm_variants.txt: the 256x256 tile wins whenever its tile count
     // quantises well on 256 CUs (wide N, or >= 2 full rounds of tiles); otherwise the 128x128 kernel at 2 workgroups/CU
     const long tiles256 = (long)((M + V3_T - 1) / V3_T) * (N / V3_T);
+    if (g_gemm_variant == 4 && N % V3_T == 0) {
+        switch (epilogue) {
+        case EPI_BIAS: return launch_v4<EPI_BIAS>(x, w, b, residual, Y, M, N, K, st);
+        case EPI_GELU: return launch_v4<EPI_GELU>(x, w, b, residual, Y, M, N, K, st);
+        default: return launch_v4<EPI_RESIDUAL>(x, w, b, residual, Y, M, N, K, st);
+        }
+    }
     const bool pick_v3 = g_gemm_variant == 3 || (g_gemm_variant == 0 && M >= 4096 && (N >= 2304 || tiles256 >= 512));
     if (pick_v3 && M >= 1024 && N % V3_T == 0) {
         switch (epilogue) {

@@ -113,7 +113,7 @@ class CoSATrainer:
             self._s_lab = cls_label.clone()
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):   # RCCL's watchdog thread may poll events meanwhile
                 if st is not None:
                     st.reset()
                 self._shadows.refresh()

@@ -18,6 +18,8 @@ for (M,N,K,epi) in [(25120,2304,768,0),(25120,768,768,2),(25120,3072,768,1),(251
     _C.lib().cosa_gemm_set_variant(1)
     t_v1=timeit(lambda: nn_ops.gemm_bf16(x,w,b,epi,residual=r if epi==2 else None))
     _C.lib().cosa_gemm_set_variant(3)
+    t_v3=timeit(lambda: nn_ops.gemm_bf16(x,w,b,epi,residual=r if epi==2 else None))
+    _C.lib().cosa_gemm_set_variant(4)
     y=nn_ops.gemm_bf16(x,w,b,epi,residual=r if epi==2 else None)
     err=(y.float()-ref).abs().max().item()/ref.abs().max().item()
     t_mine=timeit(lambda: nn_ops.gemm_bf16(x,w,b,epi,residual=r if epi==2 else None))
@@ -26,7 +28,7 @@ for (M,N,K,epi) in [(25120,2304,768,0),(25120,768,768,2),(25120,3072,768,1),(251
     else: f=lambda: r+torch.nn.functional.linear(x,w,b)
     t_ref=timeit(f)
     fl=2.0*M*N*K/1e12
-    print(f"M={M} N={N} K={K} epi={epi} relerr={err:.2e} v1 {fl/t_v1*1e3:.0f} TF | v3 {t_mine*1e3:.1f}us {fl/t_mine*1e3:.0f} TF | torch {t_ref*1e3:.1f}us {fl/t_ref*1e3:.0f} TF")
+    print(f"M={M} N={N} K={K} epi={epi} relerr={err:.2e} v1 {fl/t_v1*1e3:.0f} TF | v3 {fl/t_v3*1e3:.0f} TF | v4 {t_mine*1e3:.1f}us {fl/t_mine*1e3:.0f} TF | torch {t_ref*1e3:.1f}us {fl/t_ref*1e3:.0f} TF")
 x=torch.randn(25120,768,device='cuda')*2+0.5; g=torch.randn(768,device='cuda').bfloat16(); bb=torch.randn(768,device='cuda').bfloat16()
 y16,y32=nn_ops.layernorm_f32(x,g,bb,1e-6,True,True)
 ref=torch.nn.functional.layer_norm(x,(768,),g.float(),bb.float(),1e-6)
