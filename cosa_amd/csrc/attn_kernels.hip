@@ -205,6 +205,159 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16 *__restrict__ 
 }
 
 
+// ---- forward, 64 queries per wave ---------------------------------------------------------------------------------
+// Same algorithm as attn_fwd_kernel with a different decomposition: a workgroup is 2 waves, each wave owns TWO 32-query
+// blocks.  Every K / V^T fragment read from LDS now feeds two MFMAs (half the LDS fragment traffic per flop), each wave
+// has two independent MFMA/softmax chains to interleave, and at ~200 VGPRs four such workgroups share a CU, so one
+// workgroup's barrier / staging phase overlaps the others' compute.
+__global__ __launch_bounds__(128, 2) void attn_fwd2_kernel(const bf16 *__restrict__ qkv, const bf16 *__restrict__ vt,
+                                                       bf16 *__restrict__ out, float *__restrict__ lse,
+                                                       int N, int Npad, int H, float scale_log2e,
+                                                       unsigned long long *__restrict__ stamps)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char smem[BK * 128 + HD * VS];
+    if (stamps && threadIdx.x == 0) atomicMin(&stamps[0], __builtin_amdgcn_s_memrealtime());
+    unsigned char *Ks = smem;
+    unsigned char *Vs = smem + BK * 128;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int q0 = blockIdx.x * BQ + wave * 64;
+    const size_t rs = (size_t)3 * H * HD;
+    bf16x8 qf[2][4];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int qrow = min(q0 + 32 * u + r, N - 1);
+        const bf16 *qp = qkv + ((size_t)b * N + qrow) * rs + h * HD + 8 * hh;
+#pragma unroll
+        for (int s = 0; s < 4; s++) qf[u][s] = *reinterpret_cast<const bf16x8 *>(qp + 16 * s);
+    }
+    f32x16 o[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; u++)
+#pragma unroll
+        for (int d = 0; d < 2; d++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) o[u][d][i] = 0.f;
+    float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.f, 0.f};
+    const bf16 *kbase = qkv + (size_t)b * N * rs + (size_t)H * HD + h * HD;
+    const bf16 *vbase = vt + ((size_t)b * H + h) * HD * Npad;
+    const int swz = (r >> 1) & 7;
+    // 128 threads stage 512 + 512 16-byte chunks per tile (4 + 4 per thread).  No register prefetch here: four of these
+    // workgroups share a CU, so another workgroup computes while this one waits for its tile.
+    const int srow = tid >> 3, sslot = tid & 7;          // chunk c = tid + 128*i -> row srow + 16*i, slot sslot
+    for (int k0 = 0; k0 < N; k0 += BK) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int row = srow + 16 * i;
+            const uint4 kv = *reinterpret_cast<const uint4 *>(kbase + (size_t)min(k0 + row, N - 1) * rs + sslot * 8);
+            const uint4 vv = *reinterpret_cast<const uint4 *>(vbase + (size_t)row * Npad + k0 + sslot * 8);
+            *reinterpret_cast<uint4 *>(Ks + row * 128 + ((sslot ^ ((row >> 1) & 7)) << 4)) = kv;
+            uint2 *dv = reinterpret_cast<uint2 *>(Vs + row * VS + sslot * 16);
+            dv[0] = make_uint2(vv.x, vv.y);
+            dv[1] = make_uint2(vv.z, vv.w);
+        }
+        __syncthreads();
+
+        f32x16 sc[2][2];
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+#pragma unroll
+            for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+                for (int i = 0; i < 16; i++) sc[u][kb][i] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            const int slot = ((2 * s + hh) ^ swz) << 4;
+            const bf16x8 a0 = *reinterpret_cast<const bf16x8 *>(Ks + r * 128 + slot);
+            const bf16x8 a1 = *reinterpret_cast<const bf16x8 *>(Ks + (r + 32) * 128 + slot);
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                sc[u][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, qf[u][s], sc[u][0], 0, 0, 0);
+                sc[u][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, qf[u][s], sc[u][1], 0, 0, 0);
+            }
+        }
+        const bool tail = k0 + BK > N;
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            if (tail) {
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    if (k0 + crow(i, hh) >= N) sc[u][0][i] = -INFINITY;
+                    if (k0 + 32 + crow(i, hh) >= N) sc[u][1][i] = -INFINITY;
+                }
+            }
+            float mt = fmaxf(sc[u][0][0], sc[u][1][0]);
+#pragma unroll
+            for (int i = 1; i < 16; i++) mt = fmaxf(mt, fmaxf(sc[u][0][i], sc[u][1][i]));
+            mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+            const float mnew = fmaxf(m[u], mt * scale_log2e);
+            if (__any(mnew != m[u])) {
+                const float alpha = __builtin_amdgcn_exp2f(m[u] - mnew);
+                l[u] *= alpha;
+#pragma unroll
+                for (int i = 0; i < 16; i++) { o[u][0][i] *= alpha; o[u][1][i] *= alpha; }
+                m[u] = mnew;
+            }
+            float ls = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                sc[u][0][i] = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[u][0][i], scale_log2e, -m[u]));
+                sc[u][1][i] = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[u][1][i], scale_log2e, -m[u]));
+                ls += sc[u][0][i] + sc[u][1][i];
+            }
+            l[u] += ls;
+        }
+#pragma unroll
+        for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+            for (int sp = 0; sp < 2; sp++) {
+                const int keyb = kb * 32 + 16 * sp + 4 * hh;
+                bf16x8 v0, v1;
+                {
+                    const uint2 lo = *reinterpret_cast<const uint2 *>(Vs + r * VS + keyb * 2);
+                    const uint2 hi = *reinterpret_cast<const uint2 *>(Vs + r * VS + (keyb + 8) * 2);
+                    uint4 av = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                    v0 = *reinterpret_cast<bf16x8 *>(&av);
+                    const uint2 lo1 = *reinterpret_cast<const uint2 *>(Vs + (r + 32) * VS + keyb * 2);
+                    const uint2 hi1 = *reinterpret_cast<const uint2 *>(Vs + (r + 32) * VS + (keyb + 8) * 2);
+                    uint4 aw = make_uint4(lo1.x, lo1.y, hi1.x, hi1.y);
+                    v1 = *reinterpret_cast<bf16x8 *>(&aw);
+                }
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    bf16x8 pf;
+#pragma unroll
+                    for (int j = 0; j < 8; j++) pf[j] = (bf16)sc[u][kb][8 * sp + j];
+                    o[u][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, pf, o[u][0], 0, 0, 0);
+                    o[u][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, pf, o[u][1], 0, 0, 0);
+                }
+            }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        float lt = l[u] + __shfl_xor(l[u], 32, 64);
+        const float inv = 1.0f / lt;
+        const int q = q0 + 32 * u + r;
+        if (q < N) {
+            bf16 *op = out + ((size_t)b * N + q) * H * HD + h * HD;
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                bf16x4 v0, v1;
+#pragma unroll
+                for (int j = 0; j < 4; j++) { v0[j] = (bf16)(o[u][0][4 * g + j] * inv); v1[j] = (bf16)(o[u][1][4 * g + j] * inv); }
+                *reinterpret_cast<bf16x4 *>(op + 8 * g + 4 * hh) = v0;
+                *reinterpret_cast<bf16x4 *>(op + 32 + 8 * g + 4 * hh) = v1;
+            }
+            if (hh == 0) lse[((size_t)b * H + h) * N + q] = (m[u] + __builtin_amdgcn_logf(lt)) * 0.6931471805599453f;
+        }
+    }
+    if (stamps) {
+        __syncthreads();
+        if (threadIdx.x == 0) atomicMax(&stamps[1], __builtin_amdgcn_s_memrealtime());
+    }
+}
+
 // =====================================================================================================
 // backward (student pass).  Two MFMA kernels, no atomics, deterministic:
 //   attn_bwd_dq_kernel   workgroup owns 128 queries (query on the lane), walks the keys:
@@ -537,9 +690,16 @@ extern "C" int cosa_attn_fwd(const void *qkv, void *out, float *lse, int B, int 
         hipLaunchKernelGGL(attn_vt_kernel, dim3(Npad / BK, H, B), dim3(256), 0, st, static_cast<const bf16 *>(qkv), vt, N, Npad, H);
         COSA_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3((N + BQ - 1) / BQ, H, B), dim3(256), 0, st, static_cast<const bf16 *>(qkv), vt,
-                       static_cast<bf16 *>(out), lse, N, Npad, H, scale * 1.4426950408889634f,
-                       reinterpret_cast<unsigned long long *>(stamps));
+    // measured (tools/bench_attn.py): 2 waves x 64 queries wins for long sequences (N=1765: 568 vs 460 TF), the 4 x 32
+    // kernel with its register prefetch for short ones (N=785: 384 vs 358 TF).  flags bit 1 / bit 2 force either.
+    if ((flags & 2) || (!(flags & 4) && N < 1024))
+        hipLaunchKernelGGL(attn_fwd_kernel, dim3((N + BQ - 1) / BQ, H, B), dim3(256), 0, st, static_cast<const bf16 *>(qkv), vt,
+                           static_cast<bf16 *>(out), lse, N, Npad, H, scale * 1.4426950408889634f,
+                           reinterpret_cast<unsigned long long *>(stamps));
+    else
+        hipLaunchKernelGGL(attn_fwd2_kernel, dim3((N + BQ - 1) / BQ, H, B), dim3(128), 0, st, static_cast<const bf16 *>(qkv), vt,
+                           static_cast<bf16 *>(out), lse, N, Npad, H, scale * 1.4426950408889634f,
+                           reinterpret_cast<unsigned long long *>(stamps));
     COSA_LAUNCH_CHECK();
     return COSA_OK;
 }

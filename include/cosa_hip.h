@@ -123,7 +123,8 @@ int cosa_dense_energy_backward(const float *AS, const float *roi, const float *g
  *   qkv [B,N,3,H,64] bf16 (output of the qkv projection)   out [B,N,H*64] bf16
  *   lse [B,H,N] f32 (log-sum-exp of the scaled scores, kept for the backward pass)
  *   workspace holds V transposed per head ([B,H,64,Npad]); flags bit0 = it was already filled by
- *   cosa_attn_prepare_vt (lets a profiler time the main kernel alone).
+ *   cosa_attn_prepare_vt (lets a profiler time the main kernel alone); bit1 / bit2 force the 4x32-query /
+ *   2x64-query decomposition (default: chosen by sequence length).
  * ------------------------------------------------------------------------------------- */
 size_t cosa_attn_workspace_bytes(int B, int N, int H);
 int cosa_attn_prepare_vt(const void *qkv, int B, int N, int H, void *workspace, size_t workspace_bytes, void *stream);
