@@ -131,12 +131,12 @@ class VisionTransformer(nn.Module):
         dt = self.compute_dtype
         c = nn_ops.cast_param
         y = F.layer_norm(x, (self.embed_dim,), c(blk.norm1.weight, dt), c(blk.norm1.bias, dt), blk.norm1.eps)
-        qkv = F.linear(y, c(blk.attn.qkv.weight, dt), c(blk.attn.qkv.bias, dt))
+        qkv = nn_ops.linear(y, blk.attn.qkv.weight, blk.attn.qkv.bias, dt)
         y = nn_ops.attention(qkv, self.num_heads)
-        x = x + F.linear(y, c(blk.attn.proj.weight, dt), c(blk.attn.proj.bias, dt))
+        x = x + nn_ops.linear(y, blk.attn.proj.weight, blk.attn.proj.bias, dt)
         y = F.layer_norm(x, (self.embed_dim,), c(blk.norm2.weight, dt), c(blk.norm2.bias, dt), blk.norm2.eps)
-        y = nn_ops.gelu(F.linear(y, c(blk.mlp.fc1.weight, dt), c(blk.mlp.fc1.bias, dt)))
-        return x + F.linear(y, c(blk.mlp.fc2.weight, dt), c(blk.mlp.fc2.bias, dt))
+        y = nn_ops.gelu(nn_ops.linear(y, blk.mlp.fc1.weight, blk.mlp.fc1.bias, dt))
+        return x + nn_ops.linear(y, blk.mlp.fc2.weight, blk.mlp.fc2.bias, dt)
 
     # -- fused no-grad path (the teacher's 6 passes): fp32 residual stream, HIP GEMM/LN/attention kernels -------
     def _forward_features_fused(self, x):

@@ -184,5 +184,51 @@ def cast_param(p, dtype):
     return ent[1]
 
 
+_MM_OUT_DTYPE = None      # does torch.mm(bf16, bf16, out_dtype=fp32) work on this build?  probed on first use
+
+
+def _mm_f32(a, b):
+    """a @ b for bf16 operands with an fp32 result (weight gradients land in the fp32 master .grad without a cast pass)."""
+    global _MM_OUT_DTYPE
+    if _MM_OUT_DTYPE is None:
+        try:
+            torch.mm(a[:8, :8].contiguous(), b[:8, :8].contiguous(), out_dtype=torch.float32)
+            _MM_OUT_DTYPE = True
+        except Exception:
+            _MM_OUT_DTYPE = False
+    if _MM_OUT_DTYPE:
+        return torch.mm(a, b, out_dtype=torch.float32)
+    return torch.mm(a, b).float()
+
+
+class LinearShadowFn(Function):
+    """y = x W^T + b with the bf16 SHADOW of the fp32 master weight (ShadowSet): no per-step cast of the weight in the
+    forward, and the weight gradient is produced in fp32 directly.  Gradients are routed to the masters (w, b)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, w16, b16):
+        ctx.save_for_backward(x, w16)
+        return F.linear(x, w16, b16)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w16 = ctx.saved_tensors
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        x2 = x.reshape(-1, x.shape[-1])
+        dx = torch.mm(dy2, w16).view_as(x) if ctx.needs_input_grad[0] else None
+        dw = _mm_f32(dy2.t(), x2) if ctx.needs_input_grad[1] else None
+        db = dy2.sum(0, dtype=torch.float32) if ctx.needs_input_grad[2] else None
+        return dx, dw, db, None, None
+
+
+def linear(x, weight, bias, dtype):
+    """nn.Linear on `dtype` operands from fp32 masters: registered shadows -> LinearShadowFn, otherwise cast_param."""
+    if torch.is_grad_enabled() and weight.requires_grad and dtype == torch.bfloat16:
+        ew, eb = _shadows.get(id(weight)), _shadows.get(id(bias))
+        if ew is not None and eb is not None and ew[0] is weight and eb[0] is bias:
+            return LinearShadowFn.apply(x, weight, bias, ew[1], eb[1])
+    return F.linear(x, cast_param(weight, dtype), cast_param(bias, dtype))
+
+
 def gelu(x):
     return F.gelu(x)

@@ -88,6 +88,8 @@ class CoSATrainer:
         self._ema_pairs = (list(self.model_AN.parameters()), list(self.student.parameters()))
         # teacher: fixed-address bf16 shadow weights + (optionally) the whole multi-scale pass as one hipGraph
         self._shadows = nn_ops.ShadowSet(self.model_AN) if args.compute_dtype == torch.bfloat16 and device.type == "cuda" else None
+        # student: bf16 shadows of the big projection weights, refreshed once per step after AdamW
+        self._student_shadows = nn_ops.ShadowSet(self.student.encoder.blocks) if self._shadows is not None else None
         self.use_graph = bool(getattr(args, "teacher_graph", True)) and self._shadows is not None
         self.fused_losses = bool(getattr(args, "fused_losses", True)) and device.type == "cuda" and not args.after_softmax
         self._graph = None
@@ -193,6 +195,8 @@ class CoSATrainer:
         self.optimizer.zero_grad(set_to_none=True)
         loss.backward()
         self.optimizer.step()
+        if self._student_shadows is not None:
+            self._student_shadows.refresh()
         torch_helper.ema_update(self._ema_pairs[0], self._ema_pairs[1], self.args.momentum)
         return logs
 
