@@ -579,6 +579,113 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v4_kernel(const bf16 *__rest
 
 constexpr size_t kLdsBytesV3 = 2 * V3_STAGE;      // 131072 >= 256*272 epilogue half
 
+
+// =====================================================================================================
+// weight gradient  dW[N,K] += dY[M,N]^T X[M,K]   (autograd of nn.Linear; "TN" GEMM, contraction over tokens)
+// Both operands have the contraction index as their ROW, so the MFMA fragments (8 consecutive k per lane) are columns of
+// the row-major tiles.  The tiles are staged as they are (buffer_load ... lds, rows past M read as zero through the buffer
+// bounds check, K-offset in an SGPR so the loop has no address VALU) and the fragments are fetched with gfx950's
+// transposing LDS read ds_read_b64_tr_b16 (4 rows x 16 columns per 16-lane group, delivered column-major).  LDS image:
+// 256-byte rows with the 16-byte chunk index XOR-ed by ((row&3)<<2 | (row>>2)&3) -- conflict-free for these reads -- applied
+// on the source side of the DMA.  128 x 128 output tile, 4 waves (64 x 64 each), the token range is split across
+// workgroups (the output has at most 24 x 6 tiles) and the fp32 partial tiles are added with 256-byte-contiguous atomics.
+// =====================================================================================================
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+__device__ __forceinline__ int tr_sw(int r) { return ((r & 3) << 2) | ((r >> 2) & 3); }
+
+__global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(const bf16 *__restrict__ dY, const bf16 *__restrict__ X,
+                                                           float *__restrict__ dW, int M, int N, int K, int tiles_k,
+                                                           int stages_per_split, int nstages)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // 2 stages x (dY tile 16 KB + X tile 16 KB)
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tile = blockIdx.x, split = blockIdx.y;
+    const int tn = tile / tiles_k, tk = tile - tn * tiles_k;
+    const int n0 = tn * 128, k0 = tk * 128;
+    const int st0 = split * stages_per_split;
+    int st1 = st0 + stages_per_split;
+    st1 = st1 < nstages ? st1 : nstages;
+    if (st0 >= st1) return;
+    const int wr = wave >> 1, wc = wave & 1;
+    __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc((void *)dY, 0, (int)((size_t)M * N * 2), 0x00020000);
+    __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void *)X, 0, (int)((size_t)M * K * 2), 0x00020000);
+    // per-lane source offsets of the 4 + 4 one-KiB pieces this wave stages per K-step (fixed for the whole kernel)
+    int voY[4], voX[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int q = wave * 4 + i;                  // piece: tile rows 4q .. 4q+3
+        const int r = 4 * q + (lane >> 4), ch = (lane & 15) ^ tr_sw(r);
+        voY[i] = (r * N + n0 + ch * 8) * 2;
+        voX[i] = (r * K + k0 + ch * 8) * 2;
+    }
+    auto stage = [&](int st, unsigned char *buf) {
+        const int soY = st * 64 * N * 2, soX = st * 64 * K * 2;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int q = wave * 4 + i;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsY, (lds_void *)(buf + q * 1024), 16, voY[i], soY, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_void *)(buf + 16384 + q * 1024), 16, voX[i], soX, 0, 0);
+        }
+    };
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // fragment addressing: lane (nn = l&15, g = l>>4) supplies row 8g+4h+q (q = nn>>2), columns 4p..4p+3 (p = nn&3)
+    const int nn = lane & 15, g = lane >> 4, q = nn >> 2, p = nn & 3;
+    stage(st0, smem);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int st = st0; st < st1; st++) {
+        const int par = (st - st0) & 1;
+        unsigned char *cur = smem + par * 32768;
+        if (st + 1 < st1) stage(st + 1, smem + (par ^ 1) * 32768);
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            bf16x8 a[4], b[4];
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int r = ks * 32 + 8 * g + 4 * h + q;
+                const int sw = tr_sw(r);
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int chA = wr * 8 + 2 * i + (p >> 1), chB = wc * 8 + 2 * i + (p >> 1);
+                    const s16x4 va = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(cur + r * 256 + ((chA ^ sw) << 4) + 8 * (p & 1)));
+                    const s16x4 vb = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(cur + 16384 + r * 256 + ((chB ^ sw) << 4) + 8 * (p & 1)));
+                    s16x4 *pa = reinterpret_cast<s16x4 *>(&a[i]);
+                    s16x4 *pb = reinterpret_cast<s16x4 *>(&b[i]);
+                    pa[h] = va;
+                    pb[h] = vb;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    // acc[i][j][r]: n = wr*64 + 16i + 4g + r (row), k' = wc*64 + 16j + nn (col).  Stage the fp32 tile, then 256-B atomics.
+    float *Ct = reinterpret_cast<float *>(smem);          // [128][128] fp32 = 64 KB = both stages
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) Ct[(wr * 64 + 16 * i + 4 * g + r) * 128 + wc * 64 + 16 * j + nn] = acc[i][j][r];
+    __syncthreads();
+    for (int e = tid; e < 128 * 128; e += 256) {
+        const int row = e >> 7, col = e & 127;
+        atomicAdd(&dW[(size_t)(n0 + row) * K + k0 + col], Ct[e]);
+    }
+}
+
 constexpr size_t kLdsBytes = 128 * (BN * 4 + 16) > 2 * STAGE_BYTES ? 128 * (BN * 4 + 16) : 2 * STAGE_BYTES;
 
 // ---- LayerNorm: fp32 residual stream in, bf16 out; one wave per 768-wide row ---------------------------
@@ -746,6 +853,30 @@ extern "C" int cosa_layernorm(const float *x, const void *gamma, const void *bet
     COSA_REQUIRE(dim == 768, "cosa_layernorm: dim must be 768 (ViT-B)");
     hipLaunchKernelGGL(layernorm_kernel<768>, dim3((rows + 3) / 4), dim3(256), 0, as_stream(stream), x,
                        static_cast<const bf16 *>(gamma), static_cast<const bf16 *>(beta), static_cast<bf16 *>(y_bf16), y_f32, rows, eps);
+    COSA_LAUNCH_CHECK();
+    return COSA_OK;
+}
+
+extern "C" int cosa_gemm_wgrad_bf16(const void *dY, const void *X, float *dW, int M, int N, int K, int zero_first, void *stream)
+{
+    COSA_REQUIRE(dY && X && dW && M > 0 && N > 0 && K > 0, "cosa_gemm_wgrad_bf16: bad arguments");
+    COSA_REQUIRE(N % 128 == 0 && K % 128 == 0, "cosa_gemm_wgrad_bf16: N and K must be multiples of 128 (got %d, %d)", N, K);
+    COSA_REQUIRE((size_t)M * N * 2 < 0x7fffffffull && (size_t)M * K * 2 < 0x7fffffffull, "cosa_gemm_wgrad_bf16: operand beyond 2 GiB");
+    hipStream_t st = as_stream(stream);
+    static bool attr_done = false;
+    if (!attr_done) {
+        COSA_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+        attr_done = true;
+    }
+    if (zero_first) COSA_HIP_CHECK(hipMemsetAsync(dW, 0, (size_t)N * K * sizeof(float), st));
+    const int tiles = (N / 128) * (K / 128);
+    const int nstages = (M + 63) / 64;
+    int splits = (288 + tiles - 1) / tiles;                  // >= 1 workgroup per CU; every split costs N*K*4 B of atomics (~1.3 TB/s)
+    if (splits > nstages) splits = nstages;
+    const int per = (nstages + splits - 1) / splits;
+    splits = (nstages + per - 1) / per;
+    hipLaunchKernelGGL(gemm_wgrad_kernel, dim3(tiles, splits), dim3(256), 65536, st, static_cast<const bf16 *>(dY),
+                       static_cast<const bf16 *>(X), dW, M, N, K, K / 128, per, nstages);
     COSA_LAUNCH_CHECK();
     return COSA_OK;
 }

@@ -201,6 +201,16 @@ def _mm_f32(a, b):
     return torch.mm(a, b).float()
 
 
+def gemm_wgrad(dy2, x2):
+    """dW[N,K] fp32 = dy2[M,N]^T x2[M,K] (bf16), the TN MFMA kernel with transposing LDS reads."""
+    M, N = dy2.shape
+    K = x2.shape[1]
+    dw = torch.empty((N, K), device=dy2.device, dtype=torch.float32)
+    with _C.profiled("gemm_wgrad"):
+        _C.check(_C.lib().cosa_gemm_wgrad_bf16(_C.ptr(dy2), _C.ptr(x2), _C.ptr(dw), M, N, K, 1, _C.stream_ptr()), "cosa_gemm_wgrad_bf16")
+    return dw
+
+
 class LinearShadowFn(Function):
     """y = x W^T + b with the bf16 SHADOW of the fp32 master weight (ShadowSet): no per-step cast of the weight in the
     forward, and the weight gradient is produced in fp32 directly.  Gradients are routed to the masters (w, b)."""
@@ -216,7 +226,12 @@ class LinearShadowFn(Function):
         dy2 = dy.reshape(-1, dy.shape[-1])
         x2 = x.reshape(-1, x.shape[-1])
         dx = torch.mm(dy2, w16).view_as(x) if ctx.needs_input_grad[0] else None
-        dw = _mm_f32(dy2.t(), x2) if ctx.needs_input_grad[1] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            if dy2.shape[1] % 128 == 0 and x2.shape[1] % 128 == 0 and dy2.is_cuda:
+                dw = gemm_wgrad(dy2.contiguous(), x2.contiguous())
+            else:
+                dw = _mm_f32(dy2.t(), x2)
         db = dy2.sum(0, dtype=torch.float32) if ctx.needs_input_grad[2] else None
         return dx, dw, db, None, None
 
