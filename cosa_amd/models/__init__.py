@@ -80,13 +80,27 @@ class VITNetwork(nn.Module):
         cam = F.linear(tok, wgt).float()
         return cam.reshape(B, h, w, -1).permute(0, 3, 1, 2).contiguous()
 
+    def forward_multi(self, xs):
+        """forward() for several image batches of different sizes at once (no-grad bf16 only): the encoder runs all of
+        them through shared GEMM / LayerNorm launches (VisionTransformer._forward_features_fused_multi)."""
+        for x in xs:
+            _C.require_cuda(x)
+        feats = self.encoder._forward_features_fused_multi(xs)
+        return [self._heads(x, f, False, False, 'none') for x, f in zip(xs, feats)]
+
+    def can_forward_multi(self, x):
+        return self.encoder.use_fused(x)
+
     def forward(self, x, cam_only=False, seg_only=False, detach='none'):
         """models/__init__.py:163-206 -> (cls, cls_aux, feat[B,768,h,w], seg, cam, cam_aux)"""
         assert detach in ['all', 'feat', 'none', 'cls']
         _C.require_cuda(x)                                            # MI355X only: there is no CPU path
+        return self._heads(x, self.encoder.features_ex(x), cam_only, seg_only, detach)
+
+    def _heads(self, x, feats, cam_only, seg_only, detach):
         dt = self.compute_dtype
         B = x.shape[0]
-        _, tok, tok_aux, tok32 = self.encoder.features_ex(x)
+        _, tok, tok_aux, tok32 = feats
         p = self.encoder.patch_size
         h, w = x.shape[-2] // p, x.shape[-1] // p
         x4 = tok.reshape(B, h, w, -1).permute(0, 3, 1, 2)            # NCHW view, channels-last strides (no copy)

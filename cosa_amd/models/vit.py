@@ -140,19 +140,35 @@ class VisionTransformer(nn.Module):
 
     # -- fused no-grad path (the teacher's 6 passes): fp32 residual stream, HIP GEMM/LN/attention kernels -------
     def _forward_features_fused(self, x):
-        tok, h, w = self.prepare_tokens(x)                      # bf16 [B,N,768]
-        B, N, D = tok.shape
+        return self._forward_features_fused_multi([x])[0]
+
+    def _forward_features_fused_multi(self, xs):
+        """Several image batches (the teacher's three scales) through the encoder TOGETHER: LayerNorm and the four
+        projections are token-wise, so all tokens of all scales go through one launch each per block (M = sum B_i N_i:
+        better tile quantisation on 256 CUs, a third of the launches); only attention runs per scale, on its slice of
+        the packed qkv buffer."""
         c = lambda p_: nn_ops.cast_param(p_, torch.bfloat16)
-        xr = tok.float().reshape(B * N, D).contiguous()          # fp32 residual stream
+        toks, shapes = [], []
+        for x in xs:
+            tok, h, w = self.prepare_tokens(x)                   # bf16 [B,N,768]
+            toks.append(tok.float().reshape(-1, tok.shape[-1]))
+            shapes.append((tok.shape[0], tok.shape[1]))
+        D = self.embed_dim
+        xr = toks[0].contiguous() if len(toks) == 1 else torch.cat(toks, 0)     # fp32 residual stream [sum M_i, 768]
+        offs = [0]
+        for B, N in shapes:
+            offs.append(offs[-1] + B * N)
+        Mtot = offs[-1]
         depth = len(self.blocks)
         aux_idx = self.aux_layer % depth
         aux = None
+        o = torch.empty((Mtot, D), device=xr.device, dtype=torch.bfloat16)
         for i, blk in enumerate(self.blocks):
             y, _ = nn_ops.layernorm_f32(xr, c(blk.norm1.weight), c(blk.norm1.bias), blk.norm1.eps)
             qkv = nn_ops.gemm_bf16(y, c(blk.attn.qkv.weight), c(blk.attn.qkv.bias), nn_ops.EPI_BIAS)
-            o, _ = nn_ops._attn_fwd(qkv.view(B, N, 3 * D), B, N, self.num_heads)
-            nn_ops.gemm_bf16(o.view(B * N, D), c(blk.attn.proj.weight), c(blk.attn.proj.bias), nn_ops.EPI_RESIDUAL, residual=xr,
-                             out=xr)
+            for (B, N), o0, o1 in zip(shapes, offs[:-1], offs[1:]):
+                nn_ops._attn_fwd(qkv[o0:o1].view(B, N, 3 * D), B, N, self.num_heads, out=o[o0:o1].view(B, N, D))
+            nn_ops.gemm_bf16(o, c(blk.attn.proj.weight), c(blk.attn.proj.bias), nn_ops.EPI_RESIDUAL, residual=xr, out=xr)
             y, _ = nn_ops.layernorm_f32(xr, c(blk.norm2.weight), c(blk.norm2.bias), blk.norm2.eps)
             hmid = nn_ops.gemm_bf16(y, c(blk.mlp.fc1.weight), c(blk.mlp.fc1.bias), nn_ops.EPI_GELU)
             nn_ops.gemm_bf16(hmid, c(blk.mlp.fc2.weight), c(blk.mlp.fc2.bias), nn_ops.EPI_RESIDUAL, residual=xr, out=xr)
@@ -161,8 +177,11 @@ class VisionTransformer(nn.Module):
         xn16, xn32 = nn_ops.layernorm_f32(xr, c(self.norm.weight), c(self.norm.bias), self.norm.eps, True, True)
         if aux is None:
             aux = xn32
-        xn16, xn32, aux = xn16.view(B, N, D), xn32.view(B, N, D), aux.view(B, N, D)
-        return xn32[:, 0], xn16[:, 1:], aux[:, 1:], xn32[:, 1:]
+        outs = []
+        for (B, N), o0, o1 in zip(shapes, offs[:-1], offs[1:]):
+            a16, a32, ax = xn16[o0:o1].view(B, N, D), xn32[o0:o1].view(B, N, D), aux[o0:o1].view(B, N, D)
+            outs.append((a32[:, 0], a16[:, 1:], ax[:, 1:], a32[:, 1:]))
+        return outs
 
     def use_fused(self, x):
         return (not torch.is_grad_enabled()) and self.compute_dtype == torch.bfloat16 and x.is_cuda and self.embed_dim == 768

@@ -54,8 +54,9 @@ class KernelStamps:
 stamps = None     # set by bench.py to a KernelStamps to switch the stamping on
 
 
-def _attn_fwd(qkv, B, N, H):
-    out = torch.empty((B, N, H * 64), device=qkv.device, dtype=torch.bfloat16)
+def _attn_fwd(qkv, B, N, H, out=None):
+    if out is None:
+        out = torch.empty((B, N, H * 64), device=qkv.device, dtype=torch.bfloat16)
     lse = torch.empty((B, H, N), device=qkv.device, dtype=torch.float32)
     L = _C.lib()
     ws = _C.workspace(L.cosa_attn_workspace_bytes(B, N, H), qkv.device, "attn")

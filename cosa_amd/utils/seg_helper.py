@@ -50,13 +50,14 @@ def multi_scale_camseg(model, imgs, scales, _active_labels=None, _seg_scales=Fal
     seg_list = []
     act = _active_labels.contiguous().float() if _active_labels is not None else None
     with torch.no_grad():
+        inputs = []
+        for s in scales:
+            imgs_ = imgs if s == 1.0 else F.interpolate(imgs, size=(int(s * h), int(s * w)), mode='bilinear', align_corners=False)
+            inputs.append(torch.cat([imgs_, imgs_.flip(-1)], dim=0))
+        # cosa_amd networks can take all scales in one go (shared GEMM/LayerNorm launches across scales)
+        multi = model.forward_multi(inputs) if getattr(model, "can_forward_multi", lambda _x: False)(inputs[0]) else None
         for si, s in enumerate(scales):
-            if s != 1.0:
-                imgs_ = F.interpolate(imgs, size=(int(s * h), int(s * w)), mode='bilinear', align_corners=False)
-            else:
-                imgs_ = imgs
-            imgs_cat = torch.cat([imgs_, imgs_.flip(-1)], dim=0)
-            _, _, _, _seg, _cam, _cam_aux = model(imgs_cat, cam_only=False)
+            _, _, _, _seg, _cam, _cam_aux = multi[si] if multi is not None else model(inputs[si], cam_only=False)
             if cam is None:
                 cam = torch.empty((b, _cam.shape[1], h, w), device=imgs.device, dtype=torch.float32)
                 cam_aux = torch.empty_like(cam)
