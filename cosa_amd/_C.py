@@ -45,6 +45,9 @@ _SIGS = {
     "cosa_seg_loss_backward": (c_int, [c_void_p] * 9 + [c_int] * 5 + [c_void_p]),
     "cosa_cam_loss_targets": (c_int, [ctypes.POINTER(c_void_p), ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_int, c_void_p,
                               c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "cosa_optim_record_bytes": (c_size_t, []),
+    "cosa_optim_chunk_elems": (c_int, []),
+    "cosa_fused_adamw_ema": (c_int, [c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_int, c_float, c_void_p]),
     "cosa_attn_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "cosa_attn_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "cosa_attn_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p,

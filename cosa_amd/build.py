@@ -32,6 +32,7 @@ SOURCES = {
     "gemm_kernels.hip": FAST,
     "attn_kernels.hip": FAST,
     "loss_kernels.hip": FAST,
+    "optim_kernels.hip": ["-ffp-contract=off"],
 }
 
 

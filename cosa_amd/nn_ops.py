@@ -167,6 +167,11 @@ class ShadowSet:
         torch._foreach_copy_(self.shadows, self.params)
 
 
+def shadow_of(p):
+    ent = _shadows.get(id(p))
+    return ent[1] if ent is not None and ent[0] is p else None
+
+
 def cast_param(p, dtype):
     """bf16 view of an fp32 master parameter.  Registered shadows (teacher) are returned as they are; with grad the
     cast is differentiable (student); otherwise cached per parameter version."""

@@ -34,7 +34,7 @@ def default_args(dataset="VOC12", **over):
              segfg_alpha=0.5, cam_weight=0.05, seg_softmaxtemp=0.01, reg_weight=0.05, pseudo_scales=[1.0, 0.5, 1.5],
              high_thre=0.7, high_thre_aux=0.7, low_thre=0.25, low_thre_aux=0.25, par_downscale=2, usepar=False,
              aux_cam2seg=True, aux_cam2seg_alpha=0.5, aux_seg2cam=False, aux_seg2cam_alpha=0.5, after_softmax=False,
-             detach='none', use_cammix=False, compute_dtype=torch.bfloat16, teacher_graph=True, fused_losses=True)
+             detach='none', use_cammix=False, compute_dtype=torch.bfloat16, teacher_graph=True, fused_losses=True, fused_optimizer=True)
     if dataset == "VOC12":
         a.update(aux_layer=-4, max_iters=32000)            # run_voc.sh:9-11
     elif dataset == "COCO":
@@ -90,6 +90,11 @@ class CoSATrainer:
         self._shadows = nn_ops.ShadowSet(self.model_AN) if args.compute_dtype == torch.bfloat16 and device.type == "cuda" else None
         # student: bf16 shadows of the big projection weights, refreshed once per step after AdamW
         self._student_shadows = nn_ops.ShadowSet(self.student.encoder.blocks) if self._shadows is not None else None
+        # AdamW + EMA + shadow refresh as one multi-tensor kernel
+        self._fused_step = None
+        if self._shadows is not None and getattr(args, "fused_optimizer", True):
+            self._fused_step = torch_helper.FusedAdamWEMAStep(self.optimizer, self._ema_pairs[1], self._ema_pairs[0], args.momentum,
+                                                              shadow_of=nn_ops.shadow_of)
         self.use_graph = bool(getattr(args, "teacher_graph", True)) and self._shadows is not None
         self.fused_losses = bool(getattr(args, "fused_losses", True)) and device.type == "cuda" and not args.after_softmax
         self._graph = None
@@ -106,7 +111,7 @@ class CoSATrainer:
             self._graph_calls += 1
             if st is not None:
                 st.reset()
-            if self._shadows is not None:
+            if self._shadows is not None and self._fused_step is None:
                 self._shadows.refresh()
             return seg_helper.multi_scale_camseg(self.model_AN, wimg, args.pseudo_scales, _active_labels=act,
                                                   _seg_scales=self.fused_losses)
@@ -118,7 +123,8 @@ class CoSATrainer:
             with torch.cuda.graph(g, capture_error_mode="thread_local"):   # RCCL's watchdog thread may poll events meanwhile
                 if st is not None:
                     st.reset()
-                self._shadows.refresh()
+                if self._fused_step is None:
+                    self._shadows.refresh()
                 self._s_out = seg_helper.multi_scale_camseg(self.model_AN, self._s_wimg, args.pseudo_scales,
                                                             _active_labels=None if args.use_cammix else self._s_lab,
                                                             _seg_scales=self.fused_losses)
@@ -194,10 +200,13 @@ class CoSATrainer:
         loss, logs = self.forward_losses(wimg, simg, cls_label, img_box, n_iter)
         self.optimizer.zero_grad(set_to_none=True)
         loss.backward()
-        self.optimizer.step()
-        if self._student_shadows is not None:
-            self._student_shadows.refresh()
-        torch_helper.ema_update(self._ema_pairs[0], self._ema_pairs[1], self.args.momentum)
+        if self._fused_step is not None:
+            self._fused_step.step()
+        else:
+            self.optimizer.step()
+            if self._student_shadows is not None:
+                self._student_shadows.refresh()
+            torch_helper.ema_update(self._ema_pairs[0], self._ema_pairs[1], self.args.momentum)
         return logs
 
 

@@ -87,3 +87,78 @@ def ema_update(teacher_params, student_params, momentum):
     teacher_params, student_params = list(teacher_params), list(student_params)
     torch._foreach_mul_(teacher_params, momentum)
     torch._foreach_add_(teacher_params, student_params, alpha=1 - momentum)
+
+
+class FusedAdamWEMAStep:
+    """optimizer.step() + the teacher EMA (main.py:250-252) + refresh of the bf16 shadow weights as ONE HIP kernel.
+
+    State lives where torch keeps it (optimizer.state[p]['exp_avg'|'exp_avg_sq'], optimizer.param_groups[i]['lr']) so the
+    PolyWarmupAdamW object stays the source of truth (state_dict compatible); this class only replaces the sweeps over
+    memory.  The LR schedule is PolyWarmupAdamW's (utils/torch_helper.py:275-289)."""
+
+    def __init__(self, optimizer, student_params, teacher_params, momentum, shadow_of=None):
+        import numpy as np
+        self.opt = optimizer
+        self.momentum = float(momentum)
+        self.student = list(student_params)
+        self.teacher = list(teacher_params)
+        assert len(self.student) == len(self.teacher)
+        dev = self.student[0].device
+        L = _C.lib()
+        self.rec_dtype = np.dtype([("p", "u8"), ("g", "u8"), ("m", "u8"), ("v", "u8"), ("tp", "u8"), ("p16", "u8"), ("t16", "u8"),
+                                   ("lr", "f4"), ("wd", "f4"), ("n", "i8")])
+        assert self.rec_dtype.itemsize == L.cosa_optim_record_bytes()
+        group_of = {}
+        for gi, g in enumerate(optimizer.param_groups):
+            for p in g["params"]:
+                group_of[id(p)] = gi
+        self.group_idx = [group_of.get(id(p), -1) for p in self.student]
+        shadow_of = shadow_of or (lambda p: None)
+        n = len(self.student)
+        self.host = torch.zeros(n * self.rec_dtype.itemsize, dtype=torch.uint8).pin_memory()
+        self.rec = self.host.numpy().view(self.rec_dtype)
+        self._step_t = torch.tensor(0.0)
+        chunk = L.cosa_optim_chunk_elems()
+        chunks = []
+        for i, (p, tp) in enumerate(zip(self.student, self.teacher)):
+            assert p.is_contiguous() and tp.is_contiguous() and p.dtype == torch.float32 and tp.dtype == torch.float32
+            r = self.rec[i]
+            r["p"], r["tp"], r["n"] = p.data_ptr(), tp.data_ptr(), p.numel()
+            sp, st = shadow_of(p), shadow_of(tp)
+            r["p16"] = sp.data_ptr() if sp is not None else 0
+            r["t16"] = st.data_ptr() if st is not None else 0
+            if self.group_idx[i] >= 0:
+                stt = optimizer.state[p]
+                if "exp_avg" not in stt:
+                    stt["step"] = self._step_t
+                    stt["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    stt["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                r["m"], r["v"] = stt["exp_avg"].data_ptr(), stt["exp_avg_sq"].data_ptr()
+            chunks += [(i, c) for c in range((p.numel() + chunk - 1) // chunk)]
+        self.n_chunks = len(chunks)
+        self.d_chunks = torch.tensor(chunks, dtype=torch.int32, device=dev).contiguous()
+        self.d_rec = torch.empty(n * self.rec_dtype.itemsize, dtype=torch.uint8, device=dev)
+
+    def step(self):
+        opt = self.opt
+        mult = poly_warmup_lr_mult(opt.global_step, opt.warmup_iter, opt.max_iter, opt.warmup_ratio, opt.power, opt.min_mult)
+        if mult is not None:
+            for i, g in enumerate(opt.param_groups):
+                g["lr"] = opt._init_lr[i] * mult
+        groups = opt.param_groups
+        rec = self.rec
+        for i, p in enumerate(self.student):
+            gi = self.group_idx[i]
+            if gi >= 0 and p.grad is not None:
+                rec[i]["g"] = p.grad.data_ptr()
+                rec[i]["lr"] = groups[gi]["lr"]
+                rec[i]["wd"] = groups[gi]["weight_decay"]
+            else:
+                rec[i]["g"] = 0
+        self.d_rec.copy_(self.host, non_blocking=True)
+        b1, b2 = groups[0]["betas"]
+        opt.global_step += 1
+        self._step_t.fill_(float(opt.global_step))
+        _C.check(_C.lib().cosa_fused_adamw_ema(_C.ptr(self.d_rec), _C.ptr(self.d_chunks), self.n_chunks, float(b1), float(b2),
+                                               float(groups[0]["eps"]), int(opt.global_step), self.momentum, _C.stream_ptr()),
+                 "cosa_fused_adamw_ema")

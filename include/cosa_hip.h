@@ -182,6 +182,18 @@ int cosa_seg_loss_backward(const float *seg_lr, const float *maskA, const float 
 int cosa_cam_loss_targets(const float *const *seg_scales, const int *hs, const int *ws, int n_scales, const float *labels,
                           float *out, int B, int K, int S, int oh, int ow, float temperature, void *stream);
 
+/* ---------------------------------------------------------------------------------------
+ * utils/torch_helper.py:261-293 (AdamW with the scheduled LR) + main.py:250-252 (teacher EMA) + the bf16 shadow
+ * refresh, one multi-tensor pass.  `records`: device array, one per parameter tensor:
+ *   { float *p; const float *g (NULL = frozen: EMA only); float *m, *v; float *teacher; bf16 *p16, *t16 (or NULL);
+ *     float lr, wd; int64 n }   (cosa_optim_record_bytes() bytes each)
+ * `chunks`: device array of {int tensor, int chunk} covering every tensor in pieces of cosa_optim_chunk_elems().
+ * ------------------------------------------------------------------------------------- */
+size_t cosa_optim_record_bytes(void);
+int cosa_optim_chunk_elems(void);
+int cosa_fused_adamw_ema(const void *records, const void *chunks, int n_chunks, float beta1, float beta2, float eps,
+                         int step, float ema_momentum, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -211,3 +211,36 @@ def test_cam_loss_targets_vs_unfused():
     assert torch.allclose(out, ref, atol=2e-4, rtol=1e-3), (out - ref).abs().max().item()
     cam = torch.randn(B, K - 1, 8, 8, device="cuda")
     assert float(seg_helper.cam_loss_from_targets(cam, out)) == pytest.approx(float(seg_helper.cam_loss(cam, seg_helper.seg_refine_by_label(full, labels, 0.01))), rel=1e-4)
+
+
+def test_fused_adamw_ema_step_vs_torch():
+    """one multi-tensor kernel == optimizer.step() + EMA + shadow refresh (fp32 params 1e-6, shadows exact casts)"""
+    from cosa_amd import nn_ops
+    from cosa_amd.utils import torch_helper
+    torch.manual_seed(0)
+    mk = lambda: torch.nn.Sequential(torch.nn.Linear(33, 70), torch.nn.LayerNorm(70), torch.nn.Linear(70, 5)).cuda()
+    sa, ta, sb, tb = mk(), mk(), mk(), mk()
+    sb.load_state_dict(sa.state_dict()); tb.load_state_dict(ta.state_dict())
+    sa[2].bias.requires_grad = False; sb[2].bias.requires_grad = False            # a frozen tensor: EMA only
+    def opt_for(m):
+        return torch_helper.PolyWarmupAdamW([{"params": [p for p in m[0].parameters()], "lr": 6e-5, "weight_decay": 1e-2},
+                                             {"params": [p for p in list(m[1].parameters()) + [m[2].weight]], "lr": 6e-4, "weight_decay": 1e-2}],
+                                            lr=6e-5, weight_decay=1e-2, betas=(0.9, 0.999), warmup_iter=3, max_iter=100, warmup_ratio=1e-6, power=0.9)
+    oa, ob = opt_for(sa), opt_for(sb)
+    sh_s, sh_t = nn_ops.ShadowSet(sb), nn_ops.ShadowSet(tb)
+    fused = torch_helper.FusedAdamWEMAStep(ob, list(sb.parameters()), list(tb.parameters()), 0.9, shadow_of=nn_ops.shadow_of)
+    for it in range(5):
+        x = torch.randn(16, 33, device="cuda")
+        for m, o in ((sa, oa), (sb, ob)):
+            o.zero_grad(set_to_none=True)
+            m(x).square().mean().backward()
+        oa.step()
+        torch_helper.ema_update(list(ta.parameters()), list(sa.parameters()), 0.9)
+        fused.step()
+        assert oa.param_groups[1]["lr"] == pytest.approx(ob.param_groups[1]["lr"], rel=1e-12)
+    for a, b in zip(list(sa.parameters()) + list(ta.parameters()), list(sb.parameters()) + list(tb.parameters())):
+        assert torch.allclose(a, b, rtol=2e-5, atol=1e-7), (a - b).abs().max().item()
+    teacher_ids = {id(p) for p in tb.parameters()}
+    for p in list(sb.parameters()) + list(tb.parameters()):
+        if p.requires_grad or id(p) in teacher_ids:
+            assert torch.equal(nn_ops.shadow_of(p), p.detach().to(torch.bfloat16))
