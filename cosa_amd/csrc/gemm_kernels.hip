@@ -596,8 +596,8 @@ typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 __device__ __forceinline__ int tr_sw(int r) { return ((r & 3) << 2) | ((r >> 2) & 3); }
 
 __global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(const bf16 *__restrict__ dY, const bf16 *__restrict__ X,
-                                                           float *__restrict__ dW, int M, int N, int K, int tiles_k,
-                                                           int stages_per_split, int nstages)
+                                                           float *__restrict__ dW, float *__restrict__ db, int M, int N, int K,
+                                                           int tiles_k, int stages_per_split, int nstages)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // 2 stages x (dY tile 16 KB + X tile 16 KB)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -634,6 +634,10 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(const bf16 *__restri
     for (int i = 0; i < 4; i++)
 #pragma unroll
         for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // bias gradient db[n] = sum_m dY[m][n]: the dY^T fragments already hold 8 tokens of one feature per lane, so the workgroups
+    // of the first k-tile column (and their wc == 0 waves) add them up on the side (replaces a separate reduction kernel)
+    const bool do_bias = db != nullptr && tk == 0 && wc == 0;
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
 
     // fragment addressing: lane (nn = l&15, g = l>>4) supplies row 8g+4h+q (q = nn>>2), columns 4p..4p+3 (p = nn&3)
     const int nn = lane & 15, g = lane >> 4, q = nn >> 2, p = nn & 3;
@@ -667,9 +671,25 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(const bf16 *__restri
 #pragma unroll
                 for (int j = 0; j < 4; j++)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            if (do_bias) {
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+#pragma unroll
+                    for (int e = 0; e < 8; e++) bsum[i] += (float)a[i][e];
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+    }
+    if (do_bias) {
+        // lane (nn, g) holds the partial of feature wr*64 + 16i + nn over its token group g: fold the 4 groups, one atomic per feature
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            float v = bsum[i];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (g == 0) atomicAdd(&db[n0 + wr * 64 + 16 * i + nn], v);
+        }
     }
     // acc[i][j][r]: n = wr*64 + 16i + 4g + r (row), k' = wc*64 + 16j + nn (col).  Stage the fp32 tile, then 256-B atomics.
     float *Ct = reinterpret_cast<float *>(smem);          // [128][128] fp32 = 64 KB = both stages
@@ -857,7 +877,8 @@ extern "C" int cosa_layernorm(const float *x, const void *gamma, const void *bet
     return COSA_OK;
 }
 
-extern "C" int cosa_gemm_wgrad_bf16(const void *dY, const void *X, float *dW, int M, int N, int K, int zero_first, void *stream)
+extern "C" int cosa_gemm_wgrad_bf16(const void *dY, const void *X, float *dW, float *db, int M, int N, int K, int zero_first,
+                                    void *stream)
 {
     COSA_REQUIRE(dY && X && dW && M > 0 && N > 0 && K > 0, "cosa_gemm_wgrad_bf16: bad arguments");
     COSA_REQUIRE(N % 128 == 0 && K % 128 == 0, "cosa_gemm_wgrad_bf16: N and K must be multiples of 128 (got %d, %d)", N, K);
@@ -868,7 +889,10 @@ extern "C" int cosa_gemm_wgrad_bf16(const void *dY, const void *X, float *dW, in
         COSA_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
         attr_done = true;
     }
-    if (zero_first) COSA_HIP_CHECK(hipMemsetAsync(dW, 0, (size_t)N * K * sizeof(float), st));
+    if (zero_first) {
+        COSA_HIP_CHECK(hipMemsetAsync(dW, 0, (size_t)N * K * sizeof(float), st));
+        if (db) COSA_HIP_CHECK(hipMemsetAsync(db, 0, (size_t)N * sizeof(float), st));
+    }
     const int tiles = (N / 128) * (K / 128);
     const int nstages = (M + 63) / 64;
     int splits = (288 + tiles - 1) / tiles;                  // >= 1 workgroup per CU; every split costs N*K*4 B of atomics (~1.3 TB/s)
@@ -876,7 +900,7 @@ extern "C" int cosa_gemm_wgrad_bf16(const void *dY, const void *X, float *dW, in
     const int per = (nstages + splits - 1) / splits;
     splits = (nstages + per - 1) / per;
     hipLaunchKernelGGL(gemm_wgrad_kernel, dim3(tiles, splits), dim3(256), 65536, st, static_cast<const bf16 *>(dY),
-                       static_cast<const bf16 *>(X), dW, M, N, K, K / 128, per, nstages);
+                       static_cast<const bf16 *>(X), dW, db, M, N, K, K / 128, per, nstages);
     COSA_LAUNCH_CHECK();
     return COSA_OK;
 }

@@ -207,14 +207,17 @@ def _mm_f32(a, b):
     return torch.mm(a, b).float()
 
 
-def gemm_wgrad(dy2, x2):
-    """dW[N,K] fp32 = dy2[M,N]^T x2[M,K] (bf16), the TN MFMA kernel with transposing LDS reads."""
+def gemm_wgrad(dy2, x2, want_bias=False):
+    """dW[N,K] fp32 = dy2[M,N]^T x2[M,K] (bf16) and, optionally, db[N] = column sums of dy2: the TN MFMA kernel with
+    transposing LDS reads."""
     M, N = dy2.shape
     K = x2.shape[1]
     dw = torch.empty((N, K), device=dy2.device, dtype=torch.float32)
+    db = torch.empty((N,), device=dy2.device, dtype=torch.float32) if want_bias else None
     with _C.profiled("gemm_wgrad"):
-        _C.check(_C.lib().cosa_gemm_wgrad_bf16(_C.ptr(dy2), _C.ptr(x2), _C.ptr(dw), M, N, K, 1, _C.stream_ptr()), "cosa_gemm_wgrad_bf16")
-    return dw
+        _C.check(_C.lib().cosa_gemm_wgrad_bf16(_C.ptr(dy2), _C.ptr(x2), _C.ptr(dw), _C.ptr(db), M, N, K, 1, _C.stream_ptr()),
+                 "cosa_gemm_wgrad_bf16")
+    return (dw, db) if want_bias else dw
 
 
 class LinearShadowFn(Function):
@@ -232,13 +235,14 @@ class LinearShadowFn(Function):
         dy2 = dy.reshape(-1, dy.shape[-1])
         x2 = x.reshape(-1, x.shape[-1])
         dx = torch.mm(dy2, w16).view_as(x) if ctx.needs_input_grad[0] else None
-        dw = None
+        dw = db = None
         if ctx.needs_input_grad[1]:
             if dy2.shape[1] % 128 == 0 and x2.shape[1] % 128 == 0 and dy2.is_cuda:
-                dw = gemm_wgrad(dy2.contiguous(), x2.contiguous())
+                dw, db = gemm_wgrad(dy2.contiguous(), x2.contiguous(), want_bias=True)
             else:
                 dw = _mm_f32(dy2.t(), x2)
-        db = dy2.sum(0, dtype=torch.float32) if ctx.needs_input_grad[2] else None
+        if ctx.needs_input_grad[2] and db is None:
+            db = dy2.sum(0, dtype=torch.float32)
         return dx, dw, db, None, None
 
 

@@ -151,8 +151,9 @@ int cosa_attn_bwd(const void *qkv, const void *out, const void *dout, const floa
  * ------------------------------------------------------------------------------------- */
 int cosa_gemm_bf16(const void *X, const void *W, const void *bias, const float *residual, void *Y,
                    int M, int N, int K, int epilogue, void *stream);
-/* weight gradient of the same Linear: dW[N,K] (fp32) = (zero_first ? 0 : dW) + dY[M,N]^T X[M,K]  (bf16 operands) */
-int cosa_gemm_wgrad_bf16(const void *dY, const void *X, float *dW, int M, int N, int K, int zero_first, void *stream);
+/* weight (and bias) gradient of the same Linear: dW[N,K] (fp32) = (zero_first ? 0 : dW) + dY[M,N]^T X[M,K]  (bf16 operands);
+ * db[N] (fp32, optional) = (zero_first ? 0 : db) + column sums of dY                                                      */
+int cosa_gemm_wgrad_bf16(const void *dY, const void *X, float *dW, float *db, int M, int N, int K, int zero_first, void *stream);
 void cosa_gemm_set_variant(int v);   /* 0 (default): per-shape choice; 1: 128x128 2-stage; 2: 256x128 3-stage; 3: 256x256 8-wave */
 int cosa_layernorm(const float *x, const void *gamma, const void *beta, void *y_bf16, float *y_f32,
                    int rows, int dim, float eps, void *stream);
