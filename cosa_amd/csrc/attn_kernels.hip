@@ -542,7 +542,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16 *__restrict
     }
 }
 
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16 *__restrict__ qkv, const bf16 *__restrict__ dO,
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16 *__restrict__ qkv, const bf16 *__restrict__ dO,
                                                           const bf16 *__restrict__ qt, const bf16 *__restrict__ dot,
                                                           const float *__restrict__ lse, const float *__restrict__ delta,
                                                           bf16 *__restrict__ dqkv, int N, int Npad, int H, float scale)
@@ -584,48 +584,39 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16 *__restric
             dl_s[tid] = q < N ? dlb[q] : 0.f;
         }
         __syncthreads();
-        // S[q][key], dP[q][key] for two 32-query blocks (rows = queries in registers, key on the lane)
-        f32x16 s0, s1, p0, p1;
-#pragma unroll
-        for (int i = 0; i < 16; i++) { s0[i] = 0.f; s1[i] = 0.f; p0[i] = 0.f; p1[i] = 0.f; }
-#pragma unroll
-        for (int s = 0; s < 4; s++) {
-            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Qs, r, s, hh), kf[s], s0, 0, 0, 0);
-            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Qs, r + 32, s, hh), kf[s], s1, 0, 0, 0);
-            p0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(dOs, r, s, hh), vf[s], p0, 0, 0, 0);
-            p1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(dOs, r + 32, s, hh), vf[s], p1, 0, 0, 0);
-        }
+        // one 32-query block at a time (keeps S/dP to 32 registers so that two waves fit a SIMD):
+        // S[q][key], dP[q][key] (rows = queries in registers, key on the lane), then the dV^T / dK^T updates
         const bool tail = q0 + BK > N;
+#pragma unroll 1
+        for (int qb = 0; qb < 2; qb++) {
+            f32x16 s0, p0;
 #pragma unroll
-        for (int i = 0; i < 16; i++) {
-            const int qa = crow(i, hh), qc = 32 + crow(i, hh);
-            float a = __builtin_amdgcn_exp2f(s0[i] * scale_log2e - lse_s[qa]);
-            float c = __builtin_amdgcn_exp2f(s1[i] * scale_log2e - lse_s[qc]);
-            if (tail) {
-                if (q0 + qa >= N) a = 0.f;
-                if (q0 + qc >= N) c = 0.f;
+            for (int i = 0; i < 16; i++) { s0[i] = 0.f; p0[i] = 0.f; }
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Qs, r + 32 * qb, s, hh), kf[s], s0, 0, 0, 0);
+                p0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(dOs, r + 32 * qb, s, hh), vf[s], p0, 0, 0, 0);
             }
-            s0[i] = a;                                 // P
-            s1[i] = c;
-            p0[i] = a * (p0[i] - dl_s[qa]) * scale;    // dS
-            p1[i] = c * (p1[i] - dl_s[qc]) * scale;
-        }
 #pragma unroll
-        for (int qb = 0; qb < 2; qb++)
+            for (int i = 0; i < 16; i++) {
+                const int qa = 32 * qb + crow(i, hh);
+                float a = __builtin_amdgcn_exp2f(s0[i] * scale_log2e - lse_s[qa]);
+                if (tail && q0 + qa >= N) a = 0.f;
+                s0[i] = a;                                 // P
+                p0[i] = a * (p0[i] - dl_s[qa]) * scale;    // dS
+            }
 #pragma unroll
             for (int sp = 0; sp < 2; sp++) {
                 bf16x8 pf, df;
 #pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    pf[j] = (bf16)(qb == 0 ? s0[8 * sp + j] : s1[8 * sp + j]);
-                    df[j] = (bf16)(qb == 0 ? p0[8 * sp + j] : p1[8 * sp + j]);
-                }
+                for (int j = 0; j < 8; j++) { pf[j] = (bf16)s0[8 * sp + j]; df[j] = (bf16)p0[8 * sp + j]; }
                 const int tokb = qb * 32 + 16 * sp + 4 * hh;
                 dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(dOts, r, tokb), pf, dv0, 0, 0, 0);
                 dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(dOts, r + 32, tokb), pf, dv1, 0, 0, 0);
                 dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(Qts, r, tokb), df, dk0, 0, 0, 0);
                 dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(Qts, r + 32, tokb), df, dk1, 0, 0, 0);
             }
+        }
     }
     const int key = key0 + r;
     if (key < N) {
