@@ -170,10 +170,17 @@ def main():
         n_launch, secs, flops = nn_ops.stamps.read()
         ev_n, ev_ms = prof.get("attn_fwd", (0, 0.0))     # HIP events around the eager (student) launches, for comparison
         roof = None
+        traffic = None
+        try:        # HBM bytes of the dominant launch shape from the committed PMC passes (profiles/, separate --pmc runs)
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_attn_fwd_pmc.json")))
+            traffic = {"hbm_bytes": pmc["hbm_bytes_per_launch"], "algorithmic_bytes": pmc["algorithmic_bytes_per_launch"],
+                       "launch": f"B={pmc['B']} N={pmc['N']} H={pmc['H']}", "source": "profiles/r01_attn_fwd_pmc.json"}
+        except Exception:
+            pass
         if n_launch:
             ach = flops / secs / 1e12
-            roof = {"kernel": "attn_fwd_kernel", "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16 / 1e12,
-                    "unit": "TFLOP/s", "frac": round(ach * 1e12 / PEAK_BF16, 4), "traffic": None,
+            roof = {"kernel": "attn_fwd_kernel / attn_fwd2_kernel (fused attention forward)", "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16 / 1e12,
+                    "unit": "TFLOP/s", "frac": round(ach * 1e12 / PEAK_BF16, 4), "traffic": traffic,
                     "launches": n_launch, "avg_launch_ms": round(secs * 1e3 / n_launch, 4),
                     "share_of_step": round(secs / (dt / opt.steps), 4), "timer": "device s_memrealtime spans, last timed step",
                     "hip_event_avg_ms_eager_launches": round(ev_ms / ev_n, 4) if ev_n else None}
