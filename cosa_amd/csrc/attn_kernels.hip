@@ -15,6 +15,7 @@
 // exponentiated tile is already the B operand of O^T = V^T P^T (no LDS round trip, no shuffles),
 // and the O rescale / final 1/l are lane-local.
 #include "kernels.hpp"
+#include <type_traits>
 
 namespace cosa {
 namespace {
@@ -103,7 +104,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16 *__restrict__ 
     } while (0)
     COSA_LOAD_TILE(0);
     const float NEG_INF = -INFINITY;
-    for (int k0 = 0; k0 < N; k0 += BK) {
+    auto tile = [&](int k0, auto tail_tag) {
+        constexpr bool tail = decltype(tail_tag)::value;
         __syncthreads();
         *reinterpret_cast<uint4 *>(Ks + row_a * 128 + ((slot_s ^ ((row_a >> 1) & 7)) << 4)) = kreg0;
         *reinterpret_cast<uint4 *>(Ks + row_b * 128 + ((slot_s ^ ((row_b >> 1) & 7)) << 4)) = kreg1;
@@ -129,7 +131,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16 *__restrict__ 
             s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, qf[s], s1, 0, 0, 0);
         }
         // online softmax with the query on the lane; raw-score max, scale folded into the exp2 argument (one fma)
-        if (k0 + BK > N) {
+        if constexpr (tail) {
 #pragma unroll
             for (int i = 0; i < 16; i++) {
                 if (k0 + crow(i, hh) >= N) s0[i] = NEG_INF;
@@ -180,7 +182,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16 *__restrict__ 
                 }
             }
         }
-    }
+    };
+    const int nfull = (N / BK) * BK;
+    for (int k0 = 0; k0 < nfull; k0 += BK) tile(k0, std::false_type{});
+    if (nfull < N) tile(nfull, std::true_type{});
 #undef COSA_LOAD_TILE
     // finish: combine the two half-lane partial sums, normalise, store O (d = db*32 + crow(i,hh)) and LSE
     l += __shfl_xor(l, 32, 64);
@@ -245,7 +250,8 @@ __global__ __launch_bounds__(128, 2) void attn_fwd2_kernel(const bf16 *__restric
     // 128 threads stage 512 + 512 16-byte chunks per tile (4 + 4 per thread).  No register prefetch here: four of these
     // workgroups share a CU, so another workgroup computes while this one waits for its tile.
     const int srow = tid >> 3, sslot = tid & 7;          // chunk c = tid + 128*i -> row srow + 16*i, slot sslot
-    for (int k0 = 0; k0 < N; k0 += BK) {
+    auto tile = [&](int k0, auto tail_tag) {
+        constexpr bool tail = decltype(tail_tag)::value;
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < 4; i++) {
@@ -277,10 +283,9 @@ __global__ __launch_bounds__(128, 2) void attn_fwd2_kernel(const bf16 *__restric
                 sc[u][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, qf[u][s], sc[u][1], 0, 0, 0);
             }
         }
-        const bool tail = k0 + BK > N;
 #pragma unroll
         for (int u = 0; u < 2; u++) {
-            if (tail) {
+            if constexpr (tail) {
 #pragma unroll
                 for (int i = 0; i < 16; i++) {
                     if (k0 + crow(i, hh) >= N) sc[u][0][i] = -INFINITY;
@@ -333,7 +338,10 @@ __global__ __launch_bounds__(128, 2) void attn_fwd2_kernel(const bf16 *__restric
                     o[u][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, pf, o[u][1], 0, 0, 0);
                 }
             }
-    }
+    };
+    const int nfull = (N / BK) * BK;
+    for (int k0 = 0; k0 < nfull; k0 += BK) tile(k0, std::false_type{});
+    if (nfull < N) tile(nfull, std::true_type{});
 #pragma unroll
     for (int u = 0; u < 2; u++) {
         float lt = l[u] + __shfl_xor(l[u], 32, 64);
@@ -488,7 +496,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16 *__restrict
     const bf16 *vbase = qkv + (size_t)b * N * rs + (size_t)2 * H * HD + h * HD;
     const bf16 *ktbase = kt + ((size_t)b * H + h) * HD * Npad;
 
-    for (int k0 = 0; k0 < N; k0 += BK) {
+    auto tile = [&](int k0, auto tail_tag) {
+        constexpr bool tail = decltype(tail_tag)::value;
         __syncthreads();
         stage_rows(Ks, kbase, rs, k0, N, tid);
         stage_rows(Vsr, vbase, rs, k0, N, tid);
@@ -504,12 +513,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16 *__restrict
             p0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Vsr, r, s, hh), dof[s], p0, 0, 0, 0);
             p1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Vsr, r + 32, s, hh), dof[s], p1, 0, 0, 0);
         }
-        const bool tail = k0 + BK > N;
 #pragma unroll
         for (int i = 0; i < 16; i++) {
             float a = __builtin_amdgcn_exp2f(s0[i] * scale_log2e - lse2);
             float c = __builtin_amdgcn_exp2f(s1[i] * scale_log2e - lse2);
-            if (tail) {
+            if constexpr (tail) {
                 if (k0 + crow(i, hh) >= N) a = 0.f;
                 if (k0 + 32 + crow(i, hh) >= N) c = 0.f;
             }
@@ -527,7 +535,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16 *__restrict
                 g0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(Kts, r, keyb), df, g0, 0, 0, 0);
                 g1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(Kts, r + 32, keyb), df, g1, 0, 0, 0);
             }
-    }
+    };
+    const int nfull = (N / BK) * BK;
+    for (int k0 = 0; k0 < nfull; k0 += BK) tile(k0, std::false_type{});
+    if (nfull < N) tile(nfull, std::true_type{});
     const int q = q0 + r;
     if (q < N) {
         bf16 *op = dqkv + ((size_t)b * N + q) * rs + h * HD;
@@ -572,7 +583,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16 *__rest
     const float *lseb = lse + ((size_t)b * H + h) * N;
     const float *dlb = delta + ((size_t)b * H + h) * N;
 
-    for (int q0 = 0; q0 < N; q0 += BK) {
+    auto tile = [&](int q0, auto tail_tag) {
+        constexpr bool tail = decltype(tail_tag)::value;
         __syncthreads();
         stage_rows(Qs, qbase, rs, q0, N, tid);
         stage_rows(dOs, dobase, (size_t)H * HD, q0, N, tid);
@@ -586,7 +598,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16 *__rest
         __syncthreads();
         // one 32-query block at a time (keeps S/dP to 32 registers so that two waves fit a SIMD):
         // S[q][key], dP[q][key] (rows = queries in registers, key on the lane), then the dV^T / dK^T updates
-        const bool tail = q0 + BK > N;
 #pragma unroll 1
         for (int qb = 0; qb < 2; qb++) {
             f32x16 s0, p0;
@@ -601,7 +612,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16 *__rest
             for (int i = 0; i < 16; i++) {
                 const int qa = 32 * qb + crow(i, hh);
                 float a = __builtin_amdgcn_exp2f(s0[i] * scale_log2e - lse_s[qa]);
-                if (tail && q0 + qa >= N) a = 0.f;
+                if constexpr (tail) { if (q0 + qa >= N) a = 0.f; }
                 s0[i] = a;                                 // P
                 p0[i] = a * (p0[i] - dl_s[qa]) * scale;    // dS
             }
@@ -617,7 +628,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16 *__rest
                 dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(Qts, r + 32, tokb), df, dk1, 0, 0, 0);
             }
         }
-    }
+    };
+    const int nfull = (N / BK) * BK;
+    for (int q0 = 0; q0 < nfull; q0 += BK) tile(q0, std::false_type{});
+    if (nfull < N) tile(nfull, std::true_type{});
     const int key = key0 + r;
     if (key < N) {
         bf16 *okp = dqkv + ((size_t)b * N + key) * rs + (size_t)H * HD + h * HD;
