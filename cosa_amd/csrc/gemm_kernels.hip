@@ -400,11 +400,13 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v3_kernel(const bf16 *__rest
                 const int row = i * 16 + frow;
                 a[i] = *reinterpret_cast<const bf16x8 *>(At + row * 128 + (((fq + 4 * ks) ^ (row & 7)) << 4));
             }
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < 8; i++)
 #pragma unroll
                 for (int j = 0; j < 4; j++)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -706,6 +708,126 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(const bf16 *__restri
     }
 }
 
+
+// =====================================================================================================
+// LargeFOV 3x3 dilated convolution (models/decoder/conv_head.py:11-41: 768->512 and 512->512, dilation 5, padding 5,
+// no bias, ReLU) as an implicit GEMM on NHWC tokens:   Y[m, n] = relu( sum_t sum_c X[src(m,t), c] * Wt[t][n][c] ).
+// Same 128x128x64 MFMA tile as gemm_bf16_kernel; the K loop runs over 9 taps x Cin/64 chunks.  The activation rows of a
+// tap are the token rows shifted by (dy*w + dx); out-of-image taps must contribute zero, which the buffer bounds check
+// gives for free: those lanes get an offset past num_records and buffer_load ... lds writes zeros.  The per-lane row
+// offsets are recomputed once per tap (9 times per tile), the channel chunk moves through the scalar offset.
+// X may be a strided view: image b starts at row b*img_rows + row_off of a [*, ldx] matrix (tokens without the cls row).
+// =====================================================================================================
+__global__ __launch_bounds__(256, 2) void conv3x3_dil_kernel(const bf16 *__restrict__ X, const bf16 *__restrict__ Wt,
+                                                            bf16 *__restrict__ Y, int B, int h, int w, int Cin, int Cout,
+                                                            int dil, int img_rows, int row_off, int ldx, int relu,
+                                                            long long x_bytes, int tiles_n)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int M = B * h * w;
+    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
+    const int m0 = tm * 128, n0 = tn * 128;
+    const int wr = wave >> 1, wc = wave & 1;
+    __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void *)X, 0, (int)x_bytes, 0x00020000);
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // the 4 activation rows this lane stages per K-step, decomposed once
+    int rb[4], ry[4], rx[4], slot_sw[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int row = 8 * (wave * 4 + i) + (lane >> 3);
+        int m = m0 + row;
+        const bool ok = m < M;
+        m = ok ? m : 0;
+        const int b = m / (h * w), pix = m - b * h * w;
+        rb[i] = ok ? b * img_rows + row_off : -1;
+        ry[i] = pix / w;
+        rx[i] = pix - ry[i] * w;
+        slot_sw[i] = ((lane & 7) ^ (row & 7)) * 8;
+    }
+    int vo[4];
+    auto tap_offsets = [&](int t) {
+        const int dy = (t / 3 - 1) * dil, dx = (t % 3 - 1) * dil;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int yy = ry[i] + dy, xx = rx[i] + dx;
+            const bool ok = rb[i] >= 0 && yy >= 0 && yy < h && xx >= 0 && xx < w;
+            vo[i] = ok ? ((rb[i] + yy * w + xx) * ldx + slot_sw[i]) * 2 : 0x7ffffff0;     // past num_records -> zeros
+        }
+    };
+    const int kc = Cin / BK;                 // channel chunks per tap
+    const int nk = 9 * kc;
+    auto stage = [&](int t, int c0, unsigned char *buf) {
+        // weights: plain DMA of Wt[t][n0 .. n0+127][c0 .. c0+63]
+        stage_tile(Wt + (size_t)t * Cout * Cin, n0, Cout, Cin, c0, buf, wave, lane);
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_void *)(buf + TILE_BYTES + (wave * 4 + i) * 1024), 16, vo[i], c0 * 2, 0, 0);
+    };
+    tap_offsets(0);
+    stage(0, 0, smem);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int frow = lane & 15, fq = lane >> 4;
+    int tn_ = 0, cn_ = 0;                    // tap / channel offset of the NEXT stage to load
+    for (int ks = 0; ks < nk; ks++) {
+        unsigned char *cur = smem + (ks & 1) * STAGE_BYTES;
+        if (ks + 1 < nk) {
+            cn_ += BK;
+            if (cn_ == Cin) { cn_ = 0; tn_++; tap_offsets(tn_); }
+            stage(tn_, cn_, smem + ((ks + 1) & 1) * STAGE_BYTES);
+        }
+        const unsigned char *At = cur + (wr * 64) * 128;
+        const unsigned char *Bt = cur + TILE_BYTES + (wc * 64) * 128;
+#pragma unroll
+        for (int kk = 0; kk < 2; kk++) {
+            bf16x8 a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int row = i * 16 + frow;
+                const int slot = ((fq + 4 * kk) ^ (row & 7)) << 4;
+                a[i] = *reinterpret_cast<const bf16x8 *>(At + row * 128 + slot);
+                b[i] = *reinterpret_cast<const bf16x8 *>(Bt + row * 128 + slot);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    unsigned char *Ct = smem;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int nl = wr * 64 + 16 * i + 4 * fq;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int ml = wc * 64 + 16 * j + frow;
+            bf16x4 v;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                float t = acc[i][j][r];
+                if (relu) t = t > 0.f ? t : 0.f;
+                v[r] = (bf16)t;
+            }
+            *reinterpret_cast<bf16x4 *>(Ct + ml * CT_LD + nl * 2) = v;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = tid; c < BM * 16; c += 256) {
+        const int ml = c >> 4, s2 = c & 15;
+        if (m0 + ml < M)
+            *reinterpret_cast<uint4 *>(Y + (size_t)(m0 + ml) * Cout + n0 + s2 * 8) = *reinterpret_cast<const uint4 *>(Ct + ml * CT_LD + s2 * 16);
+    }
+}
+
 constexpr size_t kLdsBytes = 128 * (BN * 4 + 16) > 2 * STAGE_BYTES ? 128 * (BN * 4 + 16) : 2 * STAGE_BYTES;
 
 // ---- LayerNorm: fp32 residual stream in, bf16 out; one wave per 768-wide row ---------------------------
@@ -901,6 +1023,28 @@ extern "C" int cosa_gemm_wgrad_bf16(const void *dY, const void *X, float *dW, fl
     splits = (nstages + per - 1) / per;
     hipLaunchKernelGGL(gemm_wgrad_kernel, dim3(tiles, splits), dim3(256), 65536, st, static_cast<const bf16 *>(dY),
                        static_cast<const bf16 *>(X), dW, db, M, N, K, K / 128, per, nstages);
+    COSA_LAUNCH_CHECK();
+    return COSA_OK;
+}
+
+extern "C" int cosa_conv3x3_dilated_nhwc(const void *X, const void *Wt, void *Y, int B, int h, int w, int Cin, int Cout, int dilation,
+                                         int img_rows, int row_off, int ldx, int relu, void *stream)
+{
+    COSA_REQUIRE(X && Wt && Y && B > 0 && h > 0 && w > 0 && dilation > 0, "cosa_conv3x3_dilated_nhwc: bad arguments");
+    COSA_REQUIRE(Cin % 64 == 0 && Cout % 128 == 0, "cosa_conv3x3_dilated_nhwc: Cin %% 64 and Cout %% 128 must be 0");
+    COSA_REQUIRE(img_rows >= h * w + row_off && ldx >= Cin, "cosa_conv3x3_dilated_nhwc: bad view geometry");
+    const long long x_bytes = (long long)B * img_rows * ldx * 2;
+    COSA_REQUIRE(x_bytes < 0x7ffffff0ll, "cosa_conv3x3_dilated_nhwc: activation view beyond 2 GiB");
+    static bool attr_done = false;
+    if (!attr_done) {
+        COSA_HIP_CHECK(hipFuncSetAttribute((const void *)conv3x3_dil_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes));
+        attr_done = true;
+    }
+    const int M = B * h * w;
+    const int tiles_m = (M + 127) / 128, tiles_n = Cout / 128;
+    hipLaunchKernelGGL(conv3x3_dil_kernel, dim3(tiles_m * tiles_n), dim3(256), kLdsBytes, as_stream(stream), static_cast<const bf16 *>(X),
+                       static_cast<const bf16 *>(Wt), static_cast<bf16 *>(Y), B, h, w, Cin, Cout, dilation, img_rows, row_off, ldx, relu,
+                       x_bytes, tiles_n);
     COSA_LAUNCH_CHECK();
     return COSA_OK;
 }

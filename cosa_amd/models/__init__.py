@@ -24,6 +24,16 @@ class LargeFOV(nn.Module):
         self.conv7 = nn.Conv2d(self.embed_dim, self.embed_dim, 3, padding=dilation, dilation=dilation, bias=False)
         self.conv8 = nn.Conv2d(self.embed_dim, out_planes, 1, bias=False)
 
+    def forward_tokens(self, tok, B, h, w):
+        """no-grad bf16 path: both dilated convs as implicit-GEMM MFMA kernels on the NHWC tokens, conv8 as a bare GEMM.
+        tok [B, h*w, 768] bf16 (may be the strided `tokens[:, 1:]` view) -> seg [B, classes, h, w] fp32"""
+        c = nn_ops.cast_param
+        y = nn_ops.conv3x3_dilated_tokens(tok, c(self.conv6.weight, torch.bfloat16), B, h, w, self.dilation, relu=True)
+        y = nn_ops.conv3x3_dilated_tokens(y.view(B, h * w, -1), c(self.conv7.weight, torch.bfloat16), B, h, w, self.dilation, relu=True)
+        w8 = c(self.conv8.weight, torch.bfloat16).reshape(self.conv8.weight.shape[0], -1)
+        seg = F.linear(y, w8).float()
+        return seg.view(B, h, w, -1).permute(0, 3, 1, 2).contiguous()
+
     def forward_nhwc(self, x, dt):
         """x: [B,C,h,w] view with channels-last strides (tokens are NHWC already)."""
         c = nn_ops.cast_param
@@ -104,7 +114,10 @@ class VITNetwork(nn.Module):
         p = self.encoder.patch_size
         h, w = x.shape[-2] // p, x.shape[-1] // p
         x4 = tok.reshape(B, h, w, -1).permute(0, 3, 1, 2)            # NCHW view, channels-last strides (no copy)
-        seg = self.decoder.forward_nhwc(x4, dt).float().contiguous()
+        if tok32 is not None and tok.dtype == torch.bfloat16 and self.decoder.conv6.weight.shape[1] % 64 == 0:
+            seg = self.decoder.forward_tokens(tok, B, h, w)            # fused no-grad path: own implicit-GEMM convs
+        else:
+            seg = self.decoder.forward_nhwc(x4, dt).float().contiguous()
         if seg_only:
             return seg
         cam = self._cam(tok if tok32 is None else tok32, self.classifier.weight, B, h, w, detach == 'feat', detach == 'cls')

@@ -131,6 +131,24 @@ def gemm_bf16(x, w, b, epilogue=EPI_BIAS, residual=None, out=None):
     return out
 
 
+def conv3x3_dilated_tokens(tok, w16, B, h, w, dilation, relu=True):
+    """LargeFOV conv on NHWC tokens through the implicit-GEMM MFMA kernel (no MIOpen).  tok: [B, h*w, Cin] bf16, possibly a
+    row-strided view (stride(1) == Cin-dim leading size, e.g. the encoder tokens without their cls row);
+    w16: [Cout, Cin, 3, 3] bf16.  Returns [B*h*w, Cout] bf16."""
+    Cout, Cin = w16.shape[0], w16.shape[1]
+    assert tok.dtype == torch.bfloat16 and tok.stride(2) == 1 and tok.shape[1] == h * w and tok.shape[2] == Cin
+    ldx = tok.stride(1)
+    img_rows = tok.stride(0) // ldx if B > 1 else h * w
+    assert B == 1 or tok.stride(0) == img_rows * ldx
+    wt = w16.permute(2, 3, 0, 1).reshape(9, Cout, Cin).contiguous()
+    y = torch.empty((B * h * w, Cout), device=tok.device, dtype=torch.bfloat16)
+    with _C.profiled("conv3x3"):
+        _C.check(_C.lib().cosa_conv3x3_dilated_nhwc(_C.ptr(tok), _C.ptr(wt), _C.ptr(y), B, h, w, Cin, Cout, int(dilation), img_rows, 0,
+                                                    ldx, int(relu), _C.stream_ptr()), "cosa_conv3x3_dilated_nhwc")
+    _flops["conv3x3"] = _flops.get("conv3x3", 0) + 2.0 * B * h * w * Cout * Cin * 9
+    return y
+
+
 def layernorm_f32(x, g, b, eps, want_bf16=True, want_f32=False):
     """x [rows,768] fp32 -> (bf16 | None, fp32 | None)"""
     rows, D = x.shape

@@ -154,6 +154,11 @@ int cosa_gemm_bf16(const void *X, const void *W, const void *bias, const float *
 /* weight (and bias) gradient of the same Linear: dW[N,K] (fp32) = (zero_first ? 0 : dW) + dY[M,N]^T X[M,K]  (bf16 operands);
  * db[N] (fp32, optional) = (zero_first ? 0 : db) + column sums of dY                                                      */
 int cosa_gemm_wgrad_bf16(const void *dY, const void *X, float *dW, float *db, int M, int N, int K, int zero_first, void *stream);
+/* models/decoder/conv_head.py:11-41  LargeFOV's 3x3 dilated, bias-free convolution on NHWC tokens (implicit GEMM, optional ReLU):
+ *   X: image b = rows [b*img_rows + row_off, +h*w) of a [*, ldx] bf16 matrix (so the token tensor minus its cls row needs no copy)
+ *   Wt [9][Cout][Cin] bf16 (tap-major: t = ky*3 + kx);  Y [B*h*w, Cout] bf16;  padding = dilation                               */
+int cosa_conv3x3_dilated_nhwc(const void *X, const void *Wt, void *Y, int B, int h, int w, int Cin, int Cout, int dilation,
+                              int img_rows, int row_off, int ldx, int relu, void *stream);
 void cosa_gemm_set_variant(int v);   /* 0 (default): per-shape choice; 1: 128x128 2-stage; 2: 256x128 3-stage; 3: 256x256 8-wave */
 int cosa_layernorm(const float *x, const void *gamma, const void *beta, void *y_bf16, float *y_f32,
                    int rows, int dim, float eps, void *stream);

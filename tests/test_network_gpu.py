@@ -244,3 +244,18 @@ def test_fused_adamw_ema_step_vs_torch():
     for p in list(sb.parameters()) + list(tb.parameters()):
         if p.requires_grad or id(p) in teacher_ids:
             assert torch.equal(nn_ops.shadow_of(p), p.detach().to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("B,h,w,Cin,Cout", [(2, 28, 28, 768, 512), (3, 9, 14, 128, 128), (1, 5, 5, 64, 256)])
+def test_dilated_conv_implicit_gemm_vs_torch(B, h, w, Cin, Cout):
+    """LargeFOV conv kernel (NHWC tokens incl. a strided view without the cls row) vs F.conv2d in fp32 on the same bf16 data"""
+    import torch.nn.functional as F
+    from cosa_amd import nn_ops
+    torch.manual_seed(0)
+    base = torch.randn(B, h * w + 1, Cin, device="cuda").to(torch.bfloat16)
+    tok = base[:, 1:]                                            # strided view, as the encoder hands it over
+    wgt = (torch.randn(Cout, Cin, 3, 3, device="cuda") * 0.02).to(torch.bfloat16)
+    y = nn_ops.conv3x3_dilated_tokens(tok, wgt, B, h, w, 5, relu=True).view(B, h, w, Cout).permute(0, 3, 1, 2).float()
+    x = tok.float().reshape(B, h, w, Cin).permute(0, 3, 1, 2)
+    ref = F.relu(F.conv2d(x, wgt.float(), padding=5, dilation=5))
+    assert (y - ref).abs().max().item() <= 1e-2 * ref.abs().max().item() + 1e-3
