@@ -122,11 +122,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    ndev = torch.cuda.device_count()
+    local = local % ndev                  # (rehearsals put several ranks on one card; a real node has one rank per GPU)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)          # "nccl" == RCCL on ROCm
+        backend = os.environ.get("COSA_DIST_BACKEND", "nccl")   # "nccl" == RCCL on ROCm; gloo only for single-card rehearsals
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from cosa_amd import _C, nn_ops
     from cosa_amd.train_step import CoSATrainer, default_args, rank_seed, synthetic_batch
