@@ -579,6 +579,249 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v4_kernel(const bf16 *__rest
     }
 }
 
+
+// =====================================================================================================
+// v5: 256 x 256 x 64 tile, 8 waves, FOUR-PHASE-PER-K-TILE ping-pong schedule (MI355X guide, "256^2 8-phase").
+//
+// Each operand K-tile is two 16-KB half-tiles (128 rows x 64 k): X0 | W0 | X1 | W1, two K-tiles deep = 128 KB of LDS.
+// Wave (wr, wc) = (wave >> 2, wave & 3) owns features  n0 + {0,128} + wr*64 + [0,64)  and tokens
+// m0 + {0,128} + wc*32 + [0,32): one 64-row quarter of EACH W half and one 32-row quarter of EACH X half, so every
+// half-tile is read in exactly one phase of the K-tile by all waves and can be refilled right after it:
+//     phase 1: read X0 (4 ds_read_b128) + W0 (8)   | MFMA W0 x X0 | refill  W1 of tile t+1
+//     phase 2: read X1 (4)                         | MFMA W0 x X1 | refill  X0 of tile t+2
+//     phase 3: read W1 (8)                         | MFMA W1 x X1 | refill  W0 of tile t+2
+//     phase 4: (X0 fragments still in registers)   | MFMA W1 x X0 | refill  X1 of tile t+2, s_waitcnt vmcnt(6)
+// Every phase is  [reads + 2 LDS-DMA pieces]  barrier  [16 MFMAs]  barrier, and the wr = 1 waves run one barrier behind
+// the wr = 0 waves: the two waves that share a SIMD alternate between the read section and the MFMA section, so the
+// matrix pipe always has one of them.  The DMA stream runs 7 half-tiles ahead of the reads; the only vmcnt wait is the
+// counted one in phase 4 (3 half-tiles = 6 loads stay in flight), and a buffer is read no earlier than one phase
+// after the barrier that follows that wait (two barriers: the staggered group waits one barrier later).
+// Rows past M come back as zeros from the buffer range check; K-tiles past K are "loaded" from an out-of-range
+// offset (no memory traffic) so that the vmcnt arithmetic is the same in the last tiles.
+// =====================================================================================================
+constexpr int V5_HALF = 16384;
+constexpr int V5_BUF = 4 * V5_HALF;                    // X0 | W0 | X1 | W1
+constexpr size_t kLdsBytesV5 = 2 * V5_BUF;             // 128 KB; also holds the 256 x 272-byte epilogue half-tile
+
+#define V5_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define V5_BARRIER()                          \
+    do {                                      \
+        V5_FENCE();                           \
+        if (!(ABL & 4)) __builtin_amdgcn_s_barrier(); \
+        V5_FENCE();                           \
+    } while (0)
+
+template <int EPI, int ABL = 0>      // ABL: timing ablations only (1 no DMA in the loop, 2 no fragment reads, 4 no barriers) -- wrong results
+__global__ __launch_bounds__(512, 1) void gemm_bf16_v5_kernel(const bf16 *__restrict__ X, const bf16 *__restrict__ W,
+                                                             const bf16 *__restrict__ bias, const float *__restrict__ R,
+                                                             void *__restrict__ Yv, int M, int N, int K, int tiles_m, int tiles_n)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int nwg = tiles_m * tiles_n;
+    int wg = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7, idx = wg >> 3;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tm = wg / tiles_n, tn = wg - tm * tiles_n;
+    const int m0 = tm * 256, n0 = tn * 256;
+    const int wr = wave >> 2, wc = wave & 3;
+    const int frow = lane & 15, fq = lane >> 4;
+    const int nk = K / BK;
+
+    __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void *)X, 0, (int)((size_t)M * K * 2), 0x00020000);
+    __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void *)W, 0, (int)((size_t)N * K * 2), 0x00020000);
+    // LDS-DMA: this wave fills the 1-KiB pieces 2*wave and 2*wave+1 (8 rows each) of every half-tile; the XOR swizzle
+    // (16-B slot ^ (row & 7)) is applied to the per-lane source offset because the LDS image of a piece is lane-linear
+    unsigned voX[2][2], voW[2][2];
+    {
+        const int sw = ((lane & 7) ^ (lane >> 3)) * 8;
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                const int row = h * 128 + 8 * (2 * wave + i) + (lane >> 3);
+                voX[h][i] = (unsigned)(((m0 + row) * K + sw) * 2);     // rows >= M are past num_records -> zeros
+                voW[h][i] = (unsigned)(((n0 + row) * K + sw) * 2);
+            }
+    }
+    // which: 0 X0, 1 W0, 2 X1, 3 W1
+#define V5_STAGE(which, kt, bsel)                                                                                          \
+    if (!(ABL & 1) || (kt) < 2) {                                                                                          \
+        const int kt_ = (kt);                                                                                              \
+        const bool ok_ = kt_ < nk;                                                                                         \
+        unsigned char *dst_ = smem + (bsel) * V5_BUF + (which) * V5_HALF + (2 * wave) * 1024;                              \
+        const unsigned v0_ = ok_ ? (((which) & 1) ? voW[(which) >> 1][0] : voX[(which) >> 1][0]) : 0x7ffffff0u;            \
+        const unsigned v1_ = ok_ ? (((which) & 1) ? voW[(which) >> 1][1] : voX[(which) >> 1][1]) : 0x7ffffff0u;            \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(((which) & 1) ? rsW : rsX, (lds_void *)dst_, 16, v0_, kt_ * 128, 0, 0);   \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(((which) & 1) ? rsW : rsX, (lds_void *)(dst_ + 1024), 16, v1_, kt_ * 128, 0, 0); \
+    }
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // prologue: 7 half-tiles (tile 0 complete + X0, W0, X1 of tile 1), then tile 0 must have landed
+    V5_STAGE(0, 0, 0);
+    V5_STAGE(1, 0, 0);
+    V5_STAGE(2, 0, 0);
+    V5_STAGE(3, 0, 0);
+    V5_STAGE(0, 1, 1);
+    V5_STAGE(1, 1, 1);
+    V5_STAGE(2, 1, 1);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    V5_BARRIER();
+    if (wr == 1) V5_BARRIER();                         // stagger: the wr = 1 group runs one barrier behind
+
+    // fragment addressing inside a half-tile: row = quarter base + 16*blk + frow, 16-B slot (fq + 4*ks) ^ (row & 7)
+    const int lo0 = frow * 128 + ((fq ^ (frow & 7)) << 4);
+    const int lo1 = lo0 ^ 64;                                          // ks = 1
+    const unsigned char *rdW0 = smem + V5_HALF + wr * 8192 + lo0, *rdW1 = smem + V5_HALF + wr * 8192 + lo1;
+    const unsigned char *rdX0 = smem + wc * 4096 + lo0, *rdX1 = smem + wc * 4096 + lo1;
+    bf16x8 a[4][2], x0[2][2], x1[2][2];
+    if (ABL & 2) {
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                a[i][k] = (bf16x8){};
+                x0[i & 1][k] = (bf16x8){};
+                x1[i & 1][k] = (bf16x8){};
+                asm volatile("" : "+v"(a[i][k]), "+v"(x0[i & 1][k]), "+v"(x1[i & 1][k]));
+            }
+    }
+
+#define V5_LDW(q, buf)                                                                                             \
+    if (!(ABL & 2)) _Pragma("unroll") for (int blk = 0; blk < 4; blk++) {                                                          \
+        const int o_ = (buf) * V5_BUF + (q) * 2 * V5_HALF + blk * 2048;                                            \
+        a[blk][0] = *reinterpret_cast<const bf16x8 *>(rdW0 + o_);                                                  \
+        a[blk][1] = *reinterpret_cast<const bf16x8 *>(rdW1 + o_);                                                  \
+    }
+#define V5_LDX(dst, q, buf)                                                                                        \
+    if (!(ABL & 2)) _Pragma("unroll") for (int blk = 0; blk < 2; blk++) {                                                          \
+        const int o_ = (buf) * V5_BUF + (q) * 2 * V5_HALF + blk * 2048;                                            \
+        dst[blk][0] = *reinterpret_cast<const bf16x8 *>(rdX0 + o_);                                                \
+        dst[blk][1] = *reinterpret_cast<const bf16x8 *>(rdX1 + o_);                                                \
+    }
+#define V5_MMA(qa, xf, qb)                                                                                         \
+    do {                                                                                                           \
+        V5_FENCE();                                                                                                \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                         \
+        __builtin_amdgcn_s_setprio(1);                                                                             \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ks++)                                                           \
+            _Pragma("unroll") for (int i = 0; i < 4; i++)                                                          \
+                _Pragma("unroll") for (int j = 0; j < 2; j++)                                                      \
+                    acc[(qa) * 4 + i][(qb) * 2 + j] =                                                              \
+                        __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][ks], xf[j][ks], acc[(qa) * 4 + i][(qb) * 2 + j], 0, 0, 0); \
+        __builtin_amdgcn_s_setprio(0);                                                                             \
+    } while (0)
+
+    for (int t = 0; t < nk; t++) {
+        const int b = t & 1;
+        // ---- phase 1 ----
+        V5_LDX(x0, 0, b);
+        V5_FENCE();
+        V5_LDW(0, b);
+        V5_STAGE(3, t + 1, b ^ 1);
+        V5_FENCE();
+        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");       // the X0 reads (issued first) are done: X0 may be refilled in phase 2
+        V5_BARRIER();
+        V5_MMA(0, x0, 0);
+        V5_BARRIER();
+        // ---- phase 2 ----
+        V5_LDX(x1, 1, b);
+        V5_STAGE(0, t + 2, b);
+        V5_BARRIER();
+        V5_MMA(0, x1, 1);
+        V5_BARRIER();
+        // ---- phase 3 ----
+        V5_LDW(1, b);
+        V5_STAGE(1, t + 2, b);
+        V5_BARRIER();
+        V5_MMA(1, x1, 1);
+        V5_BARRIER();
+        // ---- phase 4 ----
+        V5_STAGE(2, t + 2, b);
+        V5_FENCE();
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");         // everything but the 3 newest half-tiles: tile t+1 has landed
+        V5_BARRIER();
+        V5_MMA(1, x0, 0);
+        V5_BARRIER();
+    }
+    if (wr == 0) V5_BARRIER();                         // re-align the two groups
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the out-of-range tail "loads" still write (zeros to) LDS
+    __syncthreads();
+#undef V5_STAGE
+#undef V5_LDW
+#undef V5_LDX
+#undef V5_MMA
+
+    // epilogue.  acc[i][j][r]: feature n = (i>>2)*128 + wr*64 + (i&3)*16 + 4fq + r, token m = (j>>1)*128 + wc*32 + (j&1)*16 + frow
+    if (ABL & 8) {                                     // ablation: no epilogue at all
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) asm volatile("" ::"v"(acc[i][j]));
+        return;
+    }
+    if (EPI == EPI_RESIDUAL) {
+        float *Y = static_cast<float *>(Yv);
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int n = n0 + (i >> 2) * 128 + wr * 64 + (i & 3) * 16 + 4 * fq;
+            const f32x4 bv = {(float)bias[n], (float)bias[n + 1], (float)bias[n + 2], (float)bias[n + 3]};
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int m = m0 + (j >> 1) * 128 + wc * 32 + (j & 1) * 16 + frow;
+                if (m < M) {
+                    const size_t o = (size_t)m * N + n;
+                    const f32x4 rv = *reinterpret_cast<const f32x4 *>(R + o);
+                    *reinterpret_cast<f32x4 *>(Y + o) = acc[i][j] + bv + rv;
+                }
+            }
+        }
+    } else {
+        // bf16 out through LDS, one 128-feature half at a time: tile [256 tokens][128 features], 272-byte rows
+        bf16 *Y = static_cast<bf16 *>(Yv);
+        unsigned char *Ct = smem;
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+#pragma unroll
+            for (int ii = 0; ii < 4; ii++) {
+                const int i = half * 4 + ii;
+                const int nl = wr * 64 + ii * 16 + 4 * fq;
+                float bv[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++) bv[r] = (float)bias[n0 + half * 128 + nl + r];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int ml = (j >> 1) * 128 + wc * 32 + (j & 1) * 16 + frow;
+                    bf16x4 v;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        float tv = acc[i][j][r] + bv[r];
+                        if (EPI == EPI_GELU) tv = gelu_erf(tv);
+                        v[r] = (bf16)tv;
+                    }
+                    *reinterpret_cast<bf16x4 *>(Ct + ml * CT_LD + nl * 2) = v;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int c = tid; c < 256 * 16; c += 512) {
+                const int ml = c >> 4, s = c & 15;
+                if (m0 + ml < M)
+                    *reinterpret_cast<uint4 *>(Y + (size_t)(m0 + ml) * N + n0 + half * 128 + s * 8) =
+                        *reinterpret_cast<const uint4 *>(Ct + ml * CT_LD + s * 16);
+            }
+            __syncthreads();
+        }
+    }
+}
+
 constexpr size_t kLdsBytesV3 = 2 * V3_STAGE;      // 131072 >= 256*272 epilogue half
 
 
@@ -913,6 +1156,21 @@ static int launch_v3(const bf16 *x, const bf16 *w, const bf16 *b, const float *r
     return COSA_OK;
 }
 
+template <int EPI, int ABL = 0>
+static int launch_v5(const bf16 *x, const bf16 *w, const bf16 *b, const float *residual, void *Y, int M, int N, int K, hipStream_t st)
+{
+    static bool attr_done = false;
+    if (!attr_done) {
+        COSA_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_bf16_v5_kernel<EPI, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytesV5));
+        attr_done = true;
+    }
+    const int tiles_m = (M + 255) / 256, tiles_n = N / 256;
+    hipLaunchKernelGGL((gemm_bf16_v5_kernel<EPI, ABL>), dim3(tiles_m * tiles_n), dim3(512), kLdsBytesV5, st, x, w, b, residual, Y, M, N, K,
+                       tiles_m, tiles_n);
+    COSA_LAUNCH_CHECK();
+    return COSA_OK;
+}
+
 template <int EPI>
 static int launch_v4(const bf16 *x, const bf16 *w, const bf16 *b, const float *residual, void *Y, int M, int N, int K, hipStream_t st)
 {
@@ -944,6 +1202,27 @@ extern "C" int cosa_gemm_bf16(const void *X, const void *W, const void *bias, co
     // shape rule from the measurements in profiles/r01_gemm_variants.txt: the 256x256 tile wins whenever its tile count
     // quantises well on 256 CUs (wide N, or >= 2 full rounds of tiles); otherwise the 128x128 kernel at 2 workgroups/CU
     const long tiles256 = (long)((M + V3_T - 1) / V3_T) * (N / V3_T);
+    const bool fits_v5 = N % 256 == 0 && M >= 256 && (size_t)(M + 256) * K * 2 < 0x7fffffffull && (size_t)N * K * 2 < 0x7fffffffull;
+    if (g_gemm_variant >= 50 && g_gemm_variant < 60 && fits_v5) {      // timing ablations of v5 (tools/bench_gemm.py), bias epilogue only
+        switch (g_gemm_variant - 50) {
+        case 1: return launch_v5<EPI_BIAS, 1>(x, w, b, residual, Y, M, N, K, st);
+        case 2: return launch_v5<EPI_BIAS, 2>(x, w, b, residual, Y, M, N, K, st);
+        case 3: return launch_v5<EPI_BIAS, 3>(x, w, b, residual, Y, M, N, K, st);
+        case 4: return launch_v5<EPI_BIAS, 4>(x, w, b, residual, Y, M, N, K, st);
+        case 6: return launch_v5<EPI_BIAS, 6>(x, w, b, residual, Y, M, N, K, st);
+        case 7: return launch_v5<EPI_BIAS, 7>(x, w, b, residual, Y, M, N, K, st);
+        case 8: return launch_v5<EPI_BIAS, 8>(x, w, b, residual, Y, M, N, K, st);
+        case 9: return launch_v5<EPI_BIAS, 9>(x, w, b, residual, Y, M, N, K, st);
+        default: break;
+        }
+    }
+    if ((g_gemm_variant == 5 || (g_gemm_variant == 0 && M >= 4096)) && fits_v5) {
+        switch (epilogue) {
+        case EPI_BIAS: return launch_v5<EPI_BIAS>(x, w, b, residual, Y, M, N, K, st);
+        case EPI_GELU: return launch_v5<EPI_GELU>(x, w, b, residual, Y, M, N, K, st);
+        default: return launch_v5<EPI_RESIDUAL>(x, w, b, residual, Y, M, N, K, st);
+        }
+    }
     if (g_gemm_variant == 4 && N % V3_T == 0) {
         switch (epilogue) {
         case EPI_BIAS: return launch_v4<EPI_BIAS>(x, w, b, residual, Y, M, N, K, st);

@@ -1,0 +1,87 @@
+"""GPU parity of the projection GEMM kernels (cosa_gemm_bf16 variants, cosa_gemm_wgrad_bf16, cosa_layernorm) against fp32 torch.
+
+bf16 operands, fp32 accumulation: the only differences from the fp32 reference are the bf16 rounding of the output
+(2^-9 relative) and the summation order, so the tolerance is 2^-8 of the output scale for bf16 results and 1e-5 for fp32 ones."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(4099, 768, 768), (8192, 256, 64), (4608, 2304, 768), (5000, 768, 3072), (300, 768, 768), (257, 256, 128), (1, 128, 64)]
+
+
+def _ref(x, w, b, epi, r):
+    y = x.float() @ w.float().t() + b.float()
+    if epi == 1:
+        y = torch.nn.functional.gelu(y)
+    if epi == 2:
+        y = y + r
+    return y
+
+
+@pytest.mark.parametrize("variant", [0, 1, 3, 5])
+@pytest.mark.parametrize("epi", [0, 1, 2])
+def test_gemm_bf16_variants_vs_fp32(variant, epi):
+    from cosa_amd import nn_ops, _C
+    torch.manual_seed(variant * 10 + epi)
+    try:
+        for (M, N, K) in SHAPES:
+            x = torch.randn(M, K, device="cuda").bfloat16()
+            w = (torch.randn(N, K, device="cuda") * K ** -0.5).bfloat16()
+            b = torch.randn(N, device="cuda").bfloat16()
+            r = torch.randn(M, N, device="cuda") if epi == 2 else None
+            # canaries after the operands: a tail tile that read past row M would pick these up instead of zeros
+            _C.lib().cosa_gemm_set_variant(variant)
+            y = nn_ops.gemm_bf16(x, w, b, epi, residual=r)
+            ref = _ref(x, w, b, epi, r)
+            assert y.dtype == (torch.float32 if epi == 2 else torch.bfloat16)
+            tol = (1e-5 if epi == 2 else 2.0 ** -8) * max(ref.abs().max().item(), 1.0)
+            err = (y.float() - ref).abs().max().item()
+            assert err <= tol, (variant, epi, M, N, K, err, tol)
+    finally:
+        _C.lib().cosa_gemm_set_variant(0)
+
+
+def test_gemm_variants_agree_bitwise_on_bias_epilogue():
+    """same products, same fp32 accumulation order per output (k ascending in steps of 32 inside one MFMA chain):
+    the tile shape must not change a single bit of the bf16 result"""
+    from cosa_amd import nn_ops, _C
+    torch.manual_seed(3)
+    M, N, K = 4700, 768, 768
+    x = torch.randn(M, K, device="cuda").bfloat16()
+    w = (torch.randn(N, K, device="cuda") * 0.03).bfloat16()
+    b = torch.randn(N, device="cuda").bfloat16()
+    outs = []
+    try:
+        for v in (1, 3, 5):
+            _C.lib().cosa_gemm_set_variant(v)
+            outs.append(nn_ops.gemm_bf16(x, w, b, 0).clone())
+    finally:
+        _C.lib().cosa_gemm_set_variant(0)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+@pytest.mark.parametrize("M,N,K", [(12560, 768, 768), (1000, 256, 128), (63, 128, 128), (4097, 2304, 768)])
+def test_gemm_wgrad_vs_fp32(M, N, K):
+    from cosa_amd import nn_ops
+    torch.manual_seed(M)
+    dy = torch.randn(M, N, device="cuda").bfloat16()
+    x = torch.randn(M, K, device="cuda").bfloat16()
+    dw, db = nn_ops.gemm_wgrad(dy, x, want_bias=True)
+    ref_w = dy.float().t() @ x.float()
+    ref_b = dy.float().sum(0)
+    assert dw.dtype == torch.float32 and dw.shape == (N, K)
+    assert (dw - ref_w).abs().max().item() <= 2e-4 * ref_w.abs().max().item() + 1e-3
+    assert (db - ref_b).abs().max().item() <= 2e-4 * ref_b.abs().max().item() + 1e-3
+
+
+def test_layernorm_vs_torch():
+    from cosa_amd import nn_ops
+    torch.manual_seed(5)
+    x = torch.randn(3001, 768, device="cuda") * 2 + 0.5
+    g = torch.randn(768, device="cuda").bfloat16()
+    b = torch.randn(768, device="cuda").bfloat16()
+    y16, y32 = nn_ops.layernorm_f32(x, g, b, 1e-6, True, True)
+    ref = torch.nn.functional.layer_norm(x, (768,), g.float(), b.float(), 1e-6)
+    assert (y32 - ref).abs().max().item() < 2e-5
+    assert (y16.float() - ref).abs().max().item() <= 2.0 ** -8 * ref.abs().max().item()
