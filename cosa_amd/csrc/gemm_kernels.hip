@@ -14,6 +14,7 @@
 // whole 256-B rows.  Workgroup ids are remapped so that the tiles sharing an X panel run on the
 // same XCD (private L2).
 #include "kernels.hpp"
+#include <cstdlib>
 
 namespace cosa {
 namespace {
@@ -822,6 +823,294 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v5_kernel(const bf16 *__rest
     }
 }
 
+
+// =====================================================================================================
+// v6: the v5 phase stream as a PERSISTENT kernel whose epilogue rides inside the next phases.
+//
+// One workgroup per CU walks its tiles (jobs).  The LDS-DMA stream never stops at a job boundary: the half-tiles
+// "7 ahead" simply belong to the next job (its operand panels are described by a second pair of buffer resources),
+// so no job after the first pays the pipeline fill.  A 64 x 32 accumulator quadrant is final after the phase that
+// last used it, and is written out (bias is already in: the first MFMA of a job takes C = bias; optional GELU;
+// v_cvt_pk_bf16; v_permlane16_swap so that a lane owns 8 consecutive features; 16-byte buffer stores straight from
+// registers, no LDS) inside the MFMA section of the FOLLOWING phase, in the shadow of MFMAs that work on another quadrant:
+//     last K-tile:  phase 2 stores Q(W0,X0), phase 3 Q(W0,X1), phase 4 Q(W1,X1);  first phase of the next job: Q(W1,X0).
+// Token rows past M never reach memory: the Y window is a buffer resource whose num_records ends with the last valid
+// row, and every row offset is in the per-lane VGPR offset (the part of the address that is range-checked).
+// vmcnt arithmetic (loads and stores retire in issue order on gfx9-class vmcnt): the phase-4 wait must leave only the
+// operations issued after phase 1's DMA in flight: 6 in the steady state, 14 in a job's last K-tile (3 x 2 DMA + 2 x 4 stores).
+// =====================================================================================================
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+// AUX: cache policy of the output stores (bit 1 = nt, bit 0 = sc0, bit 4 = sc1).  Plain stores allocate in L2: one round of
+// epilogues of an XCD's 32 CUs is 4 MB = the whole L2, which throws out the W panel and the X panels the DMA stream is
+// about to hit (stand-alone: plain 304 us, nt 287 us, nt+sc0+sc1 276 us, no stores 249 us on the qkv projection).  Inside the
+// training step the consumer kernel runs next and wants the output in L2 / MALL: there plain stores win (qkv 293 us vs 347 us
+// with nt+sc0+sc1; v5 314 us), so 0 is the default.
+// ABL6 (timing only): 1 = epilogue without the stores, 2 = no epilogue work, 3 = L2-resident store window, 4 = stores dropped
+template <int EPI, int ABL6 = 0, int AUX = 0>
+__global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const bf16 *__restrict__ X, const bf16 *__restrict__ W,
+                                                             const bf16 *__restrict__ bias, void *__restrict__ Yv, int M, int N, int K,
+                                                             int tiles_m, int tiles_n, int stagger_ticks)
+{
+    static_assert(EPI == EPI_BIAS || EPI == EPI_GELU, "v6 writes bf16 outputs");
+    constexpr int ABL = 0;
+    constexpr int FL = 0x00020000;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wr = wave >> 2, wc = wave & 3;
+    const int frow = lane & 15, fq = lane >> 4;
+    const int nk = K / BK;
+    const int ntiles = tiles_m * tiles_n, G = gridDim.x;
+    const int cq = ntiles >> 3, cr = ntiles & 7;
+    unsigned char *Yb = static_cast<unsigned char *>(Yv);
+
+    auto tile_of = [&](int o, int &m0_, int &n0_) {      // every XCD (o & 7) walks a contiguous chunk of the m-panel-major tile list
+        const int xcd = o & 7, idx = o >> 3;
+        const int t = (xcd < cr ? xcd * (cq + 1) : cr * (cq + 1) + (xcd - cr) * cq) + idx;
+        const int tm = t / tiles_n;
+        m0_ = tm * 256;
+        n0_ = (t - tm * tiles_n) * 256;
+    };
+    auto descX = [&](int m0_) {
+        int rows = M - m0_;
+        rows = rows > 256 ? 256 : rows;
+        return __builtin_amdgcn_make_buffer_rsrc((void *)(X + (size_t)m0_ * K), 0, rows * K * 2, FL);
+    };
+    auto descW = [&](int n0_) { return __builtin_amdgcn_make_buffer_rsrc((void *)(W + (size_t)n0_ * K), 0, 256 * K * 2, FL); };
+    auto descY = [&](int m0_, int n0_) {
+        if (ABL6 == 3) { m0_ = (int)blockIdx.x * 256 % (M - 256); n0_ = 0; }     // timing only: every job of a workgroup rewrites one L2-resident window
+        if (ABL6 == 4) return __builtin_amdgcn_make_buffer_rsrc((void *)Yb, 0, 0, FL);   // timing only: every store is out of range (dropped)
+        int rows = M - m0_;
+        rows = rows > 256 ? 256 : rows;
+        return __builtin_amdgcn_make_buffer_rsrc((void *)(Yb + ((size_t)m0_ * N + n0_) * 2), 0, (rows * N - n0_) * 2, FL);
+    };
+    const __amdgpu_buffer_rsrc_t dead = __builtin_amdgcn_make_buffer_rsrc((void *)X, 0, 0, FL);   // every access out of range
+
+    // job-independent per-lane offsets: DMA source inside a 256-row operand panel (same for X and W) ...
+    unsigned vo[2][2];
+    {
+        const int sw = ((lane & 7) ^ (lane >> 3)) * 8;
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+#pragma unroll
+            for (int i = 0; i < 2; i++) vo[h][i] = (unsigned)(((h * 128 + 8 * (2 * wave + i) + (lane >> 3)) * K + sw) * 2);
+    }
+    // ... and the store offset inside the tile's Y window for each 16-token row group (b, jj); after the lane swap a lane
+    // owns features  wr*64 + pair*32 + (fq&1)*16 + 4*(fq&2) .. +7  of its token
+    unsigned voY[4];
+#pragma unroll
+    for (int g4 = 0; g4 < 4; g4++)
+        voY[g4] = (unsigned)((((g4 >> 1) * 128 + wc * 32 + (g4 & 1) * 16 + frow) * N + wr * 64 + (fq & 1) * 16 + 4 * (fq & 2)) * 2);
+
+    int o = blockIdx.x;
+    // Optional start stagger (experiment, off by default): workgroups that have one job fewer than the busiest ones start
+    // late by a pseudo-random fraction of stagger_ticks (100 MHz).  The idea was to spread the 256 simultaneous epilogues;
+    // measured to make no difference (the store cost is L2 capacity, not burstiness).
+    if (stagger_ticks > 0) {
+        const int njobs = (ntiles - o + G - 1) / G, njobs_max = (ntiles + G - 1) / G;
+        if (njobs < njobs_max || stagger_ticks >= (1 << 20)) {
+            const unsigned long long wait = (unsigned long long)((o * 37) & 63) * (unsigned)(stagger_ticks & 0xfffff) >> 6;
+            if (wave == 0) {
+                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(32);
+            }
+            __syncthreads();
+        }
+    }
+    int m0, n0, m1 = 0, n1 = 0;
+    tile_of(o, m0, n0);
+    bool has_next = o + G < ntiles;
+    if (has_next) tile_of(o + G, m1, n1);
+    __amdgpu_buffer_rsrc_t cX = descX(m0), cW = descW(n0), cY = descY(m0, n0), pY = cY;
+    __amdgpu_buffer_rsrc_t nX = has_next ? descX(m1) : dead, nW = has_next ? descW(n1) : dead;
+    bool have_prev = false;
+
+    // bias of the job about to start, as packed bf16: features a*128 + wr*64 + ii*16 + 4fq .. +3.  Loaded by hand (inline asm) so
+    // that the compiler does not put its own vmcnt wait in front of the first use: the phase-4 waits cover these loads.
+    u32x2 bb[2][4];
+#define V6_LOAD_BIAS(nbase)                                                                               \
+    _Pragma("unroll") for (int a_ = 0; a_ < 2; a_++) _Pragma("unroll") for (int i_ = 0; i_ < 4; i_++) {   \
+        const bf16 *p_ = bias + (nbase) + a_ * 128 + wr * 64 + i_ * 16 + 4 * fq;                          \
+        asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(bb[a_][i_]) : "v"(p_) : "memory");       \
+    }
+
+    // which: 0 X0, 1 W0, 2 X1, 3 W1; K-tile kt of the running job, or kt - nk of the next one
+#define V6_STAGE(which, kt, bsel)                                                                                      \
+    do {                                                                                                               \
+        const int kt_ = (kt);                                                                                          \
+        const bool own_ = kt_ < nk;                                                                                    \
+        const __amdgpu_buffer_rsrc_t rs_ = ((which) & 1) ? (own_ ? cW : nW) : (own_ ? cX : nX);                        \
+        const int so_ = (own_ ? kt_ : kt_ - nk) * 128;                                                                 \
+        unsigned char *dst_ = smem + (bsel) * V5_BUF + (which) * V5_HALF + (2 * wave) * 1024;                          \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_, (lds_void *)dst_, 16, vo[(which) >> 1][0], so_, 0, 0);           \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_, (lds_void *)(dst_ + 1024), 16, vo[(which) >> 1][1], so_, 0, 0);  \
+    } while (0)
+
+    f32x4 acc[8][4];
+
+    // pipeline fill (first job only): bias, K-tile 0 complete, X0 W0 X1 of K-tile 1
+    V6_LOAD_BIAS(n0);
+    V5_FENCE();
+    V6_STAGE(0, 0, 0);
+    V6_STAGE(1, 0, 0);
+    V6_STAGE(2, 0, 0);
+    V6_STAGE(3, 0, 0);
+    V6_STAGE(0, 1, 1);
+    V6_STAGE(1, 1, 1);
+    V6_STAGE(2, 1, 1);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    V5_BARRIER();
+    if (wr == 1) V5_BARRIER();                         // stagger: the wr = 1 group runs one barrier behind
+
+    const int lo0 = frow * 128 + ((fq ^ (frow & 7)) << 4), lo1 = lo0 ^ 64;
+    const unsigned char *rdW0 = smem + V5_HALF + wr * 8192 + lo0, *rdW1 = smem + V5_HALF + wr * 8192 + lo1;
+    const unsigned char *rdX0 = smem + wc * 4096 + lo0, *rdX1 = smem + wc * 4096 + lo1;
+    bf16x8 a[4][2], x0[2][2], x1[2][2];
+
+#define V6_LDW(q, buf)                                                                     \
+    _Pragma("unroll") for (int blk = 0; blk < 4; blk++) {                                  \
+        const int o_ = (buf) * V5_BUF + (q) * 2 * V5_HALF + blk * 2048;                    \
+        a[blk][0] = *reinterpret_cast<const bf16x8 *>(rdW0 + o_);                          \
+        a[blk][1] = *reinterpret_cast<const bf16x8 *>(rdW1 + o_);                          \
+    }
+#define V6_LDX(dst, q, buf)                                                                \
+    _Pragma("unroll") for (int blk = 0; blk < 2; blk++) {                                  \
+        const int o_ = (buf) * V5_BUF + (q) * 2 * V5_HALF + blk * 2048;                    \
+        dst[blk][0] = *reinterpret_cast<const bf16x8 *>(rdX0 + o_);                        \
+        dst[blk][1] = *reinterpret_cast<const bf16x8 *>(rdX1 + o_);                        \
+    }
+    // quadrant (qa, qb) out: acc[qa*4 + ii][qb*2 + jj][r] = feature qa*128 + wr*64 + ii*16 + 4fq + r, token qb*128 + wc*32 + jj*16 + frow
+#define V6_EPI(qa, qb, rsY)                                                                                         \
+    if (ABL6 == 2) {                                                                                                \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; i_++) _Pragma("unroll") for (int j_ = 0; j_ < 2; j_++)           \
+            asm volatile("" ::"v"(acc[(qa) * 4 + i_][(qb) * 2 + j_]));                                              \
+    } else                                                                                                          \
+    _Pragma("unroll") for (int jj = 0; jj < 2; jj++) _Pragma("unroll") for (int pr = 0; pr < 2; pr++) {             \
+        f32x4 v0_ = acc[(qa) * 4 + 2 * pr][(qb) * 2 + jj], v1_ = acc[(qa) * 4 + 2 * pr + 1][(qb) * 2 + jj];        \
+        if (EPI == EPI_GELU) {                                                                                      \
+            _Pragma("unroll") for (int r = 0; r < 4; r++) {                                                         \
+                v0_[r] = gelu_erf(v0_[r]);                                                                          \
+                v1_[r] = gelu_erf(v1_[r]);                                                                          \
+            }                                                                                                       \
+        }                                                                                                           \
+        const bf16x2 p0_ = {(bf16)v0_[0], (bf16)v0_[1]}, p1_ = {(bf16)v0_[2], (bf16)v0_[3]};                        \
+        const bf16x2 p2_ = {(bf16)v1_[0], (bf16)v1_[1]}, p3_ = {(bf16)v1_[2], (bf16)v1_[3]};                        \
+        const auto s0_ = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, p0_), __builtin_bit_cast(unsigned, p2_), false, false); \
+        const auto s1_ = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, p1_), __builtin_bit_cast(unsigned, p3_), false, false); \
+        const u32x4 out_ = {s0_[0], s1_[0], s0_[1], s1_[1]};                                                        \
+        if (ABL6 == 0 || ABL6 == 3 || ABL6 == 4) __builtin_amdgcn_raw_buffer_store_b128(out_, rsY, voY[(qb) * 2 + jj] + ((qa) * 128 + pr * 32) * 2, 0, AUX); \
+        else asm volatile("" ::"v"(out_));                                                                          \
+    }
+    // 16 MFMAs of quadrant (qa, qb); FIRST: the accumulation starts from the bias
+#define V6_MMA(qa, xf, qb, FIRST)                                                                                   \
+    do {                                                                                                            \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ks++)                                                            \
+            _Pragma("unroll") for (int i = 0; i < 4; i++) {                                                         \
+                f32x4 cb_;                                                                                          \
+                if ((FIRST) && ks == 0) {                                                                           \
+                    const unsigned lo_ = bb[qa][i][0], hi_ = bb[qa][i][1];                                          \
+                    cb_[0] = __builtin_bit_cast(float, lo_ << 16);                                                  \
+                    cb_[1] = __builtin_bit_cast(float, lo_ & 0xffff0000u);                                          \
+                    cb_[2] = __builtin_bit_cast(float, hi_ << 16);                                                  \
+                    cb_[3] = __builtin_bit_cast(float, hi_ & 0xffff0000u);                                          \
+                }                                                                                                   \
+                _Pragma("unroll") for (int j = 0; j < 2; j++)                                                       \
+                    acc[(qa) * 4 + i][(qb) * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                      \
+                        a[i][ks], xf[j][ks], ((FIRST) && ks == 0) ? cb_ : acc[(qa) * 4 + i][(qb) * 2 + j], 0, 0, 0); \
+            }                                                                                                       \
+    } while (0)
+#define V6_MSECTION_BEGIN()                                    \
+    V5_BARRIER();                                              \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         \
+    __builtin_amdgcn_s_setprio(1)
+#define V6_MSECTION_END()                                      \
+    __builtin_amdgcn_s_setprio(0);                             \
+    V5_BARRIER()
+
+    // one K-tile = four phases.  FIRST / LAST are literals; t is the K-tile index inside the job, g the running buffer parity
+#define V6_TILE(t, FIRST, LAST)                                                                                     \
+    do {                                                                                                            \
+        const int b_ = g & 1;                                                                                       \
+        /* ---- phase 1 ---- */                                                                                     \
+        V6_LDX(x0, 0, b_);                                                                                          \
+        V5_FENCE();                                                                                                 \
+        V6_LDW(0, b_);                                                                                              \
+        if ((LAST) && has_next) { V6_LOAD_BIAS(n1); }                                                               \
+        V5_FENCE();                                                                                                 \
+        V6_STAGE(3, (t) + 1, b_ ^ 1);                                                                               \
+        V5_FENCE();                                                                                                 \
+        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");                                                          \
+        V6_MSECTION_BEGIN();                                                                                        \
+        if ((FIRST) && have_prev) { V6_EPI(1, 0, pY); }                                                             \
+        V6_MMA(0, x0, 0, FIRST);                                                                                    \
+        V6_MSECTION_END();                                                                                          \
+        /* ---- phase 2 ---- */                                                                                     \
+        V6_LDX(x1, 1, b_);                                                                                          \
+        V6_STAGE(0, (t) + 2, b_);                                                                                   \
+        V6_MSECTION_BEGIN();                                                                                        \
+        if (LAST) { V6_EPI(0, 0, cY); }                                                                             \
+        V6_MMA(0, x1, 1, FIRST);                                                                                    \
+        V6_MSECTION_END();                                                                                          \
+        /* ---- phase 3 ---- */                                                                                     \
+        V6_LDW(1, b_);                                                                                              \
+        V6_STAGE(1, (t) + 2, b_);                                                                                   \
+        V6_MSECTION_BEGIN();                                                                                        \
+        if (LAST) { V6_EPI(0, 1, cY); }                                                                             \
+        V6_MMA(1, x1, 1, FIRST);                                                                                    \
+        V6_MSECTION_END();                                                                                          \
+        /* ---- phase 4 ---- */                                                                                     \
+        V6_STAGE(2, (t) + 2, b_);                                                                                   \
+        V5_FENCE();                                                                                                 \
+        if (LAST) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");                                                 \
+        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                                       \
+        V6_MSECTION_BEGIN();                                                                                        \
+        if (LAST) { V6_EPI(1, 1, cY); }                                                                             \
+        V6_MMA(1, x0, 0, FIRST);                                                                                    \
+        V6_MSECTION_END();                                                                                          \
+        g++;                                                                                                        \
+    } while (0)
+
+    int g = 0;
+    while (true) {
+        V6_TILE(0, 1, 0);
+        for (int t = 1; t < nk - 1; t++) V6_TILE(t, 0, 0);
+        V6_TILE(nk - 1, 0, 1);
+        if (!has_next) break;
+        // next job becomes the running one
+        pY = cY;
+        have_prev = true;
+        o += G;
+        m0 = m1;
+        n0 = n1;
+        cX = nX;
+        cW = nW;
+        cY = descY(m0, n0);
+        has_next = o + G < ntiles;
+        if (has_next) {
+            tile_of(o + G, m1, n1);
+            nX = descX(m1);
+            nW = descW(n1);
+        } else {
+            nX = dead;
+            nW = dead;
+        }
+    }
+    V6_EPI(1, 0, cY);
+    if (wr == 0) V5_BARRIER();                         // re-align the two groups
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the dead-descriptor DMA of the last K-tiles still writes (zeros) to LDS
+#undef V6_LOAD_BIAS
+#undef V6_STAGE
+#undef V6_LDW
+#undef V6_LDX
+#undef V6_EPI
+#undef V6_MMA
+#undef V6_MSECTION_BEGIN
+#undef V6_MSECTION_END
+#undef V6_TILE
+}
+
 constexpr size_t kLdsBytesV3 = 2 * V3_STAGE;      // 131072 >= 256*272 epilogue half
 
 
@@ -1123,7 +1412,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
 
 using namespace cosa;
 
-static int g_gemm_variant = 0;   // 0 = pick per shape (measured, tools/bench_gemm.py); 1/2/3 force a kernel
+static int env_variant()
+{
+    const char *e = getenv("COSA_GEMM_VARIANT");
+    return e ? atoi(e) : 0;
+}
+static int g_gemm_variant = env_variant();   // 0 = pick per shape (measured, tools/bench_gemm.py); 1..8 force a kernel (experiments)
 extern "C" void cosa_gemm_set_variant(int v) { g_gemm_variant = v; }
 
 template <int EPI>
@@ -1167,6 +1461,25 @@ static int launch_v5(const bf16 *x, const bf16 *w, const bf16 *b, const float *r
     const int tiles_m = (M + 255) / 256, tiles_n = N / 256;
     hipLaunchKernelGGL((gemm_bf16_v5_kernel<EPI, ABL>), dim3(tiles_m * tiles_n), dim3(512), kLdsBytesV5, st, x, w, b, residual, Y, M, N, K,
                        tiles_m, tiles_n);
+    COSA_LAUNCH_CHECK();
+    return COSA_OK;
+}
+
+template <int EPI, int ABL6 = 0, int AUX = 0>
+static int launch_v6(const bf16 *x, const bf16 *w, const bf16 *b, void *Y, int M, int N, int K, hipStream_t st)
+{
+    static bool attr_done = false;
+    if (!attr_done) {
+        COSA_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_bf16_v6_kernel<EPI, ABL6, AUX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytesV5));
+        attr_done = true;
+    }
+    const int tiles_m = (M + 255) / 256, tiles_n = N / 256;
+    const int ntiles = tiles_m * tiles_n;
+    const int grid = ntiles < 256 ? ntiles : 256;          // one persistent workgroup per CU
+    // start stagger (see the kernel): about one job time in 100-MHz ticks, from the job's flops at ~4.3 TFLOP/s per CU
+    static const char *env = getenv("COSA_GEMM_STAGGER");
+    const int stagger = env ? atoi(env) : 0;               // start stagger (see the kernel): measured to make no difference, off
+    hipLaunchKernelGGL((gemm_bf16_v6_kernel<EPI, ABL6, AUX>), dim3(grid), dim3(512), kLdsBytesV5, st, x, w, b, Y, M, N, K, tiles_m, tiles_n, stagger);
     COSA_LAUNCH_CHECK();
     return COSA_OK;
 }
@@ -1215,6 +1528,28 @@ extern "C" int cosa_gemm_bf16(const void *X, const void *W, const void *bias, co
         case 9: return launch_v5<EPI_BIAS, 9>(x, w, b, residual, Y, M, N, K, st);
         default: break;
         }
+    }
+    const bool fits_v6 = fits_v5 && K >= 128 && epilogue != EPI_RESIDUAL;
+    if (g_gemm_variant >= 61 && g_gemm_variant <= 65 && fits_v6) {     // timing ablations of v6 (tools/bench_gemm_abl.py)
+        switch (g_gemm_variant) {
+        case 61: return launch_v6<EPI_BIAS, 1>(x, w, b, Y, M, N, K, st);
+        case 62: return launch_v6<EPI_BIAS, 2>(x, w, b, Y, M, N, K, st);
+        case 63: return launch_v6<EPI_GELU, 1>(x, w, b, Y, M, N, K, st);
+        case 64: return launch_v6<EPI_BIAS, 3>(x, w, b, Y, M, N, K, st);
+        default: return launch_v6<EPI_BIAS, 4>(x, w, b, Y, M, N, K, st);
+        }
+    }
+    if (fits_v6 && (g_gemm_variant == 6 || (g_gemm_variant == 0 && M >= 4096))) {       // plain stores
+        if (epilogue == EPI_BIAS) return launch_v6<EPI_BIAS>(x, w, b, Y, M, N, K, st);
+        return launch_v6<EPI_GELU>(x, w, b, Y, M, N, K, st);
+    }
+    if (fits_v6 && g_gemm_variant == 7) {                              // nt stores
+        if (epilogue == EPI_BIAS) return launch_v6<EPI_BIAS, 0, 2>(x, w, b, Y, M, N, K, st);
+        return launch_v6<EPI_GELU, 0, 2>(x, w, b, Y, M, N, K, st);
+    }
+    if (fits_v6 && g_gemm_variant == 8) {                              // nt + sc0 + sc1 stores
+        if (epilogue == EPI_BIAS) return launch_v6<EPI_BIAS, 0, 19>(x, w, b, Y, M, N, K, st);
+        return launch_v6<EPI_GELU, 0, 19>(x, w, b, Y, M, N, K, st);
     }
     if ((g_gemm_variant == 5 || (g_gemm_variant == 0 && M >= 4096)) && fits_v5) {
         switch (epilogue) {
