@@ -851,10 +851,12 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 // ABL6 (timing only): 1 = epilogue without the stores, 2 = no epilogue work, 3 = L2-resident store window, 4 = stores dropped
 template <int EPI, int ABL6 = 0, int AUX = 0>
 __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const bf16 *__restrict__ X, const bf16 *__restrict__ W,
-                                                             const bf16 *__restrict__ bias, void *__restrict__ Yv, int M, int N, int K,
-                                                             int tiles_m, int tiles_n, int stagger_ticks)
+                                                             const bf16 *__restrict__ bias, const float *__restrict__ R,
+                                                             void *__restrict__ Yv, int M, int N, int K, int tiles_m, int tiles_n,
+                                                             int stagger_ticks)
 {
-    static_assert(EPI == EPI_BIAS || EPI == EPI_GELU, "v6 writes bf16 outputs");
+    constexpr bool RES = EPI == EPI_RESIDUAL;          // fp32 out = fp32 residual + X W^T + bias
+    constexpr int ES = RES ? 4 : 2;
     constexpr int ABL = 0;
     constexpr int FL = 0x00020000;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -884,7 +886,14 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const bf16 *__rest
         if (ABL6 == 4) return __builtin_amdgcn_make_buffer_rsrc((void *)Yb, 0, 0, FL);   // timing only: every store is out of range (dropped)
         int rows = M - m0_;
         rows = rows > 256 ? 256 : rows;
-        return __builtin_amdgcn_make_buffer_rsrc((void *)(Yb + ((size_t)m0_ * N + n0_) * 2), 0, (rows * N - n0_) * 2, FL);
+        return __builtin_amdgcn_make_buffer_rsrc((void *)(Yb + ((size_t)m0_ * N + n0_) * ES), 0, (rows * N - n0_) * ES, FL);
+    };
+    // the residual window of a job as raw descriptor words (inline-asm loads), same geometry as the Y window
+    auto descR = [&](int m0_, int n0_) {
+        int rows = M - m0_;
+        rows = rows > 256 ? 256 : rows;
+        const unsigned long long p = (unsigned long long)(R + (size_t)m0_ * N + n0_);
+        return (u32x4){(unsigned)p, (unsigned)(p >> 32) & 0xffffu, (unsigned)((rows * N - n0_) * 4), (unsigned)FL};
     };
     const __amdgpu_buffer_rsrc_t dead = __builtin_amdgcn_make_buffer_rsrc((void *)X, 0, 0, FL);   // every access out of range
 
@@ -899,10 +908,13 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const bf16 *__rest
     }
     // ... and the store offset inside the tile's Y window for each 16-token row group (b, jj); after the lane swap a lane
     // owns features  wr*64 + pair*32 + (fq&1)*16 + 4*(fq&2) .. +7  of its token
+    // (fp32 output: no swap, a lane owns features wr*64 + ii*16 + 4fq .. +3)
     unsigned voY[4];
 #pragma unroll
-    for (int g4 = 0; g4 < 4; g4++)
-        voY[g4] = (unsigned)((((g4 >> 1) * 128 + wc * 32 + (g4 & 1) * 16 + frow) * N + wr * 64 + (fq & 1) * 16 + 4 * (fq & 2)) * 2);
+    for (int g4 = 0; g4 < 4; g4++) {
+        const int row = (g4 >> 1) * 128 + wc * 32 + (g4 & 1) * 16 + frow;
+        voY[g4] = RES ? (unsigned)((row * N + wr * 64 + 4 * fq) * 4) : (unsigned)((row * N + wr * 64 + (fq & 1) * 16 + 4 * (fq & 2)) * 2);
+    }
 
     int o = blockIdx.x;
     // Optional start stagger (experiment, off by default): workgroups that have one job fewer than the busiest ones start
@@ -925,15 +937,21 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const bf16 *__rest
     if (has_next) tile_of(o + G, m1, n1);
     __amdgpu_buffer_rsrc_t cX = descX(m0), cW = descW(n0), cY = descY(m0, n0), pY = cY;
     __amdgpu_buffer_rsrc_t nX = has_next ? descX(m1) : dead, nW = has_next ? descW(n1) : dead;
+    u32x4 cR = {0, 0, 0, 0}, nR = {0, 0, 0, 0};
+    if (RES) {
+        cR = descR(m0, n0);
+        if (has_next) nR = descR(m1, n1);
+    }
     bool have_prev = false;
 
     // bias of the job about to start, as packed bf16: features a*128 + wr*64 + ii*16 + 4fq .. +3.  Loaded by hand (inline asm) so
     // that the compiler does not put its own vmcnt wait in front of the first use: the phase-4 waits cover these loads.
     u32x2 bb[2][4];
+    const unsigned bias_lane = (unsigned)((wr * 64 + 4 * fq) * 2);        // scalar base + 32-bit lane offset: no 64-bit per-lane pointer to keep alive
 #define V6_LOAD_BIAS(nbase)                                                                               \
     _Pragma("unroll") for (int a_ = 0; a_ < 2; a_++) _Pragma("unroll") for (int i_ = 0; i_ < 4; i_++) {   \
-        const bf16 *p_ = bias + (nbase) + a_ * 128 + wr * 64 + i_ * 16 + 4 * fq;                          \
-        asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(bb[a_][i_]) : "v"(p_) : "memory");       \
+        const bf16 *p_ = bias + (nbase) + a_ * 128 + i_ * 16;                                             \
+        asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(bb[a_][i_]) : "v"(bias_lane), "s"(p_) : "memory"); \
     }
 
     // which: 0 X0, 1 W0, 2 X1, 3 W1; K-tile kt of the running job, or kt - nk of the next one
@@ -949,9 +967,21 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const bf16 *__rest
     } while (0)
 
     f32x4 acc[8][4];
+    // residual: the accumulators of a quadrant START as the residual tile (so the epilogue has no loads).  The loads are
+    // issued by hand right after the quadrant's previous contents were stored, two to three phases before its first MFMA.
+#define V6_RLOAD(qa, qb, rsR)                                                                                        \
+    _Pragma("unroll") for (int ii = 0; ii < 4; ii++) _Pragma("unroll") for (int jj = 0; jj < 2; jj++)                \
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(acc[(qa) * 4 + ii][(qb) * 2 + jj])           \
+                     : "v"(voY[(qb) * 2 + jj]), "s"(rsR), "s"(((qa) * 128 + ii * 16) * 4) : "memory");
 
-    // pipeline fill (first job only): bias, K-tile 0 complete, X0 W0 X1 of K-tile 1
+    // pipeline fill (first job only): bias, [residual tile,] K-tile 0 complete, X0 W0 X1 of K-tile 1
     V6_LOAD_BIAS(n0);
+    if (RES) {
+        V6_RLOAD(0, 0, cR);
+        V6_RLOAD(0, 1, cR);
+        V6_RLOAD(1, 1, cR);
+        V6_RLOAD(1, 0, cR);
+    }
     V5_FENCE();
     V6_STAGE(0, 0, 0);
     V6_STAGE(1, 0, 0);
@@ -986,6 +1016,17 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const bf16 *__rest
     if (ABL6 == 2) {                                                                                                \
         _Pragma("unroll") for (int i_ = 0; i_ < 4; i_++) _Pragma("unroll") for (int j_ = 0; j_ < 2; j_++)           \
             asm volatile("" ::"v"(acc[(qa) * 4 + i_][(qb) * 2 + j_]));                                              \
+    } else if (RES) {                                                                                               \
+        _Pragma("unroll") for (int ii = 0; ii < 4; ii++) {                                                          \
+            const unsigned lo_ = bb[qa][ii][0], hi_ = bb[qa][ii][1];                                                \
+            const f32x4 bv_ = {__builtin_bit_cast(float, lo_ << 16), __builtin_bit_cast(float, lo_ & 0xffff0000u),  \
+                               __builtin_bit_cast(float, hi_ << 16), __builtin_bit_cast(float, hi_ & 0xffff0000u)}; \
+            _Pragma("unroll") for (int jj = 0; jj < 2; jj++) {                                                      \
+                const f32x4 o4_ = acc[(qa) * 4 + ii][(qb) * 2 + jj] + bv_;                                          \
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o4_), rsY,                         \
+                                                       voY[(qb) * 2 + jj] + ((qa) * 128 + ii * 16) * 4, 0, AUX);    \
+            }                                                                                                       \
+        }                                                                                                           \
     } else                                                                                                          \
     _Pragma("unroll") for (int jj = 0; jj < 2; jj++) _Pragma("unroll") for (int pr = 0; pr < 2; pr++) {             \
         f32x4 v0_ = acc[(qa) * 4 + 2 * pr][(qb) * 2 + jj], v1_ = acc[(qa) * 4 + 2 * pr + 1][(qb) * 2 + jj];        \
@@ -1009,7 +1050,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const bf16 *__rest
         _Pragma("unroll") for (int ks = 0; ks < 2; ks++)                                                            \
             _Pragma("unroll") for (int i = 0; i < 4; i++) {                                                         \
                 f32x4 cb_;                                                                                          \
-                if ((FIRST) && ks == 0) {                                                                           \
+                if ((FIRST) && ks == 0 && !RES) {                                                                   \
                     const unsigned lo_ = bb[qa][i][0], hi_ = bb[qa][i][1];                                          \
                     cb_[0] = __builtin_bit_cast(float, lo_ << 16);                                                  \
                     cb_[1] = __builtin_bit_cast(float, lo_ & 0xffff0000u);                                          \
@@ -1018,7 +1059,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const bf16 *__rest
                 }                                                                                                   \
                 _Pragma("unroll") for (int j = 0; j < 2; j++)                                                       \
                     acc[(qa) * 4 + i][(qb) * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                      \
-                        a[i][ks], xf[j][ks], ((FIRST) && ks == 0) ? cb_ : acc[(qa) * 4 + i][(qb) * 2 + j], 0, 0, 0); \
+                        a[i][ks], xf[j][ks], ((FIRST) && ks == 0 && !RES) ? cb_ : acc[(qa) * 4 + i][(qb) * 2 + j], 0, 0, 0); \
             }                                                                                                       \
     } while (0)
 #define V6_MSECTION_BEGIN()                                    \
@@ -1029,7 +1070,13 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const bf16 *__rest
     __builtin_amdgcn_s_setprio(0);                             \
     V5_BARRIER()
 
-    // one K-tile = four phases.  FIRST / LAST are literals; t is the K-tile index inside the job, g the running buffer parity
+    // one K-tile = four phases.  FIRST / LAST are literals; t is the K-tile index inside the job, g the running buffer parity.
+    // VMEM operations per wave around a job boundary (st = epilogue stores: 4 bf16 / 8 fp32 per quadrant; R' = 8 residual loads):
+    //   last.1: DMA(A)        last.2: DMA, st Q00, R' Q00     last.3: DMA, st Q01, R' Q01     last.4: DMA, WAIT(A), st Q11, R' Q11
+    //   first.1: DMA(B), WAIT(R' Q00), st Q10, R' Q10, bias     first.2: DMA, WAIT(R' Q01)   first.3: DMA, WAIT(R' Q11)   first.4: DMA, WAIT(B, R' Q10)
+    // every WAIT is vmcnt(number of operations issued after its target): bf16 out 14 / - / - / - / 6, residual 38 / 38 / 46 / 30 / 6
+    // (6 instead of 14 at first.4 also covers a job without predecessor; operations retire in issue order).
+#define V6_WAIT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define V6_TILE(t, FIRST, LAST)                                                                                     \
     do {                                                                                                            \
         const int b_ = g & 1;                                                                                       \
@@ -1037,36 +1084,52 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const bf16 *__rest
         V6_LDX(x0, 0, b_);                                                                                          \
         V5_FENCE();                                                                                                 \
         V6_LDW(0, b_);                                                                                              \
-        if ((LAST) && has_next) { V6_LOAD_BIAS(n1); }                                                               \
+        if (!RES && (LAST) && has_next) { V6_LOAD_BIAS(n1); }                                                       \
         V5_FENCE();                                                                                                 \
         V6_STAGE(3, (t) + 1, b_ ^ 1);                                                                               \
         V5_FENCE();                                                                                                 \
         asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");                                                          \
         V6_MSECTION_BEGIN();                                                                                        \
-        if ((FIRST) && have_prev) { V6_EPI(1, 0, pY); }                                                             \
+        if (RES && (FIRST)) { V6_WAIT(38); V5_FENCE(); }                                                            \
+        if ((FIRST) && have_prev) {                                                                                 \
+            V6_EPI(1, 0, pY);                                                                                       \
+            if (RES) { V5_FENCE(); V6_RLOAD(1, 0, cR); V6_LOAD_BIAS(n0); V5_FENCE(); }                              \
+        }                                                                                                           \
         V6_MMA(0, x0, 0, FIRST);                                                                                    \
         V6_MSECTION_END();                                                                                          \
         /* ---- phase 2 ---- */                                                                                     \
         V6_LDX(x1, 1, b_);                                                                                          \
         V6_STAGE(0, (t) + 2, b_);                                                                                   \
         V6_MSECTION_BEGIN();                                                                                        \
-        if (LAST) { V6_EPI(0, 0, cY); }                                                                             \
+        if (RES && (FIRST)) { V6_WAIT(46); V5_FENCE(); }                                                            \
+        if (LAST) {                                                                                                 \
+            V6_EPI(0, 0, cY);                                                                                       \
+            if (RES && has_next) { V5_FENCE(); V6_RLOAD(0, 0, nR); V5_FENCE(); }                                    \
+        }                                                                                                           \
         V6_MMA(0, x1, 1, FIRST);                                                                                    \
         V6_MSECTION_END();                                                                                          \
         /* ---- phase 3 ---- */                                                                                     \
         V6_LDW(1, b_);                                                                                              \
         V6_STAGE(1, (t) + 2, b_);                                                                                   \
         V6_MSECTION_BEGIN();                                                                                        \
-        if (LAST) { V6_EPI(0, 1, cY); }                                                                             \
+        if (RES && (FIRST)) { V6_WAIT(30); V5_FENCE(); }                                                            \
+        if (LAST) {                                                                                                 \
+            V6_EPI(0, 1, cY);                                                                                       \
+            if (RES && has_next) { V5_FENCE(); V6_RLOAD(0, 1, nR); V5_FENCE(); }                                    \
+        }                                                                                                           \
         V6_MMA(1, x1, 1, FIRST);                                                                                    \
         V6_MSECTION_END();                                                                                          \
         /* ---- phase 4 ---- */                                                                                     \
         V6_STAGE(2, (t) + 2, b_);                                                                                   \
         V5_FENCE();                                                                                                 \
-        if (LAST) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");                                                 \
-        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                                       \
+        if ((LAST) && RES) V6_WAIT(38);                                                                             \
+        else if (LAST) V6_WAIT(14);                                                                                 \
+        else V6_WAIT(6);                                                                                            \
         V6_MSECTION_BEGIN();                                                                                        \
-        if (LAST) { V6_EPI(1, 1, cY); }                                                                             \
+        if (LAST) {                                                                                                 \
+            V6_EPI(1, 1, cY);                                                                                       \
+            if (RES && has_next) { V5_FENCE(); V6_RLOAD(1, 1, nR); V5_FENCE(); }                                    \
+        }                                                                                                           \
         V6_MMA(1, x0, 0, FIRST);                                                                                    \
         V6_MSECTION_END();                                                                                          \
         g++;                                                                                                        \
@@ -1087,11 +1150,13 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const bf16 *__rest
         cX = nX;
         cW = nW;
         cY = descY(m0, n0);
+        cR = nR;
         has_next = o + G < ntiles;
         if (has_next) {
             tile_of(o + G, m1, n1);
             nX = descX(m1);
             nW = descW(n1);
+            if (RES) nR = descR(m1, n1);
         } else {
             nX = dead;
             nW = dead;
@@ -1101,6 +1166,8 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const bf16 *__rest
     if (wr == 0) V5_BARRIER();                         // re-align the two groups
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the dead-descriptor DMA of the last K-tiles still writes (zeros) to LDS
 #undef V6_LOAD_BIAS
+#undef V6_RLOAD
+#undef V6_WAIT
 #undef V6_STAGE
 #undef V6_LDW
 #undef V6_LDX
@@ -1466,7 +1533,7 @@ static int launch_v5(const bf16 *x, const bf16 *w, const bf16 *b, const float *r
 }
 
 template <int EPI, int ABL6 = 0, int AUX = 0>
-static int launch_v6(const bf16 *x, const bf16 *w, const bf16 *b, void *Y, int M, int N, int K, hipStream_t st)
+static int launch_v6(const bf16 *x, const bf16 *w, const bf16 *b, const float *residual, void *Y, int M, int N, int K, hipStream_t st)
 {
     static bool attr_done = false;
     if (!attr_done) {
@@ -1479,7 +1546,7 @@ static int launch_v6(const bf16 *x, const bf16 *w, const bf16 *b, void *Y, int M
     // start stagger (see the kernel): about one job time in 100-MHz ticks, from the job's flops at ~4.3 TFLOP/s per CU
     static const char *env = getenv("COSA_GEMM_STAGGER");
     const int stagger = env ? atoi(env) : 0;               // start stagger (see the kernel): measured to make no difference, off
-    hipLaunchKernelGGL((gemm_bf16_v6_kernel<EPI, ABL6, AUX>), dim3(grid), dim3(512), kLdsBytesV5, st, x, w, b, Y, M, N, K, tiles_m, tiles_n, stagger);
+    hipLaunchKernelGGL((gemm_bf16_v6_kernel<EPI, ABL6, AUX>), dim3(grid), dim3(512), kLdsBytesV5, st, x, w, b, residual, Y, M, N, K, tiles_m, tiles_n, stagger);
     COSA_LAUNCH_CHECK();
     return COSA_OK;
 }
@@ -1529,27 +1596,28 @@ extern "C" int cosa_gemm_bf16(const void *X, const void *W, const void *bias, co
         default: break;
         }
     }
-    const bool fits_v6 = fits_v5 && K >= 128 && epilogue != EPI_RESIDUAL;
+    const bool fits_v6 = fits_v5 && K >= 128 && (epilogue != EPI_RESIDUAL || g_gemm_variant == 6 || g_gemm_variant == 0);
     if (g_gemm_variant >= 61 && g_gemm_variant <= 65 && fits_v6) {     // timing ablations of v6 (tools/bench_gemm_abl.py)
         switch (g_gemm_variant) {
-        case 61: return launch_v6<EPI_BIAS, 1>(x, w, b, Y, M, N, K, st);
-        case 62: return launch_v6<EPI_BIAS, 2>(x, w, b, Y, M, N, K, st);
-        case 63: return launch_v6<EPI_GELU, 1>(x, w, b, Y, M, N, K, st);
-        case 64: return launch_v6<EPI_BIAS, 3>(x, w, b, Y, M, N, K, st);
-        default: return launch_v6<EPI_BIAS, 4>(x, w, b, Y, M, N, K, st);
+        case 61: return launch_v6<EPI_BIAS, 1>(x, w, b, residual, Y, M, N, K, st);
+        case 62: return launch_v6<EPI_BIAS, 2>(x, w, b, residual, Y, M, N, K, st);
+        case 63: return launch_v6<EPI_GELU, 1>(x, w, b, residual, Y, M, N, K, st);
+        case 64: return launch_v6<EPI_BIAS, 3>(x, w, b, residual, Y, M, N, K, st);
+        default: return launch_v6<EPI_BIAS, 4>(x, w, b, residual, Y, M, N, K, st);
         }
     }
     if (fits_v6 && (g_gemm_variant == 6 || (g_gemm_variant == 0 && M >= 4096))) {       // plain stores
-        if (epilogue == EPI_BIAS) return launch_v6<EPI_BIAS>(x, w, b, Y, M, N, K, st);
-        return launch_v6<EPI_GELU>(x, w, b, Y, M, N, K, st);
+        if (epilogue == EPI_BIAS) return launch_v6<EPI_BIAS>(x, w, b, residual, Y, M, N, K, st);
+        if (epilogue == EPI_GELU) return launch_v6<EPI_GELU>(x, w, b, residual, Y, M, N, K, st);
+        return launch_v6<EPI_RESIDUAL>(x, w, b, residual, Y, M, N, K, st);
     }
     if (fits_v6 && g_gemm_variant == 7) {                              // nt stores
-        if (epilogue == EPI_BIAS) return launch_v6<EPI_BIAS, 0, 2>(x, w, b, Y, M, N, K, st);
-        return launch_v6<EPI_GELU, 0, 2>(x, w, b, Y, M, N, K, st);
+        if (epilogue == EPI_BIAS) return launch_v6<EPI_BIAS, 0, 2>(x, w, b, residual, Y, M, N, K, st);
+        return launch_v6<EPI_GELU, 0, 2>(x, w, b, residual, Y, M, N, K, st);
     }
     if (fits_v6 && g_gemm_variant == 8) {                              // nt + sc0 + sc1 stores
-        if (epilogue == EPI_BIAS) return launch_v6<EPI_BIAS, 0, 19>(x, w, b, Y, M, N, K, st);
-        return launch_v6<EPI_GELU, 0, 19>(x, w, b, Y, M, N, K, st);
+        if (epilogue == EPI_BIAS) return launch_v6<EPI_BIAS, 0, 19>(x, w, b, residual, Y, M, N, K, st);
+        return launch_v6<EPI_GELU, 0, 19>(x, w, b, residual, Y, M, N, K, st);
     }
     if ((g_gemm_variant == 5 || (g_gemm_variant == 0 && M >= 4096)) && fits_v5) {
         switch (epilogue) {
