@@ -59,10 +59,25 @@ __global__ __launch_bounds__(256) void attn_vt_kernel(const bf16 *__restrict__ q
     }
 }
 
+// Workgroup -> (query/key block, batch, head).  Workgroups are dealt round-robin to the 8 XCDs (id & 7), each with a private L2;
+// all blocks of one (batch, head) therefore take consecutive slots OF ONE XCD, so its K/V (or Q/dO) panel is fetched into
+// one L2 once instead of into all eight (the x-fastest 3-D grid spread them: 1.65 GB of HBM reads for 0.43 GB of operands).
+__device__ __forceinline__ bool attn_block_map(int nblk, int ngroups, int H, int &blk, int &b, int &h)
+{
+    const int id = blockIdx.x, xcd = id & 7, j = id >> 3;
+    const int gl = j / nblk;
+    blk = j - gl * nblk;
+    const int grp = gl * 8 + xcd;
+    if (grp >= ngroups) return false;
+    b = grp / H;
+    h = grp - b * H;
+    return true;
+}
+
 // ---- forward -----------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16 *__restrict__ qkv, const bf16 *__restrict__ vt,
                                                       bf16 *__restrict__ out, float *__restrict__ lse,
-                                                      int N, int Npad, int H, float scale_log2e,
+                                                      int N, int Npad, int H, int nblk, int ngroups, float scale_log2e,
                                                       unsigned long long *__restrict__ stamps)
 {
     __shared__ __attribute__((aligned(16))) unsigned char smem[BK * 128 + HD * VS];
@@ -72,8 +87,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16 *__restrict__ 
     unsigned char *Ks = smem;
     unsigned char *Vs = smem + BK * 128;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
-    const int b = blockIdx.z, h = blockIdx.y;
-    const int q0 = blockIdx.x * BQ + wave * 32;
+    int blk, b, h;
+    if (!attn_block_map(nblk, ngroups, H, blk, b, h)) return;
+    const int q0 = blk * BQ + wave * 32;
     const size_t rs = (size_t)3 * H * HD;          // elements per token row of qkv
 
     // Q fragments: B operand of S^T = K Q^T  (lane: query r, d = 16s + 8hh + j)
@@ -217,7 +233,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16 *__restrict__ 
 // workgroup's barrier / staging phase overlaps the others' compute.
 __global__ __launch_bounds__(128, 2) void attn_fwd2_kernel(const bf16 *__restrict__ qkv, const bf16 *__restrict__ vt,
                                                        bf16 *__restrict__ out, float *__restrict__ lse,
-                                                       int N, int Npad, int H, float scale_log2e,
+                                                       int N, int Npad, int H, int nblk, int ngroups, float scale_log2e,
                                                        unsigned long long *__restrict__ stamps)
 {
     __shared__ __attribute__((aligned(16))) unsigned char smem[BK * 128 + HD * VS];
@@ -225,8 +241,9 @@ __global__ __launch_bounds__(128, 2) void attn_fwd2_kernel(const bf16 *__restric
     unsigned char *Ks = smem;
     unsigned char *Vs = smem + BK * 128;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
-    const int b = blockIdx.z, h = blockIdx.y;
-    const int q0 = blockIdx.x * BQ + wave * 64;
+    int blk, b, h;
+    if (!attn_block_map(nblk, ngroups, H, blk, b, h)) return;
+    const int q0 = blk * BQ + wave * 64;
     const size_t rs = (size_t)3 * H * HD;
     bf16x8 qf[2][4];
 #pragma unroll
@@ -472,13 +489,14 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const bf16 *__restri
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16 *__restrict__ qkv, const bf16 *__restrict__ dO,
                                                          const bf16 *__restrict__ kt, const float *__restrict__ lse,
                                                          const float *__restrict__ delta, bf16 *__restrict__ dqkv,
-                                                         int N, int Npad, int H, float scale)
+                                                         int N, int Npad, int H, int nblk, int ngroups, float scale)
 {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BK * 128 + HD * VS];
     unsigned char *Ks = smem, *Vsr = smem + BK * 128, *Kts = smem + 2 * BK * 128;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
-    const int b = blockIdx.z, h = blockIdx.y;
-    const int q0 = blockIdx.x * BQ + wave * 32;
+    int blk, b, h;
+    if (!attn_block_map(nblk, ngroups, H, blk, b, h)) return;
+    const int q0 = blk * BQ + wave * 32;
     const size_t rs = (size_t)3 * H * HD;
     const int qrow = min(q0 + r, N - 1);
     const bf16 *qp = qkv + ((size_t)b * N + qrow) * rs + h * HD + 8 * hh;
@@ -556,15 +574,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16 *__restrict
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16 *__restrict__ qkv, const bf16 *__restrict__ dO,
                                                           const bf16 *__restrict__ qt, const bf16 *__restrict__ dot,
                                                           const float *__restrict__ lse, const float *__restrict__ delta,
-                                                          bf16 *__restrict__ dqkv, int N, int Npad, int H, float scale)
+                                                          bf16 *__restrict__ dqkv, int N, int Npad, int H, int nblk, int ngroups, float scale)
 {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BK * 128 + 2 * HD * VS + 2 * BK * 4];
     unsigned char *Qs = smem, *dOs = smem + BK * 128, *Qts = smem + 2 * BK * 128, *dOts = Qts + HD * VS;
     float *lse_s = reinterpret_cast<float *>(dOts + HD * VS);
     float *dl_s = lse_s + BK;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
-    const int b = blockIdx.z, h = blockIdx.y;
-    const int key0 = blockIdx.x * BQ + wave * 32;
+    int blk, b, h;
+    if (!attn_block_map(nblk, ngroups, H, blk, b, h)) return;
+    const int key0 = blk * BQ + wave * 32;
     const size_t rs = (size_t)3 * H * HD;
     const int krow = min(key0 + r, N - 1);
     const bf16 *kp = qkv + ((size_t)b * N + krow) * rs + (size_t)H * HD + h * HD + 8 * hh;
@@ -697,13 +716,14 @@ extern "C" int cosa_attn_fwd(const void *qkv, void *out, float *lse, int B, int 
     }
     // measured (tools/bench_attn.py): 2 waves x 64 queries wins for long sequences (N=1765: 568 vs 460 TF), the 4 x 32
     // kernel with its register prefetch for short ones (N=785: 384 vs 358 TF).  flags bit 1 / bit 2 force either.
+    const int nblk = (N + BQ - 1) / BQ;
     if ((flags & 2) || (!(flags & 4) && N < 1024))
-        hipLaunchKernelGGL(attn_fwd_kernel, dim3((N + BQ - 1) / BQ, H, B), dim3(256), 0, st, static_cast<const bf16 *>(qkv), vt,
-                           static_cast<bf16 *>(out), lse, N, Npad, H, scale * 1.4426950408889634f,
+        hipLaunchKernelGGL(attn_fwd_kernel, dim3(nblk * ((B * H + 7) / 8 * 8)), dim3(256), 0, st, static_cast<const bf16 *>(qkv), vt,
+                           static_cast<bf16 *>(out), lse, N, Npad, H, nblk, B * H, scale * 1.4426950408889634f,
                            reinterpret_cast<unsigned long long *>(stamps));
     else
-        hipLaunchKernelGGL(attn_fwd2_kernel, dim3((N + BQ - 1) / BQ, H, B), dim3(128), 0, st, static_cast<const bf16 *>(qkv), vt,
-                           static_cast<bf16 *>(out), lse, N, Npad, H, scale * 1.4426950408889634f,
+        hipLaunchKernelGGL(attn_fwd2_kernel, dim3(nblk * ((B * H + 7) / 8 * 8)), dim3(128), 0, st, static_cast<const bf16 *>(qkv), vt,
+                           static_cast<bf16 *>(out), lse, N, Npad, H, nblk, B * H, scale * 1.4426950408889634f,
                            reinterpret_cast<unsigned long long *>(stamps));
     COSA_LAUNCH_CHECK();
     return COSA_OK;
@@ -736,10 +756,11 @@ extern "C" int cosa_attn_bwd(const void *qkv, const void *out, const void *dout,
     const bf16 *q = static_cast<const bf16 *>(qkv), *o = static_cast<const bf16 *>(out), *d_o = static_cast<const bf16 *>(dout);
     hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3(Npad / BK, H, B), dim3(256), 0, st, q, d_o, o, qt, kt, dot, delta, N, Npad, H);
     COSA_LAUNCH_CHECK();
-    const dim3 grid((N + BQ - 1) / BQ, H, B);
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, st, q, d_o, kt, lse, delta, static_cast<bf16 *>(dqkv), N, Npad, H, scale);
+    const int nblk = (N + BQ - 1) / BQ;
+    const dim3 grid(nblk * ((B * H + 7) / 8 * 8));
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, st, q, d_o, kt, lse, delta, static_cast<bf16 *>(dqkv), N, Npad, H, nblk, B * H, scale);
     COSA_LAUNCH_CHECK();
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, st, q, d_o, qt, dot, lse, delta, static_cast<bf16 *>(dqkv), N, Npad, H, scale);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, st, q, d_o, qt, dot, lse, delta, static_cast<bf16 *>(dqkv), N, Npad, H, nblk, B * H, scale);
     COSA_LAUNCH_CHECK();
     return COSA_OK;
 }
