@@ -853,8 +853,11 @@ template <int EPI, int ABL6 = 0, int AUX = 0>
 __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const bf16 *__restrict__ X, const bf16 *__restrict__ W,
                                                              const bf16 *__restrict__ bias, const float *__restrict__ R,
                                                              void *__restrict__ Yv, int M, int N, int K, int tiles_m, int tiles_n,
-                                                             int stagger_ticks)
+                                                             int stagger_ticks, unsigned long long *__restrict__ stamps)
 {
+    // optional device-side span of this launch (100 MHz wall clock; min start / max end over workgroups): HIP events cannot be
+    // recorded inside a captured hipGraph on ROCm, so bench.py's roofline leg reads these (cosa_gemm_set_stamp_slot)
+    if (stamps && threadIdx.x == 0) atomicMin(&stamps[0], __builtin_amdgcn_s_memrealtime());
     constexpr bool RES = EPI == EPI_RESIDUAL;          // fp32 out = fp32 residual + X W^T + bias
     constexpr int ES = RES ? 4 : 2;
     constexpr int ABL = 0;
@@ -1165,6 +1168,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const bf16 *__rest
     V6_EPI(1, 0, cY);
     if (wr == 0) V5_BARRIER();                         // re-align the two groups
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the dead-descriptor DMA of the last K-tiles still writes (zeros) to LDS
+    if (stamps && threadIdx.x == 0) atomicMax(&stamps[1], __builtin_amdgcn_s_memrealtime());
 #undef V6_LOAD_BIAS
 #undef V6_RLOAD
 #undef V6_WAIT
@@ -1479,6 +1483,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
 
 using namespace cosa;
 
+static unsigned long long *g_gemm_stamp_slot = nullptr;
+extern "C" void cosa_gemm_set_stamp_slot(void *slot) { g_gemm_stamp_slot = static_cast<unsigned long long *>(slot); }
+
 static int env_variant()
 {
     const char *e = getenv("COSA_GEMM_VARIANT");
@@ -1546,7 +1553,9 @@ static int launch_v6(const bf16 *x, const bf16 *w, const bf16 *b, const float *r
     // start stagger (see the kernel): about one job time in 100-MHz ticks, from the job's flops at ~4.3 TFLOP/s per CU
     static const char *env = getenv("COSA_GEMM_STAGGER");
     const int stagger = env ? atoi(env) : 0;               // start stagger (see the kernel): measured to make no difference, off
-    hipLaunchKernelGGL((gemm_bf16_v6_kernel<EPI, ABL6, AUX>), dim3(grid), dim3(512), kLdsBytesV5, st, x, w, b, residual, Y, M, N, K, tiles_m, tiles_n, stagger);
+    hipLaunchKernelGGL((gemm_bf16_v6_kernel<EPI, ABL6, AUX>), dim3(grid), dim3(512), kLdsBytesV5, st, x, w, b, residual, Y, M, N, K, tiles_m, tiles_n, stagger,
+                       g_gemm_stamp_slot);
+    g_gemm_stamp_slot = nullptr;                            // one-shot
     COSA_LAUNCH_CHECK();
     return COSA_OK;
 }
@@ -1570,6 +1579,7 @@ static int launch_v4(const bf16 *x, const bf16 *w, const bf16 *b, const float *r
 extern "C" int cosa_gemm_bf16(const void *X, const void *W, const void *bias, const float *residual, void *Y,
                               int M, int N, int K, int epilogue, void *stream)
 {
+    struct ClearSlot { ~ClearSlot() { g_gemm_stamp_slot = nullptr; } } clear_slot_;      // the stamp slot is one-shot whatever kernel ran
     COSA_REQUIRE(X && W && bias && Y, "cosa_gemm_bf16: null pointer");
     COSA_REQUIRE(M > 0 && N > 0 && K > 0, "cosa_gemm_bf16: bad shape");
     COSA_REQUIRE(N % BN == 0 && K % BK == 0, "cosa_gemm_bf16: N must be a multiple of 128 and K of 64 (got N=%d K=%d)", N, K);

@@ -51,7 +51,8 @@ class KernelStamps:
         return int(ok.sum()), float(ticks.sum()) * 1e-8, fl
 
 
-stamps = None     # set by bench.py to a KernelStamps to switch the stamping on
+stamps = None     # set by bench.py to a KernelStamps to switch the stamping on (attention forward)
+gemm_stamps = None   # likewise for the projection GEMMs (persistent 256x256 kernel)
 
 
 def _attn_fwd(qkv, B, N, H, out=None):
@@ -124,6 +125,8 @@ def gemm_bf16(x, w, b, epilogue=EPI_BIAS, residual=None, out=None):
     N = w.shape[0]
     if out is None:
         out = torch.empty((M, N), device=x.device, dtype=torch.float32 if epilogue == EPI_RESIDUAL else torch.bfloat16)
+    if gemm_stamps is not None and M >= 4096:
+        _C.lib().cosa_gemm_set_stamp_slot(gemm_stamps.next_slot(2.0 * M * N * K))
     with _C.profiled("gemm_bf16"):
         _C.check(_C.lib().cosa_gemm_bf16(_C.ptr(x), _C.ptr(w), _C.ptr(b), _C.ptr(residual), _C.ptr(out), M, N, K, epilogue,
                                          _C.stream_ptr()), "cosa_gemm_bf16")

@@ -104,12 +104,12 @@ class CoSATrainer:
     def _teacher(self, wimg, cls_label):
         args = self.args
         act = None if args.use_cammix else cls_label
-        st = nn_ops.stamps
-        if st is not None:                      # kernel-span slots are re-dealt from 0 every step (teacher first)
+        sts = [s_ for s_ in (nn_ops.stamps, nn_ops.gemm_stamps) if s_ is not None]
+        for st in sts:                          # kernel-span slots are re-dealt from 0 every step (teacher first)
             st.n, st.flops = 0, []
         if not self.use_graph or (self._graph is None and self._graph_calls < 2):
             self._graph_calls += 1
-            if st is not None:
+            for st in sts:
                 st.reset()
             if self._shadows is not None and self._fused_step is None:
                 self._shadows.refresh()
@@ -121,7 +121,7 @@ class CoSATrainer:
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, capture_error_mode="thread_local"):   # RCCL's watchdog thread may poll events meanwhile
-                if st is not None:
+                for st in sts:
                     st.reset()
                 if self._fused_step is None:
                     self._shadows.refresh()
@@ -129,12 +129,12 @@ class CoSATrainer:
                                                             _active_labels=None if args.use_cammix else self._s_lab,
                                                             _seg_scales=self.fused_losses)
             self._graph = g
-            self._g_stamps = (st.n, list(st.flops)) if st is not None else None
+            self._g_stamps = [(st.n, list(st.flops)) for st in sts]
         self._s_wimg.copy_(wimg)
         self._s_lab.copy_(cls_label)
         self._graph.replay()
-        if st is not None and self._g_stamps is not None:
-            st.n, st.flops = self._g_stamps[0], list(self._g_stamps[1])
+        for st, (n_, fl_) in zip(sts, getattr(self, "_g_stamps", None) or []):
+            st.n, st.flops = n_, list(fl_)
         return self._s_out
 
     # main.py:114-252 -------------------------------------------------------------------------------

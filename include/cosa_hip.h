@@ -159,7 +159,12 @@ int cosa_gemm_wgrad_bf16(const void *dY, const void *X, float *dW, float *db, in
  *   Wt [9][Cout][Cin] bf16 (tap-major: t = ky*3 + kx);  Y [B*h*w, Cout] bf16;  padding = dilation                               */
 int cosa_conv3x3_dilated_nhwc(const void *X, const void *Wt, void *Y, int B, int h, int w, int Cin, int Cout, int dilation,
                               int img_rows, int row_off, int ldx, int relu, void *stream);
-void cosa_gemm_set_variant(int v);   /* 0 (default): per-shape choice; 1: 128x128 2-stage; 2: 256x128 3-stage; 3: 256x256 8-wave */
+void cosa_gemm_set_variant(int v);   /* 0 (default): per-shape choice; 1: 128x128 2-stage; 2: 256x128 3-stage; 3: 256x256 8-wave;
+                                      * 5: 256x256 4-phase ping-pong; 6: the same, persistent with the epilogue in the MFMA shadow      */
+/* measurement hook: the NEXT cosa_gemm_bf16 launch (persistent 256x256 kernel only) writes its device-clock span
+ * (100 MHz s_memrealtime: min start / max end over workgroups) to slot[0..1] (uint64, caller-initialised to max / 0).
+ * One-shot; used by bench.py because HIP events cannot be recorded inside a captured hipGraph.                       */
+void cosa_gemm_set_stamp_slot(void *slot);
 int cosa_layernorm(const float *x, const void *gamma, const void *beta, void *y_bf16, float *y_f32,
                    int rows, int dim, float eps, void *stream);
 
