@@ -107,11 +107,42 @@ def par_refine_ms_per_img(trainer, simg, lab, box, dev, opt, C):
         torch.cuda.synchronize()
         return a.elapsed_time(e) / n
     t0, t1 = timed(None), timed(par)
+
+    # bilateral (dense-energy regulariser) ms/img: get_energy_loss forward + backward at S/2 on the same images (SURVEY d-1), and the
+    # content-dependent worst case of both stages on uniform-noise images (d-2: noise inflates the lattice ~30x)
+    layer = seg_helper.DenseEnergyLoss(weight=1e-7, sigma_rgb=15, sigma_xy=100, scale_factor=0.5)
+    mask = torch.randint(0, C + 1, (b, S, S), generator=g).to(dev).float()
+
+    def timed_bilateral(img, n=5):
+        logit = torch.randn(b, C + 1, S, S, generator=g).to(dev).requires_grad_(True)
+
+        def f():
+            loss = seg_helper.get_energy_loss(img, logit, mask, box, layer)
+            loss.backward()
+        f()
+        a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(n):
+            f()
+        e.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(e) / n
+    tb = timed_bilateral(simg)
+    noise = torch.rand(b, 3, S, S, generator=g).to(dev)
+    mean = torch.tensor([123.675, 116.28, 103.53], device=dev).view(1, 3, 1, 1)
+    std = torch.tensor([58.395, 57.12, 57.375], device=dev).view(1, 3, 1, 1)
+    noise_norm = (noise * 255 - mean) / std
+    den_keep, den = den, noise                       # `timed` closes over `den`
+    t1n = timed(par, n=5)
+    den = den_keep
+    tbn = timed_bilateral(noise_norm, n=3)
     K = float((lab.sum(1) + 1).mean())
     s = S // 2
     alg = 4.0 * s * s * (3 + 2 * K * 10) * 2 * b            # bytes per cam2mask call (hi + lo stacks), BASELINE.md §2
     per_call = (t1 - t0) * 1e-3
     return {"ms_per_img": round(2 * (t1 - t0) / b, 5), "cam2mask_no_par_ms_per_img": round(t0 / b, 5), "mean_K": round(K, 2),
+            "bilateral_fwd_bwd_ms_per_img": round(tb / b, 5),
+            "noise_images": {"par_ms_per_img": round(2 * (t1n - t0) / b, 5), "bilateral_fwd_bwd_ms_per_img": round(tbn / b, 5)},
             "roofline": {"bound": "hbm", "achieved": round(alg / per_call / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(alg / per_call / 8e12, 4), "algorithmic_MB_per_call": round(alg / 1e6, 1)}}
 
