@@ -28,6 +28,7 @@ SOURCES = {
     "label_kernels.hip": EXACT,
     "par_kernels.hip": EXACT,
     "permuto_kernels.hip": EXACT,
+    "eval_kernels.hip": EXACT,
     "vit_kernels.hip": FAST,
     "gemm_kernels.hip": FAST,
     "attn_kernels.hip": FAST + ["-fno-honor-nans"],    # drops the canonicalising v_max the compiler puts in front of fmaxf

@@ -1,0 +1,87 @@
+"""evaluation_engine -- the validation pass of the reference (evaluation_engine.py:11-297), device-resident.
+
+Same call surface and return values as the reference's `evaluate`.  What changes is where the work happens:
+
+* per image: five scales x two flips through the network (`seg_helper.multi_scale_camsegv3`), then ONE kernel turns the (S,S) CAMs and
+  logits into the three uint8 label maps at the ground truth's resolution (`seg_helper.eval_label_maps` = F.interpolate x3 +
+  cam_to_label x2 + seg_validation + argmax x2 of the reference) -- nothing of size [1,C,H,W] is materialised;
+* the maps never leave the GPU: four confusion matrices are accumulated on the device (`evaluation.ConfusionMeter`) and summed over
+  ranks with one all-reduce, instead of storing every map in host lists and shipping them to rank 0 through temp files (:203-216);
+* per-image average precision is computed on the device and accumulated without a host sync.
+
+Not built (outside SURVEY section 8's hot path and its "next" row f-1): dense-CRF post-processing (`getcrf`), image/CAM dumps
+(`save_result`, `save_rawcam`) and the non-default `threshold_filters` sweep; asking for them raises NotImplementedError.
+"""
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+from .utils import evaluation, seg_helper, torch_helper
+
+EVAL_SCALES = [1.0, 0.5, 1.5, 0.75, 1.25]          # evaluation_engine.py:84
+
+
+def evaluate(model, data_loader, args, df=None, save_result=False, save_rawcam=False, epoch=None, threshold_filters=None, getcrf=False,
+             s_or_t='t', get_camiou=False, isfinal=False, class_list=None):
+    if save_result or save_rawcam:
+        raise NotImplementedError("evaluate: save_result / save_rawcam (image dumps) are not part of the device path")
+    if getcrf or threshold_filters:
+        raise NotImplementedError("evaluate: dense-CRF (getcrf) and threshold_filters are not built (SURVEY f-4)")
+    assert s_or_t in ['s', 't']
+    distributed = dist.is_available() and dist.is_initialized()
+    rank = dist.get_rank() if distributed else 0
+    device = next(model.parameters()).device
+    if device.type != "cuda":
+        raise RuntimeError("evaluate runs on the GPU (HIP kernels); no CPU path")
+    nc = args.num_classes
+    meters = {k: evaluation.ConfusionMeter(nc, device) for k in ("cam", "cam_aux", "seg_ps", "seg_vd")}
+    ap_sum = torch.zeros(2, device=device, dtype=torch.float64)          # sums of per-batch mean AP (cls, cls_aux) ...
+    ap_cnt = 0                                                           # ... over the batches (AverageMeter semantics, :86-92)
+    was_training = model.training
+    model.eval()
+    with torch.no_grad():
+        for data in data_loader:
+            name, img_org, labels, cls_label = data
+            labels = labels.to(device, non_blocking=True)
+            cls_label = cls_label.to(device, non_blocking=True).float()
+            img_org = img_org.to(device, non_blocking=True)
+            inputs = F.interpolate(img_org, size=[args.crop_size, args.crop_size], mode='bilinear', align_corners=False)
+            cams, cams_aux, seg_ps, cls_final, cls_aux = seg_helper.multi_scale_camsegv3(model, inputs, EVAL_SCALES, getcls=True)
+            # classification AP of this batch (:86-92; cls_* are [1,C] sums over scales and flips, compared with every label row)
+            for j, logit in enumerate((cls_final, cls_aux)):
+                ap, valid = torch_helper.average_precision(cls_label, torch.sigmoid(logit.float()).expand_as(cls_label))
+                ap_sum[j] += (ap * valid).sum() / valid.sum().clamp_min(1)
+            ap_cnt += 1
+            size = labels.shape[1:]
+            cam_label, pred_ps, pred_vd = seg_helper.eval_label_maps(cams, seg_ps, cls_label, size, args.bkg_thre)
+            cam_aux_label, _, _ = seg_helper.eval_label_maps(cams_aux, None, cls_label, size, args.bkg_thre)
+            gt = labels.to(torch.uint8)
+            meters["cam"].update(gt, cam_label)
+            meters["cam_aux"].update(gt, cam_aux_label)
+            meters["seg_ps"].update(gt, pred_ps)
+            meters["seg_vd"].update(gt, pred_vd)
+    for m in meters.values():
+        m.all_reduce()
+    if was_training:
+        model.train()
+    if rank != 0:
+        return (None,) * (5 if get_camiou else 4)
+
+    cam_score, cam_aux_score, seg_vd_score = meters["cam"].scores(), meters["cam_aux"].scores(), meters["seg_vd"].scores()
+    metrics, names = [cam_score, cam_aux_score, seg_vd_score], ["CAM", "aux_CAM", "Seg_vd"]
+    if isfinal:
+        metrics, names = [seg_vd_score], ["Seg_vd"]
+    cls_aps = [float(v) / max(ap_cnt, 1) for v in ap_sum.tolist()]
+    if class_list is None:
+        class_list = [str(i) for i in range(nc)]
+    tab_results, _, mioulist = torch_helper.format_tabs(scores=metrics, name_list=names, cat_list=class_list)
+    if not df:
+        df = {'Iterations': [], 'mIoU': [], 'Metrics': [], 'ST': []}
+    df['Iterations'].extend([epoch] * len(names))
+    df['mIoU'].extend(mioulist)
+    df['Metrics'].extend(names)
+    df['ST'].extend([s_or_t] * len(names))
+    seg_vd_miou, cam_miou = mioulist[-1], mioulist[0]
+    if get_camiou:
+        return tab_results, seg_vd_miou, cam_miou, df, cls_aps
+    return tab_results, seg_vd_miou, df, cls_aps

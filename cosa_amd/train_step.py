@@ -32,7 +32,7 @@ def default_args(dataset="VOC12", **over):
              crop_size=448, ignore_index=255, num_classes=21, batch_size=2, max_iters=40000, warmup_iters=6000, lr=6e-5,
              min_mult=0.0, wt_dec=1e-2, wt_dec_mult=1.0, lrscale=10.0, freeze_norm=False, momentum=0.9994, seg_weight=0.1,
              segfg_alpha=0.5, cam_weight=0.05, seg_softmaxtemp=0.01, reg_weight=0.05, pseudo_scales=[1.0, 0.5, 1.5],
-             high_thre=0.7, high_thre_aux=0.7, low_thre=0.25, low_thre_aux=0.25, par_downscale=2, usepar=False,
+             high_thre=0.7, high_thre_aux=0.7, low_thre=0.25, low_thre_aux=0.25, bkg_thre=0.5, par_downscale=2, usepar=False,
              aux_cam2seg=True, aux_cam2seg_alpha=0.5, aux_seg2cam=False, aux_seg2cam_alpha=0.5, after_softmax=False,
              detach='none', use_cammix=False, compute_dtype=torch.bfloat16, teacher_graph=True, fused_losses=True, fused_optimizer=True)
     if dataset == "VOC12":

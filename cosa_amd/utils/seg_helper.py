@@ -74,6 +74,101 @@ def multi_scale_camseg(model, imgs, scales, _active_labels=None, _seg_scales=Fal
     return cam, cam_aux, (seg_list if _seg_scales else seg)
 
 
+def multi_scale_camsegv3(model, imgs, scales, getcls=False):
+    """Evaluation-time variant (utils/seg_helper.py:399-450; evaluation_engine.py:82-85 calls it with five scales x two flips):
+    same fused tail as multi_scale_camseg, plus the classification logits summed over scales and over {orig, flip}
+    (`cls_f_ += sum(cls_f, dim=0)`, :432-434).  cam_aux again keeps only the LAST scale (:426)."""
+    b, c, h, w = imgs.shape
+    assert 1.0 in scales, 'scale 1.0 must be in scales'
+    assert h == w, "square inputs only (evaluation resizes to crop_size x crop_size first)"
+    _C.require_cuda(imgs)
+    cam = cam_aux = seg = None
+    cls_f_ = cls_a_ = None
+    with torch.no_grad():
+        inputs = []
+        for s in scales:
+            imgs_ = imgs if s == 1.0 else F.interpolate(imgs, size=(int(s * h), int(s * w)), mode='bilinear', align_corners=False)
+            inputs.append(torch.cat([imgs_, imgs_.flip(-1)], dim=0))
+        multi = model.forward_multi(inputs) if getattr(model, "can_forward_multi", lambda _x: False)(inputs[0]) else None
+        for si, s in enumerate(scales):
+            cls_f, cls_a, _, _seg, _cam, _cam_aux = multi[si] if multi is not None else model(inputs[si], cam_only=False)
+            if cam is None:
+                cam = torch.empty((b, _cam.shape[1], h, w), device=imgs.device, dtype=torch.float32)
+                cam_aux = torch.empty_like(cam)
+                seg = torch.empty((b, _seg.shape[1], h, w), device=imgs.device, dtype=torch.float32)
+            _flip_merge_upsample(_cam, cam, b, h, 0, si > 0)
+            if si == len(scales) - 1:
+                _flip_merge_upsample(_cam_aux, cam_aux, b, h, 0, False)
+            _flip_merge_upsample(_seg, seg, b, h, 1, si > 0)
+            if getcls:
+                cf, ca = cls_f.float().sum(0, keepdim=True), cls_a.float().sum(0, keepdim=True)
+                cls_f_ = cf if cls_f_ is None else cls_f_ + cf
+                cls_a_ = ca if cls_a_ is None else cls_a_ + ca
+        cam_minmax_norm_(cam)
+        cam_minmax_norm_(cam_aux)
+    if getcls:
+        return cam, cam_aux, seg, cls_f_, cls_a_
+    return cam, cam_aux, seg
+
+
+# --------------------------------------------------------------------------------------------
+# cam_to_label / seg_validation / evaluation label maps  (utils/seg_helper.py:515-546, 581-591; evaluation_engine.py:96-126,198-200)
+# --------------------------------------------------------------------------------------------
+def cam_to_label(cam, cls_label, img_box=None, bkg_thre=None, high_thre=None, low_thre=None, ignore_mid=False, ignore_index=None):
+    """utils/seg_helper.py:515-546: argmax of the class-validated CAM (+1), background where the max <= bkg_thre.
+    Returns the int64 label map when `img_box` is None, else `(valid_cam, pseudo_label)` with the label confined to the boxes
+    (ignore_index outside) and, if `ignore_mid`, the high/low threshold band marked ignore_index."""
+    _C.require_cuda(cam)
+    if bkg_thre is None:
+        raise TypeError("cam_to_label: bkg_thre is required (the reference compares against it unconditionally)")
+    cam = cam.contiguous().float()
+    b, c, h, w = cam.shape
+    cls = cls_label.contiguous().float() if cls_label is not None else None
+    label = torch.empty((b, h, w), device=cam.device, dtype=torch.int64)
+    boxes = valid = None
+    if img_box is not None:
+        boxes = _boxes_to_device(img_box, cam.device)
+        if boxes.shape != (b, 4):
+            raise ValueError("cam_to_label: img_box must be [b,4]")
+        if ignore_index is None or (ignore_mid and (high_thre is None or low_thre is None)):
+            raise TypeError("cam_to_label: ignore_index (and high_thre/low_thre with ignore_mid) are required with img_box")
+        valid = torch.empty_like(cam)
+    _C.check(_C.lib().cosa_cam_to_label(_C.ptr(cam), _C.ptr(cls), b, c, h, w, float(bkg_thre), _C.ptr(boxes), int(bool(ignore_mid)),
+                                        float(high_thre or 0.0), float(low_thre or 0.0), int(ignore_index if ignore_index is not None else 255),
+                                        _C.ptr(label), _C.ptr(valid), _C.stream_ptr()), "cosa_cam_to_label")
+    return label if img_box is None else (valid, label)
+
+
+def seg_validation(seg, cls_label):
+    """utils/seg_helper.py:581-591: logits of the classes absent from the image-level label set to -1e5 (background kept)."""
+    if cls_label is None:
+        return seg
+    b = seg.shape[0]
+    present = torch.cat([torch.ones(b, 1, device=seg.device, dtype=torch.bool), cls_label != 0], dim=1)
+    return torch.where(present[:, :, None, None], seg, torch.full((), -1e5, device=seg.device, dtype=seg.dtype))
+
+
+def eval_label_maps(cam, seg, cls_label, size, bkg_thre):
+    """One launch for evaluation_engine.py:96-126,198-200: `F.interpolate(cam, size)` -> cam_to_label(bkg_thre),
+    `F.interpolate(seg, size)` -> argmax, seg_validation -> argmax, without the resized tensors.
+    cam [b,C,S,S] and/or seg [b,C+1,S,S] -> uint8 maps [b,H,W]: (cam_label, pred_ps, pred_vd) (None for an absent input)."""
+    H, W = int(size[0]), int(size[1])
+    ref = cam if cam is not None else seg
+    _C.require_cuda(ref, cls_label)
+    b, S = ref.shape[0], ref.shape[-1]
+    C = cls_label.shape[1]
+    cam = cam.contiguous().float() if cam is not None else None
+    seg = seg.contiguous().float() if seg is not None else None
+    if (cam is not None and cam.shape != (b, C, S, S)) or (seg is not None and seg.shape != (b, C + 1, S, S)):
+        raise ValueError("eval_label_maps: cam must be [b,C,S,S] and seg [b,C+1,S,S]")
+    mk = lambda: torch.empty((b, H, W), device=ref.device, dtype=torch.uint8)
+    lc = mk() if cam is not None else None
+    lp, lv = (mk(), mk()) if seg is not None else (None, None)
+    _C.check(_C.lib().cosa_eval_labels(_C.ptr(cam), _C.ptr(seg), _C.ptr(cls_label.contiguous().float()), b, C, S, H, W, float(bkg_thre),
+                                       _C.ptr(lc), _C.ptr(lp), _C.ptr(lv), _C.stream_ptr()), "cosa_eval_labels")
+    return lc, lp, lv
+
+
 # --------------------------------------------------------------------------------------------
 # cam_validation / cam2mask  (utils/seg_helper.py:547-551, 721-797)
 # --------------------------------------------------------------------------------------------

@@ -162,3 +162,77 @@ class FusedAdamWEMAStep:
         _C.check(_C.lib().cosa_fused_adamw_ema(_C.ptr(self.d_rec), _C.ptr(self.d_chunks), self.n_chunks, float(b1), float(b2),
                                                float(groups[0]["eps"]), int(opt.global_step), self.momentum, _C.stream_ptr()),
                  "cosa_fused_adamw_ema")
+
+
+# --------------------------------------------------------------------------------------------
+# evaluation helpers  (utils/torch_helper.py:12-30 format_tabs, :61-90 AverageMeter, :140-148 compute_mAP)
+# --------------------------------------------------------------------------------------------
+def average_precision(labels, outputs):
+    """Per-sample average precision over the class axis, on the device: [b,C] {0,1} labels and scores -> ([b] AP, [b] valid).
+
+    What sklearn's average_precision_score returns for each row (utils/torch_helper.py:146): sum over the distinct score
+    thresholds, descending, of (R_n - R_{n-1}) * P_n; tied scores form ONE threshold.  Rows without a positive are invalid
+    (the reference skips them)."""
+    y = labels.double()
+    s, order = torch.sort(outputs.double(), dim=1, descending=True, stable=True)
+    yt = torch.gather(y, 1, order)
+    C = y.shape[1]
+    tps = yt.cumsum(1)
+    last = torch.ones_like(s, dtype=torch.bool)
+    last[:, :-1] = s[:, 1:] != s[:, :-1]                                  # last element of every run of equal scores
+    npos = y.sum(1, keepdim=True)
+    prec = tps / torch.arange(1, C + 1, device=y.device, dtype=torch.float64)
+    rec = tps / npos.clamp_min(1.0)
+    # recall at the previous threshold: running max of the recall at `last` positions strictly before i
+    rec_at = torch.where(last, rec, torch.zeros_like(rec))
+    prev = torch.cat([torch.zeros_like(rec[:, :1]), torch.cummax(rec_at, dim=1).values[:, :-1]], dim=1)
+    ap = (torch.where(last, (rec - prev) * prec, torch.zeros_like(rec))).sum(1)
+    return ap, npos[:, 0] > 0
+
+
+def compute_mAP(labels, outputs):
+    """utils/torch_helper.py:140-148: list of per-sample APs (samples without positives skipped).  One device->host copy."""
+    ap, valid = average_precision(labels, outputs)
+    return [float(a) for a, v in zip(ap.tolist(), valid.tolist()) if v]
+
+
+class AverageMeter:
+    """utils/torch_helper.py:61-90"""
+
+    def __init__(self, *keys):
+        self._data = {k: [0.0, 0] for k in keys}
+
+    def add(self, d):
+        for k, v in d.items():
+            e = self._data.setdefault(k, [0.0, 0])
+            e[0] += v
+            e[1] += 1
+
+    def get(self, *keys):
+        vals = [self._data[k][0] / self._data[k][1] for k in keys]
+        return vals[0] if len(vals) == 1 else tuple(vals)
+
+    def pop(self, key=None):
+        if key is None:
+            for k in self._data:
+                self._data[k] = [0.0, 0]
+            return None
+        v = self.get(key)
+        self._data[key] = [0.0, 0]
+        return v
+
+
+def format_tabs(scores, name_list, cat_list=None, getmIoU_list=True):
+    """utils/torch_helper.py:12-30 without the texttable dependency: (table text, last column's mIoU, list of mIoUs), values in
+    per cent rounded to 2 decimals; the mIoU row is the plain mean over ALL classes of the rounded per-class values, as there."""
+    import numpy as np
+    keys = list(scores[0]["iou"].keys())
+    vals = np.round(np.array([list(sc["iou"].values()) for sc in scores]) * 100, 2)
+    names = [str(cat_list[i]) if cat_list is not None else str(k) for i, k in enumerate(keys)]
+    wid = max([len(n) for n in names] + [5])
+    lines = ["| " + "Class".ljust(wid) + " | " + " | ".join(n.rjust(8) for n in name_list) + " |"]
+    for i, n in enumerate(names):
+        lines.append("| " + n.ljust(wid) + " | " + " | ".join(f"{v:8.2f}" for v in vals[:, i]) + " |")
+    means = vals.mean(1)
+    lines.append("| " + "mIoU".ljust(wid) + " | " + " | ".join(f"{v:8.2f}" for v in means) + " |")
+    return "\n".join(lines), means[-1], list(means)

@@ -205,6 +205,26 @@ int cosa_optim_chunk_elems(void);
 int cosa_fused_adamw_ema(const void *records, const void *chunks, int n_chunks, float beta1, float beta2, float eps,
                          int step, float ema_momentum, void *stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Evaluation path (SURVEY f-1; evaluation_engine.py:96-126,198-200, utils/seg_helper.py:515-546,581-591,
+ * utils/evaluation.py:10-70).
+ *   cosa_eval_labels: one launch replaces F.interpolate(cam), cam_to_label, F.interpolate(seg), seg_validation and the
+ *     three argmaxes.  cam [B,C,S,S], seg [B,C+1,S,S] (either may be NULL), cls_label [B,C] -> uint8 maps [B,H,W]:
+ *     lab_cam = argmax_c(cls*cam)+1 or 0 where the max <= bkg_thre; lab_ps = argmax(seg); lab_vd = argmax with the
+ *     classes absent from cls_label masked to -1e5 (background always present).
+ *   cosa_cam_to_label: cam_to_label on an already sized CAM [B,C,H,W] -> int64 label [B,H,W]; cls_label, boxes
+ *     ([B,4] h0,h1,w0,w1; NULL = the reference's `img_box is None` return) and valid_cam (= cls*cam) optional.
+ *   cosa_confusion_hist: hist[nc*t + p] += 1 over n pixels with truth t < nc (uint8 maps, 255 = ignore);
+ *     pseudo != 0 drops the pixels whose prediction is 255 (pseudo_scores).  hist: nc*nc uint64, caller-zeroed, accumulates.
+ * ------------------------------------------------------------------------------------- */
+int cosa_eval_labels(const float *cam, const float *seg, const float *cls_label, int B, int C, int S, int H, int W,
+                     float bkg_thre, uint8_t *lab_cam, uint8_t *lab_ps, uint8_t *lab_vd, void *stream);
+int cosa_cam_to_label(const float *cam, const float *cls_label, int B, int C, int H, int W, float bkg_thre,
+                      const int32_t *boxes, int ignore_mid, float high_thre, float low_thre, long long ignore_index,
+                      long long *label, float *valid_cam, void *stream);
+int cosa_confusion_hist(const uint8_t *gt, const uint8_t *pred, size_t n, int num_classes, int pseudo,
+                        unsigned long long *hist, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -52,6 +52,12 @@ def lib():
         L.orc_dense_energy_forward.restype = ctypes.c_float
         L.orc_dense_energy_forward.argtypes = [_f32p, _f32p, _f32p, _u8p, ctypes.c_int, ctypes.c_int,
                                                ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, _f32p]
+        vp = ctypes.c_void_p      # evaluation-path entry points take optional (NULL-able) arrays: raw addresses
+        L.orc_resize_bilinear.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp]
+        L.orc_cam_to_label.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, vp,
+                                       ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_int, vp, vp]
+        L.orc_eval_labels.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, vp, vp, vp]
+        L.orc_confusion.argtypes = [vp, vp, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, vp]
         _LIB = L
     return _LIB
 
@@ -187,3 +193,70 @@ def ref_bilateralfilter_batch(images, ins, outs, N, K, H, W, sigmargb, sigmaxy):
     assert outs.dtype == np.float32 and outs.flags.c_contiguous
     R.bilateralfilter_batch(images, images.size, ins, ins.size, outs.reshape(-1), outs.size, N, K, H, W,
                             float(sigmargb), float(sigmaxy))
+
+
+# ---- evaluation path (SURVEY f-1) ---------------------------------------------------------------------------------
+def _a(x):
+    return None if x is None else x.ctypes.data
+
+
+def resize_bilinear(p, H, W):
+    p = _c(p)
+    C, h, w = p.shape
+    out = np.empty((C, H, W), np.float32)
+    lib().orc_resize_bilinear(_a(p), C, h, w, H, W, _a(out))
+    return out
+
+
+def cam_to_label(cam, cls_label, img_box=None, bkg_thre=0.5, high_thre=0.7, low_thre=0.25, ignore_mid=False, ignore_index=255):
+    """utils/seg_helper.py:515-546: label map when img_box is None, else (valid_cam, label)."""
+    cam = _c(cam)
+    B, C, H, W = cam.shape
+    lab = np.empty((B, H, W), np.int64)
+    cl = _c(cls_label) if cls_label is not None else None
+    bx = _c(img_box, np.int32) if img_box is not None else None
+    vc = np.empty_like(cam) if img_box is not None else None
+    lib().orc_cam_to_label(_a(cam), _a(cl), B, C, H, W, bkg_thre, _a(bx), int(ignore_mid), high_thre, low_thre, ignore_index,
+                           _a(lab), _a(vc))
+    return lab if img_box is None else (vc, lab)
+
+
+def eval_labels(cam, seg, cls_label, H, W, bkg_thre=0.5):
+    """one image: (S,S) CAM [C,S,S] + logits [C+1,S,S] -> uint8 label maps (cam, seg raw, seg validated) at (H,W)"""
+    cam, seg, cl = _c(cam), _c(seg), _c(cls_label)
+    C, S, _ = cam.shape
+    outs = [np.empty((H, W), np.uint8) for _ in range(3)]
+    lib().orc_eval_labels(_a(cam), _a(seg), _a(cl), C, S, H, W, bkg_thre, *[_a(o) for o in outs])
+    return outs
+
+
+def confusion(gts, preds, nc, pseudo=False):
+    hist = np.zeros((nc, nc), np.int64)
+    for g, p in zip(gts, preds):
+        g, p = _c(g, np.uint8).ravel(), _c(p, np.uint8).ravel()
+        lib().orc_confusion(_a(g), _a(p), g.size, nc, int(pseudo), _a(hist))
+    return hist
+
+
+def scores_from_hist(hist):
+    """utils/evaluation.py:21-35 from an accumulated confusion matrix"""
+    hist = hist.astype(np.float64)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        acc = np.diag(hist).sum() / hist.sum()
+        acc_cls = np.nanmean(np.diag(hist) / hist.sum(axis=1))
+        iu = np.diag(hist) / (hist.sum(axis=1) + hist.sum(axis=0) - np.diag(hist))
+    valid = hist.sum(axis=1) > 0
+    return {"pAcc": acc, "mAcc": acc_cls, "miou": np.nanmean(iu[valid]), "iou": dict(zip(range(hist.shape[0]), iu))}
+
+
+def average_precision(y_true, y_score):
+    """sklearn.metrics.average_precision_score for one sample (binary relevance over classes): AP = sum_n (R_n - R_{n-1}) P_n over
+    the distinct score thresholds, descending (tied scores form one threshold).  torch_helper.py:140-148 calls it per image."""
+    y_true, y_score = np.asarray(y_true, np.float64), np.asarray(y_score, np.float64)
+    order = np.argsort(-y_score, kind="mergesort")
+    ys, yt = y_score[order], y_true[order]
+    last = np.r_[np.where(np.diff(ys))[0], ys.size - 1]          # last index of every run of equal scores
+    tps = np.cumsum(yt)[last]
+    prec = tps / (last + 1.0)
+    rec = tps / yt.sum()
+    return float(np.sum(np.diff(np.r_[0.0, rec]) * prec))

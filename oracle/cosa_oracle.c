@@ -627,3 +627,125 @@ float orc_dense_energy_forward(const float *images, const float *seg, const floa
     free(segm); free(gate);
     return (float)(-acc / (double)N);
 }
+
+/* ========================================================================= */
+/* Evaluation path (SURVEY f-1): evaluation_engine.py:74-126,198-207,         */
+/* utils/seg_helper.py:515-546 (cam_to_label), :581-591 (seg_validation),     */
+/* utils/evaluation.py:10-70 (_fast_hist, scores, pseudo_scores).             */
+/* ========================================================================= */
+
+/* Spec R: F.interpolate(mode='bilinear', align_corners=False) to an arbitrary (H,W), as ATen's CPU kernel evaluates it for
+ * outputs of image size (pinned by tests/golden/eval.npz at 333x500, 375x500, 500x281):
+ *   scale = (float)in / (float)out;  src = max(fmaf(scale, dst + 0.5f, -0.5f), 0);  i0 = min((int)src, in-1);  l1 = src - i0
+ *   r0 = fma(p00, lx0, p01*lx1); r1 = fma(p10, lx0, p11*lx1); v = fma(r0, ly0, r1*ly1)
+ * (for the exact x2 / x0.5 / x16 ratios of the training path the fused source index equals orc_src_index's).           */
+static inline void orc_src_index_r(int dst, int in, int out, int *i0, int *i1, float *l0, float *l1)
+{
+    float scale = (float)in / (float)out;
+    float src = fmaf(scale, (float)dst + 0.5f, -0.5f);
+    if (src < 0.0f) src = 0.0f;
+    int i = (int)src;
+    if (i > in - 1) i = in - 1;
+    float lam = src - (float)i;
+    if (lam < 0.0f) lam = 0.0f;
+    if (lam > 1.0f) lam = 1.0f;
+    *i0 = i;
+    *i1 = i < in - 1 ? i + 1 : i;
+    *l1 = lam;
+    *l0 = 1.0f - lam;
+}
+
+static inline float orc_bilerp(const float *pl, int w, int y0, int y1, int x0, int x1, float ly0, float ly1, float lx0, float lx1)
+{
+    float r0 = fmaf(pl[(size_t)y0 * w + x0], lx0, pl[(size_t)y0 * w + x1] * lx1);
+    float r1 = fmaf(pl[(size_t)y1 * w + x0], lx0, pl[(size_t)y1 * w + x1] * lx1);
+    return fmaf(r0, ly0, r1 * ly1);
+}
+
+void orc_resize_bilinear(const float *p, int C, int h, int w, int H, int W, float *out)
+{
+    for (int c = 0; c < C; c++)
+        for (int Y = 0; Y < H; Y++) {
+            int y0, y1; float ly0, ly1;
+            orc_src_index_r(Y, h, H, &y0, &y1, &ly0, &ly1);
+            for (int X = 0; X < W; X++) {
+                int x0, x1; float lx0, lx1;
+                orc_src_index_r(X, w, W, &x0, &x1, &lx0, &lx1);
+                out[((size_t)c * H + Y) * W + X] = orc_bilerp(p + (size_t)c * h * w, w, y0, y1, x0, x1, ly0, ly1, lx0, lx1);
+            }
+        }
+}
+
+/* cam_to_label (seg_helper.py:515-546) on an already resized CAM [B,C,H,W].  cls_label may be NULL.  boxes (B x 4:
+ * h0,h1,w0,w1; NULL = the `img_box is None` return) ; valid_cam (optional) receives cls_label * cam.                */
+void orc_cam_to_label(const float *cam, const float *cls_label, int B, int C, int H, int W, float bkg_thre,
+                      const int *boxes, int ignore_mid, float high_thre, float low_thre, int ignore_index,
+                      int64_t *label, float *valid_cam)
+{
+    size_t hw = (size_t)H * W;
+    for (int b = 0; b < B; b++)
+        for (size_t p = 0; p < hw; p++) {
+            float best = 0.0f; int bi = 0;
+            for (int c = 0; c < C; c++) {
+                float v = cam[((size_t)b * C + c) * hw + p];
+                if (cls_label) v = cls_label[b * C + c] * v;
+                if (valid_cam) valid_cam[((size_t)b * C + c) * hw + p] = v;
+                if (c == 0 || v > best) { best = v; bi = c; }
+            }
+            int64_t l = bi + 1;
+            if (best <= bkg_thre) l = 0;
+            if (boxes) {
+                if (ignore_mid) {
+                    if (best <= high_thre) l = ignore_index;
+                    if (best <= low_thre) l = 0;
+                }
+                int y = (int)(p / W), x = (int)(p % W);
+                const int *bx = boxes + 4 * b;
+                if (!(y >= bx[0] && y < bx[1] && x >= bx[2] && x < bx[3])) l = ignore_index;
+            }
+            label[(size_t)b * hw + p] = l;
+        }
+}
+
+/* one evaluation image: resize the (S,S) CAM and segmentation logits to the ground truth's (H,W), then
+ * cam_to_label(bkg_thre) and argmax of the raw / class-validated logits (evaluation_engine.py:96-126,198-200).
+ * cam [C,S,S], seg [C+1,S,S], cls_label [C] */
+void orc_eval_labels(const float *cam, const float *seg, const float *cls_label, int C, int S, int H, int W, float bkg_thre,
+                     uint8_t *lab_cam, uint8_t *lab_ps, uint8_t *lab_vd)
+{
+    size_t ss = (size_t)S * S;
+    for (int Y = 0; Y < H; Y++) {
+        int y0, y1; float ly0, ly1;
+        orc_src_index_r(Y, S, H, &y0, &y1, &ly0, &ly1);
+        for (int X = 0; X < W; X++) {
+            int x0, x1; float lx0, lx1;
+            orc_src_index_r(X, S, W, &x0, &x1, &lx0, &lx1);
+            float best = 0.0f; int bi = 0;
+            for (int c = 0; c < C; c++) {
+                float v = cls_label[c] * orc_bilerp(cam + c * ss, S, y0, y1, x0, x1, ly0, ly1, lx0, lx1);
+                if (c == 0 || v > best) { best = v; bi = c; }
+            }
+            lab_cam[(size_t)Y * W + X] = best <= bkg_thre ? 0 : (uint8_t)(bi + 1);
+            float bp = 0.0f, bv = 0.0f; int ip = 0, iv = 0;
+            for (int c = 0; c <= C; c++) {
+                float v = orc_bilerp(seg + c * ss, S, y0, y1, x0, x1, ly0, ly1, lx0, lx1);
+                if (c == 0 || v > bp) { bp = v; ip = c; }
+                float vv = (c == 0 || cls_label[c - 1] != 0.0f) ? v : -1e5f;        /* seg_validation :588 */
+                if (c == 0 || vv > bv) { bv = vv; iv = c; }
+            }
+            lab_ps[(size_t)Y * W + X] = (uint8_t)ip;
+            lab_vd[(size_t)Y * W + X] = (uint8_t)iv;
+        }
+    }
+}
+
+/* _fast_hist (evaluation.py:10-16) accumulated into hist[nc*nc] (row = truth).  pseudo != 0: the relabelling of
+ * pseudo_scores (:43-46): truth := 255 where the prediction is 255 (those pixels drop out), prediction 255 -> 0. */
+void orc_confusion(const uint8_t *gt, const uint8_t *pred, size_t n, int nc, int pseudo, int64_t *hist)
+{
+    for (size_t i = 0; i < n; i++) {
+        int t = gt[i], p = pred[i];
+        if (pseudo && p == 255) continue;
+        if (t < nc) hist[(size_t)nc * t + p] += 1;
+    }
+}

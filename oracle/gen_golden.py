@@ -104,7 +104,8 @@ class _StubModel:
         cam = F.conv2d(f, w_cam) + 0.1 * f[:, :1].roll(1, -1)
         cam_aux = F.conv2d(f, w_aux) - 0.05 * f[:, 1:2].roll(1, -2)
         seg = F.conv2d(f, w_seg)
-        return None, None, None, seg, cam, cam_aux
+        # (classification logits only matter to multi_scale_camsegv3(getcls=True): any deterministic function will do)
+        return cam.mean((2, 3)), cam_aux.amax((2, 3)), None, seg, cam, cam_aux
 
 
 def stub_outputs(x, C):
@@ -236,6 +237,78 @@ def gen_vit(rng):
     np.savez_compressed(os.path.join(OUT, "vit_tiny.npz"), **out)
 
 
+EVAL_SIZES = [(333, 500), (375, 500), (500, 281)]
+
+
+def eval_inputs(rng, C=4, S=448):
+    """inputs of the evaluation-path goldens, rebuilt identically by the tests from the same seed: smooth low-res fields
+    taken to (S,S) by an exact 16x bilinear resize (scale 1/16 is a power of two: no rounding in the source index)."""
+    cam_lr = torch.from_numpy(smooth_field(rng, C, S // 16, S // 16, 0.0, 1.0).reshape(1, C, S // 16, S // 16))
+    seg_lr = torch.from_numpy(smooth_field(rng, C + 1, S // 16, S // 16, -3.0, 3.0).reshape(1, C + 1, S // 16, S // 16))
+    cam = F.interpolate(cam_lr, size=(S, S), mode="bilinear", align_corners=False)
+    seg = F.interpolate(seg_lr, size=(S, S), mode="bilinear", align_corners=False)
+    cls_label = torch.tensor([[1.0, 0.0, 1.0, 1.0]])[:, :C]
+    return cam, seg, cls_label
+
+
+def gen_eval(rng):
+    """evaluation path (SURVEY f-1): evaluation_engine.py:74-126,198-207 + utils/evaluation.py:17-70 + torch_helper.compute_mAP"""
+    sh = ref_loader.seg_helper()
+    ev = ref_loader.evaluation_module()
+    th = ref_loader.torch_helper_fns()
+    out = {}
+    # (1) multi_scale_camsegv3 with the stub network: 5 scales x 2 flips, cam_aux from the LAST scale only, summed cls logits
+    b, S, C = 2, 64, 5
+    imgs = torch.from_numpy(smooth_field(rng, b * 3, S, S, -2, 2).reshape(b, 3, S, S))
+    cam, cam_aux, seg, cls_f, cls_a = sh.multi_scale_camsegv3(_StubModel(C), imgs, [1.0, 0.5, 1.5, 0.75, 1.25], getcls=True)
+    out.update(v3_imgs=imgs.numpy(), v3_cam=cam.numpy(), v3_cam_aux=cam_aux.numpy(), v3_seg=seg.numpy(), v3_cls_f=cls_f.numpy(),
+               v3_cls_a=cls_a.numpy(), v3_C=C)
+    # (2) CAM / seg -> label maps at the ground truth's resolution (evaluation_engine.py:96-126,198-200)
+    cam, seg, cls_label = eval_inputs(np.random.default_rng(171))
+    for i, (H, W) in enumerate(EVAL_SIZES):
+        rc = F.interpolate(cam, size=(H, W), mode="bilinear", align_corners=False)
+        lab = sh.cam_to_label(rc.clone(), cls_label, bkg_thre=0.5, high_thre=0.7, low_thre=0.25, ignore_index=255)
+        rs = F.interpolate(seg, size=(H, W), mode="bilinear", align_corners=False)
+        vd = sh.seg_validation(rs, cls_label)
+        out[f"lab_cam_{i}"] = lab.numpy().astype(np.uint8)
+        out[f"lab_ps_{i}"] = torch.argmax(rs, dim=1).numpy().astype(np.uint8)
+        out[f"lab_vd_{i}"] = torch.argmax(vd, dim=1).numpy().astype(np.uint8)
+    # (3) cam_to_label with boxes + ignore_mid (returns (valid_cam, pseudo_label))
+    c2 = torch.from_numpy(smooth_field(rng, 2 * 4, 40, 56, 0.0, 1.0).reshape(2, 4, 40, 56))
+    l2 = torch.tensor([[1.0, 1.0, 0.0, 0.0], [0.0, 1.0, 0.0, 1.0]])
+    boxes = torch.tensor([[0, 40, 0, 56], [3, 33, 5, 50]])
+    valid_cam, pl = sh.cam_to_label(c2.clone(), l2, img_box=boxes, bkg_thre=0.5, high_thre=0.7, low_thre=0.25, ignore_mid=True,
+                                    ignore_index=255)
+    out.update(box_cam=c2.numpy(), box_cls=l2.numpy(), box_boxes=boxes.numpy(), box_valid_cam=valid_cam.numpy(),
+               box_label=pl.numpy().astype(np.int64))
+    # (4) confusion-matrix scores
+    nc = 6
+    gts = [rng.integers(0, nc, size=(30 + 7 * i, 41)).astype(np.uint8) for i in range(3)]
+    for g in gts:
+        g[rng.random(g.shape) < 0.1] = 255
+    gts[2][gts[2] == 4] = 1                      # a class absent from one image / rare overall
+    preds = [np.where(rng.random(g.shape) < 0.7, np.minimum(g, nc - 1), rng.integers(0, nc, size=g.shape)).astype(np.uint8) for g in gts]
+    ppreds = [p.copy() for p in preds]
+    for p in ppreds:
+        p[rng.random(p.shape) < 0.15] = 255
+    sc = ev.scores(gts, preds, nc)
+    ps = ev.pseudo_scores([g.copy() for g in gts], [p.copy() for p in ppreds], nc)
+    for k, d in (("sc", sc), ("ps", ps)):
+        out[f"{k}_pAcc"], out[f"{k}_mAcc"], out[f"{k}_miou"] = d["pAcc"], d["mAcc"], d["miou"]
+        out[f"{k}_iou"] = np.array([d["iou"][i] for i in range(nc)])
+    for i in range(3):
+        out[f"sc_gt_{i}"], out[f"sc_pred_{i}"], out[f"sc_ppred_{i}"] = gts[i], preds[i], ppreds[i]
+    out["sc_nc"] = nc
+    # (5) per-sample average precision (torch_helper.compute_mAP -> sklearn average_precision_score), incl. tied scores
+    y = (rng.random((6, 8)) < 0.4).astype(np.float32)
+    y[3] = 0                                       # a sample without positives is skipped
+    p = rng.random((6, 8)).astype(np.float32)
+    p[1, 2] = p[1, 5]
+    p[4, :4] = 0.5
+    out.update(ap_labels=y, ap_scores=p, ap=np.array(th.compute_mAP(torch.from_numpy(y), torch.from_numpy(p))))
+    np.savez_compressed(os.path.join(OUT, "eval.npz"), **out)
+
+
 def main():
     assert ref_loader.available(), "reference tree not present"
     os.makedirs(OUT, exist_ok=True)
@@ -248,6 +321,7 @@ def main():
     gen_bilateral(np.random.default_rng(14))
     gen_misc(np.random.default_rng(15))
     gen_vit(np.random.default_rng(16))
+    gen_eval(np.random.default_rng(17))
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")
 

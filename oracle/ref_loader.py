@@ -97,3 +97,10 @@ def torch_helper_fns():
         pkg.misc = _stub("_cosa_ref_utils.misc")
         _cache["th"] = _load("_cosa_ref_utils.torch_helper", "utils/torch_helper.py")
     return _cache["th"]
+
+
+def evaluation_module():
+    """utils/evaluation.py (numpy + sklearn.metrics only)."""
+    if "eval" not in _cache:
+        _cache["eval"] = _load("_cosa_ref_evaluation", "utils/evaluation.py")
+    return _cache["eval"]
