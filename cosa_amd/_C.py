@@ -48,6 +48,11 @@ _SIGS = {
     "cosa_optim_record_bytes": (c_size_t, []),
     "cosa_optim_chunk_elems": (c_int, []),
     "cosa_fused_adamw_ema": (c_int, [c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_int, c_float, c_void_p]),
+    "cosa_add_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                       c_float, c_void_p]),
+    "cosa_layernorm_bwd_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "cosa_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                   c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "cosa_eval_labels": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p,
                                  c_void_p]),
     "cosa_cam_to_label": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int, c_float, c_float,

@@ -1,0 +1,210 @@
+// vit_kernels.hip -- element-wise pieces of the STUDENT's transformer blocks (training path, bf16 residual stream).
+//
+//   models/vit/vit.py:154-158   x = x + attn(norm1(x)); x = x + mlp(norm2(x))
+//
+// cosa_add_layernorm_fwd:  x_new = x + delta (rounded to bf16, the residual stream's dtype), y = LayerNorm(x_new) -- one pass
+//                          instead of torch's add kernel + layer_norm kernel; keeps mean / rstd for the backward.
+// cosa_layernorm_bwd:      dx = LayerNorm'(dy) + dskip (the gradient that reaches x_new through the skip connection), and the
+//                          weight / bias gradients: per-workgroup partial sums, then a small deterministic reduction
+//                          (no atomics) -- replaces layer_norm_grad_input + 2 gamma/beta kernels + the gradient add.
+// HBM-bound: 8 B per element forward, 8 B backward.  One wave per row, 12 elements per lane (D = 768).
+#include "kernels.hpp"
+
+namespace cosa {
+namespace {
+
+typedef __bf16 bf16;
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+constexpr int D = 768, PER = 3;            // 3 x 4 consecutive elements per lane: columns (lane + 64 i) * 4
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void add_ln_fwd_kernel(const bf16 *__restrict__ x, const bf16 *__restrict__ delta,
+                                                        const bf16 *__restrict__ g, const bf16 *__restrict__ b,
+                                                        bf16 *__restrict__ xout, bf16 *__restrict__ y, float *__restrict__ mean_o,
+                                                        float *__restrict__ rstd_o, int rows, float eps)
+{
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const size_t base = (size_t)row * D;
+    float v[PER][4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+        const int c0 = (lane + 64 * i) * 4;
+        const bf16x4 xv = *reinterpret_cast<const bf16x4 *>(x + base + c0);
+        bf16x4 sv = xv;
+        if (delta) {
+            const bf16x4 dv = *reinterpret_cast<const bf16x4 *>(delta + base + c0);
+#pragma unroll
+            for (int j = 0; j < 4; j++) sv[j] = (bf16)((float)xv[j] + (float)dv[j]);       // the stream is bf16: LN sees the rounded sum
+            if (xout) *reinterpret_cast<bf16x4 *>(xout + base + c0) = sv;
+        } else if (xout && xout != x) {
+            *reinterpret_cast<bf16x4 *>(xout + base + c0) = sv;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) { v[i][j] = (float)sv[j]; s += v[i][j]; }
+    }
+    const float mean = wave_sum(s) * (1.0f / D);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < PER; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) { const float a = v[i][j] - mean; q += a * a; }
+    const float rstd = rsqrtf(wave_sum(q) * (1.0f / D) + eps);
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+        const int c0 = (lane + 64 * i) * 4;
+        const bf16x4 gg = *reinterpret_cast<const bf16x4 *>(g + c0);
+        const bf16x4 bb = *reinterpret_cast<const bf16x4 *>(b + c0);
+        bf16x4 ov;
+#pragma unroll
+        for (int j = 0; j < 4; j++) ov[j] = (bf16)((v[i][j] - mean) * rstd * (float)gg[j] + (float)bb[j]);
+        *reinterpret_cast<bf16x4 *>(y + base + c0) = ov;
+    }
+    if (lane == 0) { mean_o[row] = mean; rstd_o[row] = rstd; }
+}
+
+// part: [gridDim.x][2][D] (dgamma partials, dbeta partials)
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16 *__restrict__ dy, const bf16 *__restrict__ xn,
+                                                    const float *__restrict__ mean, const float *__restrict__ rstd,
+                                                    const bf16 *__restrict__ g, const bf16 *__restrict__ dskip, bf16 *__restrict__ dx,
+                                                    float *__restrict__ part, int rows, int rows_per_wg)
+{
+    __shared__ float red[4][2][D];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r0 = blockIdx.x * rows_per_wg;
+    int r1 = r0 + rows_per_wg;
+    r1 = r1 < rows ? r1 : rows;
+    float gam[PER][4], dg[PER][4], db[PER][4];
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+        const bf16x4 gg = *reinterpret_cast<const bf16x4 *>(g + (lane + 64 * i) * 4);
+#pragma unroll
+        for (int j = 0; j < 4; j++) { gam[i][j] = (float)gg[j]; dg[i][j] = 0.f; db[i][j] = 0.f; }
+    }
+    for (int row = r0 + wave; row < r1; row += 4) {
+        const size_t base = (size_t)row * D;
+        const float mu = mean[row], rs = rstd[row];
+        float xh[PER][4], gy[PER][4];
+        float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+            const int c0 = (lane + 64 * i) * 4;
+            const bf16x4 dv = *reinterpret_cast<const bf16x4 *>(dy + base + c0);
+            const bf16x4 xv = *reinterpret_cast<const bf16x4 *>(xn + base + c0);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float d = (float)dv[j];
+                xh[i][j] = ((float)xv[j] - mu) * rs;
+                gy[i][j] = d * gam[i][j];
+                c1 += gy[i][j];
+                c2 += gy[i][j] * xh[i][j];
+                dg[i][j] += d * xh[i][j];
+                db[i][j] += d;
+            }
+        }
+        c1 = wave_sum(c1) * (1.0f / D);
+        c2 = wave_sum(c2) * (1.0f / D);
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+            const int c0 = (lane + 64 * i) * 4;
+            float o[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) o[j] = (gy[i][j] - c1 - xh[i][j] * c2) * rs;
+            if (dskip) {
+                const bf16x4 sv = *reinterpret_cast<const bf16x4 *>(dskip + base + c0);
+#pragma unroll
+                for (int j = 0; j < 4; j++) o[j] += (float)sv[j];
+            }
+            bf16x4 ov;
+#pragma unroll
+            for (int j = 0; j < 4; j++) ov[j] = (bf16)o[j];
+            *reinterpret_cast<bf16x4 *>(dx + base + c0) = ov;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < PER; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            red[wave][0][(lane + 64 * i) * 4 + j] = dg[i][j];
+            red[wave][1][(lane + 64 * i) * 4 + j] = db[i][j];
+        }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 2 * D; c += 256) {
+        const int k = c / D, col = c - k * D;
+        part[((size_t)blockIdx.x * 2 + k) * D + col] = red[0][k][col] + red[1][k][col] + red[2][k][col] + red[3][k][col];
+    }
+}
+
+// dgamma / dbeta [D] = sum over the workgroup partials, in a fixed order (deterministic).  grid = 2*D/32, 256 threads:
+// 32 columns x 8 slices of the partial list, slices combined through LDS.
+__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float *__restrict__ part, int nblk, float *__restrict__ dgamma,
+                                                           float *__restrict__ dbeta, int accumulate)
+{
+    __shared__ float red[8][32];
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31), sl = threadIdx.x >> 5;      // c in [0, 2D)
+    const int k = c / D, col = c - k * D;
+    float s = 0.f;
+    for (int p = sl; p < nblk; p += 8) s += part[((size_t)p * 2 + k) * D + col];
+    red[sl][threadIdx.x & 31] = s;
+    __syncthreads();
+    if (sl == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; i++) t += red[i][threadIdx.x];
+        float *dst = k == 0 ? dgamma : dbeta;
+        dst[col] = accumulate ? dst[col] + t : t;
+    }
+}
+
+}  // namespace
+}  // namespace cosa
+
+using namespace cosa;
+
+extern "C" int cosa_add_layernorm_fwd(const void *x, const void *delta, const void *gamma, const void *beta, void *x_out, void *y,
+                                      float *mean, float *rstd, int rows, int dim, float eps, void *stream)
+{
+    COSA_REQUIRE(x && gamma && beta && y && mean && rstd && rows > 0, "cosa_add_layernorm_fwd: bad arguments");
+    COSA_REQUIRE(dim == D, "cosa_add_layernorm_fwd: dim must be 768 (ViT-B)");
+    COSA_REQUIRE(!delta || x_out, "cosa_add_layernorm_fwd: x_out is required with delta");
+    hipLaunchKernelGGL(add_ln_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, as_stream(stream), static_cast<const bf16 *>(x),
+                       static_cast<const bf16 *>(delta), static_cast<const bf16 *>(gamma), static_cast<const bf16 *>(beta),
+                       static_cast<bf16 *>(x_out), static_cast<bf16 *>(y), mean, rstd, rows, eps);
+    COSA_LAUNCH_CHECK();
+    return COSA_OK;
+}
+
+extern "C" size_t cosa_layernorm_bwd_workspace_bytes(int rows, int dim)
+{
+    (void)rows;
+    return (size_t)256 * 2 * dim * sizeof(float);
+}
+
+extern "C" int cosa_layernorm_bwd(const void *dy, const void *x_new, const float *mean, const float *rstd, const void *gamma,
+                                  const void *dskip, void *dx, float *dgamma, float *dbeta, int accumulate, int rows, int dim,
+                                  void *workspace, size_t workspace_bytes, void *stream)
+{
+    COSA_REQUIRE(dy && x_new && mean && rstd && gamma && dx && dgamma && dbeta && workspace && rows > 0, "cosa_layernorm_bwd: bad arguments");
+    COSA_REQUIRE(dim == D, "cosa_layernorm_bwd: dim must be 768 (ViT-B)");
+    COSA_REQUIRE(workspace_bytes >= cosa_layernorm_bwd_workspace_bytes(rows, dim), "cosa_layernorm_bwd: workspace too small");
+    int per = (rows + 255) / 256;
+    per = (per + 3) / 4 * 4;                                  // whole rounds of the workgroup's 4 waves
+    const int nblk = (rows + per - 1) / per;
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(nblk), dim3(256), 0, st, static_cast<const bf16 *>(dy), static_cast<const bf16 *>(x_new), mean,
+                       rstd, static_cast<const bf16 *>(gamma), static_cast<const bf16 *>(dskip), static_cast<bf16 *>(dx),
+                       static_cast<float *>(workspace), rows, per);
+    COSA_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(2 * D / 32), dim3(256), 0, st, static_cast<const float *>(workspace), nblk, dgamma, dbeta,
+                       accumulate);
+    COSA_LAUNCH_CHECK();
+    return COSA_OK;
+}

@@ -138,6 +138,20 @@ class VisionTransformer(nn.Module):
         y = nn_ops.gelu(nn_ops.linear(y, blk.mlp.fc1.weight, blk.mlp.fc1.bias, dt))
         return x + nn_ops.linear(y, blk.mlp.fc2.weight, blk.mlp.fc2.bias, dt)
 
+    def _block_fused_ln(self, blk, x, delta):
+        """training-path block on the bf16 stream with the residual adds folded into the LayerNorm kernels: takes the stream x and the
+        not-yet-added output `delta` of the previous block's MLP (None for the first block), returns (x_in, x', delta'):
+        x_in = x + delta is the previous block's output as it materialises here, the block's own output is x' + delta'."""
+        dt = self.compute_dtype
+        x, y = nn_ops.add_layernorm(x, delta, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps)
+        x_in = x
+        qkv = nn_ops.linear(y, blk.attn.qkv.weight, blk.attn.qkv.bias, dt)
+        y = nn_ops.attention(qkv, self.num_heads)
+        d1 = nn_ops.linear(y, blk.attn.proj.weight, blk.attn.proj.bias, dt)
+        x, y = nn_ops.add_layernorm(x, d1, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
+        y = nn_ops.gelu(nn_ops.linear(y, blk.mlp.fc1.weight, blk.mlp.fc1.bias, dt))
+        return x_in, x, nn_ops.linear(y, blk.mlp.fc2.weight, blk.mlp.fc2.bias, dt)
+
     # -- fused no-grad path (the teacher's 6 passes): fp32 residual stream, HIP GEMM/LN/attention kernels -------
     def _forward_features_fused(self, x):
         return self._forward_features_fused_multi([x])[0]
@@ -198,6 +212,17 @@ class VisionTransformer(nn.Module):
         depth = len(self.blocks)
         aux_idx = self.aux_layer % depth
         aux = None
+        if self.compute_dtype == torch.bfloat16 and x.is_cuda and self.embed_dim == 768 and x.dtype == torch.bfloat16:
+            # student training path: the stream is (x, pending delta); x + delta materialises inside the next LayerNorm kernel
+            delta = None
+            for i, blk in enumerate(self.blocks):
+                x_in, x, delta = self._block_fused_ln(blk, x, delta)
+                if i - 1 == aux_idx:
+                    aux = x_in                                              # output of block aux_idx, materialised in this block's norm1
+            x, xn = nn_ops.add_layernorm(x, delta, self.norm.weight, self.norm.bias, self.norm.eps)
+            if aux_idx == depth - 1:
+                aux = xn
+            return xn[:, 0], xn[:, 1:], aux[:, 1:], None
         for i, blk in enumerate(self.blocks):
             x = self._block(blk, x)
             if i == aux_idx:

@@ -276,5 +276,82 @@ def linear(x, weight, bias, dtype):
     return F.linear(x, cast_param(weight, dtype), cast_param(bias, dtype))
 
 
+# --------------------------------------------------------------------------------------------
+# student blocks: residual add + LayerNorm in one kernel, with its backward  (models/vit/vit.py:154-158)
+# --------------------------------------------------------------------------------------------
+def _ln_backward(dy, x_new, mean, rstd, w16, dskip):
+    dy = dy.contiguous()
+    rows = dy.numel() // 768
+    dx = torch.empty_like(dy)
+    dgamma = torch.empty(768, device=dy.device, dtype=torch.float32)
+    dbeta = torch.empty_like(dgamma)
+    L = _C.lib()
+    ws = _C.workspace(L.cosa_layernorm_bwd_workspace_bytes(rows, 768), dy.device, "ln_bwd")
+    _C.check(L.cosa_layernorm_bwd(_C.ptr(dy), _C.ptr(x_new), _C.ptr(mean), _C.ptr(rstd), _C.ptr(w16),
+                                  _C.ptr(dskip.contiguous() if dskip is not None else None), _C.ptr(dx), _C.ptr(dgamma), _C.ptr(dbeta),
+                                  0, rows, 768, _C.ptr(ws), ws.numel(), _C.stream_ptr()), "cosa_layernorm_bwd")
+    return dx, dgamma, dbeta
+
+
+def _ln_forward(x, delta, w16, b16, eps):
+    rows = x.numel() // 768
+    x_new = torch.empty_like(x) if delta is not None else x
+    y = torch.empty_like(x)
+    mean = torch.empty(rows, device=x.device, dtype=torch.float32)
+    rstd = torch.empty_like(mean)
+    _C.check(_C.lib().cosa_add_layernorm_fwd(_C.ptr(x), _C.ptr(delta), _C.ptr(w16), _C.ptr(b16), _C.ptr(x_new if delta is not None else None),
+                                             _C.ptr(y), _C.ptr(mean), _C.ptr(rstd), rows, 768, float(eps), _C.stream_ptr()),
+             "cosa_add_layernorm_fwd")
+    return x_new, y, mean, rstd
+
+
+class AddLayerNormFn(Function):
+    """(x, delta) -> (x_new = x + delta, y = LayerNorm(x_new)) on the bf16 residual stream; gradients of gamma / beta go to the fp32
+    masters.  The backward folds the gradient arriving at x_new through the skip connection into the same pass."""
+
+    @staticmethod
+    def forward(ctx, x, delta, w, b, w16, b16, eps):
+        x_new, y, mean, rstd = _ln_forward(x.contiguous(), delta.contiguous(), w16, b16, eps)
+        ctx.save_for_backward(x_new, mean, rstd, w16)
+        return x_new, y
+
+    @staticmethod
+    def backward(ctx, dx_new, dy):
+        x_new, mean, rstd, w16 = ctx.saved_tensors
+        if dy is None:                                  # y unused: only the skip gradient flows
+            return dx_new, dx_new, None, None, None, None, None
+        dx, dgamma, dbeta = _ln_backward(dy, x_new, mean, rstd, w16, dx_new)
+        return dx, dx, dgamma, dbeta, None, None, None
+
+
+class LayerNormFn(Function):
+    """y = LayerNorm(x) (no residual add in front: the first block's norm1); backward through the same kernel, no skip term."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, w16, b16, eps):
+        x = x.contiguous()
+        _, y, mean, rstd = _ln_forward(x, None, w16, b16, eps)
+        ctx.save_for_backward(x, mean, rstd, w16)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, rstd, w16 = ctx.saved_tensors
+        dx, dgamma, dbeta = _ln_backward(dy, x, mean, rstd, w16, None)
+        return dx, dgamma, dbeta, None, None, None
+
+
+def add_layernorm(x, delta, weight, bias, eps):
+    """-> (x + delta, LayerNorm(x + delta)); delta may be None.  bf16 [.., 768] on the GPU only."""
+    ew, eb = _shadows.get(id(weight)), _shadows.get(id(bias))
+    if ew is not None and eb is not None and ew[0] is weight and eb[0] is bias:
+        w16, b16 = ew[1], eb[1]
+    else:
+        w16, b16 = weight.detach().to(torch.bfloat16), bias.detach().to(torch.bfloat16)
+    if delta is None:
+        return x, LayerNormFn.apply(x, weight, bias, w16, b16, eps)
+    return AddLayerNormFn.apply(x, delta, weight, bias, w16, b16, eps)
+
+
 def gelu(x):
     return F.gelu(x)

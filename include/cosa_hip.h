@@ -206,6 +206,20 @@ int cosa_fused_adamw_ema(const void *records, const void *chunks, int n_chunks, 
                          int step, float ema_momentum, void *stream);
 
 /* ---------------------------------------------------------------------------------------
+ * models/vit/vit.py:154-158  the student's pre-LN residual blocks (training, bf16 stream), element-wise side:
+ *   cosa_add_layernorm_fwd: x_out = bf16(x + delta) (delta may be NULL: x_out optional), y = LayerNorm(x_out; gamma, beta, eps),
+ *     mean / rstd [rows] kept for the backward.  All tensors bf16 [rows, 768] except mean / rstd (fp32).
+ *   cosa_layernorm_bwd: dx = dLayerNorm(dy) + dskip (dskip optional: the gradient arriving at x_out through the skip path),
+ *     dgamma / dbeta [768] fp32 (= or += with accumulate != 0), summed deterministically through `workspace`.
+ * ------------------------------------------------------------------------------------- */
+int cosa_add_layernorm_fwd(const void *x, const void *delta, const void *gamma, const void *beta, void *x_out, void *y,
+                           float *mean, float *rstd, int rows, int dim, float eps, void *stream);
+size_t cosa_layernorm_bwd_workspace_bytes(int rows, int dim);
+int cosa_layernorm_bwd(const void *dy, const void *x_new, const float *mean, const float *rstd, const void *gamma,
+                       const void *dskip, void *dx, float *dgamma, float *dbeta, int accumulate, int rows, int dim,
+                       void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------
  * Evaluation path (SURVEY f-1; evaluation_engine.py:96-126,198-200, utils/seg_helper.py:515-546,581-591,
  * utils/evaluation.py:10-70).
  *   cosa_eval_labels: one launch replaces F.interpolate(cam), cam_to_label, F.interpolate(seg), seg_validation and the

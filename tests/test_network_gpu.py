@@ -259,3 +259,42 @@ def test_dilated_conv_implicit_gemm_vs_torch(B, h, w, Cin, Cout):
     x = tok.float().reshape(B, h, w, Cin).permute(0, 3, 1, 2)
     ref = F.relu(F.conv2d(x, wgt.float(), padding=5, dilation=5))
     assert (y - ref).abs().max().item() <= 1e-2 * ref.abs().max().item() + 1e-3
+
+
+@pytest.mark.parametrize("rows", [(3, 50), (1, 785), (2, 1)])
+def test_add_layernorm_fwd_bwd_vs_torch(rows):
+    """student blocks' fused residual-add + LayerNorm (cosa_add_layernorm_fwd / cosa_layernorm_bwd) against torch autograd in fp32
+    on the same bf16-rounded stream"""
+    from cosa_amd import nn_ops
+    torch.manual_seed(rows[1])
+    B, N = rows
+    x = torch.randn(B, N, 768, device="cuda").bfloat16()
+    d = (torch.randn(B, N, 768, device="cuda") * 0.5).bfloat16()
+    w = torch.nn.Parameter(torch.randn(768, device="cuda") * 0.2 + 1)
+    b = torch.nn.Parameter(torch.randn(768, device="cuda") * 0.1)
+    gy = torch.randn(B, N, 768, device="cuda").bfloat16()
+    gx = torch.randn(B, N, 768, device="cuda").bfloat16()
+    for delta in (d, None):
+        xs = x.clone().requires_grad_(True)
+        ds = delta.clone().requires_grad_(True) if delta is not None else None
+        for p in (w, b):
+            p.grad = None
+        x_new, y = nn_ops.add_layernorm(xs, ds, w, b, 1e-6)
+        (y.float() * gy.float()).sum().add((x_new.float() * gx.float()).sum()).backward()
+        # reference: fp32 math on the bf16 stream value, bf16 parameters
+        xr = x.clone().float().requires_grad_(True)
+        dr = delta.clone().float().requires_grad_(True) if delta is not None else None
+        wr, br = w.detach().bfloat16().float().requires_grad_(True), b.detach().bfloat16().float().requires_grad_(True)
+        sr = (xr + dr).bfloat16().float() if delta is not None else xr
+        sr_leaf = sr.detach().requires_grad_(True)
+        yr = torch.nn.functional.layer_norm(sr_leaf, (768,), wr, br, 1e-6)
+        (yr * gy.float()).sum().add((sr_leaf * gx.float()).sum()).backward()
+        assert torch.equal(x_new, sr.bfloat16()) if delta is not None else x_new is xs
+        assert (y.float() - yr).abs().max().item() <= 2.0 ** -7 * max(yr.abs().max().item(), 1.0)
+        gref = sr_leaf.grad
+        tol = 2.0 ** -7 * gref.abs().max().item()
+        assert (xs.grad.float() - gref).abs().max().item() <= tol
+        if delta is not None:
+            assert torch.equal(ds.grad, xs.grad)
+        assert (w.grad - wr.grad).abs().max().item() <= 2e-3 * wr.grad.abs().max().item() + 1e-3
+        assert (b.grad - br.grad).abs().max().item() <= 2e-3 * br.grad.abs().max().item() + 1e-3
