@@ -1709,7 +1709,14 @@ extern "C" int cosa_gemm_wgrad_bf16(const void *dY, const void *X, float *dW, fl
     }
     const int tiles = (N / 128) * (K / 128);
     const int nstages = (M + 63) / 64;
-    int splits = (288 + tiles - 1) / tiles;                  // >= 1 workgroup per CU; every split costs N*K*4 B of atomics (~1.3 TB/s)
+    // workgroups in flight: two fit a CU (64 KB LDS each) and the K loop is latency-bound, so fill all 512 slots -- but never a
+    // second, partly filled round.  Every split costs N*K*4 B of fp32 atomics (~1.3 TB/s), which is why the small proj output
+    // (36 tiles) stays at ~one workgroup per CU (measured: tools/bench_wgrad.py, 428 -> 351 us per layer).
+    static const char *env_t = getenv("COSA_WGRAD_TARGET");
+    const int target = env_t ? atoi(env_t) : (tiles >= 64 ? 512 : 288);
+    int splits = target / tiles;
+    if (splits * tiles < 288 && (splits + 1) * tiles <= 512) splits++;
+    if (splits < 1) splits = 1;
     if (splits > nstages) splits = nstages;
     const int per = (nstages + splits - 1) / splits;
     splits = (nstages + per - 1) / per;
