@@ -228,15 +228,54 @@ def _mm_f32(a, b):
     return torch.mm(a, b).float()
 
 
+class _WgradArena:
+    """Zero-initialised home of one step's weight gradients.  The split-K wgrad kernel ACCUMULATES (fp32 atomics), so its output must
+    start at zero: instead of one small memset per gradient tensor (96 launches of ~5 us per step) the trainer clears this arena once
+    per step (`wgrad_arena_begin`) and the gradients of that step are carved out of it in call order (stable addresses step to step).
+    Off unless a trainer turns it on: with it on, gradients of step t are invalid once step t+1 begins."""
+    buf, off, high, enabled = None, 0, 0, False
+
+
+def wgrad_arena_begin(device):
+    a = _WgradArena
+    a.enabled = True
+    if a.buf is not None and a.buf.device == device and a.high > 0:
+        a.buf[: a.high].zero_()
+    a.off = 0
+
+
+def _wgrad_alloc(n, device):
+    a = _WgradArena
+    n_al = (n + 63) // 64 * 64
+    if not a.enabled:
+        return None
+    if a.buf is None or a.buf.device != device or a.off + n_al > a.buf.numel():
+        if a.buf is None or a.buf.device != device:
+            a.buf, a.off, a.high = torch.zeros(128 << 20, device=device, dtype=torch.float32), 0, 0       # 512 MB: 92.5 M params + slack
+        if a.off + n_al > a.buf.numel():
+            return None                                      # arena exhausted: this tensor falls back to its own memset
+    out = a.buf[a.off: a.off + n]
+    a.off += n_al
+    a.high = max(a.high, a.off)
+    return out
+
+
 def gemm_wgrad(dy2, x2, want_bias=False):
     """dW[N,K] fp32 = dy2[M,N]^T x2[M,K] (bf16) and, optionally, db[N] = column sums of dy2: the TN MFMA kernel with
     transposing LDS reads."""
     M, N = dy2.shape
     K = x2.shape[1]
-    dw = torch.empty((N, K), device=dy2.device, dtype=torch.float32)
-    db = torch.empty((N,), device=dy2.device, dtype=torch.float32) if want_bias else None
+    dw = _wgrad_alloc(N * K, dy2.device)
+    db = _wgrad_alloc(N, dy2.device) if (want_bias and dw is not None) else None
+    zero_first = 0
+    if dw is None or (want_bias and db is None):
+        dw = torch.empty((N, K), device=dy2.device, dtype=torch.float32)
+        db = torch.empty((N,), device=dy2.device, dtype=torch.float32) if want_bias else None
+        zero_first = 1
+    else:
+        dw = dw.view(N, K)
     with _C.profiled("gemm_wgrad"):
-        _C.check(_C.lib().cosa_gemm_wgrad_bf16(_C.ptr(dy2), _C.ptr(x2), _C.ptr(dw), _C.ptr(db), M, N, K, 1, _C.stream_ptr()),
+        _C.check(_C.lib().cosa_gemm_wgrad_bf16(_C.ptr(dy2), _C.ptr(x2), _C.ptr(dw), _C.ptr(db), M, N, K, zero_first, _C.stream_ptr()),
                  "cosa_gemm_wgrad_bf16")
     return (dw, db) if want_bias else dw
 

@@ -199,6 +199,8 @@ class CoSATrainer:
     def step(self, wimg, simg, cls_label, img_box, n_iter):
         loss, logs = self.forward_losses(wimg, simg, cls_label, img_box, n_iter)
         self.optimizer.zero_grad(set_to_none=True)
+        if self.device.type == "cuda" and self._student_shadows is not None:
+            nn_ops.wgrad_arena_begin(self.device)        # one clear for all weight gradients of this step (they are consumed below)
         loss.backward()
         if self._fused_step is not None:
             self._fused_step.step()
