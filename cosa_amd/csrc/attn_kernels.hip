@@ -5,7 +5,7 @@
 // [B,12,N,N] score tensor; here it never leaves the CU.
 //
 // Layouts (bf16):  qkv [B, N, 3, H, 64]  (straight out of the qkv projection, no permute copy)
-//                  vt  [B, H, 64, Npad]  V transposed per head, keys zero-padded to Npad % 64 == 0
+//                  (V is read in place: the PV product fetches its V^T fragments with the transposing LDS read, no V^T copy)
 //                  out [B, N, H*64]      (what the output projection consumes)
 //                  lse [B, H, N] f32     natural-log sum-exp of the scaled scores (for backward)
 //
@@ -28,36 +28,27 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int HD = 64;           // head dim
 constexpr int BQ = 128;          // queries per workgroup
 constexpr int BK = 64;           // keys per tile
-constexpr int VS = 136;          // bytes per row of the V^T LDS image (64 keys * 2 B + 8 pad: conflict-free b64 reads)
+constexpr int VS = 136;          // bytes per row of the transposed LDS images of the BACKWARD kernels (64 keys * 2 B + 8 pad)
+
+// forward V tile: row-major [64 keys][64 d] (128-B rows, exactly as it lies in qkv), read as the A operand of O^T = V^T P^T with the
+// transposing LDS read ds_read_b64_tr_b16 (a 16-lane group fetches a 4-key x 16-d block, lane nn gets column nn's 4 keys): no V^T
+// copy in HBM, no transpose kernel.  16-B chunk c of row r sits at chunk c ^ (((r >> 1) & 1) << 2): the 4 rows x 64 B a 32-lane half
+// reads then cover all 64 banks once (rows r, r+1 land 128 B apart = 32 banks; the XOR moves rows r+2, r+3 by 16 banks).
+typedef short s16x4v __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4v lds_s16x4v;
+__device__ __forceinline__ int vsw(int row) { return ((row >> 1) & 1) << 2; }
+__device__ __forceinline__ bf16x8 v_frag(const unsigned char *Vs, int keyb, int dhalf, int lane)
+{
+    const int nn = lane & 15, grp = (lane >> 4) & 1;
+    const int r0 = keyb + (nn >> 2), r1 = r0 + 8;
+    const int ch = dhalf * 4 + grp * 2 + ((nn & 3) >> 1), off = 8 * (nn & 1);
+    union { s16x4v h[2]; bf16x8 v; } u;
+    u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4v *)(Vs + r0 * 128 + ((ch ^ vsw(r0)) << 4) + off));
+    u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4v *)(Vs + r1 * 128 + ((ch ^ vsw(r1)) << 4) + off));
+    return u.v;
+}
 
 __device__ __forceinline__ int crow(int i, int hh) { return (i & 3) + 8 * (i >> 2) + 4 * hh; }
-
-// ---- V transpose: qkv[...,2,h,:] -> vt[b,h,d,key] ------------------------------------------------
-__global__ __launch_bounds__(256) void attn_vt_kernel(const bf16 *__restrict__ qkv, bf16 *__restrict__ vt, int N, int Npad, int H)
-{
-    __shared__ unsigned short tile[BK][HD + 2];
-    const int b = blockIdx.z, h = blockIdx.y, k0 = blockIdx.x * BK;
-    const int tid = threadIdx.x;
-    for (int c = tid; c < BK * 8; c += 256) {
-        const int key = c >> 3, s = c & 7;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (k0 + key < N)
-            v = *reinterpret_cast<const uint4 *>(qkv + (((size_t)b * N + k0 + key) * 3 + 2) * H * HD + h * HD + s * 8);
-        unsigned *dst = reinterpret_cast<unsigned *>(&tile[key][s * 8]);
-        dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
-    }
-    __syncthreads();
-    for (int c = tid; c < HD * 8; c += 256) {
-        const int d = c >> 3, kc = c & 7;
-        unsigned short e[8];
-#pragma unroll
-        for (int i = 0; i < 8; i++) e[i] = tile[kc * 8 + i][d];
-        uint4 v;
-        v.x = e[0] | ((unsigned)e[1] << 16); v.y = e[2] | ((unsigned)e[3] << 16);
-        v.z = e[4] | ((unsigned)e[5] << 16); v.w = e[6] | ((unsigned)e[7] << 16);
-        *reinterpret_cast<uint4 *>(vt + (((size_t)b * H + h) * HD + d) * Npad + k0 + kc * 8) = v;
-    }
-}
 
 // Workgroup -> (query/key block, batch, head).  Workgroups are dealt round-robin to the 8 XCDs (id & 7), each with a private L2;
 // all blocks of one (batch, head) therefore take consecutive slots OF ONE XCD, so its K/V (or Q/dO) panel is fetched into
@@ -80,7 +71,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16 *__restrict__ 
                                                       int N, int Npad, int H, int nblk, int ngroups, float scale_log2e,
                                                       unsigned long long *__restrict__ stamps)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[BK * 128 + HD * VS];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BK * 128];
     // optional device-side span of this launch (100 MHz wall clock): min start / max end over workgroups.
     // HIP events cannot be recorded inside a captured hipGraph on ROCm, so bench.py reads these instead.
     if (stamps && threadIdx.x == 0) atomicMin(&stamps[0], __builtin_amdgcn_s_memrealtime());
@@ -105,7 +96,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16 *__restrict__ 
     float m = -INFINITY, l = 0.f;
 
     const bf16 *kbase = qkv + (size_t)b * N * rs + (size_t)H * HD + h * HD;      // k part
-    const bf16 *vbase = vt + ((size_t)b * H + h) * HD * Npad;
+    const bf16 *vbase = kbase + (size_t)H * HD;                                   // v part, same row stride
     const int swz = (r >> 1) & 7;
 
     // register-staged software pipeline: the next tile's global loads are in flight while this tile computes
@@ -115,8 +106,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16 *__restrict__ 
     do {                                                                                                             \
         kreg0 = *reinterpret_cast<const uint4 *>(kbase + (size_t)min((K0) + row_a, N - 1) * rs + slot_s * 8);       \
         kreg1 = *reinterpret_cast<const uint4 *>(kbase + (size_t)min((K0) + row_b, N - 1) * rs + slot_s * 8);       \
-        vreg0 = *reinterpret_cast<const uint4 *>(vbase + (size_t)row_a * Npad + (K0) + slot_s * 8);                  \
-        vreg1 = *reinterpret_cast<const uint4 *>(vbase + (size_t)row_b * Npad + (K0) + slot_s * 8);                  \
+        vreg0 = *reinterpret_cast<const uint4 *>(vbase + (size_t)min((K0) + row_a, N - 1) * rs + slot_s * 8);       \
+        vreg1 = *reinterpret_cast<const uint4 *>(vbase + (size_t)min((K0) + row_b, N - 1) * rs + slot_s * 8);       \
     } while (0)
     COSA_LOAD_TILE(0);
     const float NEG_INF = -INFINITY;
@@ -125,12 +116,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16 *__restrict__ 
         __syncthreads();
         *reinterpret_cast<uint4 *>(Ks + row_a * 128 + ((slot_s ^ ((row_a >> 1) & 7)) << 4)) = kreg0;
         *reinterpret_cast<uint4 *>(Ks + row_b * 128 + ((slot_s ^ ((row_b >> 1) & 7)) << 4)) = kreg1;
-        {
-            uint2 *d0 = reinterpret_cast<uint2 *>(Vs + row_a * VS + slot_s * 16);
-            d0[0] = make_uint2(vreg0.x, vreg0.y); d0[1] = make_uint2(vreg0.z, vreg0.w);
-            uint2 *d1 = reinterpret_cast<uint2 *>(Vs + row_b * VS + slot_s * 16);
-            d1[0] = make_uint2(vreg1.x, vreg1.y); d1[1] = make_uint2(vreg1.z, vreg1.w);
-        }
+        *reinterpret_cast<uint4 *>(Vs + row_a * 128 + ((slot_s ^ vsw(row_a)) << 4)) = vreg0;
+        *reinterpret_cast<uint4 *>(Vs + row_b * 128 + ((slot_s ^ vsw(row_b)) << 4)) = vreg1;
         __syncthreads();
         if (k0 + BK < N) COSA_LOAD_TILE(k0 + BK);
 
@@ -184,18 +171,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16 *__restrict__ 
 #pragma unroll
                 for (int j = 0; j < 8; j++) pf[j] = (bf16)(kb == 0 ? s0[8 * sp + j] : s1[8 * sp + j]);
                 const int keyb = kb * 32 + 16 * sp + 4 * hh;
-                {
-                    const uint2 lo = *reinterpret_cast<const uint2 *>(Vs + r * VS + keyb * 2);
-                    const uint2 hi = *reinterpret_cast<const uint2 *>(Vs + r * VS + (keyb + 8) * 2);
-                    uint4 av = make_uint4(lo.x, lo.y, hi.x, hi.y);
-                    o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8 *>(&av), pf, o0, 0, 0, 0);
-                }
-                {
-                    const uint2 lo = *reinterpret_cast<const uint2 *>(Vs + (r + 32) * VS + keyb * 2);
-                    const uint2 hi = *reinterpret_cast<const uint2 *>(Vs + (r + 32) * VS + (keyb + 8) * 2);
-                    uint4 av = make_uint4(lo.x, lo.y, hi.x, hi.y);
-                    o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8 *>(&av), pf, o1, 0, 0, 0);
-                }
+                o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v_frag(Vs, keyb, 0, lane), pf, o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v_frag(Vs, keyb, 1, lane), pf, o1, 0, 0, 0);
             }
         }
     };
@@ -236,7 +213,7 @@ __global__ __launch_bounds__(128, 2) void attn_fwd2_kernel(const bf16 *__restric
                                                        int N, int Npad, int H, int nblk, int ngroups, float scale_log2e,
                                                        unsigned long long *__restrict__ stamps)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[BK * 128 + HD * VS];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BK * 128];
     if (stamps && threadIdx.x == 0) atomicMin(&stamps[0], __builtin_amdgcn_s_memrealtime());
     unsigned char *Ks = smem;
     unsigned char *Vs = smem + BK * 128;
@@ -262,7 +239,7 @@ __global__ __launch_bounds__(128, 2) void attn_fwd2_kernel(const bf16 *__restric
             for (int i = 0; i < 16; i++) o[u][d][i] = 0.f;
     float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.f, 0.f};
     const bf16 *kbase = qkv + (size_t)b * N * rs + (size_t)H * HD + h * HD;
-    const bf16 *vbase = vt + ((size_t)b * H + h) * HD * Npad;
+    const bf16 *vbase = kbase + (size_t)H * HD;
     const int swz = (r >> 1) & 7;
     // 128 threads stage 512 + 512 16-byte chunks per tile (4 + 4 per thread).  No register prefetch here: four of these
     // workgroups share a CU, so another workgroup computes while this one waits for its tile.
@@ -274,11 +251,9 @@ __global__ __launch_bounds__(128, 2) void attn_fwd2_kernel(const bf16 *__restric
         for (int i = 0; i < 4; i++) {
             const int row = srow + 16 * i;
             const uint4 kv = *reinterpret_cast<const uint4 *>(kbase + (size_t)min(k0 + row, N - 1) * rs + sslot * 8);
-            const uint4 vv = *reinterpret_cast<const uint4 *>(vbase + (size_t)row * Npad + k0 + sslot * 8);
+            const uint4 vv = *reinterpret_cast<const uint4 *>(vbase + (size_t)min(k0 + row, N - 1) * rs + sslot * 8);
             *reinterpret_cast<uint4 *>(Ks + row * 128 + ((sslot ^ ((row >> 1) & 7)) << 4)) = kv;
-            uint2 *dv = reinterpret_cast<uint2 *>(Vs + row * VS + sslot * 16);
-            dv[0] = make_uint2(vv.x, vv.y);
-            dv[1] = make_uint2(vv.z, vv.w);
+            *reinterpret_cast<uint4 *>(Vs + row * 128 + ((sslot ^ vsw(row)) << 4)) = vv;
         }
         __syncthreads();
 
@@ -335,17 +310,7 @@ __global__ __launch_bounds__(128, 2) void attn_fwd2_kernel(const bf16 *__restric
 #pragma unroll
             for (int sp = 0; sp < 2; sp++) {
                 const int keyb = kb * 32 + 16 * sp + 4 * hh;
-                bf16x8 v0, v1;
-                {
-                    const uint2 lo = *reinterpret_cast<const uint2 *>(Vs + r * VS + keyb * 2);
-                    const uint2 hi = *reinterpret_cast<const uint2 *>(Vs + r * VS + (keyb + 8) * 2);
-                    uint4 av = make_uint4(lo.x, lo.y, hi.x, hi.y);
-                    v0 = *reinterpret_cast<bf16x8 *>(&av);
-                    const uint2 lo1 = *reinterpret_cast<const uint2 *>(Vs + (r + 32) * VS + keyb * 2);
-                    const uint2 hi1 = *reinterpret_cast<const uint2 *>(Vs + (r + 32) * VS + (keyb + 8) * 2);
-                    uint4 aw = make_uint4(lo1.x, lo1.y, hi1.x, hi1.y);
-                    v1 = *reinterpret_cast<bf16x8 *>(&aw);
-                }
+                const bf16x8 v0 = v_frag(Vs, keyb, 0, lane), v1 = v_frag(Vs, keyb, 1, lane);
 #pragma unroll
                 for (int u = 0; u < 2; u++) {
                     bf16x8 pf;
@@ -676,11 +641,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16 *__rest
 
 using namespace cosa;
 
-/* vt scratch size in bytes for cosa_attn_fwd */
+/* scratch of cosa_attn_fwd: none any more (the V^T copy is gone); a token size keeps the calling convention */
 extern "C" size_t cosa_attn_workspace_bytes(int B, int N, int H)
 {
-    const size_t Npad = (size_t)(N + BK - 1) / BK * BK;
-    return align_up((size_t)B * H * HD * Npad * sizeof(bf16), 256);
+    (void)B; (void)N; (void)H;
+    return 256;
 }
 
 extern "C" int cosa_attn_prepare_vt(const void *qkv, int B, int N, int H, void *workspace, size_t workspace_bytes, void *stream)
@@ -690,10 +655,7 @@ extern "C" int cosa_attn_prepare_vt(const void *qkv, int B, int N, int H, void *
         set_error("cosa_attn_prepare_vt: workspace too small");
         return COSA_ENOMEM;
     }
-    const int Npad = (N + BK - 1) / BK * BK;
-    hipLaunchKernelGGL(attn_vt_kernel, dim3(Npad / BK, H, B), dim3(256), 0, as_stream(stream), static_cast<const bf16 *>(qkv),
-                       static_cast<bf16 *>(workspace), N, Npad, H);
-    COSA_LAUNCH_CHECK();
+    (void)stream;            // nothing to prepare: kept so that callers written against the V^T version keep working
     return COSA_OK;
 }
 
@@ -709,11 +671,7 @@ extern "C" int cosa_attn_fwd(const void *qkv, void *out, float *lse, int B, int 
     }
     hipStream_t st = as_stream(stream);
     const int Npad = (N + BK - 1) / BK * BK;
-    bf16 *vt = static_cast<bf16 *>(workspace);
-    if (!(flags & 1)) {   // bit 0: V^T already prepared in the workspace by cosa_attn_prepare_vt
-        hipLaunchKernelGGL(attn_vt_kernel, dim3(Npad / BK, H, B), dim3(256), 0, st, static_cast<const bf16 *>(qkv), vt, N, Npad, H);
-        COSA_LAUNCH_CHECK();
-    }
+    const bf16 *vt = nullptr;      // (flags bit 0, "V^T prepared", is ignored: there is no V^T copy)
     // measured (tools/bench_attn.py): 2 waves x 64 queries wins for long sequences (N=1765: 568 vs 460 TF), the 4 x 32
     // kernel with its register prefetch for short ones (N=785: 384 vs 358 TF).  flags bit 1 / bit 2 force either.
     const int nblk = (N + BQ - 1) / BQ;
