@@ -16,6 +16,7 @@
 // and the O rescale / final 1/l are lane-local.
 #include "kernels.hpp"
 #include <type_traits>
+#include <cstdlib>
 
 namespace cosa {
 namespace {
@@ -36,6 +37,7 @@ constexpr int VS = 136;          // bytes per row of the transposed LDS images o
 // reads then cover all 64 banks once (rows r, r+1 land 128 B apart = 32 banks; the XOR moves rows r+2, r+3 by 16 banks).
 typedef short s16x4v __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s16x4v lds_s16x4v;
+typedef __attribute__((address_space(3))) void lds_void_a;
 __device__ __forceinline__ int vsw(int row) { return ((row >> 1) & 1) << 2; }
 __device__ __forceinline__ bf16x8 v_frag(const unsigned char *Vs, int keyb, int dhalf, int lane)
 {
@@ -208,15 +210,20 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16 *__restrict__ 
 // blocks.  Every K / V^T fragment read from LDS now feeds two MFMAs (half the LDS fragment traffic per flop), each wave
 // has two independent MFMA/softmax chains to interleave, and at ~200 VGPRs four such workgroups share a CU, so one
 // workgroup's barrier / staging phase overlaps the others' compute.
+// DMA: K/V tiles arrive by LDS-DMA (buffer_load ... lds) into a 2-deep ring -- the next tile is in flight while this one is
+// computed, one barrier per tile, no staging registers; the swizzles are applied on the source side (lane-linear LDS image) and
+// key rows past N read as zeros through the buffer range check.
+template <bool DMA>
 __global__ __launch_bounds__(128, 2) void attn_fwd2_kernel(const bf16 *__restrict__ qkv, const bf16 *__restrict__ vt,
                                                        bf16 *__restrict__ out, float *__restrict__ lse,
                                                        int N, int Npad, int H, int nblk, int ngroups, float scale_log2e,
                                                        unsigned long long *__restrict__ stamps)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BK * 128];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[(DMA ? 4 : 2) * BK * 128];
     if (stamps && threadIdx.x == 0) atomicMin(&stamps[0], __builtin_amdgcn_s_memrealtime());
     unsigned char *Ks = smem;
     unsigned char *Vs = smem + BK * 128;
+    (void)vt;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
     int blk, b, h;
     if (!attn_block_map(nblk, ngroups, H, blk, b, h)) return;
@@ -244,18 +251,52 @@ __global__ __launch_bounds__(128, 2) void attn_fwd2_kernel(const bf16 *__restric
     // 128 threads stage 512 + 512 16-byte chunks per tile (4 + 4 per thread).  No register prefetch here: four of these
     // workgroups share a CU, so another workgroup computes while this one waits for its tile.
     const int srow = tid >> 3, sslot = tid & 7;          // chunk c = tid + 128*i -> row srow + 16*i, slot sslot
-    auto tile = [&](int k0, auto tail_tag) {
-        constexpr bool tail = decltype(tail_tag)::value;
-        __syncthreads();
+    // DMA staging: wave w fills the 1-KiB pieces 4w .. 4w+3 (8 rows each) of the K tile and of the V tile
+    __amdgpu_buffer_rsrc_t rsK, rsV;
+    unsigned voK[4], voV[4];
+    if (DMA) {
+        const int nbytes = (int)(((size_t)(N - 1) * rs + HD) * 2);                 // last valid byte of this (batch, head)'s K / V rows
+        rsK = __builtin_amdgcn_make_buffer_rsrc((void *)kbase, 0, nbytes, 0x00020000);
+        rsV = __builtin_amdgcn_make_buffer_rsrc((void *)vbase, 0, nbytes, 0x00020000);
 #pragma unroll
         for (int i = 0; i < 4; i++) {
+            const int row = 8 * (4 * wave + i) + (lane >> 3), ps = lane & 7;
+            voK[i] = (unsigned)((row * rs + (ps ^ ((row >> 1) & 7)) * 8) * 2);
+            voV[i] = (unsigned)((row * rs + (ps ^ vsw(row)) * 8) * 2);
+        }
+    }
+    auto dma_tile = [&](int k0, int buf) {
+        const unsigned ko = (unsigned)((size_t)k0 * rs * 2);
+        unsigned char *kd = smem + buf * 2 * BK * 128 + (4 * wave) * 1024;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (lds_void_a *)(kd + i * 1024), 16, voK[i] + ko, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (lds_void_a *)(kd + BK * 128 + i * 1024), 16, voV[i] + ko, 0, 0, 0);
+        }
+    };
+    int ring = 0;
+    if (DMA) {
+        dma_tile(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    auto tile = [&](int k0, auto tail_tag) {
+        constexpr bool tail = decltype(tail_tag)::value;
+        if (DMA) {
+            Ks = smem + ring * 2 * BK * 128;
+            Vs = Ks + BK * 128;
+            if (k0 + BK < N) dma_tile(k0 + BK, ring ^ 1);
+        }
+        if (!DMA) __syncthreads();
+#pragma unroll
+        for (int i = 0; i < (DMA ? 0 : 4); i++) {
             const int row = srow + 16 * i;
             const uint4 kv = *reinterpret_cast<const uint4 *>(kbase + (size_t)min(k0 + row, N - 1) * rs + sslot * 8);
             const uint4 vv = *reinterpret_cast<const uint4 *>(vbase + (size_t)min(k0 + row, N - 1) * rs + sslot * 8);
             *reinterpret_cast<uint4 *>(Ks + row * 128 + ((sslot ^ ((row >> 1) & 7)) << 4)) = kv;
             *reinterpret_cast<uint4 *>(Vs + row * 128 + ((sslot ^ vsw(row)) << 4)) = vv;
         }
-        __syncthreads();
+        if (!DMA) __syncthreads();
 
         f32x16 sc[2][2];
 #pragma unroll
@@ -320,6 +361,11 @@ __global__ __launch_bounds__(128, 2) void attn_fwd2_kernel(const bf16 *__restric
                     o[u][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, pf, o[u][1], 0, 0, 0);
                 }
             }
+        if (DMA) {                                     // the next tile has landed and nobody still reads this one
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            ring ^= 1;
+        }
     };
     const int nfull = (N / BK) * BK;
     for (int k0 = 0; k0 < nfull; k0 += BK) tile(k0, std::false_type{});
@@ -680,9 +726,17 @@ extern "C" int cosa_attn_fwd(const void *qkv, void *out, float *lse, int B, int 
                            static_cast<bf16 *>(out), lse, N, Npad, H, nblk, B * H, scale * 1.4426950408889634f,
                            reinterpret_cast<unsigned long long *>(stamps));
     else
-        hipLaunchKernelGGL(attn_fwd2_kernel, dim3(nblk * ((B * H + 7) / 8 * 8)), dim3(128), 0, st, static_cast<const bf16 *>(qkv), vt,
-                           static_cast<bf16 *>(out), lse, N, Npad, H, nblk, B * H, scale * 1.4426950408889634f,
-                           reinterpret_cast<unsigned long long *>(stamps));
+    {
+        static const bool no_dma = getenv("COSA_ATTN_NO_DMA") != nullptr;
+        if (no_dma || (size_t)N * 3 * H * HD * 2 >= 0x7fffffffull)
+            hipLaunchKernelGGL(attn_fwd2_kernel<false>, dim3(nblk * ((B * H + 7) / 8 * 8)), dim3(128), 0, st, static_cast<const bf16 *>(qkv), vt,
+                               static_cast<bf16 *>(out), lse, N, Npad, H, nblk, B * H, scale * 1.4426950408889634f,
+                               reinterpret_cast<unsigned long long *>(stamps));
+        else
+            hipLaunchKernelGGL(attn_fwd2_kernel<true>, dim3(nblk * ((B * H + 7) / 8 * 8)), dim3(128), 0, st, static_cast<const bf16 *>(qkv), vt,
+                               static_cast<bf16 *>(out), lse, N, Npad, H, nblk, B * H, scale * 1.4426950408889634f,
+                               reinterpret_cast<unsigned long long *>(stamps));
+    }
     COSA_LAUNCH_CHECK();
     return COSA_OK;
 }
