@@ -718,10 +718,11 @@ extern "C" int cosa_attn_fwd(const void *qkv, void *out, float *lse, int B, int 
     hipStream_t st = as_stream(stream);
     const int Npad = (N + BK - 1) / BK * BK;
     const bf16 *vt = nullptr;      // (flags bit 0, "V^T prepared", is ignored: there is no V^T copy)
-    // measured (tools/bench_attn.py): 2 waves x 64 queries wins for long sequences (N=1765: 568 vs 460 TF), the 4 x 32
-    // kernel with its register prefetch for short ones (N=785: 384 vs 358 TF).  flags bit 1 / bit 2 force either.
+    // measured (tools/bench_attn2.py): with the LDS-DMA ring the 2 waves x 64 queries kernel wins at every length of the step
+    // (N=197: 18 vs 20 us, N=785: 127 vs 154 us, N=1765: 413 vs 541 us, N=3601: 777 vs 992 us); the 4 x 32 kernel with its
+    // register prefetch stays as the alternative.  flags bit 1 / bit 2 force either.
     const int nblk = (N + BQ - 1) / BQ;
-    if ((flags & 2) || (!(flags & 4) && N < 1024))
+    if ((flags & 2) && !(flags & 4))
         hipLaunchKernelGGL(attn_fwd_kernel, dim3(nblk * ((B * H + 7) / 8 * 8)), dim3(256), 0, st, static_cast<const bf16 *>(qkv), vt,
                            static_cast<bf16 *>(out), lse, N, Npad, H, nblk, B * H, scale * 1.4426950408889634f,
                            reinterpret_cast<unsigned long long *>(stamps));
