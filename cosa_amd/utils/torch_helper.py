@@ -236,3 +236,28 @@ def format_tabs(scores, name_list, cat_list=None, getmIoU_list=True):
     means = vals.mean(1)
     lines.append("| " + "mIoU".ljust(wid) + " | " + " | ".join(f"{v:8.2f}" for v in means) + " |")
     return "\n".join(lines), means[-1], list(means)
+
+
+# --------------------------------------------------------------------------------------------
+# checkpoints  (utils/torch_helper.py:101-117 save_best; main.py:401-412 finaleval's load)
+# --------------------------------------------------------------------------------------------
+def save_best(output_dir, model, finish_epoch, result, args, s_or_t, comment=''):
+    """Same file name and dict layout as the reference ({'s_or_t','model','epoch','args','result'}), written by rank 0 only
+    (utils.save_on_master).  `model.state_dict()` has the reference's key names, so either code base reads the other's files."""
+    import os
+    import torch.distributed as dist
+    path = os.path.join(str(output_dir), f'best_{comment}.pth')
+    if dist.is_available() and dist.is_initialized() and dist.get_rank() != 0:
+        return path
+    os.makedirs(str(output_dir), exist_ok=True)
+    model = getattr(model, "module", model)                      # unwrap DistributedDataParallel
+    torch.save({'s_or_t': s_or_t, 'model': {k: v.detach().cpu() for k, v in model.state_dict().items()}, 'epoch': finish_epoch,
+                'args': args, 'result': result}, path)
+    return path
+
+
+def load_best(model, path, strict=True):
+    """main.py:410-412: `ckpt["model"]` into the network (strict by default, as there); returns the checkpoint dict."""
+    ckpt = torch.load(path, map_location="cpu", weights_only=False)
+    getattr(model, "module", model).load_state_dict(ckpt["model"], strict=strict)
+    return ckpt

@@ -60,3 +60,28 @@ def test_ops_fail_loudly_without_device():
     with pytest.raises(_C.CosaError):
         seg_helper.cam2mask(torch.zeros(1, 3, 8, 8), torch.tensor([[0, 8, 0, 8]]), torch.zeros(1, 2, 8, 8),
                             torch.ones(1, 2), 0.7, 0.25)
+
+
+def test_checkpoint_format_round_trip(tmp_path):
+    """SURVEY f-3: files in the reference's checkpoint layout (utils/torch_helper.py:101-117) load strictly (main.py:410-412),
+    with the reference's parameter names"""
+    import types
+    import torch
+    from cosa_amd.models import build_model
+    from cosa_amd.utils import torch_helper as th
+    args = types.SimpleNamespace(model='vit', backbone='vit_base_patch16_224', decoder='LargeFOV', pretrained=False, aux_layer=-3,
+                                 num_classes=21, compute_dtype=torch.float32)
+    torch.manual_seed(0)
+    m1 = build_model(args)
+    p = th.save_best(tmp_path, m1, 123, {"miou": 1.0}, {"lr": 6e-5}, 't', comment='seg')
+    assert p.endswith("best_seg.pth")
+    ck = torch.load(p, map_location="cpu", weights_only=False)
+    assert set(ck) == {'s_or_t', 'model', 'epoch', 'args', 'result'} and ck['epoch'] == 123 and ck['s_or_t'] == 't'
+    for k in ("encoder.cls_token", "encoder.pos_embed", "encoder.blocks.0.attn.qkv.weight", "encoder.blocks.11.mlp.fc2.bias",
+              "encoder.norm.weight", "classifier.weight", "aux_classifier.weight", "decoder.conv8.weight"):
+        assert k in ck['model'], k
+    torch.manual_seed(1)
+    m2 = build_model(args)
+    th.load_best(m2, p)
+    for (k1, v1), (k2, v2) in zip(m1.state_dict().items(), m2.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2)
