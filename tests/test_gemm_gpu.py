@@ -87,3 +87,32 @@ def test_layernorm_vs_torch():
     ref = torch.nn.functional.layer_norm(x, (768,), g.float(), b.float(), 1e-6)
     assert (y32 - ref).abs().max().item() < 2e-5
     assert (y16.float() - ref).abs().max().item() <= 2.0 ** -8 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("variant", [5, 6])
+def test_gemm_pipelined_kernels_are_run_to_run_deterministic(variant):
+    """race screen for the counted-vmcnt / staggered-barrier schedules: no atomics are involved, so any run-to-run difference of the
+    output bits would be an LDS-DMA data race (a buffer read before its DMA landed, or refilled while still being read)"""
+    from cosa_amd import nn_ops, _C
+    torch.manual_seed(11)
+    try:
+        _C.lib().cosa_gemm_set_variant(variant)
+        for (M, N, K, epi) in [(87904, 768, 768, 2), (20000, 2304, 768, 0), (9000, 3072, 768, 1), (66000, 768, 3072, 2), (4099, 256, 128, 0)]:
+            x = torch.randn(M, K, device="cuda").bfloat16()
+            w = (torch.randn(N, K, device="cuda") * K ** -0.5).bfloat16()
+            b = torch.randn(N, device="cuda").bfloat16()
+            r = torch.randn(M, N, device="cuda") if epi == 2 else None
+            first = nn_ops.gemm_bf16(x, w, b, epi, residual=r).clone()
+            ref = x.float() @ w.float().t() + b.float()
+            if epi == 1:
+                ref = torch.nn.functional.gelu(ref)
+            if epi == 2:
+                ref = ref + r
+            tol = (1e-5 if epi == 2 else 2.0 ** -8) * max(ref.abs().max().item(), 1.0)
+            assert (first.float() - ref).abs().max().item() <= tol
+            del ref
+            for _ in range(25):
+                again = nn_ops.gemm_bf16(x, w, b, epi, residual=r)
+                assert torch.equal(again, first)
+    finally:
+        _C.lib().cosa_gemm_set_variant(0)

@@ -298,3 +298,28 @@ def test_add_layernorm_fwd_bwd_vs_torch(rows):
             assert torch.equal(ds.grad, xs.grad)
         assert (w.grad - wr.grad).abs().max().item() <= 2e-3 * wr.grad.abs().max().item() + 1e-3
         assert (b.grad - br.grad).abs().max().item() <= 2e-3 * br.grad.abs().max().item() + 1e-3
+
+
+def test_attention_fwd_dma_ring_is_run_to_run_deterministic():
+    """race screen for the LDS-DMA ring of the forward kernel (no atomics: identical bits every run, and equal to the
+    register-staged 4x32 kernel's within bf16 rounding)"""
+    from cosa_amd import _C
+    torch.manual_seed(3)
+    L = _C.lib()
+    for (B, N, H) in [(4, 1765, 12), (8, 785, 12), (16, 197, 12), (3, 130, 2)]:
+        qkv = torch.randn(B, N, 3 * H * 64, device="cuda").bfloat16()
+        ws = _C.workspace(L.cosa_attn_workspace_bytes(B, N, H), qkv.device, "attn")
+
+        def run(flags):
+            out = torch.empty(B, N, H * 64, device="cuda", dtype=torch.bfloat16)
+            lse = torch.empty(B, H, N, device="cuda")
+            _C.check(L.cosa_attn_fwd(_C.ptr(qkv), _C.ptr(out), _C.ptr(lse), B, N, H, 64, 0.125, flags, None, _C.ptr(ws), ws.numel(),
+                                     _C.stream_ptr()), "cosa_attn_fwd")
+            return out, lse
+        o0, l0 = run(0)
+        for _ in range(20):
+            o, l = run(0)
+            assert torch.equal(o, o0) and torch.equal(l, l0)
+        o4, l4 = run(2)                                      # 4 x 32 kernel
+        assert (o4.float() - o0.float()).abs().max().item() <= 2.0 ** -7 * o0.float().abs().max().item()
+        assert (l4 - l0).abs().max().item() < 1e-3
