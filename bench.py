@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--dataset", default="VOC12", choices=["VOC12", "COCO"])
     ap.add_argument("--usepar", action="store_true", help="PAR(T=10, 6 dilations) as cam2mask's refine_model")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--teacher-sync", action="store_true",
+                    help="replay the teacher graph on the main stream (default: on a side stream, overlapping the student's forward); "
+                         "kernel spans in `roofline` are then undisturbed by co-running kernels")
     ap.add_argument("--cpu-batch", type=int, default=2, help="batch of the CPU-baseline sample (configs[0]: 2)")
     return ap.parse_args()
 
@@ -169,7 +172,7 @@ def main():
     from cosa_amd.train_step import CoSATrainer, default_args, rank_seed, synthetic_batch
 
     C = 20 if opt.dataset == "VOC12" else 80
-    args = default_args(opt.dataset, crop_size=opt.crop, batch_size=opt.batch, usepar=opt.usepar)
+    args = default_args(opt.dataset, crop_size=opt.crop, batch_size=opt.batch, usepar=opt.usepar, teacher_async=not opt.teacher_sync)
     nn_ops.stamps = nn_ops.KernelStamps(dev)          # device-side launch spans of the two dominant kernels (work inside hipGraphs)
     nn_ops.gemm_stamps = nn_ops.KernelStamps(dev)
     trainer = CoSATrainer(args, dev, ddp=world > 1, seed=0)
@@ -222,7 +225,8 @@ def main():
             return {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
                     "frac": round(ach * 1e12 / PEAK_BF16, 4), "traffic": traffic, "launches": n_launch,
                     "avg_launch_ms": round(secs * 1e3 / n_launch, 4), "share_of_step": round(secs / (dt / opt.steps), 4),
-                    "timer": "device s_memrealtime spans, last timed step",
+                    "timer": "device s_memrealtime spans, last timed step" + ("" if opt.teacher_sync else
+                                                                                   " (teacher graph on a side stream: spans include sharing the GPU with the student's forward)"),
                     "hip_event_avg_ms_eager_launches": round(ev_ms / ev_n, 4) if ev_n else None}
         fams = [family(nn_ops.gemm_stamps, "gemm_bf16_v6_kernel (persistent 256x256 MFMA GEMM: qkv / proj+residual / fc1+GELU / fc2+residual)",
                        "r01_gemm_v6_pmc.json", "gemm_bf16"),

@@ -34,7 +34,7 @@ def default_args(dataset="VOC12", **over):
              segfg_alpha=0.5, cam_weight=0.05, seg_softmaxtemp=0.01, reg_weight=0.05, pseudo_scales=[1.0, 0.5, 1.5],
              high_thre=0.7, high_thre_aux=0.7, low_thre=0.25, low_thre_aux=0.25, bkg_thre=0.5, par_downscale=2, usepar=False,
              aux_cam2seg=True, aux_cam2seg_alpha=0.5, aux_seg2cam=False, aux_seg2cam_alpha=0.5, after_softmax=False,
-             detach='none', use_cammix=False, compute_dtype=torch.bfloat16, teacher_graph=True, fused_losses=True, fused_optimizer=True)
+             detach='none', use_cammix=False, compute_dtype=torch.bfloat16, teacher_graph=True, teacher_async=True, fused_losses=True, fused_optimizer=True)
     if dataset == "VOC12":
         a.update(aux_layer=-4, max_iters=32000)            # run_voc.sh:9-11
     elif dataset == "COCO":
@@ -99,6 +99,9 @@ class CoSATrainer:
         self.fused_losses = bool(getattr(args, "fused_losses", True)) and device.type == "cuda" and not args.after_softmax
         self._graph = None
         self._graph_calls = 0
+        self.teacher_async = bool(getattr(args, "teacher_async", True)) and self.use_graph
+        self._side = None
+        self._teacher_pending = False
 
     # -- teacher pass: eager for the first calls (MIOpen/hipBLASLt pick their kernels), then captured and replayed --
     def _teacher(self, wimg, cls_label):
@@ -130,12 +133,29 @@ class CoSATrainer:
                                                             _seg_scales=self.fused_losses)
             self._graph = g
             self._g_stamps = [(st.n, list(st.flops)) for st in sts]
-        self._s_wimg.copy_(wimg)
-        self._s_lab.copy_(cls_label)
-        self._graph.replay()
+        if self.teacher_async:
+            # the teacher pass (no gradients, its own graph) and the student's forward are independent until the losses:
+            # replay the graph on a side stream and let the student's kernels fill the CUs its tile rounds leave idle
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=self.device)
+            self._side.wait_stream(torch.cuda.current_stream())        # after the previous step's EMA / shadow refresh
+            with torch.cuda.stream(self._side):
+                self._s_wimg.copy_(wimg, non_blocking=True)
+                self._s_lab.copy_(cls_label, non_blocking=True)
+                self._graph.replay()
+            self._teacher_pending = True
+        else:
+            self._s_wimg.copy_(wimg)
+            self._s_lab.copy_(cls_label)
+            self._graph.replay()
         for st, (n_, fl_) in zip(sts, getattr(self, "_g_stamps", None) or []):
             st.n, st.flops = n_, list(fl_)
         return self._s_out
+
+    def _join_teacher(self):
+        if self._teacher_pending:
+            torch.cuda.current_stream().wait_stream(self._side)
+            self._teacher_pending = False
 
     # main.py:114-252 -------------------------------------------------------------------------------
     def forward_losses(self, wimg, simg, cls_label, img_box, n_iter):
@@ -143,6 +163,7 @@ class CoSATrainer:
         img_denorm = torch_helper.denormalize_img(simg) if self.refine_model is not None else simg
         cam_ps, cam_aux_ps, seg_ps = self._teacher(wimg, cls_label)
         cls_final, cls_aux, _feat, seg_pred, cam_pred, cam_aux_pred = self.model_ON(simg, cam_only=False, detach=args.detach)
+        self._join_teacher()
         cls_loss = F.multilabel_soft_margin_loss(cls_final, cls_label)
         cls_loss_aux = F.multilabel_soft_margin_loss(cls_aux, cls_label)
         with torch.no_grad():
