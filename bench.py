@@ -172,7 +172,11 @@ def main():
     from cosa_amd.train_step import CoSATrainer, default_args, rank_seed, synthetic_batch
 
     C = 20 if opt.dataset == "VOC12" else 80
-    args = default_args(opt.dataset, crop_size=opt.crop, batch_size=opt.batch, usepar=opt.usepar, teacher_async=not opt.teacher_sync)
+    # several ranks on ONE card (single-GPU rehearsals only) time-slice the device between processes: two streams per process then
+    # ping-pong across time slices (measured: 7 s/step), so the side-stream teacher is only used with a card per rank
+    shared_card = world > ndev
+    args = default_args(opt.dataset, crop_size=opt.crop, batch_size=opt.batch, usepar=opt.usepar,
+                        teacher_async=not (opt.teacher_sync or shared_card or os.environ.get("COSA_TEACHER_SYNC")))
     nn_ops.stamps = nn_ops.KernelStamps(dev)          # device-side launch spans of the two dominant kernels (work inside hipGraphs)
     nn_ops.gemm_stamps = nn_ops.KernelStamps(dev)
     trainer = CoSATrainer(args, dev, ddp=world > 1, seed=0)
