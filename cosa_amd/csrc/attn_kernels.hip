@@ -29,7 +29,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int HD = 64;           // head dim
 constexpr int BQ = 128;          // queries per workgroup
 constexpr int BK = 64;           // keys per tile
-constexpr int VS = 136;          // bytes per row of the transposed LDS images of the BACKWARD kernels (64 keys * 2 B + 8 pad)
 
 // forward V tile: row-major [64 keys][64 d] (128-B rows, exactly as it lies in qkv), read as the A operand of O^T = V^T P^T with the
 // transposing LDS read ds_read_b64_tr_b16 (a 16-lane group fetches a 4-key x 16-d block, lane nn gets column nn's 4 keys): no V^T
@@ -407,103 +406,78 @@ __global__ __launch_bounds__(128, 2) void attn_fwd2_kernel(const bf16 *__restric
 // which also produces delta = rowsum(dO o O).
 // =====================================================================================================
 
-// [64 tokens][64 d] -> swizzled LDS tile (rows clamped to N-1)
-__device__ __forceinline__ void stage_rows(unsigned char *dst, const bf16 *__restrict__ base, size_t row_stride, int row0,
-                                           int N, int tid)
+// One LDS image serves both kinds of read of a [64 tokens][64 d] tile (128-B rows, as the rows lie in qkv / dO): 16-B chunk c of
+// row r sits at  c ^ usw(r),  usw(r) = ((r>>1)&1)<<2 | (r>>2)&3.  (a) ds_read_b128 row fragments (8 consecutive d of a token: the
+// operands of S and dP) are conflict-free: the 16 rows of a lane group give 16 distinct (r&1, usw(r)) pairs; (b) the transposing
+// read ds_read_b64_tr_b16 (4 tokens x 16 d per 16-lane group: the K^T / Q^T / dO^T operands) is conflict-free: rows r, r+1 are
+// 32 banks apart and bit 2 of usw moves rows r+2, r+3 by 16 banks.  No transposed copies in HBM, no transposed LDS images.
+__device__ __forceinline__ int usw(int r) { return (((r >> 1) & 1) << 2) | ((r >> 2) & 3); }
+
+__device__ __forceinline__ bf16x8 ufrag_rows(const unsigned char *tile, int row, int s, int hh)
+{
+    return *reinterpret_cast<const bf16x8 *>(tile + row * 128 + (((2 * s + hh) ^ usw(row)) << 4));
+}
+
+// A operand of a 32x32x16 MFMA whose rows are d (dhalf*32 + lane&31) and whose 8 k-slots are tokens tokb+{0..3, 8..11}
+__device__ __forceinline__ bf16x8 ufrag_cols(const unsigned char *tile, int tokb, int dhalf, int lane)
+{
+    const int nn = lane & 15, grp = (lane >> 4) & 1;
+    const int r0 = tokb + (nn >> 2), r1 = r0 + 8;
+    const int ch = dhalf * 4 + grp * 2 + ((nn & 3) >> 1), off = 8 * (nn & 1);
+    union { s16x4v h[2]; bf16x8 v; } u;
+    u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4v *)(tile + r0 * 128 + ((ch ^ usw(r0)) << 4) + off));
+    u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4v *)(tile + r1 * 128 + ((ch ^ usw(r1)) << 4) + off));
+    return u.v;
+}
+
+// LDS-DMA of one [64 rows][64 d] tile (8 one-KiB pieces; wave w of 4 issues pieces 2w, 2w+1).  vo[i]: per-lane source offset of
+// piece 2w+i with the swizzle applied on the source side; rows past the last valid one read as zeros (buffer range check).
+__device__ __forceinline__ void tile_offsets(unsigned vo[2], size_t row_stride, int wave, int lane)
 {
 #pragma unroll
-    for (int c = tid; c < BK * 8; c += 256) {
-        const int row = c >> 3, s = c & 7;
-        const int g = min(row0 + row, N - 1);
-        const uint4 v = *reinterpret_cast<const uint4 *>(base + (size_t)g * row_stride + s * 8);
-        *reinterpret_cast<uint4 *>(dst + row * 128 + ((s ^ ((row >> 1) & 7)) << 4)) = v;
+    for (int i = 0; i < 2; i++) {
+        const int row = 8 * (2 * wave + i) + (lane >> 3), ps = lane & 7;
+        vo[i] = (unsigned)((row * row_stride + (size_t)((ps ^ usw(row)) * 8)) * 2);
     }
 }
-
-// transposed global [64 d][Npad] -> LDS [64 d][VS bytes]
-__device__ __forceinline__ void stage_cols(unsigned char *dst, const bf16 *__restrict__ tbase, int Npad, int col0, int tid)
+__device__ __forceinline__ void tile_dma(__amdgpu_buffer_rsrc_t rs, unsigned char *dst, const unsigned vo[2], unsigned row0_bytes, int wave)
 {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_a *)(dst + (2 * wave) * 1024), 16, vo[0] + row0_bytes, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_a *)(dst + (2 * wave + 1) * 1024), 16, vo[1] + row0_bytes, 0, 0, 0);
+}
+
+// prep: delta[q] = sum_d dO[q,d] * O[q,d]  (the only thing the two kernels below need prepared)
+__global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const bf16 *__restrict__ dO, const bf16 *__restrict__ O,
+                                                           float *__restrict__ delta, int N, int H, size_t total)
+{
+    // one thread per (token, head) quarter: 4 lanes x 16 d
+    const size_t id = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t th = id >> 2;                                   // (b*N + tok)*H + h
+    const int part = (int)(id & 3);
+    float acc = 0.f;
+    if (th < total) {
+        const size_t o = th * HD + part * 16;
+        const bf16x8 d0 = *reinterpret_cast<const bf16x8 *>(dO + o), d1 = *reinterpret_cast<const bf16x8 *>(dO + o + 8);
+        const bf16x8 o0 = *reinterpret_cast<const bf16x8 *>(O + o), o1 = *reinterpret_cast<const bf16x8 *>(O + o + 8);
 #pragma unroll
-    for (int c = tid; c < HD * 8; c += 256) {
-        const int d = c >> 3, kc = c & 7;
-        const uint4 v = *reinterpret_cast<const uint4 *>(tbase + (size_t)d * Npad + col0 + kc * 8);
-        uint2 *p = reinterpret_cast<uint2 *>(dst + d * VS + kc * 16);
-        p[0] = make_uint2(v.x, v.y);
-        p[1] = make_uint2(v.z, v.w);
+        for (int i = 0; i < 8; i++) acc += (float)d0[i] * (float)o0[i] + (float)d1[i] * (float)o1[i];
     }
-}
-
-__device__ __forceinline__ bf16x8 frag_rows(const unsigned char *tile, int row, int s, int hh)
-{
-    return *reinterpret_cast<const bf16x8 *>(tile + row * 128 + (((2 * s + hh) ^ ((row >> 1) & 7)) << 4));
-}
-
-__device__ __forceinline__ bf16x8 frag_cols(const unsigned char *tile, int d, int tokb)
-{
-    const uint2 lo = *reinterpret_cast<const uint2 *>(tile + d * VS + tokb * 2);
-    const uint2 hi = *reinterpret_cast<const uint2 *>(tile + d * VS + (tokb + 8) * 2);
-    uint4 av = make_uint4(lo.x, lo.y, hi.x, hi.y);
-    return *reinterpret_cast<bf16x8 *>(&av);
-}
-
-// prep: which = 0 (q), 1 (k) of qkv and dO  ->  qt, kt, dot [B,H,64,Npad];  delta [B,H,N]
-__global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const bf16 *__restrict__ qkv, const bf16 *__restrict__ dO,
-                                                           const bf16 *__restrict__ O, bf16 *__restrict__ qt, bf16 *__restrict__ kt,
-                                                           bf16 *__restrict__ dot, float *__restrict__ delta, int N, int Npad, int H)
-{
-    __shared__ unsigned short tile[BK][HD + 2];
-    const int b = blockIdx.z, h = blockIdx.y, t0 = blockIdx.x * BK;
-    const int tid = threadIdx.x;
-    const size_t rs = (size_t)3 * H * HD;
-#pragma unroll 1
-    for (int which = 0; which < 3; which++) {
-        __syncthreads();
-        for (int c = tid; c < BK * 8; c += 256) {
-            const int tok = c >> 3, s = c & 7;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (t0 + tok < N) {
-                const bf16 *src = which < 2 ? qkv + ((size_t)b * N + t0 + tok) * rs + (size_t)which * H * HD + h * HD + s * 8
-                                            : dO + ((size_t)b * N + t0 + tok) * H * HD + h * HD + s * 8;
-                v = *reinterpret_cast<const uint4 *>(src);
-            }
-            unsigned *dst = reinterpret_cast<unsigned *>(&tile[tok][s * 8]);
-            dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
-        }
-        __syncthreads();
-        bf16 *outp = which == 0 ? qt : (which == 1 ? kt : dot);
-        for (int c = tid; c < HD * 8; c += 256) {
-            const int d = c >> 3, kc = c & 7;
-            unsigned short e[8];
-#pragma unroll
-            for (int i = 0; i < 8; i++) e[i] = tile[kc * 8 + i][d];
-            uint4 v;
-            v.x = e[0] | ((unsigned)e[1] << 16); v.y = e[2] | ((unsigned)e[3] << 16);
-            v.z = e[4] | ((unsigned)e[5] << 16); v.w = e[6] | ((unsigned)e[7] << 16);
-            *reinterpret_cast<uint4 *>(outp + (((size_t)b * H + h) * HD + d) * Npad + t0 + kc * 8) = v;
-        }
-    }
-    // delta[q] = sum_d dO[q,d] * O[q,d]: 4 lanes per token, 16 d each
-    {
-        const int tok = tid >> 2, part = tid & 3;
-        float acc = 0.f;
-        if (t0 + tok < N) {
-            const size_t o = ((size_t)b * N + t0 + tok) * H * HD + h * HD + part * 16;
-#pragma unroll
-            for (int i = 0; i < 16; i++) acc += (float)dO[o + i] * (float)O[o + i];
-        }
-        acc += __shfl_xor(acc, 1, 64);
-        acc += __shfl_xor(acc, 2, 64);
-        if (part == 0 && t0 + tok < N) delta[((size_t)b * H + h) * N + t0 + tok] = acc;
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    if (part == 0 && th < total) {
+        const size_t bt = th / H;
+        const int h = (int)(th - bt * H);
+        const size_t b = bt / N;
+        const int tok = (int)(bt - b * N);
+        delta[(b * H + h) * N + tok] = acc;
     }
 }
 
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16 *__restrict__ qkv, const bf16 *__restrict__ dO,
-                                                         const bf16 *__restrict__ kt, const float *__restrict__ lse,
-                                                         const float *__restrict__ delta, bf16 *__restrict__ dqkv,
-                                                         int N, int Npad, int H, int nblk, int ngroups, float scale)
+                                                         const float *__restrict__ lse, const float *__restrict__ delta,
+                                                         bf16 *__restrict__ dqkv, int N, int H, int nblk, int ngroups, float scale)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BK * 128 + HD * VS];
-    unsigned char *Ks = smem, *Vsr = smem + BK * 128, *Kts = smem + 2 * BK * 128;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * BK * 128];        // 2-deep ring of (K tile | V tile)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
     int blk, b, h;
     if (!attn_block_map(nblk, ngroups, H, blk, b, h)) return;
@@ -522,25 +496,34 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16 *__restrict
 #pragma unroll
     for (int i = 0; i < 16; i++) { g0[i] = 0.f; g1[i] = 0.f; }
     const bf16 *kbase = qkv + (size_t)b * N * rs + (size_t)H * HD + h * HD;
-    const bf16 *vbase = qkv + (size_t)b * N * rs + (size_t)2 * H * HD + h * HD;
-    const bf16 *ktbase = kt + ((size_t)b * H + h) * HD * Npad;
+    const int nbytes = (int)(((size_t)(N - 1) * rs + HD) * 2);
+    const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void *)kbase, 0, nbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void *)(kbase + (size_t)H * HD), 0, nbytes, 0x00020000);
+    unsigned vo[2];
+    tile_offsets(vo, rs, wave, lane);
+    auto dma = [&](int k0, int buf) {
+        const unsigned ro = (unsigned)((size_t)k0 * rs * 2);
+        tile_dma(rsK, smem + buf * 2 * BK * 128, vo, ro, wave);
+        tile_dma(rsV, smem + buf * 2 * BK * 128 + BK * 128, vo, ro, wave);
+    };
+    int ring = 0;
+    dma(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
 
     auto tile = [&](int k0, auto tail_tag) {
         constexpr bool tail = decltype(tail_tag)::value;
-        __syncthreads();
-        stage_rows(Ks, kbase, rs, k0, N, tid);
-        stage_rows(Vsr, vbase, rs, k0, N, tid);
-        stage_cols(Kts, ktbase, Npad, k0, tid);
-        __syncthreads();
+        const unsigned char *Ks = smem + ring * 2 * BK * 128, *Vsr = Ks + BK * 128;
+        if (k0 + BK < N) dma(k0 + BK, ring ^ 1);
         f32x16 s0, s1, p0, p1;
 #pragma unroll
         for (int i = 0; i < 16; i++) { s0[i] = 0.f; s1[i] = 0.f; p0[i] = 0.f; p1[i] = 0.f; }
 #pragma unroll
         for (int s = 0; s < 4; s++) {
-            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Ks, r, s, hh), qf[s], s0, 0, 0, 0);
-            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Ks, r + 32, s, hh), qf[s], s1, 0, 0, 0);
-            p0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Vsr, r, s, hh), dof[s], p0, 0, 0, 0);
-            p1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Vsr, r + 32, s, hh), dof[s], p1, 0, 0, 0);
+            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ufrag_rows(Ks, r, s, hh), qf[s], s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ufrag_rows(Ks, r + 32, s, hh), qf[s], s1, 0, 0, 0);
+            p0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ufrag_rows(Vsr, r, s, hh), dof[s], p0, 0, 0, 0);
+            p1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ufrag_rows(Vsr, r + 32, s, hh), dof[s], p1, 0, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < 16; i++) {
@@ -561,9 +544,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16 *__restrict
 #pragma unroll
                 for (int j = 0; j < 8; j++) df[j] = (bf16)(kb == 0 ? s0[8 * sp + j] : s1[8 * sp + j]);
                 const int keyb = kb * 32 + 16 * sp + 4 * hh;
-                g0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(Kts, r, keyb), df, g0, 0, 0, 0);
-                g1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(Kts, r + 32, keyb), df, g1, 0, 0, 0);
+                g0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ufrag_cols(Ks, keyb, 0, lane), df, g0, 0, 0, 0);     // K^T by transposing reads
+                g1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ufrag_cols(Ks, keyb, 1, lane), df, g1, 0, 0, 0);
             }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the next tile has landed and nobody still reads this one
+        __syncthreads();
+        ring ^= 1;
     };
     const int nfull = (N / BK) * BK;
     for (int k0 = 0; k0 < nfull; k0 += BK) tile(k0, std::false_type{});
@@ -583,14 +569,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16 *__restrict
 }
 
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16 *__restrict__ qkv, const bf16 *__restrict__ dO,
-                                                          const bf16 *__restrict__ qt, const bf16 *__restrict__ dot,
                                                           const float *__restrict__ lse, const float *__restrict__ delta,
-                                                          bf16 *__restrict__ dqkv, int N, int Npad, int H, int nblk, int ngroups, float scale)
+                                                          bf16 *__restrict__ dqkv, int N, int H, int nblk, int ngroups, float scale)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BK * 128 + 2 * HD * VS + 2 * BK * 4];
-    unsigned char *Qs = smem, *dOs = smem + BK * 128, *Qts = smem + 2 * BK * 128, *dOts = Qts + HD * VS;
-    float *lse_s = reinterpret_cast<float *>(dOts + HD * VS);
-    float *dl_s = lse_s + BK;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * BK * 128 + 4 * BK * 4];  // ring of (Q | dO) + (lse | delta) x 2
+    float *sc_s = reinterpret_cast<float *>(smem + 4 * BK * 128);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
     int blk, b, h;
     if (!attn_block_map(nblk, ngroups, H, blk, b, h)) return;
@@ -608,24 +591,33 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16 *__rest
     for (int i = 0; i < 16; i++) { dk0[i] = 0.f; dk1[i] = 0.f; dv0[i] = 0.f; dv1[i] = 0.f; }
     const bf16 *qbase = qkv + (size_t)b * N * rs + h * HD;
     const bf16 *dobase = dO + (size_t)b * N * H * HD + h * HD;
-    const bf16 *qtbase = qt + ((size_t)b * H + h) * HD * Npad;
-    const bf16 *dotbase = dot + ((size_t)b * H + h) * HD * Npad;
+    const size_t ds = (size_t)H * HD;
+    const __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc((void *)qbase, 0, (int)(((size_t)(N - 1) * rs + HD) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc((void *)dobase, 0, (int)(((size_t)(N - 1) * ds + HD) * 2), 0x00020000);
+    unsigned voQ[2], voD[2];
+    tile_offsets(voQ, rs, wave, lane);
+    tile_offsets(voD, ds, wave, lane);
     const float *lseb = lse + ((size_t)b * H + h) * N;
     const float *dlb = delta + ((size_t)b * H + h) * N;
+    auto dma = [&](int q0, int buf) {
+        tile_dma(rsQ, smem + buf * 2 * BK * 128, voQ, (unsigned)((size_t)q0 * rs * 2), wave);
+        tile_dma(rsD, smem + buf * 2 * BK * 128 + BK * 128, voD, (unsigned)((size_t)q0 * ds * 2), wave);
+        if (tid < 2 * BK) {                                           // log-sum-exp and delta of the tile's 64 queries
+            const int i = tid & (BK - 1), q = q0 + i;
+            const float v = q < N ? (tid < BK ? lseb[q] * 1.4426950408889634f : dlb[q]) : 0.f;
+            sc_s[buf * 2 * BK + tid] = v;
+        }
+    };
+    int ring = 0;
+    dma(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
 
     auto tile = [&](int q0, auto tail_tag) {
         constexpr bool tail = decltype(tail_tag)::value;
-        __syncthreads();
-        stage_rows(Qs, qbase, rs, q0, N, tid);
-        stage_rows(dOs, dobase, (size_t)H * HD, q0, N, tid);
-        stage_cols(Qts, qtbase, Npad, q0, tid);
-        stage_cols(dOts, dotbase, Npad, q0, tid);
-        if (tid < BK) {
-            const int q = q0 + tid;
-            lse_s[tid] = q < N ? lseb[q] * 1.4426950408889634f : 0.f;
-            dl_s[tid] = q < N ? dlb[q] : 0.f;
-        }
-        __syncthreads();
+        const unsigned char *Qs = smem + ring * 2 * BK * 128, *dOs = Qs + BK * 128;
+        const float *lse_s = sc_s + ring * 2 * BK, *dl_s = lse_s + BK;
+        if (q0 + BK < N) dma(q0 + BK, ring ^ 1);
         // one 32-query block at a time (keeps S/dP to 32 registers so that two waves fit a SIMD):
         // S[q][key], dP[q][key] (rows = queries in registers, key on the lane), then the dV^T / dK^T updates
 #pragma unroll 1
@@ -635,8 +627,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16 *__rest
             for (int i = 0; i < 16; i++) { s0[i] = 0.f; p0[i] = 0.f; }
 #pragma unroll
             for (int s = 0; s < 4; s++) {
-                s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Qs, r + 32 * qb, s, hh), kf[s], s0, 0, 0, 0);
-                p0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(dOs, r + 32 * qb, s, hh), vf[s], p0, 0, 0, 0);
+                s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ufrag_rows(Qs, r + 32 * qb, s, hh), kf[s], s0, 0, 0, 0);
+                p0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ufrag_rows(dOs, r + 32 * qb, s, hh), vf[s], p0, 0, 0, 0);
             }
 #pragma unroll
             for (int i = 0; i < 16; i++) {
@@ -652,12 +644,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16 *__rest
 #pragma unroll
                 for (int j = 0; j < 8; j++) { pf[j] = (bf16)s0[8 * sp + j]; df[j] = (bf16)p0[8 * sp + j]; }
                 const int tokb = qb * 32 + 16 * sp + 4 * hh;
-                dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(dOts, r, tokb), pf, dv0, 0, 0, 0);
-                dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(dOts, r + 32, tokb), pf, dv1, 0, 0, 0);
-                dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(Qts, r, tokb), df, dk0, 0, 0, 0);
-                dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(Qts, r + 32, tokb), df, dk1, 0, 0, 0);
+                dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ufrag_cols(dOs, tokb, 0, lane), pf, dv0, 0, 0, 0);   // dO^T, Q^T by transposing reads
+                dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ufrag_cols(dOs, tokb, 1, lane), pf, dv1, 0, 0, 0);
+                dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ufrag_cols(Qs, tokb, 0, lane), df, dk0, 0, 0, 0);
+                dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ufrag_cols(Qs, tokb, 1, lane), df, dk1, 0, 0, 0);
             }
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        ring ^= 1;
     };
     const int nfull = (N / BK) * BK;
     for (int q0 = 0; q0 < nfull; q0 += BK) tile(q0, std::false_type{});
@@ -742,11 +737,10 @@ extern "C" int cosa_attn_fwd(const void *qkv, void *out, float *lse, int B, int 
     return COSA_OK;
 }
 
-/* backward workspace: qt | kt | dot ([B,H,64,Npad] bf16 each) | delta [B,H,N] f32 */
+/* backward workspace: delta [B,H,N] f32 (the transposed operands come from transposing LDS reads now) */
 extern "C" size_t cosa_attn_bwd_workspace_bytes(int B, int N, int H)
 {
-    const size_t Npad = (size_t)(N + BK - 1) / BK * BK;
-    return 3 * align_up((size_t)B * H * HD * Npad * sizeof(bf16), 256) + align_up((size_t)B * H * N * sizeof(float), 256);
+    return align_up((size_t)B * H * N * sizeof(float), 256);
 }
 
 extern "C" int cosa_attn_bwd(const void *qkv, const void *out, const void *dout, const float *lse, void *dqkv,
@@ -755,25 +749,22 @@ extern "C" int cosa_attn_bwd(const void *qkv, const void *out, const void *dout,
     COSA_REQUIRE(qkv && out && dout && lse && dqkv && workspace, "cosa_attn_bwd: null pointer");
     COSA_REQUIRE(head_dim == HD, "cosa_attn_bwd: head_dim must be 64");
     COSA_REQUIRE(B > 0 && N > 0 && H > 0 && B <= 65535 && H <= 65535, "cosa_attn_bwd: bad shape");
+    COSA_REQUIRE((size_t)N * 3 * H * HD * 2 < 0x7fffffffull, "cosa_attn_bwd: one image's qkv rows must stay below 2 GiB");
     if (workspace_bytes < cosa_attn_bwd_workspace_bytes(B, N, H)) {
         set_error("cosa_attn_bwd: workspace too small");
         return COSA_ENOMEM;
     }
     hipStream_t st = as_stream(stream);
-    const int Npad = (N + BK - 1) / BK * BK;
-    Carver cv(workspace);
-    bf16 *qt = cv.take<bf16>((size_t)B * H * HD * Npad);
-    bf16 *kt = cv.take<bf16>((size_t)B * H * HD * Npad);
-    bf16 *dot = cv.take<bf16>((size_t)B * H * HD * Npad);
-    float *delta = cv.take<float>((size_t)B * H * N);
+    float *delta = static_cast<float *>(workspace);
     const bf16 *q = static_cast<const bf16 *>(qkv), *o = static_cast<const bf16 *>(out), *d_o = static_cast<const bf16 *>(dout);
-    hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3(Npad / BK, H, B), dim3(256), 0, st, q, d_o, o, qt, kt, dot, delta, N, Npad, H);
+    const size_t total = (size_t)B * N * H;
+    hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((unsigned)((total * 4 + 255) / 256)), dim3(256), 0, st, d_o, o, delta, N, H, total);
     COSA_LAUNCH_CHECK();
     const int nblk = (N + BQ - 1) / BQ;
     const dim3 grid(nblk * ((B * H + 7) / 8 * 8));
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, st, q, d_o, kt, lse, delta, static_cast<bf16 *>(dqkv), N, Npad, H, nblk, B * H, scale);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, st, q, d_o, lse, delta, static_cast<bf16 *>(dqkv), N, H, nblk, B * H, scale);
     COSA_LAUNCH_CHECK();
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, st, q, d_o, qt, dot, lse, delta, static_cast<bf16 *>(dqkv), N, Npad, H, nblk, B * H, scale);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, st, q, d_o, lse, delta, static_cast<bf16 *>(dqkv), N, H, nblk, B * H, scale);
     COSA_LAUNCH_CHECK();
     return COSA_OK;
 }

@@ -134,7 +134,9 @@ int cosa_attn_fwd(const void *qkv, void *out, float *lse, int B, int N, int H, i
 
 /* Backward of the same attention (autograd of vit.py:128-134): dqkv [B,N,3,H,64] bf16 from
  * dout [B,N,H*64]; P is recomputed from lse, nothing of size N^2 touches HBM; no atomics
- * (one kernel owns query blocks for dQ, one owns key blocks for dK/dV).                       */
+ * (one kernel owns query blocks for dQ, one owns key blocks for dK/dV); K^T / Q^T / dO^T operands come
+ * from transposing LDS reads of the row-major tiles (no transposed copies): the workspace only holds
+ * delta = rowsum(dO * O), [B,H,N] fp32.                                                        */
 size_t cosa_attn_bwd_workspace_bytes(int B, int N, int H);
 int cosa_attn_bwd(const void *qkv, const void *out, const void *dout, const float *lse, void *dqkv,
                   int B, int N, int H, int head_dim, float scale, void *workspace, size_t workspace_bytes, void *stream);

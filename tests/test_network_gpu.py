@@ -323,3 +323,20 @@ def test_attention_fwd_dma_ring_is_run_to_run_deterministic():
         o4, l4 = run(2)                                      # 4 x 32 kernel
         assert (o4.float() - o0.float()).abs().max().item() <= 2.0 ** -7 * o0.float().abs().max().item()
         assert (l4 - l0).abs().max().item() < 1e-3
+
+
+def test_attention_backward_is_run_to_run_deterministic():
+    """no atomics in the backward either (dQ and dK/dV are owned by disjoint workgroups): identical bits every run = race screen
+    for its LDS-DMA rings and transposing reads"""
+    from cosa_amd import nn_ops
+    torch.manual_seed(4)
+    for (B, N, H) in [(3, 785, 12), (2, 197, 12), (2, 130, 3)]:
+        qkv = torch.randn(B, N, 3 * H * 64, device="cuda").bfloat16().requires_grad_(True)
+        g = torch.randn(B, N, H * 64, device="cuda").bfloat16()
+        first = None
+        for _ in range(10):
+            qkv.grad = None
+            nn_ops.attention(qkv, H).backward(g)
+            if first is None:
+                first = qkv.grad.clone()
+            assert torch.equal(qkv.grad, first)
