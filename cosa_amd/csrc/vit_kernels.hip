@@ -89,20 +89,36 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16 *__restrict__ dy
 #pragma unroll
         for (int j = 0; j < 4; j++) { gam[i][j] = (float)gg[j]; dg[i][j] = 0.f; db[i][j] = 0.f; }
     }
-    for (int row = r0 + wave; row < r1; row += 4) {
+    // software-pipelined over the wave's rows: the next row's three loads are in flight while this row is reduced (a wave owns
+    // ~12 rows and its reductions are serial, so without the prefetch the kernel is load-latency-bound at ~2 TB/s)
+    bf16x4 ndy[PER], nxn[PER], nsk[PER];
+    auto load_row = [&](int row) {
+        const size_t base = (size_t)row * D;
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+            const int c0 = (lane + 64 * i) * 4;
+            ndy[i] = *reinterpret_cast<const bf16x4 *>(dy + base + c0);
+            nxn[i] = *reinterpret_cast<const bf16x4 *>(xn + base + c0);
+            if (dskip) nsk[i] = *reinterpret_cast<const bf16x4 *>(dskip + base + c0);
+        }
+    };
+    int row = r0 + wave;
+    if (row < r1) load_row(row);
+    for (; row < r1; row += 4) {
         const size_t base = (size_t)row * D;
         const float mu = mean[row], rs = rstd[row];
+        bf16x4 cdy[PER], cxn[PER], csk[PER];
+#pragma unroll
+        for (int i = 0; i < PER; i++) { cdy[i] = ndy[i]; cxn[i] = nxn[i]; csk[i] = nsk[i]; }
+        if (row + 4 < r1) load_row(row + 4);
         float xh[PER][4], gy[PER][4];
         float c1 = 0.f, c2 = 0.f;
 #pragma unroll
         for (int i = 0; i < PER; i++) {
-            const int c0 = (lane + 64 * i) * 4;
-            const bf16x4 dv = *reinterpret_cast<const bf16x4 *>(dy + base + c0);
-            const bf16x4 xv = *reinterpret_cast<const bf16x4 *>(xn + base + c0);
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const float d = (float)dv[j];
-                xh[i][j] = ((float)xv[j] - mu) * rs;
+                const float d = (float)cdy[i][j];
+                xh[i][j] = ((float)cxn[i][j] - mu) * rs;
                 gy[i][j] = d * gam[i][j];
                 c1 += gy[i][j];
                 c2 += gy[i][j] * xh[i][j];
@@ -119,9 +135,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16 *__restrict__ dy
 #pragma unroll
             for (int j = 0; j < 4; j++) o[j] = (gy[i][j] - c1 - xh[i][j] * c2) * rs;
             if (dskip) {
-                const bf16x4 sv = *reinterpret_cast<const bf16x4 *>(dskip + base + c0);
 #pragma unroll
-                for (int j = 0; j < 4; j++) o[j] += (float)sv[j];
+                for (int j = 0; j < 4; j++) o[j] += (float)csk[i][j];
             }
             bf16x4 ov;
 #pragma unroll
@@ -143,22 +158,23 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16 *__restrict__ dy
     }
 }
 
-// dgamma / dbeta [D] = sum over the workgroup partials, in a fixed order (deterministic).  grid = 2*D/32, 256 threads:
-// 32 columns x 8 slices of the partial list, slices combined through LDS.
+// dgamma / dbeta [D] = sum over the workgroup partials, in a fixed order (deterministic).  grid = 2*D/8, 256 threads:
+// 8 columns x 32 slices of the partial list (8 serial loads per thread), slices combined through LDS.
 __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float *__restrict__ part, int nblk, float *__restrict__ dgamma,
                                                            float *__restrict__ dbeta, int accumulate)
 {
-    __shared__ float red[8][32];
-    const int c = blockIdx.x * 32 + (threadIdx.x & 31), sl = threadIdx.x >> 5;      // c in [0, 2D)
+    __shared__ float red[32][8];
+    const int cl = threadIdx.x & 7, sl = threadIdx.x >> 3;
+    const int c = blockIdx.x * 8 + cl;                  // c in [0, 2D)
     const int k = c / D, col = c - k * D;
     float s = 0.f;
-    for (int p = sl; p < nblk; p += 8) s += part[((size_t)p * 2 + k) * D + col];
-    red[sl][threadIdx.x & 31] = s;
+    for (int p = sl; p < nblk; p += 32) s += part[((size_t)p * 2 + k) * D + col];
+    red[sl][cl] = s;
     __syncthreads();
     if (sl == 0) {
         float t = 0.f;
 #pragma unroll
-        for (int i = 0; i < 8; i++) t += red[i][threadIdx.x];
+        for (int i = 0; i < 32; i++) t += red[i][cl];
         float *dst = k == 0 ? dgamma : dbeta;
         dst[col] = accumulate ? dst[col] + t : t;
     }
@@ -203,7 +219,7 @@ extern "C" int cosa_layernorm_bwd(const void *dy, const void *x_new, const float
                        rstd, static_cast<const bf16 *>(gamma), static_cast<const bf16 *>(dskip), static_cast<bf16 *>(dx),
                        static_cast<float *>(workspace), rows, per);
     COSA_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(2 * D / 32), dim3(256), 0, st, static_cast<const float *>(workspace), nblk, dgamma, dbeta,
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(2 * D / 8), dim3(256), 0, st, static_cast<const float *>(workspace), nblk, dgamma, dbeta,
                        accumulate);
     COSA_LAUNCH_CHECK();
     return COSA_OK;
