@@ -340,3 +340,29 @@ def test_attention_backward_is_run_to_run_deterministic():
             if first is None:
                 first = qkv.grad.clone()
             assert torch.equal(qkv.grad, first)
+
+
+def test_teacher_pass_flip_equivariance_at_bench_size():
+    """size-independent property at BASELINE's configuration (b=16, 448^2, ViT-B bf16: 25 120 token rows through the persistent GEMM,
+    the DMA attention kernel, the implicit-GEMM convs and the fused CAM tail): multi_scale_camseg merges the passes over x and
+    flip(x) with max / sum, so feeding flip(x) must give exactly the flipped result -- bit for bit at scale 1.0, where no image
+    resampling is involved: the same two network evaluations happen with their batch halves (and hence all tile / workgroup
+    positions) swapped."""
+    from cosa_amd.models import build_model
+    from cosa_amd.train_step import default_args, synthetic_batch
+    from cosa_amd.utils import seg_helper
+    torch.manual_seed(0)
+    args = default_args("VOC12", crop_size=448, batch_size=16)
+    model = build_model(args).cuda().eval()
+    wimg, _, lab, _ = synthetic_batch(16, 448, 20, torch.device("cuda"), seed=77)
+    cam, aux, seg = seg_helper.multi_scale_camseg(model, wimg, [1.0])
+    camf, auxf, segf = seg_helper.multi_scale_camseg(model, wimg.flip(-1).contiguous(), [1.0])
+    assert torch.isfinite(cam).all() and cam.min() >= 0 and cam.max() <= 1.0
+    assert torch.equal(camf, cam.flip(-1)) and torch.equal(auxf, aux.flip(-1)) and torch.equal(segf, seg.flip(-1))
+    # with the 0.5x / 1.5x scales the resampled inputs differ in the last bit between x and flip(x): pseudo labels must still agree
+    m = seg_helper.cam2mask(wimg, torch.tensor([[0, 448, 0, 448]] * 16), seg_helper.multi_scale_camseg(model, wimg, [1.0, 0.5, 1.5])[0],
+                            lab, 0.7, 0.25, _fold_validation=True)
+    mf = seg_helper.cam2mask(wimg, torch.tensor([[0, 448, 0, 448]] * 16),
+                             seg_helper.multi_scale_camseg(model, wimg.flip(-1).contiguous(), [1.0, 0.5, 1.5])[0], lab, 0.7, 0.25,
+                             _fold_validation=True)
+    assert (mf == m.flip(-1)).float().mean().item() > 0.99
