@@ -1215,6 +1215,11 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(const bf16 *__restri
         const int id = blockIdx.x, xcd = id & 7, j = id >> 3;
         split = j / tiles_per_xcd;
         tile = xcd * tiles_per_xcd + (j - split * tiles_per_xcd);
+        if (tiles_per_xcd < 0) {                      // A/B switch (COSA_WGRAD_OLDMAP): tiles round-robin over the XCDs, splits outermost
+            const int pt = -tiles_per_xcd * 8;        // padded tile count
+            split = id / pt;
+            tile = id - split * pt;
+        }
         if (tile >= ntiles) return;
     }
     const int tn = tile / tiles_k, tk = tile - tn * tiles_k;
@@ -1730,8 +1735,9 @@ extern "C" int cosa_gemm_wgrad_bf16(const void *dY, const void *X, float *dW, fl
     if (splits > nstages) splits = nstages;
     const int per = (nstages + splits - 1) / splits;
     splits = (nstages + per - 1) / per;
-    const int tiles_per_xcd = (tiles + 7) / 8;
-    hipLaunchKernelGGL(gemm_wgrad_kernel, dim3(8 * tiles_per_xcd * splits), dim3(256), 65536, st, static_cast<const bf16 *>(dY),
+    static const bool oldmap = getenv("COSA_WGRAD_OLDMAP") != nullptr;
+    const int tiles_per_xcd = oldmap ? -((tiles + 7) / 8) : (tiles + 7) / 8;
+    hipLaunchKernelGGL(gemm_wgrad_kernel, dim3(8 * ((tiles + 7) / 8) * splits), dim3(256), 65536, st, static_cast<const bf16 *>(dY),
                        static_cast<const bf16 *>(X), dW, db, M, N, K, K / 128, per, nstages, tiles, tiles_per_xcd);
     COSA_LAUNCH_CHECK();
     return COSA_OK;
