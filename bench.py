@@ -150,6 +150,31 @@ def par_refine_ms_per_img(trainer, simg, lab, box, dev, opt, C):
                          "frac": round(alg / per_call / 8e12, 4), "algorithmic_MB_per_call": round(alg / 1e6, 1)}}
 
 
+def eval_images_per_s(trainer, dev, C, crop, n=20):
+    """SURVEY f-1: the validation pass (batch 1, five scales x two flips, label maps + confusion matrices on the device) on synthetic
+    VOC-val-shaped images with the teacher network; bounded sample."""
+    import numpy as np
+    from types import SimpleNamespace
+    from cosa_amd import evaluation_engine as ee
+    rng = np.random.default_rng(0)
+    sizes = [(375, 500), (333, 500), (500, 375), (366, 500), (500, 281)]
+    loader = []
+    for i in range(n + 3):
+        H, W = sizes[i % len(sizes)]
+        cls = torch.zeros(1, C)
+        cls[0, rng.choice(C, 2, replace=False)] = 1
+        loader.append(("x", torch.randn(1, 3, H, W), torch.from_numpy(rng.integers(0, C + 1, (1, H, W))), cls))
+    args = SimpleNamespace(num_classes=C + 1, crop_size=crop, bkg_thre=0.5)
+    model = trainer.model_AN
+    ee.evaluate(model, loader[:3], args, epoch=0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ee.evaluate(model, loader[3:], args, epoch=1)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"images_per_s": round(n / dt, 2), "ms_per_img": round(dt / n * 1e3, 3), "sample": f"{n} images ~375x500, batch 1, 5 scales x 2 flips"}
+
+
 def main():
     opt = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -253,6 +278,8 @@ def main():
             out["step_mfma"] = {"achieved_TFLOPs": round(ips * flop_img / 1e12, 2), "peak_TFLOPs": PEAK_BF16 / 1e12 * world,
                                 "frac": round(ips * flop_img / (PEAK_BF16 * world), 4), "flop_per_img": flop_img}
         out["par_refine"] = par_refine_ms_per_img(trainer, simg, lab, box, dev, opt, C)
+        if world == 1 and opt.crop == 448:
+            out["evaluation"] = eval_images_per_s(trainer, dev, C, opt.crop)
         if world == 1 and not opt.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(opt, trainer.student.state_dict(), C)
         print(json.dumps(out), flush=True)
