@@ -21,8 +21,36 @@ from .utils import evaluation, seg_helper, torch_helper
 EVAL_SCALES = [1.0, 0.5, 1.5, 0.75, 1.25]          # evaluation_engine.py:84
 
 
+class _GraphedCamSeg:
+    """multi_scale_camsegv3 at a fixed input shape (evaluation resizes every image to crop_size x crop_size, batch 1) as one hipGraph:
+    ten encoder passes at batch 1 are ~1000 small launches, i.e. launch-bound when issued one by one.  Two eager calls first (library
+    kernel selection), then capture; any other input shape falls back to eager."""
+
+    def __init__(self, model, scales, enabled=True):
+        self.model, self.scales, self.enabled = model, scales, enabled
+        self.calls, self.graph, self.static_in, self.outs = 0, None, None, None
+
+    def __call__(self, inputs):
+        eager = lambda x: seg_helper.multi_scale_camsegv3(self.model, x, self.scales, getcls=True)
+        if not self.enabled or (self.static_in is not None and inputs.shape != self.static_in.shape):
+            return eager(inputs)
+        if self.graph is None:
+            self.calls += 1
+            if self.calls <= 2:
+                return eager(inputs)
+            self.static_in = inputs.clone()
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                self.outs = eager(self.static_in)
+            self.graph = g
+        self.static_in.copy_(inputs)
+        self.graph.replay()
+        return self.outs
+
+
 def evaluate(model, data_loader, args, df=None, save_result=False, save_rawcam=False, epoch=None, threshold_filters=None, getcrf=False,
-             s_or_t='t', get_camiou=False, isfinal=False, class_list=None):
+             s_or_t='t', get_camiou=False, isfinal=False, class_list=None, use_graph=True):
     if save_result or save_rawcam:
         raise NotImplementedError("evaluate: save_result / save_rawcam (image dumps) are not part of the device path")
     if getcrf or threshold_filters:
@@ -39,6 +67,7 @@ def evaluate(model, data_loader, args, df=None, save_result=False, save_rawcam=F
     ap_cnt = 0                                                           # ... over the batches (AverageMeter semantics, :86-92)
     was_training = model.training
     model.eval()
+    camseg = _GraphedCamSeg(model, EVAL_SCALES, enabled=use_graph and getattr(model, "can_forward_multi", None) is not None)
     with torch.no_grad():
         for data in data_loader:
             name, img_org, labels, cls_label = data
@@ -46,7 +75,7 @@ def evaluate(model, data_loader, args, df=None, save_result=False, save_rawcam=F
             cls_label = cls_label.to(device, non_blocking=True).float()
             img_org = img_org.to(device, non_blocking=True)
             inputs = F.interpolate(img_org, size=[args.crop_size, args.crop_size], mode='bilinear', align_corners=False)
-            cams, cams_aux, seg_ps, cls_final, cls_aux = seg_helper.multi_scale_camsegv3(model, inputs, EVAL_SCALES, getcls=True)
+            cams, cams_aux, seg_ps, cls_final, cls_aux = camseg(inputs)
             # classification AP of this batch (:86-92; cls_* are [1,C] sums over scales and flips, compared with every label row)
             for j, logit in enumerate((cls_final, cls_aux)):
                 ap, valid = torch_helper.average_precision(cls_label, torch.sigmoid(logit.float()).expand_as(cls_label))

@@ -143,7 +143,7 @@ def test_evaluate_end_to_end_vs_oracle_composition(oracle_c):
     model = build_model(args).cuda().eval()
     rng = np.random.default_rng(3)
     loader = []
-    for (H, W) in [(50, 70), (64, 64), (81, 47)]:
+    for (H, W) in [(50, 70), (64, 64), (81, 47), (33, 90), (64, 64), (70, 50)]:      # > 2 images: the captured-graph path replays
         img = torch.from_numpy(rng.standard_normal((1, 3, H, W)).astype(np.float32))
         lab = torch.from_numpy(rng.integers(0, C + 1, (1, H, W)).astype(np.int64))
         lab[0, :3] = 255
@@ -173,5 +173,7 @@ def test_evaluate_end_to_end_vs_oracle_composition(oracle_c):
     np.testing.assert_allclose(df["mIoU"], ref_miou, atol=1e-9)
     np.testing.assert_allclose(cls_aps, [np.mean(aps[0]), np.mean(aps[1])], rtol=1e-6)
     assert "mIoU" in tab and model.training is False
+    tab2, seg_miou2, cam_miou2, _, aps2 = ee.evaluate(model, loader, args, epoch=7, s_or_t='s', get_camiou=True, use_graph=False)
+    assert abs(seg_miou2 - seg_miou) < 1e-9 and abs(cam_miou2 - cam_miou) < 1e-9 and np.allclose(aps2, cls_aps, rtol=1e-9)
     with pytest.raises(NotImplementedError):
         ee.evaluate(model, loader, args, epoch=1, getcrf=True)
