@@ -49,6 +49,7 @@ __device__ __forceinline__ bf16x8 v_frag(const unsigned char *Vs, int keyb, int 
     return u.v;
 }
 
+constexpr float kDeferLog2 = 6.0f;
 __device__ __forceinline__ int crow(int i, int hh) { return (i & 3) + 8 * (i >> 2) + 4 * hh; }
 
 // Workgroup -> (query/key block, batch, head).  Workgroups are dealt round-robin to the 8 XCDs (id & 7), each with a private L2;
@@ -304,6 +305,7 @@ __global__ __launch_bounds__(128, 2) void attn_fwd2_kernel(const bf16 *__restric
             for (int kb = 0; kb < 2; kb++)
 #pragma unroll
                 for (int i = 0; i < 16; i++) sc[u][kb][i] = 0.f;
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int s = 0; s < 4; s++) {
             const int slot = ((2 * s + hh) ^ swz) << 4;
@@ -315,6 +317,7 @@ __global__ __launch_bounds__(128, 2) void attn_fwd2_kernel(const bf16 *__restric
                 sc[u][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, qf[u][s], sc[u][1], 0, 0, 0);
             }
         }
+        __builtin_amdgcn_s_setprio(0);
 #pragma unroll
         for (int u = 0; u < 2; u++) {
             if constexpr (tail) {
@@ -329,7 +332,9 @@ __global__ __launch_bounds__(128, 2) void attn_fwd2_kernel(const bf16 *__restric
             for (int i = 1; i < 16; i++) mt = fmaxf(mt, fmaxf(sc[u][0][i], sc[u][1][i]));
             mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
             const float mnew = fmaxf(m[u], mt * scale_log2e);
-            if (__any(mnew != m[u])) {
+            // deferred rescale: the running reference m only moves when some row's max has outgrown it by more than 2^DEFER (probabilities
+            // then reach at most 2^DEFER, far inside fp32 / bf16 range; l and O carry the same factor, so the result is unchanged)
+            if (__any(mnew > m[u] + kDeferLog2)) {
                 const float alpha = __builtin_amdgcn_exp2f(m[u] - mnew);
                 l[u] *= alpha;
 #pragma unroll
@@ -345,6 +350,7 @@ __global__ __launch_bounds__(128, 2) void attn_fwd2_kernel(const bf16 *__restric
             }
             l[u] += ls;
         }
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kb = 0; kb < 2; kb++)
 #pragma unroll
@@ -360,6 +366,7 @@ __global__ __launch_bounds__(128, 2) void attn_fwd2_kernel(const bf16 *__restric
                     o[u][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, pf, o[u][1], 0, 0, 0);
                 }
             }
+        __builtin_amdgcn_s_setprio(0);
         if (DMA) {                                     // the next tile has landed and nobody still reads this one
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
