@@ -35,8 +35,8 @@ PEAK_BF16 = 2.5e15                 # dense bf16 MFMA peak (MI355X_MICROARCH.md)
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50, help="timed steps (SURVEY d-1: >= 50)")
+    ap.add_argument("--warmup", type=int, default=10, help="untimed warm-up steps (SURVEY d-1: >= 10)")
     ap.add_argument("--batch", type=int, default=16, help="per-GPU batch (BASELINE configs[1]: 16)")
     ap.add_argument("--crop", type=int, default=448)
     ap.add_argument("--dataset", default="VOC12", choices=["VOC12", "COCO"])
