@@ -333,6 +333,34 @@ __global__ __launch_bounds__(256) void lattice_slice_kernel(float *__restrict__ 
         }
         tile[pl * ld + k] = acc;
     }
+    // gate of every pixel of the tile, once (it is the same for all K channels: max over the channels -> K loads per pixel, not per element)
+    __shared__ float gate_s[TP], roi_s[TP], mx_s[4][TP];
+    if (seg) {                                              // 4 threads per pixel share the channel loop (max is order-independent)
+        const int pl = threadIdx.x & (TP - 1), q4 = threadIdx.x >> 6;
+        const int p = p0 + pl;
+        float mx = -3.402823466e38f;
+        if (p < P.N) {
+            const float *sg = seg + (size_t)n * K * hw + p;
+            for (int kk = q4; kk < K; kk += 4) { const float t = sg[(size_t)kk * hw]; mx = t > mx ? t : mx; }
+        }
+        mx_s[q4][pl] = mx;
+    }
+    __syncthreads();
+    if (seg && threadIdx.x < TP) {
+        const int p = p0 + threadIdx.x;
+        float g = 0.0f, ro = 0.0f;
+        if (p < P.N) {
+            float mx = mx_s[0][threadIdx.x];
+#pragma unroll
+            for (int i = 1; i < 4; i++) mx = mx_s[i][threadIdx.x] > mx ? mx_s[i][threadIdx.x] : mx;
+            ro = roi[(size_t)n * hw + p];
+            g = ro - mx;
+            if (unlabel[(size_t)n * hw + p]) g = 1.0f;
+            if (g < 0.0f) g = 0.0f;
+        }
+        gate_s[threadIdx.x] = g;
+        roi_s[threadIdx.x] = ro;
+    }
     __syncthreads();
     float *out = outs + (size_t)n * K * hw;
     double part = 0.0;
@@ -342,15 +370,8 @@ __global__ __launch_bounds__(256) void lattice_slice_kernel(float *__restrict__ 
         if (p >= P.N) continue;
         float v = tile[pl * ld + k];
         if (seg) {
-            const float *sg = seg + (size_t)n * K * hw + p;
-            float mx = sg[0];
-            for (int kk = 1; kk < K; kk++) { const float t = sg[(size_t)kk * hw]; mx = t > mx ? t : mx; }
-            const float ro = roi[(size_t)n * hw + p];
-            float g = ro - mx;
-            if (unlabel[(size_t)n * hw + p]) g = 1.0f;
-            if (g < 0.0f) g = 0.0f;
-            v = v * g;
-            part += (double)(sg[(size_t)k * hw] * ro) * (double)v;
+            v = v * gate_s[pl];
+            part += (double)(seg[(size_t)n * K * hw + (size_t)k * hw + p] * roi_s[pl]) * (double)v;
         }
         out[(size_t)k * hw + p] = v;
     }
