@@ -254,11 +254,14 @@ __device__ __forceinline__ float bilerp_fma(const float *pl, int w, int y0, int 
     return __builtin_fmaf(r0, ly0, r1 * ly1);
 }
 
+// One WAVE per output cell, the class index on the lane (k = lane, lane + 64): every summed logit is evaluated once (the serial version
+// recomputed it in three passes and ran 12 544 threads in total), max / sum are wave reductions.
 __global__ __launch_bounds__(256) void cam_target_kernel(SegScales sc, const float *__restrict__ labels, float *__restrict__ out,
                                                         int B, int K, int S, int oh, int ow, float inv_temp)
 {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (idx >= B * oh * ow) return;
+    const int lane = threadIdx.x & 63;
     const int b = idx / (oh * ow), cell = idx - b * oh * ow;
     const int oy = cell / ow, ox = cell - oy * ow;
     int Y[2], X[2];
@@ -266,36 +269,61 @@ __global__ __launch_bounds__(256) void cam_target_kernel(SegScales sc, const flo
     src_index(oy, S, (float)S / (float)oh, Y[0], Y[1], wy[0], wy[1]);
     src_index(ox, S, (float)S / (float)ow, X[0], X[1], wx[0], wx[1]);
     const int C = K - 1;
-    // per source pixel: softmax statistics (two passes over k recomputing the summed logits), then the blended output
-    float m[4], inv[4];
+    constexpr int KR = 2;                           // classes per lane: K <= 128
+    float z[KR][4];
+    float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
-    for (int p = 0; p < 4; p++) { m[p] = -INFINITY; inv[p] = 0.f; }
-    for (int pass = 0; pass < 3; pass++) {
-        for (int k = 0; k < K; k++) {
-            const bool present = k == 0 || labels[(size_t)b * C + k - 1] != 0.0f;
-            float acc_out = 0.f;
+    for (int kr = 0; kr < KR; kr++) {
+        const int k = lane + 64 * kr;
+        const bool live = k < K;
+        const bool present = live && (k == 0 || labels[(size_t)b * C + k - 1] != 0.0f);
 #pragma unroll
-            for (int p = 0; p < 4; p++) {
+        for (int p = 0; p < 4; p++) {
+            float zz = -INFINITY;
+            if (live) {
                 const int py = Y[p >> 1], px = X[p & 1];
-                float z = 0.f;
-                for (int s = 0; s < sc.n; s++) {
-                    const int h = sc.h[s], w = sc.w[s];
+                float acc = 0.f;
+                for (int s2 = 0; s2 < sc.n; s2++) {
+                    const int h = sc.h[s2], w = sc.w[s2];
                     int y0, y1, x0, x1, f0, f1;
                     float ly0, ly1, lx0, lx1, fl0, fl1;
                     src_index(py, h, (float)h / (float)S, y0, y1, ly0, ly1);
                     src_index(px, w, (float)w / (float)S, x0, x1, lx0, lx1);
                     src_index(S - 1 - px, w, (float)w / (float)S, f0, f1, fl0, fl1);
-                    const float *a = sc.p[s] + ((size_t)b * K + k) * h * w;
-                    const float *f = sc.p[s] + ((size_t)(b + B) * K + k) * h * w;
+                    const float *a = sc.p[s2] + ((size_t)b * K + k) * h * w;
+                    const float *f = sc.p[s2] + ((size_t)(b + B) * K + k) * h * w;
                     const float v = bilerp_fma(a, w, y0, y1, x0, x1, ly0, ly1, lx0, lx1) + bilerp_fma(f, w, y0, y1, f0, f1, ly0, ly1, fl0, fl1);
-                    z = s == 0 ? v : z + v;
+                    acc = s2 == 0 ? v : acc + v;
                 }
-                z = (present ? z : -1e5f) * inv_temp;
-                if (pass == 0) m[p] = fmaxf(m[p], z);
-                else if (pass == 1) inv[p] += __expf(z - m[p]);
-                else acc_out += wy[p >> 1] * wx[p & 1] * (__expf(z - m[p]) / inv[p]);
+                zz = (present ? acc : -1e5f) * inv_temp;
             }
-            if (pass == 2 && k > 0) out[(((size_t)b * C + k - 1) * oh + oy) * ow + ox] = acc_out;
+            z[kr][p] = zz;
+            m[p] = fmaxf(m[p], zz);
+        }
+    }
+    float se[4];
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m[p] = fmaxf(m[p], __shfl_xor(m[p], o, 64));
+        float e = 0.f;
+#pragma unroll
+        for (int kr = 0; kr < KR; kr++) {
+            z[kr][p] = __expf(z[kr][p] - m[p]);       // exp(-inf) = 0 for the lanes beyond K
+            e += z[kr][p];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) e += __shfl_xor(e, o, 64);
+        se[p] = e;
+    }
+#pragma unroll
+    for (int kr = 0; kr < KR; kr++) {
+        const int k = lane + 64 * kr;
+        if (k > 0 && k < K) {
+            float acc_out = 0.f;
+#pragma unroll
+            for (int p = 0; p < 4; p++) acc_out += wy[p >> 1] * wx[p & 1] * (z[kr][p] / se[p]);
+            out[(((size_t)b * C + k - 1) * oh + oy) * ow + ox] = acc_out;
         }
     }
 }
@@ -359,8 +387,9 @@ extern "C" int cosa_cam_loss_targets(const float *const *seg_scales, const int *
         sc.h[i] = i < n_scales ? hs[i] : 1;
         sc.w[i] = i < n_scales ? ws[i] : 1;
     }
+    COSA_REQUIRE(K <= 128, "cosa_cam_loss_targets: at most 128 classes (got %d)", K);
     const int total = B * oh * ow;
-    hipLaunchKernelGGL(cam_target_kernel, dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), sc, labels, out, B, K, S, oh, ow,
+    hipLaunchKernelGGL(cam_target_kernel, dim3((total + 3) / 4), dim3(256), 0, as_stream(stream), sc, labels, out, B, K, S, oh, ow,
                        1.0f / temperature);
     COSA_LAUNCH_CHECK();
     return COSA_OK;
