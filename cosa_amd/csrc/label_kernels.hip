@@ -134,6 +134,9 @@ __global__ __launch_bounds__(1024) void minmax_norm_kernel(float *__restrict__ c
 
 // ---- multi_scale_camseg tail: upsample + flip-merge (+relu) + accumulate ---------------------
 // thread per output pixel; grid (ceil(S*S/256), C, B)
+// grid (pixel blocks, images): the class planes are a loop INSIDE the workgroup.  Absent classes cost one uniform branch instead of a
+// launched-and-retired workgroup each (b=16 x 80 COCO planes x 784 blocks were a million workgroups per call, 97 % of them empty), and the
+// bilinear source indices / weights of a pixel are computed once for all its planes.
 __global__ __launch_bounds__(256) void flip_merge_upsample_kernel(const float *__restrict__ src, float *__restrict__ dst,
                                                                  int B, int C, int h, int w, int S, float sy, float sx,
                                                                  int mode, int accumulate, const float *__restrict__ active)
@@ -141,25 +144,27 @@ __global__ __launch_bounds__(256) void flip_merge_upsample_kernel(const float *_
     const int pix = blockIdx.x * 256 + threadIdx.x;
     if (pix >= S * S) return;
     const int Y = pix / S, X = pix - Y * S;
-    const int c = blockIdx.y, b = blockIdx.z;
-    if (active && active[b * C + c] == 0.0f) {          // class absent from the image: cam_validation zeroes it anyway
-        if (!accumulate) dst[((size_t)b * C + c) * S * S + pix] = 0.0f;
-        return;
-    }
+    const int b = blockIdx.y;
     int y0, y1, x0, x1, fx0, fx1;
     float ly0, ly1, lx0, lx1, flx0, flx1;
     src_index(Y, h, S, sy, y0, y1, ly0, ly1);
     src_index(X, w, S, sx, x0, x1, lx0, lx1);
     src_index(S - 1 - X, w, S, sx, fx0, fx1, flx0, flx1);
-    const float *p = src + ((size_t)b * C + c) * h * w;
-    const float *q = src + ((size_t)(b + B) * C + c) * h * w;
-    float u1 = bilerp(p[y0 * w + x0], p[y0 * w + x1], p[y1 * w + x0], p[y1 * w + x1], lx0, lx1, ly0, ly1);
-    float u2 = bilerp(q[y0 * w + fx0], q[y0 * w + fx1], q[y1 * w + fx0], q[y1 * w + fx1], flx0, flx1, ly0, ly1);
-    float v;
-    if (mode == 0) { v = fmaxf(u1, u2); v = v > 0.0f ? v : 0.0f; }
-    else v = u1 + u2;
-    const size_t o = ((size_t)b * C + c) * S * S + pix;
-    dst[o] = accumulate ? dst[o] + v : v;
+    for (int c = 0; c < C; c++) {
+        const size_t o = ((size_t)b * C + c) * S * S + pix;
+        if (active && active[b * C + c] == 0.0f) {      // class absent from the image: cam_validation zeroes it anyway
+            if (!accumulate) dst[o] = 0.0f;
+            continue;
+        }
+        const float *p = src + ((size_t)b * C + c) * h * w;
+        const float *q = src + ((size_t)(b + B) * C + c) * h * w;
+        const float u1 = bilerp(p[y0 * w + x0], p[y0 * w + x1], p[y1 * w + x0], p[y1 * w + x1], lx0, lx1, ly0, ly1);
+        const float u2 = bilerp(q[y0 * w + fx0], q[y0 * w + fx1], q[y1 * w + fx0], q[y1 * w + fx1], flx0, flx1, ly0, ly1);
+        float v;
+        if (mode == 0) { v = fmaxf(u1, u2); v = v > 0.0f ? v : 0.0f; }
+        else v = u1 + u2;
+        dst[o] = accumulate ? dst[o] + v : v;
+    }
 }
 
 // ---- active channel list -------------------------------------------------------------------
@@ -329,7 +334,7 @@ extern "C" int cosa_cam_flip_merge_upsample(const float *src, float *dst, int B,
     COSA_REQUIRE(mode == 0 || mode == 1, "cosa_cam_flip_merge_upsample: mode must be 0 or 1");
     COSA_REQUIRE(C <= 65535 && B <= 65535, "cosa_cam_flip_merge_upsample: grid too large");
     const float sy = (float)h / (float)S, sx = (float)w / (float)S;
-    dim3 grid((S * S + 255) / 256, C, B);
+    dim3 grid((S * S + 255) / 256, B);
     hipLaunchKernelGGL(flip_merge_upsample_kernel, grid, dim3(256), 0, as_stream(stream), src, dst, B, C, h, w, S, sy, sx,
                        mode, accumulate, active);
     COSA_LAUNCH_CHECK();
