@@ -15,7 +15,7 @@ int par_make_plan(const int *dilations, int n_dil, ParPlan *plan);
 int par_launch_affinity(const float *imgs, float *aff, int B, int h, int w, const ParPlan &plan, hipStream_t st);
 // one propagation step:  dst[b][k] = sum_n aff[b][n] * gather(src[b][k], n)   for k < kcount[b] (or K if null)
 // planes of image b start at b*plane_stride floats.
-int par_launch_step(const float *aff, const float *src, float *dst, int B, int Kmax, const int *kcount,
+int par_launch_step(const float *aff, const float *src, float *dst, int B, int Kmax, const int *kcount, int halves,
                     size_t plane_stride, int h, int w, const ParPlan &plan, hipStream_t st);
 
 }  // namespace cosa

@@ -182,7 +182,7 @@ __global__ void active_kernel(const float *__restrict__ labels, int *__restrict_
 }
 
 // ---- spec L: threshold plane + /2 bilinear + active softmax (hi and lo in one pass) ---------------
-// P layout: [B][2][Kmax][s*s]  (hi planes then lo planes), Kmax = C+1
+// P layout: [B][H][Kmax][s*s], Kmax = C+1; a CAM set owns halves h0 (hi planes) and h0+1 (lo planes); H = 2 x CAM sets
 template <int DS>
 __device__ __forceinline__ float lowres_value(const float *__restrict__ pl, float lab, int S, int y, int x)
 {
@@ -201,8 +201,10 @@ __device__ __forceinline__ float lowres_value(const float *__restrict__ pl, floa
 template <int DS>
 __global__ __launch_bounds__(256) void lowres_softmax_kernel(const float *__restrict__ cams, const float *__restrict__ labels,
                                                             const int *__restrict__ act, const int *__restrict__ kcount,
-                                                            float *__restrict__ P, int C, int S, int s, float thr_hi, float thr_lo, int fold)
+                                                            float *__restrict__ P, int C, int S, int s, float thr_hi, float thr_lo, int fold,
+                                                            int H, int h0, const float *__restrict__ thr_dev)
 {
+    if (thr_dev) { thr_hi = thr_dev[h0]; thr_lo = thr_dev[h0 + 1]; }       // device-resident thresholds of this CAM set
     const int pix = blockIdx.x * 256 + threadIdx.x;
     if (pix >= s * s) return;
     const int b = blockIdx.y;
@@ -213,8 +215,8 @@ __global__ __launch_bounds__(256) void lowres_softmax_kernel(const float *__rest
     const float *cam = cams + (size_t)b * C * S * S;
     const float *lab = labels + (size_t)b * C;
     const size_t ss = (size_t)s * s;
-    float *Phi = P + ((size_t)b * 2 + 0) * Kmax * ss + pix;
-    float *Plo = P + ((size_t)b * 2 + 1) * Kmax * ss + pix;
+    float *Phi = P + ((size_t)b * H + h0 + 0) * Kmax * ss + pix;
+    float *Plo = P + ((size_t)b * H + h0 + 1) * Kmax * ss + pix;
 
     float mc = -INFINITY;
     for (int k = 1; k < K; k++) {
@@ -276,7 +278,7 @@ __device__ __forceinline__ int argmax_up(const float *__restrict__ Pb, int K, si
 __global__ __launch_bounds__(256) void upsample_argmax_merge_kernel(const float *__restrict__ P, const int *__restrict__ act,
                                                                    const int *__restrict__ kcount, const int32_t *__restrict__ boxes,
                                                                    float *__restrict__ mask, int C, int S, int s, float scale,
-                                                                   float ignore_index)
+                                                                   float ignore_index, int H, int h0)
 {
     const int pix = blockIdx.x * 256 + threadIdx.x;
     if (pix >= S * S) return;
@@ -293,8 +295,8 @@ __global__ __launch_bounds__(256) void upsample_argmax_merge_kernel(const float 
         src_index(Y, s, S, scale, y0, y1, ly0, ly1);
         src_index(X, s, S, scale, x0, x1, lx0, lx1);
         const int *a = act + (size_t)b * Kmax;
-        const int khi = argmax_up(P + ((size_t)b * 2 + 0) * Kmax * ss, K, ss, s, y0, y1, x0, x1, ly0, ly1, lx0, lx1);
-        const int klo = argmax_up(P + ((size_t)b * 2 + 1) * Kmax * ss, K, ss, s, y0, y1, x0, x1, ly0, ly1, lx0, lx1);
+        const int khi = argmax_up(P + ((size_t)b * H + h0 + 0) * Kmax * ss, K, ss, s, y0, y1, x0, x1, ly0, ly1, lx0, lx1);
+        const int klo = argmax_up(P + ((size_t)b * H + h0 + 1) * Kmax * ss, K, ss, s, y0, y1, x0, x1, ly0, ly1, lx0, lx1);
         const float hi = (float)a[khi], lo = (float)a[klo];
         r = hi;
         if (hi == 0.0f) r = ignore_index;
@@ -341,36 +343,47 @@ extern "C" int cosa_cam_flip_merge_upsample(const float *src, float *dst, int B,
     return COSA_OK;
 }
 
-// workspace layout of cam2mask: act[B*(C+1)] | kcount[2B] | P[B][2][C+1][s*s] | P2 (same) | img_lo[B*3*s*s] | aff[B][NN][s*s]
-extern "C" size_t cosa_cam2mask_workspace_bytes(int B, int C, int S, int downscale, int n_dil)
+// workspace layout of cam2mask: act[B*(C+1)] | kcount[2B] | P[B][2G][C+1][s*s] | P2 (same) | img_lo[B*3*s*s] | aff[B][NN][s*s]
+extern "C" size_t cosa_cam2mask_multi_workspace_bytes(int G, int B, int C, int S, int downscale, int n_dil)
 {
     const int s = downscale ? S / downscale : S;
     const size_t ss = (size_t)s * s;
     size_t bytes = 0;
     bytes += align_up((size_t)B * (C + 1) * sizeof(int), 256);
     bytes += align_up((size_t)2 * B * sizeof(int), 256);
-    bytes += align_up((size_t)B * 2 * (C + 1) * ss * sizeof(float), 256);
+    bytes += align_up((size_t)B * 2 * G * (C + 1) * ss * sizeof(float), 256);
     if (n_dil > 0) {
-        bytes += align_up((size_t)B * 2 * (C + 1) * ss * sizeof(float), 256);
+        bytes += align_up((size_t)B * 2 * G * (C + 1) * ss * sizeof(float), 256);
         bytes += align_up((size_t)B * 3 * ss * sizeof(float), 256);
         bytes += align_up((size_t)B * n_dil * 8 * ss * sizeof(float), 256);
     }
     return bytes;
 }
 
-extern "C" int cosa_cam2mask(const float *images, const int32_t *boxes, const float *cams, const float *labels,
-                             float *mask, int B, int C, int S, float thr_hi, float thr_lo, int downscale,
-                             int fold_validation, const int *dilations, int n_dil, int par_iters, float ignore_index,
-                             void *workspace, size_t workspace_bytes, void *stream)
+extern "C" size_t cosa_cam2mask_workspace_bytes(int B, int C, int S, int downscale, int n_dil)
 {
-    COSA_REQUIRE(boxes && cams && labels && mask && workspace, "cosa_cam2mask: null pointer");
+    return cosa_cam2mask_multi_workspace_bytes(1, B, C, S, downscale, n_dil);
+}
+
+// G CAM sets of the SAME images (main and aux CAMs in training) become G label maps in one pass: the class bookkeeping,
+// the half-resolution image and -- the point -- PAR's affinity tensor are built once, and every propagation step streams
+// the affinities once for the hi and lo stacks of all sets (2G·K live planes per image).  Per set the arithmetic is that
+// of cosa_cam2mask, so the outputs are bit-identical to G separate calls.
+extern "C" int cosa_cam2mask_multi(const float *images, const int32_t *boxes, const float *const *cams, const float *labels,
+                                   float *const *masks, const float *thr_hi, const float *thr_lo, const float *thr_dev, int G,
+                                   int B, int C, int S, int downscale, int fold_validation, const int *dilations, int n_dil, int par_iters,
+                                   float ignore_index, void *workspace, size_t workspace_bytes, void *stream)
+{
+    COSA_REQUIRE(boxes && cams && labels && masks && thr_hi && thr_lo && workspace, "cosa_cam2mask: null pointer");
+    COSA_REQUIRE(G > 0 && G <= 8, "cosa_cam2mask: 1..8 CAM sets");
+    for (int g = 0; g < G; g++) COSA_REQUIRE(cams[g] && masks[g], "cosa_cam2mask: null CAM set / mask pointer");
     COSA_REQUIRE(B > 0 && C > 0 && S > 0 && B <= 65535, "cosa_cam2mask: bad shape");
     COSA_REQUIRE(downscale == 0 || downscale == 2, "cosa_cam2mask: downscale must be 0 or 2");
     COSA_REQUIRE(!downscale || (S % 2) == 0, "cosa_cam2mask: S must be even when downscale=2");
     const bool use_par = par_iters > 0;
     if (!use_par) n_dil = 0;
     COSA_REQUIRE(!use_par || (images && dilations && n_dil > 0 && n_dil <= kMaxDil), "cosa_cam2mask: PAR needs images and 1..8 dilations");
-    if (workspace_bytes < cosa_cam2mask_workspace_bytes(B, C, S, downscale, n_dil)) {
+    if (workspace_bytes < cosa_cam2mask_multi_workspace_bytes(G, B, C, S, downscale, n_dil)) {
         set_error("cosa_cam2mask: workspace too small");
         return COSA_ENOMEM;
     }
@@ -378,23 +391,28 @@ extern "C" int cosa_cam2mask(const float *images, const int32_t *boxes, const fl
     const int s = downscale ? S / downscale : S;
     const size_t ss = (size_t)s * s;
     const int Kmax = C + 1;
+    const int H = 2 * G;
     Carver cv(workspace);
     int *act = cv.take<int>((size_t)B * Kmax);
     int *kcount = cv.take<int>((size_t)2 * B);
-    float *P = cv.take<float>((size_t)B * 2 * Kmax * ss);
+    float *P = cv.take<float>((size_t)B * H * Kmax * ss);
 
     hipLaunchKernelGGL(active_kernel, dim3((B + 63) / 64), dim3(64), 0, st, labels, act, kcount, B, C);
     COSA_LAUNCH_CHECK();
     dim3 g1((unsigned)((ss + 255) / 256), B);
-    if (downscale == 2)
-        hipLaunchKernelGGL(lowres_softmax_kernel<2>, g1, dim3(256), 0, st, cams, labels, act, kcount, P, C, S, s, thr_hi, thr_lo, fold_validation);
-    else
-        hipLaunchKernelGGL(lowres_softmax_kernel<0>, g1, dim3(256), 0, st, cams, labels, act, kcount, P, C, S, s, thr_hi, thr_lo, fold_validation);
-    COSA_LAUNCH_CHECK();
+    for (int g = 0; g < G; g++) {
+        if (downscale == 2)
+            hipLaunchKernelGGL(lowres_softmax_kernel<2>, g1, dim3(256), 0, st, cams[g], labels, act, kcount, P, C, S, s, thr_hi[g],
+                               thr_lo[g], fold_validation, H, 2 * g, thr_dev);
+        else
+            hipLaunchKernelGGL(lowres_softmax_kernel<0>, g1, dim3(256), 0, st, cams[g], labels, act, kcount, P, C, S, s, thr_hi[g],
+                               thr_lo[g], fold_validation, H, 2 * g, thr_dev);
+        COSA_LAUNCH_CHECK();
+    }
 
     const float *Pfinal = P;
     if (use_par) {
-        float *P2 = cv.take<float>((size_t)B * 2 * Kmax * ss);
+        float *P2 = cv.take<float>((size_t)B * H * Kmax * ss);
         float *img_lo = cv.take<float>((size_t)B * 3 * ss);
         float *aff = cv.take<float>((size_t)B * n_dil * 8 * ss);
         ParPlan plan;
@@ -411,8 +429,8 @@ extern "C" int cosa_cam2mask(const float *images, const int32_t *boxes, const fl
         if (rc) return rc;
         float *src = P, *dst = P2;
         for (int it = 0; it < par_iters; it++) {
-            // hi and lo stacks are contiguous: treat as 2*Kmax planes, of which [0,K) and [Kmax,Kmax+K) are live
-            rc = par_launch_step(aff, src, dst, B, 2 * Kmax, kcount, (size_t)2 * Kmax * ss, s, s, plan, st);
+            // the H stacks of an image are contiguous: H*Kmax planes, of which the first K of each stack are live
+            rc = par_launch_step(aff, src, dst, B, H * Kmax, kcount, H, (size_t)H * Kmax * ss, s, s, plan, st);
             if (rc) return rc;
             float *t = src; src = dst; dst = t;
         }
@@ -420,7 +438,20 @@ extern "C" int cosa_cam2mask(const float *images, const int32_t *boxes, const fl
     }
     dim3 g3((S * S + 255) / 256, B);
     const float scale = (float)s / (float)S;
-    hipLaunchKernelGGL(upsample_argmax_merge_kernel, g3, dim3(256), 0, st, Pfinal, act, kcount, boxes, mask, C, S, s, scale, ignore_index);
-    COSA_LAUNCH_CHECK();
+    for (int g = 0; g < G; g++) {
+        hipLaunchKernelGGL(upsample_argmax_merge_kernel, g3, dim3(256), 0, st, Pfinal, act, kcount, boxes, masks[g], C, S, s, scale,
+                           ignore_index, H, 2 * g);
+        COSA_LAUNCH_CHECK();
+    }
     return COSA_OK;
+}
+
+extern "C" int cosa_cam2mask(const float *images, const int32_t *boxes, const float *cams, const float *labels,
+                             float *mask, int B, int C, int S, float thr_hi, float thr_lo, int downscale,
+                             int fold_validation, const int *dilations, int n_dil, int par_iters, float ignore_index,
+                             void *workspace, size_t workspace_bytes, void *stream)
+{
+    COSA_REQUIRE(cams && mask, "cosa_cam2mask: null pointer");
+    return cosa_cam2mask_multi(images, boxes, &cams, labels, &mask, &thr_hi, &thr_lo, nullptr, 1, B, C, S, downscale, fold_validation,
+                               dilations, n_dil, par_iters, ignore_index, workspace, workspace_bytes, stream);
 }

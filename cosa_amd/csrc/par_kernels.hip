@@ -9,6 +9,7 @@
 //
 // Layout: aff [B][NN][h*w] (plane per neighbour: coalesced across the wavefront),
 //         masks [B][planes][h*w].
+#include <cstdlib>
 #include "kernels.hpp"
 #include <cmath>
 
@@ -266,15 +267,10 @@ __global__ __launch_bounds__(256) void par_step_kernel(const float *__restrict__
 struct __attribute__((packed, aligned(4))) f4u { float x, y, z, w; };
 
 template <int PG>
-__global__ __launch_bounds__(256) void par_step4_kernel(const float *__restrict__ aff, const float *__restrict__ src,
-                                                       float *__restrict__ dst, const int *__restrict__ kcount, int Kfull,
-                                                       int halves, int half_planes, size_t img_stride, int h, int w, ParPlan plan)
+__device__ __forceinline__ void par_step4_body(const float *__restrict__ aff, const float *__restrict__ src, float *__restrict__ dst,
+                                               int b, int K, int j0, int nlive, int half_planes, size_t img_stride, int h, int w,
+                                               const ParPlan &plan)
 {
-    const int b = blockIdx.z;
-    const int K = kcount ? kcount[b] : Kfull;
-    const int live = K * halves;
-    const int j0 = blockIdx.y * PG;
-    if (j0 >= live) return;
     const int w4 = w >> 2;
     const int q = blockIdx.x * 256 + threadIdx.x;       // quad index
     if (q >= h * w4) return;
@@ -282,8 +278,6 @@ __global__ __launch_bounds__(256) void par_step4_kernel(const float *__restrict_
     const int hw = h * w;
     const float *sp[PG];
     float acc[PG][4];
-    int nlive = live - j0;
-    nlive = nlive > PG ? PG : nlive;
 #pragma unroll
     for (int i = 0; i < PG; i++) {
         int j = j0 + (i < nlive ? i : 0);
@@ -359,6 +353,29 @@ __global__ __launch_bounds__(256) void par_step4_kernel(const float *__restrict_
     }
 }
 
+// Up to GROUP live planes of an image go through one pass over its affinity rows.  The body is instantiated for a few
+// plane counts and picked per image (wave-uniform), so an image with 2 live planes does not pay for GROUP.  Measured
+// (b=16, 224^2, T=10): the step is bound by the neighbour gathers (L1 / address-unit rate), not by the affinity stream, and
+// the registers of a wider body cost more occupancy than the shared affinity loads save (2.19 ms per pass at GROUP=4, 2.37 at 8,
+// 4.3 at 16; capping the registers only spills): GROUP=4 is the default.
+template <int GROUP>
+__global__ __launch_bounds__(256) void par_step4_kernel(const float *__restrict__ aff, const float *__restrict__ src,
+                                                       float *__restrict__ dst, const int *__restrict__ kcount, int Kfull,
+                                                       int halves, int half_planes, size_t img_stride, int h, int w, ParPlan plan)
+{
+    const int b = blockIdx.z;
+    const int K = kcount ? kcount[b] : Kfull;
+    const int live = K * halves;
+    const int j0 = blockIdx.y * GROUP;
+    if (j0 >= live) return;
+    int nlive = live - j0;
+    nlive = nlive > GROUP ? GROUP : nlive;
+    if (nlive <= 2) par_step4_body<2>(aff, src, dst, b, K, j0, nlive, half_planes, img_stride, h, w, plan);
+    else if (GROUP <= 4 || nlive <= 4) par_step4_body<4>(aff, src, dst, b, K, j0, nlive, half_planes, img_stride, h, w, plan);
+    else if (nlive <= 6) par_step4_body<6>(aff, src, dst, b, K, j0, nlive, half_planes, img_stride, h, w, plan);
+    else par_step4_body<8>(aff, src, dst, b, K, j0, nlive, half_planes, img_stride, h, w, plan);
+}
+
 }  // namespace
 
 int par_make_plan(const int *dilations, int n_dil, ParPlan *plan)
@@ -418,17 +435,21 @@ int par_launch_affinity(const float *imgs, float *aff, int B, int h, int w, cons
 }
 
 // planes per image = Kmax; when kcount != null the live planes of image b are the first kcount[b] planes of each of
-// `halves` equal halves of the stack (cam2mask: hi stack then lo stack).
-int par_launch_step(const float *aff, const float *src, float *dst, int B, int Kmax, const int *kcount,
+// `halves` equal parts of the stack (cam2mask: hi stack then lo stack of every CAM set); halves = 1 when kcount is null.
+int par_launch_step(const float *aff, const float *src, float *dst, int B, int Kmax, const int *kcount, int halves,
                     size_t plane_stride, int h, int w, const ParPlan &plan, hipStream_t st)
 {
-    const int halves = kcount ? 2 : 1;
     const int half_planes = Kmax / halves;
     if ((w & 3) == 0) {     // rows are float4-aligned: the 4-pixel kernel (all live planes of an image in one thread for K <= 4)
-        constexpr int PG = 4;
-        dim3 grid4((h * (w >> 2) + 255) / 256, (Kmax + PG - 1) / PG, B);
-        hipLaunchKernelGGL(par_step4_kernel<PG>, grid4, dim3(256), 0, st, aff, src, dst, kcount, Kmax, halves, half_planes,
-                           plane_stride, h, w, plan);
+        static const int group = [] { const char *e = getenv("COSA_PAR_GROUP"); return e ? atoi(e) : 4; }();   // experiment switch
+        const int G = group == 8 ? 8 : 4;
+        dim3 grid4((h * (w >> 2) + 255) / 256, (Kmax + G - 1) / G, B);
+        if (G == 8)
+            hipLaunchKernelGGL(par_step4_kernel<8>, grid4, dim3(256), 0, st, aff, src, dst, kcount, Kmax, halves, half_planes,
+                               plane_stride, h, w, plan);
+        else
+            hipLaunchKernelGGL(par_step4_kernel<4>, grid4, dim3(256), 0, st, aff, src, dst, kcount, Kmax, halves, half_planes,
+                               plane_stride, h, w, plan);
         COSA_LAUNCH_CHECK();
         return COSA_OK;
     }
@@ -480,7 +501,7 @@ extern "C" int cosa_par_forward(const float *imgs, const float *masks, float *ou
     const float *src = masks;
     for (int it = 0; it < num_iter; it++) {
         float *dst = ((num_iter - 1 - it) & 1) ? tmp : out;
-        rc = par_launch_step(aff, src, dst, B, K, nullptr, (size_t)K * hw, h, w, plan, st);
+        rc = par_launch_step(aff, src, dst, B, K, nullptr, 1, (size_t)K * hw, h, w, plan, st);
         if (rc) return rc;
         src = dst;
     }

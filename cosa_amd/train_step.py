@@ -34,7 +34,8 @@ def default_args(dataset="VOC12", **over):
              segfg_alpha=0.5, cam_weight=0.05, seg_softmaxtemp=0.01, reg_weight=0.05, pseudo_scales=[1.0, 0.5, 1.5],
              high_thre=0.7, high_thre_aux=0.7, low_thre=0.25, low_thre_aux=0.25, bkg_thre=0.5, par_downscale=2, usepar=False,
              aux_cam2seg=True, aux_cam2seg_alpha=0.5, aux_seg2cam=False, aux_seg2cam_alpha=0.5, after_softmax=False,
-             detach='none', use_cammix=False, compute_dtype=torch.bfloat16, teacher_graph=True, teacher_async=True, fused_losses=True, fused_optimizer=True)
+             detach='none', use_cammix=False, usegmm=False, usegmmaux=False, gmmscale=16, gmmfilter_thre=0.05, gmmemadecay=0.99,
+             queue_update_ratio=100, compute_dtype=torch.bfloat16, teacher_graph=True, teacher_async=True, fused_losses=True, fused_optimizer=True)
     if dataset == "VOC12":
         a.update(aux_layer=-4, max_iters=32000)            # run_voc.sh:9-11
     elif dataset == "COCO":
@@ -85,6 +86,16 @@ class CoSATrainer:
             warmup_ratio=1e-6, power=0.9, min_mult=args.min_mult)
         self.reg_layer = seg_helper.DenseEnergyLoss(weight=1e-7, sigma_rgb=15, sigma_xy=100, scale_factor=0.5)
         self.refine_model = PAR(num_iter=10, dilations=[1, 2, 4, 8, 12, 24]) if args.usepar else None
+        if args.usegmm:
+            # main.py:94-103: queues of per-cell CAM maxima + EMA trackers of the fitted thresholds, all device-resident
+            qdim = (args.crop_size // args.gmmscale) ** 2
+            mk = lambda: seg_helper.DynamicQueue(args.batch_size * args.queue_update_ratio, dim=qdim, batch_size=args.batch_size,
+                                                 device=device)
+            self.cam_queue, self.camaux_queue = mk(), mk()
+            self.ema_lowthre = torch_helper.EMAtracker(args.low_thre, decay=args.gmmemadecay)
+            self.ema_highthre = torch_helper.EMAtracker(args.high_thre, decay=args.gmmemadecay)
+            self.ema_auxlowthre = torch_helper.EMAtracker(args.low_thre_aux, decay=args.gmmemadecay)
+            self.ema_auxhighthre = torch_helper.EMAtracker(args.high_thre_aux, decay=args.gmmemadecay)
         self._ema_pairs = (list(self.model_AN.parameters()), list(self.student.parameters()))
         # teacher: fixed-address bf16 shadow weights + (optionally) the whole multi-scale pass as one hipGraph
         self._shadows = nn_ops.ShadowSet(self.model_AN) if args.compute_dtype == torch.bfloat16 and device.type == "cuda" else None
@@ -157,6 +168,16 @@ class CoSATrainer:
             torch.cuda.current_stream().wait_stream(self._side)
             self._teacher_pending = False
 
+    def _adaptive_thresholds(self, cams, cls_label, queue, ema_low, ema_high, filter_thre):
+        """main.py:138-151: per-cell maxima of the validated CAMs at 1/gmmscale resolution -> queue -> rungmm -> EMA trackers.
+        cam_validation (x labels) commutes exactly with the bilinear resize for {0,1} labels, so it is applied to the small map."""
+        red = seg_helper.cell_bilinear(cams, self.args.crop_size // self.args.gmmscale) * cls_label[:, :, None, None]
+        queue.update(red.amax(dim=1))
+        fit = seg_helper.rungmm_device(queue.getqueue(), 3, filter_thre)
+        ema_low.update(fit[0])
+        ema_high.update(fit[1])
+        return ema_low.get(), ema_high.get()
+
     # main.py:114-252 -------------------------------------------------------------------------------
     def forward_losses(self, wimg, simg, cls_label, img_box, n_iter):
         args = self.args
@@ -169,26 +190,34 @@ class CoSATrainer:
         with torch.no_grad():
             if args.use_cammix:
                 cam_ps = (cam_ps + cam_aux_ps) / 2
-            refine_mask_label = seg_helper.cam2mask(img_denorm, img_box, cam_ps, cls_label, args.high_thre, args.low_thre,
-                                                    refine_model=self.refine_model, downscale=args.par_downscale,
-                                                    _fold_validation=True)
+            threlow, threhigh = args.low_thre, args.high_thre
+            auxthrelow, auxthrehigh = args.low_thre_aux, args.high_thre_aux
+            if args.usegmm:
+                # main.py:138-151,174-184: thresholds = EMA of a 3-component mixture fitted to the queue every iteration.
+                # Fit, trackers and the thresholds cam2mask reads all stay on the device (the reference syncs and runs sklearn).
+                threlow, threhigh = self._adaptive_thresholds(cam_ps, cls_label, self.cam_queue, self.ema_lowthre,
+                                                              self.ema_highthre, args.gmmfilter_thre)
+                if args.aux_cam2seg:
+                    auxthrelow, auxthrehigh = self._adaptive_thresholds(cam_aux_ps, cls_label, self.camaux_queue, self.ema_auxlowthre,
+                                                                        self.ema_auxhighthre, 0.05)   # main.py:181: default filter
+            if args.aux_cam2seg:
+                # main and auxiliary CAMs of the same images: one pass (shared bookkeeping / refine-model affinities)
+                refine_mask_label, refine_mask_label_aux = seg_helper.cam2mask_multi(
+                    img_denorm, img_box, [cam_ps, cam_aux_ps], cls_label, [threhigh, auxthrehigh], [threlow, auxthrelow],
+                    refine_model=self.refine_model, downscale=args.par_downscale, _fold_validation=True)
+            else:
+                refine_mask_label = seg_helper.cam2mask(img_denorm, img_box, cam_ps, cls_label, threhigh, threlow,
+                                                        refine_model=self.refine_model, downscale=args.par_downscale,
+                                                        _fold_validation=True)
         fused = self.fused_losses and args.aux_cam2seg and args.segfg_alpha == 0.5 and args.aux_cam2seg_alpha == 0.5
         if fused:
             # one forward + one backward kernel instead of ~10 full-resolution passes (same maths, main.py:167-212)
-            with torch.no_grad():
-                refine_mask_label_aux = seg_helper.cam2mask(img_denorm, img_box, cam_aux_ps, cls_label, args.high_thre_aux,
-                                                            args.low_thre_aux, refine_model=self.refine_model,
-                                                            downscale=args.par_downscale, _fold_validation=True)
             seg_loss, reg_loss = seg_helper.fused_seg_and_energy_loss(seg_pred, refine_mask_label, refine_mask_label_aux, simg,
                                                                       img_box, self.reg_layer)
         else:
             seg_pred = F.interpolate(seg_pred, size=refine_mask_label.shape[1:], mode='bilinear', align_corners=False)
             seg_loss = seg_helper.seg_loss(seg_pred, refine_mask_label, fg_alpha=args.segfg_alpha)
             if args.aux_cam2seg:
-                with torch.no_grad():
-                    refine_mask_label_aux = seg_helper.cam2mask(img_denorm, img_box, cam_aux_ps, cls_label, args.high_thre_aux,
-                                                                args.low_thre_aux, refine_model=self.refine_model,
-                                                                downscale=args.par_downscale, _fold_validation=True)
                 seg_loss_aux = seg_helper.seg_loss(seg_pred, refine_mask_label_aux, fg_alpha=args.segfg_alpha)
                 seg_loss = (1 - args.aux_cam2seg_alpha) * seg_loss + args.aux_cam2seg_alpha * seg_loss_aux
             reg_loss = seg_helper.get_energy_loss(img=simg, logit=seg_pred, label=refine_mask_label, img_box=img_box,

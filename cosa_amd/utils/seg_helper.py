@@ -5,6 +5,7 @@ cites the lines it replaces.  All tensors live on the GPU; nothing here falls ba
 """
 import ctypes
 
+import numpy as np
 import torch
 import torch.nn.functional as F
 from torch.autograd import Function
@@ -192,7 +193,19 @@ def cam2mask(images, img_boxes, cams, cls_labels, threshold_high, threshold_low,
     `cams` are the validated CAMs as in the reference call order (main.py:137,158-166);
     `_fold_validation=True` lets the training loop pass raw CAMs and skip cam_validation's pass.
     """
-    _C.require_cuda(cams, cls_labels)
+    return cam2mask_multi(images, img_boxes, [cams], cls_labels, [threshold_high], [threshold_low], refine_model=refine_model,
+                          ignore_index=ignore_index, downscale=downscale, _fold_validation=_fold_validation)[0]
+
+
+def cam2mask_multi(images, img_boxes, cams_list, cls_labels, thresholds_high, thresholds_low, refine_model=None, ignore_index=255,
+                   downscale=2, _fold_validation=False):
+    """cam2mask for several CAM sets of the SAME images (the training step's main and auxiliary CAMs, main.py:137-166) in
+    one pass: the refine model's affinities are built once and streamed once per propagation step for all sets.  Returns
+    a list of label maps, each bit-identical to a separate cam2mask call."""
+    G = len(cams_list)
+    if not (G >= 1 and len(thresholds_high) == G and len(thresholds_low) == G):
+        raise ValueError("cam2mask_multi: one (high, low) threshold pair per CAM set")
+    _C.require_cuda(cls_labels, *cams_list)
     b, _, h, w = images.shape
     if h != w:
         raise ValueError("cam2mask: square crops only")
@@ -201,15 +214,17 @@ def cam2mask(images, img_boxes, cams, cls_labels, threshold_high, threshold_low,
     downscale = 2 if downscale == 2 else 0
     if refine_model is not None and not isinstance(refine_model, PAR):
         raise TypeError("cam2mask: refine_model must be None or cosa_amd.models.PAR.PAR")
-    cams = cams.contiguous().float()
+    cams_list = [c.contiguous().float() for c in cams_list]
     cls_labels = cls_labels.contiguous().float()
-    C = cams.shape[1]
-    if cams.shape != (b, C, h, w) or cls_labels.shape != (b, C):
-        raise ValueError("cam2mask: cams must be [b,C,h,w] at image size and cls_labels [b,C]")
-    boxes = _boxes_to_device(img_boxes, cams.device)
+    C = cams_list[0].shape[1]
+    for c in cams_list:
+        if c.shape != (b, C, h, w) or cls_labels.shape != (b, C):
+            raise ValueError("cam2mask: cams must be [b,C,h,w] at image size and cls_labels [b,C]")
+    dev = cams_list[0].device
+    boxes = _boxes_to_device(img_boxes, dev)
     if boxes.shape != (b, 4):
         raise ValueError("cam2mask: img_boxes must be [b,4]")
-    mask = torch.empty((b, h, w), device=cams.device, dtype=torch.float32)
+    masks = [torch.empty((b, h, w), device=dev, dtype=torch.float32) for _ in range(G)]
     L = _C.lib()
     if refine_model is not None:
         _C.require_cuda(images)
@@ -217,12 +232,98 @@ def cam2mask(images, img_boxes, cams, cls_labels, threshold_high, threshold_low,
         dil, nd, iters = _C.int_array(refine_model.dilations), len(refine_model.dilations), refine_model.num_iter
     else:
         dil, nd, iters = _C.int_array([1]), 0, 0
-    ws = _C.workspace(L.cosa_cam2mask_workspace_bytes(b, C, h, downscale, nd if iters > 0 else 0), cams.device, "cam2mask")
-    _C.check(L.cosa_cam2mask(_C.ptr(images if iters > 0 else None), _C.ptr(boxes), _C.ptr(cams), _C.ptr(cls_labels),
-                             _C.ptr(mask), b, C, h, float(threshold_high), float(threshold_low), downscale,
-                             int(bool(_fold_validation)), dil, nd, iters, float(ignore_index), _C.ptr(ws), ws.numel(),
-                             _C.stream_ptr()), "cosa_cam2mask")
-    return mask
+    ws = _C.workspace(L.cosa_cam2mask_multi_workspace_bytes(G, b, C, h, downscale, nd if iters > 0 else 0), dev, "cam2mask")
+    cam_ptrs = (ctypes.c_void_p * G)(*[c.data_ptr() for c in cams_list])
+    mask_ptrs = (ctypes.c_void_p * G)(*[m.data_ptr() for m in masks])
+    on_device = any(torch.is_tensor(t) for t in list(thresholds_high) + list(thresholds_low))
+    if on_device:
+        # thresholds that live on the device (adaptive thresholds): [G][hi, lo] float32, read by the kernels -- no host sync
+        tdev = torch.stack([torch.stack([torch.as_tensor(h, device=dev).reshape(()).to(torch.float32),
+                                         torch.as_tensor(l, device=dev).reshape(()).to(torch.float32)])
+                            for h, l in zip(thresholds_high, thresholds_low)]).contiguous()
+        hi = lo = (ctypes.c_float * G)(*([0.0] * G))
+    else:
+        tdev = None
+        hi = (ctypes.c_float * G)(*[float(t) for t in thresholds_high])
+        lo = (ctypes.c_float * G)(*[float(t) for t in thresholds_low])
+    _C.check(L.cosa_cam2mask_multi(_C.ptr(images if iters > 0 else None), _C.ptr(boxes), cam_ptrs, _C.ptr(cls_labels), mask_ptrs,
+                                   hi, lo, _C.ptr(tdev), G, b, C, h, downscale, int(bool(_fold_validation)), dil, nd, iters, float(ignore_index),
+                                   _C.ptr(ws), ws.numel(), _C.stream_ptr()), "cosa_cam2mask_multi")
+    return masks
+
+
+# --------------------------------------------------------------------------------------------
+# adaptive thresholds  (utils/seg_helper.py:924-959, main.py:94-103,138-151,174-184)
+# --------------------------------------------------------------------------------------------
+class DynamicQueue(object):
+    """utils/seg_helper.py:946-959 with the storage on the device: a ring of `max_size` rows x `dim` float64 values, created
+    with uniform noise exactly as the reference's is (np.random.random) and overwritten `batch_size` rows at a time."""
+
+    def __init__(self, max_size, dim, batch_size, device="cuda"):
+        self.max_size = max_size
+        self.queue = torch.from_numpy(np.random.random((max_size, dim))).to(device)
+        self.ptr = 0
+        self.batch_size = batch_size
+
+    def update(self, income):
+        # income -> batchsize,dim (device tensor, any float dtype; stored as float64 like the reference's numpy queue)
+        self.queue[self.ptr:self.ptr + self.batch_size, :] = income.reshape(self.batch_size, -1).to(self.queue.dtype)
+        self.ptr = (self.ptr + self.batch_size) % self.max_size
+
+    def getqueue(self):
+        return self.queue
+
+
+def cell_bilinear(x, g):
+    """F.interpolate(x, size=(g, g), mode='bilinear', align_corners=False) for an integer, even reduction factor (main.py:140:
+    448 -> 28): every output is 0.5*(0.5*a + 0.5*b) + 0.5*(0.5*c + 0.5*d) of the four pixels around the cell centre, evaluated
+    in ATen's order, so the values are bit-identical -- but as four strided gathers instead of ATen's kernel, which gives a
+    whole [b*C] column to each of only g*g threads (0.74 ms per call at b=16, C=20; this: ~30 us)."""
+    S = x.shape[-1]
+    s = S // g if g > 0 else 0
+    if x.shape[-2] != S or g <= 0 or s * g != S or s % 2:
+        return F.interpolate(x, size=(g, g), mode='bilinear', align_corners=False)
+    a = s // 2 - 1
+    r0, r1 = x[:, :, a::s, :], x[:, :, a + 1::s, :]
+    top = 0.5 * r0[..., a::s] + 0.5 * r0[..., a + 1::s]
+    bot = 0.5 * r1[..., a::s] + 0.5 * r1[..., a + 1::s]
+    return 0.5 * top + 0.5 * bot
+
+
+def rungmm_device(queue, modal, filter_thre=0.05, tol=1e-3, reg_covar=1e-6, max_iter=100):
+    """The fit of `rungmm` without leaving the device: returns a float64 tensor [13] -- [0] low threshold (largest sample of
+    component 0), [1] high threshold (smallest sample of component 2; NaN for modal=2), [2] EM iterations, [3] status bits
+    (see include/cosa_hip.h), then means / weights / inverse sigmas.  No host synchronisation."""
+    assert modal in [2, 3]
+    if filter_thre < 0:
+        raise ValueError("rungmm: filter_thre must be >= 0")
+    _C.require_cuda(queue)
+    q = queue.to(torch.float64).flatten()
+    keep = q > filter_thre
+    xs, _ = torch.sort(torch.where(keep, q, torch.full_like(q, float("inf"))))
+    n = keep.sum()                                                   # int64, stays on the device
+    out = torch.empty(13, device=q.device, dtype=torch.float64)
+    L = _C.lib()
+    ws = _C.workspace(L.cosa_gmm_workspace_bytes(), q.device, "gmm")
+    _C.check(L.cosa_gmm_fit_thresholds(_C.ptr(xs), _C.ptr(n), xs.numel(), modal, tol, reg_covar, max_iter, _C.ptr(out), _C.ptr(ws),
+                                       ws.numel(), _C.stream_ptr()), "cosa_gmm_fit_thresholds")
+    return out
+
+
+def rungmm(queue, modal, filter_thre=0.05):
+    """utils/seg_helper.py:924-943: (low, high) for modal=3, low for modal=2, as Python floats (this form synchronises; the
+    training step uses rungmm_device).  An empty outer component raises ValueError like the reference's max() / min()."""
+    if isinstance(queue, np.ndarray):
+        queue = torch.from_numpy(queue).cuda()
+    out = rungmm_device(queue, modal, filter_thre).tolist()
+    status = int(out[3])
+    if status & 8:
+        raise _C.CosaError("rungmm: device barrier expired")
+    if status & 4:
+        raise ValueError("rungmm: fewer samples above filter_thre than mixture components")
+    if status & 1 or (modal == 3 and status & 2):
+        raise ValueError("rungmm: max()/min() of an empty component")
+    return out[0] if modal == 2 else (out[0], out[1])
 
 
 # --------------------------------------------------------------------------------------------

@@ -241,6 +241,25 @@ def format_tabs(scores, name_list, cat_list=None, getmIoU_list=True):
 # --------------------------------------------------------------------------------------------
 # checkpoints  (utils/torch_helper.py:101-117 save_best; main.py:401-412 finaleval's load)
 # --------------------------------------------------------------------------------------------
+class EMAtracker:
+    """utils/torch_helper.py:90-99.  `update` also takes a device scalar (the adaptive thresholds never visit the host); a
+    non-finite new value (a fit that left an outer component empty -- the reference would have raised) leaves X as it is."""
+
+    def __init__(self, initial_value=0, decay=0.9):
+        self.X = initial_value
+        self.decay = decay
+
+    def update(self, newvlaue):
+        if torch.is_tensor(newvlaue):
+            x = torch.as_tensor(self.X, dtype=newvlaue.dtype, device=newvlaue.device)
+            self.X = torch.where(torch.isfinite(newvlaue), x * self.decay + newvlaue * (1 - self.decay), x)
+        else:
+            self.X = self.X * self.decay + newvlaue * (1 - self.decay)
+
+    def get(self):
+        return self.X
+
+
 def save_best(output_dir, model, finish_epoch, result, args, s_or_t, comment=''):
     """Same file name and dict layout as the reference ({'s_or_t','model','epoch','args','result'}), written by rank 0 only
     (utils.save_on_master).  `model.state_dict()` has the reference's key names, so either code base reads the other's files."""

@@ -74,6 +74,34 @@ int cosa_cam2mask(const float *images, const int32_t *boxes, const float *cams, 
                   int fold_validation, const int *dilations, int n_dil, int par_iters, float ignore_index,
                   void *workspace, size_t workspace_bytes, void *stream);
 
+/* The same for G CAM sets of the SAME images in one pass (the training step's two calls, main.py:137-166: main CAMs
+ * and auxiliary CAMs with their own thresholds).  cams / masks: host arrays of G device pointers ([B,C,S,S] / [B,S,S]),
+ * thr_hi / thr_lo: host float[G].  Bit-identical to G cosa_cam2mask calls; the affinities of the refine model are built
+ * once and streamed once per propagation step for all sets.  thr_dev (optional): device float[G][2] = (hi, lo) per set,
+ * read by the kernels instead of the host values -- the adaptive thresholds of main.py:138-151 without a host sync. */
+size_t cosa_cam2mask_multi_workspace_bytes(int G, int B, int C, int S, int downscale, int n_dil);
+int cosa_cam2mask_multi(const float *images, const int32_t *boxes, const float *const *cams, const float *labels,
+                        float *const *masks, const float *thr_hi, const float *thr_lo, const float *thr_dev, int G, int B, int C,
+                        int S,
+                        int downscale, int fold_validation, const int *dilations, int n_dil, int par_iters,
+                        float ignore_index, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * utils/seg_helper.py:924-943  rungmm -- the adaptive-threshold fit of main.py:138-151,174-184:
+ * scikit-learn GaussianMixture(modal, weights 1/modal, means (min, median, max) | (min, max), precisions 1,
+ * tol, reg_covar, max_iter).fit_predict on the queue samples above the filter threshold, then
+ * max(samples of component 0) [and min(samples of component 2) for modal = 3].  One launch, float64, no host sync.
+ *   sorted  device float64: the samples above the filter threshold in ascending order (positive)
+ *   n_dev   device int64: how many of them (<= capacity)
+ *   out     device float64[13]: [0] low threshold, [1] high threshold (NaN for modal 2), [2] EM iterations,
+ *           [3] status bits (1: component 0 empty, 2: component 2 empty, 4: fewer samples than components,
+ *           8: grid barrier expired), [4..] means, [7..] weights, [10..] 1/sigma
+ * ------------------------------------------------------------------------------------- */
+size_t cosa_gmm_workspace_bytes(void);
+int cosa_gmm_fit_thresholds(const double *sorted, const long long *n_dev, long long capacity, int modal, double tol,
+                            double reg_covar, int max_iter, double *out, void *workspace, size_t workspace_bytes,
+                            void *stream);
+
 /* ---------------------------------------------------------------------------------------
  * models/PAR.py:64-91  PAR.forward for a batch of same-sized images / mask stacks.
  *   imgs [B,3,h,w]   masks [B,K,h,w] (in)   out [B,K,h,w]

@@ -309,6 +309,47 @@ def gen_eval(rng):
     np.savez_compressed(os.path.join(OUT, "eval.npz"), **out)
 
 
+def gmm_queue(rng, rows, dim, random_rows):
+    """a DynamicQueue as the training loop leaves it: rows of float32 CAM maxima (background near 0, object cells spread up to
+    1, stored as float64) plus `random_rows` rows still holding the uniform float64 noise the queue is created with."""
+    bgmask = rng.random((rows, dim)) < 0.55
+    vals = np.where(bgmask, np.abs(rng.normal(0.0, 0.04, (rows, dim))),
+                    np.clip(rng.normal(0.62, 0.2, (rows, dim)), 0, 1) * (rng.random((rows, dim)) < 0.8)
+                    + np.clip(rng.normal(0.25, 0.06, (rows, dim)), 0, 1) * 0.0)
+    mid = rng.random((rows, dim)) < 0.2
+    vals = np.where(mid & ~bgmask, np.clip(rng.normal(0.28, 0.07, (rows, dim)), 0, 1), vals)
+    q = vals.astype(np.float32).astype(np.float64)
+    if random_rows:
+        q[:random_rows] = rng.random((random_rows, dim))
+    return q
+
+
+def gen_gmm(rng):
+    """adaptive thresholds: the reference's rungmm (utils/seg_helper.py:924-943) on synthetic queues; the iteration count of
+    the same scikit-learn estimator is stored next to it as an extra pin for the restatement."""
+    import sklearn
+    import sklearn.mixture as skm
+    sh = ref_loader.seg_helper()
+    out = {"sklearn_version": np.array(sklearn.__version__)}
+    cases = [("a", 48, 196, 0, 3, 0.05), ("b", 40, 196, 12, 3, 0.05), ("c", 32, 196, 0, 2, 0.05), ("d", 64, 49, 5, 3, 0.1),
+             ("e", 24, 49, 24, 3, 0.05), ("f", 200, 196, 20, 3, 0.05)]      # e: the queue as created (all noise)
+    for name, rows, dim, rnd, modal, thr in cases:
+        q = gmm_queue(rng, rows, dim, rnd)
+        res = sh.rungmm(q.copy(), modal=modal, filter_thre=thr)
+        x = q.flatten()
+        x = x[x > thr].reshape(-1, 1)
+        init = [[x.min()], [np.median(x)], [x.max()]] if modal == 3 else [[x.min()], [x.max()]]
+        gm = skm.GaussianMixture(modal, weights_init=[1 / modal] * modal, means_init=init, precisions_init=[[[1.0]]] * modal).fit(x)
+        out[f"{name}_queue32"] = q[rnd:].astype(np.float32)          # exact: these rows hold float32 values
+        out[f"{name}_queue_rand"] = q[:rnd]
+        out[f"{name}_modal"], out[f"{name}_filter"] = np.array(modal), np.array(thr)
+        out[f"{name}_thresholds"] = np.atleast_1d(np.array(res, np.float64))
+        out[f"{name}_n_iter"] = np.array(gm.n_iter_)
+        out[f"{name}_means"] = gm.means_.ravel()
+        print("gmm", name, x.size, "samples", res, "iters", gm.n_iter_)
+    np.savez_compressed(os.path.join(OUT, "gmm.npz"), **out)
+
+
 def main():
     assert ref_loader.available(), "reference tree not present"
     os.makedirs(OUT, exist_ok=True)
@@ -322,6 +363,7 @@ def main():
     gen_misc(np.random.default_rng(15))
     gen_vit(np.random.default_rng(16))
     gen_eval(np.random.default_rng(17))
+    gen_gmm(np.random.default_rng(18))
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")
 

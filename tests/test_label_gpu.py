@@ -102,6 +102,34 @@ def test_cam2mask_full_size_vs_oracle(oracle_c, use_par):
     assert np.all(m[2][:, 100:] == 255) and set(np.unique(m[2][:, :100])) == {0.0}
 
 
+@pytest.mark.parametrize("use_par", [False, True])
+def test_cam2mask_multi_vs_oracle(oracle_c, use_par):
+    """two CAM sets of the same images with their own thresholds through ONE pass == the oracle's two separate calls,
+    bit for bit; label counts 1 / 3 / 6 / 0 classes so that every plane-count bracket of the PAR step runs (2..28 live planes)."""
+    from cosa_amd.models.PAR import PAR
+    from cosa_amd.utils import seg_helper
+    rng = np.random.default_rng(17)
+    B, C, S = 4, 20, 224
+    cams = [np.maximum(smooth(rng, B * C, S, S).reshape(B, C, S, S) * 1.3 - 0.15, 0).astype(np.float32) for _ in range(2)]
+    labels = np.zeros((B, C), np.float32)
+    labels[0, [3]] = 1
+    labels[1, [0, 7, 19]] = 1
+    labels[2, [1, 2, 5, 8, 13, 18]] = 1
+    boxes = np.array([[0, S, 0, S], [10, 200, 33, S], [0, S, 0, 100], [5, 220, 0, S]], np.int32)
+    images = smooth(rng, B * 3, S, S).reshape(B, 3, S, S)
+    par = PAR(num_iter=10, dilations=DIL) if use_par else None
+    thr_hi, thr_lo = [0.7, 0.55], [0.25, 0.35]
+    ms = seg_helper.cam2mask_multi(dev(images), torch.from_numpy(boxes), [dev(c) for c in cams], dev(labels), thr_hi, thr_lo,
+                                   refine_model=par, _fold_validation=True)
+    for g in range(2):
+        ref = oracle_c.cam2mask(images, boxes, cams[g], labels, thr_hi[g], thr_lo[g], 2, par=(DIL, 10) if use_par else None)
+        m = ms[g].cpu().numpy()
+        assert np.array_equal(m, ref), f"set {g}: {(m != ref).sum()} labels differ"
+        one = seg_helper.cam2mask(dev(images), torch.from_numpy(boxes), dev(cams[g]), dev(labels), thr_hi[g], thr_lo[g],
+                                  refine_model=par, _fold_validation=True)
+        assert torch.equal(one, ms[g])
+
+
 def test_cam2mask_properties_at_bench_size():
     """size-independent checks at b=16: outside-box = 255; values in {0, active classes, 255}; hi/lo merge rule."""
     from cosa_amd.utils import seg_helper

@@ -108,3 +108,29 @@ def test_misc_vs_reference(oracle_c, golden):
     ref = to.seg_refine_by_label(t(g["refine_seg"]), t(g["refine_labels"]), 0.01)
     np.testing.assert_allclose(ref.numpy(), g["refine_out"], rtol=1e-6, atol=1e-30)
     np.testing.assert_allclose(to.cam_loss(t(g["camloss_cam"]), ref).numpy(), g["camloss_out"], rtol=1e-6)
+
+
+def gmm_case(g, n):
+    q = np.concatenate([g[f"{n}_queue_rand"], g[f"{n}_queue32"].astype(np.float64)], 0)
+    return q, int(g[f"{n}_modal"]), float(g[f"{n}_filter"])
+
+
+@pytest.mark.parametrize("case", list("abcdef"))
+def test_gmm_thresholds_vs_reference(golden, case):
+    """utils/seg_helper.py:924-943 rungmm: the restated EM gives the reference's thresholds bit for bit, in as many iterations
+    as scikit-learn's estimator took, with the same means to rounding."""
+    from oracle import gmm_oracle
+    g = golden("gmm")
+    q, modal, thr = gmm_case(g, case)
+    res = np.atleast_1d(np.array(gmm_oracle.rungmm(q, modal, thr)))
+    assert np.array_equal(res, g[f"{case}_thresholds"])
+    x = q.flatten()
+    _, n_iter, (w, mu, pc) = gmm_oracle.fit(x[x > thr], modal)
+    assert n_iter == int(g[f"{case}_n_iter"])
+    np.testing.assert_allclose(mu, g[f"{case}_means"], rtol=1e-12)
+
+
+def test_gmm_empty_component_raises():
+    from oracle import gmm_oracle
+    with pytest.raises(ValueError):
+        gmm_oracle.rungmm(np.full((4, 8), 0.5), 3)                 # identical samples: everything lands in one component
