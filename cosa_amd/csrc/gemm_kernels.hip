@@ -1200,9 +1200,22 @@ typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
 __device__ __forceinline__ int tr_sw(int r) { return ((r & 3) << 2) | ((r >> 2) & 3); }
 
+// CONV = true: weight gradient of the 3x3 dilated convolution on NHWC tokens (LargeFOV, models/decoder/conv_head.py:11-41):
+//   dW9[n][t*Cin + c] += sum_m dY[m][n] * X[src(m, t)][c]        (t = ky*3 + kx, src = the token shifted by the tap, zero outside)
+// i.e. the same TN GEMM over an implicit im2col matrix: a k-tile lies inside one tap (Cin % 128 == 0), its X rows are the token rows
+// shifted by (dy*w + dx) and rows that leave the image (or M) get an offset past num_records, which the DMA turns into zeros.
+// The (image, y, x) position of each staged row is carried from stage to stage (+64 tokens) with adds and compares only.
+struct ConvGeom {
+    int h, w, dil, cin;          // image height / width in tokens, dilation, channels per tap
+    int img_rows, row_off, ldx;  // image b = rows [b*img_rows + row_off, +h*w) of a [*, ldx] matrix
+    int q64, r64;                // 64 = q64 * w + r64
+};
+
+template <bool CONV>
 __global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(const bf16 *__restrict__ dY, const bf16 *__restrict__ X,
                                                            float *__restrict__ dW, float *__restrict__ db, int M, int N, int K,
-                                                           int tiles_k, int stages_per_split, int nstages, int ntiles, int tiles_per_xcd)
+                                                           int tiles_k, int stages_per_split, int nstages, int ntiles, int tiles_per_xcd,
+                                                           ConvGeom cg, int x_bytes)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // 2 stages x (dY tile 16 KB + X tile 16 KB)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -1230,23 +1243,52 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(const bf16 *__restri
     if (st0 >= st1) return;
     const int wr = wave >> 1, wc = wave & 1;
     __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc((void *)dY, 0, (int)((size_t)M * N * 2), 0x00020000);
-    __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void *)X, 0, (int)((size_t)M * K * 2), 0x00020000);
+    __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void *)X, 0, CONV ? x_bytes : (int)((size_t)M * K * 2), 0x00020000);
     // per-lane source offsets of the 4 + 4 one-KiB pieces this wave stages per K-step (fixed for the whole kernel)
     int voY[4], voX[4];
+    // CONV: position of the staged row (image, y, x) per piece, and the tap of this k-tile
+    int pb[4], py[4], px[4], ddy = 0, ddx = 0, cbase = 0;
+    if (CONV) {
+        const int tap = k0 / cg.cin;
+        ddy = (tap / 3 - 1) * cg.dil;
+        ddx = (tap % 3 - 1) * cg.dil;
+        cbase = k0 - tap * cg.cin;
+    }
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const int q = wave * 4 + i;                  // piece: tile rows 4q .. 4q+3
         const int r = 4 * q + (lane >> 4), ch = (lane & 15) ^ tr_sw(r);
         voY[i] = (r * N + n0 + ch * 8) * 2;
-        voX[i] = (r * K + k0 + ch * 8) * 2;
+        if (CONV) {
+            const int tok = st0 * 64 + r, hw = cg.h * cg.w;
+            pb[i] = tok / hw;
+            const int rem = tok - pb[i] * hw;
+            py[i] = rem / cg.w;
+            px[i] = rem - py[i] * cg.w;
+            voX[i] = (cbase + ch * 8) * 2;           // column part; the row part is added per stage
+        } else {
+            voX[i] = (r * K + k0 + ch * 8) * 2;
+        }
     }
     auto stage = [&](int st, unsigned char *buf) {
-        const int soY = st * 64 * N * 2, soX = st * 64 * K * 2;
+        const int soY = st * 64 * N * 2, soX = CONV ? 0 : st * 64 * K * 2;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const int q = wave * 4 + i;
+            int vx = voX[i];
+            if (CONV) {
+                const int r = 4 * q + (lane >> 4);
+                const int sy = py[i] + ddy, sx = px[i] + ddx;
+                const bool in = st * 64 + r < M && sy >= 0 && sy < cg.h && sx >= 0 && sx < cg.w;
+                vx = in ? vx + ((pb[i] * cg.img_rows + cg.row_off + sy * cg.w + sx) * cg.ldx) * 2 : 0x7ffffff0;
+                // advance this piece by 64 tokens for the next stage
+                px[i] += cg.r64;
+                py[i] += cg.q64;
+                if (px[i] >= cg.w) { px[i] -= cg.w; py[i]++; }
+                while (py[i] >= cg.h) { py[i] -= cg.h; pb[i]++; }
+            }
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsY, (lds_void *)(buf + q * 1024), 16, voY[i], soY, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_void *)(buf + 16384 + q * 1024), 16, voX[i], soX, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_void *)(buf + 16384 + q * 1024), 16, vx, soX, 0, 0);
         }
     };
     f32x4 acc[4][4];
@@ -1256,7 +1298,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(const bf16 *__restri
         for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // bias gradient db[n] = sum_m dY[m][n]: the dY^T fragments already hold 8 tokens of one feature per lane, so the workgroups
     // of the first k-tile column (and their wc == 0 waves) add them up on the side (replaces a separate reduction kernel)
-    const bool do_bias = db != nullptr && tk == 0 && wc == 0;
+    const bool do_bias = !CONV && db != nullptr && tk == 0 && wc == 0;
     float bsum[4] = {0.f, 0.f, 0.f, 0.f};
 
     // fragment addressing: lane (nn = l&15, g = l>>4) supplies row 8g+4h+q (q = nn>>2), columns 4p..4p+3 (p = nn&3)
@@ -1715,7 +1757,7 @@ extern "C" int cosa_gemm_wgrad_bf16(const void *dY, const void *X, float *dW, fl
     hipStream_t st = as_stream(stream);
     static bool attr_done = false;
     if (!attr_done) {
-        COSA_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+        COSA_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_wgrad_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
         attr_done = true;
     }
     if (zero_first) {
@@ -1737,8 +1779,42 @@ extern "C" int cosa_gemm_wgrad_bf16(const void *dY, const void *X, float *dW, fl
     splits = (nstages + per - 1) / per;
     static const bool oldmap = getenv("COSA_WGRAD_OLDMAP") != nullptr;
     const int tiles_per_xcd = oldmap ? -((tiles + 7) / 8) : (tiles + 7) / 8;
-    hipLaunchKernelGGL(gemm_wgrad_kernel, dim3(8 * ((tiles + 7) / 8) * splits), dim3(256), 65536, st, static_cast<const bf16 *>(dY),
-                       static_cast<const bf16 *>(X), dW, db, M, N, K, K / 128, per, nstages, tiles, tiles_per_xcd);
+    hipLaunchKernelGGL(gemm_wgrad_kernel<false>, dim3(8 * ((tiles + 7) / 8) * splits), dim3(256), 65536, st, static_cast<const bf16 *>(dY),
+                       static_cast<const bf16 *>(X), dW, db, M, N, K, K / 128, per, nstages, tiles, tiles_per_xcd, ConvGeom{}, 0);
+    COSA_LAUNCH_CHECK();
+    return COSA_OK;
+}
+
+// weight gradient of cosa_conv3x3_dilated_nhwc:  dW9[Cout][9*Cin] (fp32, tap-major columns: t*Cin + c) = (zero_first ? 0 : dW9) +
+// dY[B*h*w, Cout]^T im2col(X); X is addressed exactly as in the forward call (strided token view, image b at row b*img_rows + row_off).
+extern "C" int cosa_conv3x3_dilated_wgrad(const void *dY, const void *X, float *dW9, int B, int h, int w, int Cin, int Cout, int dilation,
+                                          int img_rows, int row_off, int ldx, int zero_first, void *stream)
+{
+    COSA_REQUIRE(dY && X && dW9 && B > 0 && h > 0 && w > 0 && dilation > 0, "cosa_conv3x3_dilated_wgrad: bad arguments");
+    COSA_REQUIRE(Cin % 128 == 0 && Cout % 128 == 0, "cosa_conv3x3_dilated_wgrad: Cin and Cout must be multiples of 128 (got %d, %d)", Cin, Cout);
+    COSA_REQUIRE(img_rows >= h * w + row_off && ldx >= Cin, "cosa_conv3x3_dilated_wgrad: bad view geometry");
+    const long long x_bytes = (long long)B * img_rows * ldx * 2;
+    const int M = B * h * w, N = Cout, K = 9 * Cin;
+    COSA_REQUIRE(x_bytes < 0x7fffff00ll && (size_t)M * N * 2 < 0x7fffffffull, "cosa_conv3x3_dilated_wgrad: operand beyond 2 GiB");
+    hipStream_t st = as_stream(stream);
+    static bool attr_done = false;
+    if (!attr_done) {
+        COSA_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_wgrad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+        attr_done = true;
+    }
+    if (zero_first) COSA_HIP_CHECK(hipMemsetAsync(dW9, 0, (size_t)N * K * sizeof(float), st));
+    const int tiles = (N / 128) * (K / 128);
+    const int nstages = (M + 63) / 64;
+    int splits = 512 / tiles;                       // same rule as the Linear weight gradient: fill the 512 slots, never a partial round
+    if (splits * tiles < 288 && (splits + 1) * tiles <= 512) splits++;
+    if (splits < 1) splits = 1;
+    if (splits > nstages) splits = nstages;
+    const int per = (nstages + splits - 1) / splits;
+    splits = (nstages + per - 1) / per;
+    ConvGeom cg{h, w, dilation, Cin, img_rows, row_off, ldx, 64 / w, 64 % w};
+    hipLaunchKernelGGL(gemm_wgrad_kernel<true>, dim3(8 * ((tiles + 7) / 8) * splits), dim3(256), 65536, st, static_cast<const bf16 *>(dY),
+                       static_cast<const bf16 *>(X), dW9, static_cast<float *>(nullptr), M, N, K, K / 128, per, nstages, tiles,
+                       (tiles + 7) / 8, cg, (int)x_bytes);
     COSA_LAUNCH_CHECK();
     return COSA_OK;
 }

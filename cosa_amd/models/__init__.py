@@ -34,6 +34,17 @@ class LargeFOV(nn.Module):
         seg = F.linear(y, w8).float()
         return seg.view(B, h, w, -1).permute(0, 3, 1, 2).contiguous()
 
+    def forward_tokens_train(self, tok, B, h, w):
+        """bf16 training path (autograd): conv6 / conv7 forward, input- and weight-gradient on our MFMA kernels
+        (nn_ops.DilatedConvReluFn), conv8 (1x1) as a GEMM over the tokens.  tok [B, h*w, 768] bf16 -> seg [B, classes, h, w] fp32"""
+        if tok.stride(2) != 1 or (B > 1 and tok.stride(0) % tok.stride(1)):
+            tok = tok.contiguous()
+        y = nn_ops.DilatedConvReluFn.apply(tok, self.conv6.weight, B, h, w, self.dilation)
+        y = nn_ops.DilatedConvReluFn.apply(y.view(B, h * w, -1), self.conv7.weight, B, h, w, self.dilation)
+        w8 = nn_ops.cast_param(self.conv8.weight, torch.bfloat16).reshape(self.conv8.weight.shape[0], -1)
+        seg = F.linear(y, w8).float()
+        return seg.view(B, h, w, -1).permute(0, 3, 1, 2).contiguous()
+
     def forward_nhwc(self, x, dt):
         """x: [B,C,h,w] view with channels-last strides (tokens are NHWC already)."""
         c = nn_ops.cast_param
@@ -116,6 +127,9 @@ class VITNetwork(nn.Module):
         x4 = tok.reshape(B, h, w, -1).permute(0, 3, 1, 2)            # NCHW view, channels-last strides (no copy)
         if tok32 is not None and tok.dtype == torch.bfloat16 and self.decoder.conv6.weight.shape[1] % 64 == 0:
             seg = self.decoder.forward_tokens(tok, B, h, w)            # fused no-grad path: own implicit-GEMM convs
+        elif tok.dtype == torch.bfloat16 and tok.is_cuda and self.decoder.conv6.weight.shape[1] % 128 == 0 \
+                and torch.is_grad_enabled() and nn_ops.own_decoder_backward():
+            seg = self.decoder.forward_tokens_train(tok, B, h, w)      # training: forward + both gradients on own kernels
         else:
             seg = self.decoder.forward_nhwc(x4, dt).float().contiguous()
         if seg_only:

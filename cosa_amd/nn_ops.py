@@ -7,6 +7,8 @@ there is to do; everything fused or attention-shaped is hand-written HIP.
 import ctypes
 import math
 
+import os
+
 import torch
 import torch.nn.functional as F
 from torch.autograd import Function
@@ -150,6 +152,65 @@ def conv3x3_dilated_tokens(tok, w16, B, h, w, dilation, relu=True):
                                                     ldx, int(relu), _C.stream_ptr()), "cosa_conv3x3_dilated_nhwc")
     _flops["conv3x3"] = _flops.get("conv3x3", 0) + 2.0 * B * h * w * Cout * Cin * 9
     return y
+
+
+def own_decoder_backward():
+    """COSA_DECODER_MIOPEN=1 sends the student's LargeFOV convolutions back through F.conv2d (A/B switch)."""
+    return os.environ.get("COSA_DECODER_MIOPEN", "0") != "1"
+
+
+def _token_view_geometry(tok, B, h, w):
+    ldx = tok.stride(1)
+    img_rows = tok.stride(0) // ldx if B > 1 else h * w
+    assert tok.dtype == torch.bfloat16 and tok.stride(2) == 1 and tok.shape[1] == h * w
+    assert B == 1 or tok.stride(0) == img_rows * ldx
+    return ldx, img_rows
+
+
+def conv3x3_dilated_wgrad(dy, tok, B, h, w, dilation):
+    """weight gradient of conv3x3_dilated_tokens: dy [B*h*w, Cout] bf16 (contiguous), tok as in the forward call ->
+    dW [Cout, Cin, 3, 3] fp32 (a permuted view of the kernel's tap-major [Cout, 9*Cin] result).  Implicit im2col inside the TN MFMA
+    kernel: no MIOpen, no materialised patches."""
+    Cout, Cin = dy.shape[1], tok.shape[2]
+    ldx, img_rows = _token_view_geometry(tok, B, h, w)
+    assert dy.dtype == torch.bfloat16 and dy.is_contiguous() and dy.shape[0] == B * h * w
+    dw = _wgrad_alloc(Cout * 9 * Cin, dy.device)
+    zero_first = 0
+    if dw is None:
+        dw = torch.empty(Cout * 9 * Cin, device=dy.device, dtype=torch.float32)
+        zero_first = 1
+    with _C.profiled("conv3x3_wgrad"):
+        _C.check(_C.lib().cosa_conv3x3_dilated_wgrad(_C.ptr(dy), _C.ptr(tok), _C.ptr(dw), B, h, w, Cin, Cout, int(dilation), img_rows, 0,
+                                                     ldx, zero_first, _C.stream_ptr()), "cosa_conv3x3_dilated_wgrad")
+    _flops["conv3x3_wgrad"] = _flops.get("conv3x3_wgrad", 0) + 2.0 * B * h * w * Cout * Cin * 9
+    return dw.view(Cout, 3, 3, Cin).permute(0, 3, 1, 2)
+
+
+class DilatedConvReluFn(torch.autograd.Function):
+    """relu(conv3x3(x, W, dilation=d, padding=d, bias=None)) on NHWC tokens, forward and backward on our MFMA kernels:
+    forward = implicit-GEMM conv (+ReLU in the epilogue); dX = the same kernel on the gated output gradient with the taps
+    flipped and (in, out) swapped; dW = the TN weight-gradient kernel over an implicit im2col (conv3x3_dilated_wgrad)."""
+
+    @staticmethod
+    def forward(ctx, tok, weight, B, h, w, dilation):
+        w16 = cast_param(weight, torch.bfloat16)
+        y = conv3x3_dilated_tokens(tok, w16, B, h, w, dilation, relu=True)
+        ctx.save_for_backward(tok, w16, y)
+        ctx.geom = (B, h, w, dilation)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        tok, w16, y = ctx.saved_tensors
+        B, h, w, dilation = ctx.geom
+        dz = torch.where(y > 0, dy.to(torch.bfloat16), torch.zeros((), device=dy.device, dtype=torch.bfloat16)).contiguous()
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            wd = w16.flip(2, 3).permute(1, 0, 2, 3)                         # [Cin, Cout, 3, 3]: taps mirrored, roles swapped
+            dx = conv3x3_dilated_tokens(dz.view(B, h * w, -1), wd, B, h, w, dilation, relu=False).view(B, h * w, -1)
+        if ctx.needs_input_grad[1]:
+            dw = conv3x3_dilated_wgrad(dz, tok, B, h, w, dilation)
+        return dx, dw, None, None, None, None
 
 
 def layernorm_f32(x, g, b, eps, want_bf16=True, want_f32=False):

@@ -189,6 +189,11 @@ int cosa_gemm_wgrad_bf16(const void *dY, const void *X, float *dW, float *db, in
  *   Wt [9][Cout][Cin] bf16 (tap-major: t = ky*3 + kx);  Y [B*h*w, Cout] bf16;  padding = dilation                               */
 int cosa_conv3x3_dilated_nhwc(const void *X, const void *Wt, void *Y, int B, int h, int w, int Cin, int Cout, int dilation,
                               int img_rows, int row_off, int ldx, int relu, void *stream);
+/* its weight gradient (autograd of the same conv): dW9 [Cout][9*Cin] fp32, tap-major columns (t*Cin + c), = (zero_first ? 0 : dW9) +
+ * dY[B*h*w, Cout]^T im2col(X), the im2col implicit in the operand addressing; X is addressed as in the forward call.
+ * (The input gradient is the forward entry point itself on dY with Wt'[t][c][o] = Wt[8-t][o][c].)                              */
+int cosa_conv3x3_dilated_wgrad(const void *dY, const void *X, float *dW9, int B, int h, int w, int Cin, int Cout, int dilation,
+                               int img_rows, int row_off, int ldx, int zero_first, void *stream);
 void cosa_gemm_set_variant(int v);   /* 0 (default): per-shape choice; 1: 128x128 2-stage; 2: 256x128 3-stage; 3: 256x256 8-wave;
                                       * 5: 256x256 4-phase ping-pong; 6: the same, persistent with the epilogue in the MFMA shadow      */
 /* measurement hook: the NEXT cosa_gemm_bf16 launch (persistent 256x256 kernel only) writes its device-clock span

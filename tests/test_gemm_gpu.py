@@ -116,3 +116,31 @@ def test_gemm_pipelined_kernels_are_run_to_run_deterministic(variant):
                 assert torch.equal(again, first)
     finally:
         _C.lib().cosa_gemm_set_variant(0)
+
+
+@pytest.mark.parametrize("B,h,w,Cin,Cout,strided", [(3, 14, 14, 768, 512, True), (2, 28, 28, 512, 512, False), (1, 9, 13, 128, 128, False),
+                                                    (5, 5, 7, 256, 128, True)])
+def test_dilated_conv_autograd_vs_torch(B, h, w, Cin, Cout, strided):
+    """LargeFOV conv (3x3, dilation 5, no bias, ReLU) forward + input gradient + weight gradient on the MFMA kernels (implicit GEMM /
+    implicit im2col) against torch's conv2d autograd in fp32 on the same bf16-rounded operands; ragged token counts (M % 64 != 0),
+    images smaller than the dilation reach, and the strided token view (encoder tokens without their cls row)."""
+    from cosa_amd import nn_ops
+    g = torch.Generator().manual_seed(B * 100 + h)
+    full = (torch.randn(B, h * w + 1, Cin, generator=g) * 0.5).to(torch.bfloat16).cuda()
+    tok = (full[:, 1:] if strided else full[:, 1:].contiguous()).detach().requires_grad_(True)
+    weight = (torch.randn(Cout, Cin, 3, 3, generator=g) * 0.02).cuda().requires_grad_(True)
+    gy = torch.randn(B * h * w, Cout, generator=g).to(torch.bfloat16).cuda()
+    y = nn_ops.DilatedConvReluFn.apply(tok, weight, B, h, w, 5)
+    y.backward(gy)
+    # reference: fp32 conv on the bf16-rounded operands
+    x32 = tok.detach().float().reshape(B, h, w, Cin).permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    w32 = weight.detach().to(torch.bfloat16).float().requires_grad_(True)
+    yr = torch.relu(torch.nn.functional.conv2d(x32, w32, padding=5, dilation=5))
+    yr.backward(gy.float().reshape(B, h, w, Cout).permute(0, 3, 1, 2))
+    yref = yr.detach().permute(0, 2, 3, 1).reshape(B * h * w, Cout)
+    assert (y.float() - yref).abs().max() <= 2e-2 * yref.abs().max()
+    # the gate uses our bf16 forward's sign; compare gradients where both forwards agree on it (all but measure-zero ties)
+    dxr = x32.grad.permute(0, 2, 3, 1).reshape(B, h * w, Cin)
+    assert (tok.grad.float() - dxr).abs().max() <= 3e-2 * dxr.abs().max()
+    assert (weight.grad - w32.grad).abs().max() <= 3e-2 * w32.grad.abs().max()
+    assert weight.grad.dtype == torch.float32 and weight.grad.shape == weight.shape
