@@ -350,6 +350,54 @@ def gen_gmm(rng):
     np.savez_compressed(os.path.join(OUT, "gmm.npz"), **out)
 
 
+def gen_augment(rng):
+    """training input pipeline: the reference's own transforms.py / randaug.py functions, called in the order of
+    dataloaders/voc.py:262-275, under fixed seeds of Python's `random` and numpy's global generator.  Stored: the source image,
+    the seeds, and the three uint8 stages (crop, weak = after blur, strong) + img_box.  Seeds are scanned until all nine strong
+    ops, blur on/off, flips and up/down-scaling are covered."""
+    import random
+    from PIL import Image
+    tr, ra = ref_loader.dataloader_modules()
+    crop = 64
+    blur = tr.GaussianBlur(p=0.5)
+    strong = ra.OneOf(transforms=[ra.Identity(), ra.AutoContrast(), ra.RandEqualize(), ra.RandSolarize(), ra.RandColor(),
+                                  ra.RandContrast(), ra.RandBrightness(), ra.RandSharpness(), ra.RandPosterize()])
+    names = ["Identity", "AutoContrast", "RandEqualize", "RandSolarize", "RandColor", "RandContrast", "RandBrightness",
+             "RandSharpness", "RandPosterize"]
+    out = {"crop_size": np.array(crop)}
+    seen, n = set(), 0
+    for seed in range(400):
+        h, w = int(rng.integers(40, 110)), int(rng.integers(40, 110))
+        base = synth_image255(rng, 1, h, w, noise=3.0)[0].transpose(1, 2, 0)
+        image = np.clip(base, 0, 255).astype(np.uint8)
+        random.seed(seed)
+        np.random.seed(seed)
+        img = tr.random_scaling(image, scale_range=[0.5, 2.0])
+        img = tr.random_fliplr(img)
+        cimg, box = tr.random_crop(img, crop_size=crop, mean_rgb=[0, 0, 0], ignore_index=255)
+        pil = blur(Image.fromarray(cimg))
+        # which op was chosen: replay the choice on a saved copy of the generator state
+        state = np.random.get_state()
+        chosen = np.random.choice(strong.transforms)
+        np.random.set_state(state)
+        spil = strong(pil)
+        op = names.index(type(chosen).__name__)
+        key = (op, np.asarray(pil).tobytes() != cimg.tobytes())
+        if key in seen:
+            continue
+        seen.add(key)
+        out[f"{n}_image"], out[f"{n}_seed"] = image, np.array(seed)
+        out[f"{n}_crop"], out[f"{n}_weak"], out[f"{n}_strong"], out[f"{n}_box"] = cimg, np.asarray(pil), np.asarray(spil), box
+        out[f"{n}_solarize_restated"] = np.array(op == 3)          # this case went through the restatement of mmcv.solarize
+        out[f"{n}_op"] = np.array(op)
+        n += 1
+        if len(seen) == 18:
+            break
+    out["n"] = np.array(n)
+    print("augment:", n, "cases", sorted(seen))
+    np.savez_compressed(os.path.join(OUT, "augment.npz"), **out)
+
+
 def main():
     assert ref_loader.available(), "reference tree not present"
     os.makedirs(OUT, exist_ok=True)
@@ -364,6 +412,7 @@ def main():
     gen_vit(np.random.default_rng(16))
     gen_eval(np.random.default_rng(17))
     gen_gmm(np.random.default_rng(18))
+    gen_augment(np.random.default_rng(19))
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")
 

@@ -104,3 +104,15 @@ def evaluation_module():
     if "eval" not in _cache:
         _cache["eval"] = _load("_cosa_ref_evaluation", "utils/evaluation.py")
     return _cache["eval"]
+
+
+def dataloader_modules():
+    """(transforms, randaug) of the reference's dataloaders/.  mmcv is absent from this image: transforms.py uses it only in
+    PhotoMetricDistortion (never called here); randaug.py calls mmcv.solarize in ONE op, RandSolarize -- that single function is
+    supplied by the oracle's restatement of mmcv's published one-liner, and the golden cases that went through it are marked."""
+    if "dl" not in _cache:
+        from . import aug_oracle
+        import numpy as np
+        _stub("mmcv", solarize=lambda img, thr=128: np.where(img < thr, img, 255 - img).astype(img.dtype))
+        _cache["dl"] = (_load("_cosa_ref_transforms", "dataloaders/transforms.py"), _load("_cosa_ref_randaug", "dataloaders/randaug.py"))
+    return _cache["dl"]

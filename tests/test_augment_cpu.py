@@ -1,0 +1,74 @@
+"""CPU suite: the input-pipeline oracle (oracle/aug_oracle.py, SURVEY f-2) against the reference's own transforms (golden
+vectors) and against Pillow, the library whose arithmetic it restates."""
+import random
+
+import numpy as np
+import pytest
+
+
+def test_pipeline_vs_reference_golden(golden):
+    """same seeds -> same draws (scale, flip, pads, crop window, blur, op, magnitude), and the three uint8 stages + img_box of the
+    reference's transforms.py / randaug.py functions bit for bit; all nine strong ops x blur on/off are in the vectors"""
+    from oracle import aug_oracle
+    g = golden("augment")
+    crop = int(g["crop_size"])
+    seen = set()
+    for i in range(int(g["n"])):
+        img, seed = g[f"{i}_image"], int(g[f"{i}_seed"])
+        random.seed(seed)
+        np.random.seed(seed)
+        p = aug_oracle.draw_params(img.shape[0], img.shape[1], crop_size=crop)
+        c, wk, st = aug_oracle.apply(img, p, crop)
+        assert p["op"] == int(g[f"{i}_op"]) and np.array_equal(p["img_box"], g[f"{i}_box"])
+        assert np.array_equal(c, g[f"{i}_crop"]) and np.array_equal(wk, g[f"{i}_weak"]) and np.array_equal(st, g[f"{i}_strong"])
+        seen.add((p["op"], p["blur"]))
+    assert {o for o, _ in seen} == set(range(9)) and {b for _, b in seen} == {True, False}
+
+
+def test_resize_and_blur_vs_pillow():
+    from PIL import Image, ImageFilter
+    from oracle import aug_oracle
+    rng = np.random.default_rng(0)
+    for _ in range(6):
+        h, w = int(rng.integers(20, 90)), int(rng.integers(20, 90))
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        s = rng.uniform(0.5, 2.0)
+        W, H = int(s * w), int(s * h)
+        ref = np.asarray(Image.fromarray(img).resize((W, H), resample=Image.BILINEAR))
+        assert np.array_equal(aug_oracle.resize_bilinear(img, W, H), ref)
+        r = float(rng.uniform(0.1, 2.0))
+        ref = np.asarray(Image.fromarray(img).filter(ImageFilter.GaussianBlur(radius=r)))
+        assert np.array_equal(aug_oracle.gaussian_blur(img, r), ref)
+    img = rng.integers(0, 256, (500, 375, 3), dtype=np.uint8)          # VOC-sized, both directions of scaling
+    for W, H in ((187, 250), (750, 1000), (375, 333)):
+        assert np.array_equal(aug_oracle.resize_bilinear(img, W, H), np.asarray(Image.fromarray(img).resize((W, H), resample=Image.BILINEAR)))
+
+
+@pytest.mark.parametrize("magnitude", [1, 5, 9])
+def test_strong_ops_vs_pillow(magnitude):
+    from PIL import Image, ImageEnhance, ImageOps
+    from oracle import aug_oracle
+    rng = np.random.default_rng(magnitude)
+    small = rng.integers(0, 256, (14, 17, 3), dtype=np.uint8)
+    for img in (rng.integers(30, 220, (61, 47, 3), dtype=np.uint8), np.asarray(Image.fromarray(small).resize((68, 56), Image.BICUBIC)),
+                np.full((9, 9, 3), 77, np.uint8)):
+        pil = Image.fromarray(img)
+        v = aug_oracle.enhance_factor(magnitude)
+        refs = {1: ImageOps.autocontrast(pil), 2: ImageOps.equalize(pil), 4: ImageEnhance.Color(pil).enhance(v),
+                5: ImageEnhance.Contrast(pil).enhance(v), 6: ImageEnhance.Brightness(pil).enhance(v),
+                7: ImageEnhance.Sharpness(pil).enhance(v), 8: ImageOps.posterize(pil, 4 - int(magnitude * 4 / 10))}
+        for op, ref in refs.items():
+            assert np.array_equal(aug_oracle.strong_op(img, op, magnitude), np.asarray(ref)), aug_oracle.OPS[op]
+        assert np.array_equal(aug_oracle.strong_op(img, 0, magnitude), img)
+        thr = min(int(magnitude * 256 / 10), 255)
+        assert np.array_equal(aug_oracle.strong_op(img, 3, magnitude), np.asarray(ImageOps.solarize(pil, thr)))   # same rule as mmcv's
+
+
+def test_normalize_is_totensor_normalize():
+    import torch
+    from oracle import aug_oracle
+    u8 = np.random.default_rng(3).integers(0, 256, (20, 30, 3), dtype=np.uint8)
+    t = torch.from_numpy(u8).permute(2, 0, 1).to(torch.float32).div(255)                    # torchvision ToTensor
+    mean, std = torch.tensor([0.485, 0.456, 0.406]).view(3, 1, 1), torch.tensor([0.229, 0.224, 0.225]).view(3, 1, 1)
+    ref = t.sub(mean).div(std)                                                              # torchvision Normalize
+    assert np.array_equal(aug_oracle.normalize(u8), ref.numpy())
