@@ -33,6 +33,10 @@ _SIGS = {
     "cosa_cam2mask_multi": (c_int, [c_void_p, c_void_p, ctypes.POINTER(c_void_p), c_void_p, ctypes.POINTER(c_void_p),
                                     ctypes.POINTER(c_float), ctypes.POINTER(c_float), c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                     ctypes.POINTER(c_int), c_int, c_int, c_float, c_void_p, c_size_t, c_void_p]),
+    "cosa_augment_record_bytes": (c_int, []),
+    "cosa_augment_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "cosa_augment_batch": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, c_size_t, c_void_p]),
     "cosa_gmm_workspace_bytes": (c_size_t, []),
     "cosa_gmm_fit_thresholds": (c_int, [c_void_p, c_void_p, ctypes.c_longlong, c_int, ctypes.c_double, ctypes.c_double, c_int,
                                         c_void_p, c_void_p, c_size_t, c_void_p]),

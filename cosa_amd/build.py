@@ -30,6 +30,7 @@ SOURCES = {
     "permuto_kernels.hip": EXACT,
     "eval_kernels.hip": EXACT,
     "gmm_kernels.hip": EXACT,
+    "aug_kernels.hip": EXACT,
     "vit_kernels.hip": FAST,
     "gemm_kernels.hip": FAST,
     "attn_kernels.hip": FAST + ["-fno-honor-nans"],    # drops the canonicalising v_max the compiler puts in front of fmaxf

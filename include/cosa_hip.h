@@ -87,6 +87,21 @@ int cosa_cam2mask_multi(const float *images, const int32_t *boxes, const float *
                         float ignore_index, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------
+ * dataloaders/voc.py:262-275 `__transforms` (transforms.py:10-28,52-77,104-120,150-202; randaug.py:58-130) for a batch:
+ * random_scaling -> random_fliplr -> random_crop -> GaussianBlur -> weak / OneOf(9 ops) strong -> ToTensor + Normalize,
+ * with the random draws made by the caller (cosa_amd/dataloaders/augment.py: draw_params) and shipped as records.
+ *   raw      device uint8: the decoded images, HWC, packed (record.raw_off = byte offset)
+ *   records  device, B records of cosa_augment_record_bytes() bytes (26 int32, layout in csrc/aug_kernels.hip: AugImage)
+ *   wimg, simg   device float32 [B,3,S,S] out;   crop_u8 / weak_u8 / strong_u8: optional device uint8 [B,S,S,3] stages
+ * Bit-exact with Pillow's integer / fixed-point arithmetic (resize BILINEAR, GaussianBlur, ImageOps, ImageEnhance).
+ * ------------------------------------------------------------------------------------- */
+int cosa_augment_record_bytes(void);
+size_t cosa_augment_workspace_bytes(int B, int S, int max_rows);
+int cosa_augment_batch(const uint8_t *raw, const void *records, int B, int S, int max_rows, float *wimg, float *simg,
+                       uint8_t *crop_u8, uint8_t *weak_u8, uint8_t *strong_u8, void *workspace, size_t workspace_bytes,
+                       void *stream);
+
+/* ---------------------------------------------------------------------------------------
  * utils/seg_helper.py:924-943  rungmm -- the adaptive-threshold fit of main.py:138-151,174-184:
  * scikit-learn GaussianMixture(modal, weights 1/modal, means (min, median, max) | (min, max), precisions 1,
  * tol, reg_covar, max_iter).fit_predict on the queue samples above the filter threshold, then
