@@ -38,3 +38,28 @@ def oracle_c():
     from oracle import c_oracle
     c_oracle.build()
     return c_oracle
+
+
+@pytest.fixture(scope="session")
+def make_voc_tree():
+    def _make(tmp_path, n=5):
+        """a tiny VOC-shaped tree: JPEGImages/*.jpg, <lists>/train_aug.txt, <lists>/cls_labels_onehot.npy"""
+        from PIL import Image
+        rng = np.random.default_rng(0)
+        root, lists = tmp_path / "VOC2012", tmp_path / "lists"
+        (root / "JPEGImages").mkdir(parents=True)
+        lists.mkdir()
+        names, labels = [], {}
+        for i in range(n):
+            name = f"2007_{i:06d}"
+            h, w = int(rng.integers(60, 120)), int(rng.integers(60, 120))
+            small = rng.integers(0, 256, (h // 8 + 2, w // 8 + 2, 3), dtype=np.uint8)
+            Image.fromarray(small).resize((w, h), Image.BICUBIC).save(root / "JPEGImages" / (name + ".jpg"), quality=92)
+            names.append(name)
+            lab = np.zeros(20, np.uint8)
+            lab[rng.choice(20, size=int(rng.integers(1, 3)), replace=False)] = 1
+            labels[name] = lab
+        np.savetxt(lists / "train_aug.txt", np.array(names), fmt="%s")
+        np.save(lists / "cls_labels_onehot.npy", labels, allow_pickle=True)
+        return str(root), str(lists), names, labels
+    return _make

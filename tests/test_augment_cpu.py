@@ -72,3 +72,23 @@ def test_normalize_is_totensor_normalize():
     mean, std = torch.tensor([0.485, 0.456, 0.406]).view(3, 1, 1), torch.tensor([0.229, 0.224, 0.225]).view(3, 1, 1)
     ref = t.sub(mean).div(std)                                                              # torchvision Normalize
     assert np.array_equal(aug_oracle.normalize(u8), ref.numpy())
+
+
+def test_train_dataset_contract(tmp_path, make_voc_tree):
+    """dataloaders/voc.py:219-305 minus the pixels: name, decoded image, the draws (seed-reproducible, reference order), label"""
+    from PIL import Image
+    from oracle import aug_oracle
+    from cosa_amd.dataloaders import VOC12ClsDatasetNew
+    root, lists, names, labels = make_voc_tree(tmp_path)
+    ds = VOC12ClsDatasetNew(root_dir=root, name_list_dir=lists, crop_size=64, rescale_range=[0.5, 2.0])
+    assert len(ds) == len(names)
+    random.seed(5)
+    np.random.seed(5)
+    name, image, params, label = ds[2]
+    assert name == names[2] and np.array_equal(label, labels[names[2]])
+    assert np.array_equal(image, np.asarray(Image.open(f"{root}/JPEGImages/{name}.jpg").convert("RGB")))
+    random.seed(5)
+    np.random.seed(5)
+    ref = aug_oracle.draw_params(image.shape[0], image.shape[1], crop_size=64)
+    assert all(params[k] == ref[k] for k in ("new_w", "new_h", "flip", "H_pad", "W_pad", "H_start", "W_start", "blur", "radius", "op",
+                                             "magnitude")) and np.array_equal(params["img_box"], ref["img_box"])

@@ -99,3 +99,26 @@ def test_augmenter_rejects_bad_input():
         aug([np.zeros((40, 50, 3), np.float32)], [p])
     with pytest.raises(ValueError):
         aug([], [])
+
+
+def test_train_loader_end_to_end(tmp_path, make_voc_tree):
+    """JPEG files -> DeviceTrainLoader -> the reference's batch tuple; pixels equal the CPU oracle applied to the same decode + draws"""
+    from oracle import aug_oracle
+    from cosa_amd.dataloaders import DeviceTrainLoader, VOC12ClsDatasetNew
+    root, lists, names, labels = make_voc_tree(tmp_path, n=6)
+    ds = VOC12ClsDatasetNew(root_dir=root, name_list_dir=lists, crop_size=64)
+    loader = DeviceTrainLoader(ds, batch_size=4, num_workers=0)
+    assert len(loader) == 1
+    random.seed(9)
+    np.random.seed(9)
+    (img_name, wimg, simg, cls_label, img_box), = list(loader)
+    assert img_name == names[:4] and wimg.shape == simg.shape == (4, 3, 64, 64) and wimg.is_cuda
+    assert cls_label.shape == (4, 20) and img_box.shape == (4, 4) and img_box.dtype == torch.int16
+    random.seed(9)
+    np.random.seed(9)
+    for i in range(4):
+        _, image, params, label = ds[i]
+        _, wk, st = aug_oracle.apply(image, params, 64)
+        assert np.array_equal(wimg[i].cpu().numpy(), aug_oracle.normalize(wk))
+        assert np.array_equal(simg[i].cpu().numpy(), aug_oracle.normalize(st))
+        assert np.array_equal(img_box[i].numpy(), params["img_box"]) and np.array_equal(cls_label[i].numpy(), label)
