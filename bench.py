@@ -161,6 +161,40 @@ def par_refine_ms_per_img(trainer, simg, lab, box, dev, opt, C):
                          "note": "one pass = 4 PAR calls per image (main/aux CAMs x hi/lo thresholds), affinities shared"}}
 
 
+def input_pipeline_images_per_s(dev, batch, crop):
+    """SURVEY f-2: the training input pipeline (scale / flip / crop / blur / one-of-9 strong ops / normalise, Pillow-exact) on the
+    device, from decoded VOC-sized uint8 images to (wimg, simg, img_box); wall clock including host packing and the H2D copy.
+    CPU figure beside it: the same pipeline through the oracle's restatement on 1 core, bounded sample (4 images)."""
+    import random
+    import numpy as np
+    from cosa_amd.dataloaders import DeviceAugmenter, draw_params
+    from oracle import aug_oracle
+    rng = np.random.default_rng(0)
+    images = []
+    for i in range(batch):
+        h, w = [(375, 500), (500, 375), (333, 500), (500, 500)][i % 4]
+        small = rng.integers(0, 256, (h // 8 + 2, w // 8 + 2, 3), dtype=np.uint8)
+        images.append(aug_oracle.resize_bilinear(small, w, h))
+    random.seed(0)
+    np.random.seed(0)
+    params = [draw_params(im.shape[0], im.shape[1], crop_size=crop) for im in images]
+    aug = DeviceAugmenter(crop, dev)
+    for _ in range(3):
+        aug(images, params)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        aug(images, params)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 20
+    t0 = time.perf_counter()
+    for im, p in list(zip(images, params))[:4]:
+        aug_oracle.apply(im, p, crop)
+    cpu = (time.perf_counter() - t0) / 4
+    return {"images_per_s": round(batch / dt, 1), "ms_per_batch": round(dt * 1e3, 3), "batch": batch,
+            "cpu_port_images_per_s_1core": round(1.0 / cpu, 2), "sample": "decoded 375x500-class uint8 images, all draws as the reference"}
+
+
 def eval_images_per_s(trainer, dev, C, crop, n=20):
     """SURVEY f-1: the validation pass (batch 1, five scales x two flips, label maps + confusion matrices on the device) on synthetic
     VOC-val-shaped images with the teacher network; bounded sample."""
@@ -291,6 +325,7 @@ def main():
         out["par_refine"] = par_refine_ms_per_img(trainer, simg, lab, box, dev, opt, C)
         if world == 1 and opt.crop == 448:
             out["evaluation"] = eval_images_per_s(trainer, dev, C, opt.crop)
+            out["input_pipeline"] = input_pipeline_images_per_s(dev, opt.batch, opt.crop)
         if world == 1 and not opt.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(opt, trainer.student.state_dict(), C)
         print(json.dumps(out), flush=True)
