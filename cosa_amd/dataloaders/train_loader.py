@@ -111,3 +111,73 @@ def build_train_loader(args, device="cuda", num_workers=4):
     dataset = build_train_datasetv2(args)
     sampler = torch.utils.data.distributed.DistributedSampler(dataset, shuffle=True) if torch.distributed.is_initialized() else None
     return DeviceTrainLoader(dataset, args.batch_size, device=device, sampler=sampler, num_workers=num_workers, shuffle=True)
+
+
+# ---- validation / test datasets (dataloaders/voc.py:306-368, coco.py:142-200; the aug=False path the reference uses) -------------
+def normalize_img(img, mean=(123.675, 116.28, 103.53), std=(58.395, 57.12, 57.375)):
+    """dataloaders/transforms.py:42-50: (uint8 - mean) / std evaluated in float64, stored as float32, HWC"""
+    return ((np.asarray(img).astype(np.float64) - np.asarray(mean)) / np.asarray(std)).astype(np.float32)
+
+
+class _SegDataset(Dataset):
+    def __init__(self, img_dir, label_dir, name_list_dir, split, stage):
+        super().__init__()
+        self.img_dir, self.label_dir, self.stage, self.split = img_dir, label_dir, stage, split
+        self.name_list = load_img_name_list(os.path.join(name_list_dir, split + '.txt'))
+        self.label_list = load_cls_label_list(name_list_dir=name_list_dir)
+
+    def __len__(self):
+        return len(self.name_list)
+
+    def __getitem__(self, idx):
+        img_name = str(self.name_list[idx])
+        image = np.asarray(Image.open(os.path.join(self.img_dir, img_name + '.jpg')).convert('RGB'))
+        if self.stage == "test":
+            label, cls_label = image[:, :, 0], 0
+        else:
+            label = np.asarray(Image.open(os.path.join(self.label_dir, img_name + '.png')))      # class indices (L or P mode)
+            cls_label = self.label_list[img_name]
+        return img_name, np.transpose(normalize_img(image), (2, 0, 1)), label, cls_label
+
+
+class VOC12SegDataset(_SegDataset):
+    """dataloaders/voc.py:306-368 with aug=False (how build_val_dataset / build_test_dataset construct it)"""
+
+    def __init__(self, root_dir=None, name_list_dir=None, split='train', stage='train', aug=False, ignore_index=255, **kwargs):
+        if aug:
+            raise NotImplementedError("VOC12SegDataset: the augmented variant is not part of the reference's training or evaluation runs")
+        super().__init__(os.path.join(root_dir, 'JPEGImages_test' if split == 'test' else 'JPEGImages'),
+                         os.path.join(root_dir, 'SegmentationClassAug'), name_list_dir, split, stage)
+
+
+class COCOSegDataset(_SegDataset):
+    """dataloaders/coco.py (COCOSegDataset) with aug=False"""
+
+    def __init__(self, root_dir=None, name_list_dir=None, split='train', stage='train', aug=False, ignore_index=255, **kwargs):
+        if aug:
+            raise NotImplementedError("COCOSegDataset: the augmented variant is not part of the reference's training or evaluation runs")
+        splitclean = 'val' if split[:3] == 'val' else split
+        super().__init__(os.path.join(root_dir, splitclean + '2014'), os.path.join(root_dir, f'SegmentationClass/{splitclean}2014'),
+                         name_list_dir, split, stage)
+
+
+def build_val_dataset(args):
+    """dataloaders/__init__.py:10-33"""
+    name_dir = getattr(args, "name_list_dir", None)
+    if args.dataset == 'VOC12':
+        return VOC12SegDataset(root_dir=args.voc12_root, name_list_dir=name_dir or './dataloaders/voc/', split='val', stage='val', aug=False,
+                               ignore_index=args.ignore_index, num_classes=args.num_classes)
+    if args.dataset == 'COCO':
+        return COCOSegDataset(root_dir=args.coco_root, name_list_dir=name_dir or './dataloaders/coco/',
+                              split='val_part' if not getattr(args, "valfull", False) else 'val', stage='val', aug=False,
+                              ignore_index=args.ignore_index, num_classes=args.num_classes)
+    raise NotImplementedError
+
+
+def build_val_loader(args, num_workers=1):
+    """the validation half of dataloaders/__init__.py:104-113: batch 1, DistributedSampler(shuffle=False, drop_last=True)"""
+    dataset = build_val_dataset(args)
+    sampler = torch.utils.data.distributed.DistributedSampler(dataset, shuffle=False, drop_last=True) \
+        if torch.distributed.is_initialized() else None
+    return DataLoader(dataset=dataset, batch_size=1, shuffle=False, num_workers=num_workers, pin_memory=False, sampler=sampler,
+                      drop_last=False)

@@ -92,3 +92,30 @@ def test_train_dataset_contract(tmp_path, make_voc_tree):
     ref = aug_oracle.draw_params(image.shape[0], image.shape[1], crop_size=64)
     assert all(params[k] == ref[k] for k in ("new_w", "new_h", "flip", "H_pad", "W_pad", "H_start", "W_start", "blur", "radius", "op",
                                              "magnitude")) and np.array_equal(params["img_box"], ref["img_box"])
+
+
+def test_val_dataset_contract(tmp_path, make_voc_tree):
+    """dataloaders/voc.py:306-368 (aug=False): (name, normalised CHW float32 image, label map, cls_label); normalize_img is the
+    reference's float64 expression stored as float32"""
+    from types import SimpleNamespace
+    from PIL import Image
+    from cosa_amd.dataloaders import VOC12SegDataset, build_val_loader, normalize_img
+    root, lists, names, labels = make_voc_tree(tmp_path)
+    import os
+    import shutil
+    os.makedirs(f"{root}/SegmentationClassAug")
+    for n in names:
+        im = np.asarray(Image.open(f"{root}/JPEGImages/{n}.jpg"))
+        Image.fromarray((im[..., 0] // 13).astype(np.uint8)).save(f"{root}/SegmentationClassAug/{n}.png")
+    shutil.copy(f"{lists}/train_aug.txt", f"{lists}/val.txt")
+    ds = VOC12SegDataset(root_dir=root, name_list_dir=lists, split="val", stage="val", aug=False)
+    name, image, label, cls = ds[1]
+    raw = np.asarray(Image.open(f"{root}/JPEGImages/{name}.jpg").convert("RGB"))
+    ref = np.empty_like(raw, np.float32)
+    for c, (m, sd) in enumerate(zip([123.675, 116.28, 103.53], [58.395, 57.12, 57.375])):
+        ref[..., c] = (raw[..., c] - m) / sd
+    assert image.dtype == np.float32 and np.array_equal(image, ref.transpose(2, 0, 1)) and label.shape == raw.shape[:2]
+    assert np.array_equal(cls, labels[name]) and np.array_equal(normalize_img(raw), ref)
+    args = SimpleNamespace(dataset="VOC12", voc12_root=root, name_list_dir=lists, ignore_index=255, num_classes=21)
+    batch = next(iter(build_val_loader(args, num_workers=0)))
+    assert list(batch[0]) == [names[0]] and batch[1].shape[:2] == (1, 3) and batch[3].shape == (1, 20)
