@@ -49,6 +49,9 @@ _SIGS = {
     "cosa_bilateral_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "cosa_bilateralfilter_batch_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_float,
                                                c_void_p, c_void_p, c_size_t, c_void_p]),
+    "cosa_dense_energy_prepare": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p, c_size_t, c_void_p]),
+    "cosa_dense_energy_forward_prepared": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                                   c_float, c_float, c_void_p, c_size_t, c_void_p]),
     "cosa_dense_energy_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                           c_int, c_float, c_float, c_void_p, c_size_t, c_void_p]),
     "cosa_dense_energy_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

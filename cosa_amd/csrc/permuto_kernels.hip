@@ -440,32 +440,36 @@ size_t plan_layout(int N, int K, int H, int W, void *ws, Plan *pl)
     return cv.off;
 }
 
-int run_filter(const float *images, const float *ins, float *outs, int N, int K, int H, int W, float sigmargb, float sigmaxy,
-               const float *roi, const float *seg_for_energy, const unsigned char *unlabel, float *loss,
-               int32_t *lattice_sizes, void *ws, size_t ws_bytes, hipStream_t st)
+// Phase A -- everything that depends on the image only: hash table, lattice points, per-pixel offsets and barycentric weights,
+// blur neighbours.  Phase B -- splat / blur / slice of one value tensor through that lattice.  The training step builds the lattice
+// of its strong image on a side stream while the networks run (cosa_dense_energy_prepare) and only phase B waits for the logits.
+int setup_plan(int N, int K, int H, int W, float sigmargb, float sigmaxy, void *ws, size_t ws_bytes, Plan &pl)
 {
-    COSA_REQUIRE(images && ins && outs && ws, "bilateral: null pointer");
+    COSA_REQUIRE(ws, "bilateral: null workspace");
     COSA_REQUIRE(N > 0 && K > 0 && H > 0 && W > 0 && N <= 65535, "bilateral: bad shape");
     COSA_REQUIRE(sigmargb > 0.f && sigmaxy > 0.f, "bilateral: sigmas must be positive");
     COSA_REQUIRE((size_t)H * W * PD1 < (1u << 30), "bilateral: image too large");
-    Plan pl;
     if (ws_bytes < plan_layout(N, K, H, W, ws, &pl)) {
         set_error("bilateral: workspace too small (%zu < %zu)", ws_bytes, pl.bytes);
         return COSA_ENOMEM;
     }
     LatticeParams &P = pl.P;
-    ImageBuffers &B = pl.B;
     P.sigmaxy = sigmaxy; P.sigmargb = sigmargb;
-    {
-        // permutohedral.cpp:152-156: float inv_std_dev = sqrt(2/3)*(d+1); scale = 1/sqrt((i+2)(i+1)) * inv_std_dev (double)
-        const float inv_std_dev = (float)(std::sqrt(2.0 / 3.0) * (PD + 1));
-        for (int i = 0; i < PD; i++) P.scale[i] = (float)(1.0 / std::sqrt((double)((i + 2) * (i + 1))) * (double)inv_std_dev);
-    }
+    // permutohedral.cpp:152-156: float inv_std_dev = sqrt(2/3)*(d+1); scale = 1/sqrt((i+2)(i+1)) * inv_std_dev (double)
+    const float inv_std_dev = (float)(std::sqrt(2.0 / 3.0) * (PD + 1));
+    for (int i = 0; i < PD; i++) P.scale[i] = (float)(1.0 / std::sqrt((double)((i + 2) * (i + 1))) * (double)inv_std_dev);
+    return COSA_OK;
+}
+
+int lattice_phase(const float *images, int N, Plan &pl, hipStream_t st)
+{
+    COSA_REQUIRE(images, "bilateral: null image pointer");
+    LatticeParams &P = pl.P;
+    ImageBuffers &B = pl.B;
     const size_t cap = (size_t)P.cap_mask + 1;
     // zero [err | M | loss_acc] (one block at the start of the workspace), fill the key table with EMPTY
     COSA_HIP_CHECK(hipMemsetAsync(B.err, 0, (char *)B.keys - (char *)B.err, st));
     COSA_HIP_CHECK(hipMemsetAsync(B.keys, 0xFF, (size_t)N * cap * sizeof(unsigned long long), st));
-
     const dim3 blk(256);
     hipLaunchKernelGGL(lattice_build_kernel, dim3((P.Npad + 255) / 256, N), blk, 0, st, images, P, B);
     COSA_LAUNCH_CHECK();
@@ -474,6 +478,18 @@ int run_filter(const float *images, const float *ins, float *outs, int N, int K,
     const int gs = 1024;   // grid-stride launches read M on the device
     hipLaunchKernelGGL(lattice_neighbors_kernel, dim3(gs, N), blk, 0, st, P, B);
     COSA_LAUNCH_CHECK();
+    return COSA_OK;
+}
+
+int filter_phase(const float *ins, float *outs, int N, int K, const float *roi, const float *seg_for_energy,
+                 const unsigned char *unlabel, float *loss, int32_t *lattice_sizes, Plan &pl, hipStream_t st)
+{
+    COSA_REQUIRE(ins && outs, "bilateral: null pointer");
+    LatticeParams &P = pl.P;
+    ImageBuffers &B = pl.B;
+    const dim3 blk(256);
+    const int gs = 1024;
+    COSA_HIP_CHECK(hipMemsetAsync(B.loss_acc, 0, 8 * sizeof(double), st));      // a lattice may serve several filter passes
     hipLaunchKernelGGL(lattice_zero_values_kernel, dim3(gs, N), blk, 0, st, P, B);
     COSA_LAUNCH_CHECK();
     const size_t lds = (size_t)TP * (P.KP + 1) * sizeof(float);
@@ -493,6 +509,32 @@ int run_filter(const float *images, const float *ins, float *outs, int N, int K,
     }
     if (lattice_sizes) COSA_HIP_CHECK(hipMemcpyAsync(lattice_sizes, B.M, sizeof(int) * N, hipMemcpyDeviceToDevice, st));
     return COSA_OK;
+}
+
+int run_filter(const float *images, const float *ins, float *outs, int N, int K, int H, int W, float sigmargb, float sigmaxy,
+               const float *roi, const float *seg_for_energy, const unsigned char *unlabel, float *loss,
+               int32_t *lattice_sizes, void *ws, size_t ws_bytes, hipStream_t st)
+{
+    Plan pl;
+    int rc = setup_plan(N, K, H, W, sigmargb, sigmaxy, ws, ws_bytes, pl);
+    if (rc) return rc;
+    rc = lattice_phase(images, N, pl, st);
+    if (rc) return rc;
+    return filter_phase(ins, outs, N, K, roi, seg_for_energy, unlabel, loss, lattice_sizes, pl, st);
+}
+
+// half-resolution, de-normalised image of the dense-energy regulariser: F.interpolate(denormalize_img(x), scale_factor=0.5)
+// (nearest: pixel (2y, 2x)); x*std + mean as two operations, like the reference's tensor expression
+__global__ __launch_bounds__(256) void half_denorm_kernel(const float *__restrict__ simg, float *__restrict__ out, int S, int planes)
+{
+    const int Sq = S >> 1;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)planes * Sq * Sq) return;
+    const int x = (int)(i % Sq), y = (int)((i / Sq) % Sq), pl = (int)(i / ((size_t)Sq * Sq));
+    const int ch = pl % 3;
+    const float mean = ch == 0 ? 123.675f : (ch == 1 ? 116.28f : 103.53f), sd = ch == 0 ? 58.395f : (ch == 1 ? 57.12f : 57.375f);
+    const float v = simg[((size_t)pl * S + 2 * y) * S + 2 * x] * sd;
+    out[i] = v + mean;
 }
 
 }  // namespace
@@ -522,6 +564,34 @@ extern "C" int cosa_dense_energy_forward(const float *images, const float *seg, 
     COSA_REQUIRE(seg && roi && unlabel && AS && loss, "cosa_dense_energy_forward: null pointer");
     return run_filter(images, seg, AS, N, K, H, W, sigmargb, sigmaxy, roi, seg, unlabel, loss, nullptr, workspace,
                       workspace_bytes, as_stream(stream));
+}
+
+// The same forward, in two halves for overlap: `prepare` needs only the (normalised) strong image -- it writes the half-resolution
+// de-normalised image and builds the lattice in `workspace`; `forward_prepared` runs splat / blur / slice through that lattice.
+// The K passed to both (and to cosa_bilateral_workspace_bytes) must agree; the workspace must not be touched in between.
+extern "C" int cosa_dense_energy_prepare(const float *simg, float *s_img, int N, int K, int S, float sigmargb, float sigmaxy,
+                                         void *workspace, size_t workspace_bytes, void *stream)
+{
+    COSA_REQUIRE(simg && s_img && S > 0 && (S % 2) == 0, "cosa_dense_energy_prepare: bad arguments");
+    Plan pl;
+    int rc = setup_plan(N, K, S / 2, S / 2, sigmargb, sigmaxy, workspace, workspace_bytes, pl);
+    if (rc) return rc;
+    hipStream_t st = as_stream(stream);
+    const size_t tot = (size_t)N * 3 * (S / 2) * (S / 2);
+    hipLaunchKernelGGL(half_denorm_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, simg, s_img, S, N * 3);
+    COSA_LAUNCH_CHECK();
+    return lattice_phase(s_img, N, pl, st);
+}
+
+extern "C" int cosa_dense_energy_forward_prepared(const float *seg, const float *roi, const uint8_t *unlabel, float *AS, float *loss,
+                                                  int N, int K, int H, int W, float sigmargb, float sigmaxy, void *workspace,
+                                                  size_t workspace_bytes, void *stream)
+{
+    COSA_REQUIRE(seg && roi && unlabel && AS && loss, "cosa_dense_energy_forward_prepared: null pointer");
+    Plan pl;
+    int rc = setup_plan(N, K, H, W, sigmargb, sigmaxy, workspace, workspace_bytes, pl);
+    if (rc) return rc;
+    return filter_phase(seg, AS, N, K, roi, seg, unlabel, loss, nullptr, pl, as_stream(stream));
 }
 
 extern "C" int cosa_dense_energy_backward(const float *AS, const float *roi, const float *grad_out, float *grad_seg,

@@ -11,6 +11,7 @@ differences, none of which change the maths:
   * encoder.head (never used, vit.py:257,325) is frozen so DDP needs no find_unused_parameters
 """
 import math
+import os
 from types import SimpleNamespace
 
 import numpy as np
@@ -35,7 +36,7 @@ def default_args(dataset="VOC12", **over):
              high_thre=0.7, high_thre_aux=0.7, low_thre=0.25, low_thre_aux=0.25, bkg_thre=0.5, par_downscale=2, usepar=False,
              aux_cam2seg=True, aux_cam2seg_alpha=0.5, aux_seg2cam=False, aux_seg2cam_alpha=0.5, after_softmax=False,
              detach='none', use_cammix=False, usegmm=False, usegmmaux=False, gmmscale=16, gmmfilter_thre=0.05, gmmemadecay=0.99,
-             queue_update_ratio=100, compute_dtype=torch.bfloat16, teacher_graph=True, teacher_async=True, fused_losses=True, fused_optimizer=True)
+             queue_update_ratio=100, compute_dtype=torch.bfloat16, teacher_graph=True, teacher_async=True, lattice_async=False, fused_losses=True, fused_optimizer=True)
     if dataset == "VOC12":
         a.update(aux_layer=-4, max_iters=32000)            # run_voc.sh:9-11
     elif dataset == "COCO":
@@ -86,6 +87,10 @@ class CoSATrainer:
             warmup_ratio=1e-6, power=0.9, min_mult=args.min_mult)
         self.reg_layer = seg_helper.DenseEnergyLoss(weight=1e-7, sigma_rgb=15, sigma_xy=100, scale_factor=0.5)
         self.refine_model = PAR(num_iter=10, dilations=[1, 2, 4, 8, 12, 24]) if args.usepar else None
+        # the regulariser's lattice depends on the strong image only and can be built on a side stream while the networks run
+        # (lattice_async / COSA_LATTICE_ASYNC=1).  Measured neutral (334.2 vs 335.0 img/s: the CUs are already full), so it is off.
+        self._lattice = seg_helper.PreparedLattice(self.reg_layer.sigma_rgb, self.reg_layer.sigma_xy * self.reg_layer.scale_factor) \
+            if ((getattr(args, "lattice_async", False) or os.environ.get("COSA_LATTICE_ASYNC", "0") == "1") and device.type == "cuda") else None
         if args.usegmm:
             # main.py:94-103: queues of per-cell CAM maxima + EMA trackers of the fitted thresholds, all device-resident
             qdim = (args.crop_size // args.gmmscale) ** 2
@@ -182,6 +187,9 @@ class CoSATrainer:
     def forward_losses(self, wimg, simg, cls_label, img_box, n_iter):
         args = self.args
         img_denorm = torch_helper.denormalize_img(simg) if self.refine_model is not None else simg
+        fused = self.fused_losses and args.aux_cam2seg and args.segfg_alpha == 0.5 and args.aux_cam2seg_alpha == 0.5
+        if fused and self._lattice is not None:
+            self._lattice.start(simg, args.num_classes)
         cam_ps, cam_aux_ps, seg_ps = self._teacher(wimg, cls_label)
         cls_final, cls_aux, _feat, seg_pred, cam_pred, cam_aux_pred = self.model_ON(simg, cam_only=False, detach=args.detach)
         self._join_teacher()
@@ -209,11 +217,10 @@ class CoSATrainer:
                 refine_mask_label = seg_helper.cam2mask(img_denorm, img_box, cam_ps, cls_label, threhigh, threlow,
                                                         refine_model=self.refine_model, downscale=args.par_downscale,
                                                         _fold_validation=True)
-        fused = self.fused_losses and args.aux_cam2seg and args.segfg_alpha == 0.5 and args.aux_cam2seg_alpha == 0.5
         if fused:
             # one forward + one backward kernel instead of ~10 full-resolution passes (same maths, main.py:167-212)
             seg_loss, reg_loss = seg_helper.fused_seg_and_energy_loss(seg_pred, refine_mask_label, refine_mask_label_aux, simg,
-                                                                      img_box, self.reg_layer)
+                                                                      img_box, self.reg_layer, prepared=self._lattice)
         else:
             seg_pred = F.interpolate(seg_pred, size=refine_mask_label.shape[1:], mode='bilinear', align_corners=False)
             seg_loss = seg_helper.seg_loss(seg_pred, refine_mask_label, fg_alpha=args.segfg_alpha)

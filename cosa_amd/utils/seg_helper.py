@@ -412,7 +412,7 @@ class FusedSegRegLoss(Function):
     re-derive the per-pixel softmax from an LDS tile of the low-res logits.  Returns (seg_loss, reg_loss)."""
 
     @staticmethod
-    def forward(ctx, seg_lr, maskA, maskB, simg, boxes, weight, sigma_rgb, sigma_xy):
+    def forward(ctx, seg_lr, maskA, maskB, simg, boxes, weight, sigma_rgb, sigma_xy, prepared=None):
         _C.require_cuda(seg_lr, maskA, maskB, simg, boxes)
         seg_lr = seg_lr.contiguous().float()
         B, K, hs, ws = seg_lr.shape
@@ -431,10 +431,17 @@ class FusedSegRegLoss(Function):
                  "cosa_seg_loss_forward")
         AS = torch.empty_like(s_seg)
         energy = torch.empty(1, device=dev)
-        wsb = _C.workspace(L.cosa_bilateral_workspace_bytes(B, K, Sq, Sq), dev, "bilateral")
-        _C.check(L.cosa_dense_energy_forward(_C.ptr(s_img), _C.ptr(s_seg), _C.ptr(roi), _C.ptr(unl), _C.ptr(AS), _C.ptr(energy), B, K,
-                                             Sq, Sq, float(sigma_rgb), float(sigma_xy), _C.ptr(wsb), wsb.numel(), _C.stream_ptr()),
-                 "cosa_dense_energy_forward")
+        if prepared is not None and prepared.matches(B, K, Sq, sigma_rgb, sigma_xy):
+            # the lattice of this strong image was built on a side stream while the networks ran (PreparedLattice)
+            prepared.join()
+            _C.check(L.cosa_dense_energy_forward_prepared(_C.ptr(s_seg), _C.ptr(roi), _C.ptr(unl), _C.ptr(AS), _C.ptr(energy), B, K, Sq, Sq,
+                                                          float(sigma_rgb), float(sigma_xy), _C.ptr(prepared.ws), prepared.ws.numel(),
+                                                          _C.stream_ptr()), "cosa_dense_energy_forward_prepared")
+        else:
+            wsb = _C.workspace(L.cosa_bilateral_workspace_bytes(B, K, Sq, Sq), dev, "bilateral")
+            _C.check(L.cosa_dense_energy_forward(_C.ptr(s_img), _C.ptr(s_seg), _C.ptr(roi), _C.ptr(unl), _C.ptr(AS), _C.ptr(energy), B, K,
+                                                 Sq, Sq, float(sigma_rgb), float(sigma_xy), _C.ptr(wsb), wsb.numel(), _C.stream_ptr()),
+                     "cosa_dense_energy_forward")
         lossA = 0.5 * sums[0] / (sums[1] + 1e-6) + 0.5 * sums[2] / (sums[3] + 1e-6)
         lossB = 0.5 * sums[4] / (sums[5] + 1e-6) + 0.5 * sums[6] / (sums[7] + 1e-6)
         ctx.save_for_backward(seg_lr, maskA, maskB, sums, AS, roi)
@@ -452,16 +459,59 @@ class FusedSegRegLoss(Function):
         _C.check(_C.lib().cosa_seg_loss_backward(_C.ptr(seg_lr), _C.ptr(maskA), _C.ptr(maskB), _C.ptr(sums), _C.ptr(AS), _C.ptr(roi),
                                                  _C.ptr(gs), _C.ptr(gr), _C.ptr(grad), B, K, hs, ws, ctx.S, _C.stream_ptr()),
                  "cosa_seg_loss_backward")
-        return grad, None, None, None, None, None, None, None
+        return grad, None, None, None, None, None, None, None, None
 
 
-def fused_seg_and_energy_loss(seg_pred_lr, mask_main, mask_aux, img, img_box, loss_layer):
-    """(seg_loss, reg_loss) of main.py:167-212 for the reference defaults (fg_alpha 0.5, aux blend 0.5, scale_factor 0.5)."""
+class PreparedLattice:
+    """The image-only half of the dense-energy regulariser (half-resolution de-normalised strong image + permutohedral lattice:
+    hash table, per-pixel offsets / weights, blur neighbours) built on a side stream at the start of a step, so that only splat /
+    blur / slice wait for the student's logits.  One instance per trainer; `start(simg, K)` then pass it to
+    fused_seg_and_energy_loss(..., prepared=...)."""
+
+    def __init__(self, sigma_rgb, sigma_xy):
+        self.sigma = (float(sigma_rgb), float(sigma_xy))
+        self.stream = None
+        self.event = None
+        self.ws = self.s_img = None
+        self.key = None
+
+    def start(self, simg, K):
+        _C.require_cuda(simg)
+        B, _, S, _ = simg.shape
+        dev = simg.device
+        if self.stream is None:
+            self.stream, self.event = torch.cuda.Stream(device=dev), torch.cuda.Event()
+        L = _C.lib()
+        need = L.cosa_bilateral_workspace_bytes(B, K, S // 2, S // 2)
+        if self.ws is None or self.ws.numel() < need or self.ws.device != dev:
+            self.ws = torch.empty(need, device=dev, dtype=torch.uint8)
+        if self.s_img is None or self.s_img.shape != (B, 3, S // 2, S // 2):
+            self.s_img = torch.empty((B, 3, S // 2, S // 2), device=dev, dtype=torch.float32)
+        simg = simg.contiguous().float()
+        self.stream.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(self.stream):
+            _C.check(L.cosa_dense_energy_prepare(_C.ptr(simg), _C.ptr(self.s_img), B, K, S, self.sigma[0], self.sigma[1], _C.ptr(self.ws),
+                                                 self.ws.numel(), _C.stream_ptr()), "cosa_dense_energy_prepare")
+            self.event.record(self.stream)
+        simg.record_stream(self.stream)
+        self.key = (B, K, S // 2)
+
+    def matches(self, B, K, Sq, sigma_rgb, sigma_xy):
+        return self.key == (B, K, Sq) and self.sigma == (float(sigma_rgb), float(sigma_xy))
+
+    def join(self):
+        torch.cuda.current_stream().wait_event(self.event)
+        self.key = None                                  # one filter pass per prepared lattice in the training step
+
+
+def fused_seg_and_energy_loss(seg_pred_lr, mask_main, mask_aux, img, img_box, loss_layer, prepared=None):
+    """(seg_loss, reg_loss) of main.py:167-212 for the reference defaults (fg_alpha 0.5, aux blend 0.5, scale_factor 0.5).
+    `prepared`: a PreparedLattice started on this step's `img` (optional; otherwise the lattice is built here)."""
     if loss_layer.scale_factor != 0.5:
         raise NotImplementedError("fused losses are built for DenseEnergyLoss(scale_factor=0.5) (main.py:77)")
     boxes = _boxes_to_device(img_box, seg_pred_lr.device)
     return FusedSegRegLoss.apply(seg_pred_lr, mask_main, mask_aux, img, boxes, loss_layer.weight, loss_layer.sigma_rgb,
-                                 loss_layer.sigma_xy * loss_layer.scale_factor)
+                                 loss_layer.sigma_xy * loss_layer.scale_factor, prepared)
 
 
 def _crop_mask_from_boxes(img_box, b, h, w, device):

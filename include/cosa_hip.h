@@ -157,6 +157,14 @@ int cosa_dense_energy_forward(const float *images, const float *seg, const float
                               float *AS, float *loss, int N, int K, int H, int W,
                               float sigmargb, float sigmaxy,
                               void *workspace, size_t workspace_bytes, void *stream);
+/* the forward in two halves, so that the image-only half overlaps the networks: `prepare` takes the NORMALISED strong image
+ * [N,3,S,S], writes F.interpolate(denormalize_img(.), scale_factor=0.5) to s_img [N,3,S/2,S/2] and builds the lattice in
+ * `workspace`; `forward_prepared` (H = W = S/2) runs the filter through it.  Same K and workspace for both calls.          */
+int cosa_dense_energy_prepare(const float *simg, float *s_img, int N, int K, int S, float sigmargb, float sigmaxy,
+                              void *workspace, size_t workspace_bytes, void *stream);
+int cosa_dense_energy_forward_prepared(const float *seg, const float *roi, const uint8_t *unlabel, float *AS, float *loss,
+                                       int N, int K, int H, int W, float sigmargb, float sigmaxy,
+                                       void *workspace, size_t workspace_bytes, void *stream);
 int cosa_dense_energy_backward(const float *AS, const float *roi, const float *grad_out /* 1 float, device */,
                                float *grad_seg, int N, int K, int H, int W, void *stream);
 

@@ -186,6 +186,20 @@ def test_fused_seg_and_energy_loss_vs_unfused():
     assert float(f_reg) == pytest.approx(float(l_reg), rel=1e-3)
     err = (seg_lr.grad - g_ref).abs().max().item()
     assert err <= 2e-3 * g_ref.abs().max().item(), (err, g_ref.abs().max().item())
+    # the same with the lattice of the strong image built ahead on a side stream (PreparedLattice): same lattice, same numbers
+    g_fused = seg_lr.grad.clone()
+    seg_lr.grad = None
+    prep = seg_helper.PreparedLattice(layer.sigma_rgb, layer.sigma_xy * layer.scale_factor)
+    prep.start(simg, K)
+    p_seg, p_reg = seg_helper.fused_seg_and_energy_loss(seg_lr, mA, mB, simg, box, layer, prepared=prep)
+    (w_seg * p_seg + w_reg * p_reg).sum().backward()
+    assert prep.key is None                                         # consumed
+    assert float(p_seg) == float(f_seg) and float(p_reg) == pytest.approx(float(f_reg), rel=1e-5)
+    assert (seg_lr.grad - g_fused).abs().max().item() <= 1e-5 * g_fused.abs().max().item()
+    # a lattice prepared for another shape is ignored (falls back to building in place)
+    prep.start(simg[:2], K)
+    q_seg, q_reg = seg_helper.fused_seg_and_energy_loss(seg_lr, mA, mB, simg, box, layer, prepared=prep)
+    assert float(q_reg) == pytest.approx(float(f_reg), rel=1e-6)
 
 
 def test_cam_loss_targets_vs_unfused():
