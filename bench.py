@@ -314,7 +314,8 @@ def main():
             "config": {"workload": f"{opt.dataset} {C + 1}-class, ViT-B/16 bf16, batch {opt.batch}/GPU x {opt.crop}x{opt.crop}, "
                                    f"teacher 3 scales x 2 flips + student fwd/bwd + cam2mask x2 + 5 losses + AdamW + EMA"
                                    f"{' + PAR' if opt.usepar else ''}{' + adaptive thresholds (GMM)' if opt.usegmm else ''}",
-                       "global_batch": opt.batch * world, "parallelism": f"dp{world}", "final_loss": round(loss, 5)},
+                       "global_batch": opt.batch * world, "parallelism": f"dp{world}", "final_loss": round(loss, 5),
+                       "library_gemm_selection": "tunableop file" if trainer.tuned_gemms else "library default"},
             "roofline": roof,
         }
         if len(fams) > 1:

@@ -154,6 +154,37 @@ def conv3x3_dilated_tokens(tok, w16, B, h, w, dilation, relu=True):
     return y
 
 
+_TUNED = None
+
+
+def enable_tuned_gemms():
+    """The student's forward / input-gradient GEMMs and the narrow head GEMMs are plain library calls (hipBLASLt / rocBLAS through
+    torch).  PyTorch's TunableOp picks, per shape, the fastest solution the libraries offer instead of their heuristic's first
+    choice; `cosa_amd/tuning/tunableop_gfx950.csv` holds the picks for the benchmark shapes on this image's library builds
+    (made with tools/tune_gemms.sh; e.g. the 20- and 21-row head weight gradients: 95 -> 27 us).  Tuning itself stays off: shapes
+    that are not in the file, or a file whose library versions do not match, fall back to the default choice.
+    COSA_NO_TUNED_GEMMS=1 disables it.  Returns True when the file was accepted."""
+    global _TUNED
+    if _TUNED is not None:
+        return _TUNED
+    _TUNED = False
+    if os.environ.get("COSA_NO_TUNED_GEMMS", "0") == "1" or not torch.cuda.is_available():
+        return False
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuning", "tunableop_gfx950.csv")
+    try:
+        import torch.cuda.tunable as tunable
+        if os.environ.get("PYTORCH_TUNABLEOP_ENABLED") is None and os.path.exists(path):     # leave an explicit user setting alone
+            tunable.enable(True)
+            tunable.tuning_enable(False)
+            tunable.record_untuned_enable(False)
+            _TUNED = bool(tunable.read_file(path))
+            if not _TUNED:
+                tunable.enable(False)
+    except Exception:                                                                      # older torch without the module
+        _TUNED = False
+    return _TUNED
+
+
 def own_decoder_backward():
     """COSA_DECODER_MIOPEN=1 sends the student's LargeFOV convolutions back through F.conv2d (A/B switch)."""
     return os.environ.get("COSA_DECODER_MIOPEN", "0") != "1"

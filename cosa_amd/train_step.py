@@ -61,6 +61,7 @@ class CoSATrainer:
     def __init__(self, args, device, ddp=False, seed=0):
         self.args = args
         self.device = device
+        self.tuned_gemms = nn_ops.enable_tuned_gemms() if device.type == "cuda" else False
         torch_helper.setup_seed(seed)
         self.model_ON = build_model(args).to(device)
         self.model_AN = build_model(args).to(device)
