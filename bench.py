@@ -258,6 +258,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # set-up (untimed, not part of the W warm-up steps): the teacher pass becomes a hipGraph on its third call; make sure that
+    # capture is over before the timed region whatever W the caller picks
+    for _ in range(max(0, 3 - opt.warmup)):
+        trainer.step(wimg, simg, lab, box, n_iter)
     for _ in range(opt.warmup):
         trainer.step(wimg, simg, lab, box, n_iter)
     sync()

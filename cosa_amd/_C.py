@@ -165,7 +165,17 @@ def profile_stop():
     global _prof
     p, _prof = _prof, None
     torch.cuda.synchronize()
-    return {k: (len(v), sum(a.elapsed_time(b) for a, b in v)) for k, v in (p or {}).items()}
+    out = {}
+    for k, v in (p or {}).items():
+        n, ms = 0, 0.0
+        for a, b in v:
+            try:
+                ms += a.elapsed_time(b)
+                n += 1
+            except RuntimeError:                 # an event pair that cannot be timed must not take the measurement down
+                pass
+        out[k] = (n, ms)
+    return out
 
 
 class profiled:
@@ -173,14 +183,15 @@ class profiled:
         self.name = name
 
     def __enter__(self):
-        if _prof is not None:
+        self.on = _prof is not None and not torch.cuda.is_current_stream_capturing()    # events inside a graph capture cannot be timed
+        if self.on:
             self.a = torch.cuda.Event(enable_timing=True)
             self.b = torch.cuda.Event(enable_timing=True)
             self.a.record()
         return self
 
     def __exit__(self, *exc):
-        if _prof is not None:
+        if self.on and _prof is not None:
             self.b.record()
             _prof.setdefault(self.name, []).append((self.a, self.b))
         return False

@@ -380,3 +380,24 @@ def test_teacher_pass_flip_equivariance_at_bench_size():
                              seg_helper.multi_scale_camseg(model, wimg.flip(-1).contiguous(), [1.0, 0.5, 1.5])[0], lab, 0.7, 0.25,
                              _fold_validation=True)
     assert (mf == m.flip(-1)).float().mean().item() > 0.99
+
+
+@pytest.mark.parametrize("flags", [["--steps", "1", "--warmup", "0"], ["--steps", "2", "--warmup", "1", "--usepar", "--usegmm"]])
+def test_bench_contract_small(flags):
+    """bench.py as the driver calls it (own process), tiny configuration, warm-up counts below the graph-capture threshold: prints ONE JSON
+    line with the contract's keys (profiling events must not be taken inside the teacher's graph capture)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--batch", "2", "--crop", "224", "--no-cpu-baseline"] + flags,
+                         capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline"):
+        assert k in d, k
+    assert d["value"] > 0 and d["n_gpus"] == 1 and d["steps"] == int(flags[1]) and d["roofline"]["bound"] in ("mfma", "hbm")
