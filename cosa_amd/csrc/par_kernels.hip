@@ -259,6 +259,66 @@ __global__ __launch_bounds__(256) void par_step_kernel(const float *__restrict__
 }
 
 
+// v3 propagation step: ONE pixel per thread, ALL live planes of the image (up to 16) in the same thread.  The affinity tensor is
+// the HBM stream of a step (rocprofv3 PMC, profiles/r01_par_step_pmc.json: 595 MB per step launch with 4-plane groups = the 154 MB
+// tensor once per group); with every plane in one thread it is read once.  One pixel per thread keeps the registers small (16
+// accumulators + 16 plane bases) so the occupancy that the 4-pixel kernel loses with wide groups stays.
+template <int NP>
+__device__ __forceinline__ void par_step1_body(const float *__restrict__ aff, const float *__restrict__ src, float *__restrict__ dst,
+                                               int b, int K, int j0, int nlive, int half_planes, size_t img_stride, int h, int w,
+                                               const ParPlan &plan)
+{
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    const int hw = h * w;
+    if (pix >= hw) return;
+    const int y = pix / w, x = pix - y * w;
+    unsigned po[NP];                                   // plane offsets (floats) from the image base
+    float acc[NP];
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
+        const int j = j0 + (i < nlive ? i : 0);
+        const int half = j / K;
+        po[i] = (unsigned)((half * half_planes + (j - half * K)) * hw);
+        acc[i] = 0.0f;
+    }
+    const float *sb = src + (size_t)b * img_stride;
+    const float *ab = aff + (size_t)b * plan.n_dil * 8 * hw + pix;
+    for (int di = 0; di < plan.n_dil; di++) {
+        const int d = plan.dil[di];
+        const int rm = clampi(y - d, 0, h - 1) * w, r0 = y * w, rp = clampi(y + d, 0, h - 1) * w;
+        const int xm = clampi(x - d, 0, w - 1), xp = clampi(x + d, 0, w - 1);
+        const int o[8] = {rm + xm, rm + x, rm + xp, r0 + xm, r0 + xp, rp + xm, rp + x, rp + xp};
+#pragma unroll
+        for (int t = 0; t < 8; t++) {
+            const float a = ab[(size_t)(di * 8 + t) * hw];
+#pragma unroll
+            for (int i = 0; i < NP; i++) acc[i] = acc[i] + sb[po[i] + o[t]] * a;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NP; i++)
+        if (i < nlive) dst[(size_t)b * img_stride + po[i] + pix] = acc[i];
+}
+
+__global__ __launch_bounds__(256) void par_step1_kernel(const float *__restrict__ aff, const float *__restrict__ src,
+                                                       float *__restrict__ dst, const int *__restrict__ kcount, int Kfull,
+                                                       int halves, int half_planes, size_t img_stride, int h, int w, ParPlan plan)
+{
+    const int b = blockIdx.z;
+    const int K = kcount ? kcount[b] : Kfull;
+    const int live = K * halves;
+    const int j0 = blockIdx.y * 16;
+    if (j0 >= live) return;
+    int nlive = live - j0;
+    nlive = nlive > 16 ? 16 : nlive;
+    if (nlive <= 2) par_step1_body<2>(aff, src, dst, b, K, j0, nlive, half_planes, img_stride, h, w, plan);
+    else if (nlive <= 4) par_step1_body<4>(aff, src, dst, b, K, j0, nlive, half_planes, img_stride, h, w, plan);
+    else if (nlive <= 6) par_step1_body<6>(aff, src, dst, b, K, j0, nlive, half_planes, img_stride, h, w, plan);
+    else if (nlive <= 8) par_step1_body<8>(aff, src, dst, b, K, j0, nlive, half_planes, img_stride, h, w, plan);
+    else if (nlive <= 12) par_step1_body<12>(aff, src, dst, b, K, j0, nlive, half_planes, img_stride, h, w, plan);
+    else par_step1_body<16>(aff, src, dst, b, K, j0, nlive, half_planes, img_stride, h, w, plan);
+}
+
 // v2 propagation step: each thread owns FOUR consecutive pixels of up to PG live planes.  The affinity row is read once
 // per neighbour as a float4 and shared by all planes.  Interior quads (every tap stays inside the row) take a
 // branch-free path: every neighbour quad is ONE 16-byte load (4-byte aligned; gfx950 global loads do not need more), the
@@ -440,6 +500,16 @@ int par_launch_step(const float *aff, const float *src, float *dst, int B, int K
                     size_t plane_stride, int h, int w, const ParPlan &plan, hipStream_t st)
 {
     const int half_planes = Kmax / halves;
+    // default: the one-pixel, all-planes kernel (1.50 ms per shared pass against 2.19 with the 4-pixel, 4-plane kernel below, which
+    // COSA_PAR_SCALAR=0 brings back for A/B runs)
+    static const int scalar = [] { const char *e = getenv("COSA_PAR_SCALAR"); return e ? atoi(e) : 1; }();
+    if (scalar && (size_t)Kmax * h * w < (1ull << 31)) {
+        dim3 grid1((h * w + 255) / 256, (Kmax + 15) / 16, B);
+        hipLaunchKernelGGL(par_step1_kernel, grid1, dim3(256), 0, st, aff, src, dst, kcount, Kmax, halves, half_planes, plane_stride,
+                           h, w, plan);
+        COSA_LAUNCH_CHECK();
+        return COSA_OK;
+    }
     if ((w & 3) == 0) {     // rows are float4-aligned: the 4-pixel kernel (all live planes of an image in one thread for K <= 4)
         static const int group = [] { const char *e = getenv("COSA_PAR_GROUP"); return e ? atoi(e) : 4; }();   // experiment switch
         const int G = group == 8 ? 8 : 4;
