@@ -249,12 +249,13 @@ class EMAtracker:
         self.X = initial_value
         self.decay = decay
 
-    def update(self, newvlaue):
-        if torch.is_tensor(newvlaue):
-            x = torch.as_tensor(self.X, dtype=newvlaue.dtype, device=newvlaue.device)
-            self.X = torch.where(torch.isfinite(newvlaue), x * self.decay + newvlaue * (1 - self.decay), x)
+    def update(self, value):
+        keep, mix = self.decay, 1 - self.decay
+        if torch.is_tensor(value):
+            x = torch.as_tensor(self.X, dtype=value.dtype, device=value.device)
+            self.X = torch.where(torch.isfinite(value), x * keep + value * mix, x)
         else:
-            self.X = self.X * self.decay + newvlaue * (1 - self.decay)
+            self.X = self.X * keep + value * mix
 
     def get(self):
         return self.X
