@@ -54,6 +54,18 @@ def test_par_vs_golden_and_oracle_bit_exact(oracle_c, golden):
     np.testing.assert_allclose(out, g["b2_out"], rtol=2e-5, atol=1e-7)
 
 
+@pytest.mark.parametrize("K,h,w", [(21, 40, 52), (17, 33, 47), (5, 30, 31)])
+def test_par_many_planes_and_odd_sizes_bit_exact(oracle_c, K, h, w):
+    """more planes than one thread holds (two plane groups), plane counts that fall into every body size, odd / non-square sizes
+    smaller than the largest dilation: equal to the oracle in every bit"""
+    from cosa_amd.models.PAR import PAR
+    rng = np.random.default_rng(K)
+    img = rng.uniform(0, 1, (1, 3, h, w)).astype(np.float32)
+    masks = rng.uniform(0, 1, (1, K, h, w)).astype(np.float32)
+    out = PAR(num_iter=10, dilations=DIL)(dev(img), dev(masks)).cpu().numpy()
+    assert np.array_equal(out[0], oracle_c.par_forward(img[0], masks[0], DIL, 10))
+
+
 def test_par_affinity_rows_sum(oracle_c):
     """size-independent property: every affinity row sums to 1 + w2 => a constant mask stays constant * 1.01^T."""
     from cosa_amd.models.PAR import PAR
