@@ -75,7 +75,7 @@ def multi_scale_camseg(model, imgs, scales, _active_labels=None, _seg_scales=Fal
     return cam, cam_aux, (seg_list if _seg_scales else seg)
 
 
-def multi_scale_camsegv3(model, imgs, scales, getcls=False):
+def multi_scale_camsegv3(model, imgs, scales, getcls=False, _per_image_cls=False):
     """Evaluation-time variant (utils/seg_helper.py:399-450; evaluation_engine.py:82-85 calls it with five scales x two flips):
     same fused tail as multi_scale_camseg, plus the classification logits summed over scales and over {orig, flip}
     (`cls_f_ += sum(cls_f, dim=0)`, :432-434).  cam_aux again keeps only the LAST scale (:426)."""
@@ -101,7 +101,12 @@ def multi_scale_camsegv3(model, imgs, scales, getcls=False):
             if si == len(scales) - 1:
                 _flip_merge_upsample(_cam_aux, cam_aux, b, h, 0, False)
             _flip_merge_upsample(_seg, seg, b, h, 1, si > 0)
-            if getcls:
+            if getcls and _per_image_cls:
+                # several images per pass (evaluate's grouping): the reference's sum over {orig, flip} kept per image -> [b, C]
+                cf, ca = cls_f.float().reshape(2, b, -1).sum(0), cls_a.float().reshape(2, b, -1).sum(0)
+                cls_f_ = cf if cls_f_ is None else cls_f_ + cf
+                cls_a_ = ca if cls_a_ is None else cls_a_ + ca
+            elif getcls:
                 cf, ca = cls_f.float().sum(0, keepdim=True), cls_a.float().sum(0, keepdim=True)
                 cls_f_ = cf if cls_f_ is None else cls_f_ + cf
                 cls_a_ = ca if cls_a_ is None else cls_a_ + ca
