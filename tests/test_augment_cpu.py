@@ -119,3 +119,21 @@ def test_val_dataset_contract(tmp_path, make_voc_tree):
     args = SimpleNamespace(dataset="VOC12", voc12_root=root, name_list_dir=lists, ignore_index=255, num_classes=21)
     batch = next(iter(build_val_loader(args, num_workers=0)))
     assert list(batch[0]) == [names[0]] and batch[1].shape[:2] == (1, 3) and batch[3].shape == (1, 20)
+
+
+def test_train_dataset_through_worker_processes(tmp_path, make_voc_tree):
+    """decode + draws run inside DataLoader worker processes (as the reference's transforms do): items survive pickling, batches keep the
+    (names, images, draws, labels) layout, every image matches its draws"""
+    from torch.utils.data import DataLoader
+    from cosa_amd.dataloaders import VOC12ClsDatasetNew
+    from cosa_amd.dataloaders.train_loader import _collate
+    root, lists, names, labels = make_voc_tree(tmp_path, n=6)
+    ds = VOC12ClsDatasetNew(root_dir=root, name_list_dir=lists, crop_size=64)
+    got = []
+    for nm, images, params, lab in DataLoader(ds, batch_size=3, num_workers=2, collate_fn=_collate, drop_last=True):
+        assert len(nm) == len(images) == len(params) == 3 and lab.shape == (3, 20)
+        for im, p in zip(images, params):
+            assert im.dtype == np.uint8 and im.shape == (p["h"], p["w"], 3) and p["img_box"].dtype == np.int16
+            assert 0 <= p["op"] < 9 and 1 <= p["magnitude"] <= 9 and p["new_h"] == int(p["new_h"]) > 0
+        got += nm
+    assert got == names
