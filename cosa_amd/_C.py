@@ -79,6 +79,8 @@ _SIGS = {
     "cosa_gemm_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "cosa_gemm_wgrad_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "cosa_conv3x3_dilated_nhwc": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 10 + [c_void_p]),
+    "cosa_head_gemm": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, ctypes.c_longlong, c_int, c_int, c_int, c_int,
+                               c_int, c_void_p]),
     "cosa_conv3x3_dilated_wgrad": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 10 + [c_void_p]),
     "cosa_gemm_set_variant": (None, [c_int]),
     "cosa_gemm_set_stamp_slot": (None, [c_void_p]),

@@ -180,10 +180,104 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float *__restr
     }
 }
 
+// ---- narrow heads: Y[M, N<=32] (fp32) = X[M, K] W[N, K]^T -------------------------------------------------------------------
+// The CAM / auxiliary-CAM heads (1x1 conv 768 -> 20|80, models/__init__.py:190-192) and LargeFOV's conv8 (512 -> 21|81) are
+// "skinny" GEMMs: a library GEMM pads N to its tile and picks tile / split by the row count, so results move in their last bits
+// with the batch.  Here one wave owns a row at a time: lane l multiplies its 4-element slices of the row with the matching
+// slices of all N weight rows (W staged in LDS as fp32), then the N partial sums are folded over the wave.  HBM-bound on X,
+// fixed reduction order per row -> bit-identical whatever else is in the batch.
+template <typename T>
+__global__ __launch_bounds__(256) void head_gemm_kernel(const T *__restrict__ X, const T *__restrict__ W, float *__restrict__ Y,
+                                                       int M, int N, int K, int rows_per_img, long long img_stride, int ldx,
+                                                       int round_bf16, int ldy, int col0)
+{
+    extern __shared__ __attribute__((aligned(16))) float wl[];            // [N][K] fp32
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int e = tid; e < N * K; e += 256) wl[e] = (float)W[e];
+    __syncthreads();
+    const int waves = gridDim.x * 4;
+    const int chunks = K >> 8;                                            // 256 columns per sweep of the wave
+    for (int r = blockIdx.x * 4 + wave; r < M; r += waves) {
+        const int b = r / rows_per_img;
+        const T *xr = X + (size_t)b * img_stride + (size_t)(r - b * rows_per_img) * ldx;
+        float acc[32];
+#pragma unroll
+        for (int n = 0; n < 32; n++) acc[n] = 0.f;
+        for (int c = 0; c < chunks; c++) {
+            const int k = c * 256 + lane * 4;
+            float x0, x1, x2, x3;
+            if (sizeof(T) == 4) {
+                const float4 v = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(xr) + k);
+                x0 = v.x; x1 = v.y; x2 = v.z; x3 = v.w;
+            } else {
+                const bf16 *pb = reinterpret_cast<const bf16 *>(xr) + k;
+                x0 = (float)pb[0]; x1 = (float)pb[1]; x2 = (float)pb[2]; x3 = (float)pb[3];
+            }
+#pragma unroll
+            for (int n = 0; n < 32; n++) {
+                if (n < N) {
+                    const float4 w4 = *reinterpret_cast<const float4 *>(wl + (size_t)n * K + k);
+                    acc[n] = acc[n] + ((x0 * w4.x + x1 * w4.y) + (x2 * w4.z + x3 * w4.w));
+                }
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < 32; n++) {
+            if (n < N) {
+                float v = acc[n];
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+                acc[n] = v;
+            }
+        }
+        if (lane < N) {
+            float v = 0.f;
+#pragma unroll
+            for (int n = 0; n < 32; n++) v = lane == n ? acc[n] : v;
+            if (round_bf16) v = (float)(bf16)v;
+            Y[(size_t)r * ldy + col0 + lane] = v;
+        }
+    }
+}
+
 }  // namespace
 }  // namespace cosa
 
 using namespace cosa;
+
+// Y[M,N] fp32 = X W^T for N <= 32 (CAM / seg heads); X rows: image b = rows [b*rows_per_img, +rows_per_img) at X + b*img_stride
+// (elements) with row stride ldx, so token views without their cls row need no copy.  dtype: 0 = fp32 operands, 1 = bf16
+// operands (round_bf16 = 1 additionally rounds the result to bf16 precision, like a bf16 library GEMM would).  The N columns land
+// at Y[r*ldy + col0 ...]: wider heads (COCO: 80 | 81 rows) are done in slices of <= 32 weight rows.
+extern "C" int cosa_head_gemm(const void *X, const void *W, float *Y, int M, int N, int K, int rows_per_img, long long img_stride,
+                              int ldx, int dtype, int round_bf16, int ldy, int col0, void *stream)
+{
+    COSA_REQUIRE(ldy >= col0 + N && col0 >= 0, "cosa_head_gemm: output columns [col0, col0+N) must fit the row stride ldy");
+    COSA_REQUIRE(X && W && Y && M > 0 && N > 0 && K > 0 && rows_per_img > 0, "cosa_head_gemm: bad arguments");
+    COSA_REQUIRE(N <= 32 && K % 256 == 0 && ldx >= K, "cosa_head_gemm: N <= 32 and K %% 256 == 0 (got N=%d K=%d)", N, K);
+    COSA_REQUIRE(dtype == 0 || dtype == 1, "cosa_head_gemm: dtype 0 (fp32) or 1 (bf16)");
+    const size_t lds = (size_t)N * K * sizeof(float);
+    COSA_REQUIRE(lds <= 128 * 1024, "cosa_head_gemm: weight does not fit the LDS");
+    hipStream_t st = as_stream(stream);
+    static size_t attr[2] = {0, 0};
+    if (lds > attr[dtype]) {
+        if (dtype == 0)
+            COSA_HIP_CHECK(hipFuncSetAttribute((const void *)head_gemm_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        else
+            COSA_HIP_CHECK(hipFuncSetAttribute((const void *)head_gemm_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr[dtype] = lds;
+    }
+    int blocks = (M + 3) / 4;
+    blocks = blocks > 1024 ? 1024 : blocks;
+    if (dtype == 0)
+        hipLaunchKernelGGL(head_gemm_kernel<float>, dim3(blocks), dim3(256), lds, st, static_cast<const float *>(X),
+                           static_cast<const float *>(W), Y, M, N, K, rows_per_img, img_stride, ldx, round_bf16, ldy, col0);
+    else
+        hipLaunchKernelGGL(head_gemm_kernel<bf16>, dim3(blocks), dim3(256), lds, st, static_cast<const bf16 *>(X),
+                           static_cast<const bf16 *>(W), Y, M, N, K, rows_per_img, img_stride, ldx, round_bf16, ldy, col0);
+    COSA_LAUNCH_CHECK();
+    return COSA_OK;
+}
 
 extern "C" int cosa_add_layernorm_fwd(const void *x, const void *delta, const void *gamma, const void *beta, void *x_out, void *y,
                                       float *mean, float *rstd, int rows, int dim, float eps, void *stream)

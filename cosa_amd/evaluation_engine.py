@@ -50,7 +50,7 @@ class _GraphedCamSeg:
 
 
 def evaluate(model, data_loader, args, df=None, save_result=False, save_rawcam=False, epoch=None, threshold_filters=None, getcrf=False,
-             s_or_t='t', get_camiou=False, isfinal=False, class_list=None, use_graph=True, eval_group=1):
+             s_or_t='t', get_camiou=False, isfinal=False, class_list=None, use_graph=True, eval_group=4):
     if save_result or save_rawcam:
         raise NotImplementedError("evaluate: save_result / save_rawcam (image dumps) are not part of the device path")
     if getcrf or threshold_filters:
@@ -68,11 +68,12 @@ def evaluate(model, data_loader, args, df=None, save_result=False, save_rawcam=F
     was_training = model.training
     model.eval()
     camseg = _GraphedCamSeg(model, EVAL_SCALES, enabled=use_graph and getattr(model, "can_forward_multi", None) is not None)
-    # Every image is resized to crop_size x crop_size before the network (:82), so `eval_group` loader items can share one multi-scale
-    # pass (GEMMs with several times the rows instead of ten batch-1 encoder passes per image: 137 -> 242 img/s at eval_group=4); label
-    # maps, histograms and AP stay per image.  Default 1 = the reference's loop exactly.  With grouping our own kernels are batch-
-    # independent per element, but the three narrow head GEMMs are library calls whose reduction order follows the row count, so CAM /
-    # seg values move in their last bits and a few boundary pixels of the label maps with them -- opt in where that is acceptable.
+    # Every image is resized to crop_size x crop_size before the network (:82), so `eval_group` loader items share one multi-scale pass
+    # (GEMMs with several times the rows instead of ten batch-1 encoder passes per image: 137 -> 242 img/s at 4); label maps, histograms
+    # and AP stay per image.  Every kernel on the CAM / seg path (patch projection, encoder, convs, narrow heads, CAM tail) gives a token
+    # the same bits whatever else is in the batch, so the score table is that of the one-image-at-a-time loop exactly (tested); only the
+    # pooled classification logits -- the logged AP -- go through a library GEMM and may move in their last digits.  eval_group=1
+    # is the reference's loop literally.
     def flush(group):
         if not group:
             return

@@ -31,7 +31,9 @@ class LargeFOV(nn.Module):
         y = nn_ops.conv3x3_dilated_tokens(tok, c(self.conv6.weight, torch.bfloat16), B, h, w, self.dilation, relu=True)
         y = nn_ops.conv3x3_dilated_tokens(y.view(B, h * w, -1), c(self.conv7.weight, torch.bfloat16), B, h, w, self.dilation, relu=True)
         w8 = c(self.conv8.weight, torch.bfloat16).reshape(self.conv8.weight.shape[0], -1)
-        seg = F.linear(y, w8).float()
+        seg = nn_ops.head_linear(y.view(B, h * w, -1), w8, round_bf16=True)       # own narrow-head kernel (batch-invariant)
+        if seg is None:
+            seg = F.linear(y, w8).float()
         return seg.view(B, h, w, -1).permute(0, 3, 1, 2).contiguous()
 
     def forward_tokens_train(self, tok, B, h, w):
@@ -98,7 +100,11 @@ class VITNetwork(nn.Module):
             wgt = wgt.detach()
         if detach_feat:
             tok = tok.detach()
-        cam = F.linear(tok, wgt).float()
+        cam = None
+        if not torch.is_grad_enabled() and tok.is_cuda:
+            cam = nn_ops.head_linear(tok, wgt.contiguous(), round_bf16=tok.dtype == torch.bfloat16)     # no-grad: own narrow-head kernel
+        if cam is None:
+            cam = F.linear(tok, wgt).float()
         return cam.reshape(B, h, w, -1).permute(0, 3, 1, 2).contiguous()
 
     def forward_multi(self, xs):

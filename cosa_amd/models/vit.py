@@ -122,7 +122,13 @@ class VisionTransformer(nn.Module):
         # im2col view of the stride-16 conv: [B, h*w, 3*16*16] @ W^T
         cols = x.to(dt).reshape(B, nc, h, p, w, p).permute(0, 2, 4, 1, 3, 5).reshape(B, h * w, nc * p * p)
         wgt = nn_ops.cast_param(self.patch_embed.proj.weight, dt).reshape(self.embed_dim, -1)
-        tok = F.linear(cols, wgt, nn_ops.cast_param(self.patch_embed.proj.bias, dt))
+        bias = nn_ops.cast_param(self.patch_embed.proj.bias, dt)
+        if dt == torch.bfloat16 and x.is_cuda and not torch.is_grad_enabled() and wgt.shape[0] % 128 == 0 and wgt.shape[1] % 64 == 0:
+            # no-grad (teacher / evaluation): the patch projection on our own MFMA GEMM -- like every other kernel of the CAM / seg
+            # path its result for a token does not depend on the batch around it
+            tok = nn_ops.gemm_bf16(cols.reshape(B * h * w, -1).contiguous(), wgt.contiguous(), bias.contiguous(), nn_ops.EPI_BIAS).view(B, h * w, -1)
+        else:
+            tok = F.linear(cols, wgt, bias)
         cls = nn_ops.cast_param(self.cls_token, dt).expand(B, -1, -1)
         tok = torch.cat((cls, tok), dim=1)
         return tok + self._pos_for_grid(h, w, dt), h, w

@@ -244,6 +244,24 @@ class DilatedConvReluFn(torch.autograd.Function):
         return dx, dw, None, None, None, None
 
 
+def head_linear(tok, weight, round_bf16=False):
+    """tok [B, n, K] (fp32 or bf16, possibly the strided view without the cls row) x weight [N, K] (same dtype) -> [B*n, N] fp32 on the
+    narrow-head kernel (no-grad paths: teacher and evaluation).  None when the shape is outside the kernel's envelope."""
+    B, n, K = tok.shape
+    N = weight.shape[0]
+    if tok.dtype != weight.dtype or tok.dtype not in (torch.float32, torch.bfloat16) or K % 256 or tok.stride(2) != 1 \
+            or not weight.is_contiguous() or min(N, 32) * K * 4 > 128 * 1024:
+        return None
+    y = torch.empty((B * n, N), device=tok.device, dtype=torch.float32)
+    dt = 0 if tok.dtype == torch.float32 else 1
+    with _C.profiled("head_gemm"):
+        for c0 in range(0, N, 32):
+            nn_ = min(32, N - c0)
+            _C.check(_C.lib().cosa_head_gemm(_C.ptr(tok), _C.ptr(weight[c0:c0 + nn_]), _C.ptr(y), B * n, nn_, K, n, tok.stride(0) if B > 1 else n * tok.stride(1),
+                                             tok.stride(1), dt, int(round_bf16), N, c0, _C.stream_ptr()), "cosa_head_gemm")
+    return y
+
+
 def layernorm_f32(x, g, b, eps, want_bf16=True, want_f32=False):
     """x [rows,768] fp32 -> (bf16 | None, fp32 | None)"""
     rows, D = x.shape

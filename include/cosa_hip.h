@@ -223,6 +223,12 @@ void cosa_gemm_set_variant(int v);   /* 0 (default): per-shape choice; 1: 128x12
  * (100 MHz s_memrealtime: min start / max end over workgroups) to slot[0..1] (uint64, caller-initialised to max / 0).
  * One-shot; used by bench.py because HIP events cannot be recorded inside a captured hipGraph.                       */
 void cosa_gemm_set_stamp_slot(void *slot);
+/* models/__init__.py:190-192 (classifier / aux_classifier as 1x1 convs over the tokens) and conv_head.py:38 (conv8): the narrow heads
+ * Y[M, N <= 32] (fp32, columns [col0, col0+N) of rows with stride ldy) = X W^T, fp32 accumulation, fixed reduction order per row
+ * (results do not depend on what else is in the batch).  X: image b = rows_per_img rows at X + b*img_stride (elements), row stride
+ * ldx; dtype 0: fp32 X and W, 1: bf16 X and W (round_bf16 = 1 rounds the result to bf16 precision).                               */
+int cosa_head_gemm(const void *X, const void *W, float *Y, int M, int N, int K, int rows_per_img, long long img_stride,
+                   int ldx, int dtype, int round_bf16, int ldy, int col0, void *stream);
 int cosa_layernorm(const float *x, const void *gamma, const void *beta, void *y_bf16, float *y_f32,
                    int rows, int dim, float eps, void *stream);
 

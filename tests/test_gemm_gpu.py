@@ -144,3 +144,25 @@ def test_dilated_conv_autograd_vs_torch(B, h, w, Cin, Cout, strided):
     assert (tok.grad.float() - dxr).abs().max() <= 3e-2 * dxr.abs().max()
     assert (weight.grad - w32.grad).abs().max() <= 3e-2 * w32.grad.abs().max()
     assert weight.grad.dtype == torch.float32 and weight.grad.shape == weight.shape
+
+
+@pytest.mark.parametrize("dtype,N,K", [(torch.float32, 20, 768), (torch.bfloat16, 21, 512), (torch.float32, 80, 768), (torch.bfloat16, 81, 512),
+                                       (torch.bfloat16, 20, 768)])
+def test_head_linear_vs_torch_and_batch_invariance(dtype, N, K):
+    """narrow heads (CAM / aux-CAM / conv8): fp32-accumulated X W^T on the strided token view (no cls row) against torch in float64;
+    a row's result must not depend on the batch around it (bitwise), which library GEMMs do not guarantee"""
+    from cosa_amd import nn_ops
+    g = torch.Generator().manual_seed(N + K)
+    B, n = 5, 197
+    full = torch.randn(B, n + 1, K, generator=g).to(dtype).cuda()
+    tok = full[:, 1:]
+    w = (torch.randn(N, K, generator=g) * 0.05).to(dtype).cuda()
+    y = nn_ops.head_linear(tok, w, round_bf16=dtype == torch.bfloat16)
+    ref = (tok.double().reshape(-1, K) @ w.double().t())
+    tol = 2e-6 if dtype == torch.float32 else 1e-2                       # bf16: the result is rounded to bf16 precision
+    assert y.shape == (B * n, N) and y.dtype == torch.float32
+    assert (y.double() - ref).abs().max() <= tol * ref.abs().max()
+    one = nn_ops.head_linear(tok[2:3], w, round_bf16=dtype == torch.bfloat16)
+    assert torch.equal(one, y[2 * n:3 * n])
+    two = nn_ops.head_linear(tok[3:5].contiguous(), w, round_bf16=dtype == torch.bfloat16)
+    assert torch.equal(two, y[3 * n:5 * n])

@@ -16,9 +16,9 @@ for i in range(n):
     H, W = sizes[i % len(sizes)]
     cls = torch.zeros(1, 20); cls[0, rng.choice(20, 2, replace=False)] = 1
     loader.append(("x", torch.randn(1, 3, H, W), torch.from_numpy(rng.integers(0, 21, (1, H, W))), cls))
-ee.evaluate(model, loader[:12], args, epoch=0, eval_group=int(sys.argv[2]) if len(sys.argv) > 2 else 1)                      # warm-up (kernel selection, workspaces)
+ee.evaluate(model, loader[:12], args, epoch=0, eval_group=int(sys.argv[2]) if len(sys.argv) > 2 else 4)                      # warm-up (kernel selection, workspaces)
 torch.cuda.synchronize(); t0 = time.perf_counter()
-grp = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+grp = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 tab, miou, df, aps = ee.evaluate(model, loader, args, epoch=1, eval_group=grp)
 torch.cuda.synchronize(); dt = time.perf_counter() - t0
 print(f"evaluate: {n} images in {dt:.2f} s = {n/dt:.1f} img/s ({dt/n*1e3:.1f} ms/img; 10 encoder passes each); VOC val (1449 images) ~ {1449*dt/n:.0f} s on one GPU")
