@@ -71,9 +71,8 @@ def evaluate(model, data_loader, args, df=None, save_result=False, save_rawcam=F
     # Every image is resized to crop_size x crop_size before the network (:82), so `eval_group` loader items share one multi-scale pass
     # (GEMMs with several times the rows instead of ten batch-1 encoder passes per image: 137 -> 242 img/s at 4); label maps, histograms
     # and AP stay per image.  Every kernel on the CAM / seg path (patch projection, encoder, convs, narrow heads, CAM tail) gives a token
-    # the same bits whatever else is in the batch, so the score table is that of the one-image-at-a-time loop exactly (tested); only the
-    # pooled classification logits -- the logged AP -- go through a library GEMM and may move in their last digits.  eval_group=1
-    # is the reference's loop literally.
+    # the same bits whatever else is in the batch, so the score table and the AP are those of the one-image-at-a-time loop exactly
+    # (tested).  eval_group=1 is the reference's loop literally.
     def flush(group):
         if not group:
             return

@@ -107,6 +107,15 @@ class VITNetwork(nn.Module):
             cam = F.linear(tok, wgt).float()
         return cam.reshape(B, h, w, -1).permute(0, 3, 1, 2).contiguous()
 
+    @staticmethod
+    def _cls_head(pooled, wgt):
+        """classification logits from the pooled tokens; no-grad: the narrow-head kernel (batch-invariant like the CAM heads)"""
+        if not torch.is_grad_enabled() and pooled.is_cuda:
+            y = nn_ops.head_linear(pooled.unsqueeze(1).contiguous(), wgt.contiguous(), round_bf16=pooled.dtype == torch.bfloat16)
+            if y is not None:
+                return y
+        return F.linear(pooled, wgt).float()
+
     def forward_multi(self, xs):
         """forward() for several image batches of different sizes at once (no-grad bf16 only): the encoder runs all of
         them through shared GEMM / LayerNorm launches (VisionTransformer._forward_features_fused_multi)."""
@@ -148,8 +157,8 @@ class VITNetwork(nn.Module):
             return cam, cam_aux
         wc = nn_ops.cast_param(self.classifier.weight, dt).reshape(self.num_classes - 1, -1)
         wa = nn_ops.cast_param(self.aux_classifier.weight, dt).reshape(self.num_classes - 1, -1)
-        cls_x4 = F.linear(self._pool(tok).to(dt), wc).float()
-        cls_aux = F.linear(self._pool(tok_aux).to(dt), wa).float()
+        cls_x4 = self._cls_head(self._pool(tok).to(dt), wc)
+        cls_aux = self._cls_head(self._pool(tok_aux).to(dt), wa)
         return cls_x4, cls_aux, x4, seg, cam, cam_aux
 
 
