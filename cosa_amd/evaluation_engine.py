@@ -67,6 +67,11 @@ def evaluate(model, data_loader, args, df=None, save_result=False, save_rawcam=F
     ap_cnt = 0                                                           # ... over the batches (AverageMeter semantics, :86-92)
     was_training = model.training
     model.eval()
+    net = model.module if hasattr(model, "module") else model
+    heads_before = getattr(net, "batch_invariant_heads", None)
+    if heads_before is not None:                       # grouped items must reproduce the one-at-a-time bits: narrow heads on own kernel
+        net.batch_invariant_heads = True
+        net.decoder.batch_invariant = True
     camseg = _GraphedCamSeg(model, EVAL_SCALES, enabled=use_graph and getattr(model, "can_forward_multi", None) is not None)
     # Every image is resized to crop_size x crop_size before the network (:82), so `eval_group` loader items share one multi-scale pass
     # (GEMMs with several times the rows instead of ten batch-1 encoder passes per image: 137 -> 242 img/s at 4); label maps, histograms
@@ -115,6 +120,9 @@ def evaluate(model, data_loader, args, df=None, save_result=False, save_rawcam=F
         flush(group)
     for m in meters.values():
         m.all_reduce()
+    if heads_before is not None:
+        net.batch_invariant_heads = heads_before
+        net.decoder.batch_invariant = heads_before
     if was_training:
         model.train()
     if rank != 0:

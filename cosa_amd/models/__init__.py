@@ -24,6 +24,8 @@ class LargeFOV(nn.Module):
         self.conv7 = nn.Conv2d(self.embed_dim, self.embed_dim, 3, padding=dilation, dilation=dilation, bias=False)
         self.conv8 = nn.Conv2d(self.embed_dim, out_planes, 1, bias=False)
 
+    batch_invariant = False        # set by VITNetwork together with its own flag
+
     def forward_tokens(self, tok, B, h, w):
         """no-grad bf16 path: both dilated convs as implicit-GEMM MFMA kernels on the NHWC tokens, conv8 as a bare GEMM.
         tok [B, h*w, 768] bf16 (may be the strided `tokens[:, 1:]` view) -> seg [B, classes, h, w] fp32"""
@@ -31,7 +33,7 @@ class LargeFOV(nn.Module):
         y = nn_ops.conv3x3_dilated_tokens(tok, c(self.conv6.weight, torch.bfloat16), B, h, w, self.dilation, relu=True)
         y = nn_ops.conv3x3_dilated_tokens(y.view(B, h * w, -1), c(self.conv7.weight, torch.bfloat16), B, h, w, self.dilation, relu=True)
         w8 = c(self.conv8.weight, torch.bfloat16).reshape(self.conv8.weight.shape[0], -1)
-        seg = nn_ops.head_linear(y.view(B, h * w, -1), w8, round_bf16=True)       # own narrow-head kernel (batch-invariant)
+        seg = nn_ops.head_linear(y.view(B, h * w, -1), w8, round_bf16=True) if self.batch_invariant else None
         if seg is None:
             seg = F.linear(y, w8).float()
         return seg.view(B, h, w, -1).permute(0, 3, 1, 2).contiguous()
@@ -59,6 +61,11 @@ class LargeFOV(nn.Module):
 
 class VITNetwork(nn.Module):
     """models/__init__.py:82-206"""
+
+    # narrow heads (CAM / aux CAM / conv8 / classification) of the no-grad paths on the batch-invariant kernel instead of library
+    # GEMMs: evaluate() turns it on so that grouped loader items reproduce the one-at-a-time scores exactly; the training step's
+    # teacher keeps the (tuned) library GEMMs, which are faster there (skinny VALU kernel: 1.57 ms per step against ~0.4 ms)
+    batch_invariant_heads = False
 
     def __init__(self, backbone, num_classes, pretrained=True, aux_layer=-3, isgap=False, decoder='LargeFOV',
                  compute_dtype=torch.bfloat16):
@@ -101,16 +108,15 @@ class VITNetwork(nn.Module):
         if detach_feat:
             tok = tok.detach()
         cam = None
-        if not torch.is_grad_enabled() and tok.is_cuda:
-            cam = nn_ops.head_linear(tok, wgt.contiguous(), round_bf16=tok.dtype == torch.bfloat16)     # no-grad: own narrow-head kernel
+        if self.batch_invariant_heads and not torch.is_grad_enabled() and tok.is_cuda:
+            cam = nn_ops.head_linear(tok, wgt.contiguous(), round_bf16=tok.dtype == torch.bfloat16)
         if cam is None:
             cam = F.linear(tok, wgt).float()
         return cam.reshape(B, h, w, -1).permute(0, 3, 1, 2).contiguous()
 
-    @staticmethod
-    def _cls_head(pooled, wgt):
-        """classification logits from the pooled tokens; no-grad: the narrow-head kernel (batch-invariant like the CAM heads)"""
-        if not torch.is_grad_enabled() and pooled.is_cuda:
+    def _cls_head(self, pooled, wgt):
+        """classification logits from the pooled tokens (optionally on the batch-invariant narrow-head kernel, like the CAM heads)"""
+        if self.batch_invariant_heads and not torch.is_grad_enabled() and pooled.is_cuda:
             y = nn_ops.head_linear(pooled.unsqueeze(1).contiguous(), wgt.contiguous(), round_bf16=pooled.dtype == torch.bfloat16)
             if y is not None:
                 return y

@@ -151,7 +151,8 @@ def test_evaluate_end_to_end_vs_oracle_composition(oracle_c):
         cls[0, rng.choice(C, 2, replace=False)] = 1
         loader.append(("img", img, lab, cls))
     tab, seg_miou, cam_miou, df, cls_aps = ee.evaluate(model, loader, args, epoch=7, s_or_t='s', get_camiou=True)
-    # oracle composition from the same network outputs
+    # oracle composition from the same network outputs (evaluate() runs the narrow heads on the batch-invariant kernel: do the same here)
+    model.batch_invariant_heads = model.decoder.batch_invariant = True
     hist = {k: np.zeros((C + 1, C + 1), np.int64) for k in ("cam", "aux", "vd")}
     aps = [[], []]
     with torch.no_grad():
@@ -166,6 +167,7 @@ def test_evaluate_end_to_end_vs_oracle_composition(oracle_c):
                 hist[k] += oracle_c.confusion([gt], [p], C + 1)
             for j, lg in enumerate((cf, ca)):
                 aps[j].append(oracle_c.average_precision(cls[0].numpy(), torch.sigmoid(lg[0].float()).cpu().numpy()))
+    model.batch_invariant_heads = model.decoder.batch_invariant = False
     ref = [oracle_c.scores_from_hist(hist[k]) for k in ("cam", "aux", "vd")]
     ref_miou = [np.round(np.array(list(r["iou"].values())) * 100, 2).mean() for r in ref]
     assert abs(cam_miou - ref_miou[0]) < 1e-9 and abs(seg_miou - ref_miou[2]) < 1e-9
