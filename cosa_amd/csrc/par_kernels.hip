@@ -265,10 +265,10 @@ __global__ __launch_bounds__(256) void par_step_kernel(const float *__restrict__
 // accumulators + 16 plane bases) so the occupancy that the 4-pixel kernel loses with wide groups stays.
 template <int NP>
 __device__ __forceinline__ void par_step1_body(const float *__restrict__ aff, const float *__restrict__ src, float *__restrict__ dst,
-                                               int b, int K, int j0, int nlive, int half_planes, size_t img_stride, int h, int w,
-                                               const ParPlan &plan)
+                                               int b, int pblk, int K, int j0, int nlive, int half_planes, size_t img_stride, int h,
+                                               int w, const ParPlan &plan)
 {
-    const int pix = blockIdx.x * 256 + threadIdx.x;
+    const int pix = pblk * 256 + threadIdx.x;
     const int hw = h * w;
     if (pix >= hw) return;
     const int y = pix / w, x = pix - y * w;
@@ -300,23 +300,40 @@ __device__ __forceinline__ void par_step1_body(const float *__restrict__ aff, co
         if (i < nlive) dst[(size_t)b * img_stride + po[i] + pix] = acc[i];
 }
 
+// Workgroup ids are dealt round-robin to the 8 XCDs (id & 7), each with its own L2.  The taps of a pixel reach +-24 rows, so with
+// pixel blocks of one image spread over all XCDs every L2 ends up fetching every mask plane (PMC: 506 MB of fetches per launch for
+// 154 MB of affinities + 38 MB of masks).  Images are therefore pinned to XCDs: id -> (xcd = id & 7, j = id >> 3), image =
+// 8 * (j / blocks_per_image) + xcd, so an L2 only ever sees the planes of "its" images.
 __global__ __launch_bounds__(256) void par_step1_kernel(const float *__restrict__ aff, const float *__restrict__ src,
                                                        float *__restrict__ dst, const int *__restrict__ kcount, int Kfull,
-                                                       int halves, int half_planes, size_t img_stride, int h, int w, ParPlan plan)
+                                                       int halves, int half_planes, size_t img_stride, int h, int w, ParPlan plan,
+                                                       int B, int pix_blocks, int groups, int pin)
 {
-    const int b = blockIdx.z;
+    const int id = blockIdx.x;
+    const int per_img = pix_blocks * groups;
+    int b, rem;
+    if (pin) {
+        const int xcd = id & 7, j = id >> 3, slot = j / per_img;
+        rem = j - slot * per_img;
+        b = slot * 8 + xcd;
+    } else {                                           // few images: spread every image over all XCDs instead
+        b = id / per_img;
+        rem = id - b * per_img;
+    }
+    if (b >= B) return;
+    const int grp = rem / pix_blocks, pblk = rem - grp * pix_blocks;
     const int K = kcount ? kcount[b] : Kfull;
     const int live = K * halves;
-    const int j0 = blockIdx.y * 16;
+    const int j0 = grp * 16;
     if (j0 >= live) return;
     int nlive = live - j0;
     nlive = nlive > 16 ? 16 : nlive;
-    if (nlive <= 2) par_step1_body<2>(aff, src, dst, b, K, j0, nlive, half_planes, img_stride, h, w, plan);
-    else if (nlive <= 4) par_step1_body<4>(aff, src, dst, b, K, j0, nlive, half_planes, img_stride, h, w, plan);
-    else if (nlive <= 6) par_step1_body<6>(aff, src, dst, b, K, j0, nlive, half_planes, img_stride, h, w, plan);
-    else if (nlive <= 8) par_step1_body<8>(aff, src, dst, b, K, j0, nlive, half_planes, img_stride, h, w, plan);
-    else if (nlive <= 12) par_step1_body<12>(aff, src, dst, b, K, j0, nlive, half_planes, img_stride, h, w, plan);
-    else par_step1_body<16>(aff, src, dst, b, K, j0, nlive, half_planes, img_stride, h, w, plan);
+    if (nlive <= 2) par_step1_body<2>(aff, src, dst, b, pblk, K, j0, nlive, half_planes, img_stride, h, w, plan);
+    else if (nlive <= 4) par_step1_body<4>(aff, src, dst, b, pblk, K, j0, nlive, half_planes, img_stride, h, w, plan);
+    else if (nlive <= 6) par_step1_body<6>(aff, src, dst, b, pblk, K, j0, nlive, half_planes, img_stride, h, w, plan);
+    else if (nlive <= 8) par_step1_body<8>(aff, src, dst, b, pblk, K, j0, nlive, half_planes, img_stride, h, w, plan);
+    else if (nlive <= 12) par_step1_body<12>(aff, src, dst, b, pblk, K, j0, nlive, half_planes, img_stride, h, w, plan);
+    else par_step1_body<16>(aff, src, dst, b, pblk, K, j0, nlive, half_planes, img_stride, h, w, plan);
 }
 
 // v2 propagation step: each thread owns FOUR consecutive pixels of up to PG live planes.  The affinity row is read once
@@ -504,9 +521,12 @@ int par_launch_step(const float *aff, const float *src, float *dst, int B, int K
     // COSA_PAR_SCALAR=0 brings back for A/B runs)
     static const int scalar = [] { const char *e = getenv("COSA_PAR_SCALAR"); return e ? atoi(e) : 1; }();
     if (scalar && (size_t)Kmax * h * w < (1ull << 31)) {
-        dim3 grid1((h * w + 255) / 256, (Kmax + 15) / 16, B);
-        hipLaunchKernelGGL(par_step1_kernel, grid1, dim3(256), 0, st, aff, src, dst, kcount, Kmax, halves, half_planes, plane_stride,
-                           h, w, plan);
+        const int pix_blocks = (h * w + 255) / 256, groups = (Kmax + 15) / 16;
+        const int pin = (B % 8 == 0 || B >= 24) ? 1 : 0;                  // balanced (or nearly) image count per XCD
+        const long long nblk = (pin ? 8ll * ((B + 7) / 8) : (long long)B) * pix_blocks * groups;
+        COSA_REQUIRE(nblk < 0x7fffffffll, "PAR: grid too large");
+        hipLaunchKernelGGL(par_step1_kernel, dim3((unsigned)nblk), dim3(256), 0, st, aff, src, dst, kcount, Kmax, halves, half_planes,
+                           plane_stride, h, w, plan, B, pix_blocks, groups, pin);
         COSA_LAUNCH_CHECK();
         return COSA_OK;
     }
