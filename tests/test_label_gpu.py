@@ -261,3 +261,23 @@ def test_errors_are_loud():
                             torch.ones(1, 2, device="cuda"), 0.7, 0.25, refine_model=lambda a, b: b)
     with pytest.raises(_C.CosaError):
         _C.check(_C.lib().cosa_cam_minmax_norm(None, 0, 0, None, None), "bad call")
+
+
+def test_bilateral_noise_and_smooth_images_in_one_batch(oracle_c):
+    """uniform-noise image (almost every pixel owns its lattice vertices: the content-dependent worst case) next to a smooth one in the
+    same batch: lattice sizes equal to the CPU oracle's, filtered values to 2e-5"""
+    from cosa_amd import _C
+    rng = np.random.default_rng(21)
+    N, K, H, W = 2, 5, 48, 64
+    img = np.stack([rng.uniform(0, 255, (3, H, W)), smooth(rng, 3, H, W) * 255]).astype(np.float32)
+    x = rng.uniform(0, 1, (N, K, H, W)).astype(np.float32)
+    L = _C.lib()
+    di, dx = dev(img), dev(x)
+    out = torch.empty_like(dx)
+    ws = _C.workspace(L.cosa_bilateral_workspace_bytes(N, K, H, W), di.device, "bilateral")
+    sizes = torch.zeros(N, dtype=torch.int32, device="cuda")
+    _C.check(L.cosa_bilateralfilter_batch_dev(_C.ptr(di), _C.ptr(dx), _C.ptr(out), N, K, H, W, 15.0, 50.0, _C.ptr(sizes), _C.ptr(ws),
+                                              ws.numel(), _C.stream_ptr()), "bilateral")
+    ref, M = oracle_c.bilateralfilter_batch(img, x, N, K, H, W, 15.0, 50.0)
+    np.testing.assert_allclose(out.cpu().numpy().reshape(-1), np.asarray(ref).reshape(-1), rtol=2e-5, atol=2e-6)
+    assert np.array_equal(sizes.cpu().numpy(), np.asarray(M)) and int(sizes[0]) > 2 * int(sizes[1])
