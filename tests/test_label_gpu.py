@@ -281,3 +281,29 @@ def test_bilateral_noise_and_smooth_images_in_one_batch(oracle_c):
     ref, M = oracle_c.bilateralfilter_batch(img, x, N, K, H, W, 15.0, 50.0)
     np.testing.assert_allclose(out.cpu().numpy().reshape(-1), np.asarray(ref).reshape(-1), rtol=2e-5, atol=2e-6)
     assert np.array_equal(sizes.cpu().numpy(), np.asarray(M)) and int(sizes[0]) > 2 * int(sizes[1])
+
+
+def test_cam2mask_multi_with_par_at_bench_size():
+    """size-independent property at BASELINE's configuration (b=16, 448^2, PAR T=10, 6 dilations): the shared pass over main + aux CAM
+    sets equals the two separate calls bit for bit (different plane groupings, XCD pinning and launch shapes), and the invariants hold"""
+    from cosa_amd.models.PAR import PAR
+    from cosa_amd.utils import seg_helper
+    rng = np.random.default_rng(9)
+    B, C, S = 16, 20, 448
+    up = lambda t: torch.nn.functional.interpolate(t.cuda(), size=(S, S), mode="bilinear")
+    g = torch.Generator().manual_seed(9)
+    cams = [up(torch.rand(B, C, S // 8, S // 8, generator=g)) for _ in range(2)]
+    img = up(torch.rand(B, 3, S // 4, S // 4, generator=g))
+    labels = torch.zeros(B, C, device="cuda")
+    for b in range(B):
+        labels[b, rng.choice(C, size=rng.integers(1, 5), replace=False)] = 1
+    boxes = torch.tensor([[0, S, 0, S]] * 8 + [[16, 400, 32, 432]] * 8, dtype=torch.int16)
+    par = PAR(num_iter=10, dilations=DIL)
+    ms = seg_helper.cam2mask_multi(img, boxes, cams, labels, [0.7, 0.6], [0.25, 0.3], refine_model=par, _fold_validation=True)
+    for i, (hi, lo) in enumerate(((0.7, 0.25), (0.6, 0.3))):
+        one = seg_helper.cam2mask(img, boxes, cams[i], labels, hi, lo, refine_model=par, _fold_validation=True)
+        assert torch.equal(one, ms[i])
+        assert torch.all(ms[i][8:, :16] == 255) and torch.all(ms[i][8:, :, 432:] == 255)
+        for b in range(B):
+            allowed = {0.0, 255.0} | {float(c + 1) for c in torch.nonzero(labels[b])[:, 0].tolist()}
+            assert set(torch.unique(ms[i][b]).tolist()) <= allowed
