@@ -68,11 +68,12 @@ class VITNetwork(nn.Module):
     batch_invariant_heads = False
 
     def __init__(self, backbone, num_classes, pretrained=True, aux_layer=-3, isgap=False, decoder='LargeFOV',
-                 compute_dtype=torch.bfloat16):
+                 compute_dtype=torch.bfloat16, pretrained_path=None):
         super().__init__()
         assert decoder in ['LargeFOV'], "cosa_amd builds the LargeFOV decoder (the run scripts' default)"
         self.num_classes = num_classes
-        self.encoder = getattr(vitencoder, backbone)(pretrained=pretrained, aux_layer=aux_layer, compute_dtype=compute_dtype)
+        self.encoder = getattr(vitencoder, backbone)(pretrained=pretrained, pretrained_path=pretrained_path, aux_layer=aux_layer,
+                                                     compute_dtype=compute_dtype)
         self.in_channels = [self.encoder.embed_dim] * 4
         self.isgap = isgap
         self.decoder = LargeFOV(in_planes=self.in_channels[-1], out_planes=self.num_classes)
@@ -122,11 +123,17 @@ class VITNetwork(nn.Module):
                 return y
         return F.linear(pooled, wgt).float()
 
+    def refresh_shadows(self):
+        """16-bit shadows of every parameter, current as of this call (nn_ops.ensure_shadows); a no-op in fp32 mode / on the host"""
+        if self.compute_dtype != torch.float32 and self.classifier.weight.is_cuda:
+            nn_ops.ensure_shadows(self, self.compute_dtype)
+
     def forward_multi(self, xs):
         """forward() for several image batches of different sizes at once (no-grad bf16 only): the encoder runs all of
         them through shared GEMM / LayerNorm launches (VisionTransformer._forward_features_fused_multi)."""
         for x in xs:
             _C.require_cuda(x)
+        self.refresh_shadows()
         feats = self.encoder._forward_features_fused_multi(xs)
         return [self._heads(x, f, False, False, 'none') for x, f in zip(xs, feats)]
 
@@ -137,6 +144,8 @@ class VITNetwork(nn.Module):
         """models/__init__.py:163-206 -> (cls, cls_aux, feat[B,768,h,w], seg, cam, cam_aux)"""
         assert detach in ['all', 'feat', 'none', 'cls']
         _C.require_cuda(x)                                            # MI355X only: there is no CPU path
+        if not torch.is_grad_enabled():
+            self.refresh_shadows()
         return self._heads(x, self.encoder.features_ex(x), cam_only, seg_only, detach)
 
     def _heads(self, x, feats, cam_only, seg_only, detach):
@@ -176,4 +185,5 @@ def build_model(args):
     dt = getattr(args, "compute_dtype", torch.bfloat16)
     return VITNetwork(backbone=args.backbone, num_classes=args.num_classes, pretrained=getattr(args, "pretrained", False),
                       aux_layer=args.aux_layer, isgap=getattr(args, "isgap", False),
-                      decoder=getattr(args, "decoder", "LargeFOV"), compute_dtype=dt)
+                      decoder=getattr(args, "decoder", "LargeFOV"), compute_dtype=dt,
+                      pretrained_path=getattr(args, "pretrained_path", None))

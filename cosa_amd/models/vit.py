@@ -241,9 +241,43 @@ class VisionTransformer(nn.Module):
         return x[:, 0], x[:, 1:], aux[:, 1:], None
 
 
-def vit_base_patch16_224(pretrained=False, **kwargs):
-    """models/vit/vit.py:365-377 (pretrained ImageNet weights need network access: load a state_dict instead)."""
+PRETRAINED_ENV = "COSA_VIT_PRETRAINED"        # path of a local timm ViT-B/16 checkpoint (jx_vit_base_p16_224-80ecf9dd.pth)
+
+
+def load_pretrained_vit(model, path, strict_keys=True):
+    """What timm's `load_pretrained(model, filter_fn=_conv_filter)` does for the reference (models/vit/vit.py:332-339,371-374), from a
+    LOCAL file: the checkpoint's keys are the module names used here (timm ViT names); a linear-shaped patch projection is reshaped
+    to the conv layout (`_conv_filter`); the 1000-way `head` is dropped when its shape differs (timm's `num_classes` handling)."""
+    sd = torch.load(path, map_location="cpu", weights_only=True)
+    sd = sd.get("model", sd.get("state_dict", sd))
+    out = {}
+    for k, v in sd.items():
+        if "patch_embed.proj.weight" in k:
+            v = v.reshape(v.shape[0], 3, model.patch_size, model.patch_size)
+        out[k] = v
+    own = model.state_dict()
+    for k in ("head.weight", "head.bias"):
+        if k in out and (k not in own or out[k].shape != own[k].shape):
+            out.pop(k)
+    missing, unexpected = model.load_state_dict(out, strict=False)
+    missing = [k for k in missing if not k.startswith("head.")]
+    if strict_keys and (missing or unexpected):
+        raise RuntimeError(f"load_pretrained_vit({path}): missing keys {missing}, unexpected keys {list(unexpected)}")
+    return model
+
+
+def vit_base_patch16_224(pretrained=False, pretrained_path=None, **kwargs):
+    """models/vit/vit.py:365-377.  The reference's `pretrained=True` downloads ImageNet weights through timm; there is no network
+    here, so the weights come from a local file (`pretrained_path`, or $COSA_VIT_PRETRAINED) -- and a run that asks for pretrained
+    weights without one FAILS instead of silently training from random initialisation."""
+    import os
+    model = VisionTransformer(patch_size=16, embed_dim=768, depth=12, num_heads=12, mlp_ratio=4, qkv_bias=True, eps=1e-6, **kwargs)
     if pretrained:
-        print("cosa_amd: pretrained=True ignored here (no network); load weights with load_state_dict()")
-    return VisionTransformer(patch_size=16, embed_dim=768, depth=12, num_heads=12, mlp_ratio=4, qkv_bias=True, eps=1e-6,
-                             **kwargs)
+        path = pretrained_path or os.environ.get(PRETRAINED_ENV)
+        if not path or not os.path.exists(path):
+            raise FileNotFoundError(
+                "vit_base_patch16_224(pretrained=True): no local checkpoint -- pass pretrained_path= or set $" + PRETRAINED_ENV +
+                " to timm's jx_vit_base_p16_224-80ecf9dd.pth (the file the reference downloads, models/vit/vit.py:53-56), "
+                "or build with pretrained=False")
+        load_pretrained_vit(model, path)
+    return model

@@ -275,19 +275,19 @@ def layernorm_f32(x, g, b, eps, want_bf16=True, want_f32=False):
 # --------------------------------------------------------------------------------------------
 # small helpers
 # --------------------------------------------------------------------------------------------
-_cast_cache = {}
-_shadows = {}          # id(param) -> persistent bf16 shadow (teacher weights; refreshed explicitly, hipGraph-safe)
+_shadows = {}          # id(param) -> (param, persistent 16-bit shadow at a fixed address; refreshed explicitly, hipGraph-safe)
 
 
 class ShadowSet:
-    """Persistent bf16 copies of a module's fp32 parameters, refreshed with ONE multi-tensor copy.
+    """Persistent 16-bit copies of a module's fp32 parameters, refreshed with ONE multi-tensor copy.
 
-    The teacher is read 6x per step and written once (EMA).  Keeping fixed-address bf16 shadows (a) casts every weight
+    The teacher is read 6x per step and written once (EMA).  Keeping fixed-address shadows (a) casts every weight
     exactly once per step and (b) makes the whole teacher pass capturable in a hipGraph: the refresh is the first node
     of the graph, the kernels after it read fixed addresses."""
 
     def __init__(self, module, dtype=torch.bfloat16):
         self.params = [p for p in module.parameters()]
+        self.dtype = dtype
         self.shadows = [torch.empty_like(p, dtype=dtype) for p in self.params]
         for p, s in zip(self.params, self.shadows):
             _shadows[id(p)] = (p, s)
@@ -298,27 +298,54 @@ class ShadowSet:
         torch._foreach_copy_(self.shadows, self.params)
 
 
+def ensure_shadows(module, dtype=torch.bfloat16):
+    """Shadows of ALL parameters of `module` (a VITNetwork, possibly DDP-wrapped), created on first use, and -- unless an optimizer
+    kernel keeps them current (`module._cosa_shadow_auto = False`, set by CoSATrainer with the fused AdamW+EMA step) -- refreshed
+    here with one multi-tensor copy.  Called at the start of every no-grad entry point (multi_scale_camseg*, evaluate,
+    VITNetwork.forward under no_grad), so weights written by ANY route (optimizer.step, load_state_dict, the reference loop's
+    `param.data.mul_().add_()` EMA, which does not bump `_version`) are seen by the next forward: nothing is cached by version."""
+    module = getattr(module, "module", module)
+    ss = module.__dict__.get("_cosa_shadowset")
+    if ss is not None and shadows_fresh.depth > 0:
+        return ss
+    if ss is None or ss.dtype != dtype or any(a is not b for a, b in zip(ss.params, module.parameters())) \
+            or (ss.params and ss.params[0].device != ss.shadows[0].device):
+        ss = ShadowSet(module, dtype)
+        module.__dict__["_cosa_shadowset"] = ss
+        return ss
+    if module.__dict__.get("_cosa_shadow_auto", True):
+        ss.refresh()
+    return ss
+
+
+class shadows_fresh:
+    """`with shadows_fresh():` -- nested no-grad entry points skip their own refresh (one refresh per multi-scale pass, not per scale)"""
+    depth = 0
+
+    def __enter__(self):
+        shadows_fresh.depth += 1
+
+    def __exit__(self, *exc):
+        shadows_fresh.depth -= 1
+
+
 def shadow_of(p):
     ent = _shadows.get(id(p))
     return ent[1] if ent is not None and ent[0] is p else None
 
 
 def cast_param(p, dtype):
-    """bf16 view of an fp32 master parameter.  Registered shadows (teacher) are returned as they are; with grad the
-    cast is differentiable (student); otherwise cached per parameter version."""
+    """16-bit view of an fp32 master parameter.  Registered shadows are returned as they are (no-grad paths); with grad the
+    cast is differentiable (student); a parameter without a shadow is cast on every call -- no version-keyed cache (in-place
+    writes through `.data` or raw pointers do not bump `_version`)."""
     if p.dtype == dtype:
         return p
-    ent = _shadows.get(id(p))
-    if ent is not None and ent[0] is p and ent[1].dtype == dtype and not (torch.is_grad_enabled() and p.requires_grad):
-        return ent[1]
     if torch.is_grad_enabled() and p.requires_grad:
         return p.to(dtype)
-    key = id(p)
-    ent = _cast_cache.get(key)
-    if ent is None or ent[0] != p._version or ent[1].device != p.device or ent[2] is not p:
-        ent = (p._version, p.detach().to(dtype), p)
-        _cast_cache[key] = ent
-    return ent[1]
+    ent = _shadows.get(id(p))
+    if ent is not None and ent[0] is p and ent[1].dtype == dtype and ent[1].device == p.device:
+        return ent[1]
+    return p.detach().to(dtype)
 
 
 _MM_OUT_DTYPE = None      # does torch.mm(bf16, bf16, out_dtype=fp32) work on this build?  probed on first use

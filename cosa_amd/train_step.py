@@ -103,15 +103,19 @@ class CoSATrainer:
             self.ema_auxlowthre = torch_helper.EMAtracker(args.low_thre_aux, decay=args.gmmemadecay)
             self.ema_auxhighthre = torch_helper.EMAtracker(args.high_thre_aux, decay=args.gmmemadecay)
         self._ema_pairs = (list(self.model_AN.parameters()), list(self.student.parameters()))
-        # teacher: fixed-address bf16 shadow weights + (optionally) the whole multi-scale pass as one hipGraph
-        self._shadows = nn_ops.ShadowSet(self.model_AN) if args.compute_dtype == torch.bfloat16 and device.type == "cuda" else None
-        # student: bf16 shadows of the big projection weights, refreshed once per step after AdamW
-        self._student_shadows = nn_ops.ShadowSet(self.student.encoder.blocks) if self._shadows is not None else None
-        # AdamW + EMA + shadow refresh as one multi-tensor kernel
+        # fixed-address 16-bit shadows of EVERY parameter of both networks (teacher: read by the six no-grad passes of a step and by
+        # evaluation; student: the block projections of the training forward, everything in evaluation)
+        on = args.compute_dtype == torch.bfloat16 and device.type == "cuda"
+        self._shadows = nn_ops.ensure_shadows(self.model_AN) if on else None
+        self._student_shadows = nn_ops.ensure_shadows(self.student) if on else None
+        # AdamW + EMA + shadow refresh as one multi-tensor kernel: it rewrites every shadow each step, so the no-grad entry points
+        # need not refresh them (nn_ops.ensure_shadows); without it they do
         self._fused_step = None
-        if self._shadows is not None and getattr(args, "fused_optimizer", True):
+        if on and getattr(args, "fused_optimizer", True):
             self._fused_step = torch_helper.FusedAdamWEMAStep(self.optimizer, self._ema_pairs[1], self._ema_pairs[0], args.momentum,
                                                               shadow_of=nn_ops.shadow_of)
+        for m in (self.student, self.model_AN):
+            m.__dict__["_cosa_shadow_auto"] = self._fused_step is None
         self.use_graph = bool(getattr(args, "teacher_graph", True)) and self._shadows is not None
         self.fused_losses = bool(getattr(args, "fused_losses", True)) and device.type == "cuda" and not args.after_softmax
         self._graph = None
@@ -131,8 +135,6 @@ class CoSATrainer:
             self._graph_calls += 1
             for st in sts:
                 st.reset()
-            if self._shadows is not None and self._fused_step is None:
-                self._shadows.refresh()
             return seg_helper.multi_scale_camseg(self.model_AN, wimg, args.pseudo_scales, _active_labels=act,
                                                   _seg_scales=self.fused_losses)
         if self._graph is None:
@@ -143,8 +145,6 @@ class CoSATrainer:
             with torch.cuda.graph(g, capture_error_mode="thread_local"):   # RCCL's watchdog thread may poll events meanwhile
                 for st in sts:
                     st.reset()
-                if self._fused_step is None:
-                    self._shadows.refresh()
                 self._s_out = seg_helper.multi_scale_camseg(self.model_AN, self._s_wimg, args.pseudo_scales,
                                                             _active_labels=None if args.use_cammix else self._s_lab,
                                                             _seg_scales=self.fused_losses)
@@ -180,8 +180,11 @@ class CoSATrainer:
         red = seg_helper.cell_bilinear(cams, self.args.crop_size // self.args.gmmscale) * cls_label[:, :, None, None]
         queue.update(red.amax(dim=1))
         fit = seg_helper.rungmm_device(queue.getqueue(), 3, filter_thre)
-        ema_low.update(fit[0])
-        ema_high.update(fit[1])
+        # status word (include/cosa_hip.h): any bit set -- empty component, too few samples, expired grid barrier -- means the fit's
+        # numbers may be finite but wrong; the trackers then keep their value (EMAtracker skips non-finite updates)
+        bad = torch.full((), float("nan"), device=fit.device, dtype=fit.dtype)
+        ema_low.update(torch.where(fit[3] == 0, fit[0], bad))
+        ema_high.update(torch.where(fit[3] == 0, fit[1], bad))
         return ema_low.get(), ema_high.get()
 
     # main.py:114-252 -------------------------------------------------------------------------------

@@ -10,8 +10,15 @@ import torch
 import torch.nn.functional as F
 from torch.autograd import Function
 
-from .. import _C
+from .. import _C, nn_ops
 from ..models.PAR import PAR
+
+
+def _refresh_once(model):
+    """bring the network's 16-bit weight shadows up to date once per multi-scale pass (see nn_ops.ensure_shadows)"""
+    f = getattr(getattr(model, "module", model), "refresh_shadows", None)
+    if f is not None:
+        f()
 
 
 # --------------------------------------------------------------------------------------------
@@ -57,8 +64,11 @@ def multi_scale_camseg(model, imgs, scales, _active_labels=None, _seg_scales=Fal
             inputs.append(torch.cat([imgs_, imgs_.flip(-1)], dim=0))
         # cosa_amd networks can take all scales in one go (shared GEMM/LayerNorm launches across scales)
         multi = model.forward_multi(inputs) if getattr(model, "can_forward_multi", lambda _x: False)(inputs[0]) else None
+        if multi is None:
+            _refresh_once(model)
         for si, s in enumerate(scales):
-            _, _, _, _seg, _cam, _cam_aux = multi[si] if multi is not None else model(inputs[si], cam_only=False)
+            with nn_ops.shadows_fresh():
+                _, _, _, _seg, _cam, _cam_aux = multi[si] if multi is not None else model(inputs[si], cam_only=False)
             if cam is None:
                 cam = torch.empty((b, _cam.shape[1], h, w), device=imgs.device, dtype=torch.float32)
                 cam_aux = torch.empty_like(cam)
@@ -91,8 +101,11 @@ def multi_scale_camsegv3(model, imgs, scales, getcls=False, _per_image_cls=False
             imgs_ = imgs if s == 1.0 else F.interpolate(imgs, size=(int(s * h), int(s * w)), mode='bilinear', align_corners=False)
             inputs.append(torch.cat([imgs_, imgs_.flip(-1)], dim=0))
         multi = model.forward_multi(inputs) if getattr(model, "can_forward_multi", lambda _x: False)(inputs[0]) else None
+        if multi is None:
+            _refresh_once(model)
         for si, s in enumerate(scales):
-            cls_f, cls_a, _, _seg, _cam, _cam_aux = multi[si] if multi is not None else model(inputs[si], cam_only=False)
+            with nn_ops.shadows_fresh():
+                cls_f, cls_a, _, _seg, _cam, _cam_aux = multi[si] if multi is not None else model(inputs[si], cam_only=False)
             if cam is None:
                 cam = torch.empty((b, _cam.shape[1], h, w), device=imgs.device, dtype=torch.float32)
                 cam_aux = torch.empty_like(cam)
@@ -202,6 +215,38 @@ def cam2mask(images, img_boxes, cams, cls_labels, threshold_high, threshold_low,
                           ignore_index=ignore_index, downscale=downscale, _fold_validation=_fold_validation)[0]
 
 
+def _cam2mask_generic(images, img_boxes, cams, cls_labels, threshold_high, threshold_low, refine_model, ignore_index, downscale):
+    """utils/seg_helper.py:721-797 as written there (per-image loop, torch ops on the device), for what the fused kernels do not
+    cover: an arbitrary callable `refine_model`, non-square crops, other downscale factors.  `cams` are the validated CAMs."""
+    b, _, h, w = images.shape
+    dev = cams.device
+    size = [h // downscale, w // downscale] if downscale else None
+    rs = (lambda t: F.interpolate(t, size=size, mode="bilinear", align_corners=False)) if downscale else (lambda t: t)
+    _images = rs(images.float())
+    plane = torch.ones((b, 1, h, w), device=dev)
+    hi = torch.as_tensor(threshold_high, device=dev, dtype=torch.float32)
+    lo = torch.as_tensor(threshold_low, device=dev, dtype=torch.float32)
+    cams_h, cams_l = rs(torch.cat([plane * hi, cams], dim=1)), rs(torch.cat([plane * lo, cams], dim=1))
+    with_bkg = torch.cat([torch.ones((b, 1), device=dev), cls_labels.float()], dim=1)
+    out_h = torch.full((b, h, w), float(ignore_index), device=dev)
+    out_l = out_h.clone()
+
+    def refine(img, act, keys):
+        r = refine_model(img, act) if refine_model is not None else act
+        r = F.interpolate(r, size=(h, w), mode="bilinear", align_corners=False)
+        return keys[r.argmax(dim=1)]
+
+    boxes = torch.as_tensor(img_boxes).tolist()
+    for i, (y0, y1, x0, x1) in enumerate(boxes):
+        keys = torch.nonzero(with_bkg[i])[:, 0]
+        out_h[i, y0:y1, x0:x1] = refine(_images[[i]], cams_h[i, keys].unsqueeze(0).softmax(dim=1), keys)[0, y0:y1, x0:x1].float()
+        out_l[i, y0:y1, x0:x1] = refine(_images[[i]], cams_l[i, keys].unsqueeze(0).softmax(dim=1), keys)[0, y0:y1, x0:x1].float()
+    mask = out_h.clone()
+    mask[out_h == 0] = ignore_index
+    mask[(out_h + out_l) == 0] = 0
+    return mask
+
+
 def cam2mask_multi(images, img_boxes, cams_list, cls_labels, thresholds_high, thresholds_low, refine_model=None, ignore_index=255,
                    downscale=2, _fold_validation=False):
     """cam2mask for several CAM sets of the SAME images (the training step's main and auxiliary CAMs, main.py:137-166) in
@@ -212,13 +257,16 @@ def cam2mask_multi(images, img_boxes, cams_list, cls_labels, thresholds_high, th
         raise ValueError("cam2mask_multi: one (high, low) threshold pair per CAM set")
     _C.require_cuda(cls_labels, *cams_list)
     b, _, h, w = images.shape
-    if h != w:
-        raise ValueError("cam2mask: square crops only")
-    if downscale not in (0, 2, None, False):
-        raise NotImplementedError("cam2mask: downscale must be 0 or 2 (reference default 2)")
+    generic = (refine_model is not None and not isinstance(refine_model, PAR)) or h != w or downscale not in (0, 2, None, False)
+    if generic:
+        # any other callable refine model (the reference accepts whatever `refine_model(images, cams)` returns,
+        # utils/seg_helper.py:787-792), non-square crops and other downscale factors: the reference's per-image loop on the GPU
+        if refine_model is not None and not callable(refine_model):
+            raise TypeError("cam2mask: refine_model must be None or a callable (images[1,3,h,w], cams[1,K,h,w]) -> [1,K,h',w']")
+        return [_cam2mask_generic(images, img_boxes, c.float() * cls_labels[:, :, None, None] if _fold_validation else c.float(),
+                                  cls_labels, th, tl, refine_model, ignore_index, downscale)
+                for c, th, tl in zip(cams_list, thresholds_high, thresholds_low)]
     downscale = 2 if downscale == 2 else 0
-    if refine_model is not None and not isinstance(refine_model, PAR):
-        raise TypeError("cam2mask: refine_model must be None or cosa_amd.models.PAR.PAR")
     cams_list = [c.contiguous().float() for c in cams_list]
     cls_labels = cls_labels.contiguous().float()
     C = cams_list[0].shape[1]

@@ -115,8 +115,15 @@ class FusedAdamWEMAStep:
         self.group_idx = [group_of.get(id(p), -1) for p in self.student]
         shadow_of = shadow_of or (lambda p: None)
         n = len(self.student)
-        self.host = torch.zeros(n * self.rec_dtype.itemsize, dtype=torch.uint8).pin_memory()
-        self.rec = self.host.numpy().view(self.rec_dtype)
+        # The trainer has no per-step host sync, so the host may run steps ahead of the GPU: the record table (gradient pointers,
+        # scheduled lr / wd) is therefore kept in a ring of kRing pinned host tables + device tables.  Slot s is rewritten only after
+        # the event recorded behind the H2D copy that last read it has completed, and every step's kernel reads its own device table.
+        self.kRing = 4
+        self.hosts = [torch.zeros(n * self.rec_dtype.itemsize, dtype=torch.uint8).pin_memory() for _ in range(self.kRing)]
+        self.recs = [h.numpy().view(self.rec_dtype) for h in self.hosts]
+        self.copied = [None] * self.kRing
+        self.slot = 0
+        self.rec = self.recs[0]
         self._step_t = torch.tensor(0.0)
         chunk = L.cosa_optim_chunk_elems()
         chunks = []
@@ -137,7 +144,9 @@ class FusedAdamWEMAStep:
             chunks += [(i, c) for c in range((p.numel() + chunk - 1) // chunk)]
         self.n_chunks = len(chunks)
         self.d_chunks = torch.tensor(chunks, dtype=torch.int32, device=dev).contiguous()
-        self.d_rec = torch.empty(n * self.rec_dtype.itemsize, dtype=torch.uint8, device=dev)
+        for r in self.recs[1:]:
+            r[:] = self.recs[0]
+        self.d_recs = [torch.empty(n * self.rec_dtype.itemsize, dtype=torch.uint8, device=dev) for _ in range(self.kRing)]
 
     def step(self):
         opt = self.opt
@@ -146,7 +155,11 @@ class FusedAdamWEMAStep:
             for i, g in enumerate(opt.param_groups):
                 g["lr"] = opt._init_lr[i] * mult
         groups = opt.param_groups
-        rec = self.rec
+        slot = self.slot
+        self.slot = (slot + 1) % self.kRing
+        if self.copied[slot] is not None:
+            self.copied[slot].synchronize()            # the copy issued kRing steps ago; never waits in practice
+        rec, d_rec = self.recs[slot], self.d_recs[slot]
         for i, p in enumerate(self.student):
             gi = self.group_idx[i]
             if gi >= 0 and p.grad is not None:
@@ -155,11 +168,14 @@ class FusedAdamWEMAStep:
                 rec[i]["wd"] = groups[gi]["weight_decay"]
             else:
                 rec[i]["g"] = 0
-        self.d_rec.copy_(self.host, non_blocking=True)
+        d_rec.copy_(self.hosts[slot], non_blocking=True)
+        if self.copied[slot] is None:
+            self.copied[slot] = torch.cuda.Event()
+        self.copied[slot].record()
         b1, b2 = groups[0]["betas"]
         opt.global_step += 1
         self._step_t.fill_(float(opt.global_step))
-        _C.check(_C.lib().cosa_fused_adamw_ema(_C.ptr(self.d_rec), _C.ptr(self.d_chunks), self.n_chunks, float(b1), float(b2),
+        _C.check(_C.lib().cosa_fused_adamw_ema(_C.ptr(d_rec), _C.ptr(self.d_chunks), self.n_chunks, float(b1), float(b2),
                                                float(groups[0]["eps"]), int(opt.global_step), self.momentum, _C.stream_ptr()),
                  "cosa_fused_adamw_ema")
 
