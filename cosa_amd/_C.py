@@ -90,8 +90,33 @@ _SIGS = {
                       c_size_t, c_void_p]),
 }
 
+_SIGS.update({
+    "cosa_split_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, ctypes.c_longlong, c_int, c_void_p]),
+    "cosa_layernorm_split": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
+    "cosa_gemm_bf16x3": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "cosa_attn_fwd_bf16x3": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_int, c_void_p]),
+})
+
+# the fp16-operand builds of the GEMM / attention translation units export the same signatures under *_f16 names
+for _bf, _f in (("cosa_gemm_bf16", "cosa_gemm_f16"), ("cosa_gemm_wgrad_bf16", "cosa_gemm_wgrad_f16"), ("cosa_layernorm", "cosa_layernorm_f16"),
+                ("cosa_conv3x3_dilated_nhwc", "cosa_conv3x3_dilated_nhwc_f16"), ("cosa_conv3x3_dilated_wgrad", "cosa_conv3x3_dilated_wgrad_f16"),
+                ("cosa_gemm_set_variant", "cosa_gemm_set_variant_f16"), ("cosa_gemm_set_stamp_slot", "cosa_gemm_set_stamp_slot_f16"),
+                ("cosa_attn_workspace_bytes", "cosa_attn_workspace_bytes_f16"), ("cosa_attn_prepare_vt", "cosa_attn_prepare_vt_f16"),
+                ("cosa_attn_fwd", "cosa_attn_fwd_f16"), ("cosa_attn_bwd_workspace_bytes", "cosa_attn_bwd_workspace_bytes_f16"),
+                ("cosa_attn_bwd", "cosa_attn_bwd_f16")):
+    _SIGS[_f] = _SIGS[_bf]
+
 # entry points added by later translation units register themselves here (vit / gemm / attention)
 EXTRA_SIGS = {}
+
+
+def fn16(name, dtype):
+    """the entry point `name` for 16-bit operands of torch dtype `dtype`: bf16 -> name, fp16 -> its *_f16 twin"""
+    if dtype == torch.bfloat16:
+        return getattr(lib(), name)
+    if dtype == torch.float16:
+        return getattr(lib(), {"cosa_gemm_bf16": "cosa_gemm_f16", "cosa_gemm_wgrad_bf16": "cosa_gemm_wgrad_f16"}.get(name, name + "_f16"))
+    raise CosaError(f"{name}: operands must be bfloat16 or float16, got {dtype}")
 
 
 def lib():

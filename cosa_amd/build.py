@@ -32,9 +32,13 @@ SOURCES = {
     "gmm_kernels.hip": EXACT,
     "aug_kernels.hip": EXACT,
     "vit_kernels.hip": FAST,
+    "split_kernels.hip": ["-ffp-contract=off"],
     "gemm_kernels.hip": FAST,
     "attn_kernels.hip": FAST + ["-fno-honor-nans"],    # drops the canonicalising v_max the compiler puts in front of fmaxf
     "loss_kernels.hip": FAST,
+    # the same two files with fp16 operands (entry points *_f16, cosa_amd/csrc/op16.hpp)
+    "gemm_kernels.hip@f16": FAST + ["-DCOSA_OP_F16=1"],
+    "attn_kernels.hip@f16": FAST + ["-fno-honor-nans", "-DCOSA_OP_F16=1"],
     "optim_kernels.hip": ["-ffp-contract=off"],
 }
 
@@ -57,17 +61,18 @@ def build_all(force=False, verbose=False):
     headers.append(os.path.join(HERE, "..", "include", "cosa_hip.h"))
     hdr_time = max(os.path.getmtime(h) for h in headers)
     objs, relink, procs = [], force, []
-    for src, extra in SOURCES.items():
+    for key, extra in SOURCES.items():
+        src, _, tag = key.partition("@")
         sp = os.path.join(CSRC, src)
         if not os.path.exists(sp):
             continue
-        op = os.path.join(OBJDIR, src.replace(".hip", ".o"))
+        op = os.path.join(OBJDIR, src.replace(".hip", ("_" + tag if tag else "") + ".o"))
         objs.append(op)
         if force or _newer(sp, op) or os.path.getmtime(op) < hdr_time:
             cmd = [hipcc, "-c", sp, "-o", op] + COMMON + extra
             if verbose:
                 print(" ".join(cmd))
-            procs.append((src, subprocess.Popen(cmd)))
+            procs.append((key, subprocess.Popen(cmd)))
             relink = True
     for src, p in procs:
         if p.wait() != 0:

@@ -4,7 +4,7 @@
 // sequence lengths 197 / 785 / 1765 (+3601 at 640 crops).  The reference materialises the
 // [B,12,N,N] score tensor; here it never leaves the CU.
 //
-// Layouts (bf16):  qkv [B, N, 3, H, 64]  (straight out of the qkv projection, no permute copy)
+// Layouts (op16):  qkv [B, N, 3, H, 64]  (straight out of the qkv projection, no permute copy)
 //                  (V is read in place: the PV product fetches its V^T fragments with the transposing LDS read, no V^T copy)
 //                  out [B, N, H*64]      (what the output projection consumes)
 //                  lse [B, H, N] f32     natural-log sum-exp of the scaled scores (for backward)
@@ -15,15 +15,13 @@
 // exponentiated tile is already the B operand of O^T = V^T P^T (no LDS round trip, no shuffles),
 // and the O rescale / final 1/l are lane-local.
 #include "kernels.hpp"
+#include "op16.hpp"
 #include <type_traits>
 #include <cstdlib>
 
 namespace cosa {
 namespace {
 
-typedef __bf16 bf16;
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int HD = 64;           // head dim
@@ -38,12 +36,12 @@ typedef short s16x4v __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s16x4v lds_s16x4v;
 typedef __attribute__((address_space(3))) void lds_void_a;
 __device__ __forceinline__ int vsw(int row) { return ((row >> 1) & 1) << 2; }
-__device__ __forceinline__ bf16x8 v_frag(const unsigned char *Vs, int keyb, int dhalf, int lane)
+__device__ __forceinline__ op16x8 v_frag(const unsigned char *Vs, int keyb, int dhalf, int lane)
 {
     const int nn = lane & 15, grp = (lane >> 4) & 1;
     const int r0 = keyb + (nn >> 2), r1 = r0 + 8;
     const int ch = dhalf * 4 + grp * 2 + ((nn & 3) >> 1), off = 8 * (nn & 1);
-    union { s16x4v h[2]; bf16x8 v; } u;
+    union { s16x4v h[2]; op16x8 v; } u;
     u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4v *)(Vs + r0 * 128 + ((ch ^ vsw(r0)) << 4) + off));
     u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4v *)(Vs + r1 * 128 + ((ch ^ vsw(r1)) << 4) + off));
     return u.v;
@@ -68,8 +66,8 @@ __device__ __forceinline__ bool attn_block_map(int nblk, int ngroups, int H, int
 }
 
 // ---- forward -----------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16 *__restrict__ qkv, const bf16 *__restrict__ vt,
-                                                      bf16 *__restrict__ out, float *__restrict__ lse,
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const op16 *__restrict__ qkv, const op16 *__restrict__ vt,
+                                                      op16 *__restrict__ out, float *__restrict__ lse,
                                                       int N, int Npad, int H, int nblk, int ngroups, float scale_log2e,
                                                       unsigned long long *__restrict__ stamps)
 {
@@ -87,18 +85,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16 *__restrict__ 
 
     // Q fragments: B operand of S^T = K Q^T  (lane: query r, d = 16s + 8hh + j)
     const int qrow = min(q0 + r, N - 1);
-    const bf16 *qp = qkv + ((size_t)b * N + qrow) * rs + h * HD + 8 * hh;
-    bf16x8 qf[4];
+    const op16 *qp = qkv + ((size_t)b * N + qrow) * rs + h * HD + 8 * hh;
+    op16x8 qf[4];
 #pragma unroll
-    for (int s = 0; s < 4; s++) qf[s] = *reinterpret_cast<const bf16x8 *>(qp + 16 * s);
+    for (int s = 0; s < 4; s++) qf[s] = *reinterpret_cast<const op16x8 *>(qp + 16 * s);
 
     f32x16 o0, o1;
 #pragma unroll
     for (int i = 0; i < 16; i++) { o0[i] = 0.f; o1[i] = 0.f; }
     float m = -INFINITY, l = 0.f;
 
-    const bf16 *kbase = qkv + (size_t)b * N * rs + (size_t)H * HD + h * HD;      // k part
-    const bf16 *vbase = kbase + (size_t)H * HD;                                   // v part, same row stride
+    const op16 *kbase = qkv + (size_t)b * N * rs + (size_t)H * HD + h * HD;      // k part
+    const op16 *vbase = kbase + (size_t)H * HD;                                   // v part, same row stride
     const int swz = (r >> 1) & 7;
 
     // register-staged software pipeline: the next tile's global loads are in flight while this tile computes
@@ -130,10 +128,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16 *__restrict__ 
 #pragma unroll
         for (int s = 0; s < 4; s++) {
             const int slot = ((2 * s + hh) ^ swz) << 4;
-            const bf16x8 a0 = *reinterpret_cast<const bf16x8 *>(Ks + r * 128 + slot);
-            const bf16x8 a1 = *reinterpret_cast<const bf16x8 *>(Ks + (r + 32) * 128 + slot);
-            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, qf[s], s0, 0, 0, 0);
-            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, qf[s], s1, 0, 0, 0);
+            const op16x8 a0 = *reinterpret_cast<const op16x8 *>(Ks + r * 128 + slot);
+            const op16x8 a1 = *reinterpret_cast<const op16x8 *>(Ks + (r + 32) * 128 + slot);
+            s0 = COSA_MFMA_32x32x16(a0, qf[s], s0, 0, 0, 0);
+            s1 = COSA_MFMA_32x32x16(a1, qf[s], s1, 0, 0, 0);
         }
         // online softmax with the query on the lane; raw-score max, scale folded into the exp2 argument (one fma)
         if constexpr (tail) {
@@ -169,12 +167,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16 *__restrict__ 
         for (int kb = 0; kb < 2; kb++) {
 #pragma unroll
             for (int sp = 0; sp < 2; sp++) {
-                bf16x8 pf;
+                op16x8 pf;
 #pragma unroll
-                for (int j = 0; j < 8; j++) pf[j] = (bf16)(kb == 0 ? s0[8 * sp + j] : s1[8 * sp + j]);
+                for (int j = 0; j < 8; j++) pf[j] = (op16)(kb == 0 ? s0[8 * sp + j] : s1[8 * sp + j]);
                 const int keyb = kb * 32 + 16 * sp + 4 * hh;
-                o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v_frag(Vs, keyb, 0, lane), pf, o0, 0, 0, 0);
-                o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v_frag(Vs, keyb, 1, lane), pf, o1, 0, 0, 0);
+                o0 = COSA_MFMA_32x32x16(v_frag(Vs, keyb, 0, lane), pf, o0, 0, 0, 0);
+                o1 = COSA_MFMA_32x32x16(v_frag(Vs, keyb, 1, lane), pf, o1, 0, 0, 0);
             }
         }
     };
@@ -187,14 +185,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16 *__restrict__ 
     const float inv = 1.0f / l;
     const int q = q0 + r;
     if (q < N) {
-        bf16 *op = out + ((size_t)b * N + q) * H * HD + h * HD;
+        op16 *op = out + ((size_t)b * N + q) * H * HD + h * HD;
 #pragma unroll
         for (int g = 0; g < 4; g++) {
-            bf16x4 v0, v1;
+            op16x4 v0, v1;
 #pragma unroll
-            for (int j = 0; j < 4; j++) { v0[j] = (bf16)(o0[4 * g + j] * inv); v1[j] = (bf16)(o1[4 * g + j] * inv); }
-            *reinterpret_cast<bf16x4 *>(op + 8 * g + 4 * hh) = v0;
-            *reinterpret_cast<bf16x4 *>(op + 32 + 8 * g + 4 * hh) = v1;
+            for (int j = 0; j < 4; j++) { v0[j] = (op16)(o0[4 * g + j] * inv); v1[j] = (op16)(o1[4 * g + j] * inv); }
+            *reinterpret_cast<op16x4 *>(op + 8 * g + 4 * hh) = v0;
+            *reinterpret_cast<op16x4 *>(op + 32 + 8 * g + 4 * hh) = v1;
         }
         if (hh == 0) lse[((size_t)b * H + h) * N + q] = (m + __builtin_amdgcn_logf(l)) * 0.6931471805599453f;
     }
@@ -205,6 +203,180 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16 *__restrict__ 
 }
 
 
+#if !COSA_OP_F16
+// ---- forward with bf16x3 ("split") operands: the parity-grade no-grad passes ------------------------------------------------------
+// Same algorithm and lane mapping as attn_fwd_kernel; q, k, v and the probabilities are carried as hi + lo bf16 halves (16 significant
+// bits) and every product is the three MFMA terms hi*hi + hi*lo + lo*hi with fp32 accumulation:
+//     S^T  = K_h Q_h^T + K_h Q_l^T + K_l Q_h^T          O^T += V_h^T P_h^T + V_h^T P_l^T + V_l^T P_h^T
+// qkv rows are the split output of the qkv projection: [hi (3*H*64) | lo (3*H*64)], row stride ldq; the output rows are split rows for
+// the output projection: [hi (H*64) | lo (H*64) | aug (1, 1, 0, ...)], row stride ldo (gemm_kernels.hip: split_tile_x / split_tile_w).
+__global__ __launch_bounds__(256) void attn_fwd_x3_kernel(const op16 *__restrict__ qkv, op16 *__restrict__ out, float *__restrict__ lse,
+                                                         int N, int H, int nblk, int ngroups, float scale_log2e, int ldq, int ldo)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * BK * 128];
+    unsigned char *Kh = smem, *Kl = smem + BK * 128, *Vh = smem + 2 * BK * 128, *Vl = smem + 3 * BK * 128;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
+    int blk, b, h;
+    if (!attn_block_map(nblk, ngroups, H, blk, b, h)) return;
+    const int q0 = blk * BQ + wave * 32;
+    const size_t rs = (size_t)ldq;
+    const size_t lo_off = (size_t)3 * H * HD;
+
+    const int qrow = min(q0 + r, N - 1);
+    const op16 *qp = qkv + ((size_t)b * N + qrow) * rs + h * HD + 8 * hh;
+    op16x8 qh[4], ql[4];
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        qh[s] = *reinterpret_cast<const op16x8 *>(qp + 16 * s);
+        ql[s] = *reinterpret_cast<const op16x8 *>(qp + lo_off + 16 * s);
+    }
+    f32x16 o0, o1;
+#pragma unroll
+    for (int i = 0; i < 16; i++) { o0[i] = 0.f; o1[i] = 0.f; }
+    float m = -INFINITY, l = 0.f;
+
+    const op16 *kbase = qkv + (size_t)b * N * rs + (size_t)H * HD + h * HD;
+    const op16 *vbase = kbase + (size_t)H * HD;
+    const int swz = (r >> 1) & 7;
+    uint4 kr[4], vr[4];                                   // [hi row_a, hi row_b, lo row_a, lo row_b]
+    const int row_a = tid >> 3, row_b = (tid + 256) >> 3, slot_s = tid & 7;
+#define COSA_LOAD_TILE3(K0)                                                                                          \
+    do {                                                                                                             \
+        const size_t ra_ = (size_t)min((K0) + row_a, N - 1) * rs + slot_s * 8, rb_ = (size_t)min((K0) + row_b, N - 1) * rs + slot_s * 8; \
+        kr[0] = *reinterpret_cast<const uint4 *>(kbase + ra_);                                                       \
+        kr[1] = *reinterpret_cast<const uint4 *>(kbase + rb_);                                                       \
+        kr[2] = *reinterpret_cast<const uint4 *>(kbase + lo_off + ra_);                                              \
+        kr[3] = *reinterpret_cast<const uint4 *>(kbase + lo_off + rb_);                                              \
+        vr[0] = *reinterpret_cast<const uint4 *>(vbase + ra_);                                                       \
+        vr[1] = *reinterpret_cast<const uint4 *>(vbase + rb_);                                                       \
+        vr[2] = *reinterpret_cast<const uint4 *>(vbase + lo_off + ra_);                                              \
+        vr[3] = *reinterpret_cast<const uint4 *>(vbase + lo_off + rb_);                                              \
+    } while (0)
+    COSA_LOAD_TILE3(0);
+    const float NEG_INF = -INFINITY;
+    auto tile = [&](int k0, auto tail_tag) {
+        constexpr bool tail = decltype(tail_tag)::value;
+        __syncthreads();
+        const int ka = row_a * 128 + ((slot_s ^ ((row_a >> 1) & 7)) << 4), kb_ = row_b * 128 + ((slot_s ^ ((row_b >> 1) & 7)) << 4);
+        const int va = row_a * 128 + ((slot_s ^ vsw(row_a)) << 4), vb = row_b * 128 + ((slot_s ^ vsw(row_b)) << 4);
+        *reinterpret_cast<uint4 *>(Kh + ka) = kr[0];
+        *reinterpret_cast<uint4 *>(Kh + kb_) = kr[1];
+        *reinterpret_cast<uint4 *>(Kl + ka) = kr[2];
+        *reinterpret_cast<uint4 *>(Kl + kb_) = kr[3];
+        *reinterpret_cast<uint4 *>(Vh + va) = vr[0];
+        *reinterpret_cast<uint4 *>(Vh + vb) = vr[1];
+        *reinterpret_cast<uint4 *>(Vl + va) = vr[2];
+        *reinterpret_cast<uint4 *>(Vl + vb) = vr[3];
+        __syncthreads();
+        if (k0 + BK < N) COSA_LOAD_TILE3(k0 + BK);
+
+        f32x16 s0, s1;
+#pragma unroll
+        for (int i = 0; i < 16; i++) { s0[i] = 0.f; s1[i] = 0.f; }
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            const int slot = ((2 * s + hh) ^ swz) << 4;
+            const op16x8 a0h = *reinterpret_cast<const op16x8 *>(Kh + r * 128 + slot);
+            const op16x8 a1h = *reinterpret_cast<const op16x8 *>(Kh + (r + 32) * 128 + slot);
+            const op16x8 a0l = *reinterpret_cast<const op16x8 *>(Kl + r * 128 + slot);
+            const op16x8 a1l = *reinterpret_cast<const op16x8 *>(Kl + (r + 32) * 128 + slot);
+            s0 = COSA_MFMA_32x32x16(a0l, qh[s], s0, 0, 0, 0);          // small terms first
+            s1 = COSA_MFMA_32x32x16(a1l, qh[s], s1, 0, 0, 0);
+            s0 = COSA_MFMA_32x32x16(a0h, ql[s], s0, 0, 0, 0);
+            s1 = COSA_MFMA_32x32x16(a1h, ql[s], s1, 0, 0, 0);
+            s0 = COSA_MFMA_32x32x16(a0h, qh[s], s0, 0, 0, 0);
+            s1 = COSA_MFMA_32x32x16(a1h, qh[s], s1, 0, 0, 0);
+        }
+        if constexpr (tail) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                if (k0 + crow(i, hh) >= N) s0[i] = NEG_INF;
+                if (k0 + 32 + crow(i, hh) >= N) s1[i] = NEG_INF;
+            }
+        }
+        float mt = fmaxf(s0[0], s1[0]);
+#pragma unroll
+        for (int i = 1; i < 16; i++) mt = fmaxf(mt, fmaxf(s0[i], s1[i]));
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        const float mnew = fmaxf(m, mt * scale_log2e);
+        if (__any(mnew != m)) {
+            const float alpha = __builtin_amdgcn_exp2f(m - mnew);
+            l *= alpha;
+#pragma unroll
+            for (int i = 0; i < 16; i++) { o0[i] *= alpha; o1[i] *= alpha; }
+            m = mnew;
+        }
+        float ls = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            s0[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[i], scale_log2e, -m));
+            s1[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[i], scale_log2e, -m));
+            ls += s0[i] + s1[i];
+        }
+        l += ls;
+#pragma unroll
+        for (int kb = 0; kb < 2; kb++) {
+#pragma unroll
+            for (int sp = 0; sp < 2; sp++) {
+                op16x8 ph, pl;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const float p = kb == 0 ? s0[8 * sp + j] : s1[8 * sp + j];
+                    ph[j] = (op16)p;
+                    pl[j] = (op16)(p - (float)ph[j]);
+                }
+                const int keyb = kb * 32 + 16 * sp + 4 * hh;
+                const op16x8 vh0 = v_frag(Vh, keyb, 0, lane), vh1 = v_frag(Vh, keyb, 1, lane);
+                const op16x8 vl0 = v_frag(Vl, keyb, 0, lane), vl1 = v_frag(Vl, keyb, 1, lane);
+                o0 = COSA_MFMA_32x32x16(vl0, ph, o0, 0, 0, 0);
+                o1 = COSA_MFMA_32x32x16(vl1, ph, o1, 0, 0, 0);
+                o0 = COSA_MFMA_32x32x16(vh0, pl, o0, 0, 0, 0);
+                o1 = COSA_MFMA_32x32x16(vh1, pl, o1, 0, 0, 0);
+                o0 = COSA_MFMA_32x32x16(vh0, ph, o0, 0, 0, 0);
+                o1 = COSA_MFMA_32x32x16(vh1, ph, o1, 0, 0, 0);
+            }
+        }
+    };
+    const int nfull = (N / BK) * BK;
+    for (int k0 = 0; k0 < nfull; k0 += BK) tile(k0, std::false_type{});
+    if (nfull < N) tile(nfull, std::true_type{});
+#undef COSA_LOAD_TILE3
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+    const int q = q0 + r;
+    if (q < N) {
+        op16 *op = out + ((size_t)b * N + q) * ldo + h * HD;
+        const int lo_o = H * HD;
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            op16x4 h0, h1, l0, l1;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float a = o0[4 * g + j] * inv, c = o1[4 * g + j] * inv;
+                h0[j] = (op16)a; l0[j] = (op16)(a - (float)h0[j]);
+                h1[j] = (op16)c; l1[j] = (op16)(c - (float)h1[j]);
+            }
+            *reinterpret_cast<op16x4 *>(op + 8 * g + 4 * hh) = h0;
+            *reinterpret_cast<op16x4 *>(op + 32 + 8 * g + 4 * hh) = h1;
+            *reinterpret_cast<op16x4 *>(op + lo_o + 8 * g + 4 * hh) = l0;
+            *reinterpret_cast<op16x4 *>(op + lo_o + 32 + 8 * g + 4 * hh) = l1;
+        }
+        if (h == 0) {                                   // augmentation block of this token row: (1, 1, 0, ...), 64 B per half-lane
+            op16 *ap = out + ((size_t)b * N + q) * ldo + 2 * lo_o + 32 * hh;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                op16x8 a;
+#pragma unroll
+                for (int j = 0; j < 8; j++) a[j] = (op16)0.f;
+                if (hh == 0 && c == 0) { a[0] = (op16)1.f; a[1] = (op16)1.f; }
+                *reinterpret_cast<op16x8 *>(ap + 8 * c) = a;
+            }
+        }
+        if (hh == 0 && lse) lse[((size_t)b * H + h) * N + q] = (m + __builtin_amdgcn_logf(l)) * 0.6931471805599453f;
+    }
+}
+#endif
+
 // ---- forward, 64 queries per wave ---------------------------------------------------------------------------------
 // Same algorithm as attn_fwd_kernel with a different decomposition: a workgroup is 2 waves, each wave owns TWO 32-query
 // blocks.  Every K / V^T fragment read from LDS now feeds two MFMAs (half the LDS fragment traffic per flop), each wave
@@ -214,8 +386,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16 *__restrict__ 
 // computed, one barrier per tile, no staging registers; the swizzles are applied on the source side (lane-linear LDS image) and
 // key rows past N read as zeros through the buffer range check.
 template <bool DMA>
-__global__ __launch_bounds__(128, 2) void attn_fwd2_kernel(const bf16 *__restrict__ qkv, const bf16 *__restrict__ vt,
-                                                       bf16 *__restrict__ out, float *__restrict__ lse,
+__global__ __launch_bounds__(128, 2) void attn_fwd2_kernel(const op16 *__restrict__ qkv, const op16 *__restrict__ vt,
+                                                       op16 *__restrict__ out, float *__restrict__ lse,
                                                        int N, int Npad, int H, int nblk, int ngroups, float scale_log2e,
                                                        unsigned long long *__restrict__ stamps)
 {
@@ -229,13 +401,13 @@ __global__ __launch_bounds__(128, 2) void attn_fwd2_kernel(const bf16 *__restric
     if (!attn_block_map(nblk, ngroups, H, blk, b, h)) return;
     const int q0 = blk * BQ + wave * 64;
     const size_t rs = (size_t)3 * H * HD;
-    bf16x8 qf[2][4];
+    op16x8 qf[2][4];
 #pragma unroll
     for (int u = 0; u < 2; u++) {
         const int qrow = min(q0 + 32 * u + r, N - 1);
-        const bf16 *qp = qkv + ((size_t)b * N + qrow) * rs + h * HD + 8 * hh;
+        const op16 *qp = qkv + ((size_t)b * N + qrow) * rs + h * HD + 8 * hh;
 #pragma unroll
-        for (int s = 0; s < 4; s++) qf[u][s] = *reinterpret_cast<const bf16x8 *>(qp + 16 * s);
+        for (int s = 0; s < 4; s++) qf[u][s] = *reinterpret_cast<const op16x8 *>(qp + 16 * s);
     }
     f32x16 o[2][2];
 #pragma unroll
@@ -245,8 +417,8 @@ __global__ __launch_bounds__(128, 2) void attn_fwd2_kernel(const bf16 *__restric
 #pragma unroll
             for (int i = 0; i < 16; i++) o[u][d][i] = 0.f;
     float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.f, 0.f};
-    const bf16 *kbase = qkv + (size_t)b * N * rs + (size_t)H * HD + h * HD;
-    const bf16 *vbase = kbase + (size_t)H * HD;
+    const op16 *kbase = qkv + (size_t)b * N * rs + (size_t)H * HD + h * HD;
+    const op16 *vbase = kbase + (size_t)H * HD;
     const int swz = (r >> 1) & 7;
     // 128 threads stage 512 + 512 16-byte chunks per tile (4 + 4 per thread).  No register prefetch here: four of these
     // workgroups share a CU, so another workgroup computes while this one waits for its tile.
@@ -309,12 +481,12 @@ __global__ __launch_bounds__(128, 2) void attn_fwd2_kernel(const bf16 *__restric
 #pragma unroll
         for (int s = 0; s < 4; s++) {
             const int slot = ((2 * s + hh) ^ swz) << 4;
-            const bf16x8 a0 = *reinterpret_cast<const bf16x8 *>(Ks + r * 128 + slot);
-            const bf16x8 a1 = *reinterpret_cast<const bf16x8 *>(Ks + (r + 32) * 128 + slot);
+            const op16x8 a0 = *reinterpret_cast<const op16x8 *>(Ks + r * 128 + slot);
+            const op16x8 a1 = *reinterpret_cast<const op16x8 *>(Ks + (r + 32) * 128 + slot);
 #pragma unroll
             for (int u = 0; u < 2; u++) {
-                sc[u][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, qf[u][s], sc[u][0], 0, 0, 0);
-                sc[u][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, qf[u][s], sc[u][1], 0, 0, 0);
+                sc[u][0] = COSA_MFMA_32x32x16(a0, qf[u][s], sc[u][0], 0, 0, 0);
+                sc[u][1] = COSA_MFMA_32x32x16(a1, qf[u][s], sc[u][1], 0, 0, 0);
             }
         }
         __builtin_amdgcn_s_setprio(0);
@@ -333,7 +505,7 @@ __global__ __launch_bounds__(128, 2) void attn_fwd2_kernel(const bf16 *__restric
             mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
             const float mnew = fmaxf(m[u], mt * scale_log2e);
             // deferred rescale: the running reference m only moves when some row's max has outgrown it by more than 2^DEFER (probabilities
-            // then reach at most 2^DEFER, far inside fp32 / bf16 range; l and O carry the same factor, so the result is unchanged)
+            // then reach at most 2^DEFER, far inside fp32 / op16 range; l and O carry the same factor, so the result is unchanged)
             if (__any(mnew > m[u] + kDeferLog2)) {
                 const float alpha = __builtin_amdgcn_exp2f(m[u] - mnew);
                 l[u] *= alpha;
@@ -356,14 +528,14 @@ __global__ __launch_bounds__(128, 2) void attn_fwd2_kernel(const bf16 *__restric
 #pragma unroll
             for (int sp = 0; sp < 2; sp++) {
                 const int keyb = kb * 32 + 16 * sp + 4 * hh;
-                const bf16x8 v0 = v_frag(Vs, keyb, 0, lane), v1 = v_frag(Vs, keyb, 1, lane);
+                const op16x8 v0 = v_frag(Vs, keyb, 0, lane), v1 = v_frag(Vs, keyb, 1, lane);
 #pragma unroll
                 for (int u = 0; u < 2; u++) {
-                    bf16x8 pf;
+                    op16x8 pf;
 #pragma unroll
-                    for (int j = 0; j < 8; j++) pf[j] = (bf16)sc[u][kb][8 * sp + j];
-                    o[u][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, pf, o[u][0], 0, 0, 0);
-                    o[u][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, pf, o[u][1], 0, 0, 0);
+                    for (int j = 0; j < 8; j++) pf[j] = (op16)sc[u][kb][8 * sp + j];
+                    o[u][0] = COSA_MFMA_32x32x16(v0, pf, o[u][0], 0, 0, 0);
+                    o[u][1] = COSA_MFMA_32x32x16(v1, pf, o[u][1], 0, 0, 0);
                 }
             }
         __builtin_amdgcn_s_setprio(0);
@@ -382,14 +554,14 @@ __global__ __launch_bounds__(128, 2) void attn_fwd2_kernel(const bf16 *__restric
         const float inv = 1.0f / lt;
         const int q = q0 + 32 * u + r;
         if (q < N) {
-            bf16 *op = out + ((size_t)b * N + q) * H * HD + h * HD;
+            op16 *op = out + ((size_t)b * N + q) * H * HD + h * HD;
 #pragma unroll
             for (int g = 0; g < 4; g++) {
-                bf16x4 v0, v1;
+                op16x4 v0, v1;
 #pragma unroll
-                for (int j = 0; j < 4; j++) { v0[j] = (bf16)(o[u][0][4 * g + j] * inv); v1[j] = (bf16)(o[u][1][4 * g + j] * inv); }
-                *reinterpret_cast<bf16x4 *>(op + 8 * g + 4 * hh) = v0;
-                *reinterpret_cast<bf16x4 *>(op + 32 + 8 * g + 4 * hh) = v1;
+                for (int j = 0; j < 4; j++) { v0[j] = (op16)(o[u][0][4 * g + j] * inv); v1[j] = (op16)(o[u][1][4 * g + j] * inv); }
+                *reinterpret_cast<op16x4 *>(op + 8 * g + 4 * hh) = v0;
+                *reinterpret_cast<op16x4 *>(op + 32 + 8 * g + 4 * hh) = v1;
             }
             if (hh == 0) lse[((size_t)b * H + h) * N + q] = (m[u] + __builtin_amdgcn_logf(lt)) * 0.6931471805599453f;
         }
@@ -420,18 +592,18 @@ __global__ __launch_bounds__(128, 2) void attn_fwd2_kernel(const bf16 *__restric
 // 32 banks apart and bit 2 of usw moves rows r+2, r+3 by 16 banks.  No transposed copies in HBM, no transposed LDS images.
 __device__ __forceinline__ int usw(int r) { return (((r >> 1) & 1) << 2) | ((r >> 2) & 3); }
 
-__device__ __forceinline__ bf16x8 ufrag_rows(const unsigned char *tile, int row, int s, int hh)
+__device__ __forceinline__ op16x8 ufrag_rows(const unsigned char *tile, int row, int s, int hh)
 {
-    return *reinterpret_cast<const bf16x8 *>(tile + row * 128 + (((2 * s + hh) ^ usw(row)) << 4));
+    return *reinterpret_cast<const op16x8 *>(tile + row * 128 + (((2 * s + hh) ^ usw(row)) << 4));
 }
 
 // A operand of a 32x32x16 MFMA whose rows are d (dhalf*32 + lane&31) and whose 8 k-slots are tokens tokb+{0..3, 8..11}
-__device__ __forceinline__ bf16x8 ufrag_cols(const unsigned char *tile, int tokb, int dhalf, int lane)
+__device__ __forceinline__ op16x8 ufrag_cols(const unsigned char *tile, int tokb, int dhalf, int lane)
 {
     const int nn = lane & 15, grp = (lane >> 4) & 1;
     const int r0 = tokb + (nn >> 2), r1 = r0 + 8;
     const int ch = dhalf * 4 + grp * 2 + ((nn & 3) >> 1), off = 8 * (nn & 1);
-    union { s16x4v h[2]; bf16x8 v; } u;
+    union { s16x4v h[2]; op16x8 v; } u;
     u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4v *)(tile + r0 * 128 + ((ch ^ usw(r0)) << 4) + off));
     u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4v *)(tile + r1 * 128 + ((ch ^ usw(r1)) << 4) + off));
     return u.v;
@@ -454,7 +626,7 @@ __device__ __forceinline__ void tile_dma(__amdgpu_buffer_rsrc_t rs, unsigned cha
 }
 
 // prep: delta[q] = sum_d dO[q,d] * O[q,d]  (the only thing the two kernels below need prepared)
-__global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const bf16 *__restrict__ dO, const bf16 *__restrict__ O,
+__global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const op16 *__restrict__ dO, const op16 *__restrict__ O,
                                                            float *__restrict__ delta, int N, int H, size_t total)
 {
     // one thread per (token, head) quarter: 4 lanes x 16 d
@@ -464,8 +636,8 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const bf16 *__restri
     float acc = 0.f;
     if (th < total) {
         const size_t o = th * HD + part * 16;
-        const bf16x8 d0 = *reinterpret_cast<const bf16x8 *>(dO + o), d1 = *reinterpret_cast<const bf16x8 *>(dO + o + 8);
-        const bf16x8 o0 = *reinterpret_cast<const bf16x8 *>(O + o), o1 = *reinterpret_cast<const bf16x8 *>(O + o + 8);
+        const op16x8 d0 = *reinterpret_cast<const op16x8 *>(dO + o), d1 = *reinterpret_cast<const op16x8 *>(dO + o + 8);
+        const op16x8 o0 = *reinterpret_cast<const op16x8 *>(O + o), o1 = *reinterpret_cast<const op16x8 *>(O + o + 8);
 #pragma unroll
         for (int i = 0; i < 8; i++) acc += (float)d0[i] * (float)o0[i] + (float)d1[i] * (float)o1[i];
     }
@@ -480,9 +652,9 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const bf16 *__restri
     }
 }
 
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16 *__restrict__ qkv, const bf16 *__restrict__ dO,
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const op16 *__restrict__ qkv, const op16 *__restrict__ dO,
                                                          const float *__restrict__ lse, const float *__restrict__ delta,
-                                                         bf16 *__restrict__ dqkv, int N, int H, int nblk, int ngroups, float scale)
+                                                         op16 *__restrict__ dqkv, int N, int H, int nblk, int ngroups, float scale)
 {
     __shared__ __attribute__((aligned(16))) unsigned char smem[4 * BK * 128];        // 2-deep ring of (K tile | V tile)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
@@ -491,18 +663,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16 *__restrict
     const int q0 = blk * BQ + wave * 32;
     const size_t rs = (size_t)3 * H * HD;
     const int qrow = min(q0 + r, N - 1);
-    const bf16 *qp = qkv + ((size_t)b * N + qrow) * rs + h * HD + 8 * hh;
-    const bf16 *dop = dO + ((size_t)b * N + qrow) * H * HD + h * HD + 8 * hh;
-    bf16x8 qf[4], dof[4];
+    const op16 *qp = qkv + ((size_t)b * N + qrow) * rs + h * HD + 8 * hh;
+    const op16 *dop = dO + ((size_t)b * N + qrow) * H * HD + h * HD + 8 * hh;
+    op16x8 qf[4], dof[4];
 #pragma unroll
-    for (int s = 0; s < 4; s++) { qf[s] = *reinterpret_cast<const bf16x8 *>(qp + 16 * s); dof[s] = *reinterpret_cast<const bf16x8 *>(dop + 16 * s); }
+    for (int s = 0; s < 4; s++) { qf[s] = *reinterpret_cast<const op16x8 *>(qp + 16 * s); dof[s] = *reinterpret_cast<const op16x8 *>(dop + 16 * s); }
     const float scale_log2e = scale * 1.4426950408889634f;
     const float lse2 = lse[((size_t)b * H + h) * N + qrow] * 1.4426950408889634f;
     const float dl = delta[((size_t)b * H + h) * N + qrow];
     f32x16 g0, g1;
 #pragma unroll
     for (int i = 0; i < 16; i++) { g0[i] = 0.f; g1[i] = 0.f; }
-    const bf16 *kbase = qkv + (size_t)b * N * rs + (size_t)H * HD + h * HD;
+    const op16 *kbase = qkv + (size_t)b * N * rs + (size_t)H * HD + h * HD;
     const int nbytes = (int)(((size_t)(N - 1) * rs + HD) * 2);
     const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void *)kbase, 0, nbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void *)(kbase + (size_t)H * HD), 0, nbytes, 0x00020000);
@@ -527,10 +699,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16 *__restrict
         for (int i = 0; i < 16; i++) { s0[i] = 0.f; s1[i] = 0.f; p0[i] = 0.f; p1[i] = 0.f; }
 #pragma unroll
         for (int s = 0; s < 4; s++) {
-            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ufrag_rows(Ks, r, s, hh), qf[s], s0, 0, 0, 0);
-            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ufrag_rows(Ks, r + 32, s, hh), qf[s], s1, 0, 0, 0);
-            p0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ufrag_rows(Vsr, r, s, hh), dof[s], p0, 0, 0, 0);
-            p1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ufrag_rows(Vsr, r + 32, s, hh), dof[s], p1, 0, 0, 0);
+            s0 = COSA_MFMA_32x32x16(ufrag_rows(Ks, r, s, hh), qf[s], s0, 0, 0, 0);
+            s1 = COSA_MFMA_32x32x16(ufrag_rows(Ks, r + 32, s, hh), qf[s], s1, 0, 0, 0);
+            p0 = COSA_MFMA_32x32x16(ufrag_rows(Vsr, r, s, hh), dof[s], p0, 0, 0, 0);
+            p1 = COSA_MFMA_32x32x16(ufrag_rows(Vsr, r + 32, s, hh), dof[s], p1, 0, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < 16; i++) {
@@ -547,12 +719,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16 *__restrict
         for (int kb = 0; kb < 2; kb++)
 #pragma unroll
             for (int sp = 0; sp < 2; sp++) {
-                bf16x8 df;
+                op16x8 df;
 #pragma unroll
-                for (int j = 0; j < 8; j++) df[j] = (bf16)(kb == 0 ? s0[8 * sp + j] : s1[8 * sp + j]);
+                for (int j = 0; j < 8; j++) df[j] = (op16)(kb == 0 ? s0[8 * sp + j] : s1[8 * sp + j]);
                 const int keyb = kb * 32 + 16 * sp + 4 * hh;
-                g0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ufrag_cols(Ks, keyb, 0, lane), df, g0, 0, 0, 0);     // K^T by transposing reads
-                g1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ufrag_cols(Ks, keyb, 1, lane), df, g1, 0, 0, 0);
+                g0 = COSA_MFMA_32x32x16(ufrag_cols(Ks, keyb, 0, lane), df, g0, 0, 0, 0);     // K^T by transposing reads
+                g1 = COSA_MFMA_32x32x16(ufrag_cols(Ks, keyb, 1, lane), df, g1, 0, 0, 0);
             }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the next tile has landed and nobody still reads this one
         __syncthreads();
@@ -563,21 +735,21 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16 *__restrict
     if (nfull < N) tile(nfull, std::true_type{});
     const int q = q0 + r;
     if (q < N) {
-        bf16 *op = dqkv + ((size_t)b * N + q) * rs + h * HD;
+        op16 *op = dqkv + ((size_t)b * N + q) * rs + h * HD;
 #pragma unroll
         for (int g = 0; g < 4; g++) {
-            bf16x4 v0, v1;
+            op16x4 v0, v1;
 #pragma unroll
-            for (int j = 0; j < 4; j++) { v0[j] = (bf16)g0[4 * g + j]; v1[j] = (bf16)g1[4 * g + j]; }
-            *reinterpret_cast<bf16x4 *>(op + 8 * g + 4 * hh) = v0;
-            *reinterpret_cast<bf16x4 *>(op + 32 + 8 * g + 4 * hh) = v1;
+            for (int j = 0; j < 4; j++) { v0[j] = (op16)g0[4 * g + j]; v1[j] = (op16)g1[4 * g + j]; }
+            *reinterpret_cast<op16x4 *>(op + 8 * g + 4 * hh) = v0;
+            *reinterpret_cast<op16x4 *>(op + 32 + 8 * g + 4 * hh) = v1;
         }
     }
 }
 
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16 *__restrict__ qkv, const bf16 *__restrict__ dO,
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const op16 *__restrict__ qkv, const op16 *__restrict__ dO,
                                                           const float *__restrict__ lse, const float *__restrict__ delta,
-                                                          bf16 *__restrict__ dqkv, int N, int H, int nblk, int ngroups, float scale)
+                                                          op16 *__restrict__ dqkv, int N, int H, int nblk, int ngroups, float scale)
 {
     __shared__ __attribute__((aligned(16))) unsigned char smem[4 * BK * 128 + 4 * BK * 4];  // ring of (Q | dO) + (lse | delta) x 2
     float *sc_s = reinterpret_cast<float *>(smem + 4 * BK * 128);
@@ -587,17 +759,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16 *__rest
     const int key0 = blk * BQ + wave * 32;
     const size_t rs = (size_t)3 * H * HD;
     const int krow = min(key0 + r, N - 1);
-    const bf16 *kp = qkv + ((size_t)b * N + krow) * rs + (size_t)H * HD + h * HD + 8 * hh;
-    const bf16 *vp = qkv + ((size_t)b * N + krow) * rs + (size_t)2 * H * HD + h * HD + 8 * hh;
-    bf16x8 kf[4], vf[4];
+    const op16 *kp = qkv + ((size_t)b * N + krow) * rs + (size_t)H * HD + h * HD + 8 * hh;
+    const op16 *vp = qkv + ((size_t)b * N + krow) * rs + (size_t)2 * H * HD + h * HD + 8 * hh;
+    op16x8 kf[4], vf[4];
 #pragma unroll
-    for (int s = 0; s < 4; s++) { kf[s] = *reinterpret_cast<const bf16x8 *>(kp + 16 * s); vf[s] = *reinterpret_cast<const bf16x8 *>(vp + 16 * s); }
+    for (int s = 0; s < 4; s++) { kf[s] = *reinterpret_cast<const op16x8 *>(kp + 16 * s); vf[s] = *reinterpret_cast<const op16x8 *>(vp + 16 * s); }
     const float scale_log2e = scale * 1.4426950408889634f;
     f32x16 dk0, dk1, dv0, dv1;
 #pragma unroll
     for (int i = 0; i < 16; i++) { dk0[i] = 0.f; dk1[i] = 0.f; dv0[i] = 0.f; dv1[i] = 0.f; }
-    const bf16 *qbase = qkv + (size_t)b * N * rs + h * HD;
-    const bf16 *dobase = dO + (size_t)b * N * H * HD + h * HD;
+    const op16 *qbase = qkv + (size_t)b * N * rs + h * HD;
+    const op16 *dobase = dO + (size_t)b * N * H * HD + h * HD;
     const size_t ds = (size_t)H * HD;
     const __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc((void *)qbase, 0, (int)(((size_t)(N - 1) * rs + HD) * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc((void *)dobase, 0, (int)(((size_t)(N - 1) * ds + HD) * 2), 0x00020000);
@@ -634,8 +806,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16 *__rest
             for (int i = 0; i < 16; i++) { s0[i] = 0.f; p0[i] = 0.f; }
 #pragma unroll
             for (int s = 0; s < 4; s++) {
-                s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ufrag_rows(Qs, r + 32 * qb, s, hh), kf[s], s0, 0, 0, 0);
-                p0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ufrag_rows(dOs, r + 32 * qb, s, hh), vf[s], p0, 0, 0, 0);
+                s0 = COSA_MFMA_32x32x16(ufrag_rows(Qs, r + 32 * qb, s, hh), kf[s], s0, 0, 0, 0);
+                p0 = COSA_MFMA_32x32x16(ufrag_rows(dOs, r + 32 * qb, s, hh), vf[s], p0, 0, 0, 0);
             }
 #pragma unroll
             for (int i = 0; i < 16; i++) {
@@ -647,14 +819,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16 *__rest
             }
 #pragma unroll
             for (int sp = 0; sp < 2; sp++) {
-                bf16x8 pf, df;
+                op16x8 pf, df;
 #pragma unroll
-                for (int j = 0; j < 8; j++) { pf[j] = (bf16)s0[8 * sp + j]; df[j] = (bf16)p0[8 * sp + j]; }
+                for (int j = 0; j < 8; j++) { pf[j] = (op16)s0[8 * sp + j]; df[j] = (op16)p0[8 * sp + j]; }
                 const int tokb = qb * 32 + 16 * sp + 4 * hh;
-                dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ufrag_cols(dOs, tokb, 0, lane), pf, dv0, 0, 0, 0);   // dO^T, Q^T by transposing reads
-                dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ufrag_cols(dOs, tokb, 1, lane), pf, dv1, 0, 0, 0);
-                dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ufrag_cols(Qs, tokb, 0, lane), df, dk0, 0, 0, 0);
-                dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ufrag_cols(Qs, tokb, 1, lane), df, dk1, 0, 0, 0);
+                dv0 = COSA_MFMA_32x32x16(ufrag_cols(dOs, tokb, 0, lane), pf, dv0, 0, 0, 0);   // dO^T, Q^T by transposing reads
+                dv1 = COSA_MFMA_32x32x16(ufrag_cols(dOs, tokb, 1, lane), pf, dv1, 0, 0, 0);
+                dk0 = COSA_MFMA_32x32x16(ufrag_cols(Qs, tokb, 0, lane), df, dk0, 0, 0, 0);
+                dk1 = COSA_MFMA_32x32x16(ufrag_cols(Qs, tokb, 1, lane), df, dk1, 0, 0, 0);
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -666,20 +838,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16 *__rest
     if (nfull < N) tile(nfull, std::true_type{});
     const int key = key0 + r;
     if (key < N) {
-        bf16 *okp = dqkv + ((size_t)b * N + key) * rs + (size_t)H * HD + h * HD;
-        bf16 *ovp = dqkv + ((size_t)b * N + key) * rs + (size_t)2 * H * HD + h * HD;
+        op16 *okp = dqkv + ((size_t)b * N + key) * rs + (size_t)H * HD + h * HD;
+        op16 *ovp = dqkv + ((size_t)b * N + key) * rs + (size_t)2 * H * HD + h * HD;
 #pragma unroll
         for (int g = 0; g < 4; g++) {
-            bf16x4 a0, a1, c0, c1;
+            op16x4 a0, a1, c0, c1;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                a0[j] = (bf16)dk0[4 * g + j]; a1[j] = (bf16)dk1[4 * g + j];
-                c0[j] = (bf16)dv0[4 * g + j]; c1[j] = (bf16)dv1[4 * g + j];
+                a0[j] = (op16)dk0[4 * g + j]; a1[j] = (op16)dk1[4 * g + j];
+                c0[j] = (op16)dv0[4 * g + j]; c1[j] = (op16)dv1[4 * g + j];
             }
-            *reinterpret_cast<bf16x4 *>(okp + 8 * g + 4 * hh) = a0;
-            *reinterpret_cast<bf16x4 *>(okp + 32 + 8 * g + 4 * hh) = a1;
-            *reinterpret_cast<bf16x4 *>(ovp + 8 * g + 4 * hh) = c0;
-            *reinterpret_cast<bf16x4 *>(ovp + 32 + 8 * g + 4 * hh) = c1;
+            *reinterpret_cast<op16x4 *>(okp + 8 * g + 4 * hh) = a0;
+            *reinterpret_cast<op16x4 *>(okp + 32 + 8 * g + 4 * hh) = a1;
+            *reinterpret_cast<op16x4 *>(ovp + 8 * g + 4 * hh) = c0;
+            *reinterpret_cast<op16x4 *>(ovp + 32 + 8 * g + 4 * hh) = c1;
         }
     }
 }
@@ -688,6 +860,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16 *__rest
 }  // namespace cosa
 
 using namespace cosa;
+
+#if COSA_OP_F16        // second build of this file (fp16 operands): the same entry points under their _f16 names (include/cosa_hip.h)
+#define cosa_attn_workspace_bytes cosa_attn_workspace_bytes_f16
+#define cosa_attn_prepare_vt cosa_attn_prepare_vt_f16
+#define cosa_attn_fwd cosa_attn_fwd_f16
+#define cosa_attn_bwd_workspace_bytes cosa_attn_bwd_workspace_bytes_f16
+#define cosa_attn_bwd cosa_attn_bwd_f16
+#endif
 
 /* scratch of cosa_attn_fwd: none any more (the V^T copy is gone); a token size keeps the calling convention */
 extern "C" size_t cosa_attn_workspace_bytes(int B, int N, int H)
@@ -719,25 +899,25 @@ extern "C" int cosa_attn_fwd(const void *qkv, void *out, float *lse, int B, int 
     }
     hipStream_t st = as_stream(stream);
     const int Npad = (N + BK - 1) / BK * BK;
-    const bf16 *vt = nullptr;      // (flags bit 0, "V^T prepared", is ignored: there is no V^T copy)
+    const op16 *vt = nullptr;      // (flags bit 0, "V^T prepared", is ignored: there is no V^T copy)
     // measured (tools/bench_attn2.py): with the LDS-DMA ring the 2 waves x 64 queries kernel wins at every length of the step
     // (N=197: 18 vs 20 us, N=785: 127 vs 154 us, N=1765: 413 vs 541 us, N=3601: 777 vs 992 us); the 4 x 32 kernel with its
     // register prefetch stays as the alternative.  flags bit 1 / bit 2 force either.
     const int nblk = (N + BQ - 1) / BQ;
     if ((flags & 2) && !(flags & 4))
-        hipLaunchKernelGGL(attn_fwd_kernel, dim3(nblk * ((B * H + 7) / 8 * 8)), dim3(256), 0, st, static_cast<const bf16 *>(qkv), vt,
-                           static_cast<bf16 *>(out), lse, N, Npad, H, nblk, B * H, scale * 1.4426950408889634f,
+        hipLaunchKernelGGL(attn_fwd_kernel, dim3(nblk * ((B * H + 7) / 8 * 8)), dim3(256), 0, st, static_cast<const op16 *>(qkv), vt,
+                           static_cast<op16 *>(out), lse, N, Npad, H, nblk, B * H, scale * 1.4426950408889634f,
                            reinterpret_cast<unsigned long long *>(stamps));
     else
     {
         static const bool no_dma = getenv("COSA_ATTN_NO_DMA") != nullptr;
         if (no_dma || (size_t)N * 3 * H * HD * 2 >= 0x7fffffffull)
-            hipLaunchKernelGGL(attn_fwd2_kernel<false>, dim3(nblk * ((B * H + 7) / 8 * 8)), dim3(128), 0, st, static_cast<const bf16 *>(qkv), vt,
-                               static_cast<bf16 *>(out), lse, N, Npad, H, nblk, B * H, scale * 1.4426950408889634f,
+            hipLaunchKernelGGL(attn_fwd2_kernel<false>, dim3(nblk * ((B * H + 7) / 8 * 8)), dim3(128), 0, st, static_cast<const op16 *>(qkv), vt,
+                               static_cast<op16 *>(out), lse, N, Npad, H, nblk, B * H, scale * 1.4426950408889634f,
                                reinterpret_cast<unsigned long long *>(stamps));
         else
-            hipLaunchKernelGGL(attn_fwd2_kernel<true>, dim3(nblk * ((B * H + 7) / 8 * 8)), dim3(128), 0, st, static_cast<const bf16 *>(qkv), vt,
-                               static_cast<bf16 *>(out), lse, N, Npad, H, nblk, B * H, scale * 1.4426950408889634f,
+            hipLaunchKernelGGL(attn_fwd2_kernel<true>, dim3(nblk * ((B * H + 7) / 8 * 8)), dim3(128), 0, st, static_cast<const op16 *>(qkv), vt,
+                               static_cast<op16 *>(out), lse, N, Npad, H, nblk, B * H, scale * 1.4426950408889634f,
                                reinterpret_cast<unsigned long long *>(stamps));
     }
     COSA_LAUNCH_CHECK();
@@ -745,6 +925,22 @@ extern "C" int cosa_attn_fwd(const void *qkv, void *out, float *lse, int B, int 
 }
 
 /* backward workspace: delta [B,H,N] f32 (the transposed operands come from transposing LDS reads now) */
+#if !COSA_OP_F16
+extern "C" int cosa_attn_fwd_bf16x3(const void *qkv_split, void *out_split, float *lse, int B, int N, int H, int head_dim, float scale,
+                                    int ldq, int ldo, void *stream)
+{
+    COSA_REQUIRE(qkv_split && out_split && B > 0 && N > 0 && H > 0, "cosa_attn_fwd_bf16x3: bad arguments");
+    COSA_REQUIRE(head_dim == HD, "cosa_attn_fwd_bf16x3: head_dim must be 64");
+    COSA_REQUIRE(ldq >= 6 * H * HD && ldq % 8 == 0 && ldo >= 2 * H * HD + 64 && ldo % 8 == 0, "cosa_attn_fwd_bf16x3: bad row strides");
+    const int nblk = (N + BQ - 1) / BQ, ngroups = B * H;
+    const int grid = ((ngroups + 7) / 8) * 8 * nblk;
+    hipLaunchKernelGGL(attn_fwd_x3_kernel, dim3(grid), dim3(256), 0, as_stream(stream), static_cast<const op16 *>(qkv_split),
+                       static_cast<op16 *>(out_split), lse, N, H, nblk, ngroups, scale * 1.4426950408889634f, ldq, ldo);
+    COSA_LAUNCH_CHECK();
+    return COSA_OK;
+}
+#endif
+
 extern "C" size_t cosa_attn_bwd_workspace_bytes(int B, int N, int H)
 {
     return align_up((size_t)B * H * N * sizeof(float), 256);
@@ -763,15 +959,15 @@ extern "C" int cosa_attn_bwd(const void *qkv, const void *out, const void *dout,
     }
     hipStream_t st = as_stream(stream);
     float *delta = static_cast<float *>(workspace);
-    const bf16 *q = static_cast<const bf16 *>(qkv), *o = static_cast<const bf16 *>(out), *d_o = static_cast<const bf16 *>(dout);
+    const op16 *q = static_cast<const op16 *>(qkv), *o = static_cast<const op16 *>(out), *d_o = static_cast<const op16 *>(dout);
     const size_t total = (size_t)B * N * H;
     hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((unsigned)((total * 4 + 255) / 256)), dim3(256), 0, st, d_o, o, delta, N, H, total);
     COSA_LAUNCH_CHECK();
     const int nblk = (N + BQ - 1) / BQ;
     const dim3 grid(nblk * ((B * H + 7) / 8 * 8));
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, st, q, d_o, lse, delta, static_cast<bf16 *>(dqkv), N, H, nblk, B * H, scale);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, st, q, d_o, lse, delta, static_cast<op16 *>(dqkv), N, H, nblk, B * H, scale);
     COSA_LAUNCH_CHECK();
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, st, q, d_o, lse, delta, static_cast<bf16 *>(dqkv), N, H, nblk, B * H, scale);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, st, q, d_o, lse, delta, static_cast<op16 *>(dqkv), N, H, nblk, B * H, scale);
     COSA_LAUNCH_CHECK();
     return COSA_OK;
 }

@@ -1,8 +1,8 @@
-// gemm_kernels.hip -- bf16 MFMA GEMM with fused epilogues for the ViT projections (gfx950).
+// gemm_kernels.hip -- op16 MFMA GEMM with fused epilogues for the ViT projections (gfx950).
 //
 //   Y[M,N] = X[M,K] * W[N,K]^T + bias[N]      (nn.Linear layout: both operands K-contiguous)
-//   epilogues:  EPI_BIAS      -> bf16 Y                       (qkv projection,          vit.py:121)
-//               EPI_GELU      -> bf16 gelu_erf(Y)             (mlp.fc1 + GELU,          vit.py:97-98)
+//   epilogues:  EPI_BIAS      -> op16 Y                       (qkv projection,          vit.py:121)
+//               EPI_GELU      -> op16 gelu_erf(Y)             (mlp.fc1 + GELU,          vit.py:97-98)
 //               EPI_RESIDUAL  -> fp32 Yres = R + Y            (attn.proj / mlp.fc2 + residual, vit.py:156-157)
 //
 // CDNA4 structure: 128x128 output tile per 256-thread workgroup (4 wave64 as 2x2, each 64x64 =
@@ -14,14 +14,12 @@
 // whole 256-B rows.  Workgroup ids are remapped so that the tiles sharing an X panel run on the
 // same XCD (private L2).
 #include "kernels.hpp"
+#include "op16.hpp"
 #include <cstdlib>
 
 namespace cosa {
 namespace {
 
-typedef __bf16 bf16;
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BM = 128, BN = 128, BK = 64;
@@ -31,7 +29,7 @@ constexpr int CT_LD = 272;                        // bytes per row of the epilog
 
 enum { EPI_BIAS = 0, EPI_GELU = 1, EPI_RESIDUAL = 2 };
 
-// erf-GELU (nn.GELU default).  erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, far below bf16 resolution) on the
+// erf-GELU (nn.GELU default).  erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, far below op16 resolution) on the
 // hardware exp2 / rcp units: ~14 VALU ops instead of libm erff's ~40 with branches.
 __device__ __forceinline__ float gelu_erf(float x)
 {
@@ -52,7 +50,7 @@ typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
 
 // one operand tile (128 rows x 64 k) -> LDS, 16 B per lane, 4 wave-instructions per wave
-__device__ __forceinline__ void stage_tile(const bf16 *__restrict__ src, int row0, int nrows, int ld, int k0,
+__device__ __forceinline__ void stage_tile(const op16 *__restrict__ src, int row0, int nrows, int ld, int k0,
                                            unsigned char *lds_tile, int wave, int lane)
 {
 #pragma unroll
@@ -62,16 +60,32 @@ __device__ __forceinline__ void stage_tile(const bf16 *__restrict__ src, int row
         const int s = (lane & 7) ^ (row & 7);        // logical 16-B slot that lands in physical slot lane&7
         int grow = row0 + row;
         grow = grow < nrows ? grow : nrows - 1;      // clamp the M tail (masked at the store)
-        const bf16 *g = src + (size_t)grow * ld + k0 + s * 8;
+        const op16 *g = src + (size_t)grow * ld + k0 + s * 8;
         __builtin_amdgcn_global_load_lds((gbl_void *)g, (lds_void *)(lds_tile + q * 1024), 16, 0, 0);
     }
 }
 
-template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const bf16 *__restrict__ X, const bf16 *__restrict__ W,
-                                                          const bf16 *__restrict__ bias, const float *__restrict__ R,
-                                                          void *__restrict__ Yv, int M, int N, int K, int tiles_m, int tiles_n)
+// ---- bf16x3 ("split") operands --------------------------------------------------------------------------------------------------
+// A value v is carried as TWO bf16 halves hi = bf16(v), lo = bf16(v - hi) (16 significant bits together), and a product is the three
+// MFMA terms hi*hi + lo*hi + hi*lo accumulated in fp32 (the lo*lo term is below 2^-17 relative).  The GEMM kernels do this WITHOUT a
+// second code path in their main loops: operand rows are stored as [hi (K) | lo (K) | aug (64)] (row stride 2K + 64), and the K loop
+// simply runs over 3K/64 + 1 tiles whose X / W column blocks are picked by split_tile() below:
+//     tiles [0, Kp)        X hi  x W hi          tiles [Kp, 2Kp)     X lo x W hi
+//     tile   2Kp           X aug x W aug         tiles (2Kp, 3Kp]    X hi x W lo
+// The augmentation block carries the BIAS at 16-bit precision with no extra instruction: X aug = (1, 1, 0, ...), W aug[n] = (bias_hi[n],
+// bias_lo[n], 0, ...), so the kernel's own bias operand is zero.  Outputs that feed another split GEMM / the split attention kernel are
+// written as [hi (N) | lo (N)] with row stride ldy (the consumer's 2N + 64 or 2N); fp32 (residual) outputs are unchanged.
+struct SplitGeom { int Kp; };       // K tiles per half (K / 64)
+__device__ __forceinline__ int split_tile_x(int kt, int Kp) { return kt <= 2 * Kp ? kt : kt - 2 * Kp - 1; }
+__device__ __forceinline__ int split_tile_w(int kt, int Kp) { return kt < Kp ? kt : (kt < 2 * Kp ? kt - Kp : (kt == 2 * Kp ? kt : kt - Kp - 1)); }
+
+template <int EPI, int SPLIT = 0>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const op16 *__restrict__ X, const op16 *__restrict__ W,
+                                                          const op16 *__restrict__ bias, const float *__restrict__ R,
+                                                          void *__restrict__ Yv, int M, int N, int K, int tiles_m, int tiles_n,
+                                                          int ld, int ldy)
 {
+    // SPLIT: K is the LOGICAL contraction length; operand rows have stride ld = 2K + 64, 16-bit outputs go to [hi | lo] rows of stride ldy
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     // XCD-aware remap (bijective): consecutive ids of one XCD walk the n-tiles of one m-panel
@@ -91,9 +105,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const bf16 *__restric
 #pragma unroll
         for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int nk = K / BK;
-    stage_tile(W, n0, N, K, 0, smem, wave, lane);
-    stage_tile(X, m0, M, K, 0, smem + TILE_BYTES, wave, lane);
+    const int Kp = K / BK;
+    const int nk = SPLIT ? 3 * Kp + 1 : Kp;
+    stage_tile(W, n0, N, ld, 0, smem, wave, lane);
+    stage_tile(X, m0, M, ld, 0, smem + TILE_BYTES, wave, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -102,26 +117,26 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const bf16 *__restric
         unsigned char *cur = smem + (kt & 1) * STAGE_BYTES;
         unsigned char *nxt = smem + ((kt + 1) & 1) * STAGE_BYTES;
         if (kt + 1 < nk) {
-            stage_tile(W, n0, N, K, (kt + 1) * BK, nxt, wave, lane);
-            stage_tile(X, m0, M, K, (kt + 1) * BK, nxt + TILE_BYTES, wave, lane);
+            stage_tile(W, n0, N, ld, (SPLIT ? split_tile_w(kt + 1, Kp) : kt + 1) * BK, nxt, wave, lane);
+            stage_tile(X, m0, M, ld, (SPLIT ? split_tile_x(kt + 1, Kp) : kt + 1) * BK, nxt + TILE_BYTES, wave, lane);
         }
         const unsigned char *At = cur + (wr * 64) * 128;
         const unsigned char *Bt = cur + TILE_BYTES + (wc * 64) * 128;
 #pragma unroll
         for (int ks = 0; ks < 2; ks++) {
-            bf16x8 a[4], b[4];
+            op16x8 a[4], b[4];
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const int row = i * 16 + frow;
                 const int slot = ((fq + 4 * ks) ^ (row & 7)) << 4;
-                a[i] = *reinterpret_cast<const bf16x8 *>(At + row * 128 + slot);
-                b[i] = *reinterpret_cast<const bf16x8 *>(Bt + row * 128 + slot);
+                a[i] = *reinterpret_cast<const op16x8 *>(At + row * 128 + slot);
+                b[i] = *reinterpret_cast<const op16x8 *>(Bt + row * 128 + slot);
             }
 #pragma unroll
             for (int i = 0; i < 4; i++)
 #pragma unroll
                 for (int j = 0; j < 4; j++)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = COSA_MFMA_16x16x32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -146,14 +161,16 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const bf16 *__restric
                 for (int r = 0; r < 4; r++) v[r] = acc[i][j][r] + bv[r];
                 *reinterpret_cast<f32x4 *>(Ct + ml * (BN * 4 + 16) + nl * 4) = v;
             } else {
-                bf16x4 v;
+                op16x4 v, vlo;
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     float t = acc[i][j][r] + bv[r];
                     if (EPI == EPI_GELU) t = gelu_erf(t);
-                    v[r] = (bf16)t;
+                    v[r] = (op16)t;
+                    if (SPLIT) vlo[r] = (op16)(t - (float)v[r]);
                 }
-                *reinterpret_cast<bf16x4 *>(Ct + ml * CT_LD + nl * 2) = v;
+                *reinterpret_cast<op16x4 *>(Ct + ml * CT_LD + nl * 2) = v;
+                if (SPLIT) *reinterpret_cast<op16x4 *>(Ct + BM * CT_LD + ml * CT_LD + nl * 2) = vlo;
             }
         }
     }
@@ -172,13 +189,17 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const bf16 *__restric
             }
         }
     } else {
-        bf16 *Y = static_cast<bf16 *>(Yv);
+        op16 *Y = static_cast<op16 *>(Yv);
 #pragma unroll
         for (int c = tid; c < BM * 16; c += 256) {
             const int ml = c >> 4, s = c & 15;
-            if (m0 + ml < M)
-                *reinterpret_cast<uint4 *>(Y + (size_t)(m0 + ml) * N + n0 + s * 8) =
+            if (m0 + ml < M) {
+                *reinterpret_cast<uint4 *>(Y + (size_t)(m0 + ml) * ldy + n0 + s * 8) =
                     *reinterpret_cast<const uint4 *>(Ct + ml * CT_LD + s * 16);
+                if (SPLIT)
+                    *reinterpret_cast<uint4 *>(Y + (size_t)(m0 + ml) * ldy + N + n0 + s * 8) =
+                        *reinterpret_cast<const uint4 *>(Ct + BM * CT_LD + ml * CT_LD + s * 16);
+            }
         }
     }
 }
@@ -194,7 +215,7 @@ constexpr int V2_BM = 256, V2_BN = 128;
 constexpr int V2_STAGE = (V2_BM + V2_BN) * 128;        // 48 KB: W tile (128 rows) then X tile (256 rows), 128 B per row
 constexpr int V2_CT_LD_BF16 = 272, V2_CT_LD_F32 = 528;
 
-__device__ __forceinline__ void stage_v2(const bf16 *__restrict__ W, const bf16 *__restrict__ X, int n0, int m0, int M, int K,
+__device__ __forceinline__ void stage_v2(const op16 *__restrict__ W, const op16 *__restrict__ X, int n0, int m0, int M, int K,
                                          int k0, unsigned char *stage, int wave, int lane)
 {
 #pragma unroll
@@ -202,7 +223,7 @@ __device__ __forceinline__ void stage_v2(const bf16 *__restrict__ W, const bf16 
         const int q = wave * 6 + i;                    // 48 one-KiB pieces: 0..15 -> W rows, 16..47 -> X rows
         const int row = 8 * q + (lane >> 3);           // row inside the 384-row stage image
         const int s = (lane & 7) ^ (row & 7);
-        const bf16 *g;
+        const op16 *g;
         if (q < 16) g = W + (size_t)(n0 + row) * K + k0 + s * 8;
         else {
             int gm = m0 + row - 128;
@@ -214,8 +235,8 @@ __device__ __forceinline__ void stage_v2(const bf16 *__restrict__ W, const bf16 
 }
 
 template <int EPI>
-__global__ __launch_bounds__(512, 1) void gemm_bf16_v2_kernel(const bf16 *__restrict__ X, const bf16 *__restrict__ W,
-                                                             const bf16 *__restrict__ bias, const float *__restrict__ R,
+__global__ __launch_bounds__(512, 1) void gemm_bf16_v2_kernel(const op16 *__restrict__ X, const op16 *__restrict__ W,
+                                                             const op16 *__restrict__ bias, const float *__restrict__ R,
                                                              void *__restrict__ Yv, int M, int N, int K, int tiles_m, int tiles_n)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -252,19 +273,19 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v2_kernel(const bf16 *__rest
         const unsigned char *Bt = cur + 128 * 128 + (wm * 64) * 128;  // X rows (tokens)
 #pragma unroll
         for (int ks = 0; ks < 2; ks++) {
-            bf16x8 a[4], b[4];
+            op16x8 a[4], b[4];
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const int row = i * 16 + frow;
                 const int slot = ((fq + 4 * ks) ^ (row & 7)) << 4;
-                a[i] = *reinterpret_cast<const bf16x8 *>(At + row * 128 + slot);
-                b[i] = *reinterpret_cast<const bf16x8 *>(Bt + row * 128 + slot);
+                a[i] = *reinterpret_cast<const op16x8 *>(At + row * 128 + slot);
+                b[i] = *reinterpret_cast<const op16x8 *>(Bt + row * 128 + slot);
             }
 #pragma unroll
             for (int i = 0; i < 4; i++)
 #pragma unroll
                 for (int j = 0; j < 4; j++)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = COSA_MFMA_16x16x32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
     }
     __syncthreads();      // every wave is done reading the last stage before the tile image is overwritten
@@ -286,14 +307,14 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v2_kernel(const bf16 *__rest
                 for (int r = 0; r < 4; r++) v[r] = acc[i][j][r] + bv[r];
                 *reinterpret_cast<f32x4 *>(Ct + ml * V2_CT_LD_F32 + nl * 4) = v;
             } else {
-                bf16x4 v;
+                op16x4 v;
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     float t = acc[i][j][r] + bv[r];
                     if (EPI == EPI_GELU) t = gelu_erf(t);
-                    v[r] = (bf16)t;
+                    v[r] = (op16)t;
                 }
-                *reinterpret_cast<bf16x4 *>(Ct + ml * V2_CT_LD_BF16 + nl * 2) = v;
+                *reinterpret_cast<op16x4 *>(Ct + ml * V2_CT_LD_BF16 + nl * 2) = v;
             }
         }
     }
@@ -311,7 +332,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v2_kernel(const bf16 *__rest
             }
         }
     } else {
-        bf16 *Y = static_cast<bf16 *>(Yv);
+        op16 *Y = static_cast<op16 *>(Yv);
 #pragma unroll
         for (int c = tid; c < V2_BM * 16; c += 512) {
             const int ml = c >> 4, s = c & 15;
@@ -335,7 +356,7 @@ constexpr size_t kLdsBytesV2 = 3 * V2_STAGE;      // 147456 >= 256*528 (fp32 epi
 constexpr int V3_T = 256;
 constexpr int V3_STAGE = 2 * V3_T * 128;               // 64 KB: W tile (256 rows) then X tile (256 rows)
 
-__device__ __forceinline__ void stage_v3(const bf16 *__restrict__ W, const bf16 *__restrict__ X, int n0, int m0, int M, int K,
+__device__ __forceinline__ void stage_v3(const op16 *__restrict__ W, const op16 *__restrict__ X, int n0, int m0, int M, int K,
                                          int k0, unsigned char *stage, int wave, int lane)
 {
 #pragma unroll
@@ -343,7 +364,7 @@ __device__ __forceinline__ void stage_v3(const bf16 *__restrict__ W, const bf16 
         const int q = wave * 8 + i;                    // 64 one-KiB pieces: 0..31 -> W rows, 32..63 -> X rows
         const int row = 8 * q + (lane >> 3);
         const int s = (lane & 7) ^ (row & 7);
-        const bf16 *g;
+        const op16 *g;
         if (q < 32) g = W + (size_t)(n0 + row) * K + k0 + s * 8;
         else {
             int gm = m0 + row - V3_T;
@@ -355,8 +376,8 @@ __device__ __forceinline__ void stage_v3(const bf16 *__restrict__ W, const bf16 
 }
 
 template <int EPI>
-__global__ __launch_bounds__(512, 1) void gemm_bf16_v3_kernel(const bf16 *__restrict__ X, const bf16 *__restrict__ W,
-                                                             const bf16 *__restrict__ bias, const float *__restrict__ R,
+__global__ __launch_bounds__(512, 1) void gemm_bf16_v3_kernel(const op16 *__restrict__ X, const op16 *__restrict__ W,
+                                                             const op16 *__restrict__ bias, const float *__restrict__ R,
                                                              void *__restrict__ Yv, int M, int N, int K, int tiles_m, int tiles_n)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -390,23 +411,23 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v3_kernel(const bf16 *__rest
         const unsigned char *Bt = cur + V3_T * 128 + (wb * 64) * 128;
 #pragma unroll
         for (int ks = 0; ks < 2; ks++) {
-            bf16x8 a[8], b[4];
+            op16x8 a[8], b[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const int row = j * 16 + frow;
-                b[j] = *reinterpret_cast<const bf16x8 *>(Bt + row * 128 + (((fq + 4 * ks) ^ (row & 7)) << 4));
+                b[j] = *reinterpret_cast<const op16x8 *>(Bt + row * 128 + (((fq + 4 * ks) ^ (row & 7)) << 4));
             }
 #pragma unroll
             for (int i = 0; i < 8; i++) {
                 const int row = i * 16 + frow;
-                a[i] = *reinterpret_cast<const bf16x8 *>(At + row * 128 + (((fq + 4 * ks) ^ (row & 7)) << 4));
+                a[i] = *reinterpret_cast<const op16x8 *>(At + row * 128 + (((fq + 4 * ks) ^ (row & 7)) << 4));
             }
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < 8; i++)
 #pragma unroll
                 for (int j = 0; j < 4; j++)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = COSA_MFMA_16x16x32(a[i], b[j], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -432,8 +453,8 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v3_kernel(const bf16 *__rest
             }
         }
     } else {
-        // bf16 out through LDS in two 128-feature halves (the wave row wa owns one half each)
-        bf16 *Y = static_cast<bf16 *>(Yv);
+        // op16 out through LDS in two 128-feature halves (the wave row wa owns one half each)
+        op16 *Y = static_cast<op16 *>(Yv);
         unsigned char *Ct = smem;
 #pragma unroll
         for (int half = 0; half < 2; half++) {
@@ -447,14 +468,14 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v3_kernel(const bf16 *__rest
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
                         const int ml = wb * 64 + 16 * j + frow;
-                        bf16x4 v;
+                        op16x4 v;
 #pragma unroll
                         for (int r = 0; r < 4; r++) {
                             float t = acc[i][j][r] + bv[r];
                             if (EPI == EPI_GELU) t = gelu_erf(t);
-                            v[r] = (bf16)t;
+                            v[r] = (op16)t;
                         }
-                        *reinterpret_cast<bf16x4 *>(Ct + ml * CT_LD + nl * 2) = v;
+                        *reinterpret_cast<op16x4 *>(Ct + ml * CT_LD + nl * 2) = v;
                     }
                 }
             }
@@ -477,12 +498,12 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v3_kernel(const bf16 *__rest
 // tiles, and the first K-stage of the next tile is fetched (global_load_lds) during the last K-step of the
 // current one, so neither the first-stage latency nor the tile index arithmetic sits between two tiles.  The
 // epilogue goes straight from the accumulators to memory (each lane owns 4 consecutive features of a token:
-// 8-byte bf16 / 16-byte fp32 stores), which leaves LDS free for that prefetch.  With K = 768 a tile is only
+// 8-byte op16 / 16-byte fp32 stores), which leaves LDS free for that prefetch.  With K = 768 a tile is only
 // 12 K-steps long, and the non-persistent kernels spend ~25 % of their time in pro/epilogue.
 // =====================================================================================================
 template <int EPI>
-__global__ __launch_bounds__(512, 1) void gemm_bf16_v4_kernel(const bf16 *__restrict__ X, const bf16 *__restrict__ W,
-                                                             const bf16 *__restrict__ bias, const float *__restrict__ R,
+__global__ __launch_bounds__(512, 1) void gemm_bf16_v4_kernel(const op16 *__restrict__ X, const op16 *__restrict__ W,
+                                                             const op16 *__restrict__ bias, const float *__restrict__ R,
                                                              void *__restrict__ Yv, int M, int N, int K, int tiles_m, int tiles_n)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -528,22 +549,22 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v4_kernel(const bf16 *__rest
             const unsigned char *Bt = cur + V3_T * 128 + (wb * 64) * 128;
 #pragma unroll
             for (int ks = 0; ks < 2; ks++) {
-                bf16x8 a[8], b[4];
+                op16x8 a[8], b[4];
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const int row = j * 16 + frow;
-                    b[j] = *reinterpret_cast<const bf16x8 *>(Bt + row * 128 + (((fq + 4 * ks) ^ (row & 7)) << 4));
+                    b[j] = *reinterpret_cast<const op16x8 *>(Bt + row * 128 + (((fq + 4 * ks) ^ (row & 7)) << 4));
                 }
 #pragma unroll
                 for (int i = 0; i < 8; i++) {
                     const int row = i * 16 + frow;
-                    a[i] = *reinterpret_cast<const bf16x8 *>(At + row * 128 + (((fq + 4 * ks) ^ (row & 7)) << 4));
+                    a[i] = *reinterpret_cast<const op16x8 *>(At + row * 128 + (((fq + 4 * ks) ^ (row & 7)) << 4));
                 }
 #pragma unroll
                 for (int i = 0; i < 8; i++)
 #pragma unroll
                     for (int j = 0; j < 4; j++)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = COSA_MFMA_16x16x32(a[i], b[j], acc[i][j], 0, 0, 0);
             }
             g ^= 1;
         }
@@ -562,15 +583,15 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v4_kernel(const bf16 *__rest
                         const f32x4 rv = *reinterpret_cast<const f32x4 *>(R + off);
                         *reinterpret_cast<f32x4 *>(Y + off) = acc[i][j] + bv + rv;
                     } else {
-                        bf16 *Y = static_cast<bf16 *>(Yv);
-                        bf16x4 v;
+                        op16 *Y = static_cast<op16 *>(Yv);
+                        op16x4 v;
 #pragma unroll
                         for (int r = 0; r < 4; r++) {
                             float t = acc[i][j][r] + bv[r];
                             if (EPI == EPI_GELU) t = gelu_erf(t);
-                            v[r] = (bf16)t;
+                            v[r] = (op16)t;
                         }
-                        *reinterpret_cast<bf16x4 *>(Y + off) = v;
+                        *reinterpret_cast<op16x4 *>(Y + off) = v;
                     }
                 }
             }
@@ -613,8 +634,8 @@ constexpr size_t kLdsBytesV5 = 2 * V5_BUF;             // 128 KB; also holds the
     } while (0)
 
 template <int EPI, int ABL = 0>      // ABL: timing ablations only (1 no DMA in the loop, 2 no fragment reads, 4 no barriers) -- wrong results
-__global__ __launch_bounds__(512, 1) void gemm_bf16_v5_kernel(const bf16 *__restrict__ X, const bf16 *__restrict__ W,
-                                                             const bf16 *__restrict__ bias, const float *__restrict__ R,
+__global__ __launch_bounds__(512, 1) void gemm_bf16_v5_kernel(const op16 *__restrict__ X, const op16 *__restrict__ W,
+                                                             const op16 *__restrict__ bias, const float *__restrict__ R,
                                                              void *__restrict__ Yv, int M, int N, int K, int tiles_m, int tiles_n)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -682,15 +703,15 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v5_kernel(const bf16 *__rest
     const int lo1 = lo0 ^ 64;                                          // ks = 1
     const unsigned char *rdW0 = smem + V5_HALF + wr * 8192 + lo0, *rdW1 = smem + V5_HALF + wr * 8192 + lo1;
     const unsigned char *rdX0 = smem + wc * 4096 + lo0, *rdX1 = smem + wc * 4096 + lo1;
-    bf16x8 a[4][2], x0[2][2], x1[2][2];
+    op16x8 a[4][2], x0[2][2], x1[2][2];
     if (ABL & 2) {
 #pragma unroll
         for (int i = 0; i < 4; i++)
 #pragma unroll
             for (int k = 0; k < 2; k++) {
-                a[i][k] = (bf16x8){};
-                x0[i & 1][k] = (bf16x8){};
-                x1[i & 1][k] = (bf16x8){};
+                a[i][k] = (op16x8){};
+                x0[i & 1][k] = (op16x8){};
+                x1[i & 1][k] = (op16x8){};
                 asm volatile("" : "+v"(a[i][k]), "+v"(x0[i & 1][k]), "+v"(x1[i & 1][k]));
             }
     }
@@ -698,14 +719,14 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v5_kernel(const bf16 *__rest
 #define V5_LDW(q, buf)                                                                                             \
     if (!(ABL & 2)) _Pragma("unroll") for (int blk = 0; blk < 4; blk++) {                                                          \
         const int o_ = (buf) * V5_BUF + (q) * 2 * V5_HALF + blk * 2048;                                            \
-        a[blk][0] = *reinterpret_cast<const bf16x8 *>(rdW0 + o_);                                                  \
-        a[blk][1] = *reinterpret_cast<const bf16x8 *>(rdW1 + o_);                                                  \
+        a[blk][0] = *reinterpret_cast<const op16x8 *>(rdW0 + o_);                                                  \
+        a[blk][1] = *reinterpret_cast<const op16x8 *>(rdW1 + o_);                                                  \
     }
 #define V5_LDX(dst, q, buf)                                                                                        \
     if (!(ABL & 2)) _Pragma("unroll") for (int blk = 0; blk < 2; blk++) {                                                          \
         const int o_ = (buf) * V5_BUF + (q) * 2 * V5_HALF + blk * 2048;                                            \
-        dst[blk][0] = *reinterpret_cast<const bf16x8 *>(rdX0 + o_);                                                \
-        dst[blk][1] = *reinterpret_cast<const bf16x8 *>(rdX1 + o_);                                                \
+        dst[blk][0] = *reinterpret_cast<const op16x8 *>(rdX0 + o_);                                                \
+        dst[blk][1] = *reinterpret_cast<const op16x8 *>(rdX1 + o_);                                                \
     }
 #define V5_MMA(qa, xf, qb)                                                                                         \
     do {                                                                                                           \
@@ -716,7 +737,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v5_kernel(const bf16 *__rest
             _Pragma("unroll") for (int i = 0; i < 4; i++)                                                          \
                 _Pragma("unroll") for (int j = 0; j < 2; j++)                                                      \
                     acc[(qa) * 4 + i][(qb) * 2 + j] =                                                              \
-                        __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][ks], xf[j][ks], acc[(qa) * 4 + i][(qb) * 2 + j], 0, 0, 0); \
+                        COSA_MFMA_16x16x32(a[i][ks], xf[j][ks], acc[(qa) * 4 + i][(qb) * 2 + j], 0, 0, 0); \
         __builtin_amdgcn_s_setprio(0);                                                                             \
     } while (0)
 
@@ -785,8 +806,8 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v5_kernel(const bf16 *__rest
             }
         }
     } else {
-        // bf16 out through LDS, one 128-feature half at a time: tile [256 tokens][128 features], 272-byte rows
-        bf16 *Y = static_cast<bf16 *>(Yv);
+        // op16 out through LDS, one 128-feature half at a time: tile [256 tokens][128 features], 272-byte rows
+        op16 *Y = static_cast<op16 *>(Yv);
         unsigned char *Ct = smem;
 #pragma unroll
         for (int half = 0; half < 2; half++) {
@@ -800,14 +821,14 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v5_kernel(const bf16 *__rest
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const int ml = (j >> 1) * 128 + wc * 32 + (j & 1) * 16 + frow;
-                    bf16x4 v;
+                    op16x4 v;
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
                         float tv = acc[i][j][r] + bv[r];
                         if (EPI == EPI_GELU) tv = gelu_erf(tv);
-                        v[r] = (bf16)tv;
+                        v[r] = (op16)tv;
                     }
-                    *reinterpret_cast<bf16x4 *>(Ct + ml * CT_LD + nl * 2) = v;
+                    *reinterpret_cast<op16x4 *>(Ct + ml * CT_LD + nl * 2) = v;
                 }
             }
             __syncthreads();
@@ -841,7 +862,6 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v5_kernel(const bf16 *__rest
 // =====================================================================================================
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 // AUX: cache policy of the output stores (bit 1 = nt, bit 0 = sc0, bit 4 = sc1).  Plain stores allocate in L2: one round of
 // epilogues of an XCD's 32 CUs is 4 MB = the whole L2, which throws out the W panel and the X panels the DMA stream is
@@ -849,11 +869,13 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 // training step the consumer kernel runs next and wants the output in L2 / MALL: there plain stores win (qkv 293 us vs 347 us
 // with nt+sc0+sc1; v5 314 us), so 0 is the default.
 // ABL6 (timing only): 1 = epilogue without the stores, 2 = no epilogue work, 3 = L2-resident store window, 4 = stores dropped
-template <int EPI, int ABL6 = 0, int AUX = 0>
-__global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const bf16 *__restrict__ X, const bf16 *__restrict__ W,
-                                                             const bf16 *__restrict__ bias, const float *__restrict__ R,
+// SPLIT: bf16x3 operands (see split_tile_x / split_tile_w above): K is the logical contraction length, operand rows have stride ld
+// (= 2K + 64), the K loop has 3K/64 + 1 tiles, 16-bit outputs are written as [hi | lo] halves of rows with stride ldy.
+template <int EPI, int ABL6 = 0, int AUX = 0, int SPLIT = 0>
+__global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__restrict__ X, const op16 *__restrict__ W,
+                                                             const op16 *__restrict__ bias, const float *__restrict__ R,
                                                              void *__restrict__ Yv, int M, int N, int K, int tiles_m, int tiles_n,
-                                                             int stagger_ticks, unsigned long long *__restrict__ stamps)
+                                                             int stagger_ticks, unsigned long long *__restrict__ stamps, int ld, int ldy)
 {
     // optional device-side span of this launch (100 MHz wall clock; min start / max end over workgroups): HIP events cannot be
     // recorded inside a captured hipGraph on ROCm, so bench.py's roofline leg reads these (cosa_gemm_set_stamp_slot)
@@ -866,7 +888,8 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const bf16 *__rest
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wr = wave >> 2, wc = wave & 3;
     const int frow = lane & 15, fq = lane >> 4;
-    const int nk = K / BK;
+    const int Kp = K / BK;
+    const int nk = SPLIT ? 3 * Kp + 1 : Kp;
     const int ntiles = tiles_m * tiles_n, G = gridDim.x;
     const int cq = ntiles >> 3, cr = ntiles & 7;
     unsigned char *Yb = static_cast<unsigned char *>(Yv);
@@ -881,15 +904,15 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const bf16 *__rest
     auto descX = [&](int m0_) {
         int rows = M - m0_;
         rows = rows > 256 ? 256 : rows;
-        return __builtin_amdgcn_make_buffer_rsrc((void *)(X + (size_t)m0_ * K), 0, rows * K * 2, FL);
+        return __builtin_amdgcn_make_buffer_rsrc((void *)(X + (size_t)m0_ * ld), 0, rows * ld * 2, FL);
     };
-    auto descW = [&](int n0_) { return __builtin_amdgcn_make_buffer_rsrc((void *)(W + (size_t)n0_ * K), 0, 256 * K * 2, FL); };
+    auto descW = [&](int n0_) { return __builtin_amdgcn_make_buffer_rsrc((void *)(W + (size_t)n0_ * ld), 0, 256 * ld * 2, FL); };
     auto descY = [&](int m0_, int n0_) {
         if (ABL6 == 3) { m0_ = (int)blockIdx.x * 256 % (M - 256); n0_ = 0; }     // timing only: every job of a workgroup rewrites one L2-resident window
         if (ABL6 == 4) return __builtin_amdgcn_make_buffer_rsrc((void *)Yb, 0, 0, FL);   // timing only: every store is out of range (dropped)
         int rows = M - m0_;
         rows = rows > 256 ? 256 : rows;
-        return __builtin_amdgcn_make_buffer_rsrc((void *)(Yb + ((size_t)m0_ * N + n0_) * ES), 0, (rows * N - n0_) * ES, FL);
+        return __builtin_amdgcn_make_buffer_rsrc((void *)(Yb + ((size_t)m0_ * ldy + n0_) * ES), 0, (rows * ldy - n0_) * ES, FL);
     };
     // the residual window of a job as raw descriptor words (inline-asm loads), same geometry as the Y window
     auto descR = [&](int m0_, int n0_) {
@@ -907,7 +930,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const bf16 *__rest
 #pragma unroll
         for (int h = 0; h < 2; h++)
 #pragma unroll
-            for (int i = 0; i < 2; i++) vo[h][i] = (unsigned)(((h * 128 + 8 * (2 * wave + i) + (lane >> 3)) * K + sw) * 2);
+            for (int i = 0; i < 2; i++) vo[h][i] = (unsigned)(((h * 128 + 8 * (2 * wave + i) + (lane >> 3)) * ld + sw) * 2);
     }
     // ... and the store offset inside the tile's Y window for each 16-token row group (b, jj); after the lane swap a lane
     // owns features  wr*64 + pair*32 + (fq&1)*16 + 4*(fq&2) .. +7  of its token
@@ -916,7 +939,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const bf16 *__rest
 #pragma unroll
     for (int g4 = 0; g4 < 4; g4++) {
         const int row = (g4 >> 1) * 128 + wc * 32 + (g4 & 1) * 16 + frow;
-        voY[g4] = RES ? (unsigned)((row * N + wr * 64 + 4 * fq) * 4) : (unsigned)((row * N + wr * 64 + (fq & 1) * 16 + 4 * (fq & 2)) * 2);
+        voY[g4] = RES ? (unsigned)((row * ldy + wr * 64 + 4 * fq) * 4) : (unsigned)((row * ldy + wr * 64 + (fq & 1) * 16 + 4 * (fq & 2)) * 2);
     }
 
     int o = blockIdx.x;
@@ -947,13 +970,13 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const bf16 *__rest
     }
     bool have_prev = false;
 
-    // bias of the job about to start, as packed bf16: features a*128 + wr*64 + ii*16 + 4fq .. +3.  Loaded by hand (inline asm) so
+    // bias of the job about to start, as packed op16: features a*128 + wr*64 + ii*16 + 4fq .. +3.  Loaded by hand (inline asm) so
     // that the compiler does not put its own vmcnt wait in front of the first use: the phase-4 waits cover these loads.
     u32x2 bb[2][4];
     const unsigned bias_lane = (unsigned)((wr * 64 + 4 * fq) * 2);        // scalar base + 32-bit lane offset: no 64-bit per-lane pointer to keep alive
 #define V6_LOAD_BIAS(nbase)                                                                               \
     _Pragma("unroll") for (int a_ = 0; a_ < 2; a_++) _Pragma("unroll") for (int i_ = 0; i_ < 4; i_++) {   \
-        const bf16 *p_ = bias + (nbase) + a_ * 128 + i_ * 16;                                             \
+        const op16 *p_ = bias + (nbase) + a_ * 128 + i_ * 16;                                             \
         asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(bb[a_][i_]) : "v"(bias_lane), "s"(p_) : "memory"); \
     }
 
@@ -963,7 +986,8 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const bf16 *__rest
         const int kt_ = (kt);                                                                                          \
         const bool own_ = kt_ < nk;                                                                                    \
         const __amdgpu_buffer_rsrc_t rs_ = ((which) & 1) ? (own_ ? cW : nW) : (own_ ? cX : nX);                        \
-        const int so_ = (own_ ? kt_ : kt_ - nk) * 128;                                                                 \
+        const int t_ = own_ ? kt_ : kt_ - nk;                                                                          \
+        const int so_ = (SPLIT ? (((which) & 1) ? split_tile_w(t_, Kp) : split_tile_x(t_, Kp)) : t_) * 128;            \
         unsigned char *dst_ = smem + (bsel) * V5_BUF + (which) * V5_HALF + (2 * wave) * 1024;                          \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_, (lds_void *)dst_, 16, vo[(which) >> 1][0], so_, 0, 0);           \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_, (lds_void *)(dst_ + 1024), 16, vo[(which) >> 1][1], so_, 0, 0);  \
@@ -1000,19 +1024,19 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const bf16 *__rest
     const int lo0 = frow * 128 + ((fq ^ (frow & 7)) << 4), lo1 = lo0 ^ 64;
     const unsigned char *rdW0 = smem + V5_HALF + wr * 8192 + lo0, *rdW1 = smem + V5_HALF + wr * 8192 + lo1;
     const unsigned char *rdX0 = smem + wc * 4096 + lo0, *rdX1 = smem + wc * 4096 + lo1;
-    bf16x8 a[4][2], x0[2][2], x1[2][2];
+    op16x8 a[4][2], x0[2][2], x1[2][2];
 
 #define V6_LDW(q, buf)                                                                     \
     _Pragma("unroll") for (int blk = 0; blk < 4; blk++) {                                  \
         const int o_ = (buf) * V5_BUF + (q) * 2 * V5_HALF + blk * 2048;                    \
-        a[blk][0] = *reinterpret_cast<const bf16x8 *>(rdW0 + o_);                          \
-        a[blk][1] = *reinterpret_cast<const bf16x8 *>(rdW1 + o_);                          \
+        a[blk][0] = *reinterpret_cast<const op16x8 *>(rdW0 + o_);                          \
+        a[blk][1] = *reinterpret_cast<const op16x8 *>(rdW1 + o_);                          \
     }
 #define V6_LDX(dst, q, buf)                                                                \
     _Pragma("unroll") for (int blk = 0; blk < 2; blk++) {                                  \
         const int o_ = (buf) * V5_BUF + (q) * 2 * V5_HALF + blk * 2048;                    \
-        dst[blk][0] = *reinterpret_cast<const bf16x8 *>(rdX0 + o_);                        \
-        dst[blk][1] = *reinterpret_cast<const bf16x8 *>(rdX1 + o_);                        \
+        dst[blk][0] = *reinterpret_cast<const op16x8 *>(rdX0 + o_);                        \
+        dst[blk][1] = *reinterpret_cast<const op16x8 *>(rdX1 + o_);                        \
     }
     // quadrant (qa, qb) out: acc[qa*4 + ii][qb*2 + jj][r] = feature qa*128 + wr*64 + ii*16 + 4fq + r, token qb*128 + wc*32 + jj*16 + frow
 #define V6_EPI(qa, qb, rsY)                                                                                         \
@@ -1022,8 +1046,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const bf16 *__rest
     } else if (RES) {                                                                                               \
         _Pragma("unroll") for (int ii = 0; ii < 4; ii++) {                                                          \
             const unsigned lo_ = bb[qa][ii][0], hi_ = bb[qa][ii][1];                                                \
-            const f32x4 bv_ = {__builtin_bit_cast(float, lo_ << 16), __builtin_bit_cast(float, lo_ & 0xffff0000u),  \
-                               __builtin_bit_cast(float, hi_ << 16), __builtin_bit_cast(float, hi_ & 0xffff0000u)}; \
+            const f32x4 bv_ = {op16_lo(lo_), op16_hi(lo_), op16_lo(hi_), op16_hi(hi_)};                              \
             _Pragma("unroll") for (int jj = 0; jj < 2; jj++) {                                                      \
                 const f32x4 o4_ = acc[(qa) * 4 + ii][(qb) * 2 + jj] + bv_;                                          \
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o4_), rsY,                         \
@@ -1039,13 +1062,23 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const bf16 *__rest
                 v1_[r] = gelu_erf(v1_[r]);                                                                          \
             }                                                                                                       \
         }                                                                                                           \
-        const bf16x2 p0_ = {(bf16)v0_[0], (bf16)v0_[1]}, p1_ = {(bf16)v0_[2], (bf16)v0_[3]};                        \
-        const bf16x2 p2_ = {(bf16)v1_[0], (bf16)v1_[1]}, p3_ = {(bf16)v1_[2], (bf16)v1_[3]};                        \
+        const op16x2 p0_ = {(op16)v0_[0], (op16)v0_[1]}, p1_ = {(op16)v0_[2], (op16)v0_[3]};                        \
+        const op16x2 p2_ = {(op16)v1_[0], (op16)v1_[1]}, p3_ = {(op16)v1_[2], (op16)v1_[3]};                        \
         const auto s0_ = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, p0_), __builtin_bit_cast(unsigned, p2_), false, false); \
         const auto s1_ = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, p1_), __builtin_bit_cast(unsigned, p3_), false, false); \
         const u32x4 out_ = {s0_[0], s1_[0], s0_[1], s1_[1]};                                                        \
         if (ABL6 == 0 || ABL6 == 3 || ABL6 == 4) __builtin_amdgcn_raw_buffer_store_b128(out_, rsY, voY[(qb) * 2 + jj] + ((qa) * 128 + pr * 32) * 2, 0, AUX); \
         else asm volatile("" ::"v"(out_));                                                                          \
+        if (SPLIT) {          /* the lo halves: what the 16-bit rounding above dropped, at column N + n */              \
+            const op16x2 q0_ = {(op16)(v0_[0] - (float)p0_[0]), (op16)(v0_[1] - (float)p0_[1])};                    \
+            const op16x2 q1_ = {(op16)(v0_[2] - (float)p1_[0]), (op16)(v0_[3] - (float)p1_[1])};                    \
+            const op16x2 q2_ = {(op16)(v1_[0] - (float)p2_[0]), (op16)(v1_[1] - (float)p2_[1])};                    \
+            const op16x2 q3_ = {(op16)(v1_[2] - (float)p3_[0]), (op16)(v1_[3] - (float)p3_[1])};                    \
+            const auto t0_ = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, q0_), __builtin_bit_cast(unsigned, q2_), false, false); \
+            const auto t1_ = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, q1_), __builtin_bit_cast(unsigned, q3_), false, false); \
+            const u32x4 lo4_ = {t0_[0], t1_[0], t0_[1], t1_[1]};                                                    \
+            __builtin_amdgcn_raw_buffer_store_b128(lo4_, rsY, voY[(qb) * 2 + jj] + (N + (qa) * 128 + pr * 32) * 2, 0, AUX); \
+        }                                                                                                           \
     }
     // 16 MFMAs of quadrant (qa, qb); FIRST: the accumulation starts from the bias
 #define V6_MMA(qa, xf, qb, FIRST)                                                                                   \
@@ -1055,13 +1088,13 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const bf16 *__rest
                 f32x4 cb_;                                                                                          \
                 if ((FIRST) && ks == 0 && !RES) {                                                                   \
                     const unsigned lo_ = bb[qa][i][0], hi_ = bb[qa][i][1];                                          \
-                    cb_[0] = __builtin_bit_cast(float, lo_ << 16);                                                  \
-                    cb_[1] = __builtin_bit_cast(float, lo_ & 0xffff0000u);                                          \
-                    cb_[2] = __builtin_bit_cast(float, hi_ << 16);                                                  \
-                    cb_[3] = __builtin_bit_cast(float, hi_ & 0xffff0000u);                                          \
+                    cb_[0] = op16_lo(lo_);                                                                          \
+                    cb_[1] = op16_hi(lo_);                                                                          \
+                    cb_[2] = op16_lo(hi_);                                                                          \
+                    cb_[3] = op16_hi(hi_);                                                                          \
                 }                                                                                                   \
                 _Pragma("unroll") for (int j = 0; j < 2; j++)                                                       \
-                    acc[(qa) * 4 + i][(qb) * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                      \
+                    acc[(qa) * 4 + i][(qb) * 2 + j] = COSA_MFMA_16x16x32(                      \
                         a[i][ks], xf[j][ks], ((FIRST) && ks == 0 && !RES) ? cb_ : acc[(qa) * 4 + i][(qb) * 2 + j], 0, 0, 0); \
             }                                                                                                       \
     } while (0)
@@ -1074,10 +1107,10 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const bf16 *__rest
     V5_BARRIER()
 
     // one K-tile = four phases.  FIRST / LAST are literals; t is the K-tile index inside the job, g the running buffer parity.
-    // VMEM operations per wave around a job boundary (st = epilogue stores: 4 bf16 / 8 fp32 per quadrant; R' = 8 residual loads):
+    // VMEM operations per wave around a job boundary (st = epilogue stores: 4 op16 / 8 fp32 per quadrant; R' = 8 residual loads):
     //   last.1: DMA(A)        last.2: DMA, st Q00, R' Q00     last.3: DMA, st Q01, R' Q01     last.4: DMA, WAIT(A), st Q11, R' Q11
     //   first.1: DMA(B), WAIT(R' Q00), st Q10, R' Q10, bias     first.2: DMA, WAIT(R' Q01)   first.3: DMA, WAIT(R' Q11)   first.4: DMA, WAIT(B, R' Q10)
-    // every WAIT is vmcnt(number of operations issued after its target): bf16 out 14 / - / - / - / 6, residual 38 / 38 / 46 / 30 / 6
+    // every WAIT is vmcnt(number of operations issued after its target): op16 out 14 / - / - / - / 6, residual 38 / 38 / 46 / 30 / 6
     // (6 instead of 14 at first.4 also covers a job without predecessor; operations retire in issue order).
 #define V6_WAIT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define V6_TILE(t, FIRST, LAST)                                                                                     \
@@ -1212,7 +1245,7 @@ struct ConvGeom {
 };
 
 template <bool CONV>
-__global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(const bf16 *__restrict__ dY, const bf16 *__restrict__ X,
+__global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(const op16 *__restrict__ dY, const op16 *__restrict__ X,
                                                            float *__restrict__ dW, float *__restrict__ db, int M, int N, int K,
                                                            int tiles_k, int stages_per_split, int nstages, int ntiles, int tiles_per_xcd,
                                                            ConvGeom cg, int x_bytes)
@@ -1312,7 +1345,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(const bf16 *__restri
         if (st + 1 < st1) stage(st + 1, smem + (par ^ 1) * 32768);
 #pragma unroll
         for (int ks = 0; ks < 2; ks++) {
-            bf16x8 a[4], b[4];
+            op16x8 a[4], b[4];
 #pragma unroll
             for (int h = 0; h < 2; h++) {
                 const int r = ks * 32 + 8 * g + 4 * h + q;
@@ -1332,7 +1365,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(const bf16 *__restri
             for (int i = 0; i < 4; i++)
 #pragma unroll
                 for (int j = 0; j < 4; j++)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = COSA_MFMA_16x16x32(a[i], b[j], acc[i][j], 0, 0, 0);
             if (do_bias) {
 #pragma unroll
                 for (int i = 0; i < 4; i++)
@@ -1378,8 +1411,8 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(const bf16 *__restri
 // offsets are recomputed once per tap (9 times per tile), the channel chunk moves through the scalar offset.
 // X may be a strided view: image b starts at row b*img_rows + row_off of a [*, ldx] matrix (tokens without the cls row).
 // =====================================================================================================
-__global__ __launch_bounds__(256, 2) void conv3x3_dil_kernel(const bf16 *__restrict__ X, const bf16 *__restrict__ Wt,
-                                                            bf16 *__restrict__ Y, int B, int h, int w, int Cin, int Cout,
+__global__ __launch_bounds__(256, 2) void conv3x3_dil_kernel(const op16 *__restrict__ X, const op16 *__restrict__ Wt,
+                                                            op16 *__restrict__ Y, int B, int h, int w, int Cin, int Cout,
                                                             int dil, int img_rows, int row_off, int ldx, int relu,
                                                             long long x_bytes, int tiles_n)
 {
@@ -1445,19 +1478,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_dil_kernel(const bf16 *__restr
         const unsigned char *Bt = cur + TILE_BYTES + (wc * 64) * 128;
 #pragma unroll
         for (int kk = 0; kk < 2; kk++) {
-            bf16x8 a[4], b[4];
+            op16x8 a[4], b[4];
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const int row = i * 16 + frow;
                 const int slot = ((fq + 4 * kk) ^ (row & 7)) << 4;
-                a[i] = *reinterpret_cast<const bf16x8 *>(At + row * 128 + slot);
-                b[i] = *reinterpret_cast<const bf16x8 *>(Bt + row * 128 + slot);
+                a[i] = *reinterpret_cast<const op16x8 *>(At + row * 128 + slot);
+                b[i] = *reinterpret_cast<const op16x8 *>(Bt + row * 128 + slot);
             }
 #pragma unroll
             for (int i = 0; i < 4; i++)
 #pragma unroll
                 for (int j = 0; j < 4; j++)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = COSA_MFMA_16x16x32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -1469,14 +1502,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_dil_kernel(const bf16 *__restr
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int ml = wc * 64 + 16 * j + frow;
-            bf16x4 v;
+            op16x4 v;
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 float t = acc[i][j][r];
                 if (relu) t = t > 0.f ? t : 0.f;
-                v[r] = (bf16)t;
+                v[r] = (op16)t;
             }
-            *reinterpret_cast<bf16x4 *>(Ct + ml * CT_LD + nl * 2) = v;
+            *reinterpret_cast<op16x4 *>(Ct + ml * CT_LD + nl * 2) = v;
         }
     }
     __syncthreads();
@@ -1490,10 +1523,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_dil_kernel(const bf16 *__restr
 
 constexpr size_t kLdsBytes = 128 * (BN * 4 + 16) > 2 * STAGE_BYTES ? 128 * (BN * 4 + 16) : 2 * STAGE_BYTES;
 
-// ---- LayerNorm: fp32 residual stream in, bf16 out; one wave per 768-wide row ---------------------------
+// ---- LayerNorm: fp32 residual stream in, op16 out; one wave per 768-wide row ---------------------------
 template <int D>
-__global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict__ x, const bf16 *__restrict__ g,
-                                                       const bf16 *__restrict__ b, bf16 *__restrict__ y, float *__restrict__ y32,
+__global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict__ x, const op16 *__restrict__ g,
+                                                       const op16 *__restrict__ b, op16 *__restrict__ y, float *__restrict__ y32,
                                                        int rows, float eps)
 {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -1520,16 +1553,16 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
 #pragma unroll
     for (int i = 0; i < PER; i++) {
         const int c0 = (lane + 64 * i) * 4;
-        const bf16x4 gg = *reinterpret_cast<const bf16x4 *>(g + c0);
-        const bf16x4 bb = *reinterpret_cast<const bf16x4 *>(b + c0);
+        const op16x4 gg = *reinterpret_cast<const op16x4 *>(g + c0);
+        const op16x4 bb = *reinterpret_cast<const op16x4 *>(b + c0);
         float o0 = (v[i].x - mean) * rstd * (float)gg[0] + (float)bb[0];
         float o1 = (v[i].y - mean) * rstd * (float)gg[1] + (float)bb[1];
         float o2 = (v[i].z - mean) * rstd * (float)gg[2] + (float)bb[2];
         float o3 = (v[i].w - mean) * rstd * (float)gg[3] + (float)bb[3];
         if (y) {
-            bf16x4 ov;
-            ov[0] = (bf16)o0; ov[1] = (bf16)o1; ov[2] = (bf16)o2; ov[3] = (bf16)o3;
-            *reinterpret_cast<bf16x4 *>(y + (size_t)row * D + c0) = ov;
+            op16x4 ov;
+            ov[0] = (op16)o0; ov[1] = (op16)o1; ov[2] = (op16)o2; ov[3] = (op16)o3;
+            *reinterpret_cast<op16x4 *>(y + (size_t)row * D + c0) = ov;
         }
         if (y32) *reinterpret_cast<float4 *>(y32 + (size_t)row * D + c0) = make_float4(o0, o1, o2, o3);
     }
@@ -1539,6 +1572,16 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
 }  // namespace cosa
 
 using namespace cosa;
+
+#if COSA_OP_F16        // second build of this file (fp16 operands): the same entry points under their _f16 names (include/cosa_hip.h)
+#define cosa_gemm_set_stamp_slot cosa_gemm_set_stamp_slot_f16
+#define cosa_gemm_set_variant cosa_gemm_set_variant_f16
+#define cosa_gemm_bf16 cosa_gemm_f16
+#define cosa_layernorm cosa_layernorm_f16
+#define cosa_gemm_wgrad_bf16 cosa_gemm_wgrad_f16
+#define cosa_conv3x3_dilated_wgrad cosa_conv3x3_dilated_wgrad_f16
+#define cosa_conv3x3_dilated_nhwc cosa_conv3x3_dilated_nhwc_f16
+#endif
 
 static unsigned long long *g_gemm_stamp_slot = nullptr;
 extern "C" void cosa_gemm_set_stamp_slot(void *slot) { g_gemm_stamp_slot = static_cast<unsigned long long *>(slot); }
@@ -1552,7 +1595,7 @@ static int g_gemm_variant = env_variant();   // 0 = pick per shape (measured, to
 extern "C" void cosa_gemm_set_variant(int v) { g_gemm_variant = v; }
 
 template <int EPI>
-static int launch_v2(const bf16 *x, const bf16 *w, const bf16 *b, const float *residual, void *Y, int M, int N, int K, hipStream_t st)
+static int launch_v2(const op16 *x, const op16 *w, const op16 *b, const float *residual, void *Y, int M, int N, int K, hipStream_t st)
 {
     static bool attr_done = false;
     if (!attr_done) {
@@ -1567,7 +1610,7 @@ static int launch_v2(const bf16 *x, const bf16 *w, const bf16 *b, const float *r
 }
 
 template <int EPI>
-static int launch_v3(const bf16 *x, const bf16 *w, const bf16 *b, const float *residual, void *Y, int M, int N, int K, hipStream_t st)
+static int launch_v3(const op16 *x, const op16 *w, const op16 *b, const float *residual, void *Y, int M, int N, int K, hipStream_t st)
 {
     static bool attr_done = false;
     if (!attr_done) {
@@ -1582,7 +1625,7 @@ static int launch_v3(const bf16 *x, const bf16 *w, const bf16 *b, const float *r
 }
 
 template <int EPI, int ABL = 0>
-static int launch_v5(const bf16 *x, const bf16 *w, const bf16 *b, const float *residual, void *Y, int M, int N, int K, hipStream_t st)
+static int launch_v5(const op16 *x, const op16 *w, const op16 *b, const float *residual, void *Y, int M, int N, int K, hipStream_t st)
 {
     static bool attr_done = false;
     if (!attr_done) {
@@ -1596,12 +1639,13 @@ static int launch_v5(const bf16 *x, const bf16 *w, const bf16 *b, const float *r
     return COSA_OK;
 }
 
-template <int EPI, int ABL6 = 0, int AUX = 0>
-static int launch_v6(const bf16 *x, const bf16 *w, const bf16 *b, const float *residual, void *Y, int M, int N, int K, hipStream_t st)
+template <int EPI, int ABL6 = 0, int AUX = 0, int SPLIT = 0>
+static int launch_v6(const op16 *x, const op16 *w, const op16 *b, const float *residual, void *Y, int M, int N, int K, hipStream_t st,
+                     int ld = 0, int ldy = 0)
 {
     static bool attr_done = false;
     if (!attr_done) {
-        COSA_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_bf16_v6_kernel<EPI, ABL6, AUX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytesV5));
+        COSA_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_bf16_v6_kernel<EPI, ABL6, AUX, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytesV5));
         attr_done = true;
     }
     const int tiles_m = (M + 255) / 256, tiles_n = N / 256;
@@ -1610,15 +1654,15 @@ static int launch_v6(const bf16 *x, const bf16 *w, const bf16 *b, const float *r
     // start stagger (see the kernel): about one job time in 100-MHz ticks, from the job's flops at ~4.3 TFLOP/s per CU
     static const char *env = getenv("COSA_GEMM_STAGGER");
     const int stagger = env ? atoi(env) : 0;               // start stagger (see the kernel): measured to make no difference, off
-    hipLaunchKernelGGL((gemm_bf16_v6_kernel<EPI, ABL6, AUX>), dim3(grid), dim3(512), kLdsBytesV5, st, x, w, b, residual, Y, M, N, K, tiles_m, tiles_n, stagger,
-                       g_gemm_stamp_slot);
+    hipLaunchKernelGGL((gemm_bf16_v6_kernel<EPI, ABL6, AUX, SPLIT>), dim3(grid), dim3(512), kLdsBytesV5, st, x, w, b, residual, Y, M, N, K, tiles_m, tiles_n, stagger,
+                       g_gemm_stamp_slot, ld ? ld : K, ldy ? ldy : N);
     g_gemm_stamp_slot = nullptr;                            // one-shot
     COSA_LAUNCH_CHECK();
     return COSA_OK;
 }
 
 template <int EPI>
-static int launch_v4(const bf16 *x, const bf16 *w, const bf16 *b, const float *residual, void *Y, int M, int N, int K, hipStream_t st)
+static int launch_v4(const op16 *x, const op16 *w, const op16 *b, const float *residual, void *Y, int M, int N, int K, hipStream_t st)
 {
     static bool attr_done = false;
     if (!attr_done) {
@@ -1645,7 +1689,7 @@ extern "C" int cosa_gemm_bf16(const void *X, const void *W, const void *bias, co
     const int tiles_m = (M + BM - 1) / BM, tiles_n = N / BN;
     const dim3 grid(tiles_m * tiles_n), blk(256);
     hipStream_t st = as_stream(stream);
-    const bf16 *x = static_cast<const bf16 *>(X), *w = static_cast<const bf16 *>(W), *b = static_cast<const bf16 *>(bias);
+    const op16 *x = static_cast<const op16 *>(X), *w = static_cast<const op16 *>(W), *b = static_cast<const op16 *>(bias);
     // shape rule from the measurements in profiles/r01_gemm_variants.txt: the 256x256 tile wins whenever its tile count
     // quantises well on 256 CUs (wide N, or >= 2 full rounds of tiles); otherwise the 128x128 kernel at 2 workgroups/CU
     const long tiles256 = (long)((M + V3_T - 1) / V3_T) * (N / V3_T);
@@ -1724,18 +1768,65 @@ extern "C" int cosa_gemm_bf16(const void *X, const void *W, const void *bias, co
     }
     switch (epilogue) {
     case EPI_BIAS:
-        hipLaunchKernelGGL(gemm_bf16_kernel<EPI_BIAS>, grid, blk, kLdsBytes, st, x, w, b, residual, Y, M, N, K, tiles_m, tiles_n);
+        hipLaunchKernelGGL(gemm_bf16_kernel<EPI_BIAS>, grid, blk, kLdsBytes, st, x, w, b, residual, Y, M, N, K, tiles_m, tiles_n, K, N);
         break;
     case EPI_GELU:
-        hipLaunchKernelGGL(gemm_bf16_kernel<EPI_GELU>, grid, blk, kLdsBytes, st, x, w, b, residual, Y, M, N, K, tiles_m, tiles_n);
+        hipLaunchKernelGGL(gemm_bf16_kernel<EPI_GELU>, grid, blk, kLdsBytes, st, x, w, b, residual, Y, M, N, K, tiles_m, tiles_n, K, N);
         break;
     default:
-        hipLaunchKernelGGL(gemm_bf16_kernel<EPI_RESIDUAL>, grid, blk, kLdsBytes, st, x, w, b, residual, Y, M, N, K, tiles_m, tiles_n);
+        hipLaunchKernelGGL(gemm_bf16_kernel<EPI_RESIDUAL>, grid, blk, kLdsBytes, st, x, w, b, residual, Y, M, N, K, tiles_m, tiles_n, K, N);
         break;
     }
     COSA_LAUNCH_CHECK();
     return COSA_OK;
 }
+
+#if !COSA_OP_F16
+// Y = X W^T (+ bias, carried by the augmentation block) with bf16x3 operands -- see split_tile_x / split_tile_w.
+//   Xs [M, 2K + 64] = [x_hi | x_lo | 1 1 0 ...],  Ws [N, 2K + 64] = [w_hi | w_lo | b_hi b_lo 0 ...]  (bf16),  zeros: N bf16 zeros
+//   epilogue 0 / 1: Y bf16 [M, ldy], columns [0, N) = hi, [N, 2N) = lo of the (GELU'd) result;  epilogue 2: Y fp32 [M, N] = residual + .
+extern "C" int cosa_gemm_bf16x3(const void *Xs, const void *Ws, const void *zeros, const float *residual, void *Y,
+                                int M, int N, int K, int epilogue, int ldy, void *stream)
+{
+    struct ClearSlot { ~ClearSlot() { g_gemm_stamp_slot = nullptr; } } clear_slot_;
+    COSA_REQUIRE(Xs && Ws && zeros && Y, "cosa_gemm_bf16x3: null pointer");
+    COSA_REQUIRE(M > 0 && N > 0 && K > 0 && N % BN == 0 && K % BK == 0, "cosa_gemm_bf16x3: N %% 128 and K %% 64 must be 0 (got N=%d K=%d)", N, K);
+    COSA_REQUIRE(epilogue >= 0 && epilogue <= 2, "cosa_gemm_bf16x3: unknown epilogue");
+    COSA_REQUIRE(epilogue != EPI_RESIDUAL || residual, "cosa_gemm_bf16x3: residual epilogue needs the residual pointer");
+    COSA_REQUIRE(epilogue == EPI_RESIDUAL ? ldy == N : (ldy >= 2 * N && ldy % 8 == 0), "cosa_gemm_bf16x3: ldy must be N (fp32 out) or >= 2N (split out)");
+    const int ld = 2 * K + 64;
+    hipStream_t st = as_stream(stream);
+    const op16 *x = static_cast<const op16 *>(Xs), *w = static_cast<const op16 *>(Ws), *b = static_cast<const op16 *>(zeros);
+    if (N % 256 == 0 && M >= 4096 && (size_t)(M + 256) * ld * 2 < 0x7fffffffull * 8 && (size_t)N * ld * 2 < 0x7fffffffull) {
+        if (epilogue == EPI_BIAS) return launch_v6<EPI_BIAS, 0, 0, 1>(x, w, b, residual, Y, M, N, K, st, ld, ldy);
+        if (epilogue == EPI_GELU) return launch_v6<EPI_GELU, 0, 0, 1>(x, w, b, residual, Y, M, N, K, st, ld, ldy);
+        return launch_v6<EPI_RESIDUAL, 0, 0, 1>(x, w, b, residual, Y, M, N, K, st, ld, ldy);
+    }
+    constexpr int kLdsSplit = 2 * BM * CT_LD > (int)kLdsBytes ? 2 * BM * CT_LD : (int)kLdsBytes;
+    static bool attr_done = false;
+    if (!attr_done) {
+        COSA_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_bf16_kernel<EPI_BIAS, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsSplit));
+        COSA_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_bf16_kernel<EPI_GELU, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsSplit));
+        COSA_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_bf16_kernel<EPI_RESIDUAL, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsSplit));
+        attr_done = true;
+    }
+    const int tiles_m = (M + BM - 1) / BM, tiles_n = N / BN;
+    const dim3 grid(tiles_m * tiles_n), blk(256);
+    switch (epilogue) {
+    case EPI_BIAS:
+        hipLaunchKernelGGL((gemm_bf16_kernel<EPI_BIAS, 1>), grid, blk, kLdsSplit, st, x, w, b, residual, Y, M, N, K, tiles_m, tiles_n, ld, ldy);
+        break;
+    case EPI_GELU:
+        hipLaunchKernelGGL((gemm_bf16_kernel<EPI_GELU, 1>), grid, blk, kLdsSplit, st, x, w, b, residual, Y, M, N, K, tiles_m, tiles_n, ld, ldy);
+        break;
+    default:
+        hipLaunchKernelGGL((gemm_bf16_kernel<EPI_RESIDUAL, 1>), grid, blk, kLdsSplit, st, x, w, b, residual, Y, M, N, K, tiles_m, tiles_n, ld, ldy);
+        break;
+    }
+    COSA_LAUNCH_CHECK();
+    return COSA_OK;
+}
+#endif
 
 extern "C" int cosa_layernorm(const float *x, const void *gamma, const void *beta, void *y_bf16, float *y_f32,
                               int rows, int dim, float eps, void *stream)
@@ -1743,7 +1834,7 @@ extern "C" int cosa_layernorm(const float *x, const void *gamma, const void *bet
     COSA_REQUIRE(x && gamma && beta && (y_bf16 || y_f32) && rows > 0, "cosa_layernorm: bad arguments");
     COSA_REQUIRE(dim == 768, "cosa_layernorm: dim must be 768 (ViT-B)");
     hipLaunchKernelGGL(layernorm_kernel<768>, dim3((rows + 3) / 4), dim3(256), 0, as_stream(stream), x,
-                       static_cast<const bf16 *>(gamma), static_cast<const bf16 *>(beta), static_cast<bf16 *>(y_bf16), y_f32, rows, eps);
+                       static_cast<const op16 *>(gamma), static_cast<const op16 *>(beta), static_cast<op16 *>(y_bf16), y_f32, rows, eps);
     COSA_LAUNCH_CHECK();
     return COSA_OK;
 }
@@ -1779,8 +1870,8 @@ extern "C" int cosa_gemm_wgrad_bf16(const void *dY, const void *X, float *dW, fl
     splits = (nstages + per - 1) / per;
     static const bool oldmap = getenv("COSA_WGRAD_OLDMAP") != nullptr;
     const int tiles_per_xcd = oldmap ? -((tiles + 7) / 8) : (tiles + 7) / 8;
-    hipLaunchKernelGGL(gemm_wgrad_kernel<false>, dim3(8 * ((tiles + 7) / 8) * splits), dim3(256), 65536, st, static_cast<const bf16 *>(dY),
-                       static_cast<const bf16 *>(X), dW, db, M, N, K, K / 128, per, nstages, tiles, tiles_per_xcd, ConvGeom{}, 0);
+    hipLaunchKernelGGL(gemm_wgrad_kernel<false>, dim3(8 * ((tiles + 7) / 8) * splits), dim3(256), 65536, st, static_cast<const op16 *>(dY),
+                       static_cast<const op16 *>(X), dW, db, M, N, K, K / 128, per, nstages, tiles, tiles_per_xcd, ConvGeom{}, 0);
     COSA_LAUNCH_CHECK();
     return COSA_OK;
 }
@@ -1812,8 +1903,8 @@ extern "C" int cosa_conv3x3_dilated_wgrad(const void *dY, const void *X, float *
     const int per = (nstages + splits - 1) / splits;
     splits = (nstages + per - 1) / per;
     ConvGeom cg{h, w, dilation, Cin, img_rows, row_off, ldx, 64 / w, 64 % w};
-    hipLaunchKernelGGL(gemm_wgrad_kernel<true>, dim3(8 * ((tiles + 7) / 8) * splits), dim3(256), 65536, st, static_cast<const bf16 *>(dY),
-                       static_cast<const bf16 *>(X), dW9, static_cast<float *>(nullptr), M, N, K, K / 128, per, nstages, tiles,
+    hipLaunchKernelGGL(gemm_wgrad_kernel<true>, dim3(8 * ((tiles + 7) / 8) * splits), dim3(256), 65536, st, static_cast<const op16 *>(dY),
+                       static_cast<const op16 *>(X), dW9, static_cast<float *>(nullptr), M, N, K, K / 128, per, nstages, tiles,
                        (tiles + 7) / 8, cg, (int)x_bytes);
     COSA_LAUNCH_CHECK();
     return COSA_OK;
@@ -1834,8 +1925,8 @@ extern "C" int cosa_conv3x3_dilated_nhwc(const void *X, const void *Wt, void *Y,
     }
     const int M = B * h * w;
     const int tiles_m = (M + 127) / 128, tiles_n = Cout / 128;
-    hipLaunchKernelGGL(conv3x3_dil_kernel, dim3(tiles_m * tiles_n), dim3(256), kLdsBytes, as_stream(stream), static_cast<const bf16 *>(X),
-                       static_cast<const bf16 *>(Wt), static_cast<bf16 *>(Y), B, h, w, Cin, Cout, dilation, img_rows, row_off, ldx, relu,
+    hipLaunchKernelGGL(conv3x3_dil_kernel, dim3(tiles_m * tiles_n), dim3(256), kLdsBytes, as_stream(stream), static_cast<const op16 *>(X),
+                       static_cast<const op16 *>(Wt), static_cast<op16 *>(Y), B, h, w, Cin, Cout, dilation, img_rows, row_off, ldx, relu,
                        x_bytes, tiles_n);
     COSA_LAUNCH_CHECK();
     return COSA_OK;

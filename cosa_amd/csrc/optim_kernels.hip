@@ -19,9 +19,25 @@ struct TensorRec {          // one record per parameter tensor (device table)
     bf16 *p16, *t16;        // bf16 shadows or NULL
     float lr, wd;           // per-group hyper-parameters (already scheduled)
     long long n;
+    int t16_f16, p16_f16;   // the shadow's 16-bit type: 0 bf16, 1 IEEE fp16 (fp16-operand teacher passes)
 };
 
 struct ChunkRec { int tensor; int chunk; };
+
+__device__ __forceinline__ uint2 pack16x4(const float (&v)[4], int f16)
+{
+    if (f16) {
+        _Float16 o[4] = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+        return *reinterpret_cast<uint2 *>(o);
+    }
+    bf16 o[4] = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+    return *reinterpret_cast<uint2 *>(o);
+}
+__device__ __forceinline__ void store16(bf16 *dst, float v, int f16)
+{
+    if (f16) *reinterpret_cast<_Float16 *>(dst) = (_Float16)v;
+    else *dst = (bf16)v;
+}
 constexpr int kChunk = 65536;            // elements per block
 
 __global__ __launch_bounds__(256) void adamw_ema_kernel(const TensorRec *__restrict__ recs, const ChunkRec *__restrict__ chunks,
@@ -59,14 +75,8 @@ __global__ __launch_bounds__(256) void adamw_ema_kernel(const TensorRec *__restr
 #pragma unroll
             for (int e = 0; e < 4; e++) tv[e] = ema * tv[e] + (1.0f - ema) * pv[e];
             *reinterpret_cast<float4 *>(t.tp + i) = make_float4(tv[0], tv[1], tv[2], tv[3]);
-            if (t.p16 && t.g) {
-                bf16 o[4] = {(bf16)pv[0], (bf16)pv[1], (bf16)pv[2], (bf16)pv[3]};
-                *reinterpret_cast<uint2 *>(t.p16 + i) = *reinterpret_cast<uint2 *>(o);
-            }
-            if (t.t16) {
-                bf16 o[4] = {(bf16)tv[0], (bf16)tv[1], (bf16)tv[2], (bf16)tv[3]};
-                *reinterpret_cast<uint2 *>(t.t16 + i) = *reinterpret_cast<uint2 *>(o);
-            }
+            if (t.p16 && t.g) *reinterpret_cast<uint2 *>(t.p16 + i) = pack16x4(pv, t.p16_f16);
+            if (t.t16) *reinterpret_cast<uint2 *>(t.t16 + i) = pack16x4(tv, t.t16_f16);
         }
     } else {
         for (long long i = base + threadIdx.x; i < end; i += 256) {
@@ -78,11 +88,11 @@ __global__ __launch_bounds__(256) void adamw_ema_kernel(const TensorRec *__restr
                 const float v = beta2 * t.v[i] + (1.0f - beta2) * g * g;
                 p -= step_size * (m / (sqrtf(v) / bc2_sqrt + eps));
                 t.m[i] = m; t.v[i] = v; t.p[i] = p;
-                if (t.p16) t.p16[i] = (bf16)p;
+                if (t.p16) store16(t.p16 + i, p, t.p16_f16);
             }
             tp = ema * tp + (1.0f - ema) * p;
             t.tp[i] = tp;
-            if (t.t16) t.t16[i] = (bf16)tp;
+            if (t.t16) store16(t.t16 + i, tp, t.t16_f16);
         }
     }
 }
@@ -95,7 +105,7 @@ using namespace cosa;
 extern "C" size_t cosa_optim_record_bytes(void) { return sizeof(TensorRec); }
 extern "C" int cosa_optim_chunk_elems(void) { return kChunk; }
 
-/* records: device array of n_tensors TensorRec (layout: 7 pointers, float lr, float wd, int64 n); chunks: device array of
+/* records: device array of n_tensors TensorRec (layout: 7 pointers, float lr, float wd, int64 n, int32 t16_f16, int32 p16_f16); chunks: device array of
  * n_chunks {int tensor, int chunk}.  step >= 1 is the AdamW step count used for bias correction.                       */
 extern "C" int cosa_fused_adamw_ema(const void *records, const void *chunks, int n_chunks, float beta1, float beta2, float eps,
                                     int step, float ema_momentum, void *stream)

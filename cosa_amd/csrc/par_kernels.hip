@@ -453,6 +453,114 @@ __global__ __launch_bounds__(256) void par_step4_kernel(const float *__restrict_
     else par_step4_body<8>(aff, src, dst, b, K, j0, nlive, half_planes, img_stride, h, w, plan);
 }
 
+
+// v4 propagation step: LDS-tiled.  A 512-thread workgroup owns a TH x TW = 16 x 32 pixel tile of ONE image and walks ALL its live planes:
+//   * the 48 affinities of a pixel are loaded ONCE per step into registers and reused for every plane;
+//   * per plane, the tile plus a HALO-pixel ring (replicate-clamped at the image border, exactly the reference's F.pad) is staged in LDS
+//     -- 2240 floats for 512 pixels -- and the taps of every dilation d <= HALO (40 of the 48 for the named configuration
+//     1, 2, 4, 8, 12, 24) are LDS reads at compile-time offsets; only the d > HALO taps (8) remain global gathers, issued first;
+//   * two LDS buffers: the next plane's tile is fetched while this one is consumed, one barrier per plane.
+// Against one-pixel-per-thread gathers (par_step1_kernel: 48 L1 requests per pixel and plane) a plane costs 4.4 staged + 8 gathered
+// elements per pixel.  Accumulation order is the spec's (acc = acc + m * a, neighbour index ascending): bit-identical to the oracle.
+// DIL: compile-time dilation list (the only configuration the reference names, models/PAR.py:94); other lists take par_step1_kernel.
+constexpr int kTH = 16, kTW = 32, kHalo = 12;
+constexpr int kLW = kTW + 2 * kHalo, kLH = kTH + 2 * kHalo;           // 56 x 40
+struct Dil6 { static constexpr int n = 6; static constexpr int d[6] = {1, 2, 4, 8, 12, 24}; };
+
+template <typename DIL>
+__global__ __launch_bounds__(512) void par_step_tiled_kernel(const float *__restrict__ aff, const float *__restrict__ src,
+                                                            float *__restrict__ dst, const int *__restrict__ kcount, int Kfull,
+                                                            int halves, int half_planes, size_t img_stride, int h, int w,
+                                                            int B, int tiles_x, int tiles_y, int pin)
+{
+    __shared__ float tile[2][kLH * kLW];
+    constexpr int ND = DIL::n, NN = ND * 8;
+    const int id = blockIdx.x, per_img = tiles_x * tiles_y;
+    int b, rem;
+    if (pin) {                                         // images pinned to XCDs (workgroup ids are dealt round-robin to the 8 L2s)
+        const int xcd = id & 7, j = id >> 3, slot = j / per_img;
+        rem = j - slot * per_img;
+        b = slot * 8 + xcd;
+    } else {
+        b = id / per_img;
+        rem = id - b * per_img;
+    }
+    if (b >= B) return;
+    const int tyi = rem / tiles_x, txi = rem - tyi * tiles_x;
+    const int y0 = tyi * kTH, x0 = txi * kTW;
+    const int tid = threadIdx.x, ty = tid >> 5, tx = tid & 31;
+    const int y = y0 + ty, x = x0 + tx;
+    const bool valid = y < h && x < w;
+    const int hw = h * w;
+    const int K = kcount ? kcount[b] : Kfull;
+    const int live = K * halves;
+    if (live <= 0) return;
+    const int pix = valid ? y * w + x : 0;
+
+    float a[NN];
+    {
+        const float *ab = aff + (size_t)b * NN * hw + pix;
+#pragma unroll
+        for (int n = 0; n < NN; n++) a[n] = ab[(size_t)n * hw];
+    }
+    // global offsets of the far taps (d > kHalo), clamped; shared by all planes
+    int ofar[8];
+    {
+        constexpr int df = DIL::d[ND - 1];
+        const int yc = valid ? y : 0, xc = valid ? x : 0;
+        const int rm = clampi(yc - df, 0, h - 1) * w, r0 = yc * w, rp = clampi(yc + df, 0, h - 1) * w;
+        const int xm = clampi(xc - df, 0, w - 1), xp = clampi(xc + df, 0, w - 1);
+        ofar[0] = rm + xm; ofar[1] = rm + xc; ofar[2] = rm + xp; ofar[3] = r0 + xm; ofar[4] = r0 + xp;
+        ofar[5] = rp + xm; ofar[6] = rp + xc; ofar[7] = rp + xp;
+    }
+    static_assert(DIL::d[ND - 1] > kHalo && DIL::d[ND - 2] <= kHalo, "exactly the last dilation is gathered, the others are staged");
+    // staging map of this thread: elements e = tid, tid + 512, ... of the (kLH x kLW) halo tile -> clamped image offsets
+    constexpr int NE = (kLH * kLW + 511) / 512;        // 5
+    int goff[NE];
+#pragma unroll
+    for (int i = 0; i < NE; i++) {
+        const int e = tid + 512 * i;
+        const int r = e / kLW, c = e - r * kLW;
+        goff[i] = e < kLH * kLW ? clampi(y0 - kHalo + r, 0, h - 1) * w + clampi(x0 - kHalo + c, 0, w - 1) : -1;
+    }
+    auto plane_off = [&](int j) {
+        const int half = j / K;
+        return (size_t)b * img_stride + (size_t)(half * half_planes + (j - half * K)) * hw;
+    };
+    auto stage = [&](int buf, const float *pl) {
+#pragma unroll
+        for (int i = 0; i < NE; i++)
+            if (goff[i] >= 0) tile[buf][tid + 512 * i] = pl[goff[i]];
+    };
+    stage(0, src + plane_off(0));
+    __syncthreads();
+    const float *ctr = &tile[0][(ty + kHalo) * kLW + tx + kHalo];
+    for (int j = 0; j < live; j++) {
+        const float *pl = src + plane_off(j);
+        float far[8];
+#pragma unroll
+        for (int t = 0; t < 8; t++) far[t] = pl[ofar[t]];                       // the gathers go first: their latency hides under the LDS taps
+        if (j + 1 < live) stage((j + 1) & 1, src + plane_off(j + 1));
+        const float *c = ctr + (j & 1) * (kLH * kLW);
+        float acc = 0.0f;
+#pragma unroll
+        for (int di = 0; di < ND - 1; di++) {
+            constexpr int dummy = 0; (void)dummy;
+            const int d = DIL::d[di];
+#pragma unroll
+            for (int t = 0; t < 8; t++) {
+                const int tt = t < 4 ? t : t + 1;
+                const int dy = tt / 3 - 1, dx = tt % 3 - 1;
+                acc = acc + c[dy * d * kLW + dx * d] * a[di * 8 + t];
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 8; t++) acc = acc + far[t] * a[(ND - 1) * 8 + t];
+        if (valid) dst[plane_off(j) + pix] = acc;
+        __syncthreads();                                                       // next tile staged, this one no longer read
+    }
+}
+
 }  // namespace
 
 int par_make_plan(const int *dilations, int n_dil, ParPlan *plan)
@@ -520,6 +628,19 @@ int par_launch_step(const float *aff, const float *src, float *dst, int B, int K
     // default: the one-pixel, all-planes kernel (1.50 ms per shared pass against 2.19 with the 4-pixel, 4-plane kernel below, which
     // COSA_PAR_SCALAR=0 brings back for A/B runs)
     static const int scalar = [] { const char *e = getenv("COSA_PAR_SCALAR"); return e ? atoi(e) : 1; }();
+    static const int tiled = [] { const char *e = getenv("COSA_PAR_TILED"); return e ? atoi(e) : 1; }();
+    bool named = plan.n_dil == Dil6::n;
+    for (int i = 0; named && i < Dil6::n; i++) named = plan.dil[i] == Dil6::d[i];
+    if (tiled && named && (size_t)Kmax * h * w < (1ull << 31)) {              // LDS-tiled step for the named configuration
+        const int tiles_x = (w + kTW - 1) / kTW, tiles_y = (h + kTH - 1) / kTH;
+        const int pin = (B % 8 == 0 || B >= 24) ? 1 : 0;
+        const long long nblk = (pin ? 8ll * ((B + 7) / 8) : (long long)B) * tiles_x * tiles_y;
+        COSA_REQUIRE(nblk < 0x7fffffffll, "PAR: grid too large");
+        hipLaunchKernelGGL(par_step_tiled_kernel<Dil6>, dim3((unsigned)nblk), dim3(512), 0, st, aff, src, dst, kcount, Kmax, halves,
+                           half_planes, plane_stride, h, w, B, tiles_x, tiles_y, pin);
+        COSA_LAUNCH_CHECK();
+        return COSA_OK;
+    }
     if (scalar && (size_t)Kmax * h * w < (1ull << 31)) {
         const int pix_blocks = (h * w + 255) / 256, groups = (Kmax + 15) / 16;
         const int pin = (B % 8 == 0 || B >= 24) ? 1 : 0;                  // balanced (or nearly) image count per XCD

@@ -1,0 +1,131 @@
+// split_kernels.hip -- producers of bf16x3 ("split") operands for the parity-grade no-grad passes (gfx950, HBM-bound).
+//
+// A value v is carried as hi = bf16(v) and lo = bf16(v - hi): 16 significant bits.  A split operand row of logical width K is
+//     [ hi (K) | lo (K) | aug (64) ]           row stride 2K + 64 bf16
+// (layout and the three-term product: gemm_kernels.hip, split_tile_x / split_tile_w).  The augmentation block of an ACTIVATION row is
+// (1, 1, 0, ...), that of a WEIGHT row n is (bias_hi[n], bias_lo[n], 0, ...): the GEMM adds the bias at 16-bit precision as one more K
+// tile, so nn.Linear's bias (models/vit/vit.py:96-102,121,135) needs no epilogue work.
+//
+//   cosa_split_rows        fp32 [R, K] (+ optional fp32 bias [R]) -> split rows (weights: called once per step for the EMA-updated
+//                          teacher; activations: the im2col'd image of the patch projection)
+//   cosa_layernorm_split   nn.LayerNorm(768, eps) over the fp32 residual stream with fp32 gamma / beta -> split rows (and/or fp32)
+#include "kernels.hpp"
+
+namespace cosa {
+namespace {
+
+typedef __bf16 bf16;
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split4(const float (&v)[4], bf16x4 &hi, bf16x4 &lo)
+{
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        hi[j] = (bf16)v[j];
+        lo[j] = (bf16)(v[j] - (float)hi[j]);
+    }
+}
+
+// one wave per row; K % 4 == 0
+__global__ __launch_bounds__(256) void split_rows_kernel(const float *__restrict__ src, const float *__restrict__ bias, bf16 *__restrict__ dst,
+                                                        int R, int K, long long src_ld, int ones)
+{
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= R) return;
+    const int lane = threadIdx.x & 63;
+    const float *s = src + (size_t)row * src_ld;
+    bf16 *d = dst + (size_t)row * (2 * K + 64);
+    for (int c = lane * 4; c < K; c += 256) {
+        const float4 f = *reinterpret_cast<const float4 *>(s + c);
+        const float v[4] = {f.x, f.y, f.z, f.w};
+        bf16x4 hi, lo;
+        split4(v, hi, lo);
+        *reinterpret_cast<bf16x4 *>(d + c) = hi;
+        *reinterpret_cast<bf16x4 *>(d + K + c) = lo;
+    }
+    if (lane < 8) {                                   // augmentation block: 8 lanes x 8 bf16
+        bf16x8 a;
+#pragma unroll
+        for (int j = 0; j < 8; j++) a[j] = (bf16)0.f;
+        if (lane == 0) {
+            if (ones) { a[0] = (bf16)1.f; a[1] = (bf16)1.f; }
+            else if (bias) { const float b = bias[row]; a[0] = (bf16)b; a[1] = (bf16)(b - (float)a[0]); }
+        }
+        *reinterpret_cast<bf16x8 *>(d + 2 * K + lane * 8) = a;
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void layernorm_split_kernel(const float *__restrict__ x, const float *__restrict__ g, const float *__restrict__ b,
+                                                             bf16 *__restrict__ y, float *__restrict__ y32, int rows, float eps)
+{
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    constexpr int PER = D / 64 / 4;
+    const float4 *xr = reinterpret_cast<const float4 *>(x + (size_t)row * D);
+    float4 v[PER];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < PER; i++) { v[i] = xr[lane + 64 * i]; s += v[i].x + v[i].y + v[i].z + v[i].w; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float mean = s * (1.0f / D);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+        const float a = v[i].x - mean, c = v[i].y - mean, d = v[i].z - mean, e = v[i].w - mean;
+        q += a * a + c * c + d * d + e * e;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+    const float rstd = rsqrtf(q * (1.0f / D) + eps);
+    bf16 *yr = y ? y + (size_t)row * (2 * D + 64) : nullptr;
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+        const int c0 = (lane + 64 * i) * 4;
+        const float4 gg = *reinterpret_cast<const float4 *>(g + c0), bb = *reinterpret_cast<const float4 *>(b + c0);
+        const float o[4] = {(v[i].x - mean) * rstd * gg.x + bb.x, (v[i].y - mean) * rstd * gg.y + bb.y,
+                            (v[i].z - mean) * rstd * gg.z + bb.z, (v[i].w - mean) * rstd * gg.w + bb.w};
+        if (yr) {
+            bf16x4 hi, lo;
+            split4(o, hi, lo);
+            *reinterpret_cast<bf16x4 *>(yr + c0) = hi;
+            *reinterpret_cast<bf16x4 *>(yr + D + c0) = lo;
+        }
+        if (y32) *reinterpret_cast<float4 *>(y32 + (size_t)row * D + c0) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+    if (yr && lane < 8) {
+        bf16x8 a;
+#pragma unroll
+        for (int j = 0; j < 8; j++) a[j] = (bf16)0.f;
+        if (lane == 0) { a[0] = (bf16)1.f; a[1] = (bf16)1.f; }
+        *reinterpret_cast<bf16x8 *>(yr + 2 * D + lane * 8) = a;
+    }
+}
+
+}  // namespace
+}  // namespace cosa
+
+using namespace cosa;
+
+extern "C" int cosa_split_rows(const float *src, const float *bias, void *dst, int R, int K, long long src_ld, int ones, void *stream)
+{
+    COSA_REQUIRE(src && dst && R > 0 && K > 0 && K % 4 == 0 && src_ld >= K && src_ld % 4 == 0, "cosa_split_rows: bad arguments (K %% 4 == 0)");
+    hipLaunchKernelGGL(split_rows_kernel, dim3((R + 3) / 4), dim3(256), 0, as_stream(stream), src, bias, static_cast<bf16 *>(dst), R, K,
+                       src_ld, ones);
+    COSA_LAUNCH_CHECK();
+    return COSA_OK;
+}
+
+extern "C" int cosa_layernorm_split(const float *x, const float *gamma, const float *beta, void *y_split, float *y_f32, int rows, int dim,
+                                    float eps, void *stream)
+{
+    COSA_REQUIRE(x && gamma && beta && (y_split || y_f32) && rows > 0, "cosa_layernorm_split: bad arguments");
+    COSA_REQUIRE(dim == 768, "cosa_layernorm_split: dim must be 768 (ViT-B)");
+    hipLaunchKernelGGL(layernorm_split_kernel<768>, dim3((rows + 3) / 4), dim3(256), 0, as_stream(stream), x, gamma, beta,
+                       static_cast<bf16 *>(y_split), y_f32, rows, eps);
+    COSA_LAUNCH_CHECK();
+    return COSA_OK;
+}

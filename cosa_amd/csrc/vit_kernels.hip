@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256) void head_gemm_kernel(const T *__restrict__ X,
                 const float4 v = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(xr) + k);
                 x0 = v.x; x1 = v.y; x2 = v.z; x3 = v.w;
             } else {
-                const bf16 *pb = reinterpret_cast<const bf16 *>(xr) + k;
+                const T *pb = xr + k;                                   // bf16 or fp16
                 x0 = (float)pb[0]; x1 = (float)pb[1]; x2 = (float)pb[2]; x3 = (float)pb[3];
             }
 #pragma unroll
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256) void head_gemm_kernel(const T *__restrict__ X,
             float v = 0.f;
 #pragma unroll
             for (int n = 0; n < 32; n++) v = lane == n ? acc[n] : v;
-            if (round_bf16) v = (float)(bf16)v;
+            if (round_bf16) v = sizeof(T) == 4 ? (float)(bf16)v : (float)(T)v;      // the operand precision (fp32 operands: bf16)
             Y[(size_t)r * ldy + col0 + lane] = v;
         }
     }
@@ -255,16 +255,18 @@ extern "C" int cosa_head_gemm(const void *X, const void *W, float *Y, int M, int
     COSA_REQUIRE(ldy >= col0 + N && col0 >= 0, "cosa_head_gemm: output columns [col0, col0+N) must fit the row stride ldy");
     COSA_REQUIRE(X && W && Y && M > 0 && N > 0 && K > 0 && rows_per_img > 0, "cosa_head_gemm: bad arguments");
     COSA_REQUIRE(N <= 32 && K % 256 == 0 && ldx >= K, "cosa_head_gemm: N <= 32 and K %% 256 == 0 (got N=%d K=%d)", N, K);
-    COSA_REQUIRE(dtype == 0 || dtype == 1, "cosa_head_gemm: dtype 0 (fp32) or 1 (bf16)");
+    COSA_REQUIRE(dtype >= 0 && dtype <= 2, "cosa_head_gemm: dtype 0 (fp32), 1 (bf16) or 2 (fp16)");
     const size_t lds = (size_t)N * K * sizeof(float);
     COSA_REQUIRE(lds <= 128 * 1024, "cosa_head_gemm: weight does not fit the LDS");
     hipStream_t st = as_stream(stream);
-    static size_t attr[2] = {0, 0};
+    static size_t attr[3] = {0, 0, 0};
     if (lds > attr[dtype]) {
         if (dtype == 0)
             COSA_HIP_CHECK(hipFuncSetAttribute((const void *)head_gemm_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        else
+        else if (dtype == 1)
             COSA_HIP_CHECK(hipFuncSetAttribute((const void *)head_gemm_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        else
+            COSA_HIP_CHECK(hipFuncSetAttribute((const void *)head_gemm_kernel<_Float16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr[dtype] = lds;
     }
     int blocks = (M + 3) / 4;
@@ -272,9 +274,12 @@ extern "C" int cosa_head_gemm(const void *X, const void *W, float *Y, int M, int
     if (dtype == 0)
         hipLaunchKernelGGL(head_gemm_kernel<float>, dim3(blocks), dim3(256), lds, st, static_cast<const float *>(X),
                            static_cast<const float *>(W), Y, M, N, K, rows_per_img, img_stride, ldx, round_bf16, ldy, col0);
-    else
+    else if (dtype == 1)
         hipLaunchKernelGGL(head_gemm_kernel<bf16>, dim3(blocks), dim3(256), lds, st, static_cast<const bf16 *>(X),
                            static_cast<const bf16 *>(W), Y, M, N, K, rows_per_img, img_stride, ldx, round_bf16, ldy, col0);
+    else
+        hipLaunchKernelGGL(head_gemm_kernel<_Float16>, dim3(blocks), dim3(256), lds, st, static_cast<const _Float16 *>(X),
+                           static_cast<const _Float16 *>(W), Y, M, N, K, rows_per_img, img_stride, ldx, round_bf16, ldy, col0);
     COSA_LAUNCH_CHECK();
     return COSA_OK;
 }

@@ -27,12 +27,12 @@ class LargeFOV(nn.Module):
     batch_invariant = False        # set by VITNetwork together with its own flag
 
     def forward_tokens(self, tok, B, h, w):
-        """no-grad bf16 path: both dilated convs as implicit-GEMM MFMA kernels on the NHWC tokens, conv8 as a bare GEMM.
+        """no-grad 16-bit path (bf16 or fp16 tokens): both dilated convs as implicit-GEMM MFMA kernels on the NHWC tokens, conv8 as a bare GEMM.
         tok [B, h*w, 768] bf16 (may be the strided `tokens[:, 1:]` view) -> seg [B, classes, h, w] fp32"""
-        c = nn_ops.cast_param
-        y = nn_ops.conv3x3_dilated_tokens(tok, c(self.conv6.weight, torch.bfloat16), B, h, w, self.dilation, relu=True)
-        y = nn_ops.conv3x3_dilated_tokens(y.view(B, h * w, -1), c(self.conv7.weight, torch.bfloat16), B, h, w, self.dilation, relu=True)
-        w8 = c(self.conv8.weight, torch.bfloat16).reshape(self.conv8.weight.shape[0], -1)
+        c, dt = nn_ops.cast_param, tok.dtype
+        y = nn_ops.conv3x3_dilated_tokens(tok, c(self.conv6.weight, dt), B, h, w, self.dilation, relu=True)
+        y = nn_ops.conv3x3_dilated_tokens(y.view(B, h * w, -1), c(self.conv7.weight, dt), B, h, w, self.dilation, relu=True)
+        w8 = c(self.conv8.weight, dt).reshape(self.conv8.weight.shape[0], -1)
         seg = nn_ops.head_linear(y.view(B, h * w, -1), w8, round_bf16=True) if self.batch_invariant else None
         if seg is None:
             seg = F.linear(y, w8).float()
@@ -87,6 +87,14 @@ class VITNetwork(nn.Module):
         self.encoder.compute_dtype = dt
         return self
 
+    def set_nograd_precision(self, mode):
+        """operand precision of the no-grad passes (teacher pseudo-labels, evaluation): "bf16" (8 significant bits), "fp16" (11; the
+        same kernels built for fp16 operands) or "bf16x3" (16; hi + lo bf16 halves, three MFMA terms): DESIGN.md section 3"""
+        assert mode in ("bf16", "fp16", "bf16x3")
+        self.set_compute_dtype(torch.float16 if mode == "fp16" else torch.bfloat16)
+        self.encoder.precision = "bf16x3" if mode == "bf16x3" else None
+        return self
+
     def get_param_groups(self):
         """models/__init__.py:126-144: backbone; backbone norms; cls heads; decoder"""
         groups = [[], [], [], []]
@@ -109,8 +117,8 @@ class VITNetwork(nn.Module):
         if detach_feat:
             tok = tok.detach()
         cam = None
-        if self.batch_invariant_heads and not torch.is_grad_enabled() and tok.is_cuda:
-            cam = nn_ops.head_linear(tok, wgt.contiguous(), round_bf16=tok.dtype == torch.bfloat16)
+        if (self.batch_invariant_heads or self.encoder.precision == "bf16x3") and not torch.is_grad_enabled() and tok.is_cuda:
+            cam = nn_ops.head_linear(tok, wgt.contiguous(), round_bf16=tok.dtype != torch.float32)       # own kernel, fixed reduction order
         if cam is None:
             cam = F.linear(tok, wgt).float()
         return cam.reshape(B, h, w, -1).permute(0, 3, 1, 2).contiguous()
@@ -118,7 +126,7 @@ class VITNetwork(nn.Module):
     def _cls_head(self, pooled, wgt):
         """classification logits from the pooled tokens (optionally on the batch-invariant narrow-head kernel, like the CAM heads)"""
         if self.batch_invariant_heads and not torch.is_grad_enabled() and pooled.is_cuda:
-            y = nn_ops.head_linear(pooled.unsqueeze(1).contiguous(), wgt.contiguous(), round_bf16=pooled.dtype == torch.bfloat16)
+            y = nn_ops.head_linear(pooled.unsqueeze(1).contiguous(), wgt.contiguous(), round_bf16=pooled.dtype != torch.float32)
             if y is not None:
                 return y
         return F.linear(pooled, wgt).float()
@@ -155,7 +163,7 @@ class VITNetwork(nn.Module):
         p = self.encoder.patch_size
         h, w = x.shape[-2] // p, x.shape[-1] // p
         x4 = tok.reshape(B, h, w, -1).permute(0, 3, 1, 2)            # NCHW view, channels-last strides (no copy)
-        if tok32 is not None and tok.dtype == torch.bfloat16 and self.decoder.conv6.weight.shape[1] % 64 == 0:
+        if tok32 is not None and tok.dtype in vitencoder._OP16 and self.decoder.conv6.weight.shape[1] % 64 == 0:
             seg = self.decoder.forward_tokens(tok, B, h, w)            # fused no-grad path: own implicit-GEMM convs
         elif tok.dtype == torch.bfloat16 and tok.is_cuda and self.decoder.conv6.weight.shape[1] % 128 == 0 \
                 and torch.is_grad_enabled() and nn_ops.own_decoder_backward():

@@ -20,6 +20,9 @@ import torch.nn.functional as F
 from .. import nn_ops
 
 
+_OP16 = (torch.bfloat16, torch.float16)       # MFMA operand types of the HIP path (fp16: no-grad passes only)
+
+
 class Mlp(nn.Module):
     def __init__(self, in_features, hidden_features):
         super().__init__()
@@ -79,6 +82,7 @@ class VisionTransformer(nn.Module):
         self.norm = nn.LayerNorm(embed_dim, eps=eps)
         self.head = nn.Linear(embed_dim, num_classes) if num_classes > 0 else nn.Identity()   # unused by the path (vit.py:257,325)
         self.compute_dtype = compute_dtype
+        self.precision = None          # "bf16x3": the no-grad passes carry every MFMA operand as hi + lo bf16 halves (parity grade)
         self._pos_cache = {}
         _trunc_normal_(self.pos_embed)
         _trunc_normal_(self.cls_token)
@@ -123,7 +127,7 @@ class VisionTransformer(nn.Module):
         cols = x.to(dt).reshape(B, nc, h, p, w, p).permute(0, 2, 4, 1, 3, 5).reshape(B, h * w, nc * p * p)
         wgt = nn_ops.cast_param(self.patch_embed.proj.weight, dt).reshape(self.embed_dim, -1)
         bias = nn_ops.cast_param(self.patch_embed.proj.bias, dt)
-        if dt == torch.bfloat16 and x.is_cuda and not torch.is_grad_enabled() and wgt.shape[0] % 128 == 0 and wgt.shape[1] % 64 == 0:
+        if dt in _OP16 and x.is_cuda and not torch.is_grad_enabled() and wgt.shape[0] % 128 == 0 and wgt.shape[1] % 64 == 0:
             # no-grad (teacher / evaluation): the patch projection on our own MFMA GEMM -- like every other kernel of the CAM / seg
             # path its result for a token does not depend on the batch around it
             tok = nn_ops.gemm_bf16(cols.reshape(B * h * w, -1).contiguous(), wgt.contiguous(), bias.contiguous(), nn_ops.EPI_BIAS).view(B, h * w, -1)
@@ -167,10 +171,13 @@ class VisionTransformer(nn.Module):
         projections are token-wise, so all tokens of all scales go through one launch each per block (M = sum B_i N_i:
         better tile quantisation on 256 CUs, a third of the launches); only attention runs per scale, on its slice of
         the packed qkv buffer."""
-        c = lambda p_: nn_ops.cast_param(p_, torch.bfloat16)
+        if self.precision == "bf16x3":
+            return self._forward_features_x3_multi(xs)
+        dt16 = self.compute_dtype                                # bf16, or fp16 (no-grad passes only: same kernels, fp16 operands)
+        c = lambda p_: nn_ops.cast_param(p_, dt16)
         toks, shapes = [], []
         for x in xs:
-            tok, h, w = self.prepare_tokens(x)                   # bf16 [B,N,768]
+            tok, h, w = self.prepare_tokens(x)                   # 16-bit [B,N,768]
             toks.append(tok.float().reshape(-1, tok.shape[-1]))
             shapes.append((tok.shape[0], tok.shape[1]))
         D = self.embed_dim
@@ -182,7 +189,7 @@ class VisionTransformer(nn.Module):
         depth = len(self.blocks)
         aux_idx = self.aux_layer % depth
         aux = None
-        o = torch.empty((Mtot, D), device=xr.device, dtype=torch.bfloat16)
+        o = torch.empty((Mtot, D), device=xr.device, dtype=dt16)
         for i, blk in enumerate(self.blocks):
             y, _ = nn_ops.layernorm_f32(xr, c(blk.norm1.weight), c(blk.norm1.bias), blk.norm1.eps)
             qkv = nn_ops.gemm_bf16(y, c(blk.attn.qkv.weight), c(blk.attn.qkv.bias), nn_ops.EPI_BIAS)
@@ -203,8 +210,84 @@ class VisionTransformer(nn.Module):
             outs.append((a32[:, 0], a16[:, 1:], ax[:, 1:], a32[:, 1:]))
         return outs
 
+    # -- parity-grade no-grad path: every MFMA operand as hi + lo bf16 halves (bf16x3), fp32 residual / LayerNorm / CAM heads ----------
+    def _split_weights(self):
+        """split rows [N, 2K+64] (bias in the augmentation block) of the patch projection and the 48 block projections, rebuilt from
+        the fp32 masters on every pass (the teacher's masters move every step; ~0.5 GB of traffic, part of the captured graph)"""
+        ws = self.__dict__.setdefault("_x3_w", {})
+        items = [("patch", self.patch_embed.proj.weight.reshape(self.embed_dim, -1), self.patch_embed.proj.bias)]
+        for i, blk in enumerate(self.blocks):
+            items += [(f"{i}.qkv", blk.attn.qkv.weight, blk.attn.qkv.bias), (f"{i}.proj", blk.attn.proj.weight, blk.attn.proj.bias),
+                      (f"{i}.fc1", blk.mlp.fc1.weight, blk.mlp.fc1.bias), (f"{i}.fc2", blk.mlp.fc2.weight, blk.mlp.fc2.bias)]
+        for name, w, b in items:
+            buf = ws.get(name)
+            if buf is None or buf.device != w.device:
+                buf = ws[name] = torch.empty((w.shape[0], nn_ops.split_ld(w.shape[1])), device=w.device, dtype=torch.bfloat16)
+            nn_ops.split_rows(w.detach(), bias=b.detach(), out=buf)
+        return ws
+
+    def _x3_buffers(self, M, dev):
+        """persistent split-row activations for M token rows; the (1, 1, 0, ...) augmentation block of the fc1 output is set once here
+        (the GEMM epilogue writes the hi | lo halves only), the other buffers get theirs from their producing kernels"""
+        bufs = self.__dict__.setdefault("_x3_bufs", {})
+        ent = bufs.get((M, dev))
+        if ent is None:
+            D, Hd = self.embed_dim, self.blocks[0].mlp.fc1.weight.shape[0]
+            mk = lambda cols: torch.zeros((M, cols), device=dev, dtype=torch.bfloat16)
+            ent = {"y": mk(nn_ops.split_ld(D)), "qkv": mk(2 * 3 * D), "o": mk(nn_ops.split_ld(D)), "h": mk(nn_ops.split_ld(Hd))}
+            ent["h"][:, 2 * Hd:2 * Hd + 2] = 1
+            bufs[(M, dev)] = ent
+        return ent
+
+    def _forward_features_x3_multi(self, xs):
+        D, H = self.embed_dim, self.num_heads
+        p = self.patch_size
+        W = self._split_weights()
+        toks, shapes = [], []
+        for x in xs:
+            B, nc, Hh, Ww = x.shape
+            h, w = Hh // p, Ww // p
+            cols = x.float().reshape(B, nc, h, p, w, p).permute(0, 2, 4, 1, 3, 5).reshape(B * h * w, nc * p * p)
+            pos = self._pos_for_grid(h, w, torch.float32)                              # [1, n+1, D]
+            tok = pos[:, 1:].expand(B, -1, -1).contiguous().view(B * h * w, D)          # residual operand: the position rows
+            nn_ops.gemm_x3(nn_ops.split_rows(cols, ones=True), W["patch"], B * h * w, D, nc * p * p, nn_ops.EPI_RESIDUAL, residual=tok, out=tok)
+            cls = (self.cls_token.detach().float() + pos[:, :1]).expand(B, -1, -1)
+            toks.append(torch.cat((cls, tok.view(B, h * w, D)), dim=1).reshape(-1, D))
+            shapes.append((B, h * w + 1))
+        xr = toks[0].contiguous() if len(toks) == 1 else torch.cat(toks, 0)
+        offs = [0]
+        for B, N in shapes:
+            offs.append(offs[-1] + B * N)
+        M = offs[-1]
+        bf = self._x3_buffers(M, xr.device)
+        depth = len(self.blocks)
+        aux_idx = self.aux_layer % depth
+        aux = None
+        f = lambda t: t.detach()
+        for i, blk in enumerate(self.blocks):
+            nn_ops.layernorm_split(xr, f(blk.norm1.weight), f(blk.norm1.bias), blk.norm1.eps, out=bf["y"])
+            nn_ops.gemm_x3(bf["y"], W[f"{i}.qkv"], M, 3 * D, D, nn_ops.EPI_BIAS, out=bf["qkv"], ldy=2 * 3 * D)
+            for (B, N), o0, o1 in zip(shapes, offs[:-1], offs[1:]):
+                nn_ops.attn_fwd_x3(bf["qkv"][o0:o1], B, N, H, bf["o"][o0:o1])
+            nn_ops.gemm_x3(bf["o"], W[f"{i}.proj"], M, D, D, nn_ops.EPI_RESIDUAL, residual=xr, out=xr)
+            nn_ops.layernorm_split(xr, f(blk.norm2.weight), f(blk.norm2.bias), blk.norm2.eps, out=bf["y"])
+            nn_ops.gemm_x3(bf["y"], W[f"{i}.fc1"], M, bf["h"].shape[1] // 2 - 32, D, nn_ops.EPI_GELU, out=bf["h"], ldy=bf["h"].shape[1])
+            nn_ops.gemm_x3(bf["h"], W[f"{i}.fc2"], M, D, bf["h"].shape[1] // 2 - 32, nn_ops.EPI_RESIDUAL, residual=xr, out=xr)
+            if i == aux_idx and aux_idx != depth - 1:
+                aux = xr.clone()
+        yfin = torch.empty_like(bf["y"])
+        _, xn32 = nn_ops.layernorm_split(xr, f(self.norm.weight), f(self.norm.bias), self.norm.eps, out=yfin, want_f32=True)
+        if aux is None:
+            aux = xn32
+        outs = []
+        for (B, N), o0, o1 in zip(shapes, offs[:-1], offs[1:]):
+            a16 = yfin[o0:o1].view(B, N, -1)[:, :, :D]                      # the hi halves: bf16 tokens for the decoder convs (strided view)
+            a32, ax = xn32[o0:o1].view(B, N, D), aux[o0:o1].view(B, N, D)
+            outs.append((a32[:, 0], a16[:, 1:], ax[:, 1:], a32[:, 1:]))
+        return outs
+
     def use_fused(self, x):
-        return (not torch.is_grad_enabled()) and self.compute_dtype == torch.bfloat16 and x.is_cuda and self.embed_dim == 768
+        return (not torch.is_grad_enabled()) and self.compute_dtype in _OP16 and x.is_cuda and self.embed_dim == 768
 
     # -- vit.py:302-321: returns cls token, final tokens, aux-layer tokens (pre final norm unless aux is the last) --
     def forward_features(self, x):

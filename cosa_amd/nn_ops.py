@@ -58,17 +58,17 @@ gemm_stamps = None   # likewise for the projection GEMMs (persistent 256x256 ker
 
 
 def _attn_fwd(qkv, B, N, H, out=None):
+    """fused attention forward on packed qkv [B,N,3,H,64] (bf16 or fp16 operands: the kernel build is picked by qkv's dtype)"""
+    dt = qkv.dtype
     if out is None:
-        out = torch.empty((B, N, H * 64), device=qkv.device, dtype=torch.bfloat16)
+        out = torch.empty((B, N, H * 64), device=qkv.device, dtype=dt)
     lse = torch.empty((B, H, N), device=qkv.device, dtype=torch.float32)
-    L = _C.lib()
-    ws = _C.workspace(L.cosa_attn_workspace_bytes(B, N, H), qkv.device, "attn")
-    _C.check(L.cosa_attn_prepare_vt(_C.ptr(qkv), B, N, H, _C.ptr(ws), ws.numel(), _C.stream_ptr()), "cosa_attn_prepare_vt")
+    ws = _C.workspace(_C.fn16("cosa_attn_workspace_bytes", dt)(B, N, H), qkv.device, "attn")
     fl = 4.0 * B * H * N * N * 64
     st = stamps.next_slot(fl) if stamps is not None else None
     with _C.profiled("attn_fwd"):
-        _C.check(L.cosa_attn_fwd(_C.ptr(qkv), _C.ptr(out), _C.ptr(lse), B, N, H, 64, 0.125, 1, st, _C.ptr(ws), ws.numel(),
-                                 _C.stream_ptr()), "cosa_attn_fwd")
+        _C.check(_C.fn16("cosa_attn_fwd", dt)(_C.ptr(qkv), _C.ptr(out), _C.ptr(lse), B, N, H, 64, 0.125, 1, st, _C.ptr(ws), ws.numel(),
+                                              _C.stream_ptr()), "cosa_attn_fwd")
     _flops["attn_fwd"] = _flops.get("attn_fwd", 0) + fl
     return out, lse
 
@@ -122,16 +122,18 @@ EPI_BIAS, EPI_GELU, EPI_RESIDUAL = 0, 1, 2
 
 
 def gemm_bf16(x, w, b, epilogue=EPI_BIAS, residual=None, out=None):
-    """x [M,K] bf16, w [N,K] bf16, b [N] bf16 -> [M,N] (bf16, or fp32 for the residual epilogue; may be in place)."""
+    """x [M,K], w [N,K], b [N] (all bf16, or all fp16) -> [M,N] (same 16-bit type, or fp32 for the residual epilogue; may be in place)."""
     M, K = x.shape
     N = w.shape[0]
+    dt = x.dtype
+    assert w.dtype == dt and b.dtype == dt, "gemm: operands must share one 16-bit dtype"
     if out is None:
-        out = torch.empty((M, N), device=x.device, dtype=torch.float32 if epilogue == EPI_RESIDUAL else torch.bfloat16)
+        out = torch.empty((M, N), device=x.device, dtype=torch.float32 if epilogue == EPI_RESIDUAL else dt)
     if gemm_stamps is not None and M >= 4096:
-        _C.lib().cosa_gemm_set_stamp_slot(gemm_stamps.next_slot(2.0 * M * N * K))
+        _C.fn16("cosa_gemm_set_stamp_slot", dt)(gemm_stamps.next_slot(2.0 * M * N * K))
     with _C.profiled("gemm_bf16"):
-        _C.check(_C.lib().cosa_gemm_bf16(_C.ptr(x), _C.ptr(w), _C.ptr(b), _C.ptr(residual), _C.ptr(out), M, N, K, epilogue,
-                                         _C.stream_ptr()), "cosa_gemm_bf16")
+        _C.check(_C.fn16("cosa_gemm_bf16", dt)(_C.ptr(x), _C.ptr(w), _C.ptr(b), _C.ptr(residual), _C.ptr(out), M, N, K, epilogue,
+                                               _C.stream_ptr()), "cosa_gemm_bf16")
     _flops["gemm_bf16"] = _flops.get("gemm_bf16", 0) + 2.0 * M * N * K
     return out
 
@@ -141,14 +143,15 @@ def conv3x3_dilated_tokens(tok, w16, B, h, w, dilation, relu=True):
     row-strided view (stride(1) == Cin-dim leading size, e.g. the encoder tokens without their cls row);
     w16: [Cout, Cin, 3, 3] bf16.  Returns [B*h*w, Cout] bf16."""
     Cout, Cin = w16.shape[0], w16.shape[1]
-    assert tok.dtype == torch.bfloat16 and tok.stride(2) == 1 and tok.shape[1] == h * w and tok.shape[2] == Cin
+    assert tok.dtype in (torch.bfloat16, torch.float16) and tok.dtype == w16.dtype
+    assert tok.stride(2) == 1 and tok.shape[1] == h * w and tok.shape[2] == Cin
     ldx = tok.stride(1)
     img_rows = tok.stride(0) // ldx if B > 1 else h * w
     assert B == 1 or tok.stride(0) == img_rows * ldx
     wt = w16.permute(2, 3, 0, 1).reshape(9, Cout, Cin).contiguous()
-    y = torch.empty((B * h * w, Cout), device=tok.device, dtype=torch.bfloat16)
+    y = torch.empty((B * h * w, Cout), device=tok.device, dtype=tok.dtype)
     with _C.profiled("conv3x3"):
-        _C.check(_C.lib().cosa_conv3x3_dilated_nhwc(_C.ptr(tok), _C.ptr(wt), _C.ptr(y), B, h, w, Cin, Cout, int(dilation), img_rows, 0,
+        _C.check(_C.fn16("cosa_conv3x3_dilated_nhwc", tok.dtype)(_C.ptr(tok), _C.ptr(wt), _C.ptr(y), B, h, w, Cin, Cout, int(dilation), img_rows, 0,
                                                     ldx, int(relu), _C.stream_ptr()), "cosa_conv3x3_dilated_nhwc")
     _flops["conv3x3"] = _flops.get("conv3x3", 0) + 2.0 * B * h * w * Cout * Cin * 9
     return y
@@ -249,11 +252,11 @@ def head_linear(tok, weight, round_bf16=False):
     narrow-head kernel (no-grad paths: teacher and evaluation).  None when the shape is outside the kernel's envelope."""
     B, n, K = tok.shape
     N = weight.shape[0]
-    if tok.dtype != weight.dtype or tok.dtype not in (torch.float32, torch.bfloat16) or K % 256 or tok.stride(2) != 1 \
+    if tok.dtype != weight.dtype or tok.dtype not in (torch.float32, torch.bfloat16, torch.float16) or K % 256 or tok.stride(2) != 1 \
             or not weight.is_contiguous() or min(N, 32) * K * 4 > 128 * 1024:
         return None
     y = torch.empty((B * n, N), device=tok.device, dtype=torch.float32)
-    dt = 0 if tok.dtype == torch.float32 else 1
+    dt = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}[tok.dtype]
     with _C.profiled("head_gemm"):
         for c0 in range(0, N, 32):
             nn_ = min(32, N - c0)
@@ -263,13 +266,77 @@ def head_linear(tok, weight, round_bf16=False):
 
 
 def layernorm_f32(x, g, b, eps, want_bf16=True, want_f32=False):
-    """x [rows,768] fp32 -> (bf16 | None, fp32 | None)"""
+    """x [rows,768] fp32, gamma / beta 16-bit (bf16 or fp16: that is also the 16-bit output type) -> (16-bit | None, fp32 | None)"""
     rows, D = x.shape
-    y16 = torch.empty((rows, D), device=x.device, dtype=torch.bfloat16) if want_bf16 else None
+    y16 = torch.empty((rows, D), device=x.device, dtype=g.dtype) if want_bf16 else None
     y32 = torch.empty((rows, D), device=x.device, dtype=torch.float32) if want_f32 else None
-    _C.check(_C.lib().cosa_layernorm(_C.ptr(x), _C.ptr(g), _C.ptr(b), _C.ptr(y16), _C.ptr(y32), rows, D, float(eps),
-                                     _C.stream_ptr()), "cosa_layernorm")
+    _C.check(_C.fn16("cosa_layernorm", g.dtype)(_C.ptr(x), _C.ptr(g), _C.ptr(b), _C.ptr(y16), _C.ptr(y32), rows, D, float(eps),
+                                                _C.stream_ptr()), "cosa_layernorm")
     return y16, y32
+
+
+# --------------------------------------------------------------------------------------------
+# bf16x3 ("split") operands: the parity-grade precision of the no-grad passes (include/cosa_hip.h; csrc/split_kernels.hip)
+#   a split row of logical width K: [hi (K) | lo (K) | aug (64)] bf16, row stride 2K + 64
+# --------------------------------------------------------------------------------------------
+_zero_bias = {}
+
+
+def split_ld(K):
+    return 2 * K + 64
+
+
+def split_rows(src, bias=None, ones=False, out=None):
+    """fp32 [R, K] (unit column stride; any row stride) -> split rows [R, 2K + 64]; aug block = (bias_hi, bias_lo, 0..) per row,
+    (1, 1, 0..) with ones=True, zeros otherwise"""
+    R, K = src.shape
+    assert src.dtype == torch.float32 and src.stride(1) == 1
+    if out is None:
+        out = torch.empty((R, split_ld(K)), device=src.device, dtype=torch.bfloat16)
+    _C.check(_C.lib().cosa_split_rows(_C.ptr(src), _C.ptr(bias), _C.ptr(out), R, K, src.stride(0), int(ones), _C.stream_ptr()),
+             "cosa_split_rows")
+    return out
+
+
+def layernorm_split(x, g, b, eps, out=None, want_f32=False):
+    """LayerNorm(768) over the fp32 stream with fp32 gamma / beta -> (split rows [rows, 1600] | None, fp32 | None)"""
+    rows, D = x.shape
+    y32 = torch.empty((rows, D), device=x.device, dtype=torch.float32) if want_f32 else None
+    _C.check(_C.lib().cosa_layernorm_split(_C.ptr(x), _C.ptr(g), _C.ptr(b), _C.ptr(out), _C.ptr(y32), rows, D, float(eps),
+                                           _C.stream_ptr()), "cosa_layernorm_split")
+    return out, y32
+
+
+def gemm_x3(xs, ws, M, N, K, epilogue=EPI_BIAS, residual=None, out=None, ldy=None):
+    """xs [M, 2K+64], ws [N, 2K+64] split rows (bias inside ws) -> epilogue 0/1: bf16 [M, ldy >= 2N] = [hi | lo | ...];
+    epilogue 2: fp32 [M, N] = residual + . (in place allowed)"""
+    dev = xs.device
+    z = _zero_bias.get(dev)
+    if z is None:
+        z = _zero_bias[dev] = torch.zeros(8192, device=dev, dtype=torch.bfloat16)
+    if epilogue == EPI_RESIDUAL:
+        ldy = N
+        if out is None:
+            out = torch.empty((M, N), device=dev, dtype=torch.float32)
+    else:
+        ldy = ldy or 2 * N
+        if out is None:
+            out = torch.empty((M, ldy), device=dev, dtype=torch.bfloat16)
+    if gemm_stamps is not None and M >= 4096:
+        _C.lib().cosa_gemm_set_stamp_slot(gemm_stamps.next_slot(6.0 * M * N * K))
+    with _C.profiled("gemm_x3"):
+        _C.check(_C.lib().cosa_gemm_bf16x3(_C.ptr(xs), _C.ptr(ws), _C.ptr(z), _C.ptr(residual), _C.ptr(out), M, N, K, epilogue, ldy,
+                                           _C.stream_ptr()), "cosa_gemm_bf16x3")
+    _flops["gemm_x3"] = _flops.get("gemm_x3", 0) + 6.0 * M * N * K
+    return out
+
+
+def attn_fwd_x3(qkv_s, B, N, H, out_s, lse=None):
+    """attention on split qkv rows [B*N, ldq] -> split rows out_s [B*N, ldo] (hi | lo | aug) for the output projection"""
+    _C.check(_C.lib().cosa_attn_fwd_bf16x3(_C.ptr(qkv_s), _C.ptr(out_s), _C.ptr(lse), B, N, H, 64, 0.125, qkv_s.stride(0), out_s.stride(0),
+                                           _C.stream_ptr()), "cosa_attn_fwd_bf16x3")
+    _flops["attn_x3"] = _flops.get("attn_x3", 0) + 12.0 * B * H * N * N * 64
+    return out_s
 
 
 # --------------------------------------------------------------------------------------------

@@ -106,7 +106,7 @@ class FusedAdamWEMAStep:
         dev = self.student[0].device
         L = _C.lib()
         self.rec_dtype = np.dtype([("p", "u8"), ("g", "u8"), ("m", "u8"), ("v", "u8"), ("tp", "u8"), ("p16", "u8"), ("t16", "u8"),
-                                   ("lr", "f4"), ("wd", "f4"), ("n", "i8")])
+                                   ("lr", "f4"), ("wd", "f4"), ("n", "i8"), ("t16_f16", "i4"), ("p16_f16", "i4")])
         assert self.rec_dtype.itemsize == L.cosa_optim_record_bytes()
         group_of = {}
         for gi, g in enumerate(optimizer.param_groups):
@@ -134,6 +134,8 @@ class FusedAdamWEMAStep:
             sp, st = shadow_of(p), shadow_of(tp)
             r["p16"] = sp.data_ptr() if sp is not None else 0
             r["t16"] = st.data_ptr() if st is not None else 0
+            r["p16_f16"] = int(sp is not None and sp.dtype == torch.float16)
+            r["t16_f16"] = int(st is not None and st.dtype == torch.float16)
             if self.group_idx[i] >= 0:
                 stt = optimizer.state[p]
                 if "exp_avg" not in stt:

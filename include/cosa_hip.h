@@ -226,11 +226,57 @@ void cosa_gemm_set_stamp_slot(void *slot);
 /* models/__init__.py:190-192 (classifier / aux_classifier as 1x1 convs over the tokens) and conv_head.py:38 (conv8): the narrow heads
  * Y[M, N <= 32] (fp32, columns [col0, col0+N) of rows with stride ldy) = X W^T, fp32 accumulation, fixed reduction order per row
  * (results do not depend on what else is in the batch).  X: image b = rows_per_img rows at X + b*img_stride (elements), row stride
- * ldx; dtype 0: fp32 X and W, 1: bf16 X and W (round_bf16 = 1 rounds the result to bf16 precision).                               */
+ * ldx; dtype 0: fp32 X and W, 1: bf16, 2: fp16 X and W (round_bf16 = 1 rounds the result to the operand precision).                               */
 int cosa_head_gemm(const void *X, const void *W, float *Y, int M, int N, int K, int rows_per_img, long long img_stride,
                    int ldx, int dtype, int round_bf16, int ldy, int col0, void *stream);
 int cosa_layernorm(const float *x, const void *gamma, const void *beta, void *y_bf16, float *y_f32,
                    int rows, int dim, float eps, void *stream);
+
+/* The same kernels with IEEE fp16 operands (fp32 accumulation, same MFMA rate; gemm_kernels.hip / attn_kernels.hip built a second
+ * time with -DCOSA_OP_F16=1): the no-grad passes -- the teacher's six multi-scale forwards per step (utils/seg_helper.py:232-275) and
+ * evaluation -- may run on fp16 operands, which keeps the pseudo-label maps within the stated tolerance of the fp32 reference where
+ * bf16's 8 significant bits do not.  Argument lists are those of the bf16 entry points, every "bf16" buffer
+ * being fp16 instead.                                                                                                            */
+int cosa_gemm_f16(const void *X, const void *W, const void *bias, const float *residual, void *Y,
+                  int M, int N, int K, int epilogue, void *stream);
+int cosa_gemm_wgrad_f16(const void *dY, const void *X, float *dW, float *db, int M, int N, int K, int zero_first, void *stream);
+int cosa_layernorm_f16(const float *x, const void *gamma, const void *beta, void *y_f16, float *y_f32,
+                       int rows, int dim, float eps, void *stream);
+int cosa_conv3x3_dilated_nhwc_f16(const void *X, const void *Wt, void *Y, int B, int h, int w, int Cin, int Cout, int dilation,
+                                  int img_rows, int row_off, int ldx, int relu, void *stream);
+int cosa_conv3x3_dilated_wgrad_f16(const void *dY, const void *X, float *dW9, int B, int h, int w, int Cin, int Cout, int dilation,
+                                   int img_rows, int row_off, int ldx, int zero_first, void *stream);
+void cosa_gemm_set_variant_f16(int v);
+void cosa_gemm_set_stamp_slot_f16(void *slot);
+size_t cosa_attn_workspace_bytes_f16(int B, int N, int H);
+int cosa_attn_prepare_vt_f16(const void *qkv, int B, int N, int H, void *workspace, size_t workspace_bytes, void *stream);
+int cosa_attn_fwd_f16(const void *qkv, void *out, float *lse, int B, int N, int H, int head_dim, float scale,
+                      int flags, uint64_t *stamps, void *workspace, size_t workspace_bytes, void *stream);
+size_t cosa_attn_bwd_workspace_bytes_f16(int B, int N, int H);
+int cosa_attn_bwd_f16(const void *qkv, const void *out, const void *dout, const float *lse, void *dqkv,
+                      int B, int N, int H, int head_dim, float scale, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * bf16x3 ("split") operands: the parity-grade precision of the no-grad passes (teacher pseudo-labels, utils/seg_helper.py:232-275;
+ * evaluation).  The reference runs fp32; bf16's 8 significant bits put the normalised CAMs ~1e-2 and the label maps
+ * ~0.2 % away from it at 448^2, so every MFMA operand of these passes can instead be carried as hi = bf16(v), lo = bf16(v - hi)
+ * (16 significant bits) with three MFMA terms per product (hi*hi + lo*hi + hi*lo) and fp32 accumulation -- still bf16 MFMA, 3x the
+ * work.  A split row of logical width K is [hi (K) | lo (K) | aug (64)], row stride 2K + 64; aug = (1, 1, 0, ...) for activations and
+ * (bias_hi, bias_lo, 0, ...) for weight row n, so nn.Linear's bias rides in the GEMM as one more K tile.
+ *   cosa_split_rows       src fp32 [R, K] (row stride src_ld) (+ bias fp32 [R] | ones) -> dst split rows [R, 2K + 64]
+ *   cosa_layernorm_split  nn.LayerNorm(768, eps), fp32 gamma / beta, over the fp32 residual stream -> split rows and/or fp32
+ *   cosa_gemm_bf16x3      Y = Xs Ws^T (bias inside Ws): epilogue 0 / 1 (GELU): Y bf16 [M, ldy >= 2N] = [hi | lo]; epilogue 2: Y fp32
+ *                         [M, N] = residual + . (may alias);  zeros: N bf16 zeros (the kernels' bias operand)
+ *   cosa_attn_fwd_bf16x3  attention on the split qkv rows [B*N, ldq] = [hi (3*H*64) | lo ...] -> split rows [B*N, ldo >= 2*H*64 + 64]
+ *                         for the output projection; lse optional
+ * ------------------------------------------------------------------------------------- */
+int cosa_split_rows(const float *src, const float *bias, void *dst, int R, int K, long long src_ld, int ones, void *stream);
+int cosa_layernorm_split(const float *x, const float *gamma, const float *beta, void *y_split, float *y_f32, int rows, int dim,
+                         float eps, void *stream);
+int cosa_gemm_bf16x3(const void *Xs, const void *Ws, const void *zeros, const float *residual, void *Y,
+                     int M, int N, int K, int epilogue, int ldy, void *stream);
+int cosa_attn_fwd_bf16x3(const void *qkv_split, void *out_split, float *lse, int B, int N, int H, int head_dim, float scale,
+                         int ldq, int ldo, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * main.py:167-212 + utils/seg_helper.py:800-813,199-230  the student's dense losses, fused:

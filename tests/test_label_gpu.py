@@ -253,14 +253,40 @@ def test_dense_energy_full_size_vs_oracle(oracle_c):
 def test_errors_are_loud():
     from cosa_amd import _C
     from cosa_amd.utils import seg_helper
-    with pytest.raises(NotImplementedError):
-        seg_helper.cam2mask(torch.zeros(1, 3, 8, 8, device="cuda"), torch.tensor([[0, 8, 0, 8]]), torch.zeros(1, 2, 8, 8, device="cuda"),
-                            torch.ones(1, 2, device="cuda"), 0.7, 0.25, downscale=4)
     with pytest.raises(TypeError):
         seg_helper.cam2mask(torch.zeros(1, 3, 8, 8, device="cuda"), torch.tensor([[0, 8, 0, 8]]), torch.zeros(1, 2, 8, 8, device="cuda"),
-                            torch.ones(1, 2, device="cuda"), 0.7, 0.25, refine_model=lambda a, b: b)
+                            torch.ones(1, 2, device="cuda"), 0.7, 0.25, refine_model="not callable")
     with pytest.raises(_C.CosaError):
         _C.check(_C.lib().cosa_cam_minmax_norm(None, 0, 0, None, None), "bad call")
+
+
+def test_cam2mask_generic_hook_matches_the_fused_path():
+    """utils/seg_helper.py:787-792 accepts ANY callable as refine_model (and non-square crops): those go through the reference's
+    per-image loop on the GPU.  With an identity refine model it must agree with the fused kernels (same arithmetic spec up to the
+    contraction of torch's GPU bilinear kernel: a handful of tie pixels at most)."""
+    from cosa_amd.utils import seg_helper
+    rng = np.random.default_rng(5)
+    B, C, S = 2, 20, 64
+    cams = np.maximum(smooth(rng, B * C, S, S).reshape(B, C, S, S) * 1.3 - 0.15, 0).astype(np.float32)
+    labels = np.zeros((B, C), np.float32)
+    labels[0, [1, 7]] = 1
+    labels[1, [12]] = 1
+    boxes = torch.tensor([[0, S, 0, S], [4, 60, 8, 50]], dtype=torch.int32)
+    img = dev(smooth(rng, B * 3, S, S).reshape(B, 3, S, S))
+    calls = []
+
+    def identity(images, c):
+        calls.append((tuple(images.shape), tuple(c.shape)))
+        return c
+    fused = seg_helper.cam2mask(img, boxes, dev(cams), dev(labels), 0.7, 0.25, _fold_validation=True)
+    gen = seg_helper.cam2mask(img, boxes, dev(cams), dev(labels), 0.7, 0.25, refine_model=identity, _fold_validation=True)
+    assert len(calls) == 2 * B and calls[0] == ((1, 3, S // 2, S // 2), (1, 3, S // 2, S // 2))
+    assert gen.shape == fused.shape and (gen == fused).float().mean().item() > 0.995
+    assert set(np.unique(gen.cpu().numpy())) <= set([0.0, 255.0] + [float(k + 1) for k in range(C)])
+    # non-square crops take the same path
+    m = seg_helper.cam2mask(img[:, :, :48], torch.tensor([[0, 48, 0, S], [4, 40, 8, 50]]), dev(cams[:, :, :48]), dev(labels), 0.7, 0.25,
+                            _fold_validation=True)
+    assert m.shape == (B, 48, S)
 
 
 def test_bilateral_noise_and_smooth_images_in_one_batch(oracle_c):

@@ -1,0 +1,245 @@
+"""GPU parity of the operand-precision modes of the no-grad (teacher / evaluation) path.
+
+  bf16    8 significant bits per MFMA operand  (the training path's type)
+  fp16    11 significant bits, same kernels built with fp16 operands (csrc/op16.hpp)
+  bf16x3  16 significant bits: every operand as hi + lo bf16 halves, three MFMA terms (hi*hi + lo*hi + hi*lo), fp32 accumulation
+
+Kernel-level checks against fp32 torch with the tolerance of each mode written in the test, then the whole multi-scale teacher pass
+(fused ViT-B, embed 768: persistent GEMM + DMA attention + fp32 residual) against oracle/torch_oracle.py on identical weights and
+inputs: normalised-CAM relative error, label agreement and mask IoU (BASELINE.json north_star: 1e-3 / bit-exact labels / IoU >= 0.999)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _ref_gemm(x, w, b, epi, r):
+    y = x.float() @ w.float().t() + b.float()
+    if epi == 1:
+        y = torch.nn.functional.gelu(y)
+    if epi == 2:
+        y = y + r
+    return y
+
+
+@pytest.mark.parametrize("variant", [0, 1, 6])
+@pytest.mark.parametrize("epi", [0, 1, 2])
+def test_gemm_f16_vs_fp32(variant, epi):
+    """fp16 operands, fp32 accumulation: output rounding 2^-12 relative -> tolerance 2^-10 of the output scale (fp32 out: 1e-5)"""
+    from cosa_amd import nn_ops, _C
+    torch.manual_seed(variant * 10 + epi)
+    try:
+        for (M, N, K) in [(4099, 768, 768), (4608, 2304, 768), (5000, 768, 3072), (300, 768, 768), (1, 128, 64), (66000, 256, 192)]:
+            x = torch.randn(M, K, device="cuda").half()
+            w = (torch.randn(N, K, device="cuda") * K ** -0.5).half()
+            b = torch.randn(N, device="cuda").half()
+            r = torch.randn(M, N, device="cuda") if epi == 2 else None
+            _C.lib().cosa_gemm_set_variant_f16(variant)
+            y = nn_ops.gemm_bf16(x, w, b, epi, residual=r)
+            ref = _ref_gemm(x, w, b, epi, r)
+            assert y.dtype == (torch.float32 if epi == 2 else torch.float16)
+            tol = (1e-5 if epi == 2 else 2.0 ** -10) * max(ref.abs().max().item(), 1.0)
+            err = (y.float() - ref).abs().max().item()
+            assert err <= tol, (variant, epi, M, N, K, err, tol)
+    finally:
+        _C.lib().cosa_gemm_set_variant_f16(0)
+
+
+@pytest.mark.parametrize("B,N,H", [(2, 197, 12), (1, 785, 12), (2, 100, 3), (1, 1765, 2), (1, 1, 1), (1, 129, 1)])
+def test_attention_fwd_f16_vs_fp32(B, N, H):
+    """fp16 q/k/v/P/out, fp32 softmax statistics: |err| <= 3e-3 * max|ref| (bf16 build: 2e-2)"""
+    from cosa_amd import nn_ops
+    torch.manual_seed(N)
+    qkv = (torch.randn(B, N, 3 * H * 64, device="cuda") * 1.5).half()
+    out, lse = nn_ops._attn_fwd(qkv, B, N, H)
+    q, k, v = qkv.float().view(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
+    att = (q @ k.transpose(-1, -2)) * 0.125
+    ref = (att.softmax(-1) @ v).transpose(1, 2).reshape(B, N, H * 64)
+    assert out.dtype == torch.float16
+    err = (out.float() - ref).abs().max().item()
+    assert err <= 3e-3 * ref.abs().max().item() + 2e-4, err
+    assert torch.allclose(lse, torch.logsumexp(att, -1), rtol=1e-4, atol=1e-3)
+
+
+def test_layernorm_conv_head_f16_vs_torch():
+    from cosa_amd import nn_ops
+    torch.manual_seed(0)
+    x = torch.randn(1000, 768, device="cuda") * 3 + 1
+    g, b = (torch.rand(768, device="cuda") + 0.5).half(), torch.randn(768, device="cuda").half()
+    y16, y32 = nn_ops.layernorm_f32(x, g, b, 1e-6, True, True)
+    ref = torch.nn.functional.layer_norm(x, (768,), g.float(), b.float(), 1e-6)
+    assert y16.dtype == torch.float16 and (y32 - ref).abs().max().item() < 1e-4
+    assert (y16.float() - ref).abs().max().item() <= 2.0 ** -10 * ref.abs().max().item()
+    B, h, w, Cin, Cout = 2, 14, 14, 768, 512
+    tok = torch.randn(B, h * w, Cin, device="cuda").half()
+    wt = (torch.randn(Cout, Cin, 3, 3, device="cuda") * (9 * Cin) ** -0.5).half()
+    y = nn_ops.conv3x3_dilated_tokens(tok, wt, B, h, w, 5, relu=True)
+    refc = torch.relu(torch.nn.functional.conv2d(tok.float().view(B, h, w, Cin).permute(0, 3, 1, 2), wt.float(), padding=5, dilation=5))
+    refc = refc.permute(0, 2, 3, 1).reshape(B * h * w, Cout)
+    assert (y.float() - refc).abs().max().item() <= 2.0 ** -9 * refc.abs().max().item()
+    wh = (torch.randn(21, 512, device="cuda") * 0.05).half()
+    yh = nn_ops.head_linear(y.view(B, h * w, Cout), wh, round_bf16=True)
+    refh = y.float() @ wh.float().t()
+    assert (yh - refh).abs().max().item() <= 2.0 ** -10 * refh.abs().max().item() + 1e-6
+
+
+def _split_ref(v):
+    hi = v.bfloat16()
+    lo = (v - hi.float()).bfloat16()
+    return hi.float() + lo.float()
+
+
+@pytest.mark.parametrize("epi", [0, 1, 2])
+def test_gemm_bf16x3_vs_fp64(epi):
+    """hi + lo bf16 operands, three MFMA terms: the operands carry 16 significant bits (2^-17 relative rounding), the dropped lo*lo
+    term is 2^-18; against an fp64 product of the fp32 inputs the error stays below 2^-14 of the output scale, ~100x below bf16.
+    Covers the persistent 256x256 kernel (M >= 4096, several jobs per workgroup, M tails) and the 128x128 kernel."""
+    from cosa_amd import nn_ops
+    torch.manual_seed(epi)
+    for (M, N, K) in [(4099, 768, 768), (4608, 2304, 768), (5000, 768, 3072), (300, 768, 768), (70000, 256, 128), (131, 128, 64)]:
+        x = torch.randn(M, K, device="cuda")
+        w = torch.randn(N, K, device="cuda") * K ** -0.5
+        b = torch.randn(N, device="cuda")
+        r = torch.randn(M, N, device="cuda") if epi == 2 else None
+        xs, ws = nn_ops.split_rows(x, ones=True), nn_ops.split_rows(w, bias=b)
+        assert xs.shape == (M, 2 * K + 64) and torch.equal(xs[:, 2 * K:2 * K + 3].float().cpu(), torch.tensor([1., 1., 0.]).expand(M, 3))
+        y = nn_ops.gemm_x3(xs, ws, M, N, K, epi, residual=r.clone() if r is not None else None, ldy=2 * N + 64 if epi != 2 else None)
+        ref = x.double() @ w.double().t() + b.double()
+        if epi == 1:
+            ref = torch.nn.functional.gelu(ref)
+        if epi == 2:
+            ref = ref + r.double()
+            got = y.double()
+        else:
+            assert y.shape == (M, 2 * N + 64) and y.dtype == torch.bfloat16
+            got = y[:, :N].double() + y[:, N:2 * N].double()
+        scale = max(ref.abs().max().item(), 1.0)
+        err = (got - ref).abs().max().item()
+        assert err <= 2.0 ** -14 * scale, (epi, M, N, K, err / scale)
+
+
+@pytest.mark.parametrize("B,N,H", [(2, 197, 12), (1, 785, 3), (2, 100, 3), (1, 1765, 2), (1, 1, 1), (1, 129, 1)])
+def test_attention_bf16x3_vs_fp64(B, N, H):
+    from cosa_amd import nn_ops
+    torch.manual_seed(N)
+    qkv = torch.randn(B * N, 3 * H * 64, device="cuda") * 1.5
+    qs = nn_ops.split_rows(qkv)[:, :6 * H * 64].contiguous()                 # [hi | lo] rows, as the split qkv projection writes them
+    out = torch.zeros(B * N, 2 * H * 64 + 64, device="cuda", dtype=torch.bfloat16)
+    lse = torch.empty(B, H, N, device="cuda")
+    nn_ops.attn_fwd_x3(qs, B, N, H, out, lse)
+    q, k, v = qkv.double().view(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
+    att = (q @ k.transpose(-1, -2)) * 0.125
+    ref = (att.softmax(-1) @ v).transpose(1, 2).reshape(B * N, H * 64)
+    got = out[:, :H * 64].double() + out[:, H * 64:2 * H * 64].double()
+    assert (got - ref).abs().max().item() <= 2.0 ** -13 * ref.abs().max().item() + 1e-6
+    assert torch.allclose(lse.double(), torch.logsumexp(att, -1), rtol=1e-5, atol=1e-4)
+    aug = out[:, 2 * H * 64:].float().cpu()
+    assert torch.equal(aug[:, :2], torch.ones(B * N, 2)) and aug[:, 2:].abs().max().item() == 0
+
+
+def test_layernorm_split_vs_torch():
+    from cosa_amd import nn_ops
+    torch.manual_seed(0)
+    x = torch.randn(1000, 768, device="cuda") * 3 + 1
+    g, b = torch.rand(768, device="cuda") + 0.5, torch.randn(768, device="cuda")
+    out = torch.empty(1000, 1600, device="cuda", dtype=torch.bfloat16)
+    _, y32 = nn_ops.layernorm_split(x, g, b, 1e-6, out=out, want_f32=True)
+    ref = torch.nn.functional.layer_norm(x, (768,), g, b, 1e-6)
+    assert (y32 - ref).abs().max().item() < 1e-4
+    got = out[:, :768].float() + out[:, 768:1536].float()
+    assert (got - y32).abs().max().item() <= 2.0 ** -16 * y32.abs().max().item()
+    assert torch.equal(out[:, 1536:1538].float().cpu(), torch.ones(1000, 2)) and out[:, 1538:].float().abs().max().item() == 0
+
+
+def test_no_grad_forward_sees_weights_written_through_data_and_raw_pointers():
+    """the reference loop's EMA is `param.data.mul_(m).add_(...)`, which does not bump `_version`; the 16-bit weights a
+    no-grad forward reads must follow it all the same (nothing is cached by version)."""
+    from cosa_amd.models import build_model
+    from cosa_amd.train_step import default_args
+    torch.manual_seed(0)
+    net = build_model(default_args("VOC12", crop_size=64)).cuda().eval()
+    x = torch.randn(2, 3, 64, 64, device="cuda")
+    with torch.no_grad():
+        a = net(x)[4].clone()
+        for p in net.parameters():
+            p.data.mul_(0.5).add_(0.01)
+        b = net(x)[4].clone()
+        c = net(x)[4].clone()
+    assert not torch.allclose(a, b), "forward after an in-place .data update still used the old 16-bit weights"
+    assert torch.equal(b, c)
+
+
+# ---- the whole teacher pass vs the fp32 CPU oracle ----------------------------------------------------------------------------
+def _miou(a, b, n=21):
+    ious = []
+    for c in list(range(n)) + [255]:
+        A, B = a == c, b == c
+        u = (A | B).sum()
+        if u:
+            ious.append((A & B).sum() / u)
+    return float(np.mean(ious))
+
+
+_ORACLE = {}
+
+
+def _oracle_pass(S):
+    """fp32 CPU oracle (oracle/torch_oracle.py + cosa_oracle.c) on seed-3 ViT-B weights and the seed-5 synthetic batch, cached per S"""
+    if S not in _ORACLE:
+        from oracle import torch_oracle as to, c_oracle
+        from cosa_amd.models import build_model
+        from cosa_amd.train_step import default_args, synthetic_batch
+        torch.manual_seed(3)
+        net = build_model(default_args("VOC12", crop_size=S, compute_dtype=torch.float32))
+        sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+        wimg, _, lab, box = synthetic_batch(2, S, 20, torch.device("cpu"), seed=5)
+        m = to.OracleViT(num_classes=21, aux_layer=-4)
+        m.load_named(sd)
+        torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+        with torch.no_grad():
+            cam, cam_aux, _ = to.multi_scale_camseg(m, wimg, [1.0, 0.5, 1.5])
+        bx = np.asarray(box.numpy(), np.int32)
+        masks = [c_oracle.cam2mask(None, bx, c.numpy(), lab.numpy(), 0.7, 0.25, 2, par=None) for c in (cam, cam_aux)]
+        _ORACLE[S] = (sd, wimg, lab, box, cam, cam_aux, masks)
+    return _ORACLE[S]
+
+
+# mode -> (max normalised-CAM relative error, min label agreement, min mask IoU); bf16x3 carries the north-star bars
+TEACHER_BARS = {
+    "bf16": (3e-2, 0.99, 0.97),
+    "fp16": (4e-3, 0.9990, 0.995),
+    "bf16x3": (1e-3, 0.999, 0.999),        # BASELINE.json north_star: 1e-3 relative on fp32 CAMs, mask IoU >= 0.999
+}
+
+
+@pytest.mark.parametrize("S", [224, 448])
+@pytest.mark.parametrize("mode", list(TEACHER_BARS))
+def test_fused_teacher_vs_fp32_cpu_oracle(mode, S):
+    from cosa_amd.models import build_model
+    from cosa_amd.train_step import default_args
+    from cosa_amd.utils import seg_helper
+    sd, wimg, lab, box, cam_o, cam_aux_o, masks_o = _oracle_pass(S)
+    args = default_args("VOC12", crop_size=S)
+    net = build_model(args).cuda().eval()
+    net.load_state_dict(sd)
+    net.set_nograd_precision(mode)
+    assert net.encoder.use_fused(wimg.cuda()) or torch.is_grad_enabled()
+    with torch.no_grad():
+        cam, cam_aux, _ = seg_helper.multi_scale_camseg(net, wimg.cuda(), args.pseudo_scales)
+        masks = [seg_helper.cam2mask(wimg.cuda(), box, c * lab.cuda()[:, :, None, None], lab.cuda(), 0.7, 0.25).cpu().numpy() for c in (cam, cam_aux)]
+    act = lab.bool()
+    bar_rel, bar_agree, bar_iou = TEACHER_BARS[mode]
+    lines = []
+    for name, g, o, mg, mo in (("cam", cam, cam_o, masks[0], masks_o[0]), ("cam_aux", cam_aux, cam_aux_o, masks[1], masks_o[1])):
+        rel = ((g.cpu() - o).abs().amax(dim=(2, 3)) / o.abs().amax(dim=(2, 3)).clamp_min(1e-6))[act].max().item()
+        agree, iou = float(np.mean(mg == mo)), _miou(mg, mo)
+        lines.append(f"teacher {mode:7s} S={S} b=2 {name:8s}: normalised-CAM rel err {rel:.3e}  label agreement {agree:.5f}  mask mIoU {iou:.5f}")
+        assert rel <= bar_rel and agree >= bar_agree and iou >= bar_iou, lines[-1]
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "r02_accuracy_teacher.txt"), "a") as f:
+        f.write("\n".join(lines) + "\n")
