@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--usepar", action="store_true", help="PAR(T=10, 6 dilations) as cam2mask's refine_model")
     ap.add_argument("--usegmm", action="store_true", help="adaptive thresholds: 3-component mixture fitted to the CAM queue every step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--teacher-precision", default="bf16", choices=["bf16", "fp16", "bf16x3"],
+                    help="MFMA operand precision of the teacher's no-grad passes in the headline run (DESIGN.md section 3)")
+    ap.add_argument("--no-parity-grade", action="store_true", help="skip the second, parity-grade (bf16x3 teacher) measurement")
     ap.add_argument("--teacher-sync", action="store_true",
                     help="replay the teacher graph on the main stream (default: on a side stream, overlapping the student's forward); "
                          "kernel spans in `roofline` are then undisturbed by co-running kernels")
@@ -206,6 +209,64 @@ def input_pipeline_images_per_s(dev, batch, crop):
             "sample": "decoded 375x500-class uint8 images, all draws as the reference"}
 
 
+def vit_forward_roofline(trainer, wimg, dev, crop):
+    """north_star: ">= 40 % of CDNA4 bf16 MFMA peak on the ViT-B forward": the network forward alone (encoder + LargeFOV + heads,
+    no gradients) on the teacher's scale-1.0 batch (images + flips) at the crop size, HIP events over 10 passes; 166.3 GFLOP per image
+    at 448^2 (387.3 at 640^2)."""
+    flop_img = {448: 166.3e9, 640: 387.3e9, 224: 37.5e9}.get(crop)
+    if flop_img is None:
+        return None
+    x = torch.cat([wimg, wimg.flip(-1)], 0)
+    net = trainer.model_AN
+    with torch.no_grad():
+        for _ in range(3):
+            net(x)
+        a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(10):
+            net(x)
+        e.record()
+    torch.cuda.synchronize()
+    ms = a.elapsed_time(e) / 10
+    mult = 3.0 if trainer.model_AN.encoder.precision == "bf16x3" else 1.0          # issued MFMA work per algorithmic flop
+    ach = flop_img * x.shape[0] / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": round(ach * 1e12 / PEAK_BF16, 4),
+            "ms": round(ms, 3), "images": int(x.shape[0]), "flop_per_img": flop_img, "operands": trainer.args.teacher_precision,
+            "issued_mfma_frac": round(ach * mult * 1e12 / PEAK_BF16, 4),
+            "note": "algorithmic FLOPs of the fp32 reference / time; bf16x3 issues 3 MFMA terms per product"}
+
+
+def parity_grade(opt, dev, C, wimg, simg, lab, box, n_iter):
+    """The same training step with the teacher's no-grad passes on bf16x3 operands: the precision at which the pseudo-label path meets
+    BASELINE.json's tolerance against the fp32 reference (tests/test_precision_gpu.py; profiles/r02_accuracy_teacher.txt)."""
+    from cosa_amd.train_step import CoSATrainer, default_args
+    args = default_args(opt.dataset, crop_size=opt.crop, batch_size=opt.batch, usepar=opt.usepar, usegmm=opt.usegmm,
+                        teacher_precision="bf16x3", teacher_async=not opt.teacher_sync)
+    from cosa_amd import nn_ops
+    st, gst = nn_ops.stamps, nn_ops.gemm_stamps
+    nn_ops.stamps = nn_ops.gemm_stamps = None
+    try:
+        tr = CoSATrainer(args, dev, ddp=False, seed=0)
+        for _ in range(4):
+            tr.step(wimg, simg, lab, box, n_iter)
+        torch.cuda.synchronize()
+        n = max(3, min(10, opt.steps))
+        t0 = time.perf_counter()
+        for _ in range(n):
+            tr.step(wimg, simg, lab, box, n_iter)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+        out = {"teacher_operands": "bf16x3 (hi + lo bf16 halves, 3 MFMA terms, fp32 accumulation)", "student_operands": "bf16",
+               "images_per_s": round(opt.batch / dt, 2), "ms_per_step": round(dt * 1e3, 3), "steps": n,
+               "vit_forward": vit_forward_roofline(tr, wimg, dev, opt.crop)}
+    finally:
+        nn_ops.stamps, nn_ops.gemm_stamps = st, gst
+    acc = os.path.join(ROOT, "profiles", "r02_accuracy_teacher.txt")
+    if os.path.exists(acc):
+        out["accuracy_vs_fp32_cpu_oracle"] = [ln.strip() for ln in open(acc) if "bf16x3" in ln and "S=448" in ln]
+    return out
+
+
 def eval_images_per_s(trainer, dev, C, crop, n=20):
     """SURVEY f-1: the validation pass (batch 1, five scales x two flips, label maps + confusion matrices on the device) on synthetic
     VOC-val-shaped images with the teacher network; bounded sample."""
@@ -262,7 +323,7 @@ def main():
     # ping-pong across time slices (measured: 7 s/step), so the side-stream teacher is only used with a card per rank
     shared_card = world > ndev
     args = default_args(opt.dataset, crop_size=opt.crop, batch_size=opt.batch, usepar=opt.usepar, usegmm=opt.usegmm,
-                        teacher_async=not (opt.teacher_sync or shared_card or os.environ.get("COSA_TEACHER_SYNC")))
+                        teacher_precision=opt.teacher_precision, teacher_async=not (opt.teacher_sync or shared_card or os.environ.get("COSA_TEACHER_SYNC")))
     nn_ops.stamps = nn_ops.KernelStamps(dev)          # device-side launch spans of the two dominant kernels (work inside hipGraphs)
     nn_ops.gemm_stamps = nn_ops.KernelStamps(dev)
     trainer = CoSATrainer(args, dev, ddp=world > 1, seed=0)
@@ -343,7 +404,13 @@ def main():
         if flop_img:
             out["step_mfma"] = {"achieved_TFLOPs": round(ips * flop_img / 1e12, 2), "peak_TFLOPs": PEAK_BF16 / 1e12 * world,
                                 "frac": round(ips * flop_img / (PEAK_BF16 * world), 4), "flop_per_img": flop_img}
+        vf = vit_forward_roofline(trainer, wimg, dev, opt.crop)
+        if vf:
+            out["vit_forward"] = vf
+        out["config"]["teacher_operands"] = opt.teacher_precision
         out["par_refine"] = par_refine_ms_per_img(trainer, simg, lab, box, dev, opt, C)
+        if world == 1 and not opt.no_parity_grade and opt.teacher_precision != "bf16x3":
+            out["parity_grade"] = parity_grade(opt, dev, C, wimg, simg, lab, box, n_iter)
         if world == 1 and opt.crop == 448:
             out["evaluation"] = eval_images_per_s(trainer, dev, C, opt.crop)
             out["input_pipeline"] = input_pipeline_images_per_s(dev, opt.batch, opt.crop)

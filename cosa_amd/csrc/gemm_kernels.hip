@@ -83,7 +83,7 @@ template <int EPI, int SPLIT = 0>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const op16 *__restrict__ X, const op16 *__restrict__ W,
                                                           const op16 *__restrict__ bias, const float *__restrict__ R,
                                                           void *__restrict__ Yv, int M, int N, int K, int tiles_m, int tiles_n,
-                                                          int ld, int ldy)
+                                                          int ld, int ldy, void *__restrict__ Y2v)
 {
     // SPLIT: K is the LOGICAL contraction length; operand rows have stride ld = 2K + 64, 16-bit outputs go to [hi | lo] rows of stride ldy
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const op16 *__restric
         for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int Kp = K / BK;
-    const int nk = SPLIT ? 3 * Kp + 1 : Kp;
+    const int nk = SPLIT == 1 ? 3 * Kp + 1 : Kp;
     stage_tile(W, n0, N, ld, 0, smem, wave, lane);
     stage_tile(X, m0, M, ld, 0, smem + TILE_BYTES, wave, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -117,8 +117,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const op16 *__restric
         unsigned char *cur = smem + (kt & 1) * STAGE_BYTES;
         unsigned char *nxt = smem + ((kt + 1) & 1) * STAGE_BYTES;
         if (kt + 1 < nk) {
-            stage_tile(W, n0, N, ld, (SPLIT ? split_tile_w(kt + 1, Kp) : kt + 1) * BK, nxt, wave, lane);
-            stage_tile(X, m0, M, ld, (SPLIT ? split_tile_x(kt + 1, Kp) : kt + 1) * BK, nxt + TILE_BYTES, wave, lane);
+            stage_tile(W, n0, N, ld, (SPLIT == 1 ? split_tile_w(kt + 1, Kp) : kt + 1) * BK, nxt, wave, lane);
+            stage_tile(X, m0, M, ld, (SPLIT == 1 ? split_tile_x(kt + 1, Kp) : kt + 1) * BK, nxt + TILE_BYTES, wave, lane);
         }
         const unsigned char *At = cur + (wr * 64) * 128;
         const unsigned char *Bt = cur + TILE_BYTES + (wc * 64) * 128;
@@ -165,9 +165,14 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const op16 *__restric
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     float t = acc[i][j][r] + bv[r];
-                    if (EPI == EPI_GELU) t = gelu_erf(t);
-                    v[r] = (op16)t;
-                    if (SPLIT) vlo[r] = (op16)(t - (float)v[r]);
+                    if (SPLIT == 2) {                         // dual: pre-activation | gelu
+                        v[r] = (op16)t;
+                        vlo[r] = (op16)gelu_erf(t);
+                    } else {
+                        if (EPI == EPI_GELU) t = gelu_erf(t);
+                        v[r] = (op16)t;
+                        if (SPLIT) vlo[r] = (op16)(t - (float)v[r]);
+                    }
                 }
                 *reinterpret_cast<op16x4 *>(Ct + ml * CT_LD + nl * 2) = v;
                 if (SPLIT) *reinterpret_cast<op16x4 *>(Ct + BM * CT_LD + ml * CT_LD + nl * 2) = vlo;
@@ -196,8 +201,11 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const op16 *__restric
             if (m0 + ml < M) {
                 *reinterpret_cast<uint4 *>(Y + (size_t)(m0 + ml) * ldy + n0 + s * 8) =
                     *reinterpret_cast<const uint4 *>(Ct + ml * CT_LD + s * 16);
-                if (SPLIT)
+                if (SPLIT == 1)
                     *reinterpret_cast<uint4 *>(Y + (size_t)(m0 + ml) * ldy + N + n0 + s * 8) =
+                        *reinterpret_cast<const uint4 *>(Ct + BM * CT_LD + ml * CT_LD + s * 16);
+                if (SPLIT == 2)
+                    *reinterpret_cast<uint4 *>(static_cast<op16 *>(Y2v) + (size_t)(m0 + ml) * ldy + n0 + s * 8) =
                         *reinterpret_cast<const uint4 *>(Ct + BM * CT_LD + ml * CT_LD + s * 16);
             }
         }
@@ -875,7 +883,7 @@ template <int EPI, int ABL6 = 0, int AUX = 0, int SPLIT = 0>
 __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__restrict__ X, const op16 *__restrict__ W,
                                                              const op16 *__restrict__ bias, const float *__restrict__ R,
                                                              void *__restrict__ Yv, int M, int N, int K, int tiles_m, int tiles_n,
-                                                             int stagger_ticks, unsigned long long *__restrict__ stamps, int ld, int ldy)
+                                                             int stagger_ticks, unsigned long long *__restrict__ stamps, int ld, int ldy, void *__restrict__ Y2v)
 {
     // optional device-side span of this launch (100 MHz wall clock; min start / max end over workgroups): HIP events cannot be
     // recorded inside a captured hipGraph on ROCm, so bench.py's roofline leg reads these (cosa_gemm_set_stamp_slot)
@@ -889,7 +897,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
     const int wr = wave >> 2, wc = wave & 3;
     const int frow = lane & 15, fq = lane >> 4;
     const int Kp = K / BK;
-    const int nk = SPLIT ? 3 * Kp + 1 : Kp;
+    const int nk = SPLIT == 1 ? 3 * Kp + 1 : Kp;
     const int ntiles = tiles_m * tiles_n, G = gridDim.x;
     const int cq = ntiles >> 3, cr = ntiles & 7;
     unsigned char *Yb = static_cast<unsigned char *>(Yv);
@@ -907,6 +915,13 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
         return __builtin_amdgcn_make_buffer_rsrc((void *)(X + (size_t)m0_ * ld), 0, rows * ld * 2, FL);
     };
     auto descW = [&](int n0_) { return __builtin_amdgcn_make_buffer_rsrc((void *)(W + (size_t)n0_ * ld), 0, 256 * ld * 2, FL); };
+    // SPLIT == 2 ("dual", EPI_GELU only): the pre-activation goes to Y and gelu(.) to Y2 (same [M, N] geometry): the training forward of
+    // mlp.fc1 keeps the pre-activation for GELU' without a second pass over it (models/vit/vit.py:96-102 and its autograd)
+    auto descY2 = [&](int m0_, int n0_) {
+        int rows = M - m0_;
+        rows = rows > 256 ? 256 : rows;
+        return __builtin_amdgcn_make_buffer_rsrc((void *)(static_cast<unsigned char *>(Y2v) + ((size_t)m0_ * ldy + n0_) * 2), 0, (rows * ldy - n0_) * 2, FL);
+    };
     auto descY = [&](int m0_, int n0_) {
         if (ABL6 == 3) { m0_ = (int)blockIdx.x * 256 % (M - 256); n0_ = 0; }     // timing only: every job of a workgroup rewrites one L2-resident window
         if (ABL6 == 4) return __builtin_amdgcn_make_buffer_rsrc((void *)Yb, 0, 0, FL);   // timing only: every store is out of range (dropped)
@@ -962,6 +977,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
     bool has_next = o + G < ntiles;
     if (has_next) tile_of(o + G, m1, n1);
     __amdgpu_buffer_rsrc_t cX = descX(m0), cW = descW(n0), cY = descY(m0, n0), pY = cY;
+    __amdgpu_buffer_rsrc_t cY2 = SPLIT == 2 ? descY2(m0, n0) : cY, pY2 = cY2;
     __amdgpu_buffer_rsrc_t nX = has_next ? descX(m1) : dead, nW = has_next ? descW(n1) : dead;
     u32x4 cR = {0, 0, 0, 0}, nR = {0, 0, 0, 0};
     if (RES) {
@@ -987,7 +1003,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
         const bool own_ = kt_ < nk;                                                                                    \
         const __amdgpu_buffer_rsrc_t rs_ = ((which) & 1) ? (own_ ? cW : nW) : (own_ ? cX : nX);                        \
         const int t_ = own_ ? kt_ : kt_ - nk;                                                                          \
-        const int so_ = (SPLIT ? (((which) & 1) ? split_tile_w(t_, Kp) : split_tile_x(t_, Kp)) : t_) * 128;            \
+        const int so_ = (SPLIT == 1 ? (((which) & 1) ? split_tile_w(t_, Kp) : split_tile_x(t_, Kp)) : t_) * 128;            \
         unsigned char *dst_ = smem + (bsel) * V5_BUF + (which) * V5_HALF + (2 * wave) * 1024;                          \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_, (lds_void *)dst_, 16, vo[(which) >> 1][0], so_, 0, 0);           \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_, (lds_void *)(dst_ + 1024), 16, vo[(which) >> 1][1], so_, 0, 0);  \
@@ -1056,6 +1072,14 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
     } else                                                                                                          \
     _Pragma("unroll") for (int jj = 0; jj < 2; jj++) _Pragma("unroll") for (int pr = 0; pr < 2; pr++) {             \
         f32x4 v0_ = acc[(qa) * 4 + 2 * pr][(qb) * 2 + jj], v1_ = acc[(qa) * 4 + 2 * pr + 1][(qb) * 2 + jj];        \
+        if (SPLIT == 2) {     /* dual: the raw tile first, to Y */                                                   \
+            const op16x2 r0_ = {(op16)v0_[0], (op16)v0_[1]}, r1_ = {(op16)v0_[2], (op16)v0_[3]};                    \
+            const op16x2 r2_ = {(op16)v1_[0], (op16)v1_[1]}, r3_ = {(op16)v1_[2], (op16)v1_[3]};                    \
+            const auto u0_ = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, r0_), __builtin_bit_cast(unsigned, r2_), false, false); \
+            const auto u1_ = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, r1_), __builtin_bit_cast(unsigned, r3_), false, false); \
+            const u32x4 raw_ = {u0_[0], u1_[0], u0_[1], u1_[1]};                                                    \
+            __builtin_amdgcn_raw_buffer_store_b128(raw_, rsY, voY[(qb) * 2 + jj] + ((qa) * 128 + pr * 32) * 2, 0, AUX); \
+        }                                                                                                           \
         if (EPI == EPI_GELU) {                                                                                      \
             _Pragma("unroll") for (int r = 0; r < 4; r++) {                                                         \
                 v0_[r] = gelu_erf(v0_[r]);                                                                          \
@@ -1067,9 +1091,10 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
         const auto s0_ = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, p0_), __builtin_bit_cast(unsigned, p2_), false, false); \
         const auto s1_ = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, p1_), __builtin_bit_cast(unsigned, p3_), false, false); \
         const u32x4 out_ = {s0_[0], s1_[0], s0_[1], s1_[1]};                                                        \
-        if (ABL6 == 0 || ABL6 == 3 || ABL6 == 4) __builtin_amdgcn_raw_buffer_store_b128(out_, rsY, voY[(qb) * 2 + jj] + ((qa) * 128 + pr * 32) * 2, 0, AUX); \
+        if (SPLIT == 2) __builtin_amdgcn_raw_buffer_store_b128(out_, (&rsY == &pY) ? pY2 : cY2, voY[(qb) * 2 + jj] + ((qa) * 128 + pr * 32) * 2, 0, AUX); \
+        else if (ABL6 == 0 || ABL6 == 3 || ABL6 == 4) __builtin_amdgcn_raw_buffer_store_b128(out_, rsY, voY[(qb) * 2 + jj] + ((qa) * 128 + pr * 32) * 2, 0, AUX); \
         else asm volatile("" ::"v"(out_));                                                                          \
-        if (SPLIT) {          /* the lo halves: what the 16-bit rounding above dropped, at column N + n */              \
+        if (SPLIT == 1) {          /* the lo halves: what the 16-bit rounding above dropped, at column N + n */              \
             const op16x2 q0_ = {(op16)(v0_[0] - (float)p0_[0]), (op16)(v0_[1] - (float)p0_[1])};                    \
             const op16x2 q1_ = {(op16)(v0_[2] - (float)p1_[0]), (op16)(v0_[3] - (float)p1_[1])};                    \
             const op16x2 q2_ = {(op16)(v1_[0] - (float)p2_[0]), (op16)(v1_[1] - (float)p2_[1])};                    \
@@ -1179,6 +1204,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
         if (!has_next) break;
         // next job becomes the running one
         pY = cY;
+        pY2 = cY2;
         have_prev = true;
         o += G;
         m0 = m1;
@@ -1186,6 +1212,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
         cX = nX;
         cW = nW;
         cY = descY(m0, n0);
+        if (SPLIT == 2) cY2 = descY2(m0, n0);
         cR = nR;
         has_next = o + G < ntiles;
         if (has_next) {
@@ -1641,7 +1668,7 @@ static int launch_v5(const op16 *x, const op16 *w, const op16 *b, const float *r
 
 template <int EPI, int ABL6 = 0, int AUX = 0, int SPLIT = 0>
 static int launch_v6(const op16 *x, const op16 *w, const op16 *b, const float *residual, void *Y, int M, int N, int K, hipStream_t st,
-                     int ld = 0, int ldy = 0)
+                     int ld = 0, int ldy = 0, void *Y2 = nullptr)
 {
     static bool attr_done = false;
     if (!attr_done) {
@@ -1655,7 +1682,7 @@ static int launch_v6(const op16 *x, const op16 *w, const op16 *b, const float *r
     static const char *env = getenv("COSA_GEMM_STAGGER");
     const int stagger = env ? atoi(env) : 0;               // start stagger (see the kernel): measured to make no difference, off
     hipLaunchKernelGGL((gemm_bf16_v6_kernel<EPI, ABL6, AUX, SPLIT>), dim3(grid), dim3(512), kLdsBytesV5, st, x, w, b, residual, Y, M, N, K, tiles_m, tiles_n, stagger,
-                       g_gemm_stamp_slot, ld ? ld : K, ldy ? ldy : N);
+                       g_gemm_stamp_slot, ld ? ld : K, ldy ? ldy : N, Y2);
     g_gemm_stamp_slot = nullptr;                            // one-shot
     COSA_LAUNCH_CHECK();
     return COSA_OK;
@@ -1768,13 +1795,13 @@ extern "C" int cosa_gemm_bf16(const void *X, const void *W, const void *bias, co
     }
     switch (epilogue) {
     case EPI_BIAS:
-        hipLaunchKernelGGL(gemm_bf16_kernel<EPI_BIAS>, grid, blk, kLdsBytes, st, x, w, b, residual, Y, M, N, K, tiles_m, tiles_n, K, N);
+        hipLaunchKernelGGL(gemm_bf16_kernel<EPI_BIAS>, grid, blk, kLdsBytes, st, x, w, b, residual, Y, M, N, K, tiles_m, tiles_n, K, N, nullptr);
         break;
     case EPI_GELU:
-        hipLaunchKernelGGL(gemm_bf16_kernel<EPI_GELU>, grid, blk, kLdsBytes, st, x, w, b, residual, Y, M, N, K, tiles_m, tiles_n, K, N);
+        hipLaunchKernelGGL(gemm_bf16_kernel<EPI_GELU>, grid, blk, kLdsBytes, st, x, w, b, residual, Y, M, N, K, tiles_m, tiles_n, K, N, nullptr);
         break;
     default:
-        hipLaunchKernelGGL(gemm_bf16_kernel<EPI_RESIDUAL>, grid, blk, kLdsBytes, st, x, w, b, residual, Y, M, N, K, tiles_m, tiles_n, K, N);
+        hipLaunchKernelGGL(gemm_bf16_kernel<EPI_RESIDUAL>, grid, blk, kLdsBytes, st, x, w, b, residual, Y, M, N, K, tiles_m, tiles_n, K, N, nullptr);
         break;
     }
     COSA_LAUNCH_CHECK();
@@ -1814,15 +1841,41 @@ extern "C" int cosa_gemm_bf16x3(const void *Xs, const void *Ws, const void *zero
     const dim3 grid(tiles_m * tiles_n), blk(256);
     switch (epilogue) {
     case EPI_BIAS:
-        hipLaunchKernelGGL((gemm_bf16_kernel<EPI_BIAS, 1>), grid, blk, kLdsSplit, st, x, w, b, residual, Y, M, N, K, tiles_m, tiles_n, ld, ldy);
+        hipLaunchKernelGGL((gemm_bf16_kernel<EPI_BIAS, 1>), grid, blk, kLdsSplit, st, x, w, b, residual, Y, M, N, K, tiles_m, tiles_n, ld, ldy, nullptr);
         break;
     case EPI_GELU:
-        hipLaunchKernelGGL((gemm_bf16_kernel<EPI_GELU, 1>), grid, blk, kLdsSplit, st, x, w, b, residual, Y, M, N, K, tiles_m, tiles_n, ld, ldy);
+        hipLaunchKernelGGL((gemm_bf16_kernel<EPI_GELU, 1>), grid, blk, kLdsSplit, st, x, w, b, residual, Y, M, N, K, tiles_m, tiles_n, ld, ldy, nullptr);
         break;
     default:
-        hipLaunchKernelGGL((gemm_bf16_kernel<EPI_RESIDUAL, 1>), grid, blk, kLdsSplit, st, x, w, b, residual, Y, M, N, K, tiles_m, tiles_n, ld, ldy);
+        hipLaunchKernelGGL((gemm_bf16_kernel<EPI_RESIDUAL, 1>), grid, blk, kLdsSplit, st, x, w, b, residual, Y, M, N, K, tiles_m, tiles_n, ld, ldy, nullptr);
         break;
     }
+    COSA_LAUNCH_CHECK();
+    return COSA_OK;
+}
+#endif
+
+#if !COSA_OP_F16
+// training forward of mlp.fc1 (models/vit/vit.py:96-102): H = X W^T + b (bf16, kept for GELU' in the backward) and A = gelu_erf(H) (bf16)
+// from ONE pass over the accumulators
+extern "C" int cosa_gemm_bf16_dual_gelu(const void *X, const void *W, const void *bias, void *H, void *A, int M, int N, int K, void *stream)
+{
+    struct ClearSlot { ~ClearSlot() { g_gemm_stamp_slot = nullptr; } } clear_slot_;
+    COSA_REQUIRE(X && W && bias && H && A && H != A, "cosa_gemm_bf16_dual_gelu: null pointer / aliased outputs");
+    COSA_REQUIRE(M > 0 && N > 0 && K > 0 && N % BN == 0 && K % BK == 0, "cosa_gemm_bf16_dual_gelu: N %% 128 and K %% 64 must be 0 (got N=%d K=%d)", N, K);
+    hipStream_t st = as_stream(stream);
+    const op16 *x = static_cast<const op16 *>(X), *w = static_cast<const op16 *>(W), *b = static_cast<const op16 *>(bias);
+    if (N % 256 == 0 && M >= 4096 && K >= 128 && (size_t)(M + 256) * K * 2 < 0x7fffffffull && (size_t)N * K * 2 < 0x7fffffffull)
+        return launch_v6<EPI_GELU, 0, 0, 2>(x, w, b, nullptr, H, M, N, K, st, K, N, A);
+    constexpr int kLdsDual = 2 * BM * CT_LD > (int)kLdsBytes ? 2 * BM * CT_LD : (int)kLdsBytes;
+    static bool attr_done = false;
+    if (!attr_done) {
+        COSA_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_bf16_kernel<EPI_GELU, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsDual));
+        attr_done = true;
+    }
+    const int tiles_m = (M + BM - 1) / BM, tiles_n = N / BN;
+    hipLaunchKernelGGL((gemm_bf16_kernel<EPI_GELU, 2>), dim3(tiles_m * tiles_n), dim3(256), kLdsDual, st, x, w, b, static_cast<const float *>(nullptr), H,
+                       M, N, K, tiles_m, tiles_n, K, N, A);
     COSA_LAUNCH_CHECK();
     return COSA_OK;
 }

@@ -212,6 +212,86 @@ __global__ __launch_bounds__(256) void par_affinity_fast_kernel(const float *__r
         }
 }
 
+// IEEE-754 binary32 division with the divisor's part hoisted.  `x / d` on gfx950 is lowered to: (scale), r0 = rcp(d), e = fma(-d, r0, 1),
+// r = fma(e, r0, r0), q0 = x * r, e1 = fma(-d, q0, x), q1 = fma(e1, r, q0), e2 = fma(-d, q1, x), q = fma(e2, r, q1), (fixup): the
+// correctly rounded quotient.  The scale / fixup steps only act on operands near the ends of the exponent range; here 0 <= x <= 1e9
+// and 1e-8 <= d <= 1e9, so they are identities and the SAME sequence with r computed once per divisor gives the same bits for a
+// third of the instructions (the affinity kernel divides 48 values by each sigma, by 0.3 and by the softmax sum: 390 divisions / pixel).
+struct ExactRcp { float d, r; };
+__device__ __forceinline__ ExactRcp exact_rcp(float d)
+{
+    const float r0 = __builtin_amdgcn_rcpf(d);
+    const float e = __builtin_fmaf(-d, r0, 1.0f);
+    return ExactRcp{d, __builtin_fmaf(e, r0, r0)};
+}
+__device__ __forceinline__ float exact_div(float x, const ExactRcp &k)
+{
+    const float q0 = x * k.r;
+    const float e1 = __builtin_fmaf(-k.d, q0, x);
+    const float q1 = __builtin_fmaf(e1, k.r, q0);
+    const float e2 = __builtin_fmaf(-k.d, q1, x);
+    return __builtin_fmaf(e2, k.r, q1);
+}
+
+// affinity, v2: one channel at a time (48 taps + 48 logit accumulators live: ~130 VGPRs -> 3-4 waves per SIMD instead of the 304 VGPRs /
+// ONE wave per SIMD of par_affinity_fast_kernel) and the hoisted exact division above.  Same arithmetic, same order as the spec.
+template <int ND>
+__global__ __launch_bounds__(256, 3) void par_affinity_v2_kernel(const float *__restrict__ imgs, float *__restrict__ aff,
+                                                             int h, int w, ParPlan plan)
+{
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    const int hw = h * w;
+    if (pix >= hw) return;
+    const int b = blockIdx.y;
+    const int y = pix / w, x = pix - y * w;
+    constexpr int NN = ND * 8;
+    const float *img = imgs + (size_t)b * 3 * hw;
+    const ExactRcp k03 = exact_rcp(0.3f), k3 = exact_rcp(3.0f);
+    float lg[NN];
+#pragma unroll
+    for (int n = 0; n < NN; n++) lg[n] = 0.0f;
+#pragma unroll 1
+    for (int c = 0; c < 3; c++) {
+        const float *pl = img + (size_t)c * hw;
+        const float ctr = pl[pix];
+        float v[NN];
+#pragma unroll
+        for (int di = 0; di < ND; di++) {
+            const int d = plan.dil[di];
+            const int ym = clampi(y - d, 0, h - 1) * w, y0 = y * w, yp = clampi(y + d, 0, h - 1) * w;
+            const int xm = clampi(x - d, 0, w - 1), xp = clampi(x + d, 0, w - 1);
+            v[di * 8 + 0] = pl[ym + xm]; v[di * 8 + 1] = pl[ym + x]; v[di * 8 + 2] = pl[ym + xp];
+            v[di * 8 + 3] = pl[y0 + xm]; v[di * 8 + 4] = pl[y0 + xp];
+            v[di * 8 + 5] = pl[yp + xm]; v[di * 8 + 6] = pl[yp + x]; v[di * 8 + 7] = pl[yp + xp];
+        }
+        float sum = 0.0f;
+#pragma unroll
+        for (int n = 0; n < NN; n++) sum = sum + v[n];
+        const float mean = sum / (float)NN;
+        float var = 0.0f;
+#pragma unroll
+        for (int n = 0; n < NN; n++) { const float dl = v[n] - mean; var = var + dl * dl; }
+        var = var / (float)(NN - 1);
+        const ExactRcp ksd = exact_rcp(__builtin_sqrtf(var) + 1e-8f);
+#pragma unroll
+        for (int n = 0; n < NN; n++) {
+            float q = exact_div(__builtin_fabsf(v[n] - ctr), ksd);
+            q = exact_div(q, k03);
+            lg[n] = lg[n] + (-(q * q));                      // acc over c = 0,1,2 starting from 0.0f, as the spec
+        }
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int n = 0; n < NN; n++) { lg[n] = -exact_div(-lg[n], k3); mx = lg[n] > mx ? lg[n] : mx; }     // lg <= 0: divide the magnitude
+    float es = 0.0f;
+#pragma unroll
+    for (int n = 0; n < NN; n++) { lg[n] = cosa_expf(lg[n] - mx); es = es + lg[n]; }
+    const ExactRcp kes = exact_rcp(es);                      // 1 <= es <= 48
+    float *out = aff + (size_t)b * NN * hw + pix;
+#pragma unroll
+    for (int n = 0; n < NN; n++) out[(size_t)n * hw] = exact_div(lg[n], kes) + 0.01f * plan.posw[n];
+}
+
 // one propagation step; each thread owns one pixel of up to CG live planes.
 template <int CG>
 __global__ __launch_bounds__(256) void par_step_kernel(const float *__restrict__ aff, const float *__restrict__ src,
@@ -473,7 +553,8 @@ __global__ __launch_bounds__(512) void par_step_tiled_kernel(const float *__rest
                                                             int halves, int half_planes, size_t img_stride, int h, int w,
                                                             int B, int tiles_x, int tiles_y, int pin)
 {
-    __shared__ float tile[2][kLH * kLW];
+    constexpr int NE = (kLH * kLW + 511) / 512;        // staged elements per thread (5)
+    __shared__ float tile[2][NE * 512];                // kLH x kLW halo tile, padded so that every thread stages NE elements unconditionally
     constexpr int ND = DIL::n, NN = ND * 8;
     const int id = blockIdx.x, per_img = tiles_x * tiles_y;
     int b, rem;
@@ -515,24 +596,29 @@ __global__ __launch_bounds__(512) void par_step_tiled_kernel(const float *__rest
     }
     static_assert(DIL::d[ND - 1] > kHalo && DIL::d[ND - 2] <= kHalo, "exactly the last dilation is gathered, the others are staged");
     // staging map of this thread: elements e = tid, tid + 512, ... of the (kLH x kLW) halo tile -> clamped image offsets
-    constexpr int NE = (kLH * kLW + 511) / 512;        // 5
     int goff[NE];
 #pragma unroll
     for (int i = 0; i < NE; i++) {
-        const int e = tid + 512 * i;
+        const int e = tid + 512 * i;                   // (elements past the tile land in the padding: any valid address will do)
         const int r = e / kLW, c = e - r * kLW;
-        goff[i] = e < kLH * kLW ? clampi(y0 - kHalo + r, 0, h - 1) * w + clampi(x0 - kHalo + c, 0, w - 1) : -1;
+        goff[i] = clampi(y0 - kHalo + r, 0, h - 1) * w + clampi(x0 - kHalo + c, 0, w - 1);
     }
     auto plane_off = [&](int j) {
         const int half = j / K;
         return (size_t)b * img_stride + (size_t)(half * half_planes + (j - half * K)) * hw;
     };
-    auto stage = [&](int buf, const float *pl) {
+    // staging in two halves so that all NE loads of a thread are in flight together: fetch -> registers, (compute), registers -> LDS
+    float sv[NE];
+    auto fetch = [&](const float *pl) {
 #pragma unroll
-        for (int i = 0; i < NE; i++)
-            if (goff[i] >= 0) tile[buf][tid + 512 * i] = pl[goff[i]];
+        for (int i = 0; i < NE; i++) sv[i] = pl[goff[i]];
     };
-    stage(0, src + plane_off(0));
+    auto commit = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NE; i++) tile[buf][tid + 512 * i] = sv[i];
+    };
+    fetch(src + plane_off(0));
+    commit(0);
     __syncthreads();
     const float *ctr = &tile[0][(ty + kHalo) * kLW + tx + kHalo];
     for (int j = 0; j < live; j++) {
@@ -540,8 +626,9 @@ __global__ __launch_bounds__(512) void par_step_tiled_kernel(const float *__rest
         float far[8];
 #pragma unroll
         for (int t = 0; t < 8; t++) far[t] = pl[ofar[t]];                       // the gathers go first: their latency hides under the LDS taps
-        if (j + 1 < live) stage((j + 1) & 1, src + plane_off(j + 1));
-        const float *c = ctr + (j & 1) * (kLH * kLW);
+        const bool more = j + 1 < live;                                        // (wave-uniform)
+        if (more) fetch(src + plane_off(j + 1));                               // next plane's tile: in flight during this plane's taps
+        const float *c = ctr + (j & 1) * (NE * 512);
         float acc = 0.0f;
 #pragma unroll
         for (int di = 0; di < ND - 1; di++) {
@@ -557,7 +644,152 @@ __global__ __launch_bounds__(512) void par_step_tiled_kernel(const float *__rest
 #pragma unroll
         for (int t = 0; t < 8; t++) acc = acc + far[t] * a[(ND - 1) * 8 + t];
         if (valid) dst[plane_off(j) + pix] = acc;
+        if (more) commit((j + 1) & 1);                                         // the other buffer: nobody reads it during this iteration
         __syncthreads();                                                       // next tile staged, this one no longer read
+    }
+}
+
+
+// v5 propagation step: TWO horizontally adjacent pixels per thread, the whole 24-pixel halo in LDS.
+//   * 512-thread workgroup (8 waves, one workgroup per CU: the 96 affinities of a pixel pair stay in registers for the whole step, so a
+//     thread may use up to 256 VGPRs) = 16 x 64 pixel tile of one image, all its live planes;
+//   * per plane the (16 + 48) x (64 + 48) replicate-clamped halo tile (28 KB) arrives by LDS-DMA (global_load_lds_dword with per-lane
+//     clamped source addresses: no staging registers) into a ring of three buffers, two planes ahead of the one being consumed;
+//   * every tap of both pixels is ONE ds_read_b64 (even column offsets; 8-byte aligned since x, the halo and the row stride are even),
+//     issued as explicit instructions -- left to itself the compiler pairs them into ds_read2_b64, which moves the same bytes at half
+//     the rate (MI355X_MICROARCH.md, LDS table) -- one dilation (8 taps) ahead of the packed fp32 multiplies / adds that consume them;
+//   * no global gathers at all: against the one-pixel-per-thread gather kernel a pixel and plane costs 7 staged elements, 24.5 LDS
+//     read instructions and 48 packed VALU instructions instead of 48 L1 requests and 96 VALU instructions.
+// MEASURED SLOWER than the v4 kernel above (71 vs 58 us per step at b = 16, 224^2, 12 planes per image; kept as the A/B
+// alternative COSA_PAR_TILED=3): 224 VGPRs allow one 8-wave workgroup per CU, so a workgroup's affinity-load phase (196 KB at the
+// per-CU share of HBM) and its 14 LDS-DMA issues per thread and plane (~100 cycles each) are not covered by anybody else's arithmetic.
+// (Non-temporal policy on the affinity stream / outputs, tried on both tiled kernels: 5-10 % slower.  A third variant, two PLANES per
+// pass packed in ds_read_b64 / v_pk_* with one pixel per thread, needs ~135 VGPRs: at the 128 that two workgroups per CU allow it spills
+// the affinities and runs 5x slower.)  rocprofv3 PMC on v4 (profiles/r02_par_v4_pmc.txt): 196 MB fetched + 46 MB written per launch =
+// the compulsory bytes of a step (154 MB of affinities re-read + the planes), i.e. 4.2 TB/s at 58 us: the per-step kernels are within
+// 1.5x of what HBM allows as long as the affinity tensor is re-read every step.
+// Same operation order per pixel (acc = acc + m * a, neighbour index ascending; multiply and add stay separate roundings): bit-identical.
+constexpr int k5TH = 16, k5TW = 64, k5Halo = 24, k5T = 512, k5Ring = 3;
+constexpr int k5LW = k5TW + 2 * k5Halo, k5LH = k5TH + 2 * k5Halo;     // 112 x 64
+constexpr int k5NE = (k5LH * k5LW + k5T - 1) / k5T;                     // 14 staged elements per thread
+constexpr int k5Buf = k5NE * k5T * 4;                                   // bytes per ring slot
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) void lds_void_p;
+typedef const __attribute__((address_space(1))) void gbl_void_p;
+
+template <typename DIL>
+__global__ __launch_bounds__(k5T) void par_step_pair_kernel(const float *__restrict__ aff, const float *__restrict__ src,
+                                                           float *__restrict__ dst, const int *__restrict__ kcount, int Kfull,
+                                                           int halves, int half_planes, size_t img_stride, int h, int w,
+                                                           int B, int tiles_x, int tiles_y, int pin)
+{
+    extern __shared__ __attribute__((aligned(16))) float tile5[];        // [k5Ring][k5NE * k5T]
+    constexpr int ND = DIL::n, NN = ND * 8;
+    static_assert(DIL::d[ND - 1] <= k5Halo, "every dilation must fit the halo");
+    const int id = blockIdx.x, per_img = tiles_x * tiles_y;
+    int b, rem;
+    if (pin) {
+        const int xcd = id & 7, j = id >> 3, slot = j / per_img;
+        rem = j - slot * per_img;
+        b = slot * 8 + xcd;
+    } else {
+        b = id / per_img;
+        rem = id - b * per_img;
+    }
+    if (b >= B) return;
+    const int tyi = rem / tiles_x, txi = rem - tyi * tiles_x;
+    const int y0 = tyi * k5TH, x0 = txi * k5TW;
+    const int tid = threadIdx.x, ty = tid >> 5, tp = tid & 31;           // row, pixel pair
+    const int y = y0 + ty, x = x0 + 2 * tp;
+    const bool valid = y < h && x < w;                                    // (w is even: both pixels of a pair are in or out together)
+    const int hw = h * w;
+    const int K = kcount ? kcount[b] : Kfull;
+    const int live = K * halves;
+    if (live <= 0) return;
+    const int pix = valid ? y * w + x : 0;
+
+    f32x2 a[NN];
+    {
+        const float *ab = aff + (size_t)b * NN * hw + pix;
+#pragma unroll
+        for (int n = 0; n < NN; n++) a[n] = *reinterpret_cast<const f32x2 *>(ab + (size_t)n * hw);
+    }
+    int goff[k5NE];
+#pragma unroll
+    for (int i = 0; i < k5NE; i++) {
+        const int e = tid + k5T * i;
+        const int r = e / k5LW, c = e - r * k5LW;
+        goff[i] = clampi(y0 - k5Halo + r, 0, h - 1) * w + clampi(x0 - k5Halo + c, 0, w - 1);
+    }
+    auto plane_off = [&](int j) {
+        const int half = j / K;
+        return (size_t)b * img_stride + (size_t)(half * half_planes + (j - half * K)) * hw;
+    };
+    const int wave_lds = (tid & ~63) * 4;              // LDS-DMA destination: wave-uniform base, the lane adds 4 * lane itself
+    auto stage = [&](int slot, const float *pl) {
+#pragma unroll
+        for (int i = 0; i < k5NE; i++)
+            __builtin_amdgcn_global_load_lds((gbl_void_p *)(pl + goff[i]),
+                                             (lds_void_p *)((unsigned char *)tile5 + slot * k5Buf + i * (k5T * 4) + wave_lds), 4, 0, 0);
+    };
+    stage(0, src + plane_off(0));
+    if (live > 1) stage(1, src + plane_off(1));
+    // LDS byte address of the top-left corner of this thread's 49 x 50 tap window: every tap offset is a non-negative immediate
+    const unsigned win0 = (unsigned)(size_t)(lds_void_p *)tile5 + (unsigned)((ty * k5LW + 2 * tp) * 4);
+    int slot = 0;
+    for (int j = 0; j < live; j++) {
+        // plane j's tile: everything this thread staged except the newest plane's k5NE DMA pieces (stores retire in order before them)
+        if (j + 1 < live) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(k5NE) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                                     // ... and everybody else's; slot (j + 2) % 3 is free again
+        if (j + 2 < live) stage(slot == 0 ? 2 : slot - 1, src + plane_off(j + 2));     // (slot + 2) % 3
+        const unsigned win = win0 + (unsigned)(slot * k5Buf);
+        f32x2 acc = {0.0f, 0.0f};
+        f32x2 m[2][8];
+        float ol[2][8], oh[2][8];            // odd column offsets: two 4-byte reads, joined only AFTER the wait (asm results are not tracked)
+#define COSA_PAR_TAPS(di, g)                                                                                               \
+        _Pragma("unroll") for (int t = 0; t < 8; t++) {                                                                    \
+            const int tt = t < 4 ? t : t + 1;                                                                              \
+            const int dy = tt / 3 - 1, dx = tt % 3 - 1;                                                                    \
+            const int off = ((k5Halo + dy * DIL::d[di]) * k5LW + k5Halo + dx * DIL::d[di]) * 4;                            \
+            if ((dx * DIL::d[di]) % 2 == 0) {                                                                              \
+                asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(m[g][t]) : "v"(win), "i"(off));                         \
+                ol[g][t] = oh[g][t] = 0.0f;                                                                                \
+            } else {                                                                                                       \
+                asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(ol[g][t]) : "v"(win), "i"(off));                        \
+                asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(oh[g][t]) : "v"(win), "i"(off + 4));                    \
+                m[g][t] = (f32x2){0.0f, 0.0f};                                                                             \
+            }                                                                                                              \
+        }
+#define COSA_PAR_WAIT(cnt, g)                                                                                              \
+        asm volatile("s_waitcnt lgkmcnt(" #cnt ")"                                                                         \
+                     : "+v"(m[g][0]), "+v"(m[g][1]), "+v"(m[g][2]), "+v"(m[g][3]), "+v"(m[g][4]), "+v"(m[g][5]), "+v"(m[g][6]), "+v"(m[g][7]),  \
+                       "+v"(ol[g][0]), "+v"(ol[g][2]), "+v"(ol[g][3]), "+v"(ol[g][4]), "+v"(ol[g][5]), "+v"(ol[g][7]),      \
+                       "+v"(oh[g][0]), "+v"(oh[g][2]), "+v"(oh[g][3]), "+v"(oh[g][4]), "+v"(oh[g][5]), "+v"(oh[g][7]))
+        COSA_PAR_TAPS(0, 0);
+#pragma unroll
+        for (int di = 0; di < ND; di++) {
+            const int g = di & 1;
+            if (di + 1 < ND) {
+                COSA_PAR_TAPS(di + 1, (di + 1) & 1);
+                // this dilation's taps (issued before the next dilation's 8 or 14 reads) have arrived; the newer ones stay in flight
+                if (DIL::d[di + 1] % 2) { COSA_PAR_WAIT(14, g); } else { COSA_PAR_WAIT(8, g); }
+            } else {
+                COSA_PAR_WAIT(0, g);
+            }
+#pragma unroll
+            for (int t = 0; t < 8; t++) {
+                const int tt = t < 4 ? t : t + 1;
+                const int dx = tt % 3 - 1;
+                f32x2 mv = m[g][t];
+                if ((dx * DIL::d[di]) % 2 != 0) { mv[0] = ol[g][t]; mv[1] = oh[g][t]; }
+                acc = acc + mv * a[di * 8 + t];
+            }
+        }
+#undef COSA_PAR_WAIT
+#undef COSA_PAR_TAPS
+        if (valid) *reinterpret_cast<f32x2 *>(dst + plane_off(j) + pix) = acc;
+        slot = slot == 2 ? 0 : slot + 1;
     }
 }
 
@@ -612,7 +844,9 @@ int par_make_plan(const int *dilations, int n_dil, ParPlan *plan)
 int par_launch_affinity(const float *imgs, float *aff, int B, int h, int w, const ParPlan &plan, hipStream_t st)
 {
     dim3 grid((h * w + 255) / 256, B);
-    if (plan.n_dil == 6) hipLaunchKernelGGL(par_affinity_fast_kernel<6>, grid, dim3(256), 0, st, imgs, aff, h, w, plan);
+    static const int v2 = [] { const char *e = getenv("COSA_PAR_AFF_V2"); return e ? atoi(e) : 1; }();
+    if (plan.n_dil == 6 && v2) hipLaunchKernelGGL(par_affinity_v2_kernel<6>, grid, dim3(256), 0, st, imgs, aff, h, w, plan);
+    else if (plan.n_dil == 6) hipLaunchKernelGGL(par_affinity_fast_kernel<6>, grid, dim3(256), 0, st, imgs, aff, h, w, plan);
     else if (plan.n_dil == 3) hipLaunchKernelGGL(par_affinity_fast_kernel<3>, grid, dim3(256), 0, st, imgs, aff, h, w, plan);
     else hipLaunchKernelGGL(par_affinity_kernel, grid, dim3(256), 0, st, imgs, aff, h, w, plan);
     COSA_LAUNCH_CHECK();
@@ -628,9 +862,25 @@ int par_launch_step(const float *aff, const float *src, float *dst, int B, int K
     // default: the one-pixel, all-planes kernel (1.50 ms per shared pass against 2.19 with the 4-pixel, 4-plane kernel below, which
     // COSA_PAR_SCALAR=0 brings back for A/B runs)
     static const int scalar = [] { const char *e = getenv("COSA_PAR_SCALAR"); return e ? atoi(e) : 1; }();
-    static const int tiled = [] { const char *e = getenv("COSA_PAR_TILED"); return e ? atoi(e) : 1; }();
+    static const int tiled = [] { const char *e = getenv("COSA_PAR_TILED"); return e ? atoi(e) : 1; }();     // 1: LDS-tiled v4 (default), 3: pixel-pair kernel (A/B), 0: gathers
     bool named = plan.n_dil == Dil6::n;
     for (int i = 0; named && i < Dil6::n; i++) named = plan.dil[i] == Dil6::d[i];
+    if (tiled == 3 && named && (w & 1) == 0 && (size_t)Kmax * h * w < (1ull << 31)) {     // pixel-pair kernel (A/B alternative, slower)
+        constexpr int kLds5 = k5Ring * k5Buf;
+        static bool attr_done = false;
+        if (!attr_done) {
+            COSA_HIP_CHECK(hipFuncSetAttribute((const void *)par_step_pair_kernel<Dil6>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds5));
+            attr_done = true;
+        }
+        const int tiles_x = (w + k5TW - 1) / k5TW, tiles_y = (h + k5TH - 1) / k5TH;
+        const int pin = (B % 8 == 0 || B >= 24) ? 1 : 0;
+        const long long nblk = (pin ? 8ll * ((B + 7) / 8) : (long long)B) * tiles_x * tiles_y;
+        COSA_REQUIRE(nblk < 0x7fffffffll, "PAR: grid too large");
+        hipLaunchKernelGGL(par_step_pair_kernel<Dil6>, dim3((unsigned)nblk), dim3(k5T), kLds5, st, aff, src, dst, kcount, Kmax, halves,
+                           half_planes, plane_stride, h, w, B, tiles_x, tiles_y, pin);
+        COSA_LAUNCH_CHECK();
+        return COSA_OK;
+    }
     if (tiled && named && (size_t)Kmax * h * w < (1ull << 31)) {              // LDS-tiled step for the named configuration
         const int tiles_x = (w + kTW - 1) / kTW, tiles_y = (h + kTH - 1) / kTH;
         const int pin = (B % 8 == 0 || B >= 24) ? 1 : 0;

@@ -181,62 +181,127 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float *__restr
 }
 
 // ---- narrow heads: Y[M, N<=32] (fp32) = X[M, K] W[N, K]^T -------------------------------------------------------------------
-// The CAM / auxiliary-CAM heads (1x1 conv 768 -> 20|80, models/__init__.py:190-192) and LargeFOV's conv8 (512 -> 21|81) are
-// "skinny" GEMMs: a library GEMM pads N to its tile and picks tile / split by the row count, so results move in their last bits
-// with the batch.  Here one wave owns a row at a time: lane l multiplies its 4-element slices of the row with the matching
-// slices of all N weight rows (W staged in LDS as fp32), then the N partial sums are folded over the wave.  HBM-bound on X,
-// fixed reduction order per row -> bit-identical whatever else is in the batch.
+// The CAM / auxiliary-CAM heads (1x1 conv 768 -> 20|80, models/__init__.py:190-192), LargeFOV's conv8 (512 -> 21|81) and the
+// classification heads are "skinny" GEMMs: a library GEMM pads N to its tile and picks tile / split by the row count, so results
+// move in their last bits with the batch.  Here a wave owns 16 token rows at a time and runs them through the EXACT-fp32 matrix
+// instruction v_mfma_f32_16x16x4_f32 (bit for bit an fmaf chain in k order): X is read once, as whole 128-B lines -- lane (row r, q)
+// loads the 16 consecutive elements X[r][64j + 16q ..] -- and MFMA step i of a 64-wide k block contracts the elements 16q + i of the
+// four lane quarters; the weights sit in LDS as fp32 with a row stride of K + 1 floats, which makes the matching B-operand reads
+// (lane (col, q) -> W[col][64j + 16q + i]) conflict-free.  HBM-bound on X; the reduction order of a row is fixed, so the result of a
+// token does not depend on the batch around it.  16-bit inputs (bf16 / fp16) are widened on load.
+typedef float f32x4h __attribute__((ext_vector_type(4)));
+
 template <typename T>
+__device__ __forceinline__ void head_load16(const T *p, float (&v)[16])
+{
+    if constexpr (sizeof(T) == 4) {
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const float4 f = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(p) + 4 * c);
+            v[4 * c] = f.x; v[4 * c + 1] = f.y; v[4 * c + 2] = f.z; v[4 * c + 3] = f.w;
+        }
+    } else {
+        typedef T t8 __attribute__((ext_vector_type(8)));
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            const t8 f = *reinterpret_cast<const t8 *>(p + 8 * c);
+#pragma unroll
+            for (int e = 0; e < 8; e++) v[8 * c + e] = (float)f[e];
+        }
+    }
+}
+
+template <typename T, int NB>       // NB: 16-column blocks of the output (1 or 2)
 __global__ __launch_bounds__(256) void head_gemm_kernel(const T *__restrict__ X, const T *__restrict__ W, float *__restrict__ Y,
                                                        int M, int N, int K, int rows_per_img, long long img_stride, int ldx,
                                                        int round_bf16, int ldy, int col0)
 {
-    extern __shared__ __attribute__((aligned(16))) float wl[];            // [N][K] fp32
+    extern __shared__ __attribute__((aligned(16))) float wl[];            // [16 * NB][K + 1] fp32, rows >= N are zero
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int e = tid; e < N * K; e += 256) wl[e] = (float)W[e];
+    const int S = K + 1;
+    for (int e = tid; e < 16 * NB * K; e += 256) {
+        const int n = e / K, k = e - n * K;
+        wl[n * S + k] = n < N ? (float)W[(size_t)n * K + k] : 0.f;
+    }
     __syncthreads();
-    const int waves = gridDim.x * 4;
-    const int chunks = K >> 8;                                            // 256 columns per sweep of the wave
-    for (int r = blockIdx.x * 4 + wave; r < M; r += waves) {
-        const int b = r / rows_per_img;
-        const T *xr = X + (size_t)b * img_stride + (size_t)(r - b * rows_per_img) * ldx;
-        float acc[32];
+    const int r = lane & 15, q = lane >> 4;
+    const int groups = (M + 15) >> 4, gstride = gridDim.x * 4;
+    for (int g = blockIdx.x * 4 + wave; g < groups; g += gstride) {
+        int row = g * 16 + r;
+        row = row < M ? row : M - 1;
+        const int b = row / rows_per_img;
+        const T *xr = X + (size_t)b * img_stride + (size_t)(row - b * rows_per_img) * ldx + 16 * q;
+        f32x4h acc[NB];
 #pragma unroll
-        for (int n = 0; n < 32; n++) acc[n] = 0.f;
-        for (int c = 0; c < chunks; c++) {
-            const int k = c * 256 + lane * 4;
-            float x0, x1, x2, x3;
-            if (sizeof(T) == 4) {
-                const float4 v = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(xr) + k);
-                x0 = v.x; x1 = v.y; x2 = v.z; x3 = v.w;
-            } else {
-                const T *pb = xr + k;                                   // bf16 or fp16
-                x0 = (float)pb[0]; x1 = (float)pb[1]; x2 = (float)pb[2]; x3 = (float)pb[3];
+        for (int nb = 0; nb < NB; nb++) acc[nb] = (f32x4h){0.f, 0.f, 0.f, 0.f};
+        float v[16], vn[16];
+        head_load16(xr, v);
+        for (int k0 = 0; k0 < K; k0 += 64) {
+            if (k0 + 64 < K) head_load16(xr + k0 + 64, vn);
+            const float *wb = wl + r * S + k0 + 16 * q;
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+#pragma unroll
+                for (int nb = 0; nb < NB; nb++)
+                    acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[i], wb[nb * 16 * S + i], acc[nb], 0, 0, 0);
             }
 #pragma unroll
-            for (int n = 0; n < 32; n++) {
-                if (n < N) {
-                    const float4 w4 = *reinterpret_cast<const float4 *>(wl + (size_t)n * K + k);
-                    acc[n] = acc[n] + ((x0 * w4.x + x1 * w4.y) + (x2 * w4.z + x3 * w4.w));
+            for (int i = 0; i < 16; i++) v[i] = vn[i];
+        }
+        // C layout: column = lane & 15 (output feature), row = 4 * (lane >> 4) + reg (token)
+#pragma unroll
+        for (int nb = 0; nb < NB; nb++) {
+            const int col = nb * 16 + r;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int orow = g * 16 + 4 * q + j;
+                if (orow < M && col < N) {
+                    float o = acc[nb][j];
+                    if (round_bf16) o = sizeof(T) == 4 ? (float)(bf16)o : (float)(T)o;      // the operand precision (fp32 operands: bf16)
+                    Y[(size_t)orow * ldy + col0 + col] = o;
                 }
             }
         }
+    }
+}
+
+// ---- GELU' for the training backward of mlp.fc1 (autograd of vit.py:97-98): dH = dA * gelu_erf'(H), bf16, 8 elements per lane -------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const bf16 *__restrict__ dA, const bf16 *__restrict__ H, bf16 *__restrict__ dH, size_t n8)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+        const bf16x8 g = reinterpret_cast<const bf16x8 *>(dA)[i], h = reinterpret_cast<const bf16x8 *>(H)[i];
+        bf16x8 o;
 #pragma unroll
-        for (int n = 0; n < 32; n++) {
-            if (n < N) {
-                float v = acc[n];
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-                acc[n] = v;
-            }
+        for (int j = 0; j < 8; j++) {
+            const float x = (float)h[j];
+            const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+            const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+            o[j] = (bf16)((float)g[j] * (cdf + x * pdf));
         }
-        if (lane < N) {
-            float v = 0.f;
-#pragma unroll
-            for (int n = 0; n < 32; n++) v = lane == n ? acc[n] : v;
-            if (round_bf16) v = sizeof(T) == 4 ? (float)(bf16)v : (float)(T)v;      // the operand precision (fp32 operands: bf16)
-            Y[(size_t)r * ldy + col0 + lane] = v;
-        }
+        reinterpret_cast<bf16x8 *>(dH)[i] = o;
+    }
+}
+
+// ---- transposed bf16 shadows of the student's projection weights: the input-gradient GEMM dX = dY W is the forward GEMM kernel on W^T --
+struct TransposeRec { const float *src; bf16 *dst; int rows, cols, tile0, tiles_c; };       // src [rows, cols] fp32 -> dst [cols, rows] bf16
+__global__ __launch_bounds__(256) void transpose_cast_kernel(const TransposeRec *__restrict__ recs, int nrec)
+{
+    __shared__ float tile[64][65];
+    int t = 0;
+    while (t + 1 < nrec && (int)blockIdx.x >= recs[t + 1].tile0) t++;
+    const TransposeRec r = recs[t];
+    const int lt = blockIdx.x - r.tile0;
+    const int r0 = (lt / r.tiles_c) * 64, c0 = (lt % r.tiles_c) * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int rr = r0 + i, cc = c0 + tx;
+        tile[i][tx] = (rr < r.rows && cc < r.cols) ? r.src[(size_t)rr * r.cols + cc] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int cc = c0 + i, rr = r0 + tx;
+        if (cc < r.cols && rr < r.rows) r.dst[(size_t)cc * r.rows + rr] = (bf16)tile[tx][i];
     }
 }
 
@@ -244,6 +309,29 @@ __global__ __launch_bounds__(256) void head_gemm_kernel(const T *__restrict__ X,
 }  // namespace cosa
 
 using namespace cosa;
+
+extern "C" int cosa_gelu_backward(const void *dA, const void *H, void *dH, long long n, void *stream)
+{
+    COSA_REQUIRE(dA && H && dH && n > 0 && n % 8 == 0, "cosa_gelu_backward: n must be a positive multiple of 8");
+    const size_t n8 = (size_t)n / 8;
+    size_t blocks = (n8 + 255) / 256;
+    blocks = blocks > 8192 ? 8192 : blocks;
+    hipLaunchKernelGGL(gelu_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), static_cast<const bf16 *>(dA),
+                       static_cast<const bf16 *>(H), static_cast<bf16 *>(dH), n8);
+    COSA_LAUNCH_CHECK();
+    return COSA_OK;
+}
+
+extern "C" size_t cosa_transpose_record_bytes(void) { return sizeof(TransposeRec); }
+/* records: device array of n {const float *src; bf16 *dst; int rows, cols, tile0, tiles_c}: dst[cols, rows] = bf16(src[rows, cols]^T);
+ * tile0 = number of 64x64 tiles of the records before this one, tiles_c = ceil(cols / 64); total_tiles = the grand total          */
+extern "C" int cosa_transpose_cast_batched(const void *records, int n, int total_tiles, void *stream)
+{
+    COSA_REQUIRE(records && n > 0 && total_tiles > 0, "cosa_transpose_cast_batched: bad arguments");
+    hipLaunchKernelGGL(transpose_cast_kernel, dim3(total_tiles), dim3(256), 0, as_stream(stream), static_cast<const TransposeRec *>(records), n);
+    COSA_LAUNCH_CHECK();
+    return COSA_OK;
+}
 
 // Y[M,N] fp32 = X W^T for N <= 32 (CAM / seg heads); X rows: image b = rows [b*rows_per_img, +rows_per_img) at X + b*img_stride
 // (elements) with row stride ldx, so token views without their cls row need no copy.  dtype: 0 = fp32 operands, 1 = bf16
@@ -254,32 +342,29 @@ extern "C" int cosa_head_gemm(const void *X, const void *W, float *Y, int M, int
 {
     COSA_REQUIRE(ldy >= col0 + N && col0 >= 0, "cosa_head_gemm: output columns [col0, col0+N) must fit the row stride ldy");
     COSA_REQUIRE(X && W && Y && M > 0 && N > 0 && K > 0 && rows_per_img > 0, "cosa_head_gemm: bad arguments");
-    COSA_REQUIRE(N <= 32 && K % 256 == 0 && ldx >= K, "cosa_head_gemm: N <= 32 and K %% 256 == 0 (got N=%d K=%d)", N, K);
+    COSA_REQUIRE(N <= 32 && K % 64 == 0 && ldx >= K, "cosa_head_gemm: N <= 32 and K %% 64 == 0 (got N=%d K=%d)", N, K);
     COSA_REQUIRE(dtype >= 0 && dtype <= 2, "cosa_head_gemm: dtype 0 (fp32), 1 (bf16) or 2 (fp16)");
-    const size_t lds = (size_t)N * K * sizeof(float);
-    COSA_REQUIRE(lds <= 128 * 1024, "cosa_head_gemm: weight does not fit the LDS");
+    COSA_REQUIRE(ldx % (dtype == 0 ? 4 : 8) == 0 && img_stride % (dtype == 0 ? 4 : 8) == 0, "cosa_head_gemm: rows must be 16-byte aligned");
+    const int nb = N <= 16 ? 1 : 2;
+    const size_t lds = (size_t)16 * nb * (K + 1) * sizeof(float);
+    COSA_REQUIRE(lds <= 150 * 1024, "cosa_head_gemm: weight does not fit the LDS");
     hipStream_t st = as_stream(stream);
-    static size_t attr[3] = {0, 0, 0};
-    if (lds > attr[dtype]) {
-        if (dtype == 0)
-            COSA_HIP_CHECK(hipFuncSetAttribute((const void *)head_gemm_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        else if (dtype == 1)
-            COSA_HIP_CHECK(hipFuncSetAttribute((const void *)head_gemm_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        else
-            COSA_HIP_CHECK(hipFuncSetAttribute((const void *)head_gemm_kernel<_Float16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr[dtype] = lds;
-    }
-    int blocks = (M + 3) / 4;
+    int blocks = ((M + 15) / 16 + 3) / 4;
     blocks = blocks > 1024 ? 1024 : blocks;
-    if (dtype == 0)
-        hipLaunchKernelGGL(head_gemm_kernel<float>, dim3(blocks), dim3(256), lds, st, static_cast<const float *>(X),
-                           static_cast<const float *>(W), Y, M, N, K, rows_per_img, img_stride, ldx, round_bf16, ldy, col0);
-    else if (dtype == 1)
-        hipLaunchKernelGGL(head_gemm_kernel<bf16>, dim3(blocks), dim3(256), lds, st, static_cast<const bf16 *>(X),
-                           static_cast<const bf16 *>(W), Y, M, N, K, rows_per_img, img_stride, ldx, round_bf16, ldy, col0);
-    else
-        hipLaunchKernelGGL(head_gemm_kernel<_Float16>, dim3(blocks), dim3(256), lds, st, static_cast<const _Float16 *>(X),
-                           static_cast<const _Float16 *>(W), Y, M, N, K, rows_per_img, img_stride, ldx, round_bf16, ldy, col0);
+#define COSA_HEAD_LAUNCH(T, NB)                                                                                                   \
+    do {                                                                                                                          \
+        static size_t attr = 0;                                                                                                   \
+        if (lds > attr) {                                                                                                         \
+            COSA_HIP_CHECK(hipFuncSetAttribute((const void *)head_gemm_kernel<T, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            attr = lds;                                                                                                           \
+        }                                                                                                                         \
+        hipLaunchKernelGGL((head_gemm_kernel<T, NB>), dim3(blocks), dim3(256), lds, st, static_cast<const T *>(X), static_cast<const T *>(W), Y, M, N, \
+                           K, rows_per_img, img_stride, ldx, round_bf16, ldy, col0);                                              \
+    } while (0)
+    if (dtype == 0) { if (nb == 1) COSA_HEAD_LAUNCH(float, 1); else COSA_HEAD_LAUNCH(float, 2); }
+    else if (dtype == 1) { if (nb == 1) COSA_HEAD_LAUNCH(bf16, 1); else COSA_HEAD_LAUNCH(bf16, 2); }
+    else { if (nb == 1) COSA_HEAD_LAUNCH(_Float16, 1); else COSA_HEAD_LAUNCH(_Float16, 2); }
+#undef COSA_HEAD_LAUNCH
     COSA_LAUNCH_CHECK();
     return COSA_OK;
 }

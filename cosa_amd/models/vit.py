@@ -145,7 +145,7 @@ class VisionTransformer(nn.Module):
         y = nn_ops.attention(qkv, self.num_heads)
         x = x + nn_ops.linear(y, blk.attn.proj.weight, blk.attn.proj.bias, dt)
         y = F.layer_norm(x, (self.embed_dim,), c(blk.norm2.weight, dt), c(blk.norm2.bias, dt), blk.norm2.eps)
-        y = nn_ops.gelu(nn_ops.linear(y, blk.mlp.fc1.weight, blk.mlp.fc1.bias, dt))
+        y = nn_ops.linear(y, blk.mlp.fc1.weight, blk.mlp.fc1.bias, dt, act=True)
         return x + nn_ops.linear(y, blk.mlp.fc2.weight, blk.mlp.fc2.bias, dt)
 
     def _block_fused_ln(self, blk, x, delta):
@@ -159,7 +159,7 @@ class VisionTransformer(nn.Module):
         y = nn_ops.attention(qkv, self.num_heads)
         d1 = nn_ops.linear(y, blk.attn.proj.weight, blk.attn.proj.bias, dt)
         x, y = nn_ops.add_layernorm(x, d1, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
-        y = nn_ops.gelu(nn_ops.linear(y, blk.mlp.fc1.weight, blk.mlp.fc1.bias, dt))
+        y = nn_ops.linear(y, blk.mlp.fc1.weight, blk.mlp.fc1.bias, dt, act=True)
         return x_in, x, nn_ops.linear(y, blk.mlp.fc2.weight, blk.mlp.fc2.bias, dt)
 
     # -- fused no-grad path (the teacher's 6 passes): fp32 residual stream, HIP GEMM/LN/attention kernels -------

@@ -248,12 +248,14 @@ class DilatedConvReluFn(torch.autograd.Function):
 
 
 def head_linear(tok, weight, round_bf16=False):
-    """tok [B, n, K] (fp32 or bf16, possibly the strided view without the cls row) x weight [N, K] (same dtype) -> [B*n, N] fp32 on the
-    narrow-head kernel (no-grad paths: teacher and evaluation).  None when the shape is outside the kernel's envelope."""
+    """tok [B, n, K] (fp32, bf16 or fp16; possibly the strided view without the cls row) x weight [N, K] (same dtype) -> [B*n, N] fp32 on the
+    narrow-head kernel (exact-fp32 MFMA, fixed reduction order per row).  None when the shape is outside the kernel's envelope."""
     B, n, K = tok.shape
     N = weight.shape[0]
-    if tok.dtype != weight.dtype or tok.dtype not in (torch.float32, torch.bfloat16, torch.float16) or K % 256 or tok.stride(2) != 1 \
-            or not weight.is_contiguous() or min(N, 32) * K * 4 > 128 * 1024:
+    al = 4 if tok.dtype == torch.float32 else 8
+    if tok.dtype != weight.dtype or tok.dtype not in (torch.float32, torch.bfloat16, torch.float16) or K % 64 or tok.stride(2) != 1 \
+            or not weight.is_contiguous() or 32 * (K + 1) * 4 > 150 * 1024 or tok.stride(1) % al or (B > 1 and tok.stride(0) % al) \
+            or tok.data_ptr() % 16:
         return None
     y = torch.empty((B * n, N), device=tok.device, dtype=torch.float32)
     dt = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}[tok.dtype]
@@ -484,39 +486,109 @@ def gemm_wgrad(dy2, x2, want_bias=False):
     return (dw, db) if want_bias else dw
 
 
+class TransposedShadows:
+    """bf16 W^T copies of the student's projection weights, rebuilt from the fp32 masters by ONE batched launch per step (after the
+    optimizer).  With them the input-gradient GEMM dX = dY W of an nn.Linear is the forward GEMM kernel applied to W^T: no NN kernel
+    family, no library call."""
+
+    def __init__(self, weights):
+        import numpy as np
+        self.weights = list(weights)
+        dev = self.weights[0].device
+        self.t16 = [torch.empty((w.shape[1], w.shape[0]), device=dev, dtype=torch.bfloat16) for w in self.weights]
+        rec_dt = np.dtype([("src", "u8"), ("dst", "u8"), ("rows", "i4"), ("cols", "i4"), ("tile0", "i4"), ("tiles_c", "i4")])
+        assert rec_dt.itemsize == _C.lib().cosa_transpose_record_bytes()
+        rec = np.zeros(len(self.weights), rec_dt)
+        tiles = 0
+        for i, (w, t) in enumerate(zip(self.weights, self.t16)):
+            assert w.dtype == torch.float32 and w.is_contiguous() and w.dim() == 2
+            tr, tc = (w.shape[0] + 63) // 64, (w.shape[1] + 63) // 64
+            rec[i] = (w.data_ptr(), t.data_ptr(), w.shape[0], w.shape[1], tiles, tc)
+            tiles += tr * tc
+            _transposed[id(w)] = (w, t)
+        self.total_tiles = tiles
+        self.d_rec = torch.from_numpy(rec.view(np.uint8).copy()).to(dev)
+        self.refresh()
+
+    def refresh(self):
+        _C.check(_C.lib().cosa_transpose_cast_batched(_C.ptr(self.d_rec), len(self.weights), self.total_tiles, _C.stream_ptr()),
+                 "cosa_transpose_cast_batched")
+
+
+_transposed = {}       # id(weight) -> (weight, bf16 W^T)
+_zeros16 = {}
+
+
+def _zero_bias16(n, dev):
+    z = _zeros16.get(dev)
+    if z is None or z.numel() < n:
+        z = _zeros16[dev] = torch.zeros(max(n, 8192), device=dev, dtype=torch.bfloat16)
+    return z
+
+
+def _own_gemm_ok(M, N, K):
+    return N % 128 == 0 and K % 64 == 0
+
+
 class LinearShadowFn(Function):
-    """y = x W^T + b with the bf16 SHADOW of the fp32 master weight (ShadowSet): no per-step cast of the weight in the
-    forward, and the weight gradient is produced in fp32 directly.  Gradients are routed to the masters (w, b)."""
+    """y = x W^T + b (act = 1: gelu(.) of it, mlp.fc1) with the bf16 SHADOW of the fp32 master weight, forward and backward on the
+    MFMA GEMM kernels of this repository: forward = cosa_gemm_bf16 (fc1: the dual epilogue that also keeps the pre-activation),
+    dX = the same kernel on the transposed shadow W^T (TransposedShadows), dW / db = the TN weight-gradient kernel in fp32.
+    Gradients are routed to the masters (w, b)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, w16, b16):
-        ctx.save_for_backward(x, w16)
-        return F.linear(x, w16, b16)
+    def forward(ctx, x, w, b, w16, b16, wT16, act):
+        K = x.shape[-1]
+        x2 = x.reshape(-1, K)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        M, N = x2.shape[0], w16.shape[0]
+        h = None
+        if act:
+            h = torch.empty((M, N), device=x.device, dtype=torch.bfloat16)
+            y = torch.empty_like(h)
+            with _C.profiled("gemm_bf16"):
+                _C.check(_C.lib().cosa_gemm_bf16_dual_gelu(_C.ptr(x2), _C.ptr(w16), _C.ptr(b16), _C.ptr(h), _C.ptr(y), M, N, K, _C.stream_ptr()),
+                         "cosa_gemm_bf16_dual_gelu")
+            _flops["gemm_bf16"] = _flops.get("gemm_bf16", 0) + 2.0 * M * N * K
+        else:
+            y = gemm_bf16(x2, w16, b16, EPI_BIAS)
+        ctx.save_for_backward(x2, wT16, h)
+        ctx.xshape = x.shape
+        return y.view(*x.shape[:-1], N)
 
     @staticmethod
     def backward(ctx, dy):
-        x, w16 = ctx.saved_tensors
+        x2, wT16, h = ctx.saved_tensors
         dy2 = dy.reshape(-1, dy.shape[-1])
-        x2 = x.reshape(-1, x.shape[-1])
-        dx = torch.mm(dy2, w16).view_as(x) if ctx.needs_input_grad[0] else None
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        if h is not None:                                   # through the GELU: dH = dA * gelu'(H)
+            dh = torch.empty_like(h)
+            _C.check(_C.lib().cosa_gelu_backward(_C.ptr(dy2), _C.ptr(h), _C.ptr(dh), dh.numel(), _C.stream_ptr()), "cosa_gelu_backward")
+            dy2 = dh
+        M, N = dy2.shape
+        K = x2.shape[1]
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = gemm_bf16(dy2, wT16, _zero_bias16(K, dy2.device)[:K], EPI_BIAS).view(ctx.xshape)      # [M,N] x (W^T [K,N])^T
         dw = db = None
         if ctx.needs_input_grad[1]:
-            if dy2.shape[1] % 128 == 0 and x2.shape[1] % 128 == 0 and dy2.is_cuda:
-                dw, db = gemm_wgrad(dy2.contiguous(), x2.contiguous(), want_bias=True)
-            else:
-                dw = _mm_f32(dy2.t(), x2)
-        if ctx.needs_input_grad[2] and db is None:
-            db = dy2.sum(0, dtype=torch.float32)
-        return dx, dw, db, None, None
+            dw, db = gemm_wgrad(dy2, x2, want_bias=True)
+        return dx, dw, db, None, None, None, None
 
 
-def linear(x, weight, bias, dtype):
-    """nn.Linear on `dtype` operands from fp32 masters: registered shadows -> LinearShadowFn, otherwise cast_param."""
-    if torch.is_grad_enabled() and weight.requires_grad and dtype == torch.bfloat16:
-        ew, eb = _shadows.get(id(weight)), _shadows.get(id(bias))
-        if ew is not None and eb is not None and ew[0] is weight and eb[0] is bias:
-            return LinearShadowFn.apply(x, weight, bias, ew[1], eb[1])
-    return F.linear(x, cast_param(weight, dtype), cast_param(bias, dtype))
+def linear(x, weight, bias, dtype, act=False):
+    """nn.Linear (+ GELU with act=True) on `dtype` operands from fp32 masters.  Training on the GPU with registered shadows (bf16 W, b and
+    W^T): LinearShadowFn, every GEMM an own kernel; otherwise (fp32 parity mode, odd shapes) torch."""
+    if torch.is_grad_enabled() and weight.requires_grad and dtype == torch.bfloat16 and x.is_cuda:
+        ew, eb, et = _shadows.get(id(weight)), _shadows.get(id(bias)), _transposed.get(id(weight))
+        if ew is not None and eb is not None and et is not None and ew[0] is weight and eb[0] is bias and et[0] is weight \
+                and _own_gemm_ok(x.numel() // x.shape[-1], weight.shape[0], weight.shape[1]) and weight.shape[0] % 64 == 0 \
+                and weight.shape[0] % 128 == 0 and weight.shape[1] % 128 == 0:
+            return LinearShadowFn.apply(x, weight, bias, ew[1], eb[1], et[1], bool(act))
+    y = F.linear(x, cast_param(weight, dtype), cast_param(bias, dtype))
+    return F.gelu(y) if act else y
 
 
 # --------------------------------------------------------------------------------------------
@@ -596,5 +668,3 @@ def add_layernorm(x, delta, weight, bias, eps):
     return AddLayerNormFn.apply(x, delta, weight, bias, w16, b16, eps)
 
 
-def gelu(x):
-    return F.gelu(x)

@@ -122,6 +122,13 @@ class CoSATrainer:
                                                               shadow_of=nn_ops.shadow_of)
         for m in (self.student, self.model_AN):
             m.__dict__["_cosa_shadow_auto"] = self._fused_step is None
+        # bf16 W^T copies of the student's block projections (the input-gradient GEMMs run the forward kernel on them)
+        self._student_wT = None
+        if on:
+            ws = []
+            for blk in self.student.encoder.blocks:
+                ws += [blk.attn.qkv.weight, blk.attn.proj.weight, blk.mlp.fc1.weight, blk.mlp.fc2.weight]
+            self._student_wT = nn_ops.TransposedShadows(ws)
         self.use_graph = bool(getattr(args, "teacher_graph", True)) and self._shadows is not None
         self.fused_losses = bool(getattr(args, "fused_losses", True)) and device.type == "cuda" and not args.after_softmax
         self._graph = None
@@ -271,10 +278,14 @@ class CoSATrainer:
         loss.backward()
         if self._fused_step is not None:
             self._fused_step.step()
+            if self._student_wT is not None:
+                self._student_wT.refresh()
         else:
             self.optimizer.step()
             if self._student_shadows is not None:
                 self._student_shadows.refresh()
+            if self._student_wT is not None:
+                self._student_wT.refresh()
             torch_helper.ema_update(self._ema_pairs[0], self._ema_pairs[1], self.args.momentum)
         return logs
 

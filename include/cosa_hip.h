@@ -231,6 +231,15 @@ int cosa_head_gemm(const void *X, const void *W, float *Y, int M, int N, int K, 
                    int ldx, int dtype, int round_bf16, int ldy, int col0, void *stream);
 int cosa_layernorm(const float *x, const void *gamma, const void *beta, void *y_bf16, float *y_f32,
                    int rows, int dim, float eps, void *stream);
+/* the student's training path (autograd of models/vit/vit.py:96-102,119-137) on the same GEMM kernels:
+ *   cosa_gemm_bf16_dual_gelu    mlp.fc1 forward: H = X W^T + b (bf16, kept for GELU') and A = gelu_erf(H) (bf16) from one pass
+ *   cosa_gelu_backward          dH = dA * gelu_erf'(H) (bf16, n % 8 == 0)
+ *   cosa_transpose_cast_batched bf16 W^T shadows of the fp32 master weights (one launch for all tensors): the input gradient
+ *                               dX = dY W is then cosa_gemm_bf16(dY, W^T, zeros) -- the forward kernel, no second GEMM family   */
+int cosa_gemm_bf16_dual_gelu(const void *X, const void *W, const void *bias, void *H, void *A, int M, int N, int K, void *stream);
+int cosa_gelu_backward(const void *dA, const void *H, void *dH, long long n, void *stream);
+size_t cosa_transpose_record_bytes(void);
+int cosa_transpose_cast_batched(const void *records, int n, int total_tiles, void *stream);
 
 /* The same kernels with IEEE fp16 operands (fp32 accumulation, same MFMA rate; gemm_kernels.hip / attn_kernels.hip built a second
  * time with -DCOSA_OP_F16=1): the no-grad passes -- the teacher's six multi-scale forwards per step (utils/seg_helper.py:232-275) and

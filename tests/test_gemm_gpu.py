@@ -166,3 +166,33 @@ def test_head_linear_vs_torch_and_batch_invariance(dtype, N, K):
     assert torch.equal(one, y[2 * n:3 * n])
     two = nn_ops.head_linear(tok[3:5].contiguous(), w, round_bf16=dtype == torch.bfloat16)
     assert torch.equal(two, y[3 * n:5 * n])
+
+
+@pytest.mark.parametrize("M,N,K,act", [(12560, 3072, 768, True), (12560, 768, 3072, False), (300, 2304, 768, False), (130, 3072, 768, True),
+                                       (4099, 768, 768, False)])
+def test_student_linear_own_kernels_vs_torch_autograd(M, N, K, act):
+    """nn.Linear (+GELU) of the student's blocks, forward and backward on own kernels (dual-epilogue GEMM, GELU', the forward kernel on the
+    transposed shadow for dX, TN kernel for dW / db) against fp32 torch autograd on the same bf16-rounded operands.
+    Tolerances: bf16 outputs 2^-7 of the output scale (two roundings in the GELU chain), fp32 weight gradients 2e-3 relative."""
+    from cosa_amd import nn_ops
+    torch.manual_seed(M + N)
+    lin = torch.nn.Linear(K, N).cuda()
+    with torch.no_grad():
+        lin.weight.mul_(3.0)
+    sh = nn_ops.ShadowSet(lin)
+    tsh = nn_ops.TransposedShadows([lin.weight])
+    assert torch.equal(tsh.t16[0], lin.weight.detach().bfloat16().t().contiguous())
+    x = torch.randn(2, M // 2, K, device="cuda").bfloat16().requires_grad_(True)
+    y = nn_ops.linear(x, lin.weight, lin.bias, torch.bfloat16, act=act)
+    go = torch.randn_like(y)
+    y.backward(go)
+    w32, b32 = sh.shadows[0].float().requires_grad_(True), sh.shadows[1].float().requires_grad_(True)
+    x32 = x.detach().float().requires_grad_(True)
+    hh = torch.nn.functional.linear(x32, w32, b32)
+    ref = torch.nn.functional.gelu(hh) if act else hh
+    ref.backward(go.float())
+    tol = lambda r: 2.0 ** -7 * max(r.abs().max().item(), 1.0)
+    assert (y.float() - ref).abs().max().item() <= tol(ref)
+    assert (x.grad.float() - x32.grad).abs().max().item() <= 2 * tol(x32.grad)
+    assert (lin.weight.grad - w32.grad).abs().max().item() <= 4e-3 * w32.grad.abs().max().item() + 1e-3
+    assert (lin.bias.grad - b32.grad).abs().max().item() <= 4e-3 * b32.grad.abs().max().item() + 1e-3
