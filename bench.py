@@ -396,7 +396,8 @@ def main():
                                    f"teacher 3 scales x 2 flips + student fwd/bwd + cam2mask x2 + 5 losses + AdamW + EMA"
                                    f"{' + PAR' if opt.usepar else ''}{' + adaptive thresholds (GMM)' if opt.usegmm else ''}",
                        "global_batch": opt.batch * world, "parallelism": f"dp{world}", "final_loss": round(loss, 5),
-                       "library_gemm_selection": "tunableop file" if trainer.tuned_gemms else "library default"},
+                       "dist_backend": (dist.get_backend() + f" (world size seen by the collective library: {dist.get_world_size()})") if world > 1 else None,
+                       },
             "roofline": roof,
         }
         if len(fams) > 1:

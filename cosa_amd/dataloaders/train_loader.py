@@ -81,6 +81,7 @@ class DeviceTrainLoader:
         self.loader = DataLoader(dataset=dataset, batch_size=batch_size, num_workers=num_workers, drop_last=True, sampler=sampler,
                                  shuffle=shuffle and sampler is None, collate_fn=_collate)
         self.sampler = sampler
+        self.dataset = dataset
         self.augment = DeviceAugmenter(dataset.crop_size, device)
 
     def __len__(self):

@@ -33,7 +33,7 @@ class LargeFOV(nn.Module):
         y = nn_ops.conv3x3_dilated_tokens(tok, c(self.conv6.weight, dt), B, h, w, self.dilation, relu=True)
         y = nn_ops.conv3x3_dilated_tokens(y.view(B, h * w, -1), c(self.conv7.weight, dt), B, h, w, self.dilation, relu=True)
         w8 = c(self.conv8.weight, dt).reshape(self.conv8.weight.shape[0], -1)
-        seg = nn_ops.head_linear(y.view(B, h * w, -1), w8, round_bf16=True) if self.batch_invariant else None
+        seg = nn_ops.head_linear(y.view(B, h * w, -1), w8.contiguous(), round_bf16=True)
         if seg is None:
             seg = F.linear(y, w8).float()
         return seg.view(B, h, w, -1).permute(0, 3, 1, 2).contiguous()
@@ -45,8 +45,10 @@ class LargeFOV(nn.Module):
             tok = tok.contiguous()
         y = nn_ops.DilatedConvReluFn.apply(tok, self.conv6.weight, B, h, w, self.dilation)
         y = nn_ops.DilatedConvReluFn.apply(y.view(B, h * w, -1), self.conv7.weight, B, h, w, self.dilation)
-        w8 = nn_ops.cast_param(self.conv8.weight, torch.bfloat16).reshape(self.conv8.weight.shape[0], -1)
-        seg = F.linear(y, w8).float()
+        seg = nn_ops.narrow_linear(y, self.conv8.weight)
+        if seg is None:
+            w8 = nn_ops.cast_param(self.conv8.weight, torch.bfloat16).reshape(self.conv8.weight.shape[0], -1)
+            seg = F.linear(y, w8).float()
         return seg.view(B, h, w, -1).permute(0, 3, 1, 2).contiguous()
 
     def forward_nhwc(self, x, dt):
@@ -109,27 +111,34 @@ class VITNetwork(nn.Module):
         return tok.mean(dim=1) if self.isgap else tok.amax(dim=1)
 
     def _cam(self, tok, weight, B, h, w, detach_feat, detach_w):
-        """1x1 conv over tokens == tokens @ W^T; returned as fp32 NCHW [B,C,h,w] (models/__init__.py:190-192)."""
-        dt = tok.dtype                      # fp32 tokens (fused teacher path) keep the CAM head in fp32
-        wgt = nn_ops.cast_param(weight, dt).reshape(weight.shape[0], -1)
-        if detach_w:
-            wgt = wgt.detach()
+        """1x1 conv over tokens == tokens @ W^T; returned as fp32 NCHW [B,C,h,w] (models/__init__.py:190-192).  Own kernels: the
+        exact-fp32 MFMA narrow-head kernel (no-grad paths; fp32 tokens of the fused teacher keep the head in fp32) and, with autograd,
+        nn_ops.NarrowLinearFn; torch only for shapes outside their envelope / on the host."""
+        dt = tok.dtype
         if detach_feat:
             tok = tok.detach()
         cam = None
-        if (self.batch_invariant_heads or self.encoder.precision == "bf16x3") and not torch.is_grad_enabled() and tok.is_cuda:
-            cam = nn_ops.head_linear(tok, wgt.contiguous(), round_bf16=tok.dtype != torch.float32)       # own kernel, fixed reduction order
+        if tok.is_cuda and not torch.is_grad_enabled():
+            wgt = nn_ops.cast_param(weight, dt).reshape(weight.shape[0], -1)
+            cam = nn_ops.head_linear(tok, wgt.contiguous(), round_bf16=tok.dtype != torch.float32)
+        elif tok.is_cuda and dt == torch.bfloat16:
+            cam = nn_ops.narrow_linear(tok.reshape(-1, tok.shape[-1]).contiguous(), weight.detach() if detach_w else weight)
         if cam is None:
-            cam = F.linear(tok, wgt).float()
+            wgt = nn_ops.cast_param(weight, dt).reshape(weight.shape[0], -1)
+            cam = F.linear(tok, wgt.detach() if detach_w else wgt).float()
         return cam.reshape(B, h, w, -1).permute(0, 3, 1, 2).contiguous()
 
-    def _cls_head(self, pooled, wgt):
-        """classification logits from the pooled tokens (optionally on the batch-invariant narrow-head kernel, like the CAM heads)"""
-        if self.batch_invariant_heads and not torch.is_grad_enabled() and pooled.is_cuda:
-            y = nn_ops.head_linear(pooled.unsqueeze(1).contiguous(), wgt.contiguous(), round_bf16=pooled.dtype != torch.float32)
-            if y is not None:
-                return y
-        return F.linear(pooled, wgt).float()
+    def _cls_head(self, pooled, weight, dt):
+        """classification logits from the pooled tokens (models/__init__.py:196-204), on the same narrow-head kernels"""
+        y = None
+        if pooled.is_cuda and not torch.is_grad_enabled():
+            y = nn_ops.head_linear(pooled.to(dt).unsqueeze(1).contiguous(), nn_ops.cast_param(weight, dt).reshape(weight.shape[0], -1).contiguous(),
+                                   round_bf16=dt != torch.float32)
+        elif pooled.is_cuda and dt == torch.bfloat16:
+            y = nn_ops.narrow_linear(pooled.to(dt).contiguous(), weight)
+        if y is None:
+            y = F.linear(pooled.to(dt), nn_ops.cast_param(weight, dt).reshape(weight.shape[0], -1)).float()
+        return y
 
     def refresh_shadows(self):
         """16-bit shadows of every parameter, current as of this call (nn_ops.ensure_shadows); a no-op in fp32 mode / on the host"""
@@ -178,10 +187,8 @@ class VITNetwork(nn.Module):
             cam, cam_aux = cam.detach(), cam_aux.detach()
         if cam_only:
             return cam, cam_aux
-        wc = nn_ops.cast_param(self.classifier.weight, dt).reshape(self.num_classes - 1, -1)
-        wa = nn_ops.cast_param(self.aux_classifier.weight, dt).reshape(self.num_classes - 1, -1)
-        cls_x4 = self._cls_head(self._pool(tok).to(dt), wc)
-        cls_aux = self._cls_head(self._pool(tok_aux).to(dt), wa)
+        cls_x4 = self._cls_head(self._pool(tok), self.classifier.weight, dt)
+        cls_aux = self._cls_head(self._pool(tok_aux), self.aux_classifier.weight, dt)
         return cls_x4, cls_aux, x4, seg, cam, cam_aux
 
 

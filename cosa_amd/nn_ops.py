@@ -157,37 +157,6 @@ def conv3x3_dilated_tokens(tok, w16, B, h, w, dilation, relu=True):
     return y
 
 
-_TUNED = None
-
-
-def enable_tuned_gemms():
-    """The student's forward / input-gradient GEMMs and the narrow head GEMMs are plain library calls (hipBLASLt / rocBLAS through
-    torch).  PyTorch's TunableOp picks, per shape, the fastest solution the libraries offer instead of their heuristic's first
-    choice; `cosa_amd/tuning/tunableop_gfx950.csv` holds the picks for the benchmark shapes on this image's library builds
-    (made with tools/tune_gemms.sh; e.g. the 20- and 21-row head weight gradients: 95 -> 27 us).  Tuning itself stays off: shapes
-    that are not in the file, or a file whose library versions do not match, fall back to the default choice.
-    COSA_NO_TUNED_GEMMS=1 disables it.  Returns True when the file was accepted."""
-    global _TUNED
-    if _TUNED is not None:
-        return _TUNED
-    _TUNED = False
-    if os.environ.get("COSA_NO_TUNED_GEMMS", "0") == "1" or not torch.cuda.is_available():
-        return False
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuning", "tunableop_gfx950.csv")
-    try:
-        import torch.cuda.tunable as tunable
-        if os.environ.get("PYTORCH_TUNABLEOP_ENABLED") is None and os.path.exists(path):     # leave an explicit user setting alone
-            tunable.enable(True)
-            tunable.tuning_enable(False)
-            tunable.record_untuned_enable(False)
-            _TUNED = bool(tunable.read_file(path))
-            if not _TUNED:
-                tunable.enable(False)
-    except Exception:                                                                      # older torch without the module
-        _TUNED = False
-    return _TUNED
-
-
 def own_decoder_backward():
     """COSA_DECODER_MIOPEN=1 sends the student's LargeFOV convolutions back through F.conv2d (A/B switch)."""
     return os.environ.get("COSA_DECODER_MIOPEN", "0") != "1"
@@ -265,6 +234,49 @@ def head_linear(tok, weight, round_bf16=False):
             _C.check(_C.lib().cosa_head_gemm(_C.ptr(tok), _C.ptr(weight[c0:c0 + nn_]), _C.ptr(y), B * n, nn_, K, n, tok.stride(0) if B > 1 else n * tok.stride(1),
                                              tok.stride(1), dt, int(round_bf16), N, c0, _C.stream_ptr()), "cosa_head_gemm")
     return y
+
+
+class NarrowLinearFn(Function):
+    """y[M,N] (fp32) = x[M,K] W[N,K]^T for the narrow heads of the TRAINING path (CAM / aux-CAM / classification heads: 1x1 convs with
+    20 | 80 outputs, models/__init__.py:190-204; LargeFOV conv8, conv_head.py:38), forward and backward on own kernels: forward = the
+    exact-fp32 MFMA narrow-head kernel; dX = the projection GEMM kernel on the zero-padded [M,128] output gradient and the padded
+    transposed weight; dW = the TN weight-gradient kernel on the same padded gradient (rows >= N dropped)."""
+
+    @staticmethod
+    def forward(ctx, x2, weight, w16):
+        y = head_linear(x2.unsqueeze(0), w16)
+        ctx.save_for_backward(x2, w16)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w16 = ctx.saved_tensors
+        M, N = dy.shape
+        K = x2.shape[1]
+        NP = 128 * ((N + 127) // 128)
+        dyp = torch.zeros((M, NP), device=dy.device, dtype=torch.bfloat16)
+        dyp[:, :N] = dy
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            wtp = torch.zeros((K, NP), device=dy.device, dtype=torch.bfloat16)
+            wtp[:, :N] = w16.t()
+            dx = gemm_bf16(dyp, wtp, _zero_bias16(K, dy.device)[:K], EPI_BIAS)
+        if ctx.needs_input_grad[1]:
+            dw = gemm_wgrad(dyp, x2)[:N]
+        return dx, dw, None
+
+
+def narrow_linear(x2, weight):
+    """x2 [M,K] bf16 (contiguous) x fp32 master weight [N, K(,1,1)] -> [M,N] fp32 with autograd, every kernel an own one; None when the
+    shape is outside the kernels' envelope (K % 128, N <= 128)."""
+    w = weight.reshape(weight.shape[0], -1)
+    N, K = w.shape
+    if not x2.is_cuda or x2.dtype != torch.bfloat16 or K % 128 or not x2.is_contiguous():
+        return None
+    w16 = cast_param(weight, torch.bfloat16).reshape(N, K)
+    if torch.is_grad_enabled() and (weight.requires_grad or x2.requires_grad):
+        return NarrowLinearFn.apply(x2, w, w16.detach().contiguous())
+    return head_linear(x2.unsqueeze(0), w16.contiguous())
 
 
 def layernorm_f32(x, g, b, eps, want_bf16=True, want_f32=False):

@@ -61,7 +61,6 @@ class CoSATrainer:
     def __init__(self, args, device, ddp=False, seed=0):
         self.args = args
         self.device = device
-        self.tuned_gemms = nn_ops.enable_tuned_gemms() if device.type == "cuda" else False
         torch_helper.setup_seed(seed)
         self.model_ON = build_model(args).to(device)
         self.model_AN = build_model(args).to(device)
@@ -268,7 +267,7 @@ class CoSATrainer:
                 + args.reg_weight * reg_loss
         return loss, dict(overall_loss=loss.detach(), cls_loss=cls_loss.detach(), cls_aux_loss=cls_loss_aux.detach(),
                           seg_loss=seg_loss.detach(), cam_loss=cam_loss.detach(), reg_loss=reg_loss.detach(),
-                          mask=refine_mask_label)
+                          mask=refine_mask_label, cls_logits=cls_final.detach(), cls_aux_logits=cls_aux.detach())
 
     def step(self, wimg, simg, cls_label, img_box, n_iter):
         loss, logs = self.forward_losses(wimg, simg, cls_label, img_box, n_iter)
@@ -336,6 +335,6 @@ def smoke():
     wimg, simg, lab, box = synthetic_batch(2, 128, 20, dev, seed=1)
     logs = tr.step(wimg, simg, lab, box, n_iter=args.warmup_iters + 1)
     torch.cuda.synchronize()
-    vals = {k: float(v) for k, v in logs.items() if k != "mask"}
+    vals = {k: float(v) for k, v in logs.items() if torch.is_tensor(v) and v.numel() == 1}
     assert all(math.isfinite(v) for v in vals.values()), vals
     print("train_step smoke:", {k: round(v, 5) for k, v in vals.items()})

@@ -398,6 +398,42 @@ def gen_augment(rng):
     np.savez_compressed(os.path.join(OUT, "augment.npz"), **out)
 
 
+def gen_signatures():
+    """The reference's call surface for the path as data: parameter names and defaults of the functions / constructors
+    the launcher touches, read with inspect.signature from the reference's own files.  tests/test_boundary.py holds cosa_amd's
+    equivalents to it."""
+    import inspect
+    import json
+    seg, par, th, ev = ref_loader.seg_helper(), ref_loader.par_module(), ref_loader.torch_helper_fns(), ref_loader.evaluation_module()
+
+    def sig(f):
+        out = []
+        for name, p_ in inspect.signature(f).parameters.items():
+            if name == "self":
+                continue
+            d = p_.default
+            out.append([name, None if d is inspect.Parameter.empty else repr(d), p_.kind.name])
+        return out
+    table = {}
+    for name in ("multi_scale_camseg", "multi_scale_camsegv3", "cam_validation", "cam2mask", "seg_loss", "get_energy_loss", "seg_refine_by_label",
+                 "cam_loss", "cam_to_label", "seg_validation", "rungmm"):
+        table["utils.seg_helper." + name] = sig(getattr(seg, name))
+    table["utils.seg_helper.DenseEnergyLoss.__init__"] = sig(seg.DenseEnergyLoss.__init__)
+    table["utils.seg_helper.DenseEnergyLoss.forward"] = sig(seg.DenseEnergyLoss.forward)
+    table["utils.seg_helper.DynamicQueue.__init__"] = sig(seg.DynamicQueue.__init__)
+    table["models.PAR.PAR.__init__"] = sig(par.PAR.__init__)
+    table["models.PAR.PAR.forward"] = sig(par.PAR.forward)
+    table["utils.torch_helper.PolyWarmupAdamW.__init__"] = sig(th.PolyWarmupAdamW.__init__)
+    for name in ("denormalize_img", "setup_seed", "save_best", "compute_mAP"):
+        table["utils.torch_helper." + name] = sig(getattr(th, name))
+    table["utils.torch_helper.EMAtracker.__init__"] = sig(th.EMAtracker.__init__)
+    for name in ("scores", "pseudo_scores"):
+        table["utils.evaluation." + name] = sig(getattr(ev, name))
+    with open(os.path.join(OUT, "ref_signatures.json"), "w") as f:
+        json.dump(table, f, indent=1, sort_keys=True)
+    print("signatures:", len(table), "entries")
+
+
 def main():
     assert ref_loader.available(), "reference tree not present"
     os.makedirs(OUT, exist_ok=True)
@@ -413,6 +449,7 @@ def main():
     gen_eval(np.random.default_rng(17))
     gen_gmm(np.random.default_rng(18))
     gen_augment(np.random.default_rng(19))
+    gen_signatures()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")
 

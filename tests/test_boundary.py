@@ -85,3 +85,58 @@ def test_checkpoint_format_round_trip(tmp_path):
     th.load_best(m2, p)
     for (k1, v1), (k2, v2) in zip(m1.state_dict().items(), m2.state_dict().items()):
         assert k1 == k2 and torch.equal(v1, v2)
+
+
+def test_call_surface_matches_the_reference_signatures():
+    """SURVEY b-1: every function / constructor of the path keeps the reference's parameters -- same names, same order, same defaults
+    (tests/golden/ref_signatures.json, written from the reference's own files by oracle/gen_golden.py:gen_signatures).  cosa_amd may
+    append keyword parameters of its own (underscore-prefixed switches, `device=`), never rename or reorder the reference's."""
+    import importlib
+    import inspect
+    import json
+    table = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_signatures.json")))
+    for key, ref in table.items():
+        parts = key.split(".")
+        for cut in (2, 3):
+            try:
+                mod = importlib.import_module("cosa_amd." + ".".join(parts[:cut]))
+                break
+            except ModuleNotFoundError:
+                continue
+        obj = mod
+        for a in parts[cut:]:
+            obj = getattr(obj, a)
+        ours = [(n, None if p.default is inspect.Parameter.empty else repr(p.default), p.kind.name)
+                for n, p in inspect.signature(obj).parameters.items() if n != "self"]
+        assert len(ours) >= len(ref), key
+        for (rn, rd, rk), (on, od, ok) in zip(ref, ours):
+            assert rn == on, f"{key}: parameter {on!r} where the reference has {rn!r}"
+            if rk != "VAR_KEYWORD":
+                assert rd == od or (rd is not None and od is not None and eval(rd) == eval(od)), f"{key}.{rn}: default {od} != {rd}"
+        for n, d, kind in ours[len(ref):]:
+            assert d is not None or kind in ("VAR_KEYWORD", "VAR_POSITIONAL"), f"{key}: extra parameter {n!r} without a default"
+
+
+def test_dropin_aliases_resolve_the_reference_import_lines():
+    """dropin/: the reference's import lines (main.py:13-21) resolve to cosa_amd without a patch"""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, 'dropin'); "
+            "import utils.misc as utils; from args import get_parser as a, handle_defaults as b; from args_coco import get_parser as c; "
+            "from dataloaders import build_dataloader; from evaluation_engine import evaluate; from models import build_model; "
+            "from utils import seg_helper, torch_helper; import models.PAR; from utils.rrm_utils import DenseEnergyLoss; "
+            "import cosa_amd; assert seg_helper.cam2mask is cosa_amd.utils.seg_helper.cam2mask and models.PAR.PAR is cosa_amd.models.PAR; print('ok')")
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.strip() == "ok", r.stderr[-2000:]
+
+
+def test_launcher_flag_table_matches_run_scripts():
+    """cosa_amd.args: run_voc.sh / run_coco.sh command lines parse to the reference's effective configuration"""
+    from cosa_amd.args import parse
+    a, changed = parse(["EXP_VOC", "--work_dir", "/tmp/x", "--dataset", "VOC12", "--voc12_root", "/data/VOC2012", "--max_iters", "32000",
+                        "--aux_layer", "-4"])
+    assert (a.max_iters, a.aux_layer, a.num_classes, a.batch_size, a.high_thre, a.warmup_iters, a.eval_iters) == (32000, -4, 21, 2, 0.7, 6000, 2000)
+    assert a.pretrained is True and a.usepar is False and a.pseudo_scales == [1.0, 0.5, 1.5] and set(changed) == {
+        "work_dir", "dataset", "voc12_root", "max_iters", "aux_layer"}
+    c, _ = parse(["EXP_COCO", "--work_dir", "/tmp/x", "--dataset", "COCO", "--coco_root", "/data/coco/"])
+    assert (c.max_iters, c.aux_layer, c.num_classes, c.batch_size, c.high_thre, c.warmup_iters, c.eval_iters) == (60000, -3, 81, 4, 0.65, 10000, 6000)

@@ -1,0 +1,53 @@
+"""The own launcher (`python -m cosa_amd.main`, the reference's main.py:24-433 flag for flag) end to end on a tiny VOC-shaped tree:
+torchrun with one rank (RCCL world of one), ten iterations with every loss live after the warm-up, two evaluation rounds, best-checkpoint
+selection, final validation from the reloaded best_seg.pth."""
+import os
+import shutil
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("usepar", ["false", "true"])
+def test_launcher_trains_evaluates_and_reloads(tmp_path, make_voc_tree, usepar):
+    from PIL import Image
+    root, lists, names, labels = make_voc_tree(tmp_path, n=6)
+    os.makedirs(f"{root}/SegmentationClassAug")
+    for n in names:
+        im = np.asarray(Image.open(f"{root}/JPEGImages/{n}.jpg"))
+        Image.fromarray((im[..., 0] // 13).astype(np.uint8)).save(f"{root}/SegmentationClassAug/{n}.png")
+    shutil.copy(f"{lists}/train_aug.txt", f"{lists}/val.txt")
+    work = str(tmp_path / "work")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), "-m", "cosa_amd.main", "EXP_T", "--work_dir", work, "--dataset", "VOC12", "--voc12_root", root,
+           "--name_list_dir", lists, "--max_iters", "10", "--warmup_iters", "3", "--eval_iters", "5", "--log_iters", "5", "--aux_layer", "-4",
+           "--crop_size", "64", "--batch_size", "2", "--num_workers", "0", "--pretrained", "false", "--usepar", usepar]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    out = os.path.join(work, "EXP_T")
+    assert "Iter: 5;" in r.stdout and "Iter: 10;" in r.stdout and "Final Model Result:" in r.stdout, r.stdout[-3000:]
+    assert f"'usepar': {usepar == 'true'}" in r.stdout or "usepar" in r.stdout
+    for f in ("best_seg.pth", "best_cam.pth", "log_val.txt", "loss_dataframe.pt"):
+        assert os.path.exists(os.path.join(out, f)), f
+    ck = torch.load(os.path.join(out, "best_seg.pth"), map_location="cpu", weights_only=False)
+    assert set(ck) == {"s_or_t", "model", "epoch", "args", "result"} and ck["s_or_t"] in ("s", "t") and ck["epoch"] in (5, 10)
+    assert "encoder.blocks.0.attn.qkv.weight" in ck["model"] and "decoder.conv8.weight" in ck["model"] and "classifier.weight" in ck["model"]
+    df = torch.load(os.path.join(out, "loss_dataframe.pt"), weights_only=False)
+    assert df["iters"] == [5, 10] and all(np.isfinite(v) for k in df for v in df[k])
+    assert df["seg_loss"][1] > 0 and df["cam_loss"][1] > 0                       # post-warm-up iterations: every loss live
+    log = open(os.path.join(out, "log_val.txt")).read()
+    assert log.count("ON model") == 2 and log.count("AN model") == 2 and "Final Model Result" in log

@@ -1,0 +1,57 @@
+"""Two-rank rehearsal of the REAL trainer (CoSATrainer with DistributedDataParallel) for tests/test_distributed_gpu.py.
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P tools/ddp_check.py --out DIR ...
+    python tools/ddp_check.py --single --out DIR ...          (one process, the two ranks' batches concatenated)
+
+Backend: $COSA_DIST_BACKEND (default nccl == RCCL; the one-GPU boxes rehearse with gloo, both ranks on card 0).  Every rank runs `--steps`
+training steps on its own synthetic shard (seed 100 + rank) and saves its student and teacher parameters."""
+import argparse
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", required=True)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--crop", type=int, default=64)
+    ap.add_argument("--batch", type=int, default=2)
+    ap.add_argument("--n-iter", type=int, default=1, help="iteration number passed to the step (<= warmup_iters: classification losses only)")
+    ap.add_argument("--single", action="store_true")
+    ap.add_argument("--ranks", type=int, default=2, help="--single: how many ranks' shards to concatenate")
+    opt = ap.parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1")) if not opt.single else 1
+    rank = int(os.environ.get("RANK", "0")) if not opt.single else 0
+    ndev = torch.cuda.device_count()
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")) % max(ndev, 1))
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = os.environ.get("COSA_DIST_BACKEND", "nccl")
+        dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
+    from cosa_amd.train_step import CoSATrainer, default_args, synthetic_batch
+    shards = [synthetic_batch(opt.batch, opt.crop, 20, dev, seed=100 + r) for r in (range(opt.ranks) if opt.single else [rank])]
+    wimg, simg, lab = (torch.cat([s[i] for s in shards]) for i in range(3))
+    box = torch.cat([s[3] for s in shards])
+    args = default_args("VOC12", crop_size=opt.crop, batch_size=wimg.shape[0], teacher_graph=False, lr=1e-3)
+    tr = CoSATrainer(args, dev, ddp=world > 1, seed=0)
+    for _ in range(opt.steps):
+        logs = tr.step(wimg, simg, lab, box, n_iter=opt.n_iter)
+    torch.cuda.synchronize()
+    os.makedirs(opt.out, exist_ok=True)
+    state = {"student": {k: v.detach().cpu() for k, v in tr.student.named_parameters()},
+             "teacher": {k: v.detach().cpu() for k, v in tr.model_AN.named_parameters()},
+             "loss": float(logs["overall_loss"]), "world": dist.get_world_size() if world > 1 else 1}
+    torch.save(state, os.path.join(opt.out, "single.pt" if opt.single else f"rank{rank}.pt"))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
