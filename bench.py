@@ -172,7 +172,21 @@ def par_refine_ms_per_img(trainer, simg, lab, box, dev, opt, C):
     s = S // 2
     alg = 4.0 * s * s * (3 + 2 * K * 10) * 4 * b            # bytes of the 4 PAR calls per image (main/aux x hi/lo), BASELINE.md §2
     per_pass = (t1 - t0) * 1e-3
-    return {"ms_per_img": round((t1 - t0) / b, 5), "cam2mask_no_par_ms_per_img": round(t0 / 2 / b, 5), "mean_K": round(K, 2),
+    # bilateral (dense-energy regulariser) roofline, SURVEY d-3: compulsory I/O 4 (S/2)^2 (3 + 2 K) bytes per image (image once, K planes in
+    # and out) over the forward + backward time; the lattice's own gather / scatter traffic is reported from the committed PMC passes
+    comp = 4.0 * s * s * (3 + 2 * (C + 1))
+    bil = {"fwd_bwd_ms_per_img": round(tb / b, 5), "noise_images_fwd_bwd_ms_per_img": round(tbn / b, 5),
+           "roofline": {"bound": "hbm", "achieved": round(comp * b / (tb * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                        "frac": round(comp * b / (tb * 1e-3) / 8e12, 5), "compulsory_MB_per_img": round(comp / 1e6, 2), "traffic": None,
+                        "note": "gather / scatter through a hashed 5-D lattice: bound by memory-side float atomics (splat) and random row "
+                                "gathers (blur, slice), not by the compulsory bytes"}}
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_lattice_pmc.json")))
+        bil["roofline"]["traffic"] = pmc.get("hbm_bytes_per_forward_backward")
+        bil["roofline"]["traffic_source"] = "profiles/r02_lattice_pmc.json"
+    except Exception:
+        pass
+    return {"bilateral": bil, "ms_per_img": round((t1 - t0) / b, 5), "cam2mask_no_par_ms_per_img": round(t0 / 2 / b, 5), "mean_K": round(K, 2),
             "separate_calls_ms_per_img": round((t1s - t0s) / b, 5),
             "bilateral_fwd_bwd_ms_per_img": round(tb / b, 5),
             "noise_images": {"par_ms_per_img": round((t1n - t0) / b, 5), "bilateral_fwd_bwd_ms_per_img": round(tbn / b, 5)},
@@ -410,6 +424,7 @@ def main():
             out["vit_forward"] = vf
         out["config"]["teacher_operands"] = opt.teacher_precision
         out["par_refine"] = par_refine_ms_per_img(trainer, simg, lab, box, dev, opt, C)
+        out["bilateral"] = out["par_refine"].pop("bilateral")
         if world == 1 and not opt.no_parity_grade and opt.teacher_precision != "bf16x3":
             out["parity_grade"] = parity_grade(opt, dev, C, wimg, simg, lab, box, n_iter)
         if world == 1 and opt.crop == 448:

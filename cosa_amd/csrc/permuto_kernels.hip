@@ -168,6 +168,12 @@ __global__ __launch_bounds__(256) void lattice_build_kernel(const float *__restr
         if (!pack_key(key, pk)) bad = true;
         unsigned s = (unsigned)hmix(pk) & P.cap_mask;
         for (;;) {
+            // test before test-and-set: a slot only ever goes kEmpty -> key, so a plain (possibly stale) load can at worst still show
+            // kEmpty, in which case the CAS below decides.  On smooth images ~13 pixels share a lattice point (M/N = 0.08): most
+            // attempts end here with an L2 hit instead of a memory-side 64-bit atomic on a contended address.
+            const unsigned long long seen = __builtin_nontemporal_load(&keys[s]);
+            if (seen == pk) break;
+            if (seen != kEmpty) { s = (s + 1) & P.cap_mask; continue; }
             const unsigned long long prev = atomicCAS(&keys[s], kEmpty, pk);
             if (prev == kEmpty) {
                 const int id = atomicAdd(Mp, 1);

@@ -52,7 +52,7 @@ def init_distributed_mode(args):
 
 def _trainer_args(args):
     """the parsed flags + the build's own switches (compute dtype, fused paths) in the form CoSATrainer reads"""
-    return default_args(args.dataset, **{k: v for k, v in vars(args).items()})
+    return default_args(args.dataset, **{k: v for k, v in vars(args).items() if k != "dataset"})
 
 
 def main(args):
@@ -99,8 +99,9 @@ def main(args):
         with torch.no_grad():                                                     # main.py:257-268, without the per-iteration .item() syncs
             ap, ok = torch_helper.average_precision(cls_label, torch.sigmoid(logs["cls_logits"].float()))
             apa, oka = torch_helper.average_precision(cls_label, torch.sigmoid(logs["cls_aux_logits"].float()))
-            acc += torch.stack([logs['overall_loss'], logs['cls_loss'], (ap * ok).sum() / ok.sum().clamp_min(1), logs['cls_aux_loss'],
-                                (apa * oka).sum() / oka.sum().clamp_min(1), logs['seg_loss'], logs['cam_loss'], logs['reg_loss']]).double()
+            acc += torch.stack([t.reshape(()).double() for t in (
+                logs['overall_loss'], logs['cls_loss'], (ap * ok).sum() / ok.sum().clamp_min(1), logs['cls_aux_loss'],
+                (apa * oka).sum() / oka.sum().clamp_min(1), logs['seg_loss'], logs['cam_loss'], logs['reg_loss'])])
         if (n_iter + 1) % args.log_iters == 0:
             vals = (acc / args.log_iters).tolist()                                # the one host sync of the interval
             acc.zero_()

@@ -42,6 +42,7 @@ def default_args(dataset="VOC12", **over):
     elif dataset == "COCO":
         a.update(num_classes=81, batch_size=4, max_iters=60000, warmup_iters=10000, high_thre=0.65)   # args_coco.py
     a.update(over)
+    a["dataset"] = dataset
     return SimpleNamespace(**a)
 
 
