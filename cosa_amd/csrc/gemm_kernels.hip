@@ -83,27 +83,57 @@ template <int EPI, int SPLIT = 0>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const op16 *__restrict__ X, const op16 *__restrict__ W,
                                                           const op16 *__restrict__ bias, const float *__restrict__ R,
                                                           void *__restrict__ Yv, int M, int N, int K, int tiles_m, int tiles_n,
-                                                          int ld, int ldy, void *__restrict__ Y2v)
+                                                          int ld, int ldy, void *__restrict__ Y2v, int tail_o0 = -1)
 {
     // SPLIT: K is the LOGICAL contraction length; operand rows have stride ld = 2K + 64, 16-bit outputs go to [hi | lo] rows of stride ldy
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    // XCD-aware remap (bijective): consecutive ids of one XCD walk the n-tiles of one m-panel
-    const int nwg = tiles_m * tiles_n;
-    int wg = blockIdx.x;
-    {
-        const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7, idx = wg >> 3;
-        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    int m0, n0;
+    if (tail_o0 >= 0) {
+        // tail of the persistent kernel's job list (cosa_gemm_bf16): job o = tail_o0 + blockIdx.x / 4 of ITS enumeration (tiles_m x tiles_n
+        // are its 256 x 256 tile counts here), one 128 x 128 quarter per workgroup
+        const int ntl = tiles_m * tiles_n, cq = ntl >> 3, cr = ntl & 7;
+        const int o = tail_o0 + ((int)blockIdx.x >> 2), sub = blockIdx.x & 3;
+        const int xcd = o & 7, idx = o >> 3;
+        const int t = (xcd < cr ? xcd * (cq + 1) : cr * (cq + 1) + (xcd - cr) * cq) + idx;
+        const int tm = t / tiles_n;
+        m0 = tm * 256 + (sub >> 1) * BM;
+        n0 = (t - tm * tiles_n) * 256 + (sub & 1) * BN;
+        if (m0 >= M) return;                                            // lower half of a partial last m-panel
+    } else {
+        // XCD-aware remap (bijective): consecutive ids of one XCD walk the n-tiles of one m-panel
+        const int nwg = tiles_m * tiles_n;
+        int wg = blockIdx.x;
+        {
+            const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7, idx = wg >> 3;
+            wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        }
+        const int tm = wg / tiles_n, tn = wg - tm * tiles_n;
+        m0 = tm * BM;
+        n0 = tn * BN;
     }
-    const int tm = wg / tiles_n, tn = wg - tm * tiles_n;
-    const int m0 = tm * BM, n0 = tn * BN;
     const int wr = wave >> 1, wc = wave & 1;        // wave tile: n-rows [wr*64,+64) x m-cols [wc*64,+64)
 
     f32x4 acc[4][4];
+    const bool tail = tail_o0 >= 0;
+    // tail mode reproduces the persistent kernel's summation order bit for bit (its jobs and these must be interchangeable: a token's
+    // result may not depend on which of the two computed it): the accumulation STARTS from the bias (bf16 out) or from the fp32 residual
+    // tile (residual epilogue, bias added last), then the products in ascending k
 #pragma unroll
     for (int i = 0; i < 4; i++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < 4; j++) {
+            acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (tail) {
+                const int nl = (wave >> 1) * 64 + 16 * i + 4 * (lane >> 4), ml = (wave & 1) * 64 + 16 * j + (lane & 15);
+                if (EPI == EPI_RESIDUAL) {
+                    if (m0 + ml < M) acc[i][j] = *reinterpret_cast<const f32x4 *>(R + (size_t)(m0 + ml) * N + n0 + nl);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) acc[i][j][r] = (float)bias[n0 + nl + r];
+                }
+            }
+        }
 
     const int Kp = K / BK;
     const int nk = SPLIT == 1 ? 3 * Kp + 1 : Kp;
@@ -150,7 +180,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const op16 *__restric
         const int nl = wr * 64 + 16 * i + 4 * fq;
         float bv[4];
 #pragma unroll
-        for (int r = 0; r < 4; r++) bv[r] = (float)bias[n0 + nl + r];
+        for (int r = 0; r < 4; r++) bv[r] = (tail && EPI != EPI_RESIDUAL) ? 0.0f : (float)bias[n0 + nl + r];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int ml = wc * 64 + 16 * j + frow;
@@ -189,8 +219,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const op16 *__restric
             if (m0 + ml < M) {
                 const f32x4 v = *reinterpret_cast<const f32x4 *>(Ct + ml * (BN * 4 + 16) + s * 16);
                 const size_t o = (size_t)(m0 + ml) * N + n0 + s * 4;
-                const f32x4 rv = *reinterpret_cast<const f32x4 *>(R + o);
-                *reinterpret_cast<f32x4 *>(Y + o) = v + rv;
+                if (tail) {
+                    *reinterpret_cast<f32x4 *>(Y + o) = v;                       // the residual is already in the accumulators
+                } else {
+                    const f32x4 rv = *reinterpret_cast<const f32x4 *>(R + o);
+                    *reinterpret_cast<f32x4 *>(Y + o) = v + rv;
+                }
             }
         }
     } else {
@@ -883,7 +917,7 @@ template <int EPI, int ABL6 = 0, int AUX = 0, int SPLIT = 0>
 __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__restrict__ X, const op16 *__restrict__ W,
                                                              const op16 *__restrict__ bias, const float *__restrict__ R,
                                                              void *__restrict__ Yv, int M, int N, int K, int tiles_m, int tiles_n,
-                                                             int stagger_ticks, unsigned long long *__restrict__ stamps, int ld, int ldy, void *__restrict__ Y2v)
+                                                             int stagger_ticks, unsigned long long *__restrict__ stamps, int ld, int ldy, void *__restrict__ Y2v, int ntiles_run)
 {
     // optional device-side span of this launch (100 MHz wall clock; min start / max end over workgroups): HIP events cannot be
     // recorded inside a captured hipGraph on ROCm, so bench.py's roofline leg reads these (cosa_gemm_set_stamp_slot)
@@ -974,7 +1008,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
     }
     int m0, n0, m1 = 0, n1 = 0;
     tile_of(o, m0, n0);
-    bool has_next = o + G < ntiles;
+    bool has_next = o + G < ntiles_run;      // (ntiles_run <= ntiles: the jobs past it are left to a tail launch, cosa_gemm_bf16)
     if (has_next) tile_of(o + G, m1, n1);
     __amdgpu_buffer_rsrc_t cX = descX(m0), cW = descW(n0), cY = descY(m0, n0), pY = cY;
     __amdgpu_buffer_rsrc_t cY2 = SPLIT == 2 ? descY2(m0, n0) : cY, pY2 = cY2;
@@ -1214,7 +1248,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
         cY = descY(m0, n0);
         if (SPLIT == 2) cY2 = descY2(m0, n0);
         cR = nR;
-        has_next = o + G < ntiles;
+        has_next = o + G < ntiles_run;
         if (has_next) {
             tile_of(o + G, m1, n1);
             nX = descX(m1);
@@ -1678,13 +1712,30 @@ static int launch_v6(const op16 *x, const op16 *w, const op16 *b, const float *r
     const int tiles_m = (M + 255) / 256, tiles_n = N / 256;
     const int ntiles = tiles_m * tiles_n;
     const int grid = ntiles < 256 ? ntiles : 256;          // one persistent workgroup per CU
-    // start stagger (see the kernel): about one job time in 100-MHz ticks, from the job's flops at ~4.3 TFLOP/s per CU
+    // Round quantisation: 256 workgroups walk ntiles jobs, so ntiles = 4 * 256 + 8 (the N = 768 projections of a training step: 1032) costs
+    // FIVE rounds, the last with 8 busy CUs.  When the remainder is small, the persistent kernel stops after the full rounds and the
+    // leftover 256 x 256 jobs run as 128 x 128 quarters on the two-stage kernel (4 workgroups per job, 2 per CU): a few per cent of a
+    // round instead of a whole one.  Same products, same fp32 accumulation order per output element (k ascending) as the jobs it replaces.
+    static const int tail_max = [] { const char *e = getenv("COSA_GEMM_TAIL"); return e ? atoi(e) : 48; }();
+    int run = ntiles;
+    if (SPLIT == 0 && ABL6 == 0 && AUX == 0 && ntiles > 256 && ntiles % 256 != 0 && ntiles % 256 <= tail_max) run = ntiles - ntiles % 256;
+    // start stagger (see the kernel): measured to make no difference, off
     static const char *env = getenv("COSA_GEMM_STAGGER");
-    const int stagger = env ? atoi(env) : 0;               // start stagger (see the kernel): measured to make no difference, off
+    const int stagger = env ? atoi(env) : 0;
     hipLaunchKernelGGL((gemm_bf16_v6_kernel<EPI, ABL6, AUX, SPLIT>), dim3(grid), dim3(512), kLdsBytesV5, st, x, w, b, residual, Y, M, N, K, tiles_m, tiles_n, stagger,
-                       g_gemm_stamp_slot, ld ? ld : K, ldy ? ldy : N, Y2);
+                       g_gemm_stamp_slot, ld ? ld : K, ldy ? ldy : N, Y2, run);
     g_gemm_stamp_slot = nullptr;                            // one-shot
     COSA_LAUNCH_CHECK();
+    if (run < ntiles) {
+        static bool tail_attr = false;
+        if (!tail_attr) {
+            COSA_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_bf16_kernel<EPI, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes));
+            tail_attr = true;
+        }
+        hipLaunchKernelGGL((gemm_bf16_kernel<EPI, 0>), dim3(4 * (ntiles - run)), dim3(256), kLdsBytes, st, x, w, b, residual, Y, M, N, K, tiles_m, tiles_n,
+                           K, N, static_cast<void *>(nullptr), run);
+        COSA_LAUNCH_CHECK();
+    }
     return COSA_OK;
 }
 

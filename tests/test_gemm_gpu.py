@@ -196,3 +196,24 @@ def test_student_linear_own_kernels_vs_torch_autograd(M, N, K, act):
     assert (x.grad.float() - x32.grad).abs().max().item() <= 2 * tol(x32.grad)
     assert (lin.weight.grad - w32.grad).abs().max().item() <= 4e-3 * w32.grad.abs().max().item() + 1e-3
     assert (lin.bias.grad - b32.grad).abs().max().item() <= 4e-3 * b32.grad.abs().max().item() + 1e-3
+
+
+@pytest.mark.parametrize("epi", [0, 1, 2])
+def test_gemm_tail_launch_is_interchangeable_with_persistent_jobs(epi):
+    """M = 66 000, N = 768: 258 x 3 = 774 jobs = 3 full rounds of 256 + 6 -- the six leftover 256 x 256 jobs run as 128 x 128 quarters on
+    the two-stage kernel (launch_v6).  A token's result must not depend on which kernel computed it: rolling the rows of X by half the
+    matrix (every row changes tile, most change kernel) rolls the output and nothing else, bit for bit; and the values match fp32."""
+    from cosa_amd import nn_ops
+    torch.manual_seed(epi)
+    M, N, K = 66000, 768, 768
+    x = torch.randn(M, K, device="cuda").bfloat16()
+    w = (torch.randn(N, K, device="cuda") * K ** -0.5).bfloat16()
+    b = torch.randn(N, device="cuda").bfloat16()
+    r = torch.randn(M, N, device="cuda") if epi == 2 else None
+    sh = 33000 + 128
+    y = nn_ops.gemm_bf16(x, w, b, epi, residual=r.clone() if r is not None else None)
+    y2 = nn_ops.gemm_bf16(x.roll(sh, 0).contiguous(), w, b, epi, residual=r.roll(sh, 0).contiguous() if r is not None else None)
+    assert torch.equal(y2, y.roll(sh, 0))
+    ref = _ref(x, w, b, epi, r)
+    tol = (1e-5 if epi == 2 else 2.0 ** -8) * max(ref.abs().max().item(), 1.0)
+    assert (y.float() - ref).abs().max().item() <= tol
