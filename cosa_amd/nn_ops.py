@@ -532,6 +532,7 @@ class TransposedShadows:
 
 
 _transposed = {}       # id(weight) -> (weight, bf16 W^T)
+_AB_LIB_GEMM = os.environ.get("COSA_STUDENT_LIB_GEMM", "0") == "1"      # A/B switch only: student linears through torch (library GEMMs)
 _zeros16 = {}
 
 
@@ -597,7 +598,7 @@ class LinearShadowFn(Function):
 def linear(x, weight, bias, dtype, act=False):
     """nn.Linear (+ GELU with act=True) on `dtype` operands from fp32 masters.  Training on the GPU with registered shadows (bf16 W, b and
     W^T): LinearShadowFn, every GEMM an own kernel; otherwise (fp32 parity mode, odd shapes) torch."""
-    if torch.is_grad_enabled() and weight.requires_grad and dtype == torch.bfloat16 and x.is_cuda:
+    if torch.is_grad_enabled() and weight.requires_grad and dtype == torch.bfloat16 and x.is_cuda and not _AB_LIB_GEMM:
         ew, eb, et = _shadows.get(id(weight)), _shadows.get(id(bias)), _transposed.get(id(weight))
         if ew is not None and eb is not None and et is not None and ew[0] is weight and eb[0] is bias and et[0] is weight \
                 and _own_gemm_ok(x.numel() // x.shape[-1], weight.shape[0], weight.shape[1]) and weight.shape[0] % 64 == 0 \
