@@ -170,7 +170,10 @@ __global__ __launch_bounds__(256) void lattice_build_kernel(const float *__restr
         for (;;) {
             // test before test-and-set: a slot only ever goes kEmpty -> key, so a plain (possibly stale) load can at worst still show
             // kEmpty, in which case the CAS below decides.  On smooth images ~13 pixels share a lattice point (M/N = 0.08): most
-            // attempts end here with an L2 hit instead of a memory-side 64-bit atomic on a contended address.
+            // attempts end here with an L2 hit instead of a memory-side 64-bit atomic on a contended address (0.85 -> 0.64 ms per
+            // step).  Tried and dropped: de-duplicating a workgroup's 1536 keys in an LDS hash first (1.20 ms) and pre-aggregating the
+            // splat contributions of a workgroup in LDS rows (0.75 vs 0.71 ms) -- both kernels are bound by the latency of random
+            // accesses into the 128-MB table / value rows, which the occupancy lost to the LDS tables (8 -> 3 workgroups per CU) hides.
             const unsigned long long seen = __builtin_nontemporal_load(&keys[s]);
             if (seen == pk) break;
             if (seen != kEmpty) { s = (s + 1) & P.cap_mask; continue; }
