@@ -92,6 +92,7 @@ _SIGS = {
 
 _SIGS.update({
     "cosa_gemm_bf16_dual_gelu": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "cosa_pos_resize": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "cosa_gelu_backward": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_longlong, c_void_p]),
     "cosa_transpose_record_bytes": (c_size_t, []),
     "cosa_transpose_cast_batched": (c_int, [c_void_p, c_int, c_int, c_void_p]),

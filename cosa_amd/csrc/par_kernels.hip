@@ -292,6 +292,76 @@ __global__ __launch_bounds__(256, 3) void par_affinity_v2_kernel(const float *__
     for (int n = 0; n < NN; n++) out[(size_t)n * hw] = exact_div(lg[n], kes) + 0.01f * plan.posw[n];
 }
 
+// affinity, v3: the three image channels of a 16 x 16 pixel tile plus its 24-pixel replicate-clamped halo staged in LDS once (48 KB), every
+// tap an LDS read at a compile-time offset.  The taps of a channel are read three times (sum, variance, logits) instead of being held in 48
+// registers: ~80 VGPRs, six waves per SIMD, no global-load latency inside the arithmetic.  Same operations, same order as the spec.
+struct Dil6a { static constexpr int n = 6; static constexpr int d[6] = {1, 2, 4, 8, 12, 24}; };
+constexpr int kATile = 16, kAHalo = 24, kALW = kATile + 2 * kAHalo;        // 64 x 64 floats per channel
+
+template <typename DIL>
+__global__ __launch_bounds__(256) void par_affinity_v3_kernel(const float *__restrict__ imgs, float *__restrict__ aff,
+                                                             int h, int w, ParPlan plan, int tiles_x)
+{
+    __shared__ float timg[3][kALW * kALW];
+    constexpr int ND = DIL::n, NN = ND * 8;
+    static_assert(DIL::d[ND - 1] <= kAHalo, "every dilation must fit the halo");
+    const int b = blockIdx.y;
+    const int tyi = blockIdx.x / tiles_x, txi = blockIdx.x - tyi * tiles_x;
+    const int y0 = tyi * kATile, x0 = txi * kATile;
+    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+    const int hw = h * w;
+    const float *img = imgs + (size_t)b * 3 * hw;
+    // staging: 4096 elements per channel, 16 per thread; consecutive threads read consecutive columns of a row
+#pragma unroll
+    for (int i = 0; i < (kALW * kALW) / 256; i++) {
+        const int e = tid + 256 * i;
+        const int r = e / kALW, c = e - r * kALW;
+        const int go = clampi(y0 - kAHalo + r, 0, h - 1) * w + clampi(x0 - kAHalo + c, 0, w - 1);
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) timg[ch][e] = img[(size_t)ch * hw + go];
+    }
+    __syncthreads();
+    const int y = y0 + ty, x = x0 + tx;
+    if (y >= h || x >= w) return;
+    const int pix = y * w + x;
+    const int ctr = (ty + kAHalo) * kALW + tx + kAHalo;
+    const ExactRcp k03 = exact_rcp(0.3f), k3 = exact_rcp(3.0f);
+    float lg[NN];
+#pragma unroll
+    for (int n = 0; n < NN; n++) lg[n] = 0.0f;
+#define COSA_AFF_TAP(ch, n) timg[ch][ctr + ((((n) & 7) < 4 ? ((n) & 7) : ((n) & 7) + 1) / 3 - 1) * DIL::d[(n) >> 3] * kALW + ((((n) & 7) < 4 ? ((n) & 7) : ((n) & 7) + 1) % 3 - 1) * DIL::d[(n) >> 3]]
+#pragma unroll 1
+    for (int c = 0; c < 3; c++) {
+        const float cv = timg[c][ctr];
+        float sum = 0.0f;
+#pragma unroll
+        for (int n = 0; n < NN; n++) sum = sum + COSA_AFF_TAP(c, n);
+        const float mean = sum / (float)NN;
+        float var = 0.0f;
+#pragma unroll
+        for (int n = 0; n < NN; n++) { const float dl = COSA_AFF_TAP(c, n) - mean; var = var + dl * dl; }
+        var = var / (float)(NN - 1);
+        const ExactRcp ksd = exact_rcp(__builtin_sqrtf(var) + 1e-8f);
+#pragma unroll
+        for (int n = 0; n < NN; n++) {
+            float q = exact_div(__builtin_fabsf(COSA_AFF_TAP(c, n) - cv), ksd);
+            q = exact_div(q, k03);
+            lg[n] = lg[n] + (-(q * q));
+        }
+    }
+#undef COSA_AFF_TAP
+    float mx = -INFINITY;
+#pragma unroll
+    for (int n = 0; n < NN; n++) { lg[n] = -exact_div(-lg[n], k3); mx = lg[n] > mx ? lg[n] : mx; }
+    float es = 0.0f;
+#pragma unroll
+    for (int n = 0; n < NN; n++) { lg[n] = cosa_expf(lg[n] - mx); es = es + lg[n]; }
+    const ExactRcp kes = exact_rcp(es);
+    float *out = aff + (size_t)b * NN * hw + pix;
+#pragma unroll
+    for (int n = 0; n < NN; n++) out[(size_t)n * hw] = exact_div(lg[n], kes) + 0.01f * plan.posw[n];
+}
+
 // one propagation step; each thread owns one pixel of up to CG live planes.
 template <int CG>
 __global__ __launch_bounds__(256) void par_step_kernel(const float *__restrict__ aff, const float *__restrict__ src,
@@ -845,6 +915,15 @@ int par_launch_affinity(const float *imgs, float *aff, int B, int h, int w, cons
 {
     dim3 grid((h * w + 255) / 256, B);
     static const int v2 = [] { const char *e = getenv("COSA_PAR_AFF_V2"); return e ? atoi(e) : 1; }();
+    static const int v3 = [] { const char *e = getenv("COSA_PAR_AFF_V3"); return e ? atoi(e) : 1; }();
+    bool named = plan.n_dil == Dil6a::n;
+    for (int i = 0; named && i < Dil6a::n; i++) named = plan.dil[i] == Dil6a::d[i];
+    if (named && v3) {
+        const int tiles_x = (w + kATile - 1) / kATile, tiles_y = (h + kATile - 1) / kATile;
+        hipLaunchKernelGGL(par_affinity_v3_kernel<Dil6a>, dim3(tiles_x * tiles_y, B), dim3(256), 0, st, imgs, aff, h, w, plan, tiles_x);
+        COSA_LAUNCH_CHECK();
+        return COSA_OK;
+    }
     if (plan.n_dil == 6 && v2) hipLaunchKernelGGL(par_affinity_v2_kernel<6>, grid, dim3(256), 0, st, imgs, aff, h, w, plan);
     else if (plan.n_dil == 6) hipLaunchKernelGGL(par_affinity_fast_kernel<6>, grid, dim3(256), 0, st, imgs, aff, h, w, plan);
     else if (plan.n_dil == 3) hipLaunchKernelGGL(par_affinity_fast_kernel<3>, grid, dim3(256), 0, st, imgs, aff, h, w, plan);

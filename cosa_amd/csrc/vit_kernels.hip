@@ -305,10 +305,36 @@ __global__ __launch_bounds__(256) void transpose_cast_kernel(const TransposeRec 
     }
 }
 
+// ---- bicubic resize of the 14 x 14 position grid to the token grid (vit.py:288-291) as a 16-tap gather: the resize is linear in pos_embed
+// with <= 16 non-zero weights per output token (the rows of the interpolation matrix), so it is out[p][c] = sum_t w[p][t] * pe[idx[p][t]][c]
+__global__ __launch_bounds__(256) void pos_resize_kernel(const float *__restrict__ pe, const int *__restrict__ idx, const float *__restrict__ wgt,
+                                                        float *__restrict__ out, int P, int D4)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= P * D4) return;
+    const int p = e / D4, c = e - p * D4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int t = 0; t < 16; t++) {
+        const float w = wgt[p * 16 + t];
+        const float4 v = reinterpret_cast<const float4 *>(pe + (size_t)idx[p * 16 + t] * D4 * 4)[c];
+        acc.x += w * v.x; acc.y += w * v.y; acc.z += w * v.z; acc.w += w * v.w;
+    }
+    reinterpret_cast<float4 *>(out)[e] = acc;
+}
+
 }  // namespace
 }  // namespace cosa
 
 using namespace cosa;
+
+extern "C" int cosa_pos_resize(const float *pe, const int *idx, const float *wgt, float *out, int P, int D, void *stream)
+{
+    COSA_REQUIRE(pe && idx && wgt && out && P > 0 && D > 0 && D % 4 == 0, "cosa_pos_resize: bad arguments (D %% 4 == 0)");
+    hipLaunchKernelGGL(pos_resize_kernel, dim3((P * (D / 4) + 255) / 256), dim3(256), 0, as_stream(stream), pe, idx, wgt, out, P, D / 4);
+    COSA_LAUNCH_CHECK();
+    return COSA_OK;
+}
 
 extern "C" int cosa_gelu_backward(const void *dA, const void *H, void *dH, long long n, void *stream)
 {

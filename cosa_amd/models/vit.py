@@ -112,10 +112,21 @@ class VisionTransformer(nn.Module):
             with torch.no_grad():
                 eye = torch.eye(n0, device=pe.device, dtype=torch.float32).reshape(1, n0, self._size, self._size)
                 mat = F.interpolate(eye, size=(h, w), mode="bicubic", align_corners=False).reshape(n0, h * w).t().contiguous()
-            ent = {"mat": mat}
+                # bicubic: at most 4 x 4 source cells per output token -> the 16 largest-magnitude entries of a row are all its non-zeros
+                wgt, idx = torch.topk(mat.abs(), 16, dim=1)
+                wgt = torch.gather(mat, 1, idx)
+                assert float((mat.abs().sum(1) - wgt.abs().sum(1)).abs().max()) < 1e-6
+            ent = {"mat": mat, "idx": idx.to(torch.int32).contiguous(), "wgt": wgt.contiguous()}
             self._pos_cache[key] = ent
-        with torch.no_grad():      # three tiny kernels; recomputed every pass so a captured graph never holds a stale value
-            grid = ent["mat"] @ pe[0, 1:, :].float()
+        with torch.no_grad():      # recomputed every pass so a captured graph never holds a stale value
+            src = pe[0, 1:, :].float().contiguous()
+            if pe.is_cuda and self.embed_dim % 4 == 0:
+                from .. import _C
+                grid = torch.empty((h * w, self.embed_dim), device=pe.device, dtype=torch.float32)
+                _C.check(_C.lib().cosa_pos_resize(_C.ptr(src), _C.ptr(ent["idx"]), _C.ptr(ent["wgt"]), _C.ptr(grid), h * w, self.embed_dim,
+                                                  _C.stream_ptr()), "cosa_pos_resize")
+            else:
+                grid = ent["mat"] @ src
             return torch.cat((pe[0, :1, :].float(), grid), dim=0).unsqueeze(0).to(dtype)
 
     def prepare_tokens(self, x):
@@ -131,6 +142,9 @@ class VisionTransformer(nn.Module):
             # no-grad (teacher / evaluation): the patch projection on our own MFMA GEMM -- like every other kernel of the CAM / seg
             # path its result for a token does not depend on the batch around it
             tok = nn_ops.gemm_bf16(cols.reshape(B * h * w, -1).contiguous(), wgt.contiguous(), bias.contiguous(), nn_ops.EPI_BIAS).view(B, h * w, -1)
+        elif dt == torch.bfloat16 and x.is_cuda and torch.is_grad_enabled() and self.patch_embed.proj.weight.requires_grad:
+            # training: the same GEMM kernels with autograd (LinearShadowFn on the [768, 3*16*16] view of the conv weight)
+            tok = nn_ops.linear_view2d(cols, self.patch_embed.proj.weight, self.patch_embed.proj.bias, dt)
         else:
             tok = F.linear(cols, wgt, bias)
         cls = nn_ops.cast_param(self.cls_token, dt).expand(B, -1, -1)

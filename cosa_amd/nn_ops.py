@@ -511,15 +511,16 @@ class TransposedShadows:
         import numpy as np
         self.weights = list(weights)
         dev = self.weights[0].device
-        self.t16 = [torch.empty((w.shape[1], w.shape[0]), device=dev, dtype=torch.bfloat16) for w in self.weights]
+        self.t16 = [torch.empty((w.numel() // w.shape[0], w.shape[0]), device=dev, dtype=torch.bfloat16) for w in self.weights]
         rec_dt = np.dtype([("src", "u8"), ("dst", "u8"), ("rows", "i4"), ("cols", "i4"), ("tile0", "i4"), ("tiles_c", "i4")])
         assert rec_dt.itemsize == _C.lib().cosa_transpose_record_bytes()
         rec = np.zeros(len(self.weights), rec_dt)
         tiles = 0
         for i, (w, t) in enumerate(zip(self.weights, self.t16)):
-            assert w.dtype == torch.float32 and w.is_contiguous() and w.dim() == 2
-            tr, tc = (w.shape[0] + 63) // 64, (w.shape[1] + 63) // 64
-            rec[i] = (w.data_ptr(), t.data_ptr(), w.shape[0], w.shape[1], tiles, tc)
+            assert w.dtype == torch.float32 and w.is_contiguous()
+            rows, cols = w.shape[0], w.numel() // w.shape[0]                 # (a conv weight counts as its [out, -1] view)
+            tr, tc = (rows + 63) // 64, (cols + 63) // 64
+            rec[i] = (w.data_ptr(), t.data_ptr(), rows, cols, tiles, tc)
             tiles += tr * tc
             _transposed[id(w)] = (w, t)
         self.total_tiles = tiles
@@ -593,6 +594,17 @@ class LinearShadowFn(Function):
         if ctx.needs_input_grad[1]:
             dw, db = gemm_wgrad(dy2, x2, want_bias=True)
         return dx, dw, db, None, None, None, None
+
+
+def linear_view2d(x, weight, bias, dtype):
+    """nn.Linear with a weight parameter of more than two dimensions used as its [out, -1] view (the patch projection's conv weight):
+    LinearShadowFn when the parameter has registered shadows (bf16 copy and bf16 transposed copy of the 2-D view), torch otherwise"""
+    ew, eb, et = _shadows.get(id(weight)), _shadows.get(id(bias)), _transposed.get(id(weight))
+    w2 = weight.view(weight.shape[0], -1)
+    if ew is not None and eb is not None and et is not None and ew[0] is weight and eb[0] is bias and et[0] is weight \
+            and w2.shape[0] % 128 == 0 and w2.shape[1] % 128 == 0:
+        return LinearShadowFn.apply(x, w2, bias, ew[1].view(w2.shape), eb[1], et[1], False)
+    return F.linear(x, cast_param(weight, dtype).view(w2.shape), cast_param(bias, dtype))
 
 
 def linear(x, weight, bias, dtype, act=False):

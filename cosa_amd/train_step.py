@@ -125,7 +125,7 @@ class CoSATrainer:
         # bf16 W^T copies of the student's block projections (the input-gradient GEMMs run the forward kernel on them)
         self._student_wT = None
         if on:
-            ws = []
+            ws = [self.student.encoder.patch_embed.proj.weight]
             for blk in self.student.encoder.blocks:
                 ws += [blk.attn.qkv.weight, blk.attn.proj.weight, blk.mlp.fc1.weight, blk.mlp.fc2.weight]
             self._student_wT = nn_ops.TransposedShadows(ws)

@@ -236,6 +236,9 @@ int cosa_layernorm(const float *x, const void *gamma, const void *beta, void *y_
  *   cosa_gelu_backward          dH = dA * gelu_erf'(H) (bf16, n % 8 == 0)
  *   cosa_transpose_cast_batched bf16 W^T shadows of the fp32 master weights (one launch for all tensors): the input gradient
  *                               dX = dY W is then cosa_gemm_bf16(dY, W^T, zeros) -- the forward kernel, no second GEMM family   */
+/* vit.py:288-291: bicubic resize of the frozen 14 x 14 position grid to the token grid as a 16-tap gather (idx / wgt [P,16]: the non-zero
+ * entries of the interpolation matrix's rows): out[P, D] fp32 = sum_t wgt[p][t] * pe[idx[p][t]][:]                                 */
+int cosa_pos_resize(const float *pe, const int *idx, const float *wgt, float *out, int P, int D, void *stream);
 int cosa_gemm_bf16_dual_gelu(const void *X, const void *W, const void *bias, void *H, void *A, int M, int N, int K, void *stream);
 int cosa_gelu_backward(const void *dA, const void *H, void *dH, long long n, void *stream);
 size_t cosa_transpose_record_bytes(void);
