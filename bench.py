@@ -384,6 +384,8 @@ def main():
                 return None
             traffic = None
             try:        # HBM bytes of the dominant launch shape from the committed PMC passes (profiles/, separate --pmc runs)
+                if not os.path.exists(os.path.join(ROOT, "profiles", pmc_file)):
+                    pmc_file = pmc_file.replace("r02_", "r01_")
                 pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
                 traffic = {"hbm_bytes": pmc["hbm_bytes_per_launch"], "algorithmic_bytes": pmc["algorithmic_bytes_per_launch"],
                            "launch": pmc["launch"], "source": "profiles/" + pmc_file}
@@ -398,8 +400,8 @@ def main():
                                                                                    " (teacher graph on a side stream: spans include sharing the GPU with the student's forward)"),
                     "hip_event_avg_ms_eager_launches": round(ev_ms / ev_n, 4) if ev_n else None}
         fams = [family(nn_ops.gemm_stamps, "gemm_bf16_v6_kernel (persistent 256x256 MFMA GEMM: qkv / proj+residual / fc1+GELU / fc2+residual)",
-                       "r01_gemm_v6_pmc.json", "gemm_bf16"),
-                family(nn_ops.stamps, "attn_fwd_kernel / attn_fwd2_kernel (fused attention forward)", "r01_attn_fwd_pmc.json", "attn_fwd")]
+                       "r02_gemm_v6_pmc.json", "gemm_bf16"),
+                family(nn_ops.stamps, "attn_fwd_kernel / attn_fwd2_kernel (fused attention forward)", "r02_attn_fwd_pmc.json", "attn_fwd")]
         fams = sorted([f for f in fams if f], key=lambda f: -f["share_of_step"])
         roof = fams[0] if fams else None
         out = {

@@ -183,12 +183,15 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float *__restr
 // ---- narrow heads: Y[M, N<=32] (fp32) = X[M, K] W[N, K]^T -------------------------------------------------------------------
 // The CAM / auxiliary-CAM heads (1x1 conv 768 -> 20|80, models/__init__.py:190-192), LargeFOV's conv8 (512 -> 21|81) and the
 // classification heads are "skinny" GEMMs: a library GEMM pads N to its tile and picks tile / split by the row count, so results
-// move in their last bits with the batch.  Here a wave owns 16 token rows at a time and runs them through the EXACT-fp32 matrix
-// instruction v_mfma_f32_16x16x4_f32 (bit for bit an fmaf chain in k order): X is read once, as whole 128-B lines -- lane (row r, q)
+// move in their last bits with the batch.  Here a workgroup owns 16 token rows and runs them through the EXACT-fp32 matrix
+// instruction v_mfma_f32_16x16x4_f32 (bit for bit an fmaf chain in k order): X is read once, as whole lines -- lane (row r, q)
 // loads the 16 consecutive elements X[r][64j + 16q ..] -- and MFMA step i of a 64-wide k block contracts the elements 16q + i of the
-// four lane quarters; the weights sit in LDS as fp32 with a row stride of K + 1 floats, which makes the matching B-operand reads
-// (lane (col, q) -> W[col][64j + 16q + i]) conflict-free.  HBM-bound on X; the reduction order of a row is fixed, so the result of a
-// token does not depend on the batch around it.  16-bit inputs (bf16 / fp16) are widened on load.
+// four lane quarters.  The 64-wide k blocks are dealt round-robin to the four waves (wave w: blocks w, w + 4, ...), whose partial
+// sums meet in LDS and are added in wave order, so a 16-row group keeps 4 waves' worth of loads in flight and a launch has
+// M / 16 workgroups (12 waves per CU at the benchmark's 12.5k rows) -- the first version kept the weights in 98 KB of LDS (one
+// workgroup per CU, one wave per row group, a serial fill) and took 93 us on a 5 us problem.  The weights (<= 32 x K, <= 96 KB) are
+// read through the same kind of loads (lane (col, q) -> W[col][64j + 16q ..]) and stay L2-resident.  HBM-bound on X; the
+// reduction order of a row is fixed, so the result of a token does not depend on the batch around it.  16-bit inputs are widened.
 typedef float f32x4h __attribute__((ext_vector_type(4)));
 
 template <typename T>
@@ -212,21 +215,22 @@ __device__ __forceinline__ void head_load16(const T *p, float (&v)[16])
 }
 
 template <typename T, int NB>       // NB: 16-column blocks of the output (1 or 2)
-__global__ __launch_bounds__(256) void head_gemm_kernel(const T *__restrict__ X, const T *__restrict__ W, float *__restrict__ Y,
-                                                       int M, int N, int K, int rows_per_img, long long img_stride, int ldx,
-                                                       int round_bf16, int ldy, int col0)
+__global__ __launch_bounds__(256, 2) void head_gemm_kernel(const T *__restrict__ X, const T *__restrict__ W, float *__restrict__ Y,
+                                                          int M, int N, int K, int rows_per_img, long long img_stride, int ldx,
+                                                          int round_bf16, int ldy, int col0)
 {
-    extern __shared__ __attribute__((aligned(16))) float wl[];            // [16 * NB][K + 1] fp32, rows >= N are zero
+    __shared__ f32x4h part[3][NB][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int S = K + 1;
-    for (int e = tid; e < 16 * NB * K; e += 256) {
-        const int n = e / K, k = e - n * K;
-        wl[n * S + k] = n < N ? (float)W[(size_t)n * K + k] : 0.f;
-    }
-    __syncthreads();
     const int r = lane & 15, q = lane >> 4;
-    const int groups = (M + 15) >> 4, gstride = gridDim.x * 4;
-    for (int g = blockIdx.x * 4 + wave; g < groups; g += gstride) {
+    const int groups = (M + 15) >> 4, nkb = K >> 6;
+    // weight rows of this lane's output columns; columns >= N read row N - 1 and are dropped at the store
+    const T *wr[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; nb++) {
+        const int col = nb * 16 + r;
+        wr[nb] = W + (size_t)(col < N ? col : N - 1) * K + 16 * q;
+    }
+    for (int g = blockIdx.x; g < groups; g += gridDim.x) {
         int row = g * 16 + r;
         row = row < M ? row : M - 1;
         const int b = row / rows_per_img;
@@ -234,34 +238,53 @@ __global__ __launch_bounds__(256) void head_gemm_kernel(const T *__restrict__ X,
         f32x4h acc[NB];
 #pragma unroll
         for (int nb = 0; nb < NB; nb++) acc[nb] = (f32x4h){0.f, 0.f, 0.f, 0.f};
-        float v[16], vn[16];
-        head_load16(xr, v);
-        for (int k0 = 0; k0 < K; k0 += 64) {
-            if (k0 + 64 < K) head_load16(xr + k0 + 64, vn);
-            const float *wb = wl + r * S + k0 + 16 * q;
+        float v[16], vn[16], w[NB][16], wn[NB][16];
+        if (wave < nkb) {
+            head_load16(xr + wave * 64, v);
+#pragma unroll
+            for (int nb = 0; nb < NB; nb++) head_load16(wr[nb] + wave * 64, w[nb]);
+        }
+        for (int kb = wave; kb < nkb; kb += 4) {
+            if (kb + 4 < nkb) {
+                head_load16(xr + (kb + 4) * 64, vn);
+#pragma unroll
+                for (int nb = 0; nb < NB; nb++) head_load16(wr[nb] + (kb + 4) * 64, wn[nb]);
+            }
 #pragma unroll
             for (int i = 0; i < 16; i++) {
 #pragma unroll
-                for (int nb = 0; nb < NB; nb++)
-                    acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[i], wb[nb * 16 * S + i], acc[nb], 0, 0, 0);
+                for (int nb = 0; nb < NB; nb++) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[i], w[nb][i], acc[nb], 0, 0, 0);
             }
 #pragma unroll
-            for (int i = 0; i < 16; i++) v[i] = vn[i];
+            for (int i = 0; i < 16; i++) {
+                v[i] = vn[i];
+#pragma unroll
+                for (int nb = 0; nb < NB; nb++) w[nb][i] = wn[nb][i];
+            }
         }
-        // C layout: column = lane & 15 (output feature), row = 4 * (lane >> 4) + reg (token)
+        if (wave > 0) {
 #pragma unroll
-        for (int nb = 0; nb < NB; nb++) {
-            const int col = nb * 16 + r;
+            for (int nb = 0; nb < NB; nb++) part[wave - 1][nb][lane] = acc[nb];
+        }
+        __syncthreads();
+        if (wave == 0) {
+            // C layout: column = lane & 15 (output feature), row = 4 * (lane >> 4) + reg (token)
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int orow = g * 16 + 4 * q + j;
-                if (orow < M && col < N) {
-                    float o = acc[nb][j];
-                    if (round_bf16) o = sizeof(T) == 4 ? (float)(bf16)o : (float)(T)o;      // the operand precision (fp32 operands: bf16)
-                    Y[(size_t)orow * ldy + col0 + col] = o;
+            for (int nb = 0; nb < NB; nb++) {
+                const f32x4h t = ((acc[nb] + part[0][nb][lane]) + part[1][nb][lane]) + part[2][nb][lane];
+                const int col = nb * 16 + r;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int orow = g * 16 + 4 * q + j;
+                    if (orow < M && col < N) {
+                        float o = t[j];
+                        if (round_bf16) o = sizeof(T) == 4 ? (float)(bf16)o : (float)(T)o;      // the operand precision (fp32 operands: bf16)
+                        Y[(size_t)orow * ldy + col0 + col] = o;
+                    }
                 }
             }
         }
+        __syncthreads();
     }
 }
 
@@ -372,21 +395,12 @@ extern "C" int cosa_head_gemm(const void *X, const void *W, float *Y, int M, int
     COSA_REQUIRE(dtype >= 0 && dtype <= 2, "cosa_head_gemm: dtype 0 (fp32), 1 (bf16) or 2 (fp16)");
     COSA_REQUIRE(ldx % (dtype == 0 ? 4 : 8) == 0 && img_stride % (dtype == 0 ? 4 : 8) == 0, "cosa_head_gemm: rows must be 16-byte aligned");
     const int nb = N <= 16 ? 1 : 2;
-    const size_t lds = (size_t)16 * nb * (K + 1) * sizeof(float);
-    COSA_REQUIRE(lds <= 150 * 1024, "cosa_head_gemm: weight does not fit the LDS");
     hipStream_t st = as_stream(stream);
-    int blocks = ((M + 15) / 16 + 3) / 4;
-    blocks = blocks > 1024 ? 1024 : blocks;
+    int blocks = (M + 15) / 16;
+    blocks = blocks > 8192 ? 8192 : blocks;
 #define COSA_HEAD_LAUNCH(T, NB)                                                                                                   \
-    do {                                                                                                                          \
-        static size_t attr = 0;                                                                                                   \
-        if (lds > attr) {                                                                                                         \
-            COSA_HIP_CHECK(hipFuncSetAttribute((const void *)head_gemm_kernel<T, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-            attr = lds;                                                                                                           \
-        }                                                                                                                         \
-        hipLaunchKernelGGL((head_gemm_kernel<T, NB>), dim3(blocks), dim3(256), lds, st, static_cast<const T *>(X), static_cast<const T *>(W), Y, M, N, \
-                           K, rows_per_img, img_stride, ldx, round_bf16, ldy, col0);                                              \
-    } while (0)
+    hipLaunchKernelGGL((head_gemm_kernel<T, NB>), dim3(blocks), dim3(256), 0, st, static_cast<const T *>(X), static_cast<const T *>(W), Y, M, N, \
+                       K, rows_per_img, img_stride, ldx, round_bf16, ldy, col0)
     if (dtype == 0) { if (nb == 1) COSA_HEAD_LAUNCH(float, 1); else COSA_HEAD_LAUNCH(float, 2); }
     else if (dtype == 1) { if (nb == 1) COSA_HEAD_LAUNCH(bf16, 1); else COSA_HEAD_LAUNCH(bf16, 2); }
     else { if (nb == 1) COSA_HEAD_LAUNCH(_Float16, 1); else COSA_HEAD_LAUNCH(_Float16, 2); }

@@ -1,0 +1,23 @@
+"""N training steps of the bench configuration and nothing else (for rocprofv3 --kernel-trace --stats: per-step kernel shares without bench.py's
+extra legs).  usage: python tools/step_only.py [steps=10] [teacher_precision=bf16]; the first 4 steps are set-up (graph capture)."""
+import os, sys, json, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from cosa_amd.train_step import CoSATrainer, default_args, synthetic_batch
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+prec = sys.argv[2] if len(sys.argv) > 2 else "bf16"
+dev = torch.device("cuda", 0)
+args = default_args("VOC12", crop_size=448, batch_size=16, teacher_precision=prec, teacher_async=os.environ.get("COSA_TEACHER_SYNC") is None)
+tr = CoSATrainer(args, dev, seed=0)
+wimg, simg, lab, box = synthetic_batch(16, 448, 20, dev, seed=1234)
+n_iter = args.warmup_iters + 1
+for _ in range(4):
+    tr.step(wimg, simg, lab, box, n_iter)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(steps):
+    tr.step(wimg, simg, lab, box, n_iter)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / steps
+print(json.dumps({"ms_per_step": round(dt * 1e3, 3), "images_per_s": round(16 / dt, 2), "steps": steps, "setup_steps": 4, "teacher": prec}))
