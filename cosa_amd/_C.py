@@ -81,6 +81,9 @@ _SIGS = {
     "cosa_conv3x3_dilated_nhwc": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 10 + [c_void_p]),
     "cosa_head_gemm": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, ctypes.c_longlong, c_int, c_int, c_int, c_int,
                                c_int, c_void_p]),
+    "cosa_head_gemm_dgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "cosa_head_gemm_wgrad_workspace": (c_size_t, [c_int, c_int]),
+    "cosa_head_gemm_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "cosa_conv3x3_dilated_wgrad": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 10 + [c_void_p]),
     "cosa_gemm_set_variant": (None, [c_int]),
     "cosa_gemm_set_stamp_slot": (None, [c_void_p]),

@@ -913,7 +913,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // ABL6 (timing only): 1 = epilogue without the stores, 2 = no epilogue work, 3 = L2-resident store window, 4 = stores dropped
 // SPLIT: bf16x3 operands (see split_tile_x / split_tile_w above): K is the logical contraction length, operand rows have stride ld
 // (= 2K + 64), the K loop has 3K/64 + 1 tiles, 16-bit outputs are written as [hi | lo] halves of rows with stride ldy.
-template <int EPI, int ABL6 = 0, int AUX = 0, int SPLIT = 0>
+template <int EPI, int ABL6 = 0, int AUX = 0, int SPLIT = 0, int FR = 4>
 __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__restrict__ X, const op16 *__restrict__ W,
                                                              const op16 *__restrict__ bias, const float *__restrict__ R,
                                                              void *__restrict__ Yv, int M, int N, int K, int tiles_m, int tiles_n,
@@ -926,6 +926,8 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
     constexpr int ES = RES ? 4 : 2;
     constexpr int ABL = 0;
     constexpr int FL = 0x00020000;
+    static_assert(FR == 4 || (FR == 3 && SPLIT == 0), "FR: 16-feature fragments per wave and W half (tile width 64 FR)");
+    constexpr int TN = 64 * FR, HN = 32 * FR, WN = 16 * FR;     // features per tile / per W half / per wave inside a half
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wr = wave >> 2, wc = wave & 3;
@@ -941,14 +943,14 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
         const int t = (xcd < cr ? xcd * (cq + 1) : cr * (cq + 1) + (xcd - cr) * cq) + idx;
         const int tm = t / tiles_n;
         m0_ = tm * 256;
-        n0_ = (t - tm * tiles_n) * 256;
+        n0_ = (t - tm * tiles_n) * TN;
     };
     auto descX = [&](int m0_) {
         int rows = M - m0_;
         rows = rows > 256 ? 256 : rows;
         return __builtin_amdgcn_make_buffer_rsrc((void *)(X + (size_t)m0_ * ld), 0, rows * ld * 2, FL);
     };
-    auto descW = [&](int n0_) { return __builtin_amdgcn_make_buffer_rsrc((void *)(W + (size_t)n0_ * ld), 0, 256 * ld * 2, FL); };
+    auto descW = [&](int n0_) { return __builtin_amdgcn_make_buffer_rsrc((void *)(W + (size_t)n0_ * ld), 0, TN * ld * 2, FL); };
     // SPLIT == 2 ("dual", EPI_GELU only): the pre-activation goes to Y and gelu(.) to Y2 (same [M, N] geometry): the training forward of
     // mlp.fc1 keeps the pre-activation for GELU' without a second pass over it (models/vit/vit.py:96-102 and its autograd)
     auto descY2 = [&](int m0_, int n0_) {
@@ -972,14 +974,20 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
     };
     const __amdgpu_buffer_rsrc_t dead = __builtin_amdgcn_make_buffer_rsrc((void *)X, 0, 0, FL);   // every access out of range
 
-    // job-independent per-lane offsets: DMA source inside a 256-row operand panel (same for X and W) ...
-    unsigned vo[2][2];
+    // job-independent per-lane offsets: DMA source inside a 256-row operand panel (same for X and W when FR == 4) ...
+    // FR == 3: a W half has 96 rows; the DMA slots of rows 96 .. 127 of a half get an out-of-range offset (nothing fetched, zeros land
+    // in LDS rows that no fragment read touches), so that every wave still issues the same number of VMEM operations
+    unsigned vo[2][2], voW[2][2];
     {
         const int sw = ((lane & 7) ^ (lane >> 3)) * 8;
 #pragma unroll
         for (int h = 0; h < 2; h++)
 #pragma unroll
-            for (int i = 0; i < 2; i++) vo[h][i] = (unsigned)(((h * 128 + 8 * (2 * wave + i) + (lane >> 3)) * ld + sw) * 2);
+            for (int i = 0; i < 2; i++) {
+                const int rl = 8 * (2 * wave + i) + (lane >> 3);
+                vo[h][i] = (unsigned)(((h * 128 + rl) * ld + sw) * 2);
+                voW[h][i] = FR == 4 ? vo[h][i] : (rl < HN ? (unsigned)(((h * HN + rl) * ld + sw) * 2) : 0x7ffff000u);
+            }
     }
     // ... and the store offset inside the tile's Y window for each 16-token row group (b, jj); after the lane swap a lane
     // owns features  wr*64 + pair*32 + (fq&1)*16 + 4*(fq&2) .. +7  of its token
@@ -988,8 +996,10 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
 #pragma unroll
     for (int g4 = 0; g4 < 4; g4++) {
         const int row = (g4 >> 1) * 128 + wc * 32 + (g4 & 1) * 16 + frow;
-        voY[g4] = RES ? (unsigned)((row * ldy + wr * 64 + 4 * fq) * 4) : (unsigned)((row * ldy + wr * 64 + (fq & 1) * 16 + 4 * (fq & 2)) * 2);
+        voY[g4] = RES ? (unsigned)((row * ldy + wr * WN + 4 * fq) * 4) : (unsigned)((row * ldy + wr * WN + (fq & 1) * 16 + 4 * (fq & 2)) * 2);
     }
+    // FR == 3, 16-bit output: the third fragment of a wave has no partner to swap with; its lane keeps features 4fq .. 4fq + 3 (8-byte stores)
+    const unsigned voY3 = (unsigned)((32 + 4 * fq - (fq & 1) * 16 - 4 * (fq & 2)) * 2);
 
     int o = blockIdx.x;
     // Optional start stagger (experiment, off by default): workgroups that have one job fewer than the busiest ones start
@@ -1023,10 +1033,10 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
     // bias of the job about to start, as packed op16: features a*128 + wr*64 + ii*16 + 4fq .. +3.  Loaded by hand (inline asm) so
     // that the compiler does not put its own vmcnt wait in front of the first use: the phase-4 waits cover these loads.
     u32x2 bb[2][4];
-    const unsigned bias_lane = (unsigned)((wr * 64 + 4 * fq) * 2);        // scalar base + 32-bit lane offset: no 64-bit per-lane pointer to keep alive
+    const unsigned bias_lane = (unsigned)((wr * WN + 4 * fq) * 2);        // scalar base + 32-bit lane offset: no 64-bit per-lane pointer to keep alive
 #define V6_LOAD_BIAS(nbase)                                                                               \
-    _Pragma("unroll") for (int a_ = 0; a_ < 2; a_++) _Pragma("unroll") for (int i_ = 0; i_ < 4; i_++) {   \
-        const op16 *p_ = bias + (nbase) + a_ * 128 + i_ * 16;                                             \
+    _Pragma("unroll") for (int a_ = 0; a_ < 2; a_++) _Pragma("unroll") for (int i_ = 0; i_ < FR; i_++) {  \
+        const op16 *p_ = bias + (nbase) + a_ * HN + i_ * 16;                                              \
         asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(bb[a_][i_]) : "v"(bias_lane), "s"(p_) : "memory"); \
     }
 
@@ -1039,17 +1049,17 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
         const int t_ = own_ ? kt_ : kt_ - nk;                                                                          \
         const int so_ = (SPLIT == 1 ? (((which) & 1) ? split_tile_w(t_, Kp) : split_tile_x(t_, Kp)) : t_) * 128;            \
         unsigned char *dst_ = smem + (bsel) * V5_BUF + (which) * V5_HALF + (2 * wave) * 1024;                          \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_, (lds_void *)dst_, 16, vo[(which) >> 1][0], so_, 0, 0);           \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_, (lds_void *)(dst_ + 1024), 16, vo[(which) >> 1][1], so_, 0, 0);  \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_, (lds_void *)dst_, 16, ((which) & 1) ? voW[(which) >> 1][0] : vo[(which) >> 1][0], so_, 0, 0);           \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_, (lds_void *)(dst_ + 1024), 16, ((which) & 1) ? voW[(which) >> 1][1] : vo[(which) >> 1][1], so_, 0, 0);  \
     } while (0)
 
     f32x4 acc[8][4];
     // residual: the accumulators of a quadrant START as the residual tile (so the epilogue has no loads).  The loads are
     // issued by hand right after the quadrant's previous contents were stored, two to three phases before its first MFMA.
 #define V6_RLOAD(qa, qb, rsR)                                                                                        \
-    _Pragma("unroll") for (int ii = 0; ii < 4; ii++) _Pragma("unroll") for (int jj = 0; jj < 2; jj++)                \
+    _Pragma("unroll") for (int ii = 0; ii < FR; ii++) _Pragma("unroll") for (int jj = 0; jj < 2; jj++)               \
         asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(acc[(qa) * 4 + ii][(qb) * 2 + jj])           \
-                     : "v"(voY[(qb) * 2 + jj]), "s"(rsR), "s"(((qa) * 128 + ii * 16) * 4) : "memory");
+                     : "v"(voY[(qb) * 2 + jj]), "s"(rsR), "s"(((qa) * HN + ii * 16) * 4) : "memory");
 
     // pipeline fill (first job only): bias, [residual tile,] K-tile 0 complete, X0 W0 X1 of K-tile 1
     V6_LOAD_BIAS(n0);
@@ -1072,12 +1082,12 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
     if (wr == 1) V5_BARRIER();                         // stagger: the wr = 1 group runs one barrier behind
 
     const int lo0 = frow * 128 + ((fq ^ (frow & 7)) << 4), lo1 = lo0 ^ 64;
-    const unsigned char *rdW0 = smem + V5_HALF + wr * 8192 + lo0, *rdW1 = smem + V5_HALF + wr * 8192 + lo1;
+    const unsigned char *rdW0 = smem + V5_HALF + wr * (WN * 128) + lo0, *rdW1 = smem + V5_HALF + wr * (WN * 128) + lo1;
     const unsigned char *rdX0 = smem + wc * 4096 + lo0, *rdX1 = smem + wc * 4096 + lo1;
     op16x8 a[4][2], x0[2][2], x1[2][2];
 
 #define V6_LDW(q, buf)                                                                     \
-    _Pragma("unroll") for (int blk = 0; blk < 4; blk++) {                                  \
+    _Pragma("unroll") for (int blk = 0; blk < FR; blk++) {                                 \
         const int o_ = (buf) * V5_BUF + (q) * 2 * V5_HALF + blk * 2048;                    \
         a[blk][0] = *reinterpret_cast<const op16x8 *>(rdW0 + o_);                          \
         a[blk][1] = *reinterpret_cast<const op16x8 *>(rdW1 + o_);                          \
@@ -1094,17 +1104,25 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
         _Pragma("unroll") for (int i_ = 0; i_ < 4; i_++) _Pragma("unroll") for (int j_ = 0; j_ < 2; j_++)           \
             asm volatile("" ::"v"(acc[(qa) * 4 + i_][(qb) * 2 + j_]));                                              \
     } else if (RES) {                                                                                               \
-        _Pragma("unroll") for (int ii = 0; ii < 4; ii++) {                                                          \
+        _Pragma("unroll") for (int ii = 0; ii < FR; ii++) {                                                         \
             const unsigned lo_ = bb[qa][ii][0], hi_ = bb[qa][ii][1];                                                \
             const f32x4 bv_ = {op16_lo(lo_), op16_hi(lo_), op16_lo(hi_), op16_hi(hi_)};                              \
             _Pragma("unroll") for (int jj = 0; jj < 2; jj++) {                                                      \
                 const f32x4 o4_ = acc[(qa) * 4 + ii][(qb) * 2 + jj] + bv_;                                          \
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o4_), rsY,                         \
-                                                       voY[(qb) * 2 + jj] + ((qa) * 128 + ii * 16) * 4, 0, AUX);    \
+                                                       voY[(qb) * 2 + jj] + ((qa) * HN + ii * 16) * 4, 0, AUX);     \
             }                                                                                                       \
         }                                                                                                           \
     } else                                                                                                          \
     _Pragma("unroll") for (int jj = 0; jj < 2; jj++) _Pragma("unroll") for (int pr = 0; pr < 2; pr++) {             \
+        if (FR == 3 && pr == 1) {         /* the unpaired third fragment */                                         \
+            f32x4 v2_ = acc[(qa) * 4 + 2][(qb) * 2 + jj];                                                           \
+            if (EPI == EPI_GELU) { _Pragma("unroll") for (int r = 0; r < 4; r++) v2_[r] = gelu_erf(v2_[r]); }       \
+            const op16x2 s0_ = {(op16)v2_[0], (op16)v2_[1]}, s1_ = {(op16)v2_[2], (op16)v2_[3]};                    \
+            const u32x2 o2_ = {__builtin_bit_cast(unsigned, s0_), __builtin_bit_cast(unsigned, s1_)};               \
+            __builtin_amdgcn_raw_buffer_store_b64(o2_, rsY, voY[(qb) * 2 + jj] + voY3 + (qa) * HN * 2, 0, AUX);     \
+            continue;                                                                                               \
+        }                                                                                                           \
         f32x4 v0_ = acc[(qa) * 4 + 2 * pr][(qb) * 2 + jj], v1_ = acc[(qa) * 4 + 2 * pr + 1][(qb) * 2 + jj];        \
         if (SPLIT == 2) {     /* dual: the raw tile first, to Y */                                                   \
             const op16x2 r0_ = {(op16)v0_[0], (op16)v0_[1]}, r1_ = {(op16)v0_[2], (op16)v0_[3]};                    \
@@ -1112,7 +1130,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
             const auto u0_ = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, r0_), __builtin_bit_cast(unsigned, r2_), false, false); \
             const auto u1_ = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, r1_), __builtin_bit_cast(unsigned, r3_), false, false); \
             const u32x4 raw_ = {u0_[0], u1_[0], u0_[1], u1_[1]};                                                    \
-            __builtin_amdgcn_raw_buffer_store_b128(raw_, rsY, voY[(qb) * 2 + jj] + ((qa) * 128 + pr * 32) * 2, 0, AUX); \
+            __builtin_amdgcn_raw_buffer_store_b128(raw_, rsY, voY[(qb) * 2 + jj] + ((qa) * HN + pr * 32) * 2, 0, AUX); \
         }                                                                                                           \
         if (EPI == EPI_GELU) {                                                                                      \
             _Pragma("unroll") for (int r = 0; r < 4; r++) {                                                         \
@@ -1125,8 +1143,8 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
         const auto s0_ = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, p0_), __builtin_bit_cast(unsigned, p2_), false, false); \
         const auto s1_ = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, p1_), __builtin_bit_cast(unsigned, p3_), false, false); \
         const u32x4 out_ = {s0_[0], s1_[0], s0_[1], s1_[1]};                                                        \
-        if (SPLIT == 2) __builtin_amdgcn_raw_buffer_store_b128(out_, (&rsY == &pY) ? pY2 : cY2, voY[(qb) * 2 + jj] + ((qa) * 128 + pr * 32) * 2, 0, AUX); \
-        else if (ABL6 == 0 || ABL6 == 3 || ABL6 == 4) __builtin_amdgcn_raw_buffer_store_b128(out_, rsY, voY[(qb) * 2 + jj] + ((qa) * 128 + pr * 32) * 2, 0, AUX); \
+        if (SPLIT == 2) __builtin_amdgcn_raw_buffer_store_b128(out_, (&rsY == &pY) ? pY2 : cY2, voY[(qb) * 2 + jj] + ((qa) * HN + pr * 32) * 2, 0, AUX); \
+        else if (ABL6 == 0 || ABL6 == 3 || ABL6 == 4) __builtin_amdgcn_raw_buffer_store_b128(out_, rsY, voY[(qb) * 2 + jj] + ((qa) * HN + pr * 32) * 2, 0, AUX); \
         else asm volatile("" ::"v"(out_));                                                                          \
         if (SPLIT == 1) {          /* the lo halves: what the 16-bit rounding above dropped, at column N + n */              \
             const op16x2 q0_ = {(op16)(v0_[0] - (float)p0_[0]), (op16)(v0_[1] - (float)p0_[1])};                    \
@@ -1136,14 +1154,14 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
             const auto t0_ = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, q0_), __builtin_bit_cast(unsigned, q2_), false, false); \
             const auto t1_ = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, q1_), __builtin_bit_cast(unsigned, q3_), false, false); \
             const u32x4 lo4_ = {t0_[0], t1_[0], t0_[1], t1_[1]};                                                    \
-            __builtin_amdgcn_raw_buffer_store_b128(lo4_, rsY, voY[(qb) * 2 + jj] + (N + (qa) * 128 + pr * 32) * 2, 0, AUX); \
+            __builtin_amdgcn_raw_buffer_store_b128(lo4_, rsY, voY[(qb) * 2 + jj] + (N + (qa) * HN + pr * 32) * 2, 0, AUX); \
         }                                                                                                           \
     }
     // 16 MFMAs of quadrant (qa, qb); FIRST: the accumulation starts from the bias
 #define V6_MMA(qa, xf, qb, FIRST)                                                                                   \
     do {                                                                                                            \
         _Pragma("unroll") for (int ks = 0; ks < 2; ks++)                                                            \
-            _Pragma("unroll") for (int i = 0; i < 4; i++) {                                                         \
+            _Pragma("unroll") for (int i = 0; i < FR; i++) {                                                        \
                 f32x4 cb_;                                                                                          \
                 if ((FIRST) && ks == 0 && !RES) {                                                                   \
                     const unsigned lo_ = bb[qa][i][0], hi_ = bb[qa][i][1];                                          \
@@ -1170,6 +1188,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
     //   last.1: DMA(A)        last.2: DMA, st Q00, R' Q00     last.3: DMA, st Q01, R' Q01     last.4: DMA, WAIT(A), st Q11, R' Q11
     //   first.1: DMA(B), WAIT(R' Q00), st Q10, R' Q10, bias     first.2: DMA, WAIT(R' Q01)   first.3: DMA, WAIT(R' Q11)   first.4: DMA, WAIT(B, R' Q10)
     // every WAIT is vmcnt(number of operations issued after its target): op16 out 14 / - / - / - / 6, residual 38 / 38 / 46 / 30 / 6
+    // (residual, FR fragments: 6 + 8 FR / 6 + 8 FR / 6 + 10 FR / 6 + 6 FR / 6 -- 30 / 30 / 36 / 24 / 6 for the 192-wide tile)
     // (6 instead of 14 at first.4 also covers a job without predecessor; operations retire in issue order).
 #define V6_WAIT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define V6_TILE(t, FIRST, LAST)                                                                                     \
@@ -1185,7 +1204,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
         V5_FENCE();                                                                                                 \
         asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");                                                          \
         V6_MSECTION_BEGIN();                                                                                        \
-        if (RES && (FIRST)) { V6_WAIT(38); V5_FENCE(); }                                                            \
+        if (RES && (FIRST)) { if (FR == 4) V6_WAIT(38); else V6_WAIT(30); V5_FENCE(); }                             \
         if ((FIRST) && have_prev) {                                                                                 \
             V6_EPI(1, 0, pY);                                                                                       \
             if (RES) { V5_FENCE(); V6_RLOAD(1, 0, cR); V6_LOAD_BIAS(n0); V5_FENCE(); }                              \
@@ -1196,7 +1215,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
         V6_LDX(x1, 1, b_);                                                                                          \
         V6_STAGE(0, (t) + 2, b_);                                                                                   \
         V6_MSECTION_BEGIN();                                                                                        \
-        if (RES && (FIRST)) { V6_WAIT(46); V5_FENCE(); }                                                            \
+        if (RES && (FIRST)) { if (FR == 4) V6_WAIT(46); else V6_WAIT(36); V5_FENCE(); }                             \
         if (LAST) {                                                                                                 \
             V6_EPI(0, 0, cY);                                                                                       \
             if (RES && has_next) { V5_FENCE(); V6_RLOAD(0, 0, nR); V5_FENCE(); }                                    \
@@ -1207,7 +1226,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
         V6_LDW(1, b_);                                                                                              \
         V6_STAGE(1, (t) + 2, b_);                                                                                   \
         V6_MSECTION_BEGIN();                                                                                        \
-        if (RES && (FIRST)) { V6_WAIT(30); V5_FENCE(); }                                                            \
+        if (RES && (FIRST)) { if (FR == 4) V6_WAIT(30); else V6_WAIT(24); V5_FENCE(); }                             \
         if (LAST) {                                                                                                 \
             V6_EPI(0, 1, cY);                                                                                       \
             if (RES && has_next) { V5_FENCE(); V6_RLOAD(0, 1, nR); V5_FENCE(); }                                    \
@@ -1217,7 +1236,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
         /* ---- phase 4 ---- */                                                                                     \
         V6_STAGE(2, (t) + 2, b_);                                                                                   \
         V5_FENCE();                                                                                                 \
-        if ((LAST) && RES) V6_WAIT(38);                                                                             \
+        if ((LAST) && RES) { if (FR == 4) V6_WAIT(38); else V6_WAIT(30); }                                          \
         else if (LAST) V6_WAIT(14);                                                                                 \
         else V6_WAIT(6);                                                                                            \
         V6_MSECTION_BEGIN();                                                                                        \
@@ -1652,7 +1671,7 @@ static int env_variant()
     const char *e = getenv("COSA_GEMM_VARIANT");
     return e ? atoi(e) : 0;
 }
-static int g_gemm_variant = env_variant();   // 0 = pick per shape (measured, tools/bench_gemm.py); 1..8 force a kernel (experiments)
+static int g_gemm_variant = env_variant();   // 0 = pick per shape (measured, tools/bench_gemm.py); 1..9 force a kernel (experiments; 9 = v6 on 256 x 192 jobs)
 extern "C" void cosa_gemm_set_variant(int v) { g_gemm_variant = v; }
 
 template <int EPI>
@@ -1700,16 +1719,16 @@ static int launch_v5(const op16 *x, const op16 *w, const op16 *b, const float *r
     return COSA_OK;
 }
 
-template <int EPI, int ABL6 = 0, int AUX = 0, int SPLIT = 0>
+template <int EPI, int ABL6 = 0, int AUX = 0, int SPLIT = 0, int FR = 4>
 static int launch_v6(const op16 *x, const op16 *w, const op16 *b, const float *residual, void *Y, int M, int N, int K, hipStream_t st,
                      int ld = 0, int ldy = 0, void *Y2 = nullptr)
 {
     static bool attr_done = false;
     if (!attr_done) {
-        COSA_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_bf16_v6_kernel<EPI, ABL6, AUX, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytesV5));
+        COSA_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_bf16_v6_kernel<EPI, ABL6, AUX, SPLIT, FR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytesV5));
         attr_done = true;
     }
-    const int tiles_m = (M + 255) / 256, tiles_n = N / 256;
+    const int tiles_m = (M + 255) / 256, tiles_n = N / (64 * FR);
     const int ntiles = tiles_m * tiles_n;
     const int grid = ntiles < 256 ? ntiles : 256;          // one persistent workgroup per CU
     // Round quantisation: 256 workgroups walk ntiles jobs, so ntiles = 4 * 256 + 8 (the N = 768 projections of a training step: 1032) costs
@@ -1718,11 +1737,13 @@ static int launch_v6(const op16 *x, const op16 *w, const op16 *b, const float *r
     // round instead of a whole one.  Same products, same fp32 accumulation order per output element (k ascending) as the jobs it replaces.
     static const int tail_max = [] { const char *e = getenv("COSA_GEMM_TAIL"); return e ? atoi(e) : 48; }();
     int run = ntiles;
-    if (SPLIT == 0 && ABL6 == 0 && AUX == 0 && ntiles > 256 && ntiles % 256 != 0 && ntiles % 256 <= tail_max) run = ntiles - ntiles % 256;
+    if (FR == 4 && SPLIT == 0 && ABL6 == 0 && AUX == 0 && ntiles > 256 && ntiles % 256 != 0 && ntiles % 256 <= tail_max) run = ntiles - ntiles % 256;
+    // (tile order inside an XCD -- bands of 3 / 4 / 6 / 12 n-tiles so that the W panels in flight fit the L2 next to the X panels -- was
+    //  measured on the teacher's shapes: no difference beyond noise, 352 .. 357 us on the qkv projection; the m-panel-major order stays)
     // start stagger (see the kernel): measured to make no difference, off
     static const char *env = getenv("COSA_GEMM_STAGGER");
     const int stagger = env ? atoi(env) : 0;
-    hipLaunchKernelGGL((gemm_bf16_v6_kernel<EPI, ABL6, AUX, SPLIT>), dim3(grid), dim3(512), kLdsBytesV5, st, x, w, b, residual, Y, M, N, K, tiles_m, tiles_n, stagger,
+    hipLaunchKernelGGL((gemm_bf16_v6_kernel<EPI, ABL6, AUX, SPLIT, FR>), dim3(grid), dim3(512), kLdsBytesV5, st, x, w, b, residual, Y, M, N, K, tiles_m, tiles_n, stagger,
                        g_gemm_stamp_slot, ld ? ld : K, ldy ? ldy : N, Y2, run);
     g_gemm_stamp_slot = nullptr;                            // one-shot
     COSA_LAUNCH_CHECK();
@@ -1785,7 +1806,8 @@ extern "C" int cosa_gemm_bf16(const void *X, const void *W, const void *bias, co
         default: break;
         }
     }
-    const bool fits_v6 = fits_v5 && K >= 128 && (epilogue != EPI_RESIDUAL || g_gemm_variant == 6 || g_gemm_variant == 0);
+    static const int big_m = [] { const char *e = getenv("COSA_GEMM_BIG_M"); return e ? atoi(e) : 4096; }();   // experiments: rows from which the 256 x 256 kernels are used
+    const bool fits_v6 = fits_v5 && K >= 128 && (epilogue != EPI_RESIDUAL || g_gemm_variant == 6 || g_gemm_variant == 9 || g_gemm_variant == 0);
     if (g_gemm_variant >= 61 && g_gemm_variant <= 65 && fits_v6) {     // timing ablations of v6 (tools/bench_gemm_abl.py)
         switch (g_gemm_variant) {
         case 61: return launch_v6<EPI_BIAS, 1>(x, w, b, residual, Y, M, N, K, st);
@@ -1795,7 +1817,22 @@ extern "C" int cosa_gemm_bf16(const void *X, const void *W, const void *bias, co
         default: return launch_v6<EPI_BIAS, 4>(x, w, b, residual, Y, M, N, K, st);
         }
     }
-    if (fits_v6 && (g_gemm_variant == 6 || (g_gemm_variant == 0 && M >= 4096))) {       // plain stores
+    // 192-wide tiles (FR = 3) when they quantise better on the 256 CUs: the student's N = 768 projections (M = 12 560) are 150 jobs of
+    // 256 x 256 -- one round at 59 % of the CUs -- but 200 jobs of 256 x 192, one round of 3/4 the length.  Cost model: rounds x job
+    // length, the narrow job taken as 0.78 of the wide one (0.75 of the MFMA work, the X panel traffic per MFMA is 4/3).
+    if (fits_v6 && N % 192 == 0 && (g_gemm_variant == 9 || (g_gemm_variant == 0 && M >= big_m))) {
+        static const int wide_max = [] { const char *e = getenv("COSA_GEMM_TAIL"); return e ? atoi(e) : 48; }();
+        const long tm = (M + 255) / 256, n4 = tm * (N / 256), n3 = tm * (N / 192);
+        const double r4 = (n4 > 256 && n4 % 256 != 0 && n4 % 256 <= wide_max) ? (double)(n4 / 256) + 0.1 : (double)((n4 + 255) / 256);
+        const double r3 = 0.78 * (double)((n3 + 255) / 256);
+        static const bool allow3 = [] { const char *e = getenv("COSA_GEMM_FR3"); return !e || atoi(e) != 0; }();
+        if (g_gemm_variant == 9 || (allow3 && r3 < r4 - 0.05)) {
+            if (epilogue == EPI_BIAS) return launch_v6<EPI_BIAS, 0, 0, 0, 3>(x, w, b, residual, Y, M, N, K, st);
+            if (epilogue == EPI_GELU) return launch_v6<EPI_GELU, 0, 0, 0, 3>(x, w, b, residual, Y, M, N, K, st);
+            return launch_v6<EPI_RESIDUAL, 0, 0, 0, 3>(x, w, b, residual, Y, M, N, K, st);
+        }
+    }
+    if (fits_v6 && (g_gemm_variant == 6 || (g_gemm_variant == 0 && M >= big_m))) {       // plain stores
         if (epilogue == EPI_BIAS) return launch_v6<EPI_BIAS>(x, w, b, residual, Y, M, N, K, st);
         if (epilogue == EPI_GELU) return launch_v6<EPI_GELU>(x, w, b, residual, Y, M, N, K, st);
         return launch_v6<EPI_RESIDUAL>(x, w, b, residual, Y, M, N, K, st);
@@ -1808,7 +1845,7 @@ extern "C" int cosa_gemm_bf16(const void *X, const void *W, const void *bias, co
         if (epilogue == EPI_BIAS) return launch_v6<EPI_BIAS, 0, 19>(x, w, b, residual, Y, M, N, K, st);
         return launch_v6<EPI_GELU, 0, 19>(x, w, b, residual, Y, M, N, K, st);
     }
-    if ((g_gemm_variant == 5 || (g_gemm_variant == 0 && M >= 4096)) && fits_v5) {
+    if ((g_gemm_variant == 5 || (g_gemm_variant == 0 && M >= big_m)) && fits_v5) {
         switch (epilogue) {
         case EPI_BIAS: return launch_v5<EPI_BIAS>(x, w, b, residual, Y, M, N, K, st);
         case EPI_GELU: return launch_v5<EPI_GELU>(x, w, b, residual, Y, M, N, K, st);
@@ -1822,7 +1859,7 @@ extern "C" int cosa_gemm_bf16(const void *X, const void *W, const void *bias, co
         default: return launch_v4<EPI_RESIDUAL>(x, w, b, residual, Y, M, N, K, st);
         }
     }
-    const bool pick_v3 = g_gemm_variant == 3 || (g_gemm_variant == 0 && M >= 4096 && (N >= 2304 || tiles256 >= 512));
+    const bool pick_v3 = g_gemm_variant == 3 || (g_gemm_variant == 0 && M >= big_m && (N >= 2304 || tiles256 >= 512));
     if (pick_v3 && M >= 1024 && N % V3_T == 0) {
         switch (epilogue) {
         case EPI_BIAS: return launch_v3<EPI_BIAS>(x, w, b, residual, Y, M, N, K, st);

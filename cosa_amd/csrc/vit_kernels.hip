@@ -288,6 +288,113 @@ __global__ __launch_bounds__(256, 2) void head_gemm_kernel(const T *__restrict__
     }
 }
 
+// ---- backward of the narrow heads (autograd of models/__init__.py:190-204, conv_head.py:38) on the same exact-fp32 instruction ----------
+// dX[M, K] (bf16) = dY[M, N] (fp32) W[N, K] (bf16), as the transposed product C'[k][m] = sum_n W[n][k] dY[m][n]: a lane's A operands
+// of eight MFMAs come from ONE 16-byte load (lane (i, q): W[4s + q][kc + 8i .. + 7]; MFMA e takes element e, i.e. its row i stands for
+// column kc + 8i + e), so that after the n loop lane (c, q) holds, for each j, the eight consecutive columns kc + 32q + 8j .. + 7 of token
+// m0 + c: one 16-byte store.  A wave owns 16 tokens x 384 columns; dY is used in fp32 (the padded-GEMM route of round 1 rounded it to bf16).
+typedef __bf16 bf16x8h __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void head_dgrad_kernel(const float *__restrict__ dY, const bf16 *__restrict__ W, bf16 *__restrict__ dX,
+                                                        int M, int N, int K, int halves)
+{
+    const int lane = threadIdx.x & 63, wv = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int c = lane & 15, q = lane >> 4;
+    const int groups = (M + 15) >> 4;
+    const int g = wv / halves, h = wv - g * halves;
+    if (g >= groups) return;
+    const int m = g * 16 + c, mc = m < M ? m : M - 1;
+    const int nsteps = (N + 3) >> 2;
+    const int kspan = K / halves;                   // multiple of 128
+    for (int kc = h * kspan; kc < (h + 1) * kspan; kc += 128) {
+        f32x4h acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) acc[e] = (f32x4h){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+        for (int s = 0; s < nsteps; s++) {
+            const int n = 4 * s + q, nc = n < N ? n : N - 1;
+            const float dyv = (n < N && m < M) ? dY[(size_t)mc * N + n] : 0.f;        // 0 for n >= N: the clamped weight row adds nothing
+            const bf16x8h wv8 = *reinterpret_cast<const bf16x8h *>(W + (size_t)nc * K + kc + 8 * c);
+#pragma unroll
+            for (int e = 0; e < 8; e++) acc[e] = __builtin_amdgcn_mfma_f32_16x16x4f32((float)wv8[e], dyv, acc[e], 0, 0, 0);
+        }
+        if (m < M) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                bf16x8h o;
+#pragma unroll
+                for (int e = 0; e < 8; e++) o[e] = (bf16)acc[e][j];
+                *reinterpret_cast<bf16x8h *>(dX + (size_t)m * K + kc + 32 * q + 8 * j) = o;
+            }
+        }
+    }
+}
+
+// dW[N <= 32, K] (fp32) = dY^T X: C[n][k] = sum_m dY[m][n] X[m][k], four token rows per MFMA step.  Lane (c, q) loads X[m0 + q][kc + 8c .. + 7]
+// (16 bytes, eight MFMAs' B operands; column mapping as above) and dY[m0 + q][16 nb + i] as A.  A workgroup owns 128 columns and
+// 256 token rows (64 per wave, 16 steps); the four waves' partial tiles meet in LDS and are added in wave order, the workgroup's sum goes to
+// part[slab][32][K], and head_wgrad_reduce_kernel adds the slabs in order: a fixed summation tree, no atomics.
+constexpr int HW_ROWS = 256;
+__global__ __launch_bounds__(256) void head_wgrad_kernel(const float *__restrict__ dY, const bf16 *__restrict__ X, float *__restrict__ part,
+                                                        int M, int N, int K)
+{
+    __shared__ f32x4h red[3][16][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, q = lane >> 4;
+    const int kc = blockIdx.x * 128, slab = blockIdx.y;
+    const int r0 = slab * HW_ROWS + wave * (HW_ROWS / 4);
+    f32x4h acc[2][8];
+#pragma unroll
+    for (int nb = 0; nb < 2; nb++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) acc[nb][e] = (f32x4h){0.f, 0.f, 0.f, 0.f};
+    const bool two = N > 16;
+#pragma unroll 4
+    for (int it = 0; it < HW_ROWS / 16; it++) {
+        const int m = r0 + 4 * it + q, mc = m < M ? m : M - 1;
+        const bf16x8h xv = *reinterpret_cast<const bf16x8h *>(X + (size_t)mc * K + kc + 8 * c);
+        const float a0 = (m < M && c < N) ? dY[(size_t)mc * N + c] : 0.f;
+        const float a1 = (m < M && 16 + c < N) ? dY[(size_t)mc * N + 16 + c] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const float xe = (float)xv[e];
+            acc[0][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, xe, acc[0][e], 0, 0, 0);
+            if (two) acc[1][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, xe, acc[1][e], 0, 0, 0);
+        }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int nb = 0; nb < 2; nb++)
+#pragma unroll
+            for (int e = 0; e < 8; e++) red[wave - 1][nb * 8 + e][lane] = acc[nb][e];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float *dst = part + (size_t)slab * 32 * K;
+#pragma unroll
+        for (int nb = 0; nb < 2; nb++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                float o[8];
+#pragma unroll
+                for (int e = 0; e < 8; e++)
+                    o[e] = ((acc[nb][e][j] + red[0][nb * 8 + e][lane][j]) + red[1][nb * 8 + e][lane][j]) + red[2][nb * 8 + e][lane][j];
+                float *d = dst + (size_t)(nb * 16 + 4 * q + j) * K + kc + 8 * c;
+                *reinterpret_cast<float4 *>(d) = make_float4(o[0], o[1], o[2], o[3]);
+                *reinterpret_cast<float4 *>(d + 4) = make_float4(o[4], o[5], o[6], o[7]);
+            }
+    }
+}
+
+__global__ __launch_bounds__(256) void head_wgrad_reduce_kernel(const float *__restrict__ part, float *__restrict__ dW, int N, int K, int slabs)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= N * K) return;
+    const int n = e / K, k = e - n * K;
+    float t = 0.f;
+    for (int s = 0; s < slabs; s++) t += part[((size_t)s * 32 + n) * K + k];
+    dW[e] = t;
+}
+
 // ---- GELU' for the training backward of mlp.fc1 (autograd of vit.py:97-98): dH = dA * gelu_erf'(H), bf16, 8 elements per lane -------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 __global__ __launch_bounds__(256) void gelu_bwd_kernel(const bf16 *__restrict__ dA, const bf16 *__restrict__ H, bf16 *__restrict__ dH, size_t n8)
@@ -405,6 +512,33 @@ extern "C" int cosa_head_gemm(const void *X, const void *W, float *Y, int M, int
     else if (dtype == 1) { if (nb == 1) COSA_HEAD_LAUNCH(bf16, 1); else COSA_HEAD_LAUNCH(bf16, 2); }
     else { if (nb == 1) COSA_HEAD_LAUNCH(_Float16, 1); else COSA_HEAD_LAUNCH(_Float16, 2); }
 #undef COSA_HEAD_LAUNCH
+    COSA_LAUNCH_CHECK();
+    return COSA_OK;
+}
+
+// backward of the narrow heads: dX [M,K] bf16 = dY [M,N] (fp32, contiguous) W [N,K] (bf16)   (any N, K % 128 == 0)
+extern "C" int cosa_head_gemm_dgrad(const float *dY, const void *W, void *dX, int M, int N, int K, void *stream)
+{
+    COSA_REQUIRE(dY && W && dX && M > 0 && N > 0 && K > 0 && K % 128 == 0, "cosa_head_gemm_dgrad: K %% 128 == 0 (got N=%d K=%d)", N, K);
+    const int halves = (K % 256 == 0) ? 2 : 1;
+    const long waves = (long)((M + 15) / 16) * halves;
+    hipLaunchKernelGGL(head_dgrad_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, as_stream(stream), dY, static_cast<const bf16 *>(W),
+                       static_cast<bf16 *>(dX), M, N, K, halves);
+    COSA_LAUNCH_CHECK();
+    return COSA_OK;
+}
+
+extern "C" size_t cosa_head_gemm_wgrad_workspace(int M, int K) { return (size_t)((M + HW_ROWS - 1) / HW_ROWS) * 32 * (size_t)K * sizeof(float); }
+// dW [N,K] fp32 = dY^T [N,M] X [M,K] (X bf16, contiguous);  workspace: cosa_head_gemm_wgrad_workspace(M, K) bytes
+extern "C" int cosa_head_gemm_wgrad(const float *dY, const void *X, float *dW, void *workspace, int M, int N, int K, void *stream)
+{
+    COSA_REQUIRE(dY && X && dW && workspace && M > 0 && N > 0 && N <= 32 && K > 0 && K % 128 == 0, "cosa_head_gemm_wgrad: N <= 32 and K %% 128 == 0 (got N=%d K=%d)", N, K);
+    const int slabs = (M + HW_ROWS - 1) / HW_ROWS;
+    COSA_REQUIRE(slabs <= 65535, "cosa_head_gemm_wgrad: too many rows");
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(head_wgrad_kernel, dim3(K / 128, slabs), dim3(256), 0, st, dY, static_cast<const bf16 *>(X), static_cast<float *>(workspace), M, N, K);
+    COSA_LAUNCH_CHECK();
+    hipLaunchKernelGGL(head_wgrad_reduce_kernel, dim3((N * K + 255) / 256), dim3(256), 0, st, static_cast<const float *>(workspace), dW, N, K, slabs);
     COSA_LAUNCH_CHECK();
     return COSA_OK;
 }

@@ -242,9 +242,8 @@ def head_linear(tok, weight, round_bf16=False):
 
 class NarrowLinearFn(Function):
     """y[M,N] (fp32) = x[M,K] W[N,K]^T for the narrow heads of the TRAINING path (CAM / aux-CAM / classification heads: 1x1 convs with
-    20 | 80 outputs, models/__init__.py:190-204; LargeFOV conv8, conv_head.py:38), forward and backward on own kernels: forward = the
-    exact-fp32 MFMA narrow-head kernel; dX = the projection GEMM kernel on the zero-padded [M,128] output gradient and the padded
-    transposed weight; dW = the TN weight-gradient kernel on the same padded gradient (rows >= N dropped)."""
+    20 | 80 outputs, models/__init__.py:190-204; LargeFOV conv8, conv_head.py:38), forward and backward on the exact-fp32 MFMA narrow-head
+    kernels (csrc/vit_kernels.hip): dX = dY W and dW = dY^T X with dY in fp32, slices of <= 32 weight rows for the wider (COCO) heads."""
 
     @staticmethod
     def forward(ctx, x2, weight, w16):
@@ -257,16 +256,21 @@ class NarrowLinearFn(Function):
         x2, w16 = ctx.saved_tensors
         M, N = dy.shape
         K = x2.shape[1]
-        NP = 128 * ((N + 127) // 128)
-        dyp = torch.zeros((M, NP), device=dy.device, dtype=torch.bfloat16)
-        dyp[:, :N] = dy
+        dy = dy.float().contiguous()
+        st = _C.stream_ptr()
         dx = dw = None
-        if ctx.needs_input_grad[0]:
-            wtp = torch.zeros((K, NP), device=dy.device, dtype=torch.bfloat16)
-            wtp[:, :N] = w16.t()
-            dx = gemm_bf16(dyp, wtp, _zero_bias16(K, dy.device)[:K], EPI_BIAS)
-        if ctx.needs_input_grad[1]:
-            dw = gemm_wgrad(dyp, x2)[:N]
+        with _C.profiled("head_gemm_bwd"):
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty((M, K), device=dy.device, dtype=torch.bfloat16)
+                _C.check(_C.lib().cosa_head_gemm_dgrad(_C.ptr(dy), _C.ptr(w16), _C.ptr(dx), M, N, K, st), "cosa_head_gemm_dgrad")
+            if ctx.needs_input_grad[1]:
+                dw = torch.empty((N, K), device=dy.device, dtype=torch.float32)
+                ws = torch.empty(_C.lib().cosa_head_gemm_wgrad_workspace(M, K), device=dy.device, dtype=torch.uint8)
+                for c0 in range(0, N, 32):
+                    nn_ = min(32, N - c0)
+                    dys = dy if nn_ == N else dy[:, c0:c0 + nn_].contiguous()
+                    _C.check(_C.lib().cosa_head_gemm_wgrad(_C.ptr(dys), _C.ptr(x2), _C.ptr(dw[c0:c0 + nn_]), _C.ptr(ws), M, nn_, K, st),
+                             "cosa_head_gemm_wgrad")
         return dx, dw, None
 
 

@@ -229,6 +229,13 @@ void cosa_gemm_set_stamp_slot(void *slot);
  * ldx; dtype 0: fp32 X and W, 1: bf16, 2: fp16 X and W (round_bf16 = 1 rounds the result to the operand precision).                               */
 int cosa_head_gemm(const void *X, const void *W, float *Y, int M, int N, int K, int rows_per_img, long long img_stride,
                    int ldx, int dtype, int round_bf16, int ldy, int col0, void *stream);
+/* autograd of the same heads (the reference trains them through torch autograd: models/__init__.py:190-204, conv_head.py:38).
+ * dX [M,K] bf16 = dY [M,N] (fp32, contiguous) W [N,K] (bf16);  dW [N,K] fp32 = dY^T X (X [M,K] bf16, contiguous), summed in a fixed
+ * order (workspace: cosa_head_gemm_wgrad_workspace(M, K) bytes of device memory).  K % 128 == 0; the weight gradient takes N <= 32
+ * rows per call (wider heads in slices).                                                                                          */
+int cosa_head_gemm_dgrad(const float *dY, const void *W, void *dX, int M, int N, int K, void *stream);
+size_t cosa_head_gemm_wgrad_workspace(int M, int K);
+int cosa_head_gemm_wgrad(const float *dY, const void *X, float *dW, void *workspace, int M, int N, int K, void *stream);
 int cosa_layernorm(const float *x, const void *gamma, const void *beta, void *y_bf16, float *y_f32,
                    int rows, int dim, float eps, void *stream);
 /* the student's training path (autograd of models/vit/vit.py:96-102,119-137) on the same GEMM kernels:

@@ -217,3 +217,61 @@ def test_gemm_tail_launch_is_interchangeable_with_persistent_jobs(epi):
     ref = _ref(x, w, b, epi, r)
     tol = (1e-5 if epi == 2 else 2.0 ** -8) * max(ref.abs().max().item(), 1.0)
     assert (y.float() - ref).abs().max().item() <= tol
+
+
+@pytest.mark.parametrize("epi", [0, 1, 2])
+@pytest.mark.parametrize("M,N,K", [(12560, 768, 768), (4099, 768, 3072), (70001, 2304, 768)])
+def test_gemm_192_wide_tile_is_bitwise_the_256_wide_tile(epi, M, N, K):
+    """variant 9 = the persistent kernel on 256 x 192 jobs (three 16-feature fragments per wave and W half; the student's N = 768
+    projections quantise to 200 such jobs instead of 150 of 256 x 256).  Same MFMA chain per output element (bias first, k ascending),
+    so nothing may differ from variant 6, not one bit -- one job, many jobs per workgroup (70 001 x 2304: 3288 jobs), ragged M."""
+    from cosa_amd import nn_ops, _C
+    torch.manual_seed(M + epi)
+    x = torch.randn(M, K, device="cuda").bfloat16()
+    w = (torch.randn(N, K, device="cuda") * K ** -0.5).bfloat16()
+    b = torch.randn(N, device="cuda").bfloat16()
+    r = torch.randn(M, N, device="cuda") if epi == 2 else None
+    try:
+        _C.lib().cosa_gemm_set_variant(6)
+        y6 = nn_ops.gemm_bf16(x, w, b, epi, residual=r)
+        _C.lib().cosa_gemm_set_variant(9)
+        # canary-filled output: a store outside the job's window or a missed one shows up
+        out = torch.full((M + 8, N), 7.0, device="cuda", dtype=y6.dtype)
+        y9 = nn_ops.gemm_bf16(x, w, b, epi, residual=r, out=out[:M])
+    finally:
+        _C.lib().cosa_gemm_set_variant(0)
+    assert torch.equal(y9, y6)
+    assert torch.all(out[M:] == 7.0)
+    ref = _ref(x, w, b, epi, r)
+    tol = (1e-5 if epi == 2 else 2.0 ** -8) * max(ref.abs().max().item(), 1.0)
+    assert (y9.float() - ref).abs().max().item() <= tol
+
+
+@pytest.mark.parametrize("M,N,K", [(12544, 20, 768), (12544, 21, 512), (16, 20, 768), (3001, 80, 768), (777, 81, 512)])
+def test_narrow_linear_forward_backward_vs_fp64_autograd(M, N, K):
+    """the training path of the narrow heads (CAM / aux-CAM / classification heads, conv8; VOC 20 | 21 and COCO 80 | 81 rows): forward,
+    dX = dY W and dW = dY^T X on the exact-fp32 MFMA kernels against float64 autograd on the same bf16-rounded operands.  The only
+    roundings left are the bf16 store of dX and fp32 summation order."""
+    from cosa_amd import nn_ops
+    torch.manual_seed(N + K)
+    x = torch.randn(M, K, device="cuda").bfloat16().requires_grad_(True)
+    w = (torch.randn(N, K, 1, 1, device="cuda") * K ** -0.5).requires_grad_(True)
+    dy = torch.randn(M, N, device="cuda")
+    y = nn_ops.narrow_linear(x, w)
+    assert y is not None and y.dtype == torch.float32 and y.shape == (M, N)
+    y.backward(dy)
+    x64 = x.detach().double().requires_grad_(True)
+    w64 = w.detach().bfloat16().double().reshape(N, K).requires_grad_(True)
+    y64 = x64 @ w64.t()
+    y64.backward(dy.double())
+    assert (y.double() - y64).abs().max().item() <= 1e-5 * max(1.0, y64.abs().max().item())
+    assert x.grad.dtype == torch.bfloat16
+    assert (x.grad.double() - x64.grad).abs().max().item() <= 2.0 ** -8 * x64.grad.abs().max().item()
+    assert w.grad.shape == w.shape
+    assert (w.grad.double().reshape(N, K) - w64.grad).abs().max().item() <= 2e-5 * w64.grad.abs().max().item()
+    # deterministic: a second backward gives the same bits (fixed summation tree, no atomics)
+    g1 = w.grad.clone()
+    w.grad = None
+    x.grad = None
+    nn_ops.narrow_linear(x, w).backward(dy)
+    assert torch.equal(w.grad, g1)

@@ -8,7 +8,11 @@ from cosa_amd.train_step import CoSATrainer, default_args, synthetic_batch
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 prec = sys.argv[2] if len(sys.argv) > 2 else "bf16"
 dev = torch.device("cuda", 0)
-args = default_args("VOC12", crop_size=448, batch_size=16, teacher_precision=prec, teacher_async=os.environ.get("COSA_TEACHER_SYNC") is None)
+kw = dict(crop_size=448, batch_size=16, teacher_async=os.environ.get("COSA_TEACHER_SYNC") is None)
+try:
+    args = default_args("VOC12", teacher_precision=prec, **kw)
+except TypeError:        # a round-1 checkout (same-box comparisons): no precision switch
+    args = default_args("VOC12", **kw)
 tr = CoSATrainer(args, dev, seed=0)
 wimg, simg, lab, box = synthetic_batch(16, 448, 20, dev, seed=1234)
 n_iter = args.warmup_iters + 1
