@@ -14,10 +14,16 @@
 //   * all K channels ride through the lattice together: values[M+1][KP] rows (channel fastest),
 //     so splat / blur / slice touch whole rows instead of re-streaming the lattice K times.
 //   * planar [K][H*W] <-> row [pixel][KP] transposes go through LDS tiles.
+//   * splat without float atomics: the (pixel, vertex) pairs of an image are sorted by vertex once per lattice (stable LSD radix sort,
+//     rocPRIM's device primitive; the pairs are generated in pixel order, so a vertex's list is in ascending pixel order), and a
+//     half-wave per vertex adds its list up in that order -- the order of the reference's serial splat loop (permutohedral.cpp:507-530),
+//     so the value rows are bit-identical to the CPU's and the same from run to run.
 // Compiled with -ffp-contract=off (lattice coordinates must match the CPU oracle bit for bit).
 #include "kernels.hpp"
 #include <cmath>
+#include <cstring>
 #include <vector>
+#include <rocprim/device/device_radix_sort.hpp>
 
 namespace cosa {
 namespace {
@@ -48,6 +54,15 @@ struct ImageBuffers {   // per-image strides (in elements) into the workspace ar
     int *M;                     // [N]
     int *err;                   // [1]
     double *loss_acc;           // [1]
+    // sorted splat lists: pair e = 6 * pixel + r of image n has key (n << id_bits) | vertex id (padding pixels: id = Mmax)
+    unsigned *ckey0, *ckey1;    // [N*Npad*6] keys before / after the sort
+    unsigned *cent0, *cent1;    // [N*Npad*6] pair numbers e before / after the sort
+    int *seg_lo, *seg_hi;       // [N][Mmax] range of a vertex's pairs in cent1 (lo == hi == 0: none)
+    float *rows;                // [N][Npix][KP] the input of a filter pass as pixel rows (x roi)
+    double *loss_part;          // [N * ceil(Npix / TP)] per-workgroup partial sums of the energy
+    void *sort_tmp;             // rocPRIM's temporary storage
+    size_t sort_tmp_bytes;
+    int id_bits;
 };
 
 __device__ __forceinline__ unsigned long long hmix(unsigned long long k)
@@ -201,7 +216,23 @@ __global__ __launch_bounds__(256) void lattice_remap_kernel(LatticeParams P, Ima
     const int n = blockIdx.y;
     int *off = B.offset + (size_t)n * P.Npad * PD1;
     const int *slot_id = B.slot_id + (size_t)n * ((size_t)P.cap_mask + 1);
-    off[i] = slot_id[off[i]];
+    const int id = slot_id[off[i]];
+    off[i] = id;
+    const size_t g = (size_t)n * P.Npad * PD1 + i;
+    B.ckey0[g] = ((unsigned)n << B.id_bits) | (unsigned)(i / PD1 < P.N ? id : P.Mmax);
+    B.cent0[g] = (unsigned)i;
+}
+
+// ---- 2c. ranges of the sorted (vertex, pair) list ---------------------------------------------------
+__global__ __launch_bounds__(256) void csr_bounds_kernel(size_t total, LatticeParams P, ImageBuffers B)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const unsigned k = B.ckey1[i], mask = (1u << B.id_bits) - 1u;
+    const unsigned id = k & mask, n = k >> B.id_bits;
+    if (id >= (unsigned)P.Mmax) return;
+    if (i == 0 || B.ckey1[i - 1] != k) B.seg_lo[(size_t)n * P.Mmax + id] = (int)i;
+    if (i + 1 == total || B.ckey1[i + 1] != k) B.seg_hi[(size_t)n * P.Mmax + id] = (int)(i + 1);
 }
 
 // ---- 2b. blur neighbours + zero the value rows -----------------------------------------------------
@@ -281,6 +312,80 @@ __global__ __launch_bounds__(256) void lattice_splat_kernel(const float *__restr
             const int o = off[pl * PD1 + r] + 1;
             const float w = bar[pl * PD1 + r];
             atomicAdd(&val[(size_t)o * KP + k], w * v);
+        }
+    }
+}
+
+// ---- 3'. splat without atomics ------------------------------------------------------------------------
+// rows[n][p][k] = in[n][k][p] (* roi[n][p]): the filter input as pixel rows (LDS tile transpose)
+__global__ __launch_bounds__(256) void lattice_rows_kernel(const float *__restrict__ ins, const float *__restrict__ roi,
+                                                          int K, LatticeParams P, ImageBuffers B)
+{
+    extern __shared__ __attribute__((aligned(16))) float tile[];   // [TP][KP+1]
+    const int n = blockIdx.y;
+    const int p0 = blockIdx.x * TP;
+    const int KP = P.KP, ld = KP + 1;
+    const size_t hw = (size_t)P.N;
+    const float *in = ins + (size_t)n * K * hw;
+    for (int e = threadIdx.x; e < TP * KP; e += 256) {
+        const int k = e / TP, pl = e - k * TP;
+        float v = 0.0f;
+        if (k < K && p0 + pl < P.N) {
+            v = in[(size_t)k * hw + p0 + pl];
+            if (roi) v = v * roi[(size_t)n * hw + p0 + pl];
+        }
+        tile[pl * ld + k] = v;
+    }
+    __syncthreads();
+    float *rows = B.rows + ((size_t)n * hw + p0) * KP;
+    for (int e = threadIdx.x; e < TP * KP; e += 256) {
+        const int pl = e / KP, k = e - pl * KP;
+        if (p0 + pl < P.N) rows[e] = tile[pl * ld + k];
+    }
+}
+
+// values[id+1][k] = sum over the vertex's pairs, in ascending pixel order, of bary * rows[pixel][k]: 32 lanes per vertex (lane = channel),
+// four pairs' loads in flight.  Also zeroes the sink rows (row 0 of both value buffers).
+__global__ __launch_bounds__(256) void lattice_splat_sorted_kernel(LatticeParams P, ImageBuffers B)
+{
+    const int n = blockIdx.y;
+    const int M = B.M[n];
+    const int KP = P.KP;
+    const int k = threadIdx.x & 31;
+    const size_t vstride = ((size_t)P.Mmax + 1) * KP;
+    float *val = B.val0 + (size_t)n * vstride;
+    if (blockIdx.x == 0) {
+        for (int c = threadIdx.x; c < KP; c += 256) {
+            val[c] = 0.0f;
+            B.val1[(size_t)n * vstride + c] = 0.0f;
+        }
+    }
+    const int *lo = B.seg_lo + (size_t)n * P.Mmax, *hi = B.seg_hi + (size_t)n * P.Mmax;
+    const float *bary = B.bary + (size_t)n * P.Npad * PD1;
+    const float *rows = B.rows + (size_t)n * P.N * KP;
+    for (int id = blockIdx.x * 8 + (threadIdx.x >> 5); id < M; id += gridDim.x * 8) {
+        const int beg = lo[id], end = hi[id];
+        for (int kc = k; kc < KP; kc += 32) {            // K <= 32 (VOC: 21): one trip; COCO's 81 planes: three
+            int i = beg;
+            float acc = 0.0f;
+            for (; i + 4 <= end; i += 4) {
+                unsigned e[4];
+                float w[4], v[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) e[u] = B.cent1[i + u];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    w[u] = bary[e[u]];
+                    v[u] = rows[(size_t)(e[u] / PD1) * KP + kc];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) acc = acc + w[u] * v[u];
+            }
+            for (; i < end; i++) {
+                const unsigned e = B.cent1[i];
+                acc = acc + bary[e] * rows[(size_t)(e / PD1) * KP + kc];
+            }
+            val[(size_t)(id + 1) * KP + kc] = acc;
         }
     }
 }
@@ -389,11 +494,24 @@ __global__ __launch_bounds__(256) void lattice_slice_kernel(float *__restrict__ 
         for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
         __syncthreads();
-        if (threadIdx.x == 0) atomicAdd(B.loss_acc, red[0] + red[1] + red[2] + red[3]);
+        if (threadIdx.x == 0) B.loss_part[(size_t)n * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
     }
 }
 
-__global__ void energy_finalize_kernel(const double *acc, float *loss, int N) { loss[0] = (float)(-acc[0] / (double)N); }
+// loss = -(sum of the workgroups' partial sums) / N, added up in a fixed order (no atomics: the same bits every run)
+__global__ __launch_bounds__(256) void energy_finalize_kernel(const double *__restrict__ part, int nparts, float *__restrict__ loss, int N)
+{
+    __shared__ double red[256];
+    double t = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 256) t += part[i];
+    red[threadIdx.x] = t;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss[0] = (float)(-red[0] / (double)N);
+}
 
 __global__ __launch_bounds__(256) void energy_backward_kernel(const float *__restrict__ AS, const float *__restrict__ roi,
                                                              const float *__restrict__ gout, float *__restrict__ gseg,
@@ -444,6 +562,30 @@ size_t plan_layout(int N, int K, int H, int W, void *ws, Plan *pl)
     B.nb = cv.take<int2>((size_t)N * PD1 * P.Mmax);
     B.val0 = cv.take<float>((size_t)N * ((size_t)P.Mmax + 1) * P.KP);
     B.val1 = cv.take<float>((size_t)N * ((size_t)P.Mmax + 1) * P.KP);
+    const size_t pairs = (size_t)N * P.Npad * PD1;
+    B.ckey0 = cv.take<unsigned>(pairs);
+    B.ckey1 = cv.take<unsigned>(pairs);
+    B.cent0 = cv.take<unsigned>(pairs);
+    B.cent1 = cv.take<unsigned>(pairs);
+    B.seg_lo = cv.take<int>((size_t)N * P.Mmax);
+    B.seg_hi = cv.take<int>((size_t)N * P.Mmax);
+    B.rows = cv.take<float>((size_t)N * P.N * P.KP);
+    B.loss_part = cv.take<double>((size_t)N * ((P.N + TP - 1) / TP));
+    B.id_bits = 1;
+    while ((1u << B.id_bits) <= (unsigned)P.Mmax) B.id_bits++;          // ids 0 .. Mmax (Mmax = "padding pixel")
+    {
+        static size_t cached_pairs = 0, cached_bytes = 0;               // the size query launches nothing
+        if (cached_pairs != pairs) {
+            size_t bytes = 0;
+            (void)rocprim::radix_sort_pairs(nullptr, bytes, (unsigned *)nullptr, (unsigned *)nullptr, (unsigned *)nullptr, (unsigned *)nullptr,
+                                            pairs, 0u, 32u, (hipStream_t) nullptr);
+            if (bytes == 0) bytes = pairs * 16 + (1u << 20);            // no device to ask (CPU-only host): an upper bound of the same layout
+            cached_pairs = pairs;
+            cached_bytes = bytes;
+        }
+        B.sort_tmp_bytes = cached_bytes;
+    }
+    B.sort_tmp = cv.take<char>(B.sort_tmp_bytes);
     (void)head; (void)keys_end;
     pl->bytes = cv.off;
     return cv.off;
@@ -458,6 +600,12 @@ int setup_plan(int N, int K, int H, int W, float sigmargb, float sigmaxy, void *
     COSA_REQUIRE(N > 0 && K > 0 && H > 0 && W > 0 && N <= 65535, "bilateral: bad shape");
     COSA_REQUIRE(sigmargb > 0.f && sigmaxy > 0.f, "bilateral: sigmas must be positive");
     COSA_REQUIRE((size_t)H * W * PD1 < (1u << 30), "bilateral: image too large");
+    {
+        int idb = 1, nb = 0;
+        while ((1u << idb) <= (unsigned)(((size_t)H * W + 3) / 4 * 4 * PD1)) idb++;
+        while ((1 << nb) < N) nb++;
+        COSA_REQUIRE(idb + nb <= 32, "bilateral: batch x lattice size does not fit the 32-bit sort key (split the batch)");
+    }
     if (ws_bytes < plan_layout(N, K, H, W, ws, &pl)) {
         set_error("bilateral: workspace too small (%zu < %zu)", ws_bytes, pl.bytes);
         return COSA_ENOMEM;
@@ -487,6 +635,16 @@ int lattice_phase(const float *images, int N, Plan &pl, hipStream_t st)
     const int gs = 1024;   // grid-stride launches read M on the device
     hipLaunchKernelGGL(lattice_neighbors_kernel, dim3(gs, N), blk, 0, st, P, B);
     COSA_LAUNCH_CHECK();
+    // the splat lists: pairs sorted by (image, vertex); stable, so a vertex keeps its pairs in pixel order
+    const size_t pairs = (size_t)N * P.Npad * PD1;
+    int nbits = 0;
+    while ((1 << nbits) < N) nbits++;
+    size_t tmp_bytes = B.sort_tmp_bytes;
+    COSA_HIP_CHECK(rocprim::radix_sort_pairs(B.sort_tmp, tmp_bytes, B.ckey0, B.ckey1, B.cent0, B.cent1, pairs, 0u,
+                                             (unsigned)(B.id_bits + nbits), st));
+    COSA_HIP_CHECK(hipMemsetAsync(B.seg_lo, 0, (char *)B.rows - (char *)B.seg_lo, st));        // seg_lo and seg_hi are adjacent
+    hipLaunchKernelGGL(csr_bounds_kernel, dim3((unsigned)((pairs + 255) / 256)), blk, 0, st, pairs, P, B);
+    COSA_LAUNCH_CHECK();
     return COSA_OK;
 }
 
@@ -498,12 +656,19 @@ int filter_phase(const float *ins, float *outs, int N, int K, const float *roi, 
     ImageBuffers &B = pl.B;
     const dim3 blk(256);
     const int gs = 1024;
-    COSA_HIP_CHECK(hipMemsetAsync(B.loss_acc, 0, 8 * sizeof(double), st));      // a lattice may serve several filter passes
-    hipLaunchKernelGGL(lattice_zero_values_kernel, dim3(gs, N), blk, 0, st, P, B);
-    COSA_LAUNCH_CHECK();
     const size_t lds = (size_t)TP * (P.KP + 1) * sizeof(float);
-    hipLaunchKernelGGL(lattice_splat_kernel, dim3((P.N + TP - 1) / TP, N), blk, lds, st, ins, roi, K, P, B);
-    COSA_LAUNCH_CHECK();
+    static const bool atomic_splat = [] { const char *e = getenv("COSA_LATTICE_ATOMIC_SPLAT"); return e && atoi(e) != 0; }();   // A/B: round-1 splat
+    if (atomic_splat) {
+        hipLaunchKernelGGL(lattice_zero_values_kernel, dim3(gs, N), blk, 0, st, P, B);
+        COSA_LAUNCH_CHECK();
+        hipLaunchKernelGGL(lattice_splat_kernel, dim3((P.N + TP - 1) / TP, N), blk, lds, st, ins, roi, K, P, B);
+        COSA_LAUNCH_CHECK();
+    } else {
+        hipLaunchKernelGGL(lattice_rows_kernel, dim3((P.N + TP - 1) / TP, N), blk, lds, st, ins, roi, K, P, B);
+        COSA_LAUNCH_CHECK();
+        hipLaunchKernelGGL(lattice_splat_sorted_kernel, dim3(gs, N), blk, 0, st, P, B);
+        COSA_LAUNCH_CHECK();
+    }
     for (int j = 0; j <= PD; j++) {
         hipLaunchKernelGGL(lattice_blur_kernel, dim3(gs, N), blk, 0, st, j, j & 1, P, B);
         COSA_LAUNCH_CHECK();
@@ -513,7 +678,7 @@ int filter_phase(const float *ins, float *outs, int N, int K, const float *roi, 
                        unlabel, P, B);
     COSA_LAUNCH_CHECK();
     if (seg_for_energy) {
-        hipLaunchKernelGGL(energy_finalize_kernel, dim3(1), dim3(1), 0, st, B.loss_acc, loss, N);
+        hipLaunchKernelGGL(energy_finalize_kernel, dim3(1), dim3(256), 0, st, B.loss_part, N * ((P.N + TP - 1) / TP), loss, N);
         COSA_LAUNCH_CHECK();
     }
     if (lattice_sizes) COSA_HIP_CHECK(hipMemcpyAsync(lattice_sizes, B.M, sizeof(int) * N, hipMemcpyDeviceToDevice, st));
