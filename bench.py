@@ -178,8 +178,9 @@ def par_refine_ms_per_img(trainer, simg, lab, box, dev, opt, C):
     bil = {"fwd_bwd_ms_per_img": round(tb / b, 5), "noise_images_fwd_bwd_ms_per_img": round(tbn / b, 5),
            "roofline": {"bound": "hbm", "achieved": round(comp * b / (tb * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
                         "frac": round(comp * b / (tb * 1e-3) / 8e12, 5), "compulsory_MB_per_img": round(comp / 1e6, 2), "traffic": None,
-                        "note": "gather / scatter through a hashed 5-D lattice: bound by memory-side float atomics (splat) and random row "
-                                "gathers (blur, slice), not by the compulsory bytes"}}
+                        "note": "gather / scatter through a hashed 5-D lattice: bound by the hash insertions (64-bit CAS, build) and random row "
+                                "gathers (sorted splat, blur, slice), not by the compulsory bytes; no float atomics: the output is "
+                                "bit-identical to the reference's"}}
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_lattice_pmc.json")))
         bil["roofline"]["traffic"] = pmc.get("hbm_bytes_per_forward_backward")

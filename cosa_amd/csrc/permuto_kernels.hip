@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void lattice_remap_kernel(LatticeParams P, Ima
 }
 
 // ---- 2c. ranges of the sorted (vertex, pair) list ---------------------------------------------------
-__global__ __launch_bounds__(256) void csr_bounds_kernel(size_t total, LatticeParams P, ImageBuffers B)
+__global__ __launch_bounds__(256) void lattice_bounds_kernel(size_t total, LatticeParams P, ImageBuffers B)
 {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
@@ -643,7 +643,7 @@ int lattice_phase(const float *images, int N, Plan &pl, hipStream_t st)
     COSA_HIP_CHECK(rocprim::radix_sort_pairs(B.sort_tmp, tmp_bytes, B.ckey0, B.ckey1, B.cent0, B.cent1, pairs, 0u,
                                              (unsigned)(B.id_bits + nbits), st));
     COSA_HIP_CHECK(hipMemsetAsync(B.seg_lo, 0, (char *)B.rows - (char *)B.seg_lo, st));        // seg_lo and seg_hi are adjacent
-    hipLaunchKernelGGL(csr_bounds_kernel, dim3((unsigned)((pairs + 255) / 256)), blk, 0, st, pairs, P, B);
+    hipLaunchKernelGGL(lattice_bounds_kernel, dim3((unsigned)((pairs + 255) / 256)), blk, 0, st, pairs, P, B);
     COSA_LAUNCH_CHECK();
     return COSA_OK;
 }
