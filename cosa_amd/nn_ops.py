@@ -31,25 +31,52 @@ class KernelStamps:
 
     def __init__(self, device, max_launches=4096):
         self.buf = torch.zeros((max_launches, 2), dtype=torch.int64, device=device)
+        self.half = max_launches // 2
+        self.n = 0                  # slots [0, half): launches of the teacher section (captured in its hipGraph, re-armed by the captured reset)
+        self.flops = []
+        self.eager = False          # slots [half, ..): the step's eager launches (student), re-armed on their own stream by begin_eager()
+        self.n_eager = 0
+        self.flops_eager = []
+
+    def reset(self):
+        """re-arm the teacher section's slots (a device op: captured with the section and replayed with it)"""
+        self.buf[: self.half, 0] = torch.iinfo(torch.int64).max
+        self.buf[: self.half, 1] = 0
+
+    def begin_eager(self):
+        """the teacher section has been issued: the launches that follow are eager ones on the current stream.  Their slots are re-armed
+        here, on that stream -- the captured reset runs on the teacher's side stream, concurrently with them (a reset landing between a
+        kernel's two stamps used to leave (start = max, end = t): negative spans in the round-1 / early round-2 bench lines)."""
+        self.eager = True
+        self.n_eager = 0
+        self.flops_eager = []
+        self.buf[self.half:, 0] = torch.iinfo(torch.int64).max
+        self.buf[self.half:, 1] = 0
+
+    def begin_section(self):
+        self.eager = False
         self.n = 0
         self.flops = []
 
-    def reset(self):
-        self.buf[:, 0] = torch.iinfo(torch.int64).max
-        self.buf[:, 1] = 0
-
     def next_slot(self, flops):
-        i = self.n
-        self.n += 1
-        self.flops.append(flops)
+        if self.eager:
+            i = self.half + self.n_eager
+            self.n_eager += 1
+            self.flops_eager.append(flops)
+        else:
+            i = self.n
+            self.n += 1
+            self.flops.append(flops)
+        assert i < self.buf.shape[0] and (self.eager or i < self.half), "KernelStamps: out of slots"
         return ctypes.c_void_p(self.buf.data_ptr() + 16 * i)
 
     def read(self):
-        """-> (n_launches, total_seconds, total_flops) of the launches stamped since the last reset (after a sync)"""
-        b = self.buf[: self.n].cpu()
-        ok = b[:, 1] > 0
+        """-> (n_launches, total_seconds, total_flops) of the launches stamped since the last re-arm (after a sync)"""
+        b = torch.cat([self.buf[: self.n], self.buf[self.half: self.half + self.n_eager]]).cpu()
+        fl_all = list(self.flops) + list(self.flops_eager)
+        ok = (b[:, 1] > 0) & (b[:, 0] < b[:, 1])
         ticks = (b[:, 1] - b[:, 0])[ok]
-        fl = sum(f for f, k in zip(self.flops, ok.tolist()) if k)
+        fl = sum(f for f, k in zip(fl_all, ok.tolist()) if k)
         return int(ok.sum()), float(ticks.sum()) * 1e-8, fl
 
 

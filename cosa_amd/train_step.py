@@ -142,14 +142,17 @@ class CoSATrainer:
         args = self.args
         act = None if args.use_cammix else cls_label
         sts = [s_ for s_ in (nn_ops.stamps, nn_ops.gemm_stamps) if s_ is not None]
-        for st in sts:                          # kernel-span slots are re-dealt from 0 every step (teacher first)
-            st.n, st.flops = 0, []
+        for st in sts:                          # kernel-span slots are re-dealt every step: the teacher section's, then the eager ones
+            st.begin_section()
         if not self.use_graph or (self._graph is None and self._graph_calls < 2):
             self._graph_calls += 1
             for st in sts:
                 st.reset()
-            return seg_helper.multi_scale_camseg(self.model_AN, wimg, args.pseudo_scales, _active_labels=act,
-                                                  _seg_scales=self.fused_losses)
+            out = seg_helper.multi_scale_camseg(self.model_AN, wimg, args.pseudo_scales, _active_labels=act,
+                                                _seg_scales=self.fused_losses)
+            for st in sts:
+                st.begin_eager()
+            return out
         if self._graph is None:
             self._s_wimg = wimg.clone()
             self._s_lab = cls_label.clone()
@@ -180,6 +183,7 @@ class CoSATrainer:
             self._graph.replay()
         for st, (n_, fl_) in zip(sts, getattr(self, "_g_stamps", None) or []):
             st.n, st.flops = n_, list(fl_)
+            st.begin_eager()
         return self._s_out
 
     def _join_teacher(self):
