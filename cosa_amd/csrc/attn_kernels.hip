@@ -210,11 +210,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const op16 *__restrict__ 
 //     S^T  = K_h Q_h^T + K_h Q_l^T + K_l Q_h^T          O^T += V_h^T P_h^T + V_h^T P_l^T + V_l^T P_h^T
 // qkv rows are the split output of the qkv projection: [hi (3*H*64) | lo (3*H*64)], row stride ldq; the output rows are split rows for
 // the output projection: [hi (H*64) | lo (H*64) | aug (1, 1, 0, ...)], row stride ldo (gemm_kernels.hip: split_tile_x / split_tile_w).
+// K / V tiles (hi and lo halves: four [64][64] images, 32 KB) arrive by LDS-DMA into a 2-deep ring -- the next tile is in flight while this
+// one is computed, one barrier per tile, no staging registers.  (The first version staged them through 32 registers that the compiler
+// kept in scratch: every tile waited for its global loads to store them, 1.02 ms per launch of the teacher's mix against 0.14 ms for
+// the bf16 kernel.)
 __global__ __launch_bounds__(256) void attn_fwd_x3_kernel(const op16 *__restrict__ qkv, op16 *__restrict__ out, float *__restrict__ lse,
                                                          int N, int H, int nblk, int ngroups, float scale_log2e, int ldq, int ldo)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * BK * 128];
-    unsigned char *Kh = smem, *Kl = smem + BK * 128, *Vh = smem + 2 * BK * 128, *Vl = smem + 3 * BK * 128;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];          // [2 stages][Kh | Kl | Vh | Vl][64 * 128]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
     int blk, b, h;
     if (!attn_block_map(nblk, ngroups, H, blk, b, h)) return;
@@ -238,37 +241,40 @@ __global__ __launch_bounds__(256) void attn_fwd_x3_kernel(const op16 *__restrict
     const op16 *kbase = qkv + (size_t)b * N * rs + (size_t)H * HD + h * HD;
     const op16 *vbase = kbase + (size_t)H * HD;
     const int swz = (r >> 1) & 7;
-    uint4 kr[4], vr[4];                                   // [hi row_a, hi row_b, lo row_a, lo row_b]
-    const int row_a = tid >> 3, row_b = (tid + 256) >> 3, slot_s = tid & 7;
-#define COSA_LOAD_TILE3(K0)                                                                                          \
-    do {                                                                                                             \
-        const size_t ra_ = (size_t)min((K0) + row_a, N - 1) * rs + slot_s * 8, rb_ = (size_t)min((K0) + row_b, N - 1) * rs + slot_s * 8; \
-        kr[0] = *reinterpret_cast<const uint4 *>(kbase + ra_);                                                       \
-        kr[1] = *reinterpret_cast<const uint4 *>(kbase + rb_);                                                       \
-        kr[2] = *reinterpret_cast<const uint4 *>(kbase + lo_off + ra_);                                              \
-        kr[3] = *reinterpret_cast<const uint4 *>(kbase + lo_off + rb_);                                              \
-        vr[0] = *reinterpret_cast<const uint4 *>(vbase + ra_);                                                       \
-        vr[1] = *reinterpret_cast<const uint4 *>(vbase + rb_);                                                       \
-        vr[2] = *reinterpret_cast<const uint4 *>(vbase + lo_off + ra_);                                              \
-        vr[3] = *reinterpret_cast<const uint4 *>(vbase + lo_off + rb_);                                              \
-    } while (0)
-    COSA_LOAD_TILE3(0);
+    // DMA: wave w fills the 1-KiB pieces 2w, 2w + 1 (8 rows each) of each of the four images; swizzles on the source side, rows past
+    // the last key read as zeros through the buffer range check
+    const int nbytes = (int)(((size_t)(N - 1) * rs + HD) * 2);
+    const __amdgpu_buffer_rsrc_t rsKh = __builtin_amdgcn_make_buffer_rsrc((void *)kbase, 0, nbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsKl = __builtin_amdgcn_make_buffer_rsrc((void *)(kbase + lo_off), 0, nbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsVh = __builtin_amdgcn_make_buffer_rsrc((void *)vbase, 0, nbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsVl = __builtin_amdgcn_make_buffer_rsrc((void *)(vbase + lo_off), 0, nbytes, 0x00020000);
+    unsigned voK[2], voV[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int row = 8 * (2 * wave + i) + (lane >> 3), ps = lane & 7;
+        voK[i] = (unsigned)((row * rs + (ps ^ ((row >> 1) & 7)) * 8) * 2);
+        voV[i] = (unsigned)((row * rs + (ps ^ vsw(row)) * 8) * 2);
+    }
+    auto dma_tile = [&](int k0, int buf) {
+        const unsigned ko = (unsigned)((size_t)k0 * rs * 2);
+        unsigned char *d = smem + buf * 4 * BK * 128 + (2 * wave) * 1024;
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsKh, (lds_void_a *)(d + i * 1024), 16, voK[i] + ko, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsKl, (lds_void_a *)(d + BK * 128 + i * 1024), 16, voK[i] + ko, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsVh, (lds_void_a *)(d + 2 * BK * 128 + i * 1024), 16, voV[i] + ko, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsVl, (lds_void_a *)(d + 3 * BK * 128 + i * 1024), 16, voV[i] + ko, 0, 0, 0);
+        }
+    };
+    int ring = 0;
+    dma_tile(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     const float NEG_INF = -INFINITY;
     auto tile = [&](int k0, auto tail_tag) {
         constexpr bool tail = decltype(tail_tag)::value;
-        __syncthreads();
-        const int ka = row_a * 128 + ((slot_s ^ ((row_a >> 1) & 7)) << 4), kb_ = row_b * 128 + ((slot_s ^ ((row_b >> 1) & 7)) << 4);
-        const int va = row_a * 128 + ((slot_s ^ vsw(row_a)) << 4), vb = row_b * 128 + ((slot_s ^ vsw(row_b)) << 4);
-        *reinterpret_cast<uint4 *>(Kh + ka) = kr[0];
-        *reinterpret_cast<uint4 *>(Kh + kb_) = kr[1];
-        *reinterpret_cast<uint4 *>(Kl + ka) = kr[2];
-        *reinterpret_cast<uint4 *>(Kl + kb_) = kr[3];
-        *reinterpret_cast<uint4 *>(Vh + va) = vr[0];
-        *reinterpret_cast<uint4 *>(Vh + vb) = vr[1];
-        *reinterpret_cast<uint4 *>(Vl + va) = vr[2];
-        *reinterpret_cast<uint4 *>(Vl + vb) = vr[3];
-        __syncthreads();
-        if (k0 + BK < N) COSA_LOAD_TILE3(k0 + BK);
+        const unsigned char *Kh = smem + ring * 4 * BK * 128, *Kl = Kh + BK * 128, *Vh = Kh + 2 * BK * 128, *Vl = Kh + 3 * BK * 128;
+        if (k0 + BK < N) dma_tile(k0 + BK, ring ^ 1);
 
         f32x16 s0, s1;
 #pragma unroll
@@ -336,11 +342,13 @@ __global__ __launch_bounds__(256) void attn_fwd_x3_kernel(const op16 *__restrict
                 o1 = COSA_MFMA_32x32x16(vh1, ph, o1, 0, 0, 0);
             }
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the next tile has landed and nobody still reads this one
+        __syncthreads();
+        ring ^= 1;
     };
     const int nfull = (N / BK) * BK;
     for (int k0 = 0; k0 < nfull; k0 += BK) tile(k0, std::false_type{});
     if (nfull < N) tile(nfull, std::true_type{});
-#undef COSA_LOAD_TILE3
     l += __shfl_xor(l, 32, 64);
     const float inv = 1.0f / l;
     const int q = q0 + r;
@@ -934,7 +942,14 @@ extern "C" int cosa_attn_fwd_bf16x3(const void *qkv_split, void *out_split, floa
     COSA_REQUIRE(ldq >= 6 * H * HD && ldq % 8 == 0 && ldo >= 2 * H * HD + 64 && ldo % 8 == 0, "cosa_attn_fwd_bf16x3: bad row strides");
     const int nblk = (N + BQ - 1) / BQ, ngroups = B * H;
     const int grid = ((ngroups + 7) / 8) * 8 * nblk;
-    hipLaunchKernelGGL(attn_fwd_x3_kernel, dim3(grid), dim3(256), 0, as_stream(stream), static_cast<const op16 *>(qkv_split),
+    COSA_REQUIRE((size_t)N * ldq * 2 < 0x7fffffffull, "cosa_attn_fwd_bf16x3: one image's qkv rows must stay below 2 GB (buffer addressing)");
+    constexpr int kLdsX3 = 2 * 4 * BK * 128;
+    static bool attr_done = false;
+    if (!attr_done) {
+        COSA_HIP_CHECK(hipFuncSetAttribute((const void *)attn_fwd_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsX3));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(attn_fwd_x3_kernel, dim3(grid), dim3(256), kLdsX3, as_stream(stream), static_cast<const op16 *>(qkv_split),
                        static_cast<op16 *>(out_split), lse, N, H, nblk, ngroups, scale * 1.4426950408889634f, ldq, ldo);
     COSA_LAUNCH_CHECK();
     return COSA_OK;
