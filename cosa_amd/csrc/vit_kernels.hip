@@ -395,6 +395,66 @@ __global__ __launch_bounds__(256) void head_wgrad_reduce_kernel(const float *__r
     dW[e] = t;
 }
 
+// ---- im2col of the stride-16 patch projection for an image batch AND its horizontal flip (seg_helper.py:241-246: every scale goes through
+// the teacher as cat(x, x.flip(-1))): cols[(f*B + b)*h*w + py*w + px][c*P*P + dy*P + dx] = x[b][c][P*py + dy][f ? W-1-(P*px+dx) : P*px+dx]
+// in the 16-bit operand type.  Replaces flip + cat + .to(16 bit) + the permuted .contiguous() (1.3 GB of traffic per teacher pass).
+template <typename T>
+__global__ __launch_bounds__(256) void im2col_flip_kernel(const float *__restrict__ x, T *__restrict__ cols, int B, int C, int H, int W, int P, int flips)
+{
+    typedef T t8 __attribute__((ext_vector_type(8)));
+    const int h = H / P, w = W / P, KC = C * P * P, K8 = KC / 8;
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t total = (size_t)flips * B * h * w * K8;
+    if (e >= total) return;
+    const int k = (int)(e % K8) * 8;
+    size_t row = e / K8;
+    const int px = (int)(row % w);
+    row /= w;
+    const int py = (int)(row % h);
+    row /= h;
+    const int b = (int)(row % B), f = (int)(row / B);
+    const int c = k / (P * P), dy = (k - c * P * P) / P, dx = k % P;          // P % 8 == 0: the 8 elements share (c, dy)
+    const float *src = x + (((size_t)b * C + c) * H + (size_t)P * py + dy) * W;
+    const int x0 = P * px + dx;
+    t8 o;
+    if (!f) {
+        const float4 a = *reinterpret_cast<const float4 *>(src + x0), d = *reinterpret_cast<const float4 *>(src + x0 + 4);
+        o[0] = (T)a.x; o[1] = (T)a.y; o[2] = (T)a.z; o[3] = (T)a.w; o[4] = (T)d.x; o[5] = (T)d.y; o[6] = (T)d.z; o[7] = (T)d.w;
+    } else {
+        const int xe = W - 8 - x0;                                             // source columns xe .. xe + 7, reversed
+        const float4 a = *reinterpret_cast<const float4 *>(src + xe), d = *reinterpret_cast<const float4 *>(src + xe + 4);
+        o[0] = (T)d.w; o[1] = (T)d.z; o[2] = (T)d.y; o[3] = (T)d.x; o[4] = (T)a.w; o[5] = (T)a.z; o[6] = (T)a.y; o[7] = (T)a.x;
+    }
+    reinterpret_cast<t8 *>(cols)[e] = o;
+}
+
+// ---- token assembly of the no-grad encoder passes (vit.py:303-313: cat(cls, patch tokens) + pos_embed) straight into the fp32 residual
+// stream: out[b][0] = cls + pos[0], out[b][1 + i] = tok[b][i] + pos[1 + i], each sum rounded to the 16-bit operand type first (what the
+// 16-bit torch expression did) and then widened.  One pass instead of cat + add + float() + the concatenation of the scales.
+template <typename T>
+__global__ __launch_bounds__(256) void embed_finish_kernel(const T *__restrict__ tok, const T *__restrict__ cls, const T *__restrict__ pos,
+                                                          float *__restrict__ out, int B, int n, int D8)
+{
+    typedef T t8 __attribute__((ext_vector_type(8)));
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t total = (size_t)B * (n + 1) * D8;
+    if (e >= total) return;
+    const int c = (int)(e % D8);
+    const size_t row = e / D8;
+    const int j = (int)(row % (n + 1));
+    const size_t b = row / (n + 1);
+    const t8 a = j == 0 ? reinterpret_cast<const t8 *>(cls)[c] : reinterpret_cast<const t8 *>(tok)[(b * n + (j - 1)) * D8 + c];
+    const t8 p = reinterpret_cast<const t8 *>(pos)[(size_t)j * D8 + c];
+    float4 o0, o1;
+    o0.x = (float)(T)((float)a[0] + (float)p[0]); o0.y = (float)(T)((float)a[1] + (float)p[1]);
+    o0.z = (float)(T)((float)a[2] + (float)p[2]); o0.w = (float)(T)((float)a[3] + (float)p[3]);
+    o1.x = (float)(T)((float)a[4] + (float)p[4]); o1.y = (float)(T)((float)a[5] + (float)p[5]);
+    o1.z = (float)(T)((float)a[6] + (float)p[6]); o1.w = (float)(T)((float)a[7] + (float)p[7]);
+    float4 *d = reinterpret_cast<float4 *>(out + e * 8);
+    d[0] = o0;
+    d[1] = o1;
+}
+
 // ---- GELU' for the training backward of mlp.fc1 (autograd of vit.py:97-98): dH = dA * gelu_erf'(H), bf16, 8 elements per lane -------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 __global__ __launch_bounds__(256) void gelu_bwd_kernel(const bf16 *__restrict__ dA, const bf16 *__restrict__ H, bf16 *__restrict__ dH, size_t n8)
@@ -539,6 +599,39 @@ extern "C" int cosa_head_gemm_wgrad(const float *dY, const void *X, float *dW, v
     hipLaunchKernelGGL(head_wgrad_kernel, dim3(K / 128, slabs), dim3(256), 0, st, dY, static_cast<const bf16 *>(X), static_cast<float *>(workspace), M, N, K);
     COSA_LAUNCH_CHECK();
     hipLaunchKernelGGL(head_wgrad_reduce_kernel, dim3((N * K + 255) / 256), dim3(256), 0, st, static_cast<const float *>(workspace), dW, N, K, slabs);
+    COSA_LAUNCH_CHECK();
+    return COSA_OK;
+}
+
+// cols [flips * B * (H/P) * (W/P), C*P*P] (16-bit, dtype 1 = bf16 / 2 = fp16) = im2col of x [B,C,H,W] fp32 (flips = 1) or of cat(x, x.flip(-1)) (flips = 2)
+extern "C" int cosa_im2col_flip(const float *x, void *cols, int B, int C, int H, int W, int P, int flips, int dtype, void *stream)
+{
+    COSA_REQUIRE(x && cols && B > 0 && C > 0 && H > 0 && W > 0 && P > 0, "cosa_im2col_flip: bad arguments");
+    COSA_REQUIRE(P % 8 == 0 && H % P == 0 && W % P == 0 && W % 4 == 0, "cosa_im2col_flip: patch size must be a multiple of 8 and divide H and W (got P=%d H=%d W=%d)", P, H, W);
+    COSA_REQUIRE((flips == 1 || flips == 2) && (dtype == 1 || dtype == 2), "cosa_im2col_flip: flips 1 | 2, dtype 1 (bf16) | 2 (fp16)");
+    const size_t total = (size_t)flips * B * (H / P) * (W / P) * (C * P * P / 8);
+    const unsigned grid = (unsigned)((total + 255) / 256);
+    if (dtype == 1)
+        hipLaunchKernelGGL(im2col_flip_kernel<bf16>, dim3(grid), dim3(256), 0, as_stream(stream), x, static_cast<bf16 *>(cols), B, C, H, W, P, flips);
+    else
+        hipLaunchKernelGGL(im2col_flip_kernel<_Float16>, dim3(grid), dim3(256), 0, as_stream(stream), x, static_cast<_Float16 *>(cols), B, C, H, W, P, flips);
+    COSA_LAUNCH_CHECK();
+    return COSA_OK;
+}
+
+// out [B, n+1, D] fp32 = (cls | tok [B, n, D]) + pos [n+1, D]; tok / cls / pos in one 16-bit type (dtype 1 = bf16, 2 = fp16), D % 8 == 0
+extern "C" int cosa_embed_finish(const void *tok, const void *cls, const void *pos, float *out, int B, int n, int D, int dtype, void *stream)
+{
+    COSA_REQUIRE(tok && cls && pos && out && B > 0 && n > 0 && D > 0 && D % 8 == 0, "cosa_embed_finish: bad arguments (D %% 8 == 0)");
+    COSA_REQUIRE(dtype == 1 || dtype == 2, "cosa_embed_finish: dtype 1 (bf16) or 2 (fp16)");
+    const size_t total = (size_t)B * (n + 1) * (D / 8);
+    const unsigned grid = (unsigned)((total + 255) / 256);
+    if (dtype == 1)
+        hipLaunchKernelGGL(embed_finish_kernel<bf16>, dim3(grid), dim3(256), 0, as_stream(stream), static_cast<const bf16 *>(tok),
+                           static_cast<const bf16 *>(cls), static_cast<const bf16 *>(pos), out, B, n, D / 8);
+    else
+        hipLaunchKernelGGL(embed_finish_kernel<_Float16>, dim3(grid), dim3(256), 0, as_stream(stream), static_cast<const _Float16 *>(tok),
+                           static_cast<const _Float16 *>(cls), static_cast<const _Float16 *>(pos), out, B, n, D / 8);
     COSA_LAUNCH_CHECK();
     return COSA_OK;
 }

@@ -145,13 +145,16 @@ class VITNetwork(nn.Module):
         if self.compute_dtype != torch.float32 and self.classifier.weight.is_cuda:
             nn_ops.ensure_shadows(self, self.compute_dtype)
 
-    def forward_multi(self, xs):
+    def forward_multi(self, xs, flip_pairs=False):
         """forward() for several image batches of different sizes at once (no-grad bf16 only): the encoder runs all of
-        them through shared GEMM / LayerNorm launches (VisionTransformer._forward_features_fused_multi)."""
+        them through shared GEMM / LayerNorm launches (VisionTransformer._forward_features_fused_multi).  flip_pairs: every batch x
+        stands for cat(x, x.flip(-1)) (the multi-scale passes of seg_helper.py:241-246); the mirror images then exist only as im2col rows."""
         for x in xs:
             _C.require_cuda(x)
         self.refresh_shadows()
-        feats = self.encoder._forward_features_fused_multi(xs)
+        feats = self.encoder._forward_features_fused_multi(xs, flip_pairs=flip_pairs)
+        if flip_pairs:          # _heads reads only the shape of its image argument
+            xs = [torch.empty((2 * x.shape[0],) + tuple(x.shape[1:]), device="meta") for x in xs]
         return [self._heads(x, f, False, False, 'none') for x, f in zip(xs, feats)]
 
     def can_forward_multi(self, x):

@@ -180,26 +180,46 @@ class VisionTransformer(nn.Module):
     def _forward_features_fused(self, x):
         return self._forward_features_fused_multi([x])[0]
 
-    def _forward_features_fused_multi(self, xs):
+    def _forward_features_fused_multi(self, xs, flip_pairs=False):
         """Several image batches (the teacher's three scales) through the encoder TOGETHER: LayerNorm and the four
         projections are token-wise, so all tokens of all scales go through one launch each per block (M = sum B_i N_i:
         better tile quantisation on 256 CUs, a third of the launches); only attention runs per scale, on its slice of
         the packed qkv buffer."""
         if self.precision == "bf16x3":
-            return self._forward_features_x3_multi(xs)
+            return self._forward_features_x3_multi([torch.cat([x, x.flip(-1)], dim=0) for x in xs] if flip_pairs else xs)
         dt16 = self.compute_dtype                                # bf16, or fp16 (no-grad passes only: same kernels, fp16 operands)
         c = lambda p_: nn_ops.cast_param(p_, dt16)
-        toks, shapes = [], []
-        for x in xs:
-            tok, h, w = self.prepare_tokens(x)                   # 16-bit [B,N,768]
-            toks.append(tok.float().reshape(-1, tok.shape[-1]))
-            shapes.append((tok.shape[0], tok.shape[1]))
         D = self.embed_dim
-        xr = toks[0].contiguous() if len(toks) == 1 else torch.cat(toks, 0)     # fp32 residual stream [sum M_i, 768]
+        p = self.patch_size
+        nf = 2 if flip_pairs else 1                              # flip_pairs: every batch stands for cat(x, x.flip(-1)) (the teacher's passes)
+        shapes = [(nf * x.shape[0], (x.shape[2] // p) * (x.shape[3] // p) + 1) for x in xs]
         offs = [0]
         for B, N in shapes:
             offs.append(offs[-1] + B * N)
         Mtot = offs[-1]
+        if all(x.is_cuda for x in xs) and D % 128 == 0 and (3 * p * p) % 64 == 0 and p % 8 == 0:
+            # patch projection on the own GEMM, then ONE pass per scale that adds the class token and the position rows and writes the fp32
+            # residual stream in place (cosa_embed_finish) -- instead of cat(cls, tok) + pos, .float() and the concatenation of the scales
+            from .. import _C
+            xr = torch.empty((Mtot, D), device=xs[0].device, dtype=torch.float32)
+            wgt = c(self.patch_embed.proj.weight).reshape(D, -1).contiguous()
+            bias, cls = c(self.patch_embed.proj.bias).contiguous(), c(self.cls_token).reshape(-1).contiguous()
+            for x, (B, N), o0 in zip(xs, shapes, offs[:-1]):
+                h, w = x.shape[2] // p, x.shape[3] // p
+                xf = x.float().contiguous()
+                cols = torch.empty((B * h * w, x.shape[1] * p * p), device=x.device, dtype=dt16)
+                _C.check(_C.lib().cosa_im2col_flip(_C.ptr(xf), _C.ptr(cols), x.shape[0], x.shape[1], x.shape[2], x.shape[3], p, nf,
+                                                   1 if dt16 == torch.bfloat16 else 2, _C.stream_ptr()), "cosa_im2col_flip")
+                tok = nn_ops.gemm_bf16(cols, wgt, bias, nn_ops.EPI_BIAS)
+                pos = self._pos_for_grid(h, w, dt16).reshape(N, D).contiguous()
+                _C.check(_C.lib().cosa_embed_finish(_C.ptr(tok), _C.ptr(cls), _C.ptr(pos), _C.ptr(xr[o0:o0 + B * N]), B, N - 1, D,
+                                                    1 if dt16 == torch.bfloat16 else 2, _C.stream_ptr()), "cosa_embed_finish")
+        else:
+            toks = []
+            for x in ([torch.cat([x, x.flip(-1)], dim=0) for x in xs] if flip_pairs else xs):
+                tok, h, w = self.prepare_tokens(x)                   # 16-bit [B,N,768]
+                toks.append(tok.float().reshape(-1, tok.shape[-1]))
+            xr = toks[0].contiguous() if len(toks) == 1 else torch.cat(toks, 0)     # fp32 residual stream [sum M_i, 768]
         depth = len(self.blocks)
         aux_idx = self.aux_layer % depth
         aux = None

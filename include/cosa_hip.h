@@ -223,6 +223,14 @@ void cosa_gemm_set_variant(int v);   /* 0 (default): per-shape choice; 1: 128x12
  * (100 MHz s_memrealtime: min start / max end over workgroups) to slot[0..1] (uint64, caller-initialised to max / 0).
  * One-shot; used by bench.py because HIP events cannot be recorded inside a captured hipGraph.                       */
 void cosa_gemm_set_stamp_slot(void *slot);
+/* vit.py:254-262 (PatchEmbed: stride-16 conv) as a GEMM needs the image as im2col rows; the teacher's passes run every scale as
+ * cat(x, x.flip(-1)) (seg_helper.py:241-246).  cols [flips*B*(H/P)*(W/P), C*P*P] in a 16-bit type (dtype 1 = bf16, 2 = fp16) from
+ * x [B,C,H,W] fp32: rows of the images first, then (flips = 2) of their horizontal mirror images.  P % 8 == 0, P | H, P | W.        */
+int cosa_im2col_flip(const float *x, void *cols, int B, int C, int H, int W, int P, int flips, int dtype, void *stream);
+/* vit.py:303-313 (prepare_tokens: cat(cls_token, patch tokens) + interpolated pos_embed) for the no-grad passes, written straight into
+ * the fp32 residual stream: out [B, n+1, D] = (cls [D] | tok [B, n, D]) + pos [n+1, D]; tok / cls / pos share one 16-bit type
+ * (dtype 1 = bf16, 2 = fp16), each sum is rounded to that type before it is widened (the 16-bit torch expression's value); D % 8 == 0. */
+int cosa_embed_finish(const void *tok, const void *cls, const void *pos, float *out, int B, int n, int D, int dtype, void *stream);
 /* models/__init__.py:190-192 (classifier / aux_classifier as 1x1 convs over the tokens) and conv_head.py:38 (conv8): the narrow heads
  * Y[M, N <= 32] (fp32, columns [col0, col0+N) of rows with stride ldy) = X W^T, fp32 accumulation, fixed reduction order per row
  * (results do not depend on what else is in the batch).  X: image b = rows_per_img rows at X + b*img_stride (elements), row stride
