@@ -229,12 +229,16 @@ class VisionTransformer(nn.Module):
             qkv = nn_ops.gemm_bf16(y, c(blk.attn.qkv.weight), c(blk.attn.qkv.bias), nn_ops.EPI_BIAS)
             for (B, N), o0, o1 in zip(shapes, offs[:-1], offs[1:]):
                 nn_ops._attn_fwd(qkv[o0:o1].view(B, N, 3 * D), B, N, self.num_heads, out=o[o0:o1].view(B, N, D))
-            nn_ops.gemm_bf16(o, c(blk.attn.proj.weight), c(blk.attn.proj.bias), nn_ops.EPI_RESIDUAL, residual=xr, out=xr)
+            # the stream is updated in place, except right after the auxiliary layer: its output stays where it is (it IS the aux
+            # feature) and the next residual GEMM writes the stream to a fresh buffer -- no 270-MB clone
+            xn = torch.empty_like(xr) if aux is xr else xr
+            nn_ops.gemm_bf16(o, c(blk.attn.proj.weight), c(blk.attn.proj.bias), nn_ops.EPI_RESIDUAL, residual=xr, out=xn)
+            xr = xn
             y, _ = nn_ops.layernorm_f32(xr, c(blk.norm2.weight), c(blk.norm2.bias), blk.norm2.eps)
             hmid = nn_ops.gemm_bf16(y, c(blk.mlp.fc1.weight), c(blk.mlp.fc1.bias), nn_ops.EPI_GELU)
             nn_ops.gemm_bf16(hmid, c(blk.mlp.fc2.weight), c(blk.mlp.fc2.bias), nn_ops.EPI_RESIDUAL, residual=xr, out=xr)
             if i == aux_idx and aux_idx != depth - 1:
-                aux = xr.clone()
+                aux = xr
         xn16, xn32 = nn_ops.layernorm_f32(xr, c(self.norm.weight), c(self.norm.bias), self.norm.eps, True, True)
         if aux is None:
             aux = xn32
