@@ -401,3 +401,31 @@ def test_bench_contract_small(flags):
               "data", "config", "roofline"):
         assert k in d, k
     assert d["value"] > 0 and d["n_gpus"] == 1 and d["steps"] == int(flags[1]) and d["roofline"]["bound"] in ("mfma", "hbm")
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_im2col_flip_and_embed_finish_equal_the_torch_expressions(dt):
+    """the teacher's token assembly: cosa_im2col_flip = the im2col view of cat(x, x.flip(-1)) in 16 bits (vit.py:254-262 as a GEMM operand,
+    seg_helper.py:241-246), cosa_embed_finish = (cat(cls, tok) + pos).float() (vit.py:303-313) -- both bit for bit, ragged sizes included"""
+    from cosa_amd import _C
+    L = _C.lib()
+    code = 1 if dt == torch.bfloat16 else 2
+    torch.manual_seed(5)
+    for B, H, W in ((3, 64, 96), (2, 224, 224), (1, 16, 16)):
+        x = torch.randn(B, 3, H, W, device="cuda")
+        p = 16
+        h, w = H // p, W // p
+        for flips in (1, 2):
+            cols = torch.full((flips * B * h * w + 2, 768), 7.0, device="cuda", dtype=dt)        # two canary rows
+            _C.check(L.cosa_im2col_flip(_C.ptr(x), _C.ptr(cols), B, 3, H, W, p, flips, code, _C.stream_ptr()), "im2col")
+            xx = torch.cat([x, x.flip(-1)], 0) if flips == 2 else x
+            ref = xx.to(dt).reshape(flips * B, 3, h, p, w, p).permute(0, 2, 4, 1, 3, 5).reshape(flips * B * h * w, 768)
+            assert torch.equal(cols[:-2], ref) and torch.all(cols[-2:] == 7.0)
+        n, D = h * w, 768
+        tok = torch.randn(B, n, D, device="cuda").to(dt)
+        cls = torch.randn(1, 1, D, device="cuda").to(dt)
+        pos = torch.randn(1, n + 1, D, device="cuda").to(dt)
+        out = torch.full((B * (n + 1) + 1, D), 7.0, device="cuda")
+        _C.check(L.cosa_embed_finish(_C.ptr(tok), _C.ptr(cls), _C.ptr(pos), _C.ptr(out), B, n, D, code, _C.stream_ptr()), "embed")
+        ref = (torch.cat((cls.expand(B, -1, -1), tok), dim=1) + pos).float().reshape(-1, D)
+        assert torch.equal(out[:-1], ref) and torch.all(out[-1] == 7.0)
