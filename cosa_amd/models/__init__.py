@@ -145,17 +145,18 @@ class VITNetwork(nn.Module):
         if self.compute_dtype != torch.float32 and self.classifier.weight.is_cuda:
             nn_ops.ensure_shadows(self, self.compute_dtype)
 
-    def forward_multi(self, xs, flip_pairs=False):
+    def forward_multi(self, xs, flip_pairs=False, need_cls=True):
         """forward() for several image batches of different sizes at once (no-grad bf16 only): the encoder runs all of
         them through shared GEMM / LayerNorm launches (VisionTransformer._forward_features_fused_multi).  flip_pairs: every batch x
-        stands for cat(x, x.flip(-1)) (the multi-scale passes of seg_helper.py:241-246); the mirror images then exist only as im2col rows."""
+        stands for cat(x, x.flip(-1)) (the multi-scale passes of seg_helper.py:241-246); the mirror images then exist only as im2col rows.
+        need_cls=False leaves out global pooling and the two classification heads (their slots in the result tuples are None)."""
         for x in xs:
             _C.require_cuda(x)
         self.refresh_shadows()
         feats = self.encoder._forward_features_fused_multi(xs, flip_pairs=flip_pairs)
         if flip_pairs:          # _heads reads only the shape of its image argument
             xs = [torch.empty((2 * x.shape[0],) + tuple(x.shape[1:]), device="meta") for x in xs]
-        return [self._heads(x, f, False, False, 'none') for x, f in zip(xs, feats)]
+        return [self._heads(x, f, False, False, 'none', need_cls=need_cls) for x, f in zip(xs, feats)]
 
     def can_forward_multi(self, x):
         return self.encoder.use_fused(x)
@@ -168,7 +169,7 @@ class VITNetwork(nn.Module):
             self.refresh_shadows()
         return self._heads(x, self.encoder.features_ex(x), cam_only, seg_only, detach)
 
-    def _heads(self, x, feats, cam_only, seg_only, detach):
+    def _heads(self, x, feats, cam_only, seg_only, detach, need_cls=True):
         dt = self.compute_dtype
         B = x.shape[0]
         _, tok, tok_aux, tok32 = feats
@@ -190,6 +191,8 @@ class VITNetwork(nn.Module):
             cam, cam_aux = cam.detach(), cam_aux.detach()
         if cam_only:
             return cam, cam_aux
+        if not need_cls:        # the training loop's teacher passes never read the classification logits (seg_helper.py:247-249 drops them)
+            return None, None, x4, seg, cam, cam_aux
         cls_x4 = self._cls_head(self._pool(tok), self.classifier.weight, dt)
         cls_aux = self._cls_head(self._pool(tok_aux), self.aux_classifier.weight, dt)
         return cls_x4, cls_aux, x4, seg, cam, cam_aux

@@ -62,7 +62,7 @@ def multi_scale_camseg(model, imgs, scales, _active_labels=None, _seg_scales=Fal
         # cosa_amd networks can take all scales in one go (shared GEMM/LayerNorm launches across scales), the mirror images only as
         # im2col rows of the patch projection (flip_pairs)
         if getattr(model, "can_forward_multi", lambda _x: False)(scaled[0]):
-            multi, inputs = model.forward_multi(scaled, flip_pairs=True), None
+            multi, inputs = model.forward_multi(scaled, flip_pairs=True, need_cls=False), None
         else:
             multi, inputs = None, [torch.cat([x_, x_.flip(-1)], dim=0) for x_ in scaled]
             _refresh_once(model)
@@ -96,12 +96,11 @@ def multi_scale_camsegv3(model, imgs, scales, getcls=False, _per_image_cls=False
     cam = cam_aux = seg = None
     cls_f_ = cls_a_ = None
     with torch.no_grad():
-        inputs = []
-        for s in scales:
-            imgs_ = imgs if s == 1.0 else F.interpolate(imgs, size=(int(s * h), int(s * w)), mode='bilinear', align_corners=False)
-            inputs.append(torch.cat([imgs_, imgs_.flip(-1)], dim=0))
-        multi = model.forward_multi(inputs) if getattr(model, "can_forward_multi", lambda _x: False)(inputs[0]) else None
-        if multi is None:
+        scaled = [imgs if s == 1.0 else F.interpolate(imgs, size=(int(s * h), int(s * w)), mode='bilinear', align_corners=False) for s in scales]
+        if getattr(model, "can_forward_multi", lambda _x: False)(scaled[0]):
+            multi, inputs = model.forward_multi(scaled, flip_pairs=True, need_cls=bool(getcls)), None
+        else:
+            multi, inputs = None, [torch.cat([x_, x_.flip(-1)], dim=0) for x_ in scaled]
             _refresh_once(model)
         for si, s in enumerate(scales):
             with nn_ops.shadows_fresh():
