@@ -1737,7 +1737,12 @@ static int launch_v6(const op16 *x, const op16 *w, const op16 *b, const float *r
     // round instead of a whole one.  Same products, same fp32 accumulation order per output element (k ascending) as the jobs it replaces.
     static const int tail_max = [] { const char *e = getenv("COSA_GEMM_TAIL"); return e ? atoi(e) : 48; }();
     int run = ntiles;
-    if (FR == 4 && SPLIT == 0 && ABL6 == 0 && AUX == 0 && ntiles > 256 && ntiles % 256 != 0 && ntiles % 256 <= tail_max) run = ntiles - ntiles % 256;
+    // ... when it pays: the idle share of the last round must be a sizeable part of the whole launch (> 10 % of its rounds).  The teacher's
+    // N = 768 projections (4.03 rounds) qualify; its 12.09- and 16.1-round launches do not -- measured in the step: tail for all three
+    // 45.83 / 45.96 ms, for the 4.03-round launches only 45.66 / 45.65, none 46.05 / 46.22
+    const int rem = ntiles % 256, rounds_up = (ntiles + 255) / 256;
+    if (FR == 4 && SPLIT == 0 && ABL6 == 0 && AUX == 0 && ntiles > 256 && rem != 0 && rem <= tail_max && (256 - rem) * 10 > 256 * rounds_up)
+        run = ntiles - rem;
     // (tile order inside an XCD -- bands of 3 / 4 / 6 / 12 n-tiles so that the W panels in flight fit the L2 next to the X panels -- was
     //  measured on the teacher's shapes: no difference beyond noise, 352 .. 357 us on the qkv projection; the m-panel-major order stays)
     // start stagger (see the kernel): measured to make no difference, off

@@ -160,7 +160,8 @@ def gemm_bf16(x, w, b, epilogue=EPI_BIAS, residual=None, out=None):
         # the stamped span is the persistent kernel's; when the job count leaves a small remainder its tail runs as a second, tiny launch
         # (csrc/gemm_kernels.hip: launch_v6) whose share of the flops is not inside the span
         nt = ((M + 255) // 256) * (N // 256) if N % 256 == 0 else 0
-        frac = (nt - nt % 256) / nt if (nt > 256 and 0 < nt % 256 <= int(os.environ.get("COSA_GEMM_TAIL", "48"))) else 1.0
+        rem, rounds_up = nt % 256, (nt + 255) // 256
+        frac = (nt - rem) / nt if (nt > 256 and 0 < rem <= int(os.environ.get("COSA_GEMM_TAIL", "48")) and (256 - rem) * 10 > 256 * rounds_up) else 1.0
         _C.fn16("cosa_gemm_set_stamp_slot", dt)(gemm_stamps.next_slot(2.0 * M * N * K * frac))
     with _C.profiled("gemm_bf16"):
         _C.check(_C.fn16("cosa_gemm_bf16", dt)(_C.ptr(x), _C.ptr(w), _C.ptr(b), _C.ptr(residual), _C.ptr(out), M, N, K, epilogue,
