@@ -68,6 +68,7 @@ def build_all(force=False, verbose=False):
             continue
         op = os.path.join(OBJDIR, src.replace(".hip", ("_" + tag if tag else "") + ".o"))
         objs.append(op)
+        extra = extra + os.environ.get("COSA_EXTRA_FLAGS_" + src.split(".")[0].upper(), "").split()     # experiments: per-file extra flags
         if force or _newer(sp, op) or os.path.getmtime(op) < hdr_time:
             cmd = [hipcc, "-c", sp, "-o", op] + COMMON + extra
             if verbose:

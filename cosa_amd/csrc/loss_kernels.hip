@@ -163,6 +163,16 @@ __global__ __launch_bounds__(256) void seg_loss_bwd_kernel(const float *__restri
     const int tid = threadIdx.y * 16 + threadIdx.x;
     for (int e = tid; e < K * TC * TC; e += 256) gt[e] = 0.f;
     __syncthreads();
+    // The gradient of a low-res cell collects 16 x 16 pixels: per-thread LDS atomics on the same four addresses serialise.  In a wave, the
+    // 4 x 4 quads whose lane numbers differ in bits 0, 1 (x) and 4, 5 (y) read the same four cells whenever the up-sampling factor is 16
+    // and the tile origin a multiple of 32 (checked, not assumed); then they are summed with four butterfly steps and one lane adds.
+    bool grp_ok = c.valid && c.t[0].o00 == c.t[3].o00 && c.t[0].o11 == c.t[3].o11 && c.t[0].o01 == c.t[3].o01 && c.t[0].o10 == c.t[3].o10;
+#pragma unroll
+    for (int sft = 0; sft < 4; sft++) {
+        const int x = sft == 0 ? 1 : (sft == 1 ? 2 : (sft == 2 ? 16 : 32));
+        grp_ok = grp_ok && __shfl_xor(c.t[0].o00, x, 64) == c.t[0].o00 && __shfl_xor(c.t[0].o11, x, 64) == c.t[0].o11;
+    }
+    const bool grouped = __all(grp_ok) != 0;
     if (c.valid) {
         const size_t SS = (size_t)S * S;
         const int Sq = S >> 1;
@@ -208,7 +218,26 @@ __global__ __launch_bounds__(256) void seg_loss_bwd_kernel(const float *__restri
                 dz[p] = ca[p] * (pk - (la[p] == k ? 1.f : 0.f)) + cb[p] * (pk - (lb[p] == k ? 1.f : 0.f)) + pk * (dP - dot[p]);
             }
             float *gp = gt + k * TC * TC;
-            if (same) {       // the quad's four pixels share their four low-res cells (always true for S = 16 h)
+            if (grouped) {    // 4 x 4 quads (lanes differing in bits 0, 1, 4, 5) share their four cells: one lane adds the sum of all sixteen
+                float v00 = dz[0] * c.t[0].w00 + dz[1] * c.t[1].w00 + dz[2] * c.t[2].w00 + dz[3] * c.t[3].w00;
+                float v01 = dz[0] * c.t[0].w01 + dz[1] * c.t[1].w01 + dz[2] * c.t[2].w01 + dz[3] * c.t[3].w01;
+                float v10 = dz[0] * c.t[0].w10 + dz[1] * c.t[1].w10 + dz[2] * c.t[2].w10 + dz[3] * c.t[3].w10;
+                float v11 = dz[0] * c.t[0].w11 + dz[1] * c.t[1].w11 + dz[2] * c.t[2].w11 + dz[3] * c.t[3].w11;
+#pragma unroll
+                for (int sft = 0; sft < 4; sft++) {
+                    const int x = sft == 0 ? 1 : (sft == 1 ? 2 : (sft == 2 ? 16 : 32));
+                    v00 += __shfl_xor(v00, x, 64);
+                    v01 += __shfl_xor(v01, x, 64);
+                    v10 += __shfl_xor(v10, x, 64);
+                    v11 += __shfl_xor(v11, x, 64);
+                }
+                if (((threadIdx.y * 16 + threadIdx.x) & 0x33) == 0) {
+                    atomicAdd(gp + c.t[0].o00, v00);
+                    atomicAdd(gp + c.t[0].o01, v01);
+                    atomicAdd(gp + c.t[0].o10, v10);
+                    atomicAdd(gp + c.t[0].o11, v11);
+                }
+            } else if (same) {       // the quad's four pixels share their four low-res cells (always true for S = 16 h)
                 atomicAdd(gp + c.t[0].o00, dz[0] * c.t[0].w00 + dz[1] * c.t[1].w00 + dz[2] * c.t[2].w00 + dz[3] * c.t[3].w00);
                 atomicAdd(gp + c.t[0].o01, dz[0] * c.t[0].w01 + dz[1] * c.t[1].w01 + dz[2] * c.t[2].w01 + dz[3] * c.t[3].w01);
                 atomicAdd(gp + c.t[0].o10, dz[0] * c.t[0].w10 + dz[1] * c.t[1].w10 + dz[2] * c.t[2].w10 + dz[3] * c.t[3].w10);
