@@ -24,6 +24,7 @@ _SIGS = {
     "cosa_last_error": (ctypes.c_char_p, []),
     "cosa_denormalize_img": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "cosa_cam_minmax_norm": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "cosa_cam_minmax_norm_ws": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "cosa_cam_flip_merge_upsample": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                      c_void_p]),
     "cosa_cam2mask_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),

@@ -132,6 +132,47 @@ __global__ __launch_bounds__(1024) void minmax_norm_kernel(float *__restrict__ c
     }
 }
 
+// The same normalisation with the plane spread over several workgroups (the one-block-per-plane kernel above keeps ~40 of 256 CUs busy when
+// only the 2-3 classes of an image are live): pass 1 reduces min and max of the plane through order-preserving unsigned keys and integer
+// atomics, pass 2 normalises.  max_x fl(x + mneg) = fl(max_x x + mneg) (rounding is monotonic), so the result is bit for bit the above.
+__device__ __forceinline__ unsigned f2key(float f) { const unsigned u = __float_as_uint(f); return u ^ ((u >> 31) ? 0xffffffffu : 0x80000000u); }
+__device__ __forceinline__ float key2f(unsigned k) { return __uint_as_float(k ^ ((k >> 31) ? 0x80000000u : 0xffffffffu)); }
+
+__global__ __launch_bounds__(256) void minmax_reduce_kernel(const float *__restrict__ cam, int HW, const float *__restrict__ active,
+                                                           unsigned *__restrict__ kmin, unsigned *__restrict__ kmax)
+{
+    __shared__ float sh[8];
+    const int plane = blockIdx.y;
+    if (active && active[plane] == 0.0f) return;
+    const float *x = cam + (size_t)plane * HW;
+    const int per = (HW + gridDim.x - 1) / gridDim.x, i0 = blockIdx.x * per, i1 = min(HW, i0 + per);
+    float mn = INFINITY, mx = -INFINITY;
+    for (int i = i0 + threadIdx.x; i < i1; i += 256) {
+        const float v = x[i];
+        mn = fminf(mn, v);
+        mx = fmaxf(mx, v);
+    }
+    mx = block_max<256>(mx, sh);
+    __syncthreads();
+    mn = -block_max<256>(-mn, sh);
+    if (threadIdx.x == 0 && i0 < i1) {
+        atomicMin(&kmin[plane], f2key(mn));
+        atomicMax(&kmax[plane], f2key(mx));
+    }
+}
+
+__global__ __launch_bounds__(256) void minmax_apply_kernel(float *__restrict__ cam, int HW, const float *__restrict__ active,
+                                                          const unsigned *__restrict__ kmin, const unsigned *__restrict__ kmax)
+{
+    const int plane = blockIdx.y;
+    if (active && active[plane] == 0.0f) return;
+    float *x = cam + (size_t)plane * HW;
+    const float mneg = -key2f(kmin[plane]);
+    const float den = (key2f(kmax[plane]) + mneg) + 1e-5f;
+    const int per = (HW + gridDim.x - 1) / gridDim.x, i0 = blockIdx.x * per, i1 = min(HW, i0 + per);
+    for (int i = i0 + threadIdx.x; i < i1; i += 256) x[i] = (x[i] + mneg) / den;
+}
+
 // ---- multi_scale_camseg tail: upsample + flip-merge (+relu) + accumulate ---------------------
 // thread per output pixel; grid (ceil(S*S/256), C, B)
 // grid (pixel blocks, images): the class planes are a loop INSIDE the workgroup.  Absent classes cost one uniform branch instead of a
@@ -325,6 +366,23 @@ extern "C" int cosa_cam_minmax_norm(float *cam, int BC, int HW, const float *act
 {
     COSA_REQUIRE(cam && BC > 0 && HW > 0, "cosa_cam_minmax_norm: bad arguments");
     hipLaunchKernelGGL(minmax_norm_kernel, dim3(BC), dim3(1024), 0, as_stream(stream), cam, HW, active);
+    COSA_LAUNCH_CHECK();
+    return COSA_OK;
+}
+
+// the same, a plane spread over several workgroups; workspace: 2 * BC unsigned (min keys, then max keys), written by this call
+extern "C" int cosa_cam_minmax_norm_ws(float *cam, int BC, int HW, const float *active, void *workspace, void *stream)
+{
+    COSA_REQUIRE(cam && workspace && BC > 0 && HW > 0 && BC <= 65535, "cosa_cam_minmax_norm_ws: bad arguments");
+    hipStream_t st = as_stream(stream);
+    unsigned *kmin = static_cast<unsigned *>(workspace), *kmax = kmin + BC;
+    COSA_HIP_CHECK(hipMemsetAsync(kmin, 0xFF, (size_t)BC * sizeof(unsigned), st));
+    COSA_HIP_CHECK(hipMemsetAsync(kmax, 0x00, (size_t)BC * sizeof(unsigned), st));
+    int chunks = (HW + 8191) / 8192;                 // >= 32 elements per thread
+    chunks = chunks < 1 ? 1 : (chunks > 64 ? 64 : chunks);
+    hipLaunchKernelGGL(minmax_reduce_kernel, dim3(chunks, BC), dim3(256), 0, st, cam, HW, active, kmin, kmax);
+    COSA_LAUNCH_CHECK();
+    hipLaunchKernelGGL(minmax_apply_kernel, dim3(chunks, BC), dim3(256), 0, st, cam, HW, active, kmin, kmax);
     COSA_LAUNCH_CHECK();
     return COSA_OK;
 }

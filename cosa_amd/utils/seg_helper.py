@@ -34,7 +34,8 @@ def _flip_merge_upsample(src, dst, B, S, mode, accumulate, active=None):
 def cam_minmax_norm_(cam, active=None):
     """In place x -= min; x /= max + 1e-5 per (b,c) plane (utils/seg_helper.py:265-266,269-270)."""
     b, c, h, w = cam.shape
-    _C.check(_C.lib().cosa_cam_minmax_norm(_C.ptr(cam), b * c, h * w, _C.ptr(active), _C.stream_ptr()), "cosa_cam_minmax_norm")
+    ws = torch.empty(2 * b * c, device=cam.device, dtype=torch.int32)      # per-plane min / max keys (csrc/label_kernels.hip)
+    _C.check(_C.lib().cosa_cam_minmax_norm_ws(_C.ptr(cam), b * c, h * w, _C.ptr(active), _C.ptr(ws), _C.stream_ptr()), "cosa_cam_minmax_norm_ws")
     return cam
 
 

@@ -42,6 +42,8 @@ int cosa_denormalize_img(const float *img, float *out, int B, int H, int W, void
  *   cam [BC, HW]; `active` (optional, [BC]): planes whose entry is 0 are known all-zero and skipped
  * ------------------------------------------------------------------------------------- */
 int cosa_cam_minmax_norm(float *cam, int BC, int HW, const float *active /* [BC] or NULL */, void *stream);
+/* the same result bit for bit with a plane spread over several workgroups; workspace: 2 * BC unsigned ints of device memory */
+int cosa_cam_minmax_norm_ws(float *cam, int BC, int HW, const float *active /* [BC] or NULL */, void *workspace, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * utils/seg_helper.py:252-270  fused tail of multi_scale_camseg for ONE scale:
