@@ -9,6 +9,7 @@
 //                          (no atomics) -- replaces layer_norm_grad_input + 2 gamma/beta kernels + the gradient add.
 // HBM-bound: 8 B per element forward, 8 B backward.  One wave per row, 12 elements per lane (D = 768).
 #include "kernels.hpp"
+#include <cstdlib>
 
 namespace cosa {
 namespace {
@@ -652,7 +653,7 @@ extern "C" int cosa_add_layernorm_fwd(const void *x, const void *delta, const vo
 extern "C" size_t cosa_layernorm_bwd_workspace_bytes(int rows, int dim)
 {
     (void)rows;
-    return (size_t)256 * 2 * dim * sizeof(float);
+    return (size_t)1024 * 2 * dim * sizeof(float);             // partial rows of up to 1024 workgroups
 }
 
 extern "C" int cosa_layernorm_bwd(const void *dy, const void *x_new, const float *mean, const float *rstd, const void *gamma,
@@ -662,7 +663,10 @@ extern "C" int cosa_layernorm_bwd(const void *dy, const void *x_new, const float
     COSA_REQUIRE(dy && x_new && mean && rstd && gamma && dx && dgamma && dbeta && workspace && rows > 0, "cosa_layernorm_bwd: bad arguments");
     COSA_REQUIRE(dim == D, "cosa_layernorm_bwd: dim must be 768 (ViT-B)");
     COSA_REQUIRE(workspace_bytes >= cosa_layernorm_bwd_workspace_bytes(rows, dim), "cosa_layernorm_bwd: workspace too small");
-    int per = (rows + 255) / 256;
+    // two workgroups per CU: a wave walks its rows serially with one row of loads in flight, so the kernel is latency-bound on occupancy
+    // (256 / 512 / 768 / 1024 workgroups: 22.3 + 4.8 / 16.0 + 6.5 / 17.1 + 8.1 / 18.9 + 9.5 us for the kernel + its partial-sum reduction)
+    static const int target_blocks = [] { const char *e = getenv("COSA_LN_BWD_BLOCKS"); const int v = e ? atoi(e) : 512; return v < 1 ? 1 : (v > 1024 ? 1024 : v); }();
+    int per = (rows + target_blocks - 1) / target_blocks;
     per = (per + 3) / 4 * 4;                                  // whole rounds of the workgroup's 4 waves
     const int nblk = (rows + per - 1) / per;
     hipStream_t st = as_stream(stream);
