@@ -478,21 +478,48 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const bf16 *__restrict__ 
 struct TransposeRec { const float *src; bf16 *dst; int rows, cols, tile0, tiles_c; };       // src [rows, cols] fp32 -> dst [cols, rows] bf16
 __global__ __launch_bounds__(256) void transpose_cast_kernel(const TransposeRec *__restrict__ recs, int nrec)
 {
+    // 64 x 64 tiles; 16-byte loads (a row of the tile = 16 lanes), 4-byte stores (a lane writes two consecutive destination elements).
+    // Measured per step (85 M weights): 4-byte loads + 2-byte stores 160 us; 128-row tiles (33 KB of LDS) 254-260 us; this form 112 us (4.5 TB/s)
     __shared__ float tile[64][65];
+    typedef __bf16 bf16x2t __attribute__((ext_vector_type(2)));
     int t = 0;
     while (t + 1 < nrec && (int)blockIdx.x >= recs[t + 1].tile0) t++;
     const TransposeRec r = recs[t];
     const int lt = blockIdx.x - r.tile0;
     const int r0 = (lt / r.tiles_c) * 64, c0 = (lt % r.tiles_c) * 64;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    for (int i = ty; i < 64; i += 4) {
-        const int rr = r0 + i, cc = c0 + tx;
-        tile[i][tx] = (rr < r.rows && cc < r.cols) ? r.src[(size_t)rr * r.cols + cc] : 0.f;
+    const int tid = threadIdx.x;
+    const bool vec = (r.cols & 3) == 0;
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+        const int i = (tid >> 4) + 16 * it, c4 = (tid & 15) * 4;
+        const int rr = r0 + i, cc = c0 + c4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (rr < r.rows) {
+            if (vec && cc + 3 < r.cols) v = *reinterpret_cast<const float4 *>(r.src + (size_t)rr * r.cols + cc);
+            else {
+                if (cc < r.cols) v.x = r.src[(size_t)rr * r.cols + cc];
+                if (cc + 1 < r.cols) v.y = r.src[(size_t)rr * r.cols + cc + 1];
+                if (cc + 2 < r.cols) v.z = r.src[(size_t)rr * r.cols + cc + 2];
+                if (cc + 3 < r.cols) v.w = r.src[(size_t)rr * r.cols + cc + 3];
+            }
+        }
+        tile[i][c4] = v.x; tile[i][c4 + 1] = v.y; tile[i][c4 + 2] = v.z; tile[i][c4 + 3] = v.w;
     }
     __syncthreads();
-    for (int i = ty; i < 64; i += 4) {
-        const int cc = c0 + i, rr = r0 + tx;
-        if (cc < r.cols && rr < r.rows) r.dst[(size_t)cc * r.rows + rr] = (bf16)tile[tx][i];
+    const bool even = (r.rows & 1) == 0;
+    const int l32 = tid & 31, sub = tid >> 5;            // 8 half-waves: each writes one destination row segment (64 elements) per trip
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+        const int i = sub + 8 * it;
+        const int cc = c0 + i, rr = r0 + 2 * l32;
+        if (cc >= r.cols || rr >= r.rows) continue;
+        bf16 *d = r.dst + (size_t)cc * r.rows + rr;
+        if (even) {
+            *reinterpret_cast<bf16x2t *>(d) = (bf16x2t){(bf16)tile[2 * l32][i], (bf16)tile[2 * l32 + 1][i]};
+        } else {
+            d[0] = (bf16)tile[2 * l32][i];
+            if (rr + 1 < r.rows) d[1] = (bf16)tile[2 * l32 + 1][i];
+        }
     }
 }
 
