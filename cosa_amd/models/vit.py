@@ -307,12 +307,14 @@ class VisionTransformer(nn.Module):
             nn_ops.gemm_x3(bf["y"], W[f"{i}.qkv"], M, 3 * D, D, nn_ops.EPI_BIAS, out=bf["qkv"], ldy=2 * 3 * D)
             for (B, N), o0, o1 in zip(shapes, offs[:-1], offs[1:]):
                 nn_ops.attn_fwd_x3(bf["qkv"][o0:o1], B, N, H, bf["o"][o0:o1])
-            nn_ops.gemm_x3(bf["o"], W[f"{i}.proj"], M, D, D, nn_ops.EPI_RESIDUAL, residual=xr, out=xr)
+            xn = torch.empty_like(xr) if aux is xr else xr              # right after the auxiliary layer: keep its output, no clone
+            nn_ops.gemm_x3(bf["o"], W[f"{i}.proj"], M, D, D, nn_ops.EPI_RESIDUAL, residual=xr, out=xn)
+            xr = xn
             nn_ops.layernorm_split(xr, f(blk.norm2.weight), f(blk.norm2.bias), blk.norm2.eps, out=bf["y"])
             nn_ops.gemm_x3(bf["y"], W[f"{i}.fc1"], M, bf["h"].shape[1] // 2 - 32, D, nn_ops.EPI_GELU, out=bf["h"], ldy=bf["h"].shape[1])
             nn_ops.gemm_x3(bf["h"], W[f"{i}.fc2"], M, D, bf["h"].shape[1] // 2 - 32, nn_ops.EPI_RESIDUAL, residual=xr, out=xr)
             if i == aux_idx and aux_idx != depth - 1:
-                aux = xr.clone()
+                aux = xr
         yfin = torch.empty_like(bf["y"])
         _, xn32 = nn_ops.layernorm_split(xr, f(self.norm.weight), f(self.norm.bias), self.norm.eps, out=yfin, want_f32=True)
         if aux is None:
