@@ -265,6 +265,52 @@ __global__ __launch_bounds__(256) void seg_loss_bwd_kernel(const float *__restri
 }
 
 
+// ---- multilabel soft-margin loss (the two classification losses main.py:127-128 and cam_loss seg_helper.py:593-602), forward and gradient
+// in one pass: loss = mean_r mean_c -( y log s(v) + (1 - y) log s(-v) ),  v = x or relu(x);  d loss / d x = (s(v) - y) / (R C) [x > 0].
+// x, y, grad: element (r, c) at (r / HW) * C * HW + c * HW + r % HW  (HW = 1: row-major [R, C]; HW = h w: NCHW planes, r = (b, pixel)).
+// torch evaluates this as ~10 element-wise kernels forward and as many backward, four times per step.
+__global__ __launch_bounds__(256) void msm_loss_kernel(const float *__restrict__ x, const float *__restrict__ y, float *__restrict__ grad,
+                                                      double *__restrict__ part, int R, int C, int HW, int relu, float inv_rc)
+{
+    __shared__ double red[4];
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    double acc = 0.0;
+    if (r < R) {
+        const size_t base = (size_t)(r / HW) * C * HW + (size_t)(r % HW);
+        float s = 0.f;
+        for (int c = 0; c < C; c++) {
+            const size_t o = base + (size_t)c * HW;
+            const float xv = x[o], yv = y[o];
+            const float v = relu ? fmaxf(xv, 0.f) : xv;
+            const float e = __expf(-fabsf(v));
+            const float ls = fminf(v, 0.f) - log1pf(e);                 // log sigmoid(v)
+            s += (1.f - yv) * v - ls;
+            const float sg = v >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);   // sigmoid(v)
+            grad[o] = (relu && !(xv > 0.f)) ? 0.f : (sg - yv) * inv_rc;
+        }
+        acc = (double)s;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void msm_loss_finalize_kernel(const double *__restrict__ part, int nparts, float *__restrict__ loss, float inv_rc)
+{
+    __shared__ double red[256];
+    double t = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 256) t += part[i];
+    red[threadIdx.x] = t;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss[0] = (float)(red[0] * (double)inv_rc);
+}
+
 // ---- cam_loss targets without the full-resolution teacher seg ----------------------------------------------------
 // main.py:227-228 + seg_helper.py:553-568,593-597: seg_ps (sum over scales of up(seg)+unflip(up(seg_flip)), [b,K,S,S]) ->
 // mask absent classes with -1e5 -> softmax(x / T) -> foreground channels -> bilinear down to the CAM grid.  The
@@ -400,6 +446,21 @@ extern "C" int cosa_seg_loss_backward(const float *seg_lr, const float *maskA, c
     const size_t lds = (size_t)2 * K * TC * TC * sizeof(float);
     hipLaunchKernelGGL(seg_loss_bwd_kernel, grid, blk, lds, st, seg_lr, maskA, maskB, sums, AS, roi, g_seg, g_regw, grad_seg_lr, B, K, hs,
                        ws, S, (float)hs / (float)S, (float)ws / (float)S);
+    COSA_LAUNCH_CHECK();
+    return COSA_OK;
+}
+
+// multilabel_soft_margin_loss(v, y) with v = x or relu(x), and its gradient w.r.t. x for a unit upstream gradient (F.multilabel_soft_margin_loss,
+// main.py:127-128, seg_helper.py:593-602).  x / y / grad fp32 with the element layout above; workspace: ceil(R / 256) doubles.
+extern "C" int cosa_msm_loss(const float *x, const float *y, float *grad, float *loss, void *workspace, int R, int C, int HW, int relu, void *stream)
+{
+    COSA_REQUIRE(x && y && grad && loss && workspace && R > 0 && C > 0 && HW > 0 && R % HW == 0, "cosa_msm_loss: bad arguments");
+    const int nblk = (R + 255) / 256;
+    const float inv_rc = (float)(1.0 / ((double)R * (double)C));
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(msm_loss_kernel, dim3(nblk), dim3(256), 0, st, x, y, grad, static_cast<double *>(workspace), R, C, HW, relu, inv_rc);
+    COSA_LAUNCH_CHECK();
+    hipLaunchKernelGGL(msm_loss_finalize_kernel, dim3(1), dim3(256), 0, st, static_cast<const double *>(workspace), nblk, loss, inv_rc);
     COSA_LAUNCH_CHECK();
     return COSA_OK;
 }

@@ -214,8 +214,8 @@ class CoSATrainer:
         cam_ps, cam_aux_ps, seg_ps = self._teacher(wimg, cls_label)
         cls_final, cls_aux, _feat, seg_pred, cam_pred, cam_aux_pred = self.model_ON(simg, cam_only=False, detach=args.detach)
         self._join_teacher()
-        cls_loss = F.multilabel_soft_margin_loss(cls_final, cls_label)
-        cls_loss_aux = F.multilabel_soft_margin_loss(cls_aux, cls_label)
+        cls_loss = seg_helper.multilabel_soft_margin(cls_final, cls_label)          # main.py:127-128, one kernel each
+        cls_loss_aux = seg_helper.multilabel_soft_margin(cls_aux, cls_label)
         with torch.no_grad():
             if args.use_cammix:
                 cam_ps = (cam_ps + cam_aux_ps) / 2

@@ -618,8 +618,49 @@ def cam_loss_targets(seg_scales, cls_label, S, out_hw, softmaxtemp):
     return out
 
 
+class _MultilabelSoftMarginFn(torch.autograd.Function):
+    """F.multilabel_soft_margin_loss(v, y), v = x or relu(x), value and gradient from one kernel pass (cosa_msm_loss)"""
+
+    @staticmethod
+    def forward(ctx, x, y, relu):
+        x = x.contiguous()
+        y = y.contiguous().float()
+        if x.dim() == 4:
+            B, C, H, W = x.shape
+            R, HW = B * H * W, H * W
+        else:
+            R, C = x.shape
+            HW = 1
+        grad = torch.empty_like(x)
+        loss = torch.empty(1, device=x.device, dtype=torch.float32)
+        ws = torch.empty((R + 255) // 256, device=x.device, dtype=torch.float64)
+        _C.check(_C.lib().cosa_msm_loss(_C.ptr(x), _C.ptr(y), _C.ptr(grad), _C.ptr(loss), _C.ptr(ws), R, C, HW, int(relu), _C.stream_ptr()),
+                 "cosa_msm_loss")
+        ctx.save_for_backward(grad)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g, None, None
+
+
+def multilabel_soft_margin(x, y, relu=False):
+    """F.multilabel_soft_margin_loss(relu(x) if relu else x, y) over the class dimension (dim 1 of [R,C] or [B,C,H,W] logits: every pixel a
+    row, as cam_loss flattens them): the fused kernel for fp32 CUDA logits, torch otherwise"""
+    if x.is_cuda and x.dtype == torch.float32 and x.dim() in (2, 4) and y.shape == x.shape:
+        return _MultilabelSoftMarginFn.apply(x, y, relu)
+    v = F.relu(x) if relu else x
+    if x.dim() == 4:
+        C = x.shape[1]
+        v, y = v.float().permute(0, 2, 3, 1).reshape(-1, C), y.permute(0, 2, 3, 1).reshape(-1, C)
+    return F.multilabel_soft_margin_loss(v.float(), y)
+
+
 def cam_loss_from_targets(cam, targets, is_relu=True):
     """cam_loss (seg_helper.py:593-602) given pre-resized targets [B,C,H,W]"""
+    if cam.is_cuda and cam.dtype == torch.float32 and targets.shape == cam.shape:
+        return multilabel_soft_margin(cam, targets, relu=is_relu)
     B, C, H, W = cam.shape
     if is_relu:
         cam = F.relu(cam)

@@ -325,6 +325,11 @@ int cosa_seg_loss_backward(const float *seg_lr, const float *maskA, const float 
                            const float *roi, const float *g_seg, const float *g_regw, float *grad_seg_lr,
                            int B, int K, int hs, int ws, int S, void *stream);
 
+/* F.multilabel_soft_margin_loss (main.py:127-128 on the classification logits; seg_helper.py:593-602 on relu(cam) against the resized teacher
+ * probabilities) and its gradient in one pass: loss[0] = mean_r mean_c -(y log s(v) + (1-y) log s(-v)), v = relu ? max(x,0) : x;
+ * grad = d loss / d x.  Element (r, c) of x / y / grad lies at (r / HW) * C * HW + c * HW + r % HW (HW = 1: row-major [R,C]; HW = h*w: NCHW).
+ * workspace: ceil(R / 256) doubles.                                                                                                   */
+int cosa_msm_loss(const float *x, const float *y, float *grad, float *loss, void *workspace, int R, int C, int HW, int relu, void *stream);
 /* main.py:227-228 + utils/seg_helper.py:553-568,593-597: targets of cam_loss -- seg_refine_by_label(teacher seg, T) foreground
  * channels, bilinearly down-sampled to the CAM grid -- evaluated only at the pixels the down-sampling reads, straight from the
  * per-scale low-res teacher seg outputs seg_scales[i] [2B,K,hs[i],ws[i]] (original batch, then the flipped batch).

@@ -429,3 +429,25 @@ def test_im2col_flip_and_embed_finish_equal_the_torch_expressions(dt):
         _C.check(L.cosa_embed_finish(_C.ptr(tok), _C.ptr(cls), _C.ptr(pos), _C.ptr(out), B, n, D, code, _C.stream_ptr()), "embed")
         ref = (torch.cat((cls.expand(B, -1, -1), tok), dim=1) + pos).float().reshape(-1, D)
         assert torch.equal(out[:-1], ref) and torch.all(out[-1] == 7.0)
+
+
+@pytest.mark.parametrize("shape,relu", [((16, 20), False), ((3, 80), False), ((4, 20, 28, 28), True), ((2, 81, 40, 40), True), ((1, 5, 3, 7), False)])
+def test_multilabel_soft_margin_kernel_vs_torch(shape, relu):
+    """the fused loss (classification losses main.py:127-128, cam_loss seg_helper.py:593-602) against F.multilabel_soft_margin_loss: value and
+    gradient, row-major logits and NCHW maps (every pixel a row), with the ReLU of cam_loss folded in"""
+    from cosa_amd.utils import seg_helper
+    torch.manual_seed(len(shape) * 7 + shape[1])
+    x = (torch.randn(*shape, device="cuda") * 3).requires_grad_(True)
+    y = (torch.rand(*shape, device="cuda") < 0.3).float() if len(shape) == 2 else torch.rand(*shape, device="cuda")
+    loss = seg_helper.multilabel_soft_margin(x, y, relu=relu)
+    (loss * 1.7).backward()
+    x2 = x.detach().clone().requires_grad_(True)
+    v = torch.relu(x2) if relu else x2
+    if len(shape) == 4:
+        C = shape[1]
+        ref = torch.nn.functional.multilabel_soft_margin_loss(v.permute(0, 2, 3, 1).reshape(-1, C), y.permute(0, 2, 3, 1).reshape(-1, C))
+    else:
+        ref = torch.nn.functional.multilabel_soft_margin_loss(v, y)
+    (ref * 1.7).backward()
+    assert loss.item() == pytest.approx(ref.item(), rel=2e-6, abs=1e-7)
+    assert (x.grad - x2.grad).abs().max().item() <= 2e-6 * x2.grad.abs().max().item() + 1e-9
