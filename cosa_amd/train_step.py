@@ -132,6 +132,7 @@ class CoSATrainer:
         self.use_graph = bool(getattr(args, "teacher_graph", True)) and self._shadows is not None
         self.fused_losses = bool(getattr(args, "fused_losses", True)) and device.type == "cuda" and not args.after_softmax
         self._graph = None
+        self._loss_weights = {}
         self._graph_calls = 0
         self.teacher_async = bool(getattr(args, "teacher_async", True)) and self.use_graph
         self._side = None
@@ -265,11 +266,14 @@ class CoSATrainer:
             if args.aux_seg2cam:
                 cam_aux_loss = seg_helper.cam_loss(cam_aux_pred, valid_seg_ps)
                 cam_loss = (1 - args.aux_seg2cam_alpha) * cam_loss + args.aux_seg2cam_alpha * cam_aux_loss
-        if n_iter <= args.warmup_iters:
-            loss = 1.0 * cls_loss + 1.0 * cls_loss_aux + 0.0 * seg_loss + 0.0 * cam_loss + 0.0 * reg_loss
-        else:
-            loss = 1.0 * cls_loss + 1.0 * cls_loss_aux + args.seg_weight * seg_loss + args.cam_weight * cam_loss \
-                + args.reg_weight * reg_loss
+        # main.py:230-236: the weighted sum of the five losses (warm-up: classification losses only) as one dot product
+        wkey = n_iter <= args.warmup_iters
+        wvec = self._loss_weights.get(wkey)
+        if wvec is None:
+            wl = [1.0, 1.0, 0.0, 0.0, 0.0] if wkey else [1.0, 1.0, args.seg_weight, args.cam_weight, args.reg_weight]
+            wvec = self._loss_weights[wkey] = torch.tensor(wl, device=cls_loss.device, dtype=torch.float32)
+        loss = torch.dot(torch.stack([cls_loss.reshape(()), cls_loss_aux.reshape(()), seg_loss.reshape(()).float(), cam_loss.reshape(()).float(),
+                                      reg_loss.reshape(()).float()]), wvec)
         return loss, dict(overall_loss=loss.detach(), cls_loss=cls_loss.detach(), cls_aux_loss=cls_loss_aux.detach(),
                           seg_loss=seg_loss.detach(), cam_loss=cam_loss.detach(), reg_loss=reg_loss.detach(),
                           mask=refine_mask_label, cls_logits=cls_final.detach(), cls_aux_logits=cls_aux.detach())

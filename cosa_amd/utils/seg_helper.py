@@ -495,12 +495,14 @@ class FusedSegRegLoss(Function):
             _C.check(L.cosa_dense_energy_forward(_C.ptr(s_img), _C.ptr(s_seg), _C.ptr(roi), _C.ptr(unl), _C.ptr(AS), _C.ptr(energy), B, K,
                                                  Sq, Sq, float(sigma_rgb), float(sigma_xy), _C.ptr(wsb), wsb.numel(), _C.stream_ptr()),
                      "cosa_dense_energy_forward")
-        lossA = 0.5 * sums[0] / (sums[1] + 1e-6) + 0.5 * sums[2] / (sums[3] + 1e-6)
-        lossB = 0.5 * sums[4] / (sums[5] + 1e-6) + 0.5 * sums[6] / (sums[7] + 1e-6)
+        # 0.5 * (0.5 bgA + 0.5 fgA) + 0.5 * (0.5 bgB + 0.5 fgB), each term sum / (count + 1e-6)  (seg_helper.py:800-813, main.py:200-203):
+        # four vector ops instead of eighteen scalar ones
+        pairs = sums.view(4, 2)
+        seg_l = (pairs[:, 0] / (pairs[:, 1] + 1e-6)).sum() * 0.25
         ctx.save_for_backward(seg_lr, maskA, maskB, sums, AS, roi)
         ctx.weight = float(weight)
         ctx.S = S
-        return 0.5 * lossA + 0.5 * lossB, energy * float(weight)
+        return seg_l, energy * float(weight)
 
     @staticmethod
     def backward(ctx, g_seg, g_reg):
