@@ -27,6 +27,8 @@ _SIGS = {
     "cosa_cam_minmax_norm_ws": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "cosa_cam_flip_merge_upsample": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                      c_void_p]),
+    "cosa_cam_flip_merge_upsample_reuse": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                                           c_void_p]),
     "cosa_cam2mask_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "cosa_cam2mask": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float,
                               c_int, c_int, ctypes.POINTER(c_int), c_int, c_int, c_float, c_void_p, c_size_t, c_void_p]),

@@ -180,23 +180,57 @@ __global__ __launch_bounds__(256) void minmax_apply_kernel(float *__restrict__ c
 // bilinear source indices / weights of a pixel are computed once for all its planes.
 __global__ __launch_bounds__(256) void flip_merge_upsample_kernel(const float *__restrict__ src, float *__restrict__ dst,
                                                                  int B, int C, int h, int w, int S, float sy, float sx,
-                                                                 int mode, int accumulate, const float *__restrict__ active)
+                                                                 int mode, int accumulate, const float *__restrict__ active,
+                                                                 const float *__restrict__ prev_active)
 {
     const int pix = blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    // the live planes (and those to clear) of this image as bit masks, built once per wave by ballot: the plane loop then visits only them
+    // (80 COCO planes with ~3 live: the per-plane test of the activity flag was most of the kernel's time)
+    unsigned long long live[2] = {0ull, 0ull}, clr[2] = {0ull, 0ull};
+    const bool masked = active != nullptr && C <= 128;
+    if (masked) {
+        const int lane = threadIdx.x & 63;
+#pragma unroll
+        for (int wd = 0; wd < 2; wd++) {
+            const int c = wd * 64 + lane;
+            const float a = c < C ? active[b * C + c] : 0.0f;
+            const float pv = (c < C && prev_active) ? prev_active[b * C + c] : 1.0f;
+            live[wd] = __ballot(c < C && a != 0.0f);
+            clr[wd] = __ballot(c < C && a == 0.0f && pv != 0.0f);
+        }
+    }
     if (pix >= S * S) return;
     const int Y = pix / S, X = pix - Y * S;
-    const int b = blockIdx.y;
     int y0, y1, x0, x1, fx0, fx1;
     float ly0, ly1, lx0, lx1, flx0, flx1;
     src_index(Y, h, S, sy, y0, y1, ly0, ly1);
     src_index(X, w, S, sx, x0, x1, lx0, lx1);
     src_index(S - 1 - X, w, S, sx, fx0, fx1, flx0, flx1);
-    for (int c = 0; c < C; c++) {
-        const size_t o = ((size_t)b * C + c) * S * S + pix;
-        if (active && active[b * C + c] == 0.0f) {      // class absent from the image: cam_validation zeroes it anyway
-            if (!accumulate) dst[o] = 0.0f;
-            continue;
+    if (masked && !accumulate) {
+        // class absent from the image: cam_validation zeroes it anyway.  prev_active: dst is a buffer that this routine filled last time
+        // under that activity map, so an absent plane is already zero unless it was live then
+#pragma unroll
+        for (int wd = 0; wd < 2; wd++)
+            for (unsigned long long mk = clr[wd]; mk; mk &= mk - 1) {
+                const int c = wd * 64 + __builtin_ctzll(mk);
+                dst[((size_t)b * C + c) * S * S + pix] = 0.0f;
+            }
+    }
+    for (int it = 0, c = -1; it < C; it++) {
+        if (masked) {                                   // next live plane
+            const int wd = live[0] ? 0 : 1;
+            if (!live[wd]) break;
+            c = wd * 64 + __builtin_ctzll(live[wd]);
+            live[wd] &= live[wd] - 1;
+        } else {
+            c = it;
+            if (active && active[b * C + c] == 0.0f) {
+                if (!accumulate && (!prev_active || prev_active[b * C + c] != 0.0f)) dst[((size_t)b * C + c) * S * S + pix] = 0.0f;
+                continue;
+            }
         }
+        const size_t o = ((size_t)b * C + c) * S * S + pix;
         const float *p = src + ((size_t)b * C + c) * h * w;
         const float *q = src + ((size_t)(b + B) * C + c) * h * w;
         const float u1 = bilerp(p[y0 * w + x0], p[y0 * w + x1], p[y1 * w + x0], p[y1 * w + x1], lx0, lx1, ly0, ly1);
@@ -396,7 +430,23 @@ extern "C" int cosa_cam_flip_merge_upsample(const float *src, float *dst, int B,
     const float sy = (float)h / (float)S, sx = (float)w / (float)S;
     dim3 grid((S * S + 255) / 256, B);
     hipLaunchKernelGGL(flip_merge_upsample_kernel, grid, dim3(256), 0, as_stream(stream), src, dst, B, C, h, w, S, sy, sx,
-                       mode, accumulate, active);
+                       mode, accumulate, active, static_cast<const float *>(nullptr));
+    COSA_LAUNCH_CHECK();
+    return COSA_OK;
+}
+
+// the same for a destination that the previous call of this routine filled with the activity map prev_active ([B*C]): planes absent then
+// and now are not written at all (they are still zero)
+extern "C" int cosa_cam_flip_merge_upsample_reuse(const float *src, float *dst, int B, int C, int h, int w, int S,
+                                                  int mode, int accumulate, const float *active, const float *prev_active, void *stream)
+{
+    COSA_REQUIRE(src && dst && active && prev_active && B > 0 && C > 0 && h > 0 && w > 0 && S > 0, "cosa_cam_flip_merge_upsample_reuse: bad arguments");
+    COSA_REQUIRE(mode == 0 || mode == 1, "cosa_cam_flip_merge_upsample_reuse: mode must be 0 or 1");
+    COSA_REQUIRE(C <= 65535 && B <= 65535, "cosa_cam_flip_merge_upsample_reuse: grid too large");
+    const float sy = (float)h / (float)S, sx = (float)w / (float)S;
+    dim3 grid((S * S + 255) / 256, B);
+    hipLaunchKernelGGL(flip_merge_upsample_kernel, grid, dim3(256), 0, as_stream(stream), src, dst, B, C, h, w, S, sy, sx,
+                       mode, accumulate, active, prev_active);
     COSA_LAUNCH_CHECK();
     return COSA_OK;
 }

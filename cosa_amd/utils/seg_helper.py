@@ -24,11 +24,31 @@ def _refresh_once(model):
 # --------------------------------------------------------------------------------------------
 # multi_scale_camseg  (utils/seg_helper.py:232-275)
 # --------------------------------------------------------------------------------------------
-def _flip_merge_upsample(src, dst, B, S, mode, accumulate, active=None):
+def _flip_merge_upsample(src, dst, B, S, mode, accumulate, active=None, prev_active=None):
     src = src.contiguous().float()
     _, C, h, w = src.shape
+    if prev_active is not None:
+        _C.check(_C.lib().cosa_cam_flip_merge_upsample_reuse(_C.ptr(src), _C.ptr(dst), B, C, h, w, S, mode, int(accumulate), _C.ptr(active),
+                                                             _C.ptr(prev_active), _C.stream_ptr()), "cosa_cam_flip_merge_upsample_reuse")
+        return
     _C.check(_C.lib().cosa_cam_flip_merge_upsample(_C.ptr(src), _C.ptr(dst), B, C, h, w, S, mode, int(accumulate),
                                                    _C.ptr(active), _C.stream_ptr()), "cosa_cam_flip_merge_upsample")
+
+
+# CAM buffers of the training loop's teacher passes, kept from step to step: a plane that is absent from the image now and was absent
+# last time is already zero, so only the planes that were live last time are cleared (80 COCO planes per image, ~3 live: 1 GB of zero
+# stores per call otherwise).  Results returned from these buffers are valid until the next call with the same shapes.
+_cam_buffers = {}
+
+
+def _persistent_cams(b, C, h, w, device):
+    key = (str(device), b, C, h, w)
+    ent = _cam_buffers.get(key)
+    if ent is None:
+        ent = _cam_buffers[key] = {"cam": torch.zeros((b, C, h, w), device=device, dtype=torch.float32),
+                                   "aux": torch.zeros((b, C, h, w), device=device, dtype=torch.float32),
+                                   "prev": torch.zeros((b, C), device=device, dtype=torch.float32)}
+    return ent
 
 
 def cam_minmax_norm_(cam, active=None):
@@ -71,18 +91,25 @@ def multi_scale_camseg(model, imgs, scales, _active_labels=None, _seg_scales=Fal
             with nn_ops.shadows_fresh():
                 _, _, _, _seg, _cam, _cam_aux = multi[si] if multi is not None else model(inputs[si], cam_only=False)
             if cam is None:
-                cam = torch.empty((b, _cam.shape[1], h, w), device=imgs.device, dtype=torch.float32)
-                cam_aux = torch.empty_like(cam)
-                seg = torch.empty((b, _seg.shape[1], h, w), device=imgs.device, dtype=torch.float32)
-            _flip_merge_upsample(_cam, cam, b, h, 0, si > 0, act)
+                if act is not None:
+                    keep = _persistent_cams(b, _cam.shape[1], h, w, imgs.device)
+                    cam, cam_aux, prev = keep["cam"], keep["aux"], keep["prev"]
+                else:
+                    cam = torch.empty((b, _cam.shape[1], h, w), device=imgs.device, dtype=torch.float32)
+                    cam_aux = torch.empty_like(cam)
+                    prev = None
+                seg = None if _seg_scales else torch.empty((b, _seg.shape[1], h, w), device=imgs.device, dtype=torch.float32)
+            _flip_merge_upsample(_cam, cam, b, h, 0, si > 0, act, prev if si == 0 else None)
             if si == len(scales) - 1:                                   # only the last scale survives (:258)
-                _flip_merge_upsample(_cam_aux, cam_aux, b, h, 0, False, act)
+                _flip_merge_upsample(_cam_aux, cam_aux, b, h, 0, False, act, prev)
             if _seg_scales:
                 seg_list.append(_seg.contiguous().float())
             else:
                 _flip_merge_upsample(_seg, seg, b, h, 1, si > 0)
         cam_minmax_norm_(cam, act)
         cam_minmax_norm_(cam_aux, act)
+        if act is not None:
+            prev.copy_(act.view_as(prev))
     return cam, cam_aux, (seg_list if _seg_scales else seg)
 
 

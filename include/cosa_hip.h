@@ -57,6 +57,10 @@ int cosa_cam_minmax_norm_ws(float *cam, int BC, int HW, const float *active /* [
  * ------------------------------------------------------------------------------------- */
 int cosa_cam_flip_merge_upsample(const float *src, float *dst, int B, int C, int h, int w, int S,
                                  int mode, int accumulate, const float *active /* [B,C] or NULL */, void *stream);
+/* the same for a destination buffer that the previous call filled under the activity map prev_active [B*C]: planes absent then and now are
+ * not touched (they are still zero) -- the training loop keeps its CAM buffers from step to step                                        */
+int cosa_cam_flip_merge_upsample_reuse(const float *src, float *dst, int B, int C, int h, int w, int S, int mode, int accumulate,
+                                       const float *active, const float *prev_active, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * utils/seg_helper.py:721-797  cam2mask (+ _refine_cams), with cam_validation (:547-551)

@@ -343,3 +343,30 @@ def test_cam2mask_multi_with_par_at_bench_size():
         for b in range(B):
             allowed = {0.0, 255.0} | {float(c + 1) for c in torch.nonzero(labels[b])[:, 0].tolist()}
             assert set(torch.unique(ms[i][b]).tolist()) <= allowed
+
+
+def test_multi_scale_camseg_persistent_buffers_track_the_active_planes(golden):
+    """the training loop's CAM buffers live from step to step and only the planes that were live LAST time are cleared: three calls with
+    different label sets must each equal the stateless path followed by cam_validation (seg_helper.py:547-551), bit for bit"""
+    from cosa_amd.utils import seg_helper
+    from oracle.gen_golden import _StubModel
+    g = golden("camseg_tail")
+    C = int(g["C"])
+    stub = _StubModel(C)
+
+    def model(x, cam_only=False):
+        outs = stub(x.cpu())
+        return tuple(o.cuda() if o is not None else None for o in outs)
+
+    imgs = dev(g["imgs"])
+    b = imgs.shape[0]
+    rng = np.random.default_rng(3)
+    for trial in range(3):
+        lab = (rng.uniform(size=(b, C)) < (0.5, 0.15, 0.8)[trial]).astype(np.float32)
+        lab[:, trial % C] = 1.0
+        labels = dev(lab)
+        cam, aux, _ = seg_helper.multi_scale_camseg(model, imgs, [1.0, 0.5, 1.5], _active_labels=labels)
+        ref_cam, ref_aux, _ = seg_helper.multi_scale_camseg(model, imgs, [1.0, 0.5, 1.5])
+        # stateless reference: normalise all planes, then zero the absent ones -- the normalisation is per plane, so the live planes agree
+        m = labels[:, :, None, None]
+        assert torch.equal(cam, ref_cam * m) and torch.equal(aux, ref_aux * m)

@@ -1,5 +1,5 @@
 """N training steps of the bench configuration and nothing else (for rocprofv3 --kernel-trace --stats: per-step kernel shares without bench.py's
-extra legs).  usage: python tools/step_only.py [steps=10] [teacher_precision=bf16]; the first 4 steps are set-up (graph capture)."""
+extra legs).  usage: python tools/step_only.py [steps=10] [teacher_precision=bf16] [dataset=VOC12]; the first 4 steps are set-up (graph capture)."""
 import os, sys, json, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -7,14 +7,15 @@ from cosa_amd.train_step import CoSATrainer, default_args, synthetic_batch
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 prec = sys.argv[2] if len(sys.argv) > 2 else "bf16"
+dataset = sys.argv[3] if len(sys.argv) > 3 else "VOC12"          # VOC12 (20 classes) | COCO (80)
 dev = torch.device("cuda", 0)
 kw = dict(crop_size=448, batch_size=16, teacher_async=os.environ.get("COSA_TEACHER_SYNC") is None)
 try:
-    args = default_args("VOC12", teacher_precision=prec, **kw)
+    args = default_args(dataset, teacher_precision=prec, **kw)
 except TypeError:        # a round-1 checkout (same-box comparisons): no precision switch
-    args = default_args("VOC12", **kw)
+    args = default_args(dataset, **kw)
 tr = CoSATrainer(args, dev, seed=0)
-wimg, simg, lab, box = synthetic_batch(16, 448, 20, dev, seed=1234)
+wimg, simg, lab, box = synthetic_batch(16, 448, 80 if dataset == "COCO" else 20, dev, seed=1234)
 n_iter = args.warmup_iters + 1
 for _ in range(4):
     tr.step(wimg, simg, lab, box, n_iter)
