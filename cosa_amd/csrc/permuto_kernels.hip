@@ -346,6 +346,7 @@ __global__ __launch_bounds__(256) void lattice_rows_kernel(const float *__restri
 
 // values[id+1][k] = sum over the vertex's pairs, in ascending pixel order, of bary * rows[pixel][k]: 32 lanes per vertex (lane = channel),
 // four pairs' loads in flight.  Also zeroes the sink rows (row 0 of both value buffers).
+template <int NT>       // NT 32-channel groups per lane: KP <= 32 NT (VOC 21 planes: 1; COCO 81: 3) -- a vertex's pair list is walked once
 __global__ __launch_bounds__(256) void lattice_splat_sorted_kernel(LatticeParams P, ImageBuffers B)
 {
     const int n = blockIdx.y;
@@ -363,29 +364,43 @@ __global__ __launch_bounds__(256) void lattice_splat_sorted_kernel(LatticeParams
     const int *lo = B.seg_lo + (size_t)n * P.Mmax, *hi = B.seg_hi + (size_t)n * P.Mmax;
     const float *bary = B.bary + (size_t)n * P.Npad * PD1;
     const float *rows = B.rows + (size_t)n * P.N * KP;
+    bool on[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) on[t] = k + 32 * t < KP;
     for (int id = blockIdx.x * 8 + (threadIdx.x >> 5); id < M; id += gridDim.x * 8) {
         const int beg = lo[id], end = hi[id];
-        for (int kc = k; kc < KP; kc += 32) {            // K <= 32 (VOC: 21): one trip; COCO's 81 planes: three
+        for (int kc0 = 0; kc0 < KP; kc0 += 32 * NT) {     // (one trip unless KP > 32 NT)
             int i = beg;
-            float acc = 0.0f;
+            float acc[NT];
+#pragma unroll
+            for (int t = 0; t < NT; t++) acc[t] = 0.0f;
             for (; i + 4 <= end; i += 4) {
                 unsigned e[4];
-                float w[4], v[4];
+                float w[4], v[4][NT];
 #pragma unroll
                 for (int u = 0; u < 4; u++) e[u] = B.cent1[i + u];
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     w[u] = bary[e[u]];
-                    v[u] = rows[(size_t)(e[u] / PD1) * KP + kc];
+                    const float *rp = rows + (size_t)(e[u] / PD1) * KP + kc0 + k;
+#pragma unroll
+                    for (int t = 0; t < NT; t++) v[u][t] = (on[t] && kc0 + k + 32 * t < KP) ? rp[32 * t] : 0.0f;
                 }
 #pragma unroll
-                for (int u = 0; u < 4; u++) acc = acc + w[u] * v[u];
+                for (int u = 0; u < 4; u++)
+#pragma unroll
+                    for (int t = 0; t < NT; t++) acc[t] = acc[t] + w[u] * v[u][t];
             }
             for (; i < end; i++) {
                 const unsigned e = B.cent1[i];
-                acc = acc + bary[e] * rows[(size_t)(e / PD1) * KP + kc];
+                const float w = bary[e];
+                const float *rp = rows + (size_t)(e / PD1) * KP + kc0 + k;
+#pragma unroll
+                for (int t = 0; t < NT; t++) acc[t] = acc[t] + w * ((on[t] && kc0 + k + 32 * t < KP) ? rp[32 * t] : 0.0f);
             }
-            val[(size_t)(id + 1) * KP + kc] = acc;
+#pragma unroll
+            for (int t = 0; t < NT; t++)
+                if (kc0 + k + 32 * t < KP) val[(size_t)(id + 1) * KP + kc0 + k + 32 * t] = acc[t];
         }
     }
 }
@@ -666,7 +681,9 @@ int filter_phase(const float *ins, float *outs, int N, int K, const float *roi, 
     } else {
         hipLaunchKernelGGL(lattice_rows_kernel, dim3((P.N + TP - 1) / TP, N), blk, lds, st, ins, roi, K, P, B);
         COSA_LAUNCH_CHECK();
-        hipLaunchKernelGGL(lattice_splat_sorted_kernel, dim3(gs, N), blk, 0, st, P, B);
+        if (P.KP <= 32) hipLaunchKernelGGL(lattice_splat_sorted_kernel<1>, dim3(gs, N), blk, 0, st, P, B);
+        else if (P.KP <= 64) hipLaunchKernelGGL(lattice_splat_sorted_kernel<2>, dim3(gs, N), blk, 0, st, P, B);
+        else hipLaunchKernelGGL(lattice_splat_sorted_kernel<3>, dim3(gs, N), blk, 0, st, P, B);
         COSA_LAUNCH_CHECK();
     }
     for (int j = 0; j <= PD; j++) {
