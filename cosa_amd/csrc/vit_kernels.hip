@@ -215,7 +215,7 @@ __device__ __forceinline__ void head_load16(const T *p, float (&v)[16])
     }
 }
 
-template <typename T, int NB>       // NB: 16-column blocks of the output (1 or 2)
+template <typename T, int NB>       // NB: 16-column blocks of the output per slice (1 or 2); N > 16 NB: the slices are a loop inside the kernel
 __global__ __launch_bounds__(256, 2) void head_gemm_kernel(const T *__restrict__ X, const T *__restrict__ W, float *__restrict__ Y,
                                                           int M, int N, int K, int rows_per_img, long long img_stride, int ldx,
                                                           int round_bf16, int ldy, int col0)
@@ -224,68 +224,71 @@ __global__ __launch_bounds__(256, 2) void head_gemm_kernel(const T *__restrict__
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
     const int groups = (M + 15) >> 4, nkb = K >> 6;
-    // weight rows of this lane's output columns; columns >= N read row N - 1 and are dropped at the store
-    const T *wr[NB];
-#pragma unroll
-    for (int nb = 0; nb < NB; nb++) {
-        const int col = nb * 16 + r;
-        wr[nb] = W + (size_t)(col < N ? col : N - 1) * K + 16 * q;
-    }
     for (int g = blockIdx.x; g < groups; g += gridDim.x) {
         int row = g * 16 + r;
         row = row < M ? row : M - 1;
         const int b = row / rows_per_img;
         const T *xr = X + (size_t)b * img_stride + (size_t)(row - b * rows_per_img) * ldx + 16 * q;
-        f32x4h acc[NB];
-#pragma unroll
-        for (int nb = 0; nb < NB; nb++) acc[nb] = (f32x4h){0.f, 0.f, 0.f, 0.f};
-        float v[16], vn[16], w[NB][16], wn[NB][16];
-        if (wave < nkb) {
-            head_load16(xr + wave * 64, v);
-#pragma unroll
-            for (int nb = 0; nb < NB; nb++) head_load16(wr[nb] + wave * 64, w[nb]);
-        }
-        for (int kb = wave; kb < nkb; kb += 4) {
-            if (kb + 4 < nkb) {
-                head_load16(xr + (kb + 4) * 64, vn);
-#pragma unroll
-                for (int nb = 0; nb < NB; nb++) head_load16(wr[nb] + (kb + 4) * 64, wn[nb]);
-            }
-#pragma unroll
-            for (int i = 0; i < 16; i++) {
-#pragma unroll
-                for (int nb = 0; nb < NB; nb++) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[i], w[nb][i], acc[nb], 0, 0, 0);
-            }
-#pragma unroll
-            for (int i = 0; i < 16; i++) {
-                v[i] = vn[i];
-#pragma unroll
-                for (int nb = 0; nb < NB; nb++) w[nb][i] = wn[nb][i];
-            }
-        }
-        if (wave > 0) {
-#pragma unroll
-            for (int nb = 0; nb < NB; nb++) part[wave - 1][nb][lane] = acc[nb];
-        }
-        __syncthreads();
-        if (wave == 0) {
-            // C layout: column = lane & 15 (output feature), row = 4 * (lane >> 4) + reg (token)
+        // wider heads (COCO: 80 | 81 rows) take several slices of 16 NB columns: X comes from HBM for the first one and from L2 afterwards
+        for (int c0 = 0; c0 < N; c0 += 16 * NB) {
+            // weight rows of this lane's output columns; columns >= N read row N - 1 and are dropped at the store
+            const T *wr[NB];
 #pragma unroll
             for (int nb = 0; nb < NB; nb++) {
-                const f32x4h t = ((acc[nb] + part[0][nb][lane]) + part[1][nb][lane]) + part[2][nb][lane];
-                const int col = nb * 16 + r;
+                const int col = c0 + nb * 16 + r;
+                wr[nb] = W + (size_t)(col < N ? col : N - 1) * K + 16 * q;
+            }
+            f32x4h acc[NB];
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const int orow = g * 16 + 4 * q + j;
-                    if (orow < M && col < N) {
-                        float o = t[j];
-                        if (round_bf16) o = sizeof(T) == 4 ? (float)(bf16)o : (float)(T)o;      // the operand precision (fp32 operands: bf16)
-                        Y[(size_t)orow * ldy + col0 + col] = o;
+            for (int nb = 0; nb < NB; nb++) acc[nb] = (f32x4h){0.f, 0.f, 0.f, 0.f};
+            float v[16], vn[16], w[NB][16], wn[NB][16];
+            if (wave < nkb) {
+                head_load16(xr + wave * 64, v);
+#pragma unroll
+                for (int nb = 0; nb < NB; nb++) head_load16(wr[nb] + wave * 64, w[nb]);
+            }
+            for (int kb = wave; kb < nkb; kb += 4) {
+                if (kb + 4 < nkb) {
+                    head_load16(xr + (kb + 4) * 64, vn);
+#pragma unroll
+                    for (int nb = 0; nb < NB; nb++) head_load16(wr[nb] + (kb + 4) * 64, wn[nb]);
+                }
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+#pragma unroll
+                    for (int nb = 0; nb < NB; nb++) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[i], w[nb][i], acc[nb], 0, 0, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    v[i] = vn[i];
+#pragma unroll
+                    for (int nb = 0; nb < NB; nb++) w[nb][i] = wn[nb][i];
+                }
+            }
+            if (wave > 0) {
+#pragma unroll
+                for (int nb = 0; nb < NB; nb++) part[wave - 1][nb][lane] = acc[nb];
+            }
+            __syncthreads();
+            if (wave == 0) {
+                // C layout: column = lane & 15 (output feature), row = 4 * (lane >> 4) + reg (token)
+#pragma unroll
+                for (int nb = 0; nb < NB; nb++) {
+                    const f32x4h t = ((acc[nb] + part[0][nb][lane]) + part[1][nb][lane]) + part[2][nb][lane];
+                    const int col = c0 + nb * 16 + r;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const int orow = g * 16 + 4 * q + j;
+                        if (orow < M && col < N) {
+                            float o = t[j];
+                            if (round_bf16) o = sizeof(T) == 4 ? (float)(bf16)o : (float)(T)o;      // the operand precision (fp32 operands: bf16)
+                            Y[(size_t)orow * ldy + col0 + col] = o;
+                        }
                     }
                 }
             }
+            __syncthreads();
         }
-        __syncthreads();
     }
 }
 
@@ -577,16 +580,16 @@ extern "C" int cosa_transpose_cast_batched(const void *records, int n, int total
     return COSA_OK;
 }
 
-// Y[M,N] fp32 = X W^T for N <= 32 (CAM / seg heads); X rows: image b = rows [b*rows_per_img, +rows_per_img) at X + b*img_stride
+// Y[M,N] fp32 = X W^T for narrow N (CAM / seg heads: 20 | 21 | 80 | 81 rows); X rows: image b = rows [b*rows_per_img, +rows_per_img) at X + b*img_stride
 // (elements) with row stride ldx, so token views without their cls row need no copy.  dtype: 0 = fp32 operands, 1 = bf16
 // operands (round_bf16 = 1 additionally rounds the result to bf16 precision, like a bf16 library GEMM would).  The N columns land
-// at Y[r*ldy + col0 ...]: wider heads (COCO: 80 | 81 rows) are done in slices of <= 32 weight rows.
+// at Y[r*ldy + col0 ...]; wider heads (COCO: 80 | 81 rows) run as slices of 32 weight rows inside the kernel (X is then re-read from L2).
 extern "C" int cosa_head_gemm(const void *X, const void *W, float *Y, int M, int N, int K, int rows_per_img, long long img_stride,
                               int ldx, int dtype, int round_bf16, int ldy, int col0, void *stream)
 {
     COSA_REQUIRE(ldy >= col0 + N && col0 >= 0, "cosa_head_gemm: output columns [col0, col0+N) must fit the row stride ldy");
     COSA_REQUIRE(X && W && Y && M > 0 && N > 0 && K > 0 && rows_per_img > 0, "cosa_head_gemm: bad arguments");
-    COSA_REQUIRE(N <= 32 && K % 64 == 0 && ldx >= K, "cosa_head_gemm: N <= 32 and K %% 64 == 0 (got N=%d K=%d)", N, K);
+    COSA_REQUIRE(N <= 1024 && K % 64 == 0 && ldx >= K, "cosa_head_gemm: N <= 1024 and K %% 64 == 0 (got N=%d K=%d)", N, K);
     COSA_REQUIRE(dtype >= 0 && dtype <= 2, "cosa_head_gemm: dtype 0 (fp32), 1 (bf16) or 2 (fp16)");
     COSA_REQUIRE(ldx % (dtype == 0 ? 4 : 8) == 0 && img_stride % (dtype == 0 ? 4 : 8) == 0, "cosa_head_gemm: rows must be 16-byte aligned");
     const int nb = N <= 16 ? 1 : 2;

@@ -261,10 +261,8 @@ def head_linear(tok, weight, round_bf16=False):
     y = torch.empty((B * n, N), device=tok.device, dtype=torch.float32)
     dt = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}[tok.dtype]
     with _C.profiled("head_gemm"):
-        for c0 in range(0, N, 32):
-            nn_ = min(32, N - c0)
-            _C.check(_C.lib().cosa_head_gemm(_C.ptr(tok), _C.ptr(weight[c0:c0 + nn_]), _C.ptr(y), B * n, nn_, K, n, tok.stride(0) if B > 1 else n * tok.stride(1),
-                                             tok.stride(1), dt, int(round_bf16), N, c0, _C.stream_ptr()), "cosa_head_gemm")
+        _C.check(_C.lib().cosa_head_gemm(_C.ptr(tok), _C.ptr(weight), _C.ptr(y), B * n, N, K, n, tok.stride(0) if B > 1 else n * tok.stride(1),
+                                         tok.stride(1), dt, int(round_bf16), N, 0, _C.stream_ptr()), "cosa_head_gemm")
     return y
 
 

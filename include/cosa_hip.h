@@ -238,7 +238,8 @@ int cosa_im2col_flip(const float *x, void *cols, int B, int C, int H, int W, int
  * (dtype 1 = bf16, 2 = fp16), each sum is rounded to that type before it is widened (the 16-bit torch expression's value); D % 8 == 0. */
 int cosa_embed_finish(const void *tok, const void *cls, const void *pos, float *out, int B, int n, int D, int dtype, void *stream);
 /* models/__init__.py:190-192 (classifier / aux_classifier as 1x1 convs over the tokens) and conv_head.py:38 (conv8): the narrow heads
- * Y[M, N <= 32] (fp32, columns [col0, col0+N) of rows with stride ldy) = X W^T, fp32 accumulation, fixed reduction order per row
+ * Y[M, N] (fp32, columns [col0, col0+N) of rows with stride ldy; N of a few dozen rows, slices of 32 inside the kernel) = X W^T, fp32
+ * accumulation, fixed reduction order per row
  * (results do not depend on what else is in the batch).  X: image b = rows_per_img rows at X + b*img_stride (elements), row stride
  * ldx; dtype 0: fp32 X and W, 1: bf16, 2: fp16 X and W (round_bf16 = 1 rounds the result to the operand precision).                               */
 int cosa_head_gemm(const void *X, const void *W, float *Y, int M, int N, int K, int rows_per_img, long long img_stride,
