@@ -1656,6 +1656,7 @@ using namespace cosa;
 #if COSA_OP_F16        // second build of this file (fp16 operands): the same entry points under their _f16 names (include/cosa_hip.h)
 #define cosa_gemm_set_stamp_slot cosa_gemm_set_stamp_slot_f16
 #define cosa_gemm_set_variant cosa_gemm_set_variant_f16
+#define cosa_gemm_set_grid_policy cosa_gemm_set_grid_policy_f16
 #define cosa_gemm_bf16 cosa_gemm_f16
 #define cosa_layernorm cosa_layernorm_f16
 #define cosa_gemm_wgrad_bf16 cosa_gemm_wgrad_f16
@@ -1671,8 +1672,10 @@ static int env_variant()
     const char *e = getenv("COSA_GEMM_VARIANT");
     return e ? atoi(e) : 0;
 }
+static int g_gemm_balanced_grid = 0;          // see launch_v6
 static int g_gemm_variant = env_variant();   // 0 = pick per shape (measured, tools/bench_gemm.py); 1..9 force a kernel (experiments; 9 = v6 on 256 x 192 jobs)
 extern "C" void cosa_gemm_set_variant(int v) { g_gemm_variant = v; }
+extern "C" void cosa_gemm_set_grid_policy(int balanced) { g_gemm_balanced_grid = balanced; }
 
 template <int EPI>
 static int launch_v2(const op16 *x, const op16 *w, const op16 *b, const float *residual, void *Y, int M, int N, int K, hipStream_t st)
@@ -1748,7 +1751,20 @@ static int launch_v6(const op16 *x, const op16 *w, const op16 *b, const float *r
     // start stagger (see the kernel): measured to make no difference, off
     static const char *env = getenv("COSA_GEMM_STAGGER");
     const int stagger = env ? atoi(env) : 0;
-    hipLaunchKernelGGL((gemm_bf16_v6_kernel<EPI, ABL6, AUX, SPLIT, FR>), dim3(grid), dim3(512), kLdsBytesV5, st, x, w, b, residual, Y, M, N, K, tiles_m, tiles_n, stagger,
+    // The persistent grid is balanced over the rounds it needs anyway: 600 jobs are three rounds on 256 workgroups and on 200, and 200
+    // leave 56 CUs to whatever else is running (the other stream's kernels, RCCL's channels under DDP: a 256-workgroup launch that finds
+    // only 224 free CUs runs its last 32 workgroups AFTER the others -- twice the time).  Multiples of 8 keep a workgroup on one XCD chunk.
+    // Single GPU: 0.25 % slower than the full grid (44.57 / 44.74 vs 44.46 / 44.62 ms per step), so it is switched on by the trainer only
+    // when the process is one rank of several (cosa_gemm_set_grid_policy), or by COSA_GEMM_BALANCED_GRID=1.
+    static const int balanced_env = [] { const char *e = getenv("COSA_GEMM_BALANCED_GRID"); return e ? atoi(e) : -1; }();
+    const bool balanced = balanced_env >= 0 ? balanced_env != 0 : g_gemm_balanced_grid != 0;
+    int grid_b = grid;
+    if (balanced && run > 256) {
+        const int rounds = (run + 255) / 256;
+        grid_b = ((run + rounds - 1) / rounds + 7) / 8 * 8;
+        grid_b = grid_b > 256 ? 256 : grid_b;
+    }
+    hipLaunchKernelGGL((gemm_bf16_v6_kernel<EPI, ABL6, AUX, SPLIT, FR>), dim3(grid_b), dim3(512), kLdsBytesV5, st, x, w, b, residual, Y, M, N, K, tiles_m, tiles_n, stagger,
                        g_gemm_stamp_slot, ld ? ld : K, ldy ? ldy : N, Y2, run);
     g_gemm_stamp_slot = nullptr;                            // one-shot
     COSA_LAUNCH_CHECK();

@@ -21,6 +21,7 @@ import torch.nn.functional as F
 from . import nn_ops
 from .models import build_model
 from .models.PAR import PAR
+from . import _C
 from .utils import seg_helper, torch_helper
 
 IMAGENET_MEAN = (123.675, 116.28, 103.53)
@@ -76,6 +77,9 @@ class CoSATrainer:
         self.student = self.model_ON
         if ddp:
             self.model_ON = wrap_ddp(self.model_ON, device)
+            if device.type == "cuda":        # leave CUs to RCCL's channels: persistent GEMM grids balanced over their rounds (include/cosa_hip.h)
+                _C.lib().cosa_gemm_set_grid_policy(1)
+                _C.lib().cosa_gemm_set_grid_policy_f16(1)
         self.optimizer = torch_helper.PolyWarmupAdamW(
             params=[
                 {'params': [p for p in groups[0] if p.requires_grad], 'lr': args.lr, 'weight_decay': args.wt_dec},
