@@ -1759,7 +1759,7 @@ static int launch_v6(const op16 *x, const op16 *w, const op16 *b, const float *r
     static const int balanced_env = [] { const char *e = getenv("COSA_GEMM_BALANCED_GRID"); return e ? atoi(e) : -1; }();
     const bool balanced = balanced_env >= 0 ? balanced_env != 0 : g_gemm_balanced_grid != 0;
     int grid_b = grid;
-    if (balanced && run > 256) {
+    if (balanced && run > 256 && (balanced_env >= 0 || M < 40000)) {       // (policy 1: the student's launches -- the ones a backward pass overlaps with all-reduces)
         const int rounds = (run + 255) / 256;
         grid_b = ((run + rounds - 1) / rounds + 7) / 8 * 8;
         grid_b = grid_b > 256 ? 256 : grid_b;

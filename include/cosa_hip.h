@@ -226,7 +226,8 @@ int cosa_conv3x3_dilated_wgrad(const void *dY, const void *X, float *dW9, int B,
 void cosa_gemm_set_variant(int v);   /* 0 (default): per-shape choice; 1: 128x128 2-stage; 2: 256x128 3-stage; 3: 256x256 8-wave;
                                       * 5: 256x256 4-phase ping-pong; 6: the same, persistent with the epilogue in the MFMA shadow      */
 /* persistent-grid policy of cosa_gemm_bf16: 0 (default) one workgroup per CU; 1 the workgroups balanced over the rounds the launch needs
- * anyway (600 jobs: 200 workgroups x 3 instead of 256 x 2.3), which leaves CUs to concurrently running kernels -- RCCL's channels when the
+ * anyway (600 jobs: 200 workgroups x 3 instead of 256 x 2.3; launches of fewer than 40 000 rows, i.e. the student's), which leaves CUs to
+ * concurrently running kernels -- RCCL's channels when the
  * process is one rank of a data-parallel job (utils/misc.py:439 init_distributed_mode + main.py:49-50 DDP)                              */
 void cosa_gemm_set_grid_policy(int balanced);
 void cosa_gemm_set_grid_policy_f16(int balanced);
