@@ -917,7 +917,7 @@ template <int EPI, int ABL6 = 0, int AUX = 0, int SPLIT = 0, int FR = 4>
 __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__restrict__ X, const op16 *__restrict__ W,
                                                              const op16 *__restrict__ bias, const float *__restrict__ R,
                                                              void *__restrict__ Yv, int M, int N, int K, int tiles_m, int tiles_n,
-                                                             int stagger_ticks, unsigned long long *__restrict__ stamps, int ld, int ldy, void *__restrict__ Y2v, int ntiles_run)
+                                                             int stagger_ticks, unsigned long long *__restrict__ stamps, int ld, int ldy, void *__restrict__ Y2v, int ntiles_run, int band)
 {
     // optional device-side span of this launch (100 MHz wall clock; min start / max end over workgroups): HIP events cannot be
     // recorded inside a captured hipGraph on ROCm, so bench.py's roofline leg reads these (cosa_gemm_set_stamp_slot)
@@ -940,6 +940,14 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
 
     auto tile_of = [&](int o, int &m0_, int &n0_) {      // every XCD (o & 7) walks a contiguous chunk of the m-panel-major tile list
         const int xcd = o & 7, idx = o >> 3;
+        if (band > 0) {          // an XCD owns tiles_m / 8 whole m-panels and walks them in bands of `band` n-tiles (m-panel-major inside a band):
+            const int rows_per = tiles_m >> 3, per_band = rows_per * band;          // the band's W panels stay in its L2 while the X panels stream
+            const int bi = idx / per_band, j = idx - bi * per_band;
+            const int rr = j / band;
+            m0_ = (xcd * rows_per + rr) * 256;
+            n0_ = (bi * band + (j - rr * band)) * TN;
+            return;
+        }
         const int t = (xcd < cr ? xcd * (cq + 1) : cr * (cq + 1) + (xcd - cr) * cq) + idx;
         const int tm = t / tiles_n;
         m0_ = tm * 256;
@@ -1746,8 +1754,18 @@ static int launch_v6(const op16 *x, const op16 *w, const op16 *b, const float *r
     const int rem = ntiles % 256, rounds_up = (ntiles + 255) / 256;
     if (FR == 4 && SPLIT == 0 && ABL6 == 0 && AUX == 0 && ntiles > 256 && rem != 0 && rem <= tail_max && (256 - rem) * 10 > 256 * rounds_up)
         run = ntiles - rem;
-    // (tile order inside an XCD -- bands of 3 / 4 / 6 / 12 n-tiles so that the W panels in flight fit the L2 next to the X panels -- was
-    //  measured on the teacher's shapes: no difference beyond noise, 352 .. 357 us on the qkv projection; the m-panel-major order stays)
+    // Tile order inside an XCD: with all n-tiles of an m-panel in flight the W panels of a wide layer (fc1: 12 x 393 KB = 4.7 MB) cycle
+    // through a 4-MB L2 and are re-fetched every round.  Bands of n-tiles whose W panels total <= 2.4 MB keep them resident (X is then read
+    // once per band): PMC on the fc1 launch 864 -> 632 MB fetched (1.41 -> 1.17 GB in total).  Time does not improve -- stand-alone equal, in
+    // the step 44.78 / 44.81 ms against 44.65 / 44.74 (the re-fetches are served by the Infinity Cache off the critical path) -- so it is
+    // OFF by default; COSA_GEMM_BAND=-1 picks the band width as described, COSA_GEMM_BAND=n forces n.
+    static const int band_env = [] { const char *e = getenv("COSA_GEMM_BAND"); return e ? atoi(e) : 0; }();
+    int band = 0;
+    if (tiles_m % 8 == 0 && run == ntiles && band_env != 0) {
+        const size_t panel = (size_t)64 * FR * (size_t)(ld ? ld : K) * 2;
+        for (int cand = tiles_n - 1; cand >= 2; cand--)
+            if (tiles_n % cand == 0 && (band_env > 0 ? cand == band_env : cand * panel <= (size_t)2400 * 1024)) { band = cand; break; }
+    }
     // start stagger (see the kernel): measured to make no difference, off
     static const char *env = getenv("COSA_GEMM_STAGGER");
     const int stagger = env ? atoi(env) : 0;
@@ -1765,7 +1783,7 @@ static int launch_v6(const op16 *x, const op16 *w, const op16 *b, const float *r
         grid_b = grid_b > 256 ? 256 : grid_b;
     }
     hipLaunchKernelGGL((gemm_bf16_v6_kernel<EPI, ABL6, AUX, SPLIT, FR>), dim3(grid_b), dim3(512), kLdsBytesV5, st, x, w, b, residual, Y, M, N, K, tiles_m, tiles_n, stagger,
-                       g_gemm_stamp_slot, ld ? ld : K, ldy ? ldy : N, Y2, run);
+                       g_gemm_stamp_slot, ld ? ld : K, ldy ? ldy : N, Y2, run, band);
     g_gemm_stamp_slot = nullptr;                            // one-shot
     COSA_LAUNCH_CHECK();
     if (run < ntiles) {

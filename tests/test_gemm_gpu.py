@@ -8,7 +8,8 @@ import torch
 pytestmark = pytest.mark.gpu
 
 SHAPES = [(4099, 768, 768), (8192, 256, 64), (4608, 2304, 768), (5000, 768, 3072), (300, 768, 768), (257, 256, 128), (1, 128, 64),
-          (70000, 768, 128), (66000, 256, 192)]          # > 256 tiles: the persistent kernel (v6) runs several jobs per workgroup
+          (70000, 768, 128), (66000, 256, 192),          # > 256 tiles: the persistent kernel (v6) runs several jobs per workgroup
+          (16384, 3072, 768), (18432, 2304, 768)]        # tiles_m % 8 == 0: the banded tile order (6 / 3 n-tiles per band)
 
 
 def _ref(x, w, b, epi, r):
