@@ -16,6 +16,7 @@
 // and the O rescale / final 1/l are lane-local.
 #include "kernels.hpp"
 #include "op16.hpp"
+#include "c8.hpp"
 #include <type_traits>
 #include <cstdlib>
 
@@ -393,7 +394,11 @@ __global__ __launch_bounds__(256) void attn_fwd_x3_kernel(const op16 *__restrict
 // DMA: K/V tiles arrive by LDS-DMA (buffer_load ... lds) into a 2-deep ring -- the next tile is in flight while this one is
 // computed, one barrier per tile, no staging registers; the swizzles are applied on the source side (lane-linear LDS image) and
 // key rows past N read as zeros through the buffer range check.
-template <bool DMA>
+// C8OUT (fp16 build): the output leaves as fp16c8 rows (c8.hpp: hi fp16 | lo8 | hi8 | aug (1, 1, 0, ...), row stride 4 H HD + 128 bytes)
+// for the c8 output projection: q, k, v and P stay plain fp16 (the pseudo labels are insensitive to 11-bit attention operands, but not to
+// an 11-bit attention OUTPUT: at near-uniform attention the output is a large common mean plus a small token-specific part that the
+// projection must still see -- tools/sim_precision_map.py)
+template <bool DMA, bool C8OUT = false>
 __global__ __launch_bounds__(128, 2) void attn_fwd2_kernel(const op16 *__restrict__ qkv, const op16 *__restrict__ vt,
                                                        op16 *__restrict__ out, float *__restrict__ lse,
                                                        int N, int Npad, int H, int nblk, int ngroups, float scale_log2e,
@@ -561,7 +566,31 @@ __global__ __launch_bounds__(128, 2) void attn_fwd2_kernel(const op16 *__restric
         float lt = l[u] + __shfl_xor(l[u], 32, 64);
         const float inv = 1.0f / lt;
         const int q = q0 + 32 * u + r;
-        if (q < N) {
+        if (q < N && C8OUT) {
+#if COSA_OP_F16
+            const int D = H * HD;
+            unsigned char *row = reinterpret_cast<unsigned char *>(out) + ((size_t)b * N + q) * (size_t)(4 * D + 128);
+#pragma unroll
+            for (int g = 0; g < 4; g++)
+#pragma unroll
+                for (int d = 0; d < 2; d++) {
+                    const int col = h * HD + 32 * d + 8 * g + 4 * hh;
+                    const float v[4] = {o[u][d][4 * g] * inv, o[u][d][4 * g + 1] * inv, o[u][d][4 * g + 2] * inv, o[u][d][4 * g + 3] * inv};
+                    _Float16 hi[4];
+                    unsigned lo8, hi8;
+                    c8_split4(v, hi, lo8, hi8);
+                    *reinterpret_cast<op16x4 *>(row + 2 * col) = (op16x4){hi[0], hi[1], hi[2], hi[3]};
+                    *reinterpret_cast<unsigned *>(row + 2 * D + col) = lo8;
+                    *reinterpret_cast<unsigned *>(row + 3 * D + col) = hi8;
+                }
+            if (h == 0) {                       // augmentation block (1, 1, 0, ...): 64 fp16, a half per lane half
+                uint4 z = {0u, 0u, 0u, 0u}, one = {0x3c003c00u, 0u, 0u, 0u};
+#pragma unroll
+                for (int c = 0; c < 4; c++) *reinterpret_cast<uint4 *>(row + 4 * D + 64 * hh + 16 * c) = (hh == 0 && c == 0) ? one : z;
+            }
+            if (hh == 0 && lse) lse[((size_t)b * H + h) * N + q] = (m[u] + __builtin_amdgcn_logf(lt)) * 0.6931471805599453f;
+#endif
+        } else if (q < N) {
             op16 *op = out + ((size_t)b * N + q) * H * HD + h * HD;
 #pragma unroll
             for (int g = 0; g < 4; g++) {
@@ -931,6 +960,26 @@ extern "C" int cosa_attn_fwd(const void *qkv, void *out, float *lse, int B, int 
     COSA_LAUNCH_CHECK();
     return COSA_OK;
 }
+
+#if COSA_OP_F16
+/* attention on plain fp16 qkv rows [B, N, 3, H, 64] whose output leaves as fp16c8 rows [B*N, 4 H 64 + 128 bytes] (c8.hpp) for the c8 output
+ * projection; lse optional */
+extern "C" int cosa_attn_fwd_f16c8(const void *qkv, void *out_c8, float *lse, int B, int N, int H, int head_dim, float scale,
+                                   uint64_t *stamps, void *stream)
+{
+    COSA_REQUIRE(qkv && out_c8, "cosa_attn_fwd_f16c8: null pointer");
+    COSA_REQUIRE(head_dim == HD, "cosa_attn_fwd_f16c8: head_dim must be 64");
+    COSA_REQUIRE(B > 0 && N > 0 && H > 0 && B <= 65535 && H <= 65535, "cosa_attn_fwd_f16c8: bad shape");
+    COSA_REQUIRE((size_t)N * 3 * H * HD * 2 < 0x7fffffffull, "cosa_attn_fwd_f16c8: one image's qkv rows must stay below 2 GiB (buffer addressing)");
+    const int Npad = (N + BK - 1) / BK * BK;
+    const int nblk = (N + BQ - 1) / BQ;
+    hipLaunchKernelGGL((attn_fwd2_kernel<true, true>), dim3(nblk * ((B * H + 7) / 8 * 8)), dim3(128), 0, as_stream(stream), static_cast<const op16 *>(qkv),
+                       static_cast<const op16 *>(nullptr), static_cast<op16 *>(out_c8), lse, N, Npad, H, nblk, B * H, scale * 1.4426950408889634f,
+                       reinterpret_cast<unsigned long long *>(stamps));
+    COSA_LAUNCH_CHECK();
+    return COSA_OK;
+}
+#endif
 
 /* backward workspace: delta [B,H,N] f32 (the transposed operands come from transposing LDS reads now) */
 #if !COSA_OP_F16

@@ -15,6 +15,7 @@
 // same XCD (private L2).
 #include "kernels.hpp"
 #include "op16.hpp"
+#include "c8.hpp"
 #include <cstdlib>
 
 namespace cosa {
@@ -78,6 +79,33 @@ __device__ __forceinline__ void stage_tile(const op16 *__restrict__ src, int row
 struct SplitGeom { int Kp; };       // K tiles per half (K / 64)
 __device__ __forceinline__ int split_tile_x(int kt, int Kp) { return kt <= 2 * Kp ? kt : kt - 2 * Kp - 1; }
 __device__ __forceinline__ int split_tile_w(int kt, int Kp) { return kt < Kp ? kt : (kt < 2 * Kp ? kt - Kp : (kt == 2 * Kp ? kt : kt - Kp - 1)); }
+
+// ---- fp16c8 operands (c8.hpp): fp16 hi x fp16 hi on the 16-bit MFMA + two 8-bit correction terms on the block-scaled MFMA ----------------
+// Row layout in 128-byte column tiles (Kp = K / 64, Kh = Kp / 2): hi [0, Kp) | lo8 [Kp, Kp + Kh) | hi8 [Kp + Kh, 2 Kp) | aug 2 Kp.  K loop:
+//     tiles [0, Kp)              X hi  x W hi    (fp16 MFMA, 64 k per tile)
+//     tile   Kp                  X aug x W aug   (fp16: the bias at 16-bit precision, as in the bf16x3 layout)
+//     tiles (Kp, Kp + Kh]        X lo8 x W hi8   (e5m2 MFMA, 128 k per tile, scale 2^-11)
+//     tiles (Kp + Kh, 2 Kp]      X hi8 x W lo8   (e5m2, scale 2^-11)
+// 2 Kp + 1 tiles of equal MFMA time (a 16x16x128 e5m2 MFMA takes the cycles of two 16x16x32 fp16 ones): 2.08x the 1x path, bf16x3 is 3.08x.
+// Both 8-bit operands of a tile are fetched with the SAME lane -> byte map (two 16-byte LDS reads per row: slots fq and fq + 4), so byte p of
+// lane group g meets byte p of lane group g whatever k index the hardware gives it, and the E8M0 scales are uniform: no dependence on
+// the instruction's k layout.
+__device__ __forceinline__ bool c8_is_f8(int kt, int Kp) { return kt > Kp; }
+__device__ __forceinline__ int c8_tile_x(int kt, int Kp) { return kt < Kp ? kt : (kt == Kp ? 2 * Kp : kt - 1); }                 // hi | aug | lo8 | hi8
+__device__ __forceinline__ int c8_tile_w(int kt, int Kp)
+{
+    const int Kh = Kp >> 1;
+    return kt < Kp ? kt : (kt == Kp ? 2 * Kp : (kt <= Kp + Kh ? kt + Kh - 1 : kt - Kh - 1));                                        // hi | aug | hi8 | lo8
+}
+typedef int c8_i32x8 __attribute__((ext_vector_type(8)));
+typedef int c8_i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ c8_i32x8 c8_cat(op16x8 lo, op16x8 hi)
+{
+    return __builtin_shufflevector(__builtin_bit_cast(c8_i32x4, lo), __builtin_bit_cast(c8_i32x4, hi), 0, 1, 2, 3, 4, 5, 6, 7);
+}
+constexpr int kC8ScaleW = 0x7f7f7f7f;       // E8M0 2^0 in every byte (A operand: weight rows)
+constexpr int kC8ScaleX = 0x74747474;       // E8M0 2^-11 (B operand: token rows): both correction terms carry one lo8 factor = x 2^11
+#define COSA_MFMA_C8(a8, b8, c) __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8, b8, c, 1, 1, 0, kC8ScaleW, 0, kC8ScaleX)
 
 template <int EPI, int SPLIT = 0>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const op16 *__restrict__ X, const op16 *__restrict__ W,
@@ -927,13 +955,15 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
     constexpr int ABL = 0;
     constexpr int FL = 0x00020000;
     static_assert(FR == 4 || (FR == 3 && SPLIT == 0), "FR: 16-feature fragments per wave and W half (tile width 64 FR)");
+    constexpr bool C8 = SPLIT == 3;                    // fp16c8 operands (see c8_tile_x / c8_tile_w); 16-bit GELU outputs leave as c8 rows
+    constexpr bool C8OUT = C8 && EPI == EPI_GELU;
     constexpr int TN = 64 * FR, HN = 32 * FR, WN = 16 * FR;     // features per tile / per W half / per wave inside a half
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wr = wave >> 2, wc = wave & 3;
     const int frow = lane & 15, fq = lane >> 4;
     const int Kp = K / BK;
-    const int nk = SPLIT == 1 ? 3 * Kp + 1 : Kp;
+    const int nk = SPLIT == 1 ? 3 * Kp + 1 : (C8 ? 2 * Kp + 1 : Kp);
     const int ntiles = tiles_m * tiles_n, G = gridDim.x;
     const int cq = ntiles >> 3, cr = ntiles & 7;
     unsigned char *Yb = static_cast<unsigned char *>(Yv);
@@ -1008,6 +1038,8 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
     }
     // FR == 3, 16-bit output: the third fragment of a wave has no partner to swap with; its lane keeps features 4fq .. 4fq + 3 (8-byte stores)
     const unsigned voY3 = (unsigned)((32 + 4 * fq - (fq & 1) * 16 - 4 * (fq & 2)) * 2);
+    // c8 rows out: the lane's feature offset inside the tile in BYTES of an 8-bit plane (voY holds it doubled, for the fp16 plane)
+    const unsigned fo8 = (unsigned)(wr * WN + (fq & 1) * 16 + 4 * (fq & 2));
 
     int o = blockIdx.x;
     // Optional start stagger (experiment, off by default): workgroups that have one job fewer than the busiest ones start
@@ -1024,7 +1056,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
             __syncthreads();
         }
     }
-    int m0, n0, m1 = 0, n1 = 0;
+    int m0, n0, m1 = 0, n1 = 0, pn0 = 0;
     tile_of(o, m0, n0);
     bool has_next = o + G < ntiles_run;      // (ntiles_run <= ntiles: the jobs past it are left to a tail launch, cosa_gemm_bf16)
     if (has_next) tile_of(o + G, m1, n1);
@@ -1043,7 +1075,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
     u32x2 bb[2][4];
     const unsigned bias_lane = (unsigned)((wr * WN + 4 * fq) * 2);        // scalar base + 32-bit lane offset: no 64-bit per-lane pointer to keep alive
 #define V6_LOAD_BIAS(nbase)                                                                               \
-    _Pragma("unroll") for (int a_ = 0; a_ < 2; a_++) _Pragma("unroll") for (int i_ = 0; i_ < FR; i_++) {  \
+    if (!C8) _Pragma("unroll") for (int a_ = 0; a_ < 2; a_++) _Pragma("unroll") for (int i_ = 0; i_ < FR; i_++) {  \
         const op16 *p_ = bias + (nbase) + a_ * HN + i_ * 16;                                              \
         asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(bb[a_][i_]) : "v"(bias_lane), "s"(p_) : "memory"); \
     }
@@ -1055,7 +1087,8 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
         const bool own_ = kt_ < nk;                                                                                    \
         const __amdgpu_buffer_rsrc_t rs_ = ((which) & 1) ? (own_ ? cW : nW) : (own_ ? cX : nX);                        \
         const int t_ = own_ ? kt_ : kt_ - nk;                                                                          \
-        const int so_ = (SPLIT == 1 ? (((which) & 1) ? split_tile_w(t_, Kp) : split_tile_x(t_, Kp)) : t_) * 128;            \
+        const int so_ = (SPLIT == 1 ? (((which) & 1) ? split_tile_w(t_, Kp) : split_tile_x(t_, Kp))                       \
+                         : (C8 ? (((which) & 1) ? c8_tile_w(t_, Kp) : c8_tile_x(t_, Kp)) : t_)) * 128;                         \
         unsigned char *dst_ = smem + (bsel) * V5_BUF + (which) * V5_HALF + (2 * wave) * 1024;                          \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_, (lds_void *)dst_, 16, ((which) & 1) ? voW[(which) >> 1][0] : vo[(which) >> 1][0], so_, 0, 0);           \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_, (lds_void *)(dst_ + 1024), 16, ((which) & 1) ? voW[(which) >> 1][1] : vo[(which) >> 1][1], so_, 0, 0);  \
@@ -1113,8 +1146,8 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
             asm volatile("" ::"v"(acc[(qa) * 4 + i_][(qb) * 2 + j_]));                                              \
     } else if (RES) {                                                                                               \
         _Pragma("unroll") for (int ii = 0; ii < FR; ii++) {                                                         \
-            const unsigned lo_ = bb[qa][ii][0], hi_ = bb[qa][ii][1];                                                \
-            const f32x4 bv_ = {op16_lo(lo_), op16_hi(lo_), op16_lo(hi_), op16_hi(hi_)};                              \
+            const unsigned lo_ = C8 ? 0u : bb[qa][ii][0], hi_ = C8 ? 0u : bb[qa][ii][1];                            \
+            const f32x4 bv_ = C8 ? (f32x4){0.f, 0.f, 0.f, 0.f} : (f32x4){op16_lo(lo_), op16_hi(lo_), op16_lo(hi_), op16_hi(hi_)};  \
             _Pragma("unroll") for (int jj = 0; jj < 2; jj++) {                                                      \
                 const f32x4 o4_ = acc[(qa) * 4 + ii][(qb) * 2 + jj] + bv_;                                          \
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o4_), rsY,                         \
@@ -1164,15 +1197,35 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
             const u32x4 lo4_ = {t0_[0], t1_[0], t0_[1], t1_[1]};                                                    \
             __builtin_amdgcn_raw_buffer_store_b128(lo4_, rsY, voY[(qb) * 2 + jj] + (N + (qa) * HN + pr * 32) * 2, 0, AUX); \
         }                                                                                                           \
+        if (C8OUT) {       /* c8 rows: lo8 at byte 2N + n, hi8 at byte 3N + n of the row (the window starts at byte 2 n0 of it) */   \
+            const float h0_ = (float)p0_[0], h1_ = (float)p0_[1], h2_ = (float)p1_[0], h3_ = (float)p1_[1];        \
+            const float h4_ = (float)p2_[0], h5_ = (float)p2_[1], h6_ = (float)p3_[0], h7_ = (float)p3_[1];        \
+            const unsigned hA_ = c8_pack4(h0_, h1_, h2_, h3_), hB_ = c8_pack4(h4_, h5_, h6_, h7_);                  \
+            const unsigned lA_ = c8_pack4((v0_[0] - h0_) * kC8LoScale, (v0_[1] - h1_) * kC8LoScale, (v0_[2] - h2_) * kC8LoScale, (v0_[3] - h3_) * kC8LoScale); \
+            const unsigned lB_ = c8_pack4((v1_[0] - h4_) * kC8LoScale, (v1_[1] - h5_) * kC8LoScale, (v1_[2] - h6_) * kC8LoScale, (v1_[3] - h7_) * kC8LoScale); \
+            const auto th_ = __builtin_amdgcn_permlane16_swap(hA_, hB_, false, false);                              \
+            const auto tl_ = __builtin_amdgcn_permlane16_swap(lA_, lB_, false, false);                              \
+            const int jn0_ = (&rsY == &pY) ? pn0 : n0;                                                              \
+            const unsigned v8_ = voY[(qb) * 2 + jj] - fo8;                                                          \
+            __builtin_amdgcn_raw_buffer_store_b64((u32x2){tl_[0], tl_[1]}, rsY, v8_, 2 * N - jn0_ + (qa) * HN + pr * 32, AUX); \
+            __builtin_amdgcn_raw_buffer_store_b64((u32x2){th_[0], th_[1]}, rsY, v8_, 3 * N - jn0_ + (qa) * HN + pr * 32, AUX); \
+        }                                                                                                           \
     }
     // 16 MFMAs of quadrant (qa, qb); FIRST: the accumulation starts from the bias
-#define V6_MMA(qa, xf, qb, FIRST)                                                                                   \
+#define V6_MMA(qa, xf, qb, FIRST, F8)                                                                               \
     do {                                                                                                            \
+        if (F8) {      /* one 16x16x128 e5m2 MFMA per accumulator: the two 16-byte fragments of a row side by side */ \
+            _Pragma("unroll") for (int i = 0; i < FR; i++) {                                                        \
+                const c8_i32x8 a8_ = c8_cat(a[i][0], a[i][1]);                                                      \
+                _Pragma("unroll") for (int j = 0; j < 2; j++)                                                       \
+                    acc[(qa) * 4 + i][(qb) * 2 + j] = COSA_MFMA_C8(a8_, c8_cat(xf[j][0], xf[j][1]), acc[(qa) * 4 + i][(qb) * 2 + j]); \
+            }                                                                                                       \
+        } else                                                                                                      \
         _Pragma("unroll") for (int ks = 0; ks < 2; ks++)                                                            \
             _Pragma("unroll") for (int i = 0; i < FR; i++) {                                                        \
                 f32x4 cb_;                                                                                          \
                 if ((FIRST) && ks == 0 && !RES) {                                                                   \
-                    const unsigned lo_ = bb[qa][i][0], hi_ = bb[qa][i][1];                                          \
+                    const unsigned lo_ = C8 ? 0u : bb[qa][i][0], hi_ = C8 ? 0u : bb[qa][i][1];      /* c8: the bias rides in the aug tile */ \
                     cb_[0] = op16_lo(lo_);                                                                          \
                     cb_[1] = op16_hi(lo_);                                                                          \
                     cb_[2] = op16_lo(hi_);                                                                          \
@@ -1199,7 +1252,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
     // (residual, FR fragments: 6 + 8 FR / 6 + 8 FR / 6 + 10 FR / 6 + 6 FR / 6 -- 30 / 30 / 36 / 24 / 6 for the 192-wide tile)
     // (6 instead of 14 at first.4 also covers a job without predecessor; operations retire in issue order).
 #define V6_WAIT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
-#define V6_TILE(t, FIRST, LAST)                                                                                     \
+#define V6_TILE(t, FIRST, LAST, F8)                                                                                 \
     do {                                                                                                            \
         const int b_ = g & 1;                                                                                       \
         /* ---- phase 1 ---- */                                                                                     \
@@ -1217,7 +1270,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
             V6_EPI(1, 0, pY);                                                                                       \
             if (RES) { V5_FENCE(); V6_RLOAD(1, 0, cR); V6_LOAD_BIAS(n0); V5_FENCE(); }                              \
         }                                                                                                           \
-        V6_MMA(0, x0, 0, FIRST);                                                                                    \
+        V6_MMA(0, x0, 0, FIRST, F8);                                                                                    \
         V6_MSECTION_END();                                                                                          \
         /* ---- phase 2 ---- */                                                                                     \
         V6_LDX(x1, 1, b_);                                                                                          \
@@ -1228,7 +1281,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
             V6_EPI(0, 0, cY);                                                                                       \
             if (RES && has_next) { V5_FENCE(); V6_RLOAD(0, 0, nR); V5_FENCE(); }                                    \
         }                                                                                                           \
-        V6_MMA(0, x1, 1, FIRST);                                                                                    \
+        V6_MMA(0, x1, 1, FIRST, F8);                                                                                    \
         V6_MSECTION_END();                                                                                          \
         /* ---- phase 3 ---- */                                                                                     \
         V6_LDW(1, b_);                                                                                              \
@@ -1239,12 +1292,13 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
             V6_EPI(0, 1, cY);                                                                                       \
             if (RES && has_next) { V5_FENCE(); V6_RLOAD(0, 1, nR); V5_FENCE(); }                                    \
         }                                                                                                           \
-        V6_MMA(1, x1, 1, FIRST);                                                                                    \
+        V6_MMA(1, x1, 1, FIRST, F8);                                                                                    \
         V6_MSECTION_END();                                                                                          \
         /* ---- phase 4 ---- */                                                                                     \
         V6_STAGE(2, (t) + 2, b_);                                                                                   \
         V5_FENCE();                                                                                                 \
         if ((LAST) && RES) { if (FR == 4) V6_WAIT(38); else V6_WAIT(30); }                                          \
+        else if ((LAST) && C8OUT) V6_WAIT(30);                                                                      \
         else if (LAST) V6_WAIT(14);                                                                                 \
         else V6_WAIT(6);                                                                                            \
         V6_MSECTION_BEGIN();                                                                                        \
@@ -1252,18 +1306,26 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
             V6_EPI(1, 1, cY);                                                                                       \
             if (RES && has_next) { V5_FENCE(); V6_RLOAD(1, 1, nR); V5_FENCE(); }                                    \
         }                                                                                                           \
-        V6_MMA(1, x0, 0, FIRST);                                                                                    \
+        V6_MMA(1, x0, 0, FIRST, F8);                                                                                    \
         V6_MSECTION_END();                                                                                          \
         g++;                                                                                                        \
     } while (0)
 
     int g = 0;
     while (true) {
-        V6_TILE(0, 1, 0);
-        for (int t = 1; t < nk - 1; t++) V6_TILE(t, 0, 0);
-        V6_TILE(nk - 1, 0, 1);
+        if (C8) {         // Kp + 1 fp16 tiles (hi x hi, aug), then Kp e5m2 tiles: two loop bodies
+            V6_TILE(0, 1, 0, 0);
+            for (int t = 1; t <= Kp; t++) V6_TILE(t, 0, 0, 0);
+            for (int t = Kp + 1; t < nk - 1; t++) V6_TILE(t, 0, 0, 1);
+            V6_TILE(nk - 1, 0, 1, 1);
+        } else {
+            V6_TILE(0, 1, 0, 0);
+            for (int t = 1; t < nk - 1; t++) V6_TILE(t, 0, 0, 0);
+            V6_TILE(nk - 1, 0, 1, 0);
+        }
         if (!has_next) break;
         // next job becomes the running one
+        pn0 = n0;
         pY = cY;
         pY2 = cY2;
         have_prev = true;
@@ -1979,6 +2041,31 @@ extern "C" int cosa_gemm_bf16x3(const void *Xs, const void *Ws, const void *zero
     }
     COSA_LAUNCH_CHECK();
     return COSA_OK;
+}
+#endif
+
+#if COSA_OP_F16
+// Y = X W^T (+ bias, carried by the augmentation block) with fp16c8 operands (c8.hpp; c8_tile_x / c8_tile_w above).
+//   Xs [M, 4K + 128 bytes] = [x_hi fp16 | x_lo8 | x_hi8 | 1 1 0 ...],  Ws [N, 4K + 128] = [w_hi | w_lo8 | w_hi8 | b_hi b_lo 0 ...],  zeros: N fp16 zeros
+//   epilogue 0: Y fp16 [M, ldy >= N] (plain: the qkv projection feeds the fp16 attention kernel);  1: GELU, Y = c8 rows [M, ldy = 2N + 64
+//   fp16 units] (hi | lo8 | hi8; the augmentation block is the consumer's to set);  2: Y fp32 [M, N] = residual + .
+extern "C" int cosa_gemm_f16c8(const void *Xs, const void *Ws, const void *zeros, const float *residual, void *Y,
+                               int M, int N, int K, int epilogue, int ldy, void *stream)
+{
+    struct ClearSlot { ~ClearSlot() { g_gemm_stamp_slot = nullptr; } } clear_slot_;
+    COSA_REQUIRE(Xs && Ws && zeros && Y, "cosa_gemm_f16c8: null pointer");
+    COSA_REQUIRE(M > 0 && N > 0 && K > 0 && N % 256 == 0 && K % 128 == 0, "cosa_gemm_f16c8: N %% 256 == 0 and K %% 128 == 0 required (got M=%d N=%d K=%d)", M, N, K);
+    COSA_REQUIRE(epilogue >= 0 && epilogue <= 2, "cosa_gemm_f16c8: unknown epilogue");
+    COSA_REQUIRE(epilogue != EPI_RESIDUAL || residual, "cosa_gemm_f16c8: residual epilogue needs the residual pointer");
+    COSA_REQUIRE(epilogue == EPI_RESIDUAL ? ldy == N : (epilogue == EPI_GELU ? ldy == 2 * N + 64 : (ldy >= N && ldy % 8 == 0)),
+                 "cosa_gemm_f16c8: ldy must be N (fp32 out), 2N + 64 (c8 rows out) or >= N (fp16 out)");
+    const int ld = 2 * K + 64;
+    COSA_REQUIRE((size_t)256 * ld * 2 < 0x7fffffffull && (size_t)N * ld * 2 < 0x7fffffffull && (size_t)256 * ldy * 4 < 0x7fffffffull, "cosa_gemm_f16c8: panel beyond 2 GiB");
+    hipStream_t st = as_stream(stream);
+    const op16 *x = static_cast<const op16 *>(Xs), *w = static_cast<const op16 *>(Ws), *b = static_cast<const op16 *>(zeros);
+    if (epilogue == EPI_BIAS) return launch_v6<EPI_BIAS, 0, 0, 3>(x, w, b, residual, Y, M, N, K, st, ld, ldy);
+    if (epilogue == EPI_GELU) return launch_v6<EPI_GELU, 0, 0, 3>(x, w, b, residual, Y, M, N, K, st, ld, ldy);
+    return launch_v6<EPI_RESIDUAL, 0, 0, 3>(x, w, b, residual, Y, M, N, K, st, ld, ldy);
 }
 #endif
 

@@ -10,6 +10,7 @@
 //                          teacher; activations: the im2col'd image of the patch projection)
 //   cosa_layernorm_split   nn.LayerNorm(768, eps) over the fp32 residual stream with fp32 gamma / beta -> split rows (and/or fp32)
 #include "kernels.hpp"
+#include "c8.hpp"
 
 namespace cosa {
 namespace {
@@ -105,6 +106,91 @@ __global__ __launch_bounds__(256) void layernorm_split_kernel(const float *__res
     }
 }
 
+
+// ---- fp16c8 rows (c8.hpp): [hi fp16 (2K bytes) | lo8 (K) | hi8 (K) | aug fp16 (128)] -----------------------------------------------------
+typedef _Float16 f16;
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void c8_store4(unsigned char *row, int K, int c, const float (&v)[4])
+{
+    f16 hi[4];
+    unsigned lo8, hi8;
+    c8_split4(v, hi, lo8, hi8);
+    *reinterpret_cast<f16x4 *>(row + 2 * c) = (f16x4){hi[0], hi[1], hi[2], hi[3]};
+    *reinterpret_cast<unsigned *>(row + 2 * K + c) = lo8;
+    *reinterpret_cast<unsigned *>(row + 3 * K + c) = hi8;
+}
+
+__device__ __forceinline__ void c8_store_aug(unsigned char *row, int K, int lane, bool ones, const float *bias_of_row)
+{
+    if (lane < 8) {                                   // augmentation block: 8 lanes x 8 fp16
+        f16x8 a;
+#pragma unroll
+        for (int j = 0; j < 8; j++) a[j] = (f16)0.f;
+        if (lane == 0) {
+            if (ones) { a[0] = (f16)1.f; a[1] = (f16)1.f; }
+            else if (bias_of_row) { const float b = *bias_of_row; a[0] = (f16)b; a[1] = (f16)(b - (float)a[0]); }
+        }
+        *reinterpret_cast<f16x8 *>(row + 4 * K + lane * 16) = a;
+    }
+}
+
+// one wave per row; K % 4 == 0
+__global__ __launch_bounds__(256) void c8_rows_kernel(const float *__restrict__ src, const float *__restrict__ bias, unsigned char *__restrict__ dst,
+                                                     int R, int K, long long src_ld, int ones)
+{
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= R) return;
+    const int lane = threadIdx.x & 63;
+    const float *s = src + (size_t)row * src_ld;
+    unsigned char *d = dst + (size_t)row * (4 * K + 128);
+    for (int c = lane * 4; c < K; c += 256) {
+        const float4 f = *reinterpret_cast<const float4 *>(s + c);
+        const float v[4] = {f.x, f.y, f.z, f.w};
+        c8_store4(d, K, c, v);
+    }
+    c8_store_aug(d, K, lane, ones != 0, bias ? bias + row : nullptr);
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void layernorm_c8_kernel(const float *__restrict__ x, const float *__restrict__ g, const float *__restrict__ b,
+                                                          unsigned char *__restrict__ y, float *__restrict__ y32, int rows, float eps)
+{
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    constexpr int PER = D / 64 / 4;
+    const float4 *xr = reinterpret_cast<const float4 *>(x + (size_t)row * D);
+    float4 v[PER];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < PER; i++) { v[i] = xr[lane + 64 * i]; s += v[i].x + v[i].y + v[i].z + v[i].w; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float mean = s * (1.0f / D);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+        const float a = v[i].x - mean, c = v[i].y - mean, d = v[i].z - mean, e = v[i].w - mean;
+        q += a * a + c * c + d * d + e * e;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+    const float rstd = rsqrtf(q * (1.0f / D) + eps);
+    unsigned char *yr = y ? y + (size_t)row * (4 * D + 128) : nullptr;
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+        const int c0 = (lane + 64 * i) * 4;
+        const float4 gg = *reinterpret_cast<const float4 *>(g + c0), bb = *reinterpret_cast<const float4 *>(b + c0);
+        const float o[4] = {(v[i].x - mean) * rstd * gg.x + bb.x, (v[i].y - mean) * rstd * gg.y + bb.y,
+                            (v[i].z - mean) * rstd * gg.z + bb.z, (v[i].w - mean) * rstd * gg.w + bb.w};
+        if (yr) c8_store4(yr, D, c0, o);
+        if (y32) *reinterpret_cast<float4 *>(y32 + (size_t)row * D + c0) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+    if (yr) c8_store_aug(yr, D, lane, true, nullptr);
+}
+
 }  // namespace
 }  // namespace cosa
 
@@ -126,6 +212,27 @@ extern "C" int cosa_layernorm_split(const float *x, const float *gamma, const fl
     COSA_REQUIRE(dim == 768, "cosa_layernorm_split: dim must be 768 (ViT-B)");
     hipLaunchKernelGGL(layernorm_split_kernel<768>, dim3((rows + 3) / 4), dim3(256), 0, as_stream(stream), x, gamma, beta,
                        static_cast<bf16 *>(y_split), y_f32, rows, eps);
+    COSA_LAUNCH_CHECK();
+    return COSA_OK;
+}
+
+// ---- fp16c8 producers (c8.hpp; include/cosa_hip.h) ---------------------------------------------------------------------------------
+extern "C" int cosa_c8_rows(const float *src, const float *bias, void *dst, int R, int K, long long src_ld, int ones, void *stream)
+{
+    COSA_REQUIRE(src && dst && R > 0 && K > 0 && K % 128 == 0 && src_ld >= K && src_ld % 4 == 0, "cosa_c8_rows: bad arguments (K %% 128 == 0)");
+    hipLaunchKernelGGL(c8_rows_kernel, dim3((R + 3) / 4), dim3(256), 0, as_stream(stream), src, bias, static_cast<unsigned char *>(dst), R, K,
+                       src_ld, ones);
+    COSA_LAUNCH_CHECK();
+    return COSA_OK;
+}
+
+extern "C" int cosa_layernorm_c8(const float *x, const float *gamma, const float *beta, void *y_c8, float *y_f32, int rows, int dim,
+                                 float eps, void *stream)
+{
+    COSA_REQUIRE(x && gamma && beta && (y_c8 || y_f32) && rows > 0, "cosa_layernorm_c8: bad arguments");
+    COSA_REQUIRE(dim == 768, "cosa_layernorm_c8: dim must be 768 (ViT-B)");
+    hipLaunchKernelGGL(layernorm_c8_kernel<768>, dim3((rows + 3) / 4), dim3(256), 0, as_stream(stream), x, gamma, beta,
+                       static_cast<unsigned char *>(y_c8), y_f32, rows, eps);
     COSA_LAUNCH_CHECK();
     return COSA_OK;
 }

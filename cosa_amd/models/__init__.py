@@ -91,10 +91,11 @@ class VITNetwork(nn.Module):
 
     def set_nograd_precision(self, mode):
         """operand precision of the no-grad passes (teacher pseudo-labels, evaluation): "bf16" (8 significant bits), "fp16" (11; the
-        same kernels built for fp16 operands) or "bf16x3" (16; hi + lo bf16 halves, three MFMA terms): DESIGN.md section 3"""
-        assert mode in ("bf16", "fp16", "bf16x3")
-        self.set_compute_dtype(torch.float16 if mode == "fp16" else torch.bfloat16)
-        self.encoder.precision = "bf16x3" if mode == "bf16x3" else None
+        same kernels built for fp16 operands), "bf16x3" (16; hi + lo bf16 halves, three MFMA terms) or "fp16c8" (fp16 + 8-bit correction
+        terms on the block-scaled MFMA, ~14 bits at twice the 16-bit work; attention operands plain fp16): DESIGN.md section 3"""
+        assert mode in ("bf16", "fp16", "bf16x3", "fp16c8")
+        self.set_compute_dtype(torch.float16 if mode in ("fp16", "fp16c8") else torch.bfloat16)
+        self.encoder.precision = mode if mode in ("bf16x3", "fp16c8") else None
         return self
 
     def get_param_groups(self):

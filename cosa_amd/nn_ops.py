@@ -388,6 +388,70 @@ def attn_fwd_x3(qkv_s, B, N, H, out_s, lse=None):
 
 
 # --------------------------------------------------------------------------------------------
+# fp16c8 operands: parity-grade no-grad passes at 2x the 16-bit MFMA work (include/cosa_hip.h; csrc/c8.hpp)
+#   a c8 row of logical width K, in bytes: [hi fp16 (2K) | lo8 e5m2 (K) | hi8 e5m2 (K) | aug fp16 (128)]; held as fp16 tensors of
+#   2K + 64 columns (the same stride as a bf16x3 row)
+# --------------------------------------------------------------------------------------------
+_zero_bias16 = {}
+
+
+def c8_rows(src, bias=None, ones=False, out=None):
+    """fp32 [R, K] (unit column stride; any row stride; K % 128 == 0) -> c8 rows [R, 2K + 64] (fp16 units); aug block = (bias_hi,
+    bias_lo, 0..) per row, (1, 1, 0..) with ones=True, zeros otherwise"""
+    R, K = src.shape
+    assert src.dtype == torch.float32 and src.stride(1) == 1
+    if out is None:
+        out = torch.empty((R, split_ld(K)), device=src.device, dtype=torch.float16)
+    _C.check(_C.lib().cosa_c8_rows(_C.ptr(src), _C.ptr(bias), _C.ptr(out), R, K, src.stride(0), int(ones), _C.stream_ptr()), "cosa_c8_rows")
+    return out
+
+
+def layernorm_c8(x, g, b, eps, out=None, want_f32=False):
+    """LayerNorm(768) over the fp32 stream with fp32 gamma / beta -> (c8 rows [rows, 1600 fp16 units] | None, fp32 | None)"""
+    rows, D = x.shape
+    y32 = torch.empty((rows, D), device=x.device, dtype=torch.float32) if want_f32 else None
+    _C.check(_C.lib().cosa_layernorm_c8(_C.ptr(x), _C.ptr(g), _C.ptr(b), _C.ptr(out), _C.ptr(y32), rows, D, float(eps), _C.stream_ptr()),
+             "cosa_layernorm_c8")
+    return out, y32
+
+
+def gemm_c8(xs, ws, M, N, K, epilogue=EPI_BIAS, residual=None, out=None, ldy=None):
+    """xs [M, 2K+64], ws [N, 2K+64] c8 rows (bias inside ws).  epilogue 0: plain fp16 [M, ldy >= N]; 1 (GELU): c8 rows [M, 2N + 64]
+    (hi | lo8 | hi8 written; the caller owns the aug block); 2: fp32 [M, N] = residual + . (in place allowed)"""
+    dev = xs.device
+    z = _zero_bias16.get(dev)
+    if z is None:
+        z = _zero_bias16[dev] = torch.zeros(8192, device=dev, dtype=torch.float16)
+    if epilogue == EPI_RESIDUAL:
+        ldy = N
+        if out is None:
+            out = torch.empty((M, N), device=dev, dtype=torch.float32)
+    else:
+        ldy = ldy or (split_ld(N) if epilogue == EPI_GELU else N)
+        if out is None:
+            out = torch.empty((M, ldy), device=dev, dtype=torch.float16)
+    if gemm_stamps is not None and M >= 4096:
+        _C.lib().cosa_gemm_set_stamp_slot_f16(gemm_stamps.next_slot(2.0 * M * N * K))        # algorithmic FLOPs: one product per (m, n, k)
+    with _C.profiled("gemm_c8"):
+        _C.check(_C.lib().cosa_gemm_f16c8(_C.ptr(xs), _C.ptr(ws), _C.ptr(z), _C.ptr(residual), _C.ptr(out), M, N, K, epilogue, ldy,
+                                          _C.stream_ptr()), "cosa_gemm_f16c8")
+    _flops["gemm_c8"] = _flops.get("gemm_c8", 0) + 2.0 * M * N * K * (2 * (K // 64) + 1) / (K // 64)
+    return out
+
+
+def attn_fwd_c8(qkv, B, N, H, out_c8, lse=None):
+    """attention on plain fp16 qkv [B, N, 3 H 64] -> c8 rows out_c8 [B*N, 2 H 64 + 64 fp16 units] (hi | lo8 | hi8 | aug)"""
+    assert qkv.dtype == torch.float16 and qkv.is_contiguous() and out_c8.stride(0) == split_ld(H * 64)
+    fl = 4.0 * B * H * N * N * 64
+    st = stamps.next_slot(fl) if stamps is not None else None
+    with _C.profiled("attn_fwd"):
+        _C.check(_C.lib().cosa_attn_fwd_f16c8(_C.ptr(qkv), _C.ptr(out_c8), _C.ptr(lse), B, N, H, 64, 0.125, st, _C.stream_ptr()),
+                 "cosa_attn_fwd_f16c8")
+    _flops["attn_fwd"] = _flops.get("attn_fwd", 0) + fl
+    return out_c8
+
+
+# --------------------------------------------------------------------------------------------
 # small helpers
 # --------------------------------------------------------------------------------------------
 _shadows = {}          # id(param) -> (param, persistent 16-bit shadow at a fixed address; refreshed explicitly, hipGraph-safe)

@@ -319,6 +319,31 @@ int cosa_attn_fwd_bf16x3(const void *qkv_split, void *out_split, float *lse, int
                          int ldq, int ldo, void *stream);
 
 /* ---------------------------------------------------------------------------------------
+ * fp16c8 operands: the parity-grade precision of the no-grad passes at 2x (not 3x) the MFMA work of the 16-bit path
+ * (teacher pseudo-labels, utils/seg_helper.py:232-275; replaces the fp32 arithmetic of models/vit/vit.py:96-137 on the no-grad path).
+ * A value v is carried as hi = fp16(v) plus two e5m2 bytes: hi8 = e5m2(hi) and lo8 = e5m2((v - hi) * 2^11); a product is
+ * x_hi w_hi (fp16 MFMA) + 2^-11 (x_lo8 w_hi8 + x_hi8 w_lo8) (block-scaled 8-bit MFMA, K = 128 per instruction, twice the fp16 rate; the
+ * 2^-11 is the instruction's E8M0 scale).  e5m2 has fp16's exponent range: no per-tensor statistics or scales exist.  A c8 row of logical
+ * width K is, in bytes, [hi fp16 (2K) | lo8 (K) | hi8 (K) | aug fp16 (128)], row stride 4K + 128 (= the bf16x3 stride); aug = (1, 1, 0, ...)
+ * for activations and (bias_hi, bias_lo, 0, ...) for weight row n (the bias rides in the GEMM as one more fp16 K tile).
+ *   cosa_c8_rows          src fp32 [R, K] (row stride src_ld) (+ bias fp32 [R] | ones) -> dst c8 rows; K % 128 == 0
+ *   cosa_layernorm_c8     nn.LayerNorm(768, eps), fp32 gamma / beta, over the fp32 residual stream -> c8 rows and/or fp32
+ *   cosa_gemm_f16c8       Y = Xs Ws^T (bias inside Ws); N % 256 == 0, K % 128 == 0.  epilogue 0: Y fp16 [M, ldy >= N] (plain: the
+ *                         qkv projection feeds the fp16 attention kernel); 1 (GELU): Y = c8 rows [M, ldy = 2N + 64 fp16 units], hi | lo8 |
+ *                         hi8 written, the augmentation block left to the caller; 2: Y fp32 [M, N] = residual + . (may alias);
+ *                         zeros: N fp16 zeros (the kernel's unused bias operand)
+ *   cosa_attn_fwd_f16c8   attention on plain fp16 qkv rows [B, N, 3, H, 64] -> c8 rows [B*N, 4*H*64 + 128 bytes] (incl. the augmentation
+ *                         block) for the c8 output projection; lse optional
+ * ------------------------------------------------------------------------------------- */
+int cosa_c8_rows(const float *src, const float *bias, void *dst, int R, int K, long long src_ld, int ones, void *stream);
+int cosa_layernorm_c8(const float *x, const float *gamma, const float *beta, void *y_c8, float *y_f32, int rows, int dim,
+                      float eps, void *stream);
+int cosa_gemm_f16c8(const void *Xs, const void *Ws, const void *zeros, const float *residual, void *Y,
+                    int M, int N, int K, int epilogue, int ldy, void *stream);
+int cosa_attn_fwd_f16c8(const void *qkv, void *out_c8, float *lse, int B, int N, int H, int head_dim, float scale,
+                        uint64_t *stamps, void *stream);
+
+/* ---------------------------------------------------------------------------------------
  * main.py:167-212 + utils/seg_helper.py:800-813,199-230  the student's dense losses, fused:
  *   seg_loss(main) and seg_loss(aux) of the bilinearly up-sampled logits, and the inputs of the
  *   dense-energy regulariser (softmax -> x0.5, ROI from boxes, nearest image / label), without

@@ -1,0 +1,189 @@
+"""CPU simulation (authoring container, no GPU): which operand-precision scheme of the teacher's matrix products keeps the
+north-star tolerance (normalised-CAM rel. err <= 1e-3, mask IoU >= 0.999 against the fp32 oracle on identical weights / inputs).
+
+Every matrix product of the fused teacher path is a "site" (patch, qkv, qk, pv, proj, fc1, fc2); a scheme says how its two
+operands are represented:
+
+  f32     exact
+  bf16    both operands rounded to bf16                      (1 MFMA term)
+  fp16    both operands rounded to fp16                      (1 term)
+  x3      bf16 hi + bf16 lo, hi*hi + lo*hi + hi*lo           (3 bf16 terms)
+  h8      fp16 hi * fp16 hi + fp8(lo) * fp8(hi) + fp8(hi) * fp8(lo), e4m3 with one power-of-two scale per operand
+          (the two correction terms run on the block-scaled MFMA at twice the fp16 rate: 2 term-equivalents)
+  h8a     as h8 but only the activation-side correction (lo(a) * hi8(b)):  1.5 term-equivalents
+  h8w     only the weight-side correction
+  h5      as h8 with e5m2 corrections and FIXED scales (1 for the hi copies, 2^11 for the lo parts): no statistics needed
+  h4      as h8 with e2m1 (fp4) corrections and one shared exponent per 32 elements along k:  1.5 term-equivalents
+
+usage: python tools/sim_precision_map.py S "name=site:scheme,site:scheme,...;name2=..."   (unlisted sites: default scheme `def:`)
+"""
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, '.')
+from oracle import torch_oracle as to, c_oracle          # noqa: E402
+from cosa_amd.train_step import synthetic_batch          # noqa: E402
+
+F8 = torch.float8_e4m3fn
+
+
+def pow2_scale(t, top):
+    m = t.abs().max().item()
+    return 1.0 if m == 0 else 2.0 ** np.floor(np.log2(top / m))
+
+
+def q8(t, scale=None):
+    """e4m3 with a per-tensor power-of-two scale, saturating"""
+    s = pow2_scale(t, 448.0) if scale is None else scale
+    return (t * s).clamp(-448, 448).to(F8).float() / s
+
+
+F5 = torch.float8_e5m2
+
+
+def q5(t, scale=1.0):
+    """e5m2 with a fixed power-of-two scale, saturating"""
+    return (t * scale).clamp(-57344, 57344).to(F5).float() / scale
+
+
+def q4_block(t):
+    """e2m1 with one power-of-two scale per 32 consecutive elements of the last dim (MX block)"""
+    sh = t.shape
+    K = sh[-1]
+    pad = (-K) % 32
+    x = F.pad(t, (0, pad)).reshape(-1, 32)
+    m = x.abs().amax(1, keepdim=True).clamp_min(1e-30)
+    s = 2.0 ** torch.floor(torch.log2(6.0 / m))
+    y = x * s
+    grid = torch.tensor([0, 0.5, 1, 1.5, 2, 3, 4, 6.0])
+    a = y.abs().clamp(max=6.0)
+    idx = (a[..., None] - grid).abs().argmin(-1)
+    y = torch.sign(y) * grid[idx] / s
+    return y.reshape(*sh[:-1], K + pad)[..., :K]
+
+
+def split(t, dt):
+    h = t.to(dt).float()
+    return h, t - h
+
+
+def prod(a, b, scheme):
+    """a [.., M, K] @ b[.., N, K]^T under a scheme"""
+    mm = lambda x, y: x @ y.transpose(-1, -2)
+    if scheme == "f32":
+        return mm(a, b)
+    if scheme in ("bf16", "fp16"):
+        dt = torch.bfloat16 if scheme == "bf16" else torch.float16
+        return mm(a.to(dt).float(), b.to(dt).float())
+    if scheme == "x3":
+        ah, al = split(a, torch.bfloat16)
+        bh, bl = split(b, torch.bfloat16)
+        return mm(ah, bh) + mm(al.bfloat16().float(), bh) + mm(ah, bl.bfloat16().float())
+    ah, al = split(a, torch.float16)
+    bh, bl = split(b, torch.float16)
+    y = mm(ah, bh)
+    if scheme in ("h8", "h8a", "h8w"):
+        if scheme != "h8w":
+            y = y + mm(q8(al), q8(bh))
+        if scheme != "h8a":
+            y = y + mm(q8(ah), q8(bl))
+        return y
+    if scheme == "h5":          # e5m2 corrections, fixed scales: hi copies x 1, lo parts x 2^11 (no per-tensor statistics)
+        return y + mm(q5(al, 2048.0), q5(bh)) + mm(q5(ah), q5(bl, 2048.0))
+    if scheme == "h85":         # lo parts e4m3 (x 2^11 x per-tensor scale), hi copies e5m2
+        return y + mm(q8(al), q5(bh)) + mm(q5(ah), q8(bl))
+    if scheme == "h4":
+        return y + mm(q4_block(al), q4_block(bh)) + mm(q4_block(ah), q4_block(bl))
+    raise ValueError(scheme)
+
+
+def make_encoder(cfg):
+    sch = lambda site: cfg.get(site, cfg.get("def", "f32"))
+
+    def lin(x, w, b, site):
+        return prod(x, w, sch(site)) + b
+
+    def encoder(self, x):
+        p = self.p
+        B, _, H, W = x.shape
+        h, w = H // self.patch, W // self.patch
+        cols = F.unfold(x, self.patch, stride=self.patch).transpose(1, 2)                      # [B, n, 768]
+        t = lin(cols, p("encoder.patch_embed.proj.weight").flatten(1), p("encoder.patch_embed.proj.bias"), "patch")
+        pe = p("encoder.pos_embed")
+        grid = pe[:, 1:].reshape(1, self.grid, self.grid, -1).permute(0, 3, 1, 2)
+        grid = F.interpolate(grid, size=(h, w), mode="bicubic", align_corners=False).reshape(1, -1, h * w).permute(0, 2, 1)
+        t = torch.cat([p("encoder.cls_token").expand(B, -1, -1), t], 1) + torch.cat([pe[:, :1], grid], 1)
+        B, N, D = t.shape
+        hd = D // self.heads
+        embeds = []
+        for i in range(self.depth):
+            pre = f"encoder.blocks.{i}."
+            y = F.layer_norm(t, (D,), p(pre + "norm1.weight"), p(pre + "norm1.bias"), 1e-6)
+            qkv = lin(y, p(pre + "attn.qkv.weight"), p(pre + "attn.qkv.bias"), "qkv").reshape(B, N, 3, self.heads, hd).permute(2, 0, 3, 1, 4)
+            att = prod(qkv[0], qkv[1], sch("qk")) * hd ** -0.5
+            m = att.amax(-1, keepdim=True)
+            e = torch.exp(att - m)
+            y = (prod(e, qkv[2].transpose(-1, -2), sch("pv")) / e.sum(-1, keepdim=True)).transpose(1, 2).reshape(B, N, D)
+            t = t + lin(y, p(pre + "attn.proj.weight"), p(pre + "attn.proj.bias"), "proj")
+            y = F.layer_norm(t, (D,), p(pre + "norm2.weight"), p(pre + "norm2.bias"), 1e-6)
+            y = F.gelu(lin(y, p(pre + "mlp.fc1.weight"), p(pre + "mlp.fc1.bias"), "fc1"))
+            t = t + lin(y, p(pre + "mlp.fc2.weight"), p(pre + "mlp.fc2.bias"), "fc2")
+            embeds.append(t)
+        final = F.layer_norm(t, (D,), p("encoder.norm.weight"), p("encoder.norm.bias"), 1e-6)
+        embeds[-1] = final
+        return final[:, 0], final[:, 1:], embeds[self.aux_layer][:, 1:], h, w
+    return encoder
+
+
+def miou(a, b, n=21):
+    ious = []
+    for c in list(range(n)) + [255]:
+        A, B = a == c, b == c
+        u = (A | B).sum()
+        if u:
+            ious.append((A & B).sum() / u)
+    return float(np.mean(ious))
+
+
+def main():
+    S = int(sys.argv[1])
+    specs = sys.argv[2].split(";")
+    torch.manual_seed(3)
+    from cosa_amd.models import build_model
+    from cosa_amd.train_step import default_args
+    args = default_args("VOC12", crop_size=S, compute_dtype=torch.float32)
+    net = build_model(args)
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    wimg, simg, lab, box = synthetic_batch(2, S, 20, torch.device('cpu'), seed=5)
+
+    def run(cfg):
+        m = to.OracleViT(num_classes=21, aux_layer=-4)
+        m.load_named(sd)
+        if cfg is not None:
+            m.encoder = types.MethodType(make_encoder(cfg), m)
+        with torch.no_grad():
+            cam, cam_aux, seg = to.multi_scale_camseg(m, wimg, [1.0, 0.5, 1.5])
+        masks = [c_oracle.cam2mask(None, np.asarray(box.numpy(), np.int32), c.numpy(), lab.numpy(), 0.7, 0.25, 2, par=None)
+                 for c in (cam, cam_aux)]
+        return cam, cam_aux, masks
+
+    ref = run(None)
+    act = lab.bool()
+    for spec in specs:
+        name, body = spec.split("=")
+        cfg = dict(kv.split(":") for kv in body.split(","))
+        got = run(cfg)
+        out = []
+        for k, nm in ((0, "cam"), (1, "aux")):
+            rel = ((got[k] - ref[k]).abs().amax(dim=(2, 3)) / ref[k].abs().amax(dim=(2, 3)).clamp_min(1e-6))[act].max().item()
+            agree = np.mean(got[2][k] == ref[2][k])
+            out.append(f"{nm} rel {rel:.2e} agree {agree:.5f} mIoU {miou(got[2][k], ref[2][k]):.5f}")
+        print(f"S={S} {name:28s} " + " | ".join(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()
