@@ -392,7 +392,7 @@ def attn_fwd_x3(qkv_s, B, N, H, out_s, lse=None):
 #   a c8 row of logical width K, in bytes: [hi fp16 (2K) | lo8 e5m2 (K) | hi8 e5m2 (K) | aug fp16 (128)]; held as fp16 tensors of
 #   2K + 64 columns (the same stride as a bf16x3 row)
 # --------------------------------------------------------------------------------------------
-_zero_bias16 = {}
+_c8_zero_bias = {}
 
 
 def c8_rows(src, bias=None, ones=False, out=None):
@@ -419,9 +419,9 @@ def gemm_c8(xs, ws, M, N, K, epilogue=EPI_BIAS, residual=None, out=None, ldy=Non
     """xs [M, 2K+64], ws [N, 2K+64] c8 rows (bias inside ws).  epilogue 0: plain fp16 [M, ldy >= N]; 1 (GELU): c8 rows [M, 2N + 64]
     (hi | lo8 | hi8 written; the caller owns the aug block); 2: fp32 [M, N] = residual + . (in place allowed)"""
     dev = xs.device
-    z = _zero_bias16.get(dev)
+    z = _c8_zero_bias.get(dev)
     if z is None:
-        z = _zero_bias16[dev] = torch.zeros(8192, device=dev, dtype=torch.float16)
+        z = _c8_zero_bias[dev] = torch.zeros(8192, device=dev, dtype=torch.float16)
     if epilogue == EPI_RESIDUAL:
         ldy = N
         if out is None:

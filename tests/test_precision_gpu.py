@@ -199,7 +199,7 @@ def test_c8_rows_and_layernorm_c8_fields():
     hi, lo8, hi8, aug = _c8_fields(rows, K)
     rh, rl, rh8 = _c8_ref_fields(v)
     assert torch.equal(hi, rh) and torch.equal(lo8, rl) and torch.equal(hi8, rh8)
-    assert ((hi + lo8 - v).abs() <= 2.0 ** -14 * v.abs() + 1e-12).all()
+    assert ((hi + lo8 - v).abs() <= 2.0 ** -14 * v.abs() + 2.0 ** -27).all()          # (absolute floor: fp16 subnormals)
     bh = bias.half().float()
     assert torch.equal(aug[:, 0], bh) and torch.equal(aug[:, 1], (bias - bh).half().float()) and aug[:, 2:].abs().max().item() == 0
     ones = _c8_fields(nn_ops.c8_rows(v, ones=True), K)[3]
@@ -274,7 +274,7 @@ def test_gemm_f16c8_residual_beats_fp16_by_its_correction_terms():
 
 @pytest.mark.parametrize("B,N,H", [(2, 197, 12), (1, 785, 3), (2, 100, 3), (1, 1765, 2), (1, 1, 1), (1, 129, 1)])
 def test_attention_c8_output_rows(B, N, H):
-    """fp16 attention whose output leaves as c8 rows: hi is bit for bit the plain fp16 kernel's output, hi + lo8 is the fp32 result
+    """fp16 attention whose output leaves as c8 rows: hi is the plain fp16 kernel's output (up to double rounding), hi + lo8 is the fp32 result
     before that rounding (so it is closer to the fp32 reference of the same fp16 inputs), hi8 / aug as specified"""
     from cosa_amd import nn_ops
     torch.manual_seed(N)
@@ -285,7 +285,10 @@ def test_attention_c8_output_rows(B, N, H):
     lse = torch.empty(B, H, N, device="cuda")
     nn_ops.attn_fwd_c8(qkv, B, N, H, out, lse)
     hi, lo8, hi8, aug = _c8_fields(out, D)
-    assert torch.equal(hi, plain.view(B * N, D).float()) and torch.equal(lse, lse_p)
+    # (the plain kernel's o * (1 / l) is rounded to fp16 ONCE by a mixed-precision fma, here the fp32 product is kept for lo8 and rounded
+    # again: the two agree except for rare double-rounding cases, which are one fp16 ulp apart)
+    p = plain.view(B * N, D).float()
+    assert ((hi - p).abs() <= 2.0 ** -10 * p.abs() + 1e-7).all() and (hi != p).float().mean().item() < 1e-3 and torch.equal(lse, lse_p)
     assert torch.equal(hi8, hi.clamp(-57344, 57344).to(torch.float8_e5m2).float())
     assert torch.equal(aug[:, :2].cpu(), torch.ones(B * N, 2)) and aug[:, 2:].abs().max().item() == 0
     q, k, v = qkv.double().view(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)

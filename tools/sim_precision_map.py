@@ -102,7 +102,17 @@ def prod(a, b, scheme):
 
 
 def make_encoder(cfg):
-    sch = lambda site: cfg.get(site, cfg.get("def", "f32"))
+    layer = [0]
+    gemm_sites = ("qkv", "proj", "fc1", "fc2")
+
+    def sch(site):
+        # depth-dependent maps: "from:6,late:fp16" runs the block projections of layers >= 6 in `late`; "until:6,early:fp16" layers < 6
+        if site in gemm_sites:
+            if "from" in cfg and layer[0] >= int(cfg["from"]):
+                return cfg["late"]
+            if "until" in cfg and layer[0] < int(cfg["until"]):
+                return cfg["early"]
+        return cfg.get(site, cfg.get("def", "f32"))
 
     def lin(x, w, b, site):
         return prod(x, w, sch(site)) + b
@@ -121,6 +131,7 @@ def make_encoder(cfg):
         hd = D // self.heads
         embeds = []
         for i in range(self.depth):
+            layer[0] = i
             pre = f"encoder.blocks.{i}."
             y = F.layer_norm(t, (D,), p(pre + "norm1.weight"), p(pre + "norm1.bias"), 1e-6)
             qkv = lin(y, p(pre + "attn.qkv.weight"), p(pre + "attn.qkv.bias"), "qkv").reshape(B, N, 3, self.heads, hd).permute(2, 0, 3, 1, 4)
