@@ -1,0 +1,144 @@
+"""GPU parity of the loss kernels and of the bf16 student's own-kernel autograd path against the ORACLE and the reference's golden vectors
+(round 2's tests of these kernels compared them with this repository's own op-by-op torch path only).
+
+  * msm_loss_kernel / cam_target_kernel            vs tests/golden/misc.npz {refine_out, camloss_out} (reference: utils/seg_helper.py:553-602)
+  * seg_loss_fwd/bwd + lattice (dense energy)      vs oracle/torch_oracle.py {seg_loss, energy_loss_and_grad} on the same inputs
+                                                   (the oracle is pinned to misc.npz / bilateral.npz by tests/test_oracle_golden.py)
+  * the whole bf16 training step at ViT-B          vs oracle/cpu_step.py (fp32 CPU) on identical weights and inputs: five losses and the
+                                                   gradients of qkv / fc1 / conv6 / classifier weights
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def test_hip_cam_loss_kernels_vs_reference_golden(golden):
+    """cam_loss of the reference (seg_helper.py:593-602) = multilabel soft margin of relu(cam) against the bilinearly resized
+    seg_refine_by_label output.  (a) msm_loss_kernel on the reference's own resized targets reproduces `camloss_out` to 1e-6 relative;
+    (b) cam_target_kernel, fed the golden seg as a single full-size 'scale' (+ a zero flipped half), reproduces the resized `refine_out`;
+    (c) both kernels chained reproduce `camloss_out`."""
+    from cosa_amd.utils import seg_helper
+    g = golden("misc")
+    dev = "cuda"
+    cam = torch.from_numpy(g["camloss_cam"]).to(dev)
+    ref_ps = torch.from_numpy(g["refine_out"]).to(dev)
+    labels = torch.from_numpy(g["refine_labels"]).to(dev)
+    tgt = F.interpolate(ref_ps[:, 1:], size=cam.shape[-2:], mode="bilinear", align_corners=False).contiguous()
+    loss = seg_helper.cam_loss_from_targets(cam, tgt)                       # the fused HIP value + gradient kernel (fp32 CUDA logits)
+    assert float(loss) == pytest.approx(float(g["camloss_out"]), rel=1e-6)
+    # gradient of the kernel against autograd of the torch expression
+    cam_t = cam.clone().requires_grad_(True)
+    cam_k = cam.clone().requires_grad_(True)
+    F.multilabel_soft_margin_loss(F.relu(cam_t).permute(0, 2, 3, 1).reshape(-1, cam.shape[1]), tgt.permute(0, 2, 3, 1).reshape(-1, cam.shape[1])).backward()
+    seg_helper.cam_loss_from_targets(cam_k, tgt).backward()
+    assert torch.allclose(cam_k.grad, cam_t.grad, rtol=1e-5, atol=1e-8)
+    seg = torch.from_numpy(g["refine_seg"]).to(dev)
+    B, K, S, _ = seg.shape
+    scales = [torch.cat([seg, torch.zeros_like(seg)], 0).contiguous()]     # full = seg + flip(0) = seg
+    out = seg_helper.cam_loss_targets(scales, labels, S, tuple(cam.shape[-2:]), 0.01)
+    assert torch.allclose(out, tgt, atol=2e-6, rtol=1e-5), (out - tgt).abs().max().item()
+    assert float(seg_helper.cam_loss_from_targets(cam, out)) == pytest.approx(float(g["camloss_out"]), rel=1e-5)
+    # the public functions on the device (torch expressions) against the same vectors
+    assert torch.allclose(seg_helper.seg_refine_by_label(seg, labels, 0.01), ref_ps, rtol=1e-4, atol=2e-6)     # (torch's device softmax at T = 0.01)
+    assert float(seg_helper.cam_loss(cam, ref_ps)) == pytest.approx(float(g["camloss_out"]), rel=1e-5)
+    pred, mask = torch.from_numpy(g["segloss_pred"]).to(dev), torch.from_numpy(g["segloss_mask"]).to(dev)
+    assert float(seg_helper.seg_loss(pred, mask)) == pytest.approx(float(g["segloss_out"]), rel=1e-5)
+
+
+@pytest.mark.parametrize("K,hs,S,boxes", [(21, 12, 192, [[0, 192, 0, 192], [10, 150, 20, 190]]), (6, 4, 64, [[0, 64, 0, 64], [3, 60, 0, 50]])])
+def test_hip_seg_and_energy_loss_vs_oracle(K, hs, S, boxes):
+    """seg_loss x 2 (main + aux labels, blended 0.5 / 0.5, main.py:200-203) and the dense-energy regulariser (seg_helper.py:199-230,
+    864-903) from the fused HIP kernels against oracle/torch_oracle.py on the same inputs: values 1e-4 / 1e-3 relative, the gradient
+    with respect to the low-resolution logits 2e-3 of its maximum (the regulariser's gradient is the reference's hand-written one)."""
+    from cosa_amd.utils import seg_helper
+    from oracle import torch_oracle as to
+    torch.manual_seed(K)
+    rng = np.random.default_rng(K)
+    B = len(boxes)
+    seg_lr = (torch.randn(B, K, hs, hs) * 2)
+    vals = [0, 1, K - 1, 255] if K < 8 else [0, 1, 5, K - 1, 255]
+    mk = lambda: torch.from_numpy(rng.choice(vals, size=(B, S, S)).astype(np.float32))
+    mA, mB = mk(), mk()
+    simg = torch.randn(B, 3, S, S)
+    box = torch.tensor(boxes, dtype=torch.int16)
+    w_seg, w_reg = 0.1, 0.05
+    # oracle (CPU, fp32)
+    lr_o = seg_lr.clone().requires_grad_(True)
+    up = F.interpolate(lr_o, size=(S, S), mode="bilinear", align_corners=False)
+    l_seg = 0.5 * to.seg_loss(up, mA) + 0.5 * to.seg_loss(up, mB)
+    l_reg, g_up = to.energy_loss_and_grad(simg, up.detach(), mA.to(torch.uint8).unsqueeze(1), box.numpy())
+    (w_seg * l_seg).backward(retain_graph=True)
+    up.backward(w_reg * g_up)
+    # HIP
+    lr_g = seg_lr.cuda().requires_grad_(True)
+    layer = seg_helper.DenseEnergyLoss(weight=1e-7, sigma_rgb=15, sigma_xy=100, scale_factor=0.5)
+    f_seg, f_reg = seg_helper.fused_seg_and_energy_loss(lr_g, mA.cuda(), mB.cuda(), simg.cuda(), box, layer)
+    (w_seg * f_seg + w_reg * f_reg).sum().backward()
+    assert float(f_seg) == pytest.approx(float(l_seg), rel=1e-4)
+    assert float(f_reg) == pytest.approx(float(l_reg), rel=1e-3, abs=1e-12)
+    err = (lr_g.grad.cpu() - lr_o.grad).abs().max().item()
+    assert err <= 2e-3 * lr_o.grad.abs().max().item(), (err, lr_o.grad.abs().max().item())
+
+
+def _cos(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a @ b) / (a.norm() * b.norm() + 1e-300))
+
+
+def test_bf16_student_step_vs_cpu_oracle_vitb():
+    """The student's forward / backward through this repository's own kernels (bf16 GEMMs with fused epilogues, fused attention forward /
+    backward, add+LayerNorm, dilated convs, narrow heads, fused losses) at ViT-B against oracle/cpu_step.py (fp32 CPU) on identical
+    weights and inputs, S = 224, b = 2, all five losses live.  The teacher runs in the parity-grade mode (fp16c8), so both sides see the
+    same pseudo labels; what is compared is the student: losses within 3e-3 relative (measured: <= 9e-4), weight gradients by cosine:
+    >= 0.99 for decoder convs / CAM heads, >= 0.98 for encoder weights (bf16 operands and a bf16 stream: 8 significant bits per value)."""
+    from cosa_amd.train_step import CoSATrainer, default_args, synthetic_batch
+    from oracle.cpu_step import CpuStep
+    dev = torch.device("cuda", 0)
+    S, b, C = 224, 2, 20
+    args = default_args("VOC12", crop_size=S, teacher_precision="fp16c8", teacher_graph=False, teacher_async=False)
+    tr = CoSATrainer(args, dev, seed=3)
+    sd = {k: v.detach().cpu().clone() for k, v in tr.student.state_dict().items()}
+    wimg, simg, lab, box = synthetic_batch(b, S, C, dev, seed=5)
+    n_iter = args.warmup_iters + 1
+    loss, logs = tr.forward_losses(wimg, simg, lab, box, n_iter)
+    torch.set_num_threads(max(1, min(16, torch.get_num_threads())))
+    cpu = CpuStep(sd, num_classes=21, aux_layer=-4)
+    closs, clogs = cpu.losses(wimg.cpu(), simg.cpu(), lab.cpu(), box.numpy(), n_iter)
+    agree = (logs["mask"].cpu().numpy() == clogs["mask"].numpy()).mean()
+    assert agree >= 0.999, f"label agreement {agree}"
+    lines = []
+    for k in ("cls_loss", "cls_aux_loss", "seg_loss", "cam_loss", "reg_loss", "overall_loss"):
+        a, c = float(logs[k]), float(clogs[k])
+        lines.append(f"{k}: hip {a:.6f} oracle {c:.6f}")
+        assert a == pytest.approx(c, rel=3e-3, abs=1e-4), (k, a, c)
+    tr.optimizer.zero_grad(set_to_none=True)
+    loss.backward()
+    cpu.opt.zero_grad(set_to_none=True)
+    closs.backward()
+    named = dict(tr.student.named_parameters())
+    checks = []
+    for name in ("encoder.blocks.0.attn.qkv.weight", "encoder.blocks.6.attn.qkv.weight", "encoder.blocks.11.attn.qkv.weight",
+                 "encoder.blocks.0.attn.proj.weight", "encoder.blocks.5.mlp.fc1.weight", "encoder.blocks.0.mlp.fc2.weight",
+                 "encoder.blocks.11.mlp.fc2.weight", "encoder.patch_embed.proj.weight", "decoder.conv6.weight", "decoder.conv7.weight",
+                 "decoder.conv8.weight", "classifier.weight", "aux_classifier.weight", "encoder.blocks.3.norm1.weight"):
+        gg, gc = named[name].grad.float().cpu(), cpu.student.p(name).grad
+        parts = [("", gg, gc)]
+        if name.endswith("qkv.weight"):          # query / key / value rows separately: at near-uniform attention (random initialisation) the
+            parts += [(":" + n, gg[i * 768:(i + 1) * 768], gc[i * 768:(i + 1) * 768]) for i, n in enumerate("qkv")]      # q / k gradients are tiny
+        for tag, a, c in parts:
+            cs, ratio = _cos(a, c), float(a.norm() / (c.norm() + 1e-30))
+            lines.append(f"grad {name}{tag}: cosine {cs:.5f} norm ratio {ratio:.4f} (oracle norm {float(c.norm()):.3e})")
+            checks.append((name + tag, cs, ratio))
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(root, "gpurun_out", "r03_student_vs_oracle.txt"), "w") as f:
+        f.write("\n".join(lines) + "\n")
+    for name, cs, ratio in checks:
+        # measured (profiles/r03_student_vs_oracle.txt): decoder / heads >= 0.999, encoder blocks 0.9856 (block 0) ... 0.9994 (block 11): the
+        # bf16 residual stream and 16-bit saved activations add ~1.5 % per layer to the back-propagated error at random initialisation
+        bar = 0.97 if name.endswith((":q", ":k")) else (0.98 if "encoder.blocks" in name or "patch_embed" in name else 0.99)
+        assert cs >= bar and 0.9 <= ratio <= 1.1, (name, cs, ratio)

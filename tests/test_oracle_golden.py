@@ -134,3 +134,19 @@ def test_gmm_empty_component_raises():
     from oracle import gmm_oracle
     with pytest.raises(ValueError):
         gmm_oracle.rungmm(np.full((4, 8), 0.5), 3)                 # identical samples: everything lands in one component
+
+
+def test_product_poly_warmup_adamw_lr_vs_reference(golden):
+    """the PRODUCT's PolyWarmupAdamW (cosa_amd/utils/torch_helper.py; utils/torch_helper.py:261-293 of the reference) steps to the learning
+    rates the reference's optimizer produced at the same global steps (tests/golden/misc.npz:lr_values), to the last digit"""
+    from cosa_amd.utils import torch_helper as th
+    g = golden("misc")
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = th.PolyWarmupAdamW([{"params": [p], "lr": 6e-5}], lr=6e-5, weight_decay=1e-2, betas=(0.9, 0.999), warmup_iter=1500,
+                             max_iter=32000, warmup_ratio=1e-6, power=0.9, min_mult=0.0)
+    for st, lr in zip(g["lr_steps"], g["lr_values"]):
+        opt.global_step = int(st)
+        p.grad = torch.zeros(1)
+        opt.step()
+        assert opt.param_groups[0]["lr"] == lr, (st, opt.param_groups[0]["lr"], lr)
+        assert th.poly_warmup_lr_mult(int(st), 1500, 32000, 1e-6, 0.9, 0.0) * 6e-5 == lr
