@@ -175,6 +175,31 @@ def build_val_dataset(args):
     raise NotImplementedError
 
 
+def build_test_dataset(args):
+    """dataloaders/__init__.py:34-58: what `finaleval` evaluates on -- VOC12 `val`, COCO the FULL `val` split (build_val_dataset takes
+    `val_part` unless --valfull)"""
+    name_dir = getattr(args, "name_list_dir", None)
+    if args.dataset == 'VOC12':
+        return VOC12SegDataset(root_dir=args.voc12_root, name_list_dir=name_dir or './dataloaders/voc/', split='val', stage='val', aug=False,
+                               ignore_index=args.ignore_index, num_classes=args.num_classes)
+    if args.dataset == 'COCO':
+        return COCOSegDataset(root_dir=args.coco_root, name_list_dir=name_dir or './dataloaders/coco/', split='val', stage='val', aug=False,
+                              ignore_index=args.ignore_index, num_classes=args.num_classes)
+    raise NotImplementedError
+
+
+def _eval_loader(dataset, num_workers):
+    sampler = torch.utils.data.distributed.DistributedSampler(dataset, shuffle=False, drop_last=True) \
+        if torch.distributed.is_initialized() else None
+    return DataLoader(dataset=dataset, batch_size=1, shuffle=False, num_workers=num_workers, pin_memory=False, sampler=sampler,
+                      drop_last=False)
+
+
+def build_test_loader(args, num_workers=1):
+    """the `is_train=False` branch of dataloaders/__init__.py:114-124"""
+    return _eval_loader(build_test_dataset(args), num_workers)
+
+
 def build_val_loader(args, num_workers=1):
     """the validation half of dataloaders/__init__.py:104-113: batch 1, DistributedSampler(shuffle=False, drop_last=True)"""
     dataset = build_val_dataset(args)

@@ -9,8 +9,11 @@ Same call surface and return values as the reference's `evaluate`.  What changes
   ranks with one all-reduce, instead of storing every map in host lists and shipping them to rank 0 through temp files (:203-216);
 * per-image average precision is computed on the device and accumulated without a host sync.
 
-Not built (outside SURVEY section 8's hot path and its "next" row f-1): dense-CRF post-processing (`getcrf`), image/CAM dumps
-(`save_result`, `save_rawcam`) and the non-default `threshold_filters` sweep; asking for them raises NotImplementedError.
+`threshold_filters` (evaluation_engine.py:43-50,132-152,252-262): for every threshold t the pseudo-label maps cam2mask(valid CAM,
+high = 1 - t, low = t) of the main and the auxiliary CAMs at the ground truth's resolution, scored with `pseudo_scores` (pixels labelled
+255 are dropped) into rows `cam_<t>` / `camaux_<t>` of the table.
+
+Not built: image / CAM dumps (`save_result`, `save_rawcam`); asking for them raises NotImplementedError.
 """
 import torch
 import torch.distributed as dist
@@ -53,8 +56,9 @@ def evaluate(model, data_loader, args, df=None, save_result=False, save_rawcam=F
              s_or_t='t', get_camiou=False, isfinal=False, class_list=None, use_graph=True, eval_group=4):
     if save_result or save_rawcam:
         raise NotImplementedError("evaluate: save_result / save_rawcam (image dumps) are not part of the device path")
-    if getcrf or threshold_filters:
-        raise NotImplementedError("evaluate: dense-CRF (getcrf) and threshold_filters are not built (SURVEY f-4)")
+    if getcrf:
+        raise NotImplementedError("evaluate: dense-CRF (getcrf) is not built (SURVEY f-4)")
+    threshold_filters = list(threshold_filters) if threshold_filters else []
     assert s_or_t in ['s', 't']
     distributed = dist.is_available() and dist.is_initialized()
     rank = dist.get_rank() if distributed else 0
@@ -63,6 +67,9 @@ def evaluate(model, data_loader, args, df=None, save_result=False, save_rawcam=F
         raise RuntimeError("evaluate runs on the GPU (HIP kernels); no CPU path")
     nc = args.num_classes
     meters = {k: evaluation.ConfusionMeter(nc, device) for k in ("cam", "cam_aux", "seg_ps", "seg_vd")}
+    for thre in threshold_filters:                    # pseudo_scores' relabelling: a prediction of 255 drops the pixel (utils/evaluation.py:43-46)
+        meters[f"cam_{thre}"] = evaluation.ConfusionMeter(nc, device, pseudo=True)
+        meters[f"camaux_{thre}"] = evaluation.ConfusionMeter(nc, device, pseudo=True)
     ap_sum = torch.zeros(2, device=device, dtype=torch.float64)          # sums of per-batch mean AP (cls, cls_aux) ...
     ap_cnt = 0                                                           # ... over the batches (AverageMeter semantics, :86-92)
     was_training = model.training
@@ -98,6 +105,16 @@ def evaluate(model, data_loader, args, df=None, save_result=False, save_rawcam=F
             meters["cam_aux"].update(gt, cam_aux_label)
             meters["seg_ps"].update(gt, pred_ps)
             meters["seg_vd"].update(gt, pred_vd)
+            if threshold_filters:
+                # evaluation_engine.py:132-152: the CAMs resized to the ground truth's size, validated, then cam2mask with the box
+                # [0, -1, 0, -1] (Python slice semantics: the last row and column stay `ignore`, as in the reference) and no refine model
+                shape_only = torch.zeros(1, device=device).expand(1, 3, *size)
+                for thre in threshold_filters:
+                    for key, c in ((f"cam_{thre}", cams), (f"camaux_{thre}", cams_aux)):
+                        rc = F.interpolate(c[i:i + 1], size=size, mode='bilinear', align_corners=False)
+                        m = seg_helper.cam2mask(images=shape_only, img_boxes=[[0, -1, 0, -1]], cams=seg_helper.cam_validation(rc, cls_label),
+                                                cls_labels=cls_label, threshold_high=1 - thre, threshold_low=thre)
+                        meters[key].update(gt, m.to(torch.uint8))
 
     with torch.no_grad():
         group = []
@@ -132,6 +149,10 @@ def evaluate(model, data_loader, args, df=None, save_result=False, save_rawcam=F
     metrics, names = [cam_score, cam_aux_score, seg_vd_score], ["CAM", "aux_CAM", "Seg_vd"]
     if isfinal:
         metrics, names = [seg_vd_score], ["Seg_vd"]
+    if threshold_filters:                                # evaluation_engine.py:252-262: inserted after the first three rows
+        tk = [f"cam_{t}" for t in threshold_filters] + [f"camaux_{t}" for t in threshold_filters]
+        metrics = metrics[:3] + [meters[k].scores() for k in tk] + metrics[3:]
+        names = names[:3] + tk + names[3:]
     cls_aps = [float(v) / max(ap_cnt, 1) for v in ap_sum.tolist()]
     if class_list is None:
         class_list = [str(i) for i in range(nc)]
@@ -142,6 +163,7 @@ def evaluate(model, data_loader, args, df=None, save_result=False, save_rawcam=F
     df['mIoU'].extend(mioulist)
     df['Metrics'].extend(names)
     df['ST'].extend([s_or_t] * len(names))
+    # (as the reference, evaluation_engine.py:289: the LAST row -- with threshold_filters that is the last `camaux_<t>` row, not Seg_vd)
     seg_vd_miou, cam_miou = mioulist[-1], mioulist[0]
     if get_camiou:
         return tab_results, seg_vd_miou, cam_miou, df, cls_aps

@@ -20,7 +20,7 @@ import torch
 import torch.distributed as dist
 
 from . import args as cosa_args
-from .dataloaders import build_train_loader, build_val_loader
+from .dataloaders import build_test_loader, build_train_loader, build_val_loader
 from .evaluation_engine import evaluate
 from .models import build_model
 from .train_step import CoSATrainer, default_args
@@ -55,7 +55,27 @@ def _trainer_args(args):
     return default_args(args.dataset, **{k: v for k, v in vars(args).items() if k != "dataset"})
 
 
+def check_supported(args):
+    """Flags this build parses but does not honour must not be accepted silently (the reference dispatches on them, main.py:216-224,338):
+    a run that asks for another objective or for dumps fails here instead of training / evaluating something else."""
+    if args.camloss_version != 'v1':
+        raise NotImplementedError(f"--camloss_version {args.camloss_version}: only cam_loss v1 is built (the reference dispatches "
+                                  f"cam_lossv2 / cam_lossv3_wrap with --segconf_thre, main.py:216-224)")
+    if args.turnon_rawcam:
+        raise NotImplementedError("--turnon_rawcam: raw-CAM dumps (evaluate(save_rawcam=True)) are not part of the device evaluation path")
+    if args.model != 'vit' or args.decoder != 'LargeFOV':
+        raise NotImplementedError("only --model vit --decoder LargeFOV (the run scripts' configuration) is built")
+    notes = []
+    if not args.find_unused:
+        notes.append("--find_unused false: no effect (DDP runs without find_unused_parameters; the unused ImageNet head is frozen)")
+    if args.segconf_thre != 0.25:
+        notes.append("--segconf_thre: only read by cam_loss v3, which is not built")
+    for n in notes:
+        print("note:", n, flush=True)
+
+
 def main(args):
+    check_supported(args)
     output_dir = Path(args.output_dir) if args.output_dir else Path(args.work_dir) / args.name
     output_dir.mkdir(parents=True, exist_ok=True)
     args.output_dir = output_dir
@@ -117,12 +137,14 @@ def main(args):
                     "cls_aux_loss: %.4f, cls_aux_acc: %.3f, seg_loss: %.4f, cam_loss: %.4f, reg_loss: %.4f ..."
                     % ((n_iter + 1, delta, str(eta).split('.')[0], itertime, trainer.optimizer.param_groups[0]['lr']) + tuple(vals)))
         if (n_iter + 1) % args.eval_iters == 0:                                   # main.py:313-383
-            res_o = evaluate(trainer.student, val_loader, args, df=df, epoch=n_iter + 1, s_or_t='s', get_camiou=True)
+            res_o = evaluate(trainer.student, val_loader, args, df=df, epoch=n_iter + 1, s_or_t='s', get_camiou=True,
+                             threshold_filters=args.eval_threshold_filters)
             if is_main:
                 tab, segvd, camiou, df, aps = res_o
                 log(f'ON Model Classification: cls:{aps[0]}, clsaux: {aps[1]}')
                 log(tab)
-            res_a = evaluate(trainer.model_AN, val_loader, args, df=df, epoch=n_iter + 1, s_or_t='t', get_camiou=True)
+            res_a = evaluate(trainer.model_AN, val_loader, args, df=df, epoch=n_iter + 1, s_or_t='t', get_camiou=True,
+                             threshold_filters=args.eval_threshold_filters)
             if is_main:
                 tab_a, segvd_a, camiou_a, df, aps_a = res_a
                 log(f'AN: cls:{aps_a[0]}, clsaux: {aps_a[1]}')
@@ -165,7 +187,7 @@ def finaleval(args):
     model = build_model(_trainer_args(args))
     torch_helper.load_best(model, args.bestseg_path, strict=True)
     model = model.to(device)
-    res = evaluate(model, build_val_loader(args), args, df=None, epoch='best1', isfinal=True)
+    res = evaluate(model, build_test_loader(args), args, df=None, epoch='best1', isfinal=True)      # main.py:414: build_dataloader(is_train=False)
     if getattr(args, "rank", 0) == 0:
         print('Final Model Result:\n' + res[0], flush=True)
         with (output_dir / "log_val.txt").open("a") as f:

@@ -489,6 +489,13 @@ def ensure_shadows(module, dtype=torch.bfloat16):
         return ss
     if ss is None or ss.dtype != dtype or any(a is not b for a, b in zip(ss.params, module.parameters())) \
             or (ss.params and ss.params[0].device != ss.shadows[0].device):
+        if ss is not None and not module.__dict__.get("_cosa_shadow_auto", True):
+            # a trainer has baked the addresses / dtype of the existing shadows into its fused optimizer records and its captured teacher
+            # graph (CoSATrainer): replacing the set would leave both writing to and reading from freed memory, and the new shadows would
+            # never be refreshed
+            raise RuntimeError("ensure_shadows: this module's 16-bit shadows are owned by a CoSATrainer (fused AdamW + EMA step, captured "
+                               "teacher graph); changing its compute dtype / precision or its parameters after the trainer was built is "
+                               "not supported -- build a new trainer, or evaluate a copy of the network")
         ss = ShadowSet(module, dtype)
         module.__dict__["_cosa_shadowset"] = ss
         return ss

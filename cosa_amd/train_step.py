@@ -138,6 +138,7 @@ class CoSATrainer:
         self._graph = None
         self._loss_weights = {}
         self._graph_calls = 0
+        self._cam_buffers = {}               # this trainer's CAM buffers of the teacher passes (seg_helper.multi_scale_camseg, `_buffers`)
         self.teacher_async = bool(getattr(args, "teacher_async", True)) and self.use_graph
         self._side = None
         self._teacher_pending = False
@@ -154,7 +155,7 @@ class CoSATrainer:
             for st in sts:
                 st.reset()
             out = seg_helper.multi_scale_camseg(self.model_AN, wimg, args.pseudo_scales, _active_labels=act,
-                                                _seg_scales=self.fused_losses)
+                                                _seg_scales=self.fused_losses, _buffers=self._cam_buffers)
             for st in sts:
                 st.begin_eager()
             return out
@@ -168,7 +169,7 @@ class CoSATrainer:
                     st.reset()
                 self._s_out = seg_helper.multi_scale_camseg(self.model_AN, self._s_wimg, args.pseudo_scales,
                                                             _active_labels=None if args.use_cammix else self._s_lab,
-                                                            _seg_scales=self.fused_losses)
+                                                            _seg_scales=self.fused_losses, _buffers=self._cam_buffers)
             self._graph = g
             self._g_stamps = [(st.n, list(st.flops)) for st in sts]
         if self.teacher_async:

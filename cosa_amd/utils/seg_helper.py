@@ -35,19 +35,17 @@ def _flip_merge_upsample(src, dst, B, S, mode, accumulate, active=None, prev_act
                                                    _C.ptr(active), _C.stream_ptr()), "cosa_cam_flip_merge_upsample")
 
 
-# CAM buffers of the training loop's teacher passes, kept from step to step: a plane that is absent from the image now and was absent
+# CAM buffers of a training loop's teacher passes, kept from step to step: a plane that is absent from the image now and was absent
 # last time is already zero, so only the planes that were live last time are cleared (80 COCO planes per image, ~3 live: 1 GB of zero
-# stores per call otherwise).  Results returned from these buffers are valid until the next call with the same shapes.
-_cam_buffers = {}
-
-
-def _persistent_cams(b, C, h, w, device):
+# stores per call otherwise).  The buffers and the `prev` map belong to the CALLER (CoSATrainer passes its own dict as `_buffers`):
+# nothing is shared between trainers or with other callers in the process.
+def _persistent_cams(store, b, C, h, w, device):
     key = (str(device), b, C, h, w)
-    ent = _cam_buffers.get(key)
+    ent = store.get(key)
     if ent is None:
-        ent = _cam_buffers[key] = {"cam": torch.zeros((b, C, h, w), device=device, dtype=torch.float32),
-                                   "aux": torch.zeros((b, C, h, w), device=device, dtype=torch.float32),
-                                   "prev": torch.zeros((b, C), device=device, dtype=torch.float32)}
+        ent = store[key] = {"cam": torch.zeros((b, C, h, w), device=device, dtype=torch.float32),
+                            "aux": torch.zeros((b, C, h, w), device=device, dtype=torch.float32),
+                            "prev": torch.zeros((b, C), device=device, dtype=torch.float32)}
     return ent
 
 
@@ -59,7 +57,7 @@ def cam_minmax_norm_(cam, active=None):
     return cam
 
 
-def multi_scale_camseg(model, imgs, scales, _active_labels=None, _seg_scales=False):
+def multi_scale_camseg(model, imgs, scales, _active_labels=None, _seg_scales=False, _buffers=None):
     """Teacher forward over scales x {orig, flip}; returns (cam, cam_aux, seg) at input size.
 
     utils/seg_helper.py:232-275.  Per scale one fused kernel does bilinear-up + un-flip + max/sum
@@ -70,6 +68,9 @@ def multi_scale_camseg(model, imgs, scales, _active_labels=None, _seg_scales=Fal
     `_seg_scales=True` returns the per-scale low-res seg outputs (a list of [2b,K,h_s,w_s]) in place of the summed
     full-resolution seg: the only consumer in the loop (cam_loss's targets) reads 4 pixels per 16x16 block of it
     (see cam_loss_targets), so the [b,K,S,S] tensor need not exist.
+    `_buffers` (a dict owned by the caller, with `_active_labels` only): the returned cam / cam_aux then live in buffers kept in that dict
+    from call to call (planes absent now and last time are not re-zeroed) -- they are VALID ONLY UNTIL THE NEXT CALL with the same dict
+    and shapes, and must not be written in place by the caller.  Without it every call returns fresh tensors.
     """
     b, c, h, w = imgs.shape
     assert 1.0 in scales, 'scale 1.0 must be in scales'
@@ -91,9 +92,13 @@ def multi_scale_camseg(model, imgs, scales, _active_labels=None, _seg_scales=Fal
             with nn_ops.shadows_fresh():
                 _, _, _, _seg, _cam, _cam_aux = multi[si] if multi is not None else model(inputs[si], cam_only=False)
             if cam is None:
-                if act is not None:
-                    keep = _persistent_cams(b, _cam.shape[1], h, w, imgs.device)
+                if act is not None and _buffers is not None:
+                    keep = _persistent_cams(_buffers, b, _cam.shape[1], h, w, imgs.device)
                     cam, cam_aux, prev = keep["cam"], keep["aux"], keep["prev"]
+                elif act is not None:
+                    cam = torch.zeros((b, _cam.shape[1], h, w), device=imgs.device, dtype=torch.float32)
+                    cam_aux = torch.zeros_like(cam)
+                    prev = torch.zeros((b, _cam.shape[1]), device=imgs.device, dtype=torch.float32)
                 else:
                     cam = torch.empty((b, _cam.shape[1], h, w), device=imgs.device, dtype=torch.float32)
                     cam_aux = torch.empty_like(cam)

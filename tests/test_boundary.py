@@ -140,3 +140,18 @@ def test_launcher_flag_table_matches_run_scripts():
         "work_dir", "dataset", "voc12_root", "max_iters", "aux_layer"}
     c, _ = parse(["EXP_COCO", "--work_dir", "/tmp/x", "--dataset", "COCO", "--coco_root", "/data/coco/"])
     assert (c.max_iters, c.aux_layer, c.num_classes, c.batch_size, c.high_thre, c.warmup_iters, c.eval_iters) == (60000, -3, 81, 4, 0.65, 10000, 6000)
+
+
+def test_launcher_rejects_flags_it_does_not_honour():
+    """--camloss_version v2 / v3 (and raw-CAM dumps) parse like in the reference but are not built: the launcher must fail
+    loudly (the reference dispatches cam_lossv2 / cam_lossv3_wrap or raises NotImplementedError, main.py:216-224), not train v1 silently"""
+    import pytest
+    from cosa_amd import args as cosa_args, main as launcher
+    ok, _ = cosa_args.parse(["exp"])
+    launcher.check_supported(ok)
+    for extra in (["--camloss_version", "v2"], ["--camloss_version", "v3", "--segconf_thre", "0.3"], ["--turnon_rawcam"]):
+        bad, _ = cosa_args.parse(["exp"] + extra)
+        with pytest.raises(NotImplementedError):
+            launcher.check_supported(bad)
+    thr, changed = cosa_args.parse(["exp", "--eval_threshold_filters", "0.11", "0.25"])
+    assert thr.eval_threshold_filters == [0.11, 0.25] and "eval_threshold_filters" in changed

@@ -114,9 +114,33 @@ def test_teacher_pass_flip_equivariance_coco_640():
     assert (mf == m.flip(-1)).float().mean().item() > 0.99
 
 
-def test_coco_training_step_runs_at_448_and_learns():
-    """one COCO-configured step sequence (81 classes, aux_layer -3, thresholds of args_coco.py) on the HIP path: finite losses, the
-    classification loss goes down over a few steps on a fixed batch"""
+@pytest.mark.parametrize("crop,batch", [(448, 16), (640, 8)])
+def test_coco_training_steps_at_the_configured_sizes(crop, batch):
+    """BASELINE configs[3] / configs[4] as whole steps at their per-rank sizes (COCO 81 classes: b = 16 x 448^2; b = 8 x 640^2 crops, global
+    batch 64 over 8 ranks): three steps incl. the graph-captured teacher pass -- every loss finite, label maps within {0..80, 255},
+    the update moves the student and (EMA) the teacher.  Size-independent properties; the bit-level checks of the label path at these
+    sizes are the cam2mask / flip-equivariance tests above."""
+    from cosa_amd.train_step import CoSATrainer, default_args, synthetic_batch
+    dev_ = torch.device("cuda", 0)
+    args = default_args("COCO", crop_size=crop, batch_size=batch)
+    tr = CoSATrainer(args, dev_, seed=2)
+    wimg, simg, lab, box = synthetic_batch(batch, crop, 80, dev_, seed=11, dataset="COCO")
+    w0 = tr.student.encoder.blocks[0].mlp.fc1.weight.detach().clone()
+    t0 = tr.model_AN.encoder.blocks[0].mlp.fc1.weight.detach().clone()
+    for it in range(3):
+        logs = tr.step(wimg, simg, lab, box, n_iter=args.warmup_iters + 1 + it)
+        for k in ("cls_loss", "cls_aux_loss", "seg_loss", "cam_loss", "reg_loss", "overall_loss"):
+            assert np.isfinite(float(logs[k])), (it, k, float(logs[k]))
+        assert logs["mask"].shape == (batch, crop, crop)
+        assert set(torch.unique(logs["mask"]).tolist()) <= set(range(81)) | {255}
+    assert not torch.equal(tr.student.encoder.blocks[0].mlp.fc1.weight, w0) and not torch.equal(tr.model_AN.encoder.blocks[0].mlp.fc1.weight, t0)
+    del tr
+    torch.cuda.empty_cache()
+
+
+def test_coco_training_step_learns_at_224():
+    """one COCO-configured step sequence (81 classes, aux_layer -3, thresholds of args_coco.py) at a small crop (224^2, b = 4) on the HIP
+    path: finite losses, the classification loss goes down over a few steps on a fixed batch"""
     from cosa_amd.train_step import CoSATrainer, default_args, synthetic_batch
     dev_ = torch.device("cuda", 0)
     args = default_args("COCO", crop_size=224, batch_size=4, lr=3e-4, teacher_graph=False)

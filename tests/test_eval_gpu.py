@@ -183,4 +183,52 @@ def test_evaluate_end_to_end_vs_oracle_composition(oracle_c):
     assert tab3 == tab and seg_miou3 == seg_miou and cam_miou3 == cam_miou and df3["mIoU"] == df["mIoU"]
     assert np.allclose(aps3, cls_aps, rtol=1e-12)
     with pytest.raises(NotImplementedError):
-        ee.evaluate(model, loader, args, epoch=1, getcrf=True)
+        ee.evaluate(model, loader, args, epoch=1, save_result=True)
+
+
+def test_evaluate_threshold_filters_sweep_vs_oracle(oracle_c):
+    """evaluation_engine.py:43-50,132-152,252-262: per threshold t the pseudo-label maps cam2mask(valid CAM, 1 - t, t) of both CAMs, scored
+    with pseudo_scores, as rows cam_<t> / camaux_<t> after the first three rows.  Square ground truths go through the fused HIP cam2mask
+    and are compared with the C oracle's cam2mask + pseudo confusion on the engine's own network outputs; a non-square item exercises the
+    per-image path."""
+    from cosa_amd import evaluation_engine as ee
+    from cosa_amd.models import build_model
+    from cosa_amd.train_step import default_args
+    from cosa_amd.utils import seg_helper
+    torch.manual_seed(1)
+    C, S = 4, 64
+    args = default_args("VOC12", crop_size=S, batch_size=1)
+    args.num_classes, args.bkg_thre = C + 1, 0.5
+    model = build_model(args).cuda().eval()
+    rng = np.random.default_rng(9)
+    loader = []
+    for _ in range(4):
+        img = torch.from_numpy(rng.standard_normal((1, 3, S, S)).astype(np.float32))
+        lab = torch.from_numpy(rng.integers(0, C + 1, (1, S, S)).astype(np.int64))
+        cls = torch.zeros(1, C)
+        cls[0, rng.choice(C, 2, replace=False)] = 1
+        loader.append(("img", img, lab, cls))
+    thr = [0.2, 0.35]
+    tab, seg_miou, cam_miou, df, _ = ee.evaluate(model, loader, args, epoch=3, s_or_t='t', get_camiou=True, threshold_filters=thr)
+    assert df["Metrics"] == ["CAM", "aux_CAM", "Seg_vd", "cam_0.2", "cam_0.35", "camaux_0.2", "camaux_0.35"]
+    assert seg_miou == df["mIoU"][-1]                                          # the reference returns the LAST row here (:289)
+    model.batch_invariant_heads = model.decoder.batch_invariant = True
+    hist = {k: np.zeros((C + 1, C + 1), np.int64) for k in df["Metrics"][3:]}
+    box = np.array([[0, S - 1, 0, S - 1]], np.int32)                           # [0, -1, 0, -1] as slice bounds
+    with torch.no_grad():
+        for _, img, lab, cls in loader:
+            x = torch.nn.functional.interpolate(img.cuda(), size=[S, S], mode="bilinear", align_corners=False)
+            cam, aux, _, _, _ = seg_helper.multi_scale_camsegv3(model, x, ee.EVAL_SCALES, getcls=True)
+            gt = lab[0].numpy().astype(np.uint8)
+            for t in thr:
+                for key, c in ((f"cam_{t}", cam), (f"camaux_{t}", aux)):
+                    m = oracle_c.cam2mask(None, box, c.cpu().numpy(), cls.numpy(), 1 - t, t, 2, par=None)
+                    hist[key] += oracle_c.confusion([gt], [m[0].astype(np.uint8)], C + 1, True)
+    model.batch_invariant_heads = model.decoder.batch_invariant = False
+    ref_miou = [np.round(np.array(list(oracle_c.scores_from_hist(hist[k])["iou"].values())) * 100, 2).mean() for k in df["Metrics"][3:]]
+    np.testing.assert_allclose(df["mIoU"][3:], ref_miou, atol=1e-9)
+    # a non-square ground truth: the per-image path (the reference's own loop on the device)
+    img = torch.from_numpy(rng.standard_normal((1, 3, 50, 70)).astype(np.float32))
+    lab = torch.from_numpy(rng.integers(0, C + 1, (1, 50, 70)).astype(np.int64))
+    tab2, _, _, df2, _ = ee.evaluate(model, [("img", img, lab, loader[0][3])], args, epoch=3, get_camiou=True, threshold_filters=[0.3], isfinal=True)
+    assert df2["Metrics"] == ["Seg_vd", "cam_0.3", "camaux_0.3"] and all(np.isfinite(df2["mIoU"]))

@@ -2,7 +2,7 @@
 # usage (GPU box): tools/par_pmc.sh <tag> [ENV=VALUE ...] -- rocprofv3 PMC passes (counters only + kernel trace) of tools/bench_par.py
 tag=$1; shift
 for kv in "$@"; do export "$kv"; done
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT (the repository root on the GPU box)}" || exit 1
 rm -rf gpurun_out/pmc_par_$tag; mkdir -p gpurun_out/pmc_par_$tag
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_INST_LDS" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum"; do
   d=gpurun_out/pmc_par_$tag/pass_$(echo $set | cut -d' ' -f1)

@@ -4,7 +4,7 @@
 # substring, divided by the number of `iterations` the tool reports (JSON key "iters", default 13 = 3 warm-up + 10 timed).
 tag=$1; tool=$2; sub=$3; shift; shift; shift
 for kv in "$@"; do export "$kv"; done
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT (the repository root on the GPU box)}" || exit 1
 rm -rf gpurun_out/pmc_$tag; mkdir -p gpurun_out/pmc_$tag
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "TCC_HIT_sum TCC_MISS_sum TCC_ATOMIC_sum SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"; do
   d=gpurun_out/pmc_$tag/pass_$(echo $set | cut -d' ' -f1)
