@@ -58,8 +58,9 @@ _SIGS = {
     "cosa_dense_energy_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                           c_int, c_float, c_float, c_void_p, c_size_t, c_void_p]),
     "cosa_dense_energy_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
-    "cosa_seg_loss_forward": (c_int, [c_void_p] * 10 + [c_int] * 5 + [c_void_p]),
-    "cosa_seg_loss_backward": (c_int, [c_void_p] * 9 + [c_int] * 5 + [c_void_p]),
+    "cosa_seg_loss_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "cosa_seg_loss_forward": (c_int, [c_void_p] * 10 + [c_int] * 5 + [c_void_p, c_size_t, c_void_p]),
+    "cosa_seg_loss_backward": (c_int, [c_void_p] * 9 + [c_int] * 5 + [c_void_p, c_size_t, c_void_p]),
     "cosa_cam_loss_targets": (c_int, [ctypes.POINTER(c_void_p), ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_int, c_void_p,
                               c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "cosa_optim_record_bytes": (c_size_t, []),
@@ -80,7 +81,8 @@ _SIGS = {
     "cosa_attn_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p,
                       c_size_t, c_void_p]),
     "cosa_gemm_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
-    "cosa_gemm_wgrad_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "cosa_gemm_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "cosa_gemm_wgrad_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "cosa_conv3x3_dilated_nhwc": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 10 + [c_void_p]),
     "cosa_head_gemm": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, ctypes.c_longlong, c_int, c_int, c_int, c_int,
                                c_int, c_void_p]),
@@ -90,7 +92,7 @@ _SIGS = {
     "cosa_head_gemm_dgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "cosa_head_gemm_wgrad_workspace": (c_size_t, [c_int, c_int]),
     "cosa_head_gemm_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
-    "cosa_conv3x3_dilated_wgrad": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 10 + [c_void_p]),
+    "cosa_conv3x3_dilated_wgrad": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 10 + [c_void_p, c_size_t, c_void_p]),
     "cosa_gemm_set_variant": (None, [c_int]),
     "cosa_gemm_set_grid_policy": (None, [c_int]),
     "cosa_gemm_set_grid_policy_f16": (None, [c_int]),

@@ -1369,14 +1369,21 @@ constexpr size_t kLdsBytesV3 = 2 * V3_STAGE;      // 131072 >= 256*272 epilogue 
 
 
 // =====================================================================================================
-// weight gradient  dW[N,K] += dY[M,N]^T X[M,K]   (autograd of nn.Linear; "TN" GEMM, contraction over tokens)
+// weight gradient  dW[N,K] = dY[M,N]^T X[M,K]   (autograd of nn.Linear; "TN" GEMM, contraction over tokens)
 // Both operands have the contraction index as their ROW, so the MFMA fragments (8 consecutive k per lane) are columns of
 // the row-major tiles.  The tiles are staged as they are (buffer_load ... lds, rows past M read as zero through the buffer
 // bounds check, K-offset in an SGPR so the loop has no address VALU) and the fragments are fetched with gfx950's
 // transposing LDS read ds_read_b64_tr_b16 (4 rows x 16 columns per 16-lane group, delivered column-major).  LDS image:
 // 256-byte rows with the 16-byte chunk index XOR-ed by ((row&3)<<2 | (row>>2)&3) -- conflict-free for these reads -- applied
-// on the source side of the DMA.  128 x 128 output tile, 4 waves (64 x 64 each), the token range is split across
-// workgroups (the output has at most 24 x 6 tiles) and the fp32 partial tiles are added with 256-byte-contiguous atomics.
+// on the source side of the DMA.
+// Round 3: 256 (features) x 128 (inputs) output tile per 512-thread workgroup (8 waves as 4 x 2, 64 x 64 each), one workgroup per CU,
+// THREE 48-KB stages of 64 tokens (two dY images of 128 features + one X image) in a ring: the DMA of stage s + 2 is issued at the start
+// of stage s and waited for with a counted vmcnt two stages later (one raw barrier per stage), so a stage's issue -> landed latency
+// (~1.2 us) is covered by two stages of MFMA work instead of none -- the round-2 kernel (128 x 128 tiles, two stages, vmcnt(0) per stage,
+// two workgroups per CU) spent ~1.7 us per stage of 0.25 us of MFMA work.  The token range is split across workgroups only as far as the
+// 256 CUs need it (54 / 18 / 72 / 72 tiles for qkv / proj / fc1 / fc2), and the splits meet WITHOUT atomics: every split writes its fp32
+// partial tile to its own slab of a workspace and wgrad_reduce_kernel adds the slabs in split order -- the same bits every run
+// (round 2 added the partial tiles with fp32 atomics: run-to-run differences in the last bits, ~1.3 TB/s of atomic traffic).
 // =====================================================================================================
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
@@ -1384,7 +1391,7 @@ typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 __device__ __forceinline__ int tr_sw(int r) { return ((r & 3) << 2) | ((r >> 2) & 3); }
 
 // CONV = true: weight gradient of the 3x3 dilated convolution on NHWC tokens (LargeFOV, models/decoder/conv_head.py:11-41):
-//   dW9[n][t*Cin + c] += sum_m dY[m][n] * X[src(m, t)][c]        (t = ky*3 + kx, src = the token shifted by the tap, zero outside)
+//   dW9[n][t*Cin + c] = sum_m dY[m][n] * X[src(m, t)][c]        (t = ky*3 + kx, src = the token shifted by the tap, zero outside)
 // i.e. the same TN GEMM over an implicit im2col matrix: a k-tile lies inside one tap (Cin % 128 == 0), its X rows are the token rows
 // shifted by (dy*w + dx) and rows that leave the image (or M) get an offset past num_records, which the DMA turns into zeros.
 // The (image, y, x) position of each staged row is carried from stage to stage (+64 tokens) with adds and compares only.
@@ -1394,43 +1401,41 @@ struct ConvGeom {
     int q64, r64;                // 64 = q64 * w + r64
 };
 
+constexpr int WG_IMG = 16384;                 // one [64 tokens][128 columns] bf16 image
+constexpr int WG_STAGE = 3 * WG_IMG;          // dY features [0,128) | dY features [128,256) | X
+constexpr int WG_LDS = 3 * WG_STAGE;          // 144 KB: three stages; the fp32 [256][128] epilogue tile (128 KB) reuses them
+
 template <bool CONV>
-__global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(const op16 *__restrict__ dY, const op16 *__restrict__ X,
-                                                           float *__restrict__ dW, float *__restrict__ db, int M, int N, int K,
+__global__ __launch_bounds__(512, 1) void gemm_wgrad_kernel(const op16 *__restrict__ dY, const op16 *__restrict__ X,
+                                                           float *__restrict__ out, float *__restrict__ dbp, int M, int N, int K,
                                                            int tiles_k, int stages_per_split, int nstages, int ntiles, int tiles_per_xcd,
-                                                           ConvGeom cg, int x_bytes)
+                                                           ConvGeom cg, int x_bytes, long long slab_elems, int direct_accumulate)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // 2 stages x (dY tile 16 KB + X tile 16 KB)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     // Workgroup -> (tile, split).  Workgroups that read the same operand slabs are the tiles of ONE split (the dY slab of an n-tile is
     // shared by its tiles_k k-tiles, the X slab of a k-tile by all n-tiles); ids are dealt round-robin to the 8 XCDs, so give every XCD a
-    // contiguous chunk of the n-major tile list (for each split) and its L2 serves the re-reads.  With tiles spread over the XCDs every
-    // slab was fetched by all eight L2s: ~0.9 GB of Infinity-Cache traffic per launch for 96 MB of operands, ~10 TB/s -- the bound.
+    // contiguous chunk of the n-major tile list (for each split) and its L2 serves the re-reads.
     int tile, split;
     {
         const int id = blockIdx.x, xcd = id & 7, j = id >> 3;
         split = j / tiles_per_xcd;
         tile = xcd * tiles_per_xcd + (j - split * tiles_per_xcd);
-        if (tiles_per_xcd < 0) {                      // A/B switch (COSA_WGRAD_OLDMAP): tiles round-robin over the XCDs, splits outermost
-            const int pt = -tiles_per_xcd * 8;        // padded tile count
-            split = id / pt;
-            tile = id - split * pt;
-        }
         if (tile >= ntiles) return;
     }
     const int tn = tile / tiles_k, tk = tile - tn * tiles_k;
-    const int n0 = tn * 128, k0 = tk * 128;
+    const int n0 = tn * 256, k0 = tk * 128;
     const int st0 = split * stages_per_split;
     int st1 = st0 + stages_per_split;
     st1 = st1 < nstages ? st1 : nstages;
     if (st0 >= st1) return;
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = wave >> 1, wc = wave & 1;          // wave tile: features [wr*64, +64) x inputs [wc*64, +64)
     __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc((void *)dY, 0, (int)((size_t)M * N * 2), 0x00020000);
     __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void *)X, 0, CONV ? x_bytes : (int)((size_t)M * K * 2), 0x00020000);
-    // per-lane source offsets of the 4 + 4 one-KiB pieces this wave stages per K-step (fixed for the whole kernel)
-    int voY[4], voX[4];
+    // per-lane source offsets of the 2 + 2 + 2 one-KiB pieces this wave stages per stage (fixed for the whole kernel)
+    int voY[2][2], voX[2];
     // CONV: position of the staged row (image, y, x) per piece, and the tap of this k-tile
-    int pb[4], py[4], px[4], ddy = 0, ddx = 0, cbase = 0;
+    int pb[2], py[2], px[2], ddy = 0, ddx = 0, cbase = 0;
     if (CONV) {
         const int tap = k0 / cg.cin;
         ddy = (tap / 3 - 1) * cg.dil;
@@ -1438,10 +1443,12 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(const op16 *__restri
         cbase = k0 - tap * cg.cin;
     }
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int q = wave * 4 + i;                  // piece: tile rows 4q .. 4q+3
+    for (int i = 0; i < 2; i++) {
+        const int q = wave * 2 + i;                  // piece: tile rows 4q .. 4q+3
         const int r = 4 * q + (lane >> 4), ch = (lane & 15) ^ tr_sw(r);
-        voY[i] = (r * N + n0 + ch * 8) * 2;
+#pragma unroll
+        for (int j = 0; j < 2; j++)                  // (a feature half past N: every load out of range -> zeros)
+            voY[j][i] = n0 + j * 128 < N ? (r * N + n0 + j * 128 + ch * 8) * 2 : 0x7ffffff0;
         if (CONV) {
             const int tok = st0 * 64 + r, hw = cg.h * cg.w;
             pb[i] = tok / hw;
@@ -1453,25 +1460,25 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(const op16 *__restri
             voX[i] = (r * K + k0 + ch * 8) * 2;
         }
     }
-    auto stage = [&](int st, unsigned char *buf) {
+    auto stage = [&](int st, unsigned char *buf) {     // stages are issued in ascending order: the CONV positions advance by 64 tokens per call
         const int soY = st * 64 * N * 2, soX = CONV ? 0 : st * 64 * K * 2;
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int q = wave * 4 + i;
+        for (int i = 0; i < 2; i++) {
+            const int q = wave * 2 + i;
             int vx = voX[i];
             if (CONV) {
                 const int r = 4 * q + (lane >> 4);
                 const int sy = py[i] + ddy, sx = px[i] + ddx;
                 const bool in = st * 64 + r < M && sy >= 0 && sy < cg.h && sx >= 0 && sx < cg.w;
                 vx = in ? vx + ((pb[i] * cg.img_rows + cg.row_off + sy * cg.w + sx) * cg.ldx) * 2 : 0x7ffffff0;
-                // advance this piece by 64 tokens for the next stage
                 px[i] += cg.r64;
                 py[i] += cg.q64;
                 if (px[i] >= cg.w) { px[i] -= cg.w; py[i]++; }
                 while (py[i] >= cg.h) { py[i] -= cg.h; pb[i]++; }
             }
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsY, (lds_void *)(buf + q * 1024), 16, voY[i], soY, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_void *)(buf + 16384 + q * 1024), 16, vx, soX, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsY, (lds_void *)(buf + q * 1024), 16, voY[0][i], soY, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsY, (lds_void *)(buf + WG_IMG + q * 1024), 16, voY[1][i], soY, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_void *)(buf + 2 * WG_IMG + q * 1024), 16, vx, soX, 0, 0);
         }
     };
     f32x4 acc[4][4];
@@ -1480,64 +1487,84 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(const op16 *__restri
 #pragma unroll
         for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // bias gradient db[n] = sum_m dY[m][n]: the dY^T fragments already hold 8 tokens of one feature per lane, so the workgroups
-    // of the first k-tile column (and their wc == 0 waves) add them up on the side (replaces a separate reduction kernel)
-    const bool do_bias = !CONV && db != nullptr && tk == 0 && wc == 0;
+    // of the first k-tile column (and their wc == 0 waves) add them up on the side
+    const bool do_bias = !CONV && dbp != nullptr && tk == 0 && wc == 0;
     float bsum[4] = {0.f, 0.f, 0.f, 0.f};
 
     // fragment addressing: lane (nn = l&15, g = l>>4) supplies row 8g+4h+q (q = nn>>2), columns 4p..4p+3 (p = nn&3)
     const int nn = lane & 15, g = lane >> 4, q = nn >> 2, p = nn & 3;
+    const int ns = st1 - st0;
     stage(st0, smem);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (int st = st0; st < st1; st++) {
-        const int par = (st - st0) & 1;
-        unsigned char *cur = smem + par * 32768;
-        if (st + 1 < st1) stage(st + 1, smem + (par ^ 1) * 32768);
-#pragma unroll
-        for (int ks = 0; ks < 2; ks++) {
-            op16x8 a[4], b[4];
+    if (ns > 1) stage(st0 + 1, smem + WG_STAGE);
+    for (int s = 0; s < ns; s++) {
+        // this wave's pieces of stage s have landed (6 DMA per stage: those of stage s + 1 may stay in flight) ...
+        if (s + 1 < ns) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // ... and so have everybody's; every wave is also done reading stage s - 1, whose buffer stage s + 2 reuses
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 2 < ns) stage(st0 + s + 2, smem + ((s + 2) % 3) * WG_STAGE);
+        // The fragment reads are inline asm: behind a pending LDS-DMA hipcc (ROCm 7.2) puts `s_waitcnt vmcnt(0)` in front of the
+        // ds_read_tr16_b64 BUILTIN (it cannot tell the read from the stage being filled; plain LDS loads do not get that wait), which
+        // would drain the two stages in flight every iteration.  The asm reads are ordered by hand: one lgkmcnt(0) per k-step, tied to
+        // the fragment registers so that no MFMA can be scheduled above it.
+        const unsigned cur = (unsigned)(s % 3) * WG_STAGE;
+        const unsigned curA = cur + (wr >> 1) * WG_IMG, curB = cur + 2 * WG_IMG;
+        op16x8 a[2][4], b[2][4];
+        auto read_frags = [&](int ks) {
 #pragma unroll
             for (int h = 0; h < 2; h++) {
                 const int r = ks * 32 + 8 * g + 4 * h + q;
                 const int sw = tr_sw(r);
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
-                    const int chA = wr * 8 + 2 * i + (p >> 1), chB = wc * 8 + 2 * i + (p >> 1);
-                    const s16x4 va = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(cur + r * 256 + ((chA ^ sw) << 4) + 8 * (p & 1)));
-                    const s16x4 vb = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(cur + 16384 + r * 256 + ((chB ^ sw) << 4) + 8 * (p & 1)));
-                    s16x4 *pa = reinterpret_cast<s16x4 *>(&a[i]);
-                    s16x4 *pb = reinterpret_cast<s16x4 *>(&b[i]);
-                    pa[h] = va;
-                    pb[h] = vb;
+                    const int chA = (wr & 1) * 8 + 2 * i + (p >> 1), chB = wc * 8 + 2 * i + (p >> 1);
+                    s16x4 va, vb;
+                    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(va) : "v"(curA + r * 256 + ((chA ^ sw) << 4) + 8 * (p & 1)));
+                    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(vb) : "v"(curB + r * 256 + ((chB ^ sw) << 4) + 8 * (p & 1)));
+                    reinterpret_cast<s16x4 *>(&a[ks][i])[h] = va;
+                    reinterpret_cast<s16x4 *>(&b[ks][i])[h] = vb;
                 }
             }
+        };
+        auto mma = [&](int ks) {
 #pragma unroll
             for (int i = 0; i < 4; i++)
 #pragma unroll
                 for (int j = 0; j < 4; j++)
-                    acc[i][j] = COSA_MFMA_16x16x32(a[i], b[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = COSA_MFMA_16x16x32(a[ks][i], b[ks][j], acc[i][j], 0, 0, 0);
             if (do_bias) {
 #pragma unroll
                 for (int i = 0; i < 4; i++)
 #pragma unroll
-                    for (int e = 0; e < 8; e++) bsum[i] += (float)a[i][e];
+                    for (int e = 0; e < 8; e++) bsum[i] += (float)a[ks][i][e];
             }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        };
+        // the second k-step's fragments are requested before the first one's MFMAs are issued (they land in their shadow)
+        read_frags(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[0][2]), "+v"(a[0][3]), "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[0][2]), "+v"(b[0][3]));
+        read_frags(1);
+        mma(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[1][0]), "+v"(a[1][1]), "+v"(a[1][2]), "+v"(a[1][3]), "+v"(b[1][0]), "+v"(b[1][1]), "+v"(b[1][2]), "+v"(b[1][3]));
+        mma(1);
     }
+    float *dst = out + (size_t)split * (size_t)slab_elems;
     if (do_bias) {
-        // lane (nn, g) holds the partial of feature wr*64 + 16i + nn over its token group g: fold the 4 groups, one atomic per feature
+        // lane (nn, g) holds the partial of feature wr*64 + 16i + nn over its token group g: fold the 4 groups, one store per feature
+        float *dbs = dbp + (size_t)split * N;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             float v = bsum[i];
             v += __shfl_xor(v, 16, 64);
             v += __shfl_xor(v, 32, 64);
-            if (g == 0) atomicAdd(&db[n0 + wr * 64 + 16 * i + nn], v);
+            const int n = n0 + wr * 64 + 16 * i + nn;
+            if (g == 0 && n < N) dbs[n] = direct_accumulate ? dbs[n] + v : v;
         }
     }
-    // acc[i][j][r]: n = wr*64 + 16i + 4g + r (row), k' = wc*64 + 16j + nn (col).  Stage the fp32 tile, then 256-B atomics.
-    float *Ct = reinterpret_cast<float *>(smem);          // [128][128] fp32 = 64 KB = both stages
+    // acc[i][j][r]: n = wr*64 + 16i + 4g + r (row), k' = wc*64 + 16j + nn (col).  Stage the fp32 tile, then whole 512-byte rows.
+    __syncthreads();                                      // (every wave is done with the last stage's fragments)
+    float *Ct = reinterpret_cast<float *>(smem);          // [256][128] fp32 = 128 KB
 #pragma unroll
     for (int i = 0; i < 4; i++)
 #pragma unroll
@@ -1545,9 +1572,32 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(const op16 *__restri
 #pragma unroll
             for (int r = 0; r < 4; r++) Ct[(wr * 64 + 16 * i + 4 * g + r) * 128 + wc * 64 + 16 * j + nn] = acc[i][j][r];
     __syncthreads();
-    for (int e = tid; e < 128 * 128; e += 256) {
-        const int row = e >> 7, col = e & 127;
-        atomicAdd(&dW[(size_t)(n0 + row) * K + k0 + col], Ct[e]);
+    for (int e = tid; e < 256 * 32; e += 512) {
+        const int row = e >> 5, c4 = e & 31;
+        if (n0 + row < N) {
+            f32x4 v = *reinterpret_cast<const f32x4 *>(Ct + row * 128 + 4 * c4);
+            float *d = dst + (size_t)(n0 + row) * K + k0 + 4 * c4;
+            if (direct_accumulate) v = v + *reinterpret_cast<const f32x4 *>(d);
+            *reinterpret_cast<f32x4 *>(d) = v;
+        }
+    }
+}
+
+// dW = (accumulate ? dW : 0) + slab_0 + slab_1 + ... in split order (and the same for the bias partials): fixed order, no atomics
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ part, int splits, long long elems, float *__restrict__ dW,
+                                                          const float *__restrict__ dbp, float *__restrict__ db, int N, int accumulate)
+{
+    const long long nv = elems >> 2;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < nv) {
+        f32x4 a = accumulate ? reinterpret_cast<const f32x4 *>(dW)[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < splits; s++) a = a + reinterpret_cast<const f32x4 *>(part + (size_t)s * elems)[i];
+        reinterpret_cast<f32x4 *>(dW)[i] = a;
+    } else if (db != nullptr && i - nv < (N >> 2)) {
+        const long long j = i - nv;
+        f32x4 a = accumulate ? reinterpret_cast<const f32x4 *>(db)[j] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < splits; s++) a = a + reinterpret_cast<const f32x4 *>(dbp + (size_t)s * N)[j];
+        reinterpret_cast<f32x4 *>(db)[j] = a;
     }
 }
 
@@ -2106,47 +2156,82 @@ extern "C" int cosa_layernorm(const float *x, const void *gamma, const void *bet
     return COSA_OK;
 }
 
+// split count of the weight-gradient launch for (M, N, K): one workgroup per CU, never a second, partly filled round; at most 16 slabs
+static int wgrad_splits(int M, int N, int K, int *per_out)
+{
+    const int tiles = ((N + 255) / 256) * (K / 128);
+    const int nstages = (M + 63) / 64;
+    int splits = tiles >= 256 ? 1 : 256 / tiles;
+    if (splits > 16) splits = 16;
+    if (splits > nstages) splits = nstages;
+    if (splits < 1) splits = 1;
+    const int per = (nstages + splits - 1) / splits;
+    splits = (nstages + per - 1) / per;
+    if (per_out) *per_out = per;
+    return splits;
+}
+
+#if !COSA_OP_F16
+extern "C" size_t cosa_gemm_wgrad_workspace_bytes(int M, int N, int K)
+{
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    const int splits = wgrad_splits(M, N, K, nullptr);
+    return splits > 1 ? align_up((size_t)splits * ((size_t)N * K + N) * sizeof(float), 256) : 256;
+}
+#endif
+
+template <bool CONV>
+static int launch_wgrad(const op16 *dY, const op16 *X, float *dW, float *db, int M, int N, int K, int zero_first, void *workspace,
+                        size_t workspace_bytes, hipStream_t st, ConvGeom cg, int x_bytes, const char *who)
+{
+    static bool attr_done = false;
+    if (!attr_done) {
+        COSA_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_wgrad_kernel<CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, WG_LDS));
+        attr_done = true;
+    }
+    int per = 0;
+    const int splits = wgrad_splits(M, N, K, &per);
+    const int tiles = ((N + 255) / 256) * (K / 128);
+    const int nstages = (M + 63) / 64;
+    const size_t elems = (size_t)N * K;
+    float *out = dW, *dbp = db;
+    if (splits > 1) {
+        const size_t need = (size_t)splits * (elems + N) * sizeof(float);
+        if (!workspace || workspace_bytes < need) {
+            set_error("%s: workspace too small (%zu < %zu): size it with cosa_gemm_wgrad_workspace_bytes", who, workspace_bytes, need);
+            return COSA_ENOMEM;
+        }
+        out = static_cast<float *>(workspace);
+        dbp = db ? out + (size_t)splits * elems : nullptr;
+    }
+    const int tiles_per_xcd = (tiles + 7) / 8;
+    hipLaunchKernelGGL(gemm_wgrad_kernel<CONV>, dim3(8 * tiles_per_xcd * splits), dim3(512), WG_LDS, st, dY, X, out, dbp, M, N, K, K / 128, per,
+                       nstages, tiles, tiles_per_xcd, cg, x_bytes, (long long)elems, (splits == 1 && !zero_first) ? 1 : 0);
+    COSA_LAUNCH_CHECK();
+    if (splits > 1) {
+        const long long nv = (long long)(elems >> 2) + (db ? (N >> 2) : 0);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, st, out, splits, (long long)elems, dW, dbp, db, N,
+                           zero_first ? 0 : 1);
+        COSA_LAUNCH_CHECK();
+    }
+    return COSA_OK;
+}
+
 extern "C" int cosa_gemm_wgrad_bf16(const void *dY, const void *X, float *dW, float *db, int M, int N, int K, int zero_first,
-                                    void *stream)
+                                    void *workspace, size_t workspace_bytes, void *stream)
 {
     COSA_REQUIRE(dY && X && dW && M > 0 && N > 0 && K > 0, "cosa_gemm_wgrad_bf16: bad arguments");
     COSA_REQUIRE(N % 128 == 0 && K % 128 == 0, "cosa_gemm_wgrad_bf16: N and K must be multiples of 128 (got %d, %d)", N, K);
     COSA_REQUIRE((size_t)M * N * 2 < 0x7fffffffull && (size_t)M * K * 2 < 0x7fffffffull, "cosa_gemm_wgrad_bf16: operand beyond 2 GiB");
-    hipStream_t st = as_stream(stream);
-    static bool attr_done = false;
-    if (!attr_done) {
-        COSA_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_wgrad_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
-        attr_done = true;
-    }
-    if (zero_first) {
-        COSA_HIP_CHECK(hipMemsetAsync(dW, 0, (size_t)N * K * sizeof(float), st));
-        if (db) COSA_HIP_CHECK(hipMemsetAsync(db, 0, (size_t)N * sizeof(float), st));
-    }
-    const int tiles = (N / 128) * (K / 128);
-    const int nstages = (M + 63) / 64;
-    // workgroups in flight: two fit a CU (64 KB LDS each) and the K loop is latency-bound, so fill all 512 slots -- but never a
-    // second, partly filled round.  Every split costs N*K*4 B of fp32 atomics (~1.3 TB/s), which is why the small proj output
-    // (36 tiles) stays at ~one workgroup per CU (measured: tools/bench_wgrad.py, 428 -> 351 us per layer).
-    static const char *env_t = getenv("COSA_WGRAD_TARGET");
-    const int target = env_t ? atoi(env_t) : (tiles >= 64 ? 512 : 288);
-    int splits = target / tiles;
-    if (splits * tiles < 288 && (splits + 1) * tiles <= 512) splits++;
-    if (splits < 1) splits = 1;
-    if (splits > nstages) splits = nstages;
-    const int per = (nstages + splits - 1) / splits;
-    splits = (nstages + per - 1) / per;
-    static const bool oldmap = getenv("COSA_WGRAD_OLDMAP") != nullptr;
-    const int tiles_per_xcd = oldmap ? -((tiles + 7) / 8) : (tiles + 7) / 8;
-    hipLaunchKernelGGL(gemm_wgrad_kernel<false>, dim3(8 * ((tiles + 7) / 8) * splits), dim3(256), 65536, st, static_cast<const op16 *>(dY),
-                       static_cast<const op16 *>(X), dW, db, M, N, K, K / 128, per, nstages, tiles, tiles_per_xcd, ConvGeom{}, 0);
-    COSA_LAUNCH_CHECK();
-    return COSA_OK;
+    return launch_wgrad<false>(static_cast<const op16 *>(dY), static_cast<const op16 *>(X), dW, db, M, N, K, zero_first, workspace, workspace_bytes,
+                               as_stream(stream), ConvGeom{}, 0, "cosa_gemm_wgrad_bf16");
 }
 
 // weight gradient of cosa_conv3x3_dilated_nhwc:  dW9[Cout][9*Cin] (fp32, tap-major columns: t*Cin + c) = (zero_first ? 0 : dW9) +
 // dY[B*h*w, Cout]^T im2col(X); X is addressed exactly as in the forward call (strided token view, image b at row b*img_rows + row_off).
+// workspace: cosa_gemm_wgrad_workspace_bytes(B*h*w, Cout, 9*Cin)
 extern "C" int cosa_conv3x3_dilated_wgrad(const void *dY, const void *X, float *dW9, int B, int h, int w, int Cin, int Cout, int dilation,
-                                          int img_rows, int row_off, int ldx, int zero_first, void *stream)
+                                          int img_rows, int row_off, int ldx, int zero_first, void *workspace, size_t workspace_bytes, void *stream)
 {
     COSA_REQUIRE(dY && X && dW9 && B > 0 && h > 0 && w > 0 && dilation > 0, "cosa_conv3x3_dilated_wgrad: bad arguments");
     COSA_REQUIRE(Cin % 128 == 0 && Cout % 128 == 0, "cosa_conv3x3_dilated_wgrad: Cin and Cout must be multiples of 128 (got %d, %d)", Cin, Cout);
@@ -2154,27 +2239,9 @@ extern "C" int cosa_conv3x3_dilated_wgrad(const void *dY, const void *X, float *
     const long long x_bytes = (long long)B * img_rows * ldx * 2;
     const int M = B * h * w, N = Cout, K = 9 * Cin;
     COSA_REQUIRE(x_bytes < 0x7fffff00ll && (size_t)M * N * 2 < 0x7fffffffull, "cosa_conv3x3_dilated_wgrad: operand beyond 2 GiB");
-    hipStream_t st = as_stream(stream);
-    static bool attr_done = false;
-    if (!attr_done) {
-        COSA_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_wgrad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
-        attr_done = true;
-    }
-    if (zero_first) COSA_HIP_CHECK(hipMemsetAsync(dW9, 0, (size_t)N * K * sizeof(float), st));
-    const int tiles = (N / 128) * (K / 128);
-    const int nstages = (M + 63) / 64;
-    int splits = 512 / tiles;                       // same rule as the Linear weight gradient: fill the 512 slots, never a partial round
-    if (splits * tiles < 288 && (splits + 1) * tiles <= 512) splits++;
-    if (splits < 1) splits = 1;
-    if (splits > nstages) splits = nstages;
-    const int per = (nstages + splits - 1) / splits;
-    splits = (nstages + per - 1) / per;
     ConvGeom cg{h, w, dilation, Cin, img_rows, row_off, ldx, 64 / w, 64 % w};
-    hipLaunchKernelGGL(gemm_wgrad_kernel<true>, dim3(8 * ((tiles + 7) / 8) * splits), dim3(256), 65536, st, static_cast<const op16 *>(dY),
-                       static_cast<const op16 *>(X), dW9, static_cast<float *>(nullptr), M, N, K, K / 128, per, nstages, tiles,
-                       (tiles + 7) / 8, cg, (int)x_bytes);
-    COSA_LAUNCH_CHECK();
-    return COSA_OK;
+    return launch_wgrad<true>(static_cast<const op16 *>(dY), static_cast<const op16 *>(X), dW9, nullptr, M, N, K, zero_first, workspace,
+                              workspace_bytes, as_stream(stream), cg, (int)x_bytes, "cosa_conv3x3_dilated_wgrad");
 }
 
 extern "C" int cosa_conv3x3_dilated_nhwc(const void *X, const void *Wt, void *Y, int B, int h, int w, int Cin, int Cout, int dilation,

@@ -84,11 +84,19 @@ __device__ __forceinline__ float wave_sum(float v)
     return v;
 }
 
+// Sums that meet from many threads / workgroups are kept in 64-bit FIXED POINT and added with integer atomics: integer addition is
+// associative, so the result does not depend on the order in which the adds land -- the loss and its gradient are the same bits every
+// run (round 2 used float atomics in LDS and in global memory here: the last source of run-to-run differences in the student's
+// gradients, together with the weight-gradient GEMM's).  Forward sums (up to ~1e7): 32 fractional bits; gradient cells (|sum| < 32):
+// 52 fractional bits, i.e. finer than fp32's own resolution for every value above 2^-28.
+__device__ __forceinline__ unsigned long long fix32(float v) { return (unsigned long long)(long long)__builtin_rint((double)v * 4294967296.0); }
+__device__ __forceinline__ unsigned long long fix52(float v) { return (unsigned long long)(long long)__builtin_rint((double)v * 4503599627370496.0); }
+
 // ---- forward ---------------------------------------------------------------------------------------------------
 // sums[8] = {bgA_sum, bgA_cnt, fgA_sum, fgA_cnt, bgB_sum, bgB_cnt, fgB_sum, fgB_cnt}
 __global__ __launch_bounds__(256) void seg_loss_fwd_kernel(const float *__restrict__ seg_lr, const float *__restrict__ maskA,
                                                           const float *__restrict__ maskB, const float *__restrict__ simg,
-                                                          const int32_t *__restrict__ boxes, float *__restrict__ sums,
+                                                          const int32_t *__restrict__ boxes, unsigned long long *__restrict__ sums,
                                                           float *__restrict__ s_seg, float *__restrict__ s_img,
                                                           float *__restrict__ roi, unsigned char *__restrict__ unlabel,
                                                           int K, int hs, int ws, int S, float sy, float sx)
@@ -143,7 +151,12 @@ __global__ __launch_bounds__(256) void seg_loss_fwd_kernel(const float *__restri
         if (lane == 0) red[wave][i] = v;
     }
     __syncthreads();
-    if (tid < 8) atomicAdd(&sums[tid], red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid]);
+    if (tid < 8) atomicAdd(&sums[tid], fix32(red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid]));
+}
+
+__global__ void seg_loss_sums_kernel(const unsigned long long *__restrict__ fix, float *__restrict__ sums)
+{
+    if (threadIdx.x < 8) sums[threadIdx.x] = (float)((double)(long long)fix[threadIdx.x] * (1.0 / 4294967296.0));
 }
 
 // ---- backward ---------------------------------------------------------------------------------------------------
@@ -153,15 +166,15 @@ __global__ __launch_bounds__(256) void seg_loss_bwd_kernel(const float *__restri
                                                           const float *__restrict__ maskB, const float *__restrict__ sums,
                                                           const float *__restrict__ AS, const float *__restrict__ roi,
                                                           const float *__restrict__ g_seg, const float *__restrict__ g_regw,
-                                                          float *__restrict__ grad, int B, int K, int hs, int ws, int S,
+                                                          unsigned long long *__restrict__ grad, int B, int K, int hs, int ws, int S,
                                                           float sy, float sx)
 {
-    extern __shared__ __attribute__((aligned(16))) float tile[];       // [K][TC][TC] logits, then [K][TC][TC] gradient
+    extern __shared__ __attribute__((aligned(16))) float tile[];       // [K][TC][TC] logits, then [K][TC][TC] gradient cells (64-bit fixed point)
     const int b = blockIdx.z;
     const QuadCtx c = setup(seg_lr, tile, K, hs, ws, S, sy, sx, b);
-    float *gt = tile + K * TC * TC;
+    unsigned long long *gt = reinterpret_cast<unsigned long long *>(tile + ((K * TC * TC + 1) & ~1));
     const int tid = threadIdx.y * 16 + threadIdx.x;
-    for (int e = tid; e < K * TC * TC; e += 256) gt[e] = 0.f;
+    for (int e = tid; e < K * TC * TC; e += 256) gt[e] = 0ull;
     __syncthreads();
     // The gradient of a low-res cell collects 16 x 16 pixels: per-thread LDS atomics on the same four addresses serialise.  In a wave, the
     // 4 x 4 quads whose lane numbers differ in bits 0, 1 (x) and 4, 5 (y) read the same four cells whenever the up-sampling factor is 16
@@ -217,7 +230,7 @@ __global__ __launch_bounds__(256) void seg_loss_bwd_kernel(const float *__restri
                 const float pk = __expf(tap(pl, c.t[p]) - m[p]) * inv[p];
                 dz[p] = ca[p] * (pk - (la[p] == k ? 1.f : 0.f)) + cb[p] * (pk - (lb[p] == k ? 1.f : 0.f)) + pk * (dP - dot[p]);
             }
-            float *gp = gt + k * TC * TC;
+            unsigned long long *gp = gt + k * TC * TC;
             if (grouped) {    // 4 x 4 quads (lanes differing in bits 0, 1, 4, 5) share their four cells: one lane adds the sum of all sixteen
                 float v00 = dz[0] * c.t[0].w00 + dz[1] * c.t[1].w00 + dz[2] * c.t[2].w00 + dz[3] * c.t[3].w00;
                 float v01 = dz[0] * c.t[0].w01 + dz[1] * c.t[1].w01 + dz[2] * c.t[2].w01 + dz[3] * c.t[3].w01;
@@ -232,36 +245,42 @@ __global__ __launch_bounds__(256) void seg_loss_bwd_kernel(const float *__restri
                     v11 += __shfl_xor(v11, x, 64);
                 }
                 if (((threadIdx.y * 16 + threadIdx.x) & 0x33) == 0) {
-                    atomicAdd(gp + c.t[0].o00, v00);
-                    atomicAdd(gp + c.t[0].o01, v01);
-                    atomicAdd(gp + c.t[0].o10, v10);
-                    atomicAdd(gp + c.t[0].o11, v11);
+                    atomicAdd(gp + c.t[0].o00, fix52(v00));
+                    atomicAdd(gp + c.t[0].o01, fix52(v01));
+                    atomicAdd(gp + c.t[0].o10, fix52(v10));
+                    atomicAdd(gp + c.t[0].o11, fix52(v11));
                 }
             } else if (same) {       // the quad's four pixels share their four low-res cells (always true for S = 16 h)
-                atomicAdd(gp + c.t[0].o00, dz[0] * c.t[0].w00 + dz[1] * c.t[1].w00 + dz[2] * c.t[2].w00 + dz[3] * c.t[3].w00);
-                atomicAdd(gp + c.t[0].o01, dz[0] * c.t[0].w01 + dz[1] * c.t[1].w01 + dz[2] * c.t[2].w01 + dz[3] * c.t[3].w01);
-                atomicAdd(gp + c.t[0].o10, dz[0] * c.t[0].w10 + dz[1] * c.t[1].w10 + dz[2] * c.t[2].w10 + dz[3] * c.t[3].w10);
-                atomicAdd(gp + c.t[0].o11, dz[0] * c.t[0].w11 + dz[1] * c.t[1].w11 + dz[2] * c.t[2].w11 + dz[3] * c.t[3].w11);
+                atomicAdd(gp + c.t[0].o00, fix52(dz[0] * c.t[0].w00 + dz[1] * c.t[1].w00 + dz[2] * c.t[2].w00 + dz[3] * c.t[3].w00));
+                atomicAdd(gp + c.t[0].o01, fix52(dz[0] * c.t[0].w01 + dz[1] * c.t[1].w01 + dz[2] * c.t[2].w01 + dz[3] * c.t[3].w01));
+                atomicAdd(gp + c.t[0].o10, fix52(dz[0] * c.t[0].w10 + dz[1] * c.t[1].w10 + dz[2] * c.t[2].w10 + dz[3] * c.t[3].w10));
+                atomicAdd(gp + c.t[0].o11, fix52(dz[0] * c.t[0].w11 + dz[1] * c.t[1].w11 + dz[2] * c.t[2].w11 + dz[3] * c.t[3].w11));
             } else {
 #pragma unroll
                 for (int p = 0; p < 4; p++) {
-                    atomicAdd(gp + c.t[p].o00, dz[p] * c.t[p].w00);
-                    atomicAdd(gp + c.t[p].o01, dz[p] * c.t[p].w01);
-                    atomicAdd(gp + c.t[p].o10, dz[p] * c.t[p].w10);
-                    atomicAdd(gp + c.t[p].o11, dz[p] * c.t[p].w11);
+                    atomicAdd(gp + c.t[p].o00, fix52(dz[p] * c.t[p].w00));
+                    atomicAdd(gp + c.t[p].o01, fix52(dz[p] * c.t[p].w01));
+                    atomicAdd(gp + c.t[p].o10, fix52(dz[p] * c.t[p].w10));
+                    atomicAdd(gp + c.t[p].o11, fix52(dz[p] * c.t[p].w11));
                 }
             }
         }
     }
     __syncthreads();
     for (int e = tid; e < K * TC * TC; e += 256) {
-        const float v = gt[e];
-        if (v != 0.f) {
+        const unsigned long long v = gt[e];
+        if (v != 0ull) {
             const int k = e / (TC * TC), r = e - k * TC * TC;
             const int cy = c.cy0 + r / TC, cx = c.cx0 + r % TC;
             if (cy < hs && cx < ws) atomicAdd(&grad[(((size_t)b * K + k) * hs + cy) * ws + cx], v);
         }
     }
+}
+
+__global__ __launch_bounds__(256) void seg_loss_grad_kernel(const unsigned long long *__restrict__ fix, float *__restrict__ grad, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) grad[i] = (float)((double)(long long)fix[i] * (1.0 / 4503599627370496.0));
 }
 
 
@@ -416,36 +435,63 @@ static int check_shapes(int B, int K, int hs, int ws, int S)
     return COSA_OK;
 }
 
+/* scratch of the two entry points below: the 64-bit fixed-point sums (8 of the forward, B*K*hs*ws gradient cells of the backward) */
+extern "C" size_t cosa_seg_loss_workspace_bytes(int B, int K, int hs, int ws)
+{
+    if (B <= 0 || K <= 0 || hs <= 0 || ws <= 0) return 0;
+    return align_up((size_t)B * K * hs * ws * sizeof(unsigned long long) + 64, 256);
+}
+
 extern "C" int cosa_seg_loss_forward(const float *seg_lr, const float *maskA, const float *maskB, const float *simg,
                                      const int32_t *boxes, float *sums, float *s_seg, float *s_img, float *roi, uint8_t *unlabel,
-                                     int B, int K, int hs, int ws, int S, void *stream)
+                                     int B, int K, int hs, int ws, int S, void *workspace, size_t workspace_bytes, void *stream)
 {
-    COSA_REQUIRE(seg_lr && maskA && maskB && simg && boxes && sums && s_seg && s_img && roi && unlabel, "cosa_seg_loss_forward: null pointer");
+    COSA_REQUIRE(seg_lr && maskA && maskB && simg && boxes && sums && s_seg && s_img && roi && unlabel && workspace, "cosa_seg_loss_forward: null pointer");
     int rc = check_shapes(B, K, hs, ws, S);
     if (rc) return rc;
+    if (workspace_bytes < 64) {
+        set_error("cosa_seg_loss_forward: workspace too small");
+        return COSA_ENOMEM;
+    }
     hipStream_t st = as_stream(stream);
-    COSA_HIP_CHECK(hipMemsetAsync(sums, 0, 8 * sizeof(float), st));
+    unsigned long long *fix = static_cast<unsigned long long *>(workspace);
+    COSA_HIP_CHECK(hipMemsetAsync(fix, 0, 8 * sizeof(unsigned long long), st));
     const dim3 grid((S + 31) / 32, (S + 31) / 32, B), blk(16, 16);
     const size_t lds = (size_t)K * TC * TC * sizeof(float);
-    hipLaunchKernelGGL(seg_loss_fwd_kernel, grid, blk, lds, st, seg_lr, maskA, maskB, simg, boxes, sums, s_seg, s_img, roi, unlabel, K,
+    hipLaunchKernelGGL(seg_loss_fwd_kernel, grid, blk, lds, st, seg_lr, maskA, maskB, simg, boxes, fix, s_seg, s_img, roi, unlabel, K,
                        hs, ws, S, (float)hs / (float)S, (float)ws / (float)S);
+    COSA_LAUNCH_CHECK();
+    hipLaunchKernelGGL(seg_loss_sums_kernel, dim3(1), dim3(64), 0, st, fix, sums);
     COSA_LAUNCH_CHECK();
     return COSA_OK;
 }
 
 extern "C" int cosa_seg_loss_backward(const float *seg_lr, const float *maskA, const float *maskB, const float *sums, const float *AS,
                                       const float *roi, const float *g_seg, const float *g_regw, float *grad_seg_lr,
-                                      int B, int K, int hs, int ws, int S, void *stream)
+                                      int B, int K, int hs, int ws, int S, void *workspace, size_t workspace_bytes, void *stream)
 {
-    COSA_REQUIRE(seg_lr && maskA && maskB && sums && AS && roi && g_seg && g_regw && grad_seg_lr, "cosa_seg_loss_backward: null pointer");
+    COSA_REQUIRE(seg_lr && maskA && maskB && sums && AS && roi && g_seg && g_regw && grad_seg_lr && workspace, "cosa_seg_loss_backward: null pointer");
     int rc = check_shapes(B, K, hs, ws, S);
     if (rc) return rc;
+    const size_t n = (size_t)B * K * hs * ws;
+    if (workspace_bytes < cosa_seg_loss_workspace_bytes(B, K, hs, ws)) {
+        set_error("cosa_seg_loss_backward: workspace too small (size it with cosa_seg_loss_workspace_bytes)");
+        return COSA_ENOMEM;
+    }
     hipStream_t st = as_stream(stream);
-    COSA_HIP_CHECK(hipMemsetAsync(grad_seg_lr, 0, (size_t)B * K * hs * ws * sizeof(float), st));
+    unsigned long long *fix = static_cast<unsigned long long *>(workspace) + 8;
+    COSA_HIP_CHECK(hipMemsetAsync(fix, 0, n * sizeof(unsigned long long), st));
     const dim3 grid((S + 31) / 32, (S + 31) / 32, B), blk(16, 16);
-    const size_t lds = (size_t)2 * K * TC * TC * sizeof(float);
-    hipLaunchKernelGGL(seg_loss_bwd_kernel, grid, blk, lds, st, seg_lr, maskA, maskB, sums, AS, roi, g_seg, g_regw, grad_seg_lr, B, K, hs,
+    const size_t lds = (size_t)((K * TC * TC + 1) & ~1) * sizeof(float) + (size_t)K * TC * TC * sizeof(unsigned long long);
+    static size_t lds_set = 0;
+    if (lds > 65536 && lds > lds_set) {
+        COSA_HIP_CHECK(hipFuncSetAttribute((const void *)seg_loss_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        lds_set = lds;
+    }
+    hipLaunchKernelGGL(seg_loss_bwd_kernel, grid, blk, lds, st, seg_lr, maskA, maskB, sums, AS, roi, g_seg, g_regw, fix, B, K, hs,
                        ws, S, (float)hs / (float)S, (float)ws / (float)S);
+    COSA_LAUNCH_CHECK();
+    hipLaunchKernelGGL(seg_loss_grad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, fix, grad_seg_lr, n);
     COSA_LAUNCH_CHECK();
     return COSA_OK;
 }

@@ -210,13 +210,12 @@ def conv3x3_dilated_wgrad(dy, tok, B, h, w, dilation):
     ldx, img_rows = _token_view_geometry(tok, B, h, w)
     assert dy.dtype == torch.bfloat16 and dy.is_contiguous() and dy.shape[0] == B * h * w
     dw = _wgrad_alloc(Cout * 9 * Cin, dy.device)
-    zero_first = 0
     if dw is None:
         dw = torch.empty(Cout * 9 * Cin, device=dy.device, dtype=torch.float32)
-        zero_first = 1
+    ws = _C.workspace(_C.lib().cosa_gemm_wgrad_workspace_bytes(B * h * w, Cout, 9 * Cin), dy.device, "wgrad")
     with _C.profiled("conv3x3_wgrad"):
         _C.check(_C.lib().cosa_conv3x3_dilated_wgrad(_C.ptr(dy), _C.ptr(tok), _C.ptr(dw), B, h, w, Cin, Cout, int(dilation), img_rows, 0,
-                                                     ldx, zero_first, _C.stream_ptr()), "cosa_conv3x3_dilated_wgrad")
+                                                     ldx, 1, _C.ptr(ws), ws.numel(), _C.stream_ptr()), "cosa_conv3x3_dilated_wgrad")
     _flops["conv3x3_wgrad"] = _flops.get("conv3x3_wgrad", 0) + 2.0 * B * h * w * Cout * Cin * 9
     return dw.view(Cout, 3, 3, Cin).permute(0, 3, 1, 2)
 
@@ -552,9 +551,9 @@ def _mm_f32(a, b):
 
 
 class _WgradArena:
-    """Zero-initialised home of one step's weight gradients.  The split-K wgrad kernel ACCUMULATES (fp32 atomics), so its output must
-    start at zero: instead of one small memset per gradient tensor (96 launches of ~5 us per step) the trainer clears this arena once
-    per step (`wgrad_arena_begin`) and the gradients of that step are carved out of it in call order (stable addresses step to step).
+    """Home of one step's weight gradients: the gradients of a step are carved out of ONE buffer in call order (stable addresses from
+    step to step, no allocator traffic in the backward pass).  Since round 3 the weight-gradient kernels OVERWRITE their output (partial
+    slabs + a fixed-order reduction instead of fp32 atomics), so the arena is no longer cleared per step.
     Off unless a trainer turns it on: with it on, gradients of step t are invalid once step t+1 begins."""
     buf, off, high, enabled = None, 0, 0, False
 
@@ -562,8 +561,6 @@ class _WgradArena:
 def wgrad_arena_begin(device):
     a = _WgradArena
     a.enabled = True
-    if a.buf is not None and a.buf.device == device and a.high > 0:
-        a.buf[: a.high].zero_()
     a.off = 0
 
 
@@ -585,21 +582,20 @@ def _wgrad_alloc(n, device):
 
 def gemm_wgrad(dy2, x2, want_bias=False):
     """dW[N,K] fp32 = dy2[M,N]^T x2[M,K] (bf16) and, optionally, db[N] = column sums of dy2: the TN MFMA kernel with
-    transposing LDS reads."""
+    transposing LDS reads; token range split over workgroups, partial slabs reduced in a fixed order (deterministic, no atomics)."""
     M, N = dy2.shape
     K = x2.shape[1]
     dw = _wgrad_alloc(N * K, dy2.device)
     db = _wgrad_alloc(N, dy2.device) if (want_bias and dw is not None) else None
-    zero_first = 0
     if dw is None or (want_bias and db is None):
         dw = torch.empty((N, K), device=dy2.device, dtype=torch.float32)
         db = torch.empty((N,), device=dy2.device, dtype=torch.float32) if want_bias else None
-        zero_first = 1
     else:
         dw = dw.view(N, K)
+    ws = _C.workspace(_C.lib().cosa_gemm_wgrad_workspace_bytes(M, N, K), dy2.device, "wgrad")
     with _C.profiled("gemm_wgrad"):
-        _C.check(_C.lib().cosa_gemm_wgrad_bf16(_C.ptr(dy2), _C.ptr(x2), _C.ptr(dw), _C.ptr(db), M, N, K, zero_first, _C.stream_ptr()),
-                 "cosa_gemm_wgrad_bf16")
+        _C.check(_C.lib().cosa_gemm_wgrad_bf16(_C.ptr(dy2), _C.ptr(x2), _C.ptr(dw), _C.ptr(db), M, N, K, 1, _C.ptr(ws), ws.numel(),
+                                               _C.stream_ptr()), "cosa_gemm_wgrad_bf16")
     return (dw, db) if want_bias else dw
 
 

@@ -306,6 +306,13 @@ def cam2mask_multi(images, img_boxes, cams_list, cls_labels, thresholds_high, th
         if c.shape != (b, C, h, w) or cls_labels.shape != (b, C):
             raise ValueError("cam2mask: cams must be [b,C,h,w] at image size and cls_labels [b,C]")
     dev = cams_list[0].device
+    # the reference slices with the box (`mask[y0:y1, x0:x1]`, seg_helper.py:776-777), so negative bounds count from the end -- evaluation passes
+    # [0, -1, 0, -1] (evaluation_engine.py:136): bring them to the kernels' absolute form (checked on the host when the boxes live there)
+    if not torch.is_tensor(img_boxes):
+        img_boxes = torch.as_tensor(img_boxes)
+    if img_boxes.is_cuda or bool((img_boxes < 0).any()):
+        size = torch.tensor([h, h, w, w], device=img_boxes.device, dtype=img_boxes.dtype)
+        img_boxes = torch.where(img_boxes < 0, img_boxes + size, img_boxes)
     boxes = _boxes_to_device(img_boxes, dev)
     if boxes.shape != (b, 4):
         raise ValueError("cam2mask: img_boxes must be [b,4]")
@@ -511,9 +518,10 @@ class FusedSegRegLoss(Function):
         unl = torch.empty((B, Sq, Sq), device=dev, dtype=torch.uint8)
         L = _C.lib()
         maskA, maskB, simg = maskA.contiguous().float(), maskB.contiguous().float(), simg.contiguous().float()
+        wsl = _C.workspace(L.cosa_seg_loss_workspace_bytes(B, K, hs, ws), dev, "seg_loss")
         _C.check(L.cosa_seg_loss_forward(_C.ptr(seg_lr), _C.ptr(maskA), _C.ptr(maskB), _C.ptr(simg), _C.ptr(boxes), _C.ptr(sums),
-                                         _C.ptr(s_seg), _C.ptr(s_img), _C.ptr(roi), _C.ptr(unl), B, K, hs, ws, S, _C.stream_ptr()),
-                 "cosa_seg_loss_forward")
+                                         _C.ptr(s_seg), _C.ptr(s_img), _C.ptr(roi), _C.ptr(unl), B, K, hs, ws, S, _C.ptr(wsl), wsl.numel(),
+                                         _C.stream_ptr()), "cosa_seg_loss_forward")
         AS = torch.empty_like(s_seg)
         energy = torch.empty(1, device=dev)
         if prepared is not None and prepared.matches(B, K, Sq, sigma_rgb, sigma_xy):
@@ -543,9 +551,10 @@ class FusedSegRegLoss(Function):
         grad = torch.empty_like(seg_lr)
         gs = g_seg.reshape(1).float().contiguous()
         gr = (g_reg.reshape(1).float() * ctx.weight).contiguous()
+        wsl = _C.workspace(_C.lib().cosa_seg_loss_workspace_bytes(B, K, hs, ws), seg_lr.device, "seg_loss")
         _C.check(_C.lib().cosa_seg_loss_backward(_C.ptr(seg_lr), _C.ptr(maskA), _C.ptr(maskB), _C.ptr(sums), _C.ptr(AS), _C.ptr(roi),
-                                                 _C.ptr(gs), _C.ptr(gr), _C.ptr(grad), B, K, hs, ws, ctx.S, _C.stream_ptr()),
-                 "cosa_seg_loss_backward")
+                                                 _C.ptr(gs), _C.ptr(gr), _C.ptr(grad), B, K, hs, ws, ctx.S, _C.ptr(wsl), wsl.numel(),
+                                                 _C.stream_ptr()), "cosa_seg_loss_backward")
         return grad, None, None, None, None, None, None, None, None
 
 

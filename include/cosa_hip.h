@@ -211,8 +211,12 @@ int cosa_attn_bwd(const void *qkv, const void *out, const void *dout, const floa
 int cosa_gemm_bf16(const void *X, const void *W, const void *bias, const float *residual, void *Y,
                    int M, int N, int K, int epilogue, void *stream);
 /* weight (and bias) gradient of the same Linear: dW[N,K] (fp32) = (zero_first ? 0 : dW) + dY[M,N]^T X[M,K]  (bf16 operands);
- * db[N] (fp32, optional) = (zero_first ? 0 : db) + column sums of dY                                                      */
-int cosa_gemm_wgrad_bf16(const void *dY, const void *X, float *dW, float *db, int M, int N, int K, int zero_first, void *stream);
+ * db[N] (fp32, optional) = (zero_first ? 0 : db) + column sums of dY.  N % 128 == 0, K % 128 == 0.  Deterministic: the token range is
+ * split over workgroups, every split writes an fp32 partial slab into `workspace` (cosa_gemm_wgrad_workspace_bytes) and a second
+ * kernel adds the slabs in split order -- no float atomics, the same bits every run.                                           */
+size_t cosa_gemm_wgrad_workspace_bytes(int M, int N, int K);
+int cosa_gemm_wgrad_bf16(const void *dY, const void *X, float *dW, float *db, int M, int N, int K, int zero_first,
+                         void *workspace, size_t workspace_bytes, void *stream);
 /* models/decoder/conv_head.py:11-41  LargeFOV's 3x3 dilated, bias-free convolution on NHWC tokens (implicit GEMM, optional ReLU):
  *   X: image b = rows [b*img_rows + row_off, +h*w) of a [*, ldx] bf16 matrix (so the token tensor minus its cls row needs no copy)
  *   Wt [9][Cout][Cin] bf16 (tap-major: t = ky*3 + kx);  Y [B*h*w, Cout] bf16;  padding = dilation                               */
@@ -222,7 +226,8 @@ int cosa_conv3x3_dilated_nhwc(const void *X, const void *Wt, void *Y, int B, int
  * dY[B*h*w, Cout]^T im2col(X), the im2col implicit in the operand addressing; X is addressed as in the forward call.
  * (The input gradient is the forward entry point itself on dY with Wt'[t][c][o] = Wt[8-t][o][c].)                              */
 int cosa_conv3x3_dilated_wgrad(const void *dY, const void *X, float *dW9, int B, int h, int w, int Cin, int Cout, int dilation,
-                               int img_rows, int row_off, int ldx, int zero_first, void *stream);
+                               int img_rows, int row_off, int ldx, int zero_first, void *workspace, size_t workspace_bytes,
+                               void *stream);      /* workspace: cosa_gemm_wgrad_workspace_bytes(B*h*w, Cout, 9*Cin) */
 void cosa_gemm_set_variant(int v);   /* 0 (default): per-shape choice; 1: 128x128 2-stage; 2: 256x128 3-stage; 3: 256x256 8-wave;
                                       * 5: 256x256 4-phase ping-pong; 6: the same, persistent with the epilogue in the MFMA shadow      */
 /* persistent-grid policy of cosa_gemm_bf16: 0 (default) one workgroup per CU; 1 the workgroups balanced over the rounds the launch needs
@@ -279,13 +284,15 @@ int cosa_transpose_cast_batched(const void *records, int n, int total_tiles, voi
  * being fp16 instead.                                                                                                            */
 int cosa_gemm_f16(const void *X, const void *W, const void *bias, const float *residual, void *Y,
                   int M, int N, int K, int epilogue, void *stream);
-int cosa_gemm_wgrad_f16(const void *dY, const void *X, float *dW, float *db, int M, int N, int K, int zero_first, void *stream);
+int cosa_gemm_wgrad_f16(const void *dY, const void *X, float *dW, float *db, int M, int N, int K, int zero_first,
+                        void *workspace, size_t workspace_bytes, void *stream);
 int cosa_layernorm_f16(const float *x, const void *gamma, const void *beta, void *y_f16, float *y_f32,
                        int rows, int dim, float eps, void *stream);
 int cosa_conv3x3_dilated_nhwc_f16(const void *X, const void *Wt, void *Y, int B, int h, int w, int Cin, int Cout, int dilation,
                                   int img_rows, int row_off, int ldx, int relu, void *stream);
 int cosa_conv3x3_dilated_wgrad_f16(const void *dY, const void *X, float *dW9, int B, int h, int w, int Cin, int Cout, int dilation,
-                                   int img_rows, int row_off, int ldx, int zero_first, void *stream);
+                                   int img_rows, int row_off, int ldx, int zero_first, void *workspace, size_t workspace_bytes,
+                                   void *stream);
 void cosa_gemm_set_variant_f16(int v);
 void cosa_gemm_set_stamp_slot_f16(void *slot);
 size_t cosa_attn_workspace_bytes_f16(int B, int N, int H);
@@ -353,13 +360,16 @@ int cosa_attn_fwd_f16c8(const void *qkv, void *out_c8, float *lse, int B, int N,
  *               roi [B,S/2,S/2]; unlabel [B,S/2,S/2] u8   (then cosa_dense_energy_forward on these)
  *   backward -> grad_seg_lr [B,K,hs,ws] for  g_seg * (0.5*seg_loss_A + 0.5*seg_loss_B)  +  g_regw * energy
  *               (AS = the gated filter output kept by cosa_dense_energy_forward)
+ *   Sums that meet from many threads (the eight loss sums, the gradient cells) are accumulated in 64-bit fixed point with INTEGER atomics
+ *   in `workspace` (cosa_seg_loss_workspace_bytes) and converted at the end: order-independent, the same bits every run.
  * ------------------------------------------------------------------------------------- */
+size_t cosa_seg_loss_workspace_bytes(int B, int K, int hs, int ws);
 int cosa_seg_loss_forward(const float *seg_lr, const float *maskA, const float *maskB, const float *simg,
                           const int32_t *boxes, float *sums, float *s_seg, float *s_img, float *roi, uint8_t *unlabel,
-                          int B, int K, int hs, int ws, int S, void *stream);
+                          int B, int K, int hs, int ws, int S, void *workspace, size_t workspace_bytes, void *stream);
 int cosa_seg_loss_backward(const float *seg_lr, const float *maskA, const float *maskB, const float *sums, const float *AS,
                            const float *roi, const float *g_seg, const float *g_regw, float *grad_seg_lr,
-                           int B, int K, int hs, int ws, int S, void *stream);
+                           int B, int K, int hs, int ws, int S, void *workspace, size_t workspace_bytes, void *stream);
 
 /* F.multilabel_soft_margin_loss (main.py:127-128 on the classification logits; seg_helper.py:593-602 on relu(cam) against the resized teacher
  * probabilities) and its gradient in one pass: loss[0] = mean_r mean_c -(y log s(v) + (1-y) log s(-v)), v = relu ? max(x,0) : x;

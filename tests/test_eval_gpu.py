@@ -211,7 +211,7 @@ def test_evaluate_threshold_filters_sweep_vs_oracle(oracle_c):
     thr = [0.2, 0.35]
     tab, seg_miou, cam_miou, df, _ = ee.evaluate(model, loader, args, epoch=3, s_or_t='t', get_camiou=True, threshold_filters=thr)
     assert df["Metrics"] == ["CAM", "aux_CAM", "Seg_vd", "cam_0.2", "cam_0.35", "camaux_0.2", "camaux_0.35"]
-    assert seg_miou == df["mIoU"][-1]                                          # the reference returns the LAST row here (:289)
+    assert np.array_equal([seg_miou], [df["mIoU"][-1]], equal_nan=True)        # the reference returns the LAST row here (:289)
     model.batch_invariant_heads = model.decoder.batch_invariant = True
     hist = {k: np.zeros((C + 1, C + 1), np.int64) for k in df["Metrics"][3:]}
     box = np.array([[0, S - 1, 0, S - 1]], np.int32)                           # [0, -1, 0, -1] as slice bounds

@@ -78,6 +78,27 @@ def test_gemm_wgrad_vs_fp32(M, N, K):
     assert (db - ref_b).abs().max().item() <= 2e-4 * ref_b.abs().max().item() + 1e-3
 
 
+@pytest.mark.parametrize("M,N,K", [(12560, 2304, 768), (12560, 768, 3072), (12544, 768, 768), (700, 128, 256)])
+def test_gemm_wgrad_is_bit_identical_run_to_run_and_accumulates(M, N, K):
+    """round 3: the token splits of the weight gradient meet in a fixed-order reduction of fp32 slabs instead of fp32 atomics -- the same
+    bits every run (also a race screen for the three-stage LDS-DMA ring with its counted vmcnt); zero_first = 0 adds to what is there"""
+    from cosa_amd import nn_ops, _C
+    torch.manual_seed(K)
+    dy = torch.randn(M, N, device="cuda").bfloat16()
+    x = torch.randn(M, K, device="cuda").bfloat16()
+    first_w, first_b = (t.clone() for t in nn_ops.gemm_wgrad(dy, x, want_bias=True))
+    for _ in range(20):
+        w, b = nn_ops.gemm_wgrad(dy, x, want_bias=True)
+        assert torch.equal(w, first_w) and torch.equal(b, first_b)
+    L = _C.lib()
+    ws = _C.workspace(L.cosa_gemm_wgrad_workspace_bytes(M, N, K), dy.device, "wgrad")
+    base_w, base_b = torch.randn(N, K, device="cuda"), torch.randn(N, device="cuda")
+    acc_w, acc_b = base_w.clone(), base_b.clone()
+    _C.check(L.cosa_gemm_wgrad_bf16(_C.ptr(dy), _C.ptr(x), _C.ptr(acc_w), _C.ptr(acc_b), M, N, K, 0, _C.ptr(ws), ws.numel(), _C.stream_ptr()), "wgrad")
+    scale = first_w.abs().max().item()
+    assert (acc_w - (base_w + first_w)).abs().max().item() <= 1e-5 * scale and (acc_b - (base_b + first_b)).abs().max().item() <= 1e-4 * first_b.abs().max().item()
+
+
 def test_layernorm_vs_torch():
     from cosa_amd import nn_ops
     torch.manual_seed(5)

@@ -142,3 +142,30 @@ def test_bf16_student_step_vs_cpu_oracle_vitb():
         # bf16 residual stream and 16-bit saved activations add ~1.5 % per layer to the back-propagated error at random initialisation
         bar = 0.97 if name.endswith((":q", ":k")) else (0.98 if "encoder.blocks" in name or "patch_embed" in name else 0.99)
         assert cs >= bar and 0.9 <= ratio <= 1.1, (name, cs, ratio)
+
+
+def test_training_step_loss_and_gradients_are_bit_identical_run_to_run():
+    """no float atomics are left on the student's path (round 3: weight-gradient splits meet in a fixed-order reduction, the seg-loss sums
+    and gradient cells in 64-bit fixed point): the same weights and the same batch give the same loss and the same gradient bits, every
+    parameter, every run -- also a race screen for the three-stage LDS-DMA ring of the weight-gradient kernel"""
+    from cosa_amd.train_step import CoSATrainer, default_args, synthetic_batch
+    dev = torch.device("cuda", 0)
+    S, b, C = 224, 4, 20
+    args = default_args("VOC12", crop_size=S, batch_size=b, teacher_graph=False, teacher_async=False)
+    tr = CoSATrainer(args, dev, seed=7)
+    wimg, simg, lab, box = synthetic_batch(b, S, C, dev, seed=9)
+    n_iter = args.warmup_iters + 1
+    runs = []
+    for _ in range(3):
+        tr.optimizer.zero_grad(set_to_none=True)
+        loss, logs = tr.forward_losses(wimg, simg, lab, box, n_iter)
+        loss.backward()
+        runs.append((loss.detach().clone(), {n: p.grad.detach().clone() for n, p in tr.student.named_parameters() if p.grad is not None},
+                     {k: logs[k].detach().clone() for k in ("seg_loss", "cam_loss", "reg_loss", "cls_loss")}))
+    assert len(runs[0][1]) > 100
+    for other in runs[1:]:
+        assert torch.equal(other[0], runs[0][0])
+        for k, v in runs[0][2].items():
+            assert torch.equal(other[2][k], v), k
+        for n, g in runs[0][1].items():
+            assert torch.equal(other[1][n], g), n
