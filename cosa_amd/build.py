@@ -39,6 +39,8 @@ SOURCES = {
     # the same two files with fp16 operands (entry points *_f16, cosa_amd/csrc/op16.hpp)
     "gemm_kernels.hip@f16": FAST + ["-DCOSA_OP_F16=1"],
     "attn_kernels.hip@f16": FAST + ["-fno-honor-nans", "-DCOSA_OP_F16=1"],
+    # the lattice file once more with a 2-D lattice: the position-only Gaussian kernel of the dense-CRF post-processing
+    "permuto_kernels.hip@d2": EXACT + ["-DCOSA_PD=2"],
     "optim_kernels.hip": ["-ffp-contract=off"],
 }
 

@@ -28,8 +28,14 @@
 namespace cosa {
 namespace {
 
-constexpr int PD = 5;
-constexpr int PD1 = 6;
+// The lattice is dimension-generic.  COSA_PD = 5 (default build): positions / sigma_xy + colours / sigma_rgb -- the bilateral filter of the
+// hot path.  The same file compiled with -DCOSA_PD=2 (object permuto_kernels_d2.o, entry points cosa_lattice_filter_d2*) is the
+// position-only Gaussian kernel of the dense-CRF post-processing (utils/seg_helper.py:961-996: pydensecrf's addPairwiseGaussian).
+#ifndef COSA_PD
+#define COSA_PD 5
+#endif
+constexpr int PD = COSA_PD;
+constexpr int PD1 = COSA_PD + 1;
 constexpr unsigned long long kEmpty = 0xFFFFFFFFFFFFFFFFull;
 constexpr int TP = 64;  // pixels per LDS transpose tile
 
@@ -106,14 +112,20 @@ __global__ __launch_bounds__(256) void lattice_build_kernel(const float *__restr
     const int n = blockIdx.y;
     const size_t hw = (size_t)P.H * P.W;
     const float *img = images + (size_t)n * 3 * hw;
-    float f[PD] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    float f[PD];
+#pragma unroll
+    for (int i = 0; i < PD; i++) f[i] = 0.f;
     if (p < P.N) {
         const int yj = p / P.W, xi = p - yj * P.W;
         f[0] = (float)xi / P.sigmaxy;
         f[1] = (float)yj / P.sigmaxy;
+#if COSA_PD == 5
         f[2] = img[p] / P.sigmargb;
         f[3] = img[hw + p] / P.sigmargb;
         f[4] = img[2 * hw + p] / P.sigmargb;
+#else
+        (void)img;
+#endif
     }
     float el[PD1], rem0[PD1], rank[PD1], bc[PD1 + 1];
     float sm = 0.0f;
@@ -448,7 +460,7 @@ __global__ __launch_bounds__(256) void lattice_slice_kernel(float *__restrict__ 
     const float *val = (final_parity ? B.val1 : B.val0) + (size_t)n * ((size_t)P.Mmax + 1) * KP;
     const int *off = B.offset + ((size_t)n * P.Npad + p0) * PD1;
     const float *bar = B.bary + ((size_t)n * P.Npad + p0) * PD1;
-    const float alpha = 1.0f / (1.0f + 0.03125f);   // 1/(1+2^-d), d = 5
+    const float alpha = 1.0f / (1.0f + 1.0f / (float)(1 << PD));   // 1/(1+2^-d)
     for (int e = threadIdx.x; e < TP * KP; e += 256) {
         const int pl = e / KP, k = e - pl * KP;
         float acc = 0.0f;
@@ -635,7 +647,7 @@ int setup_plan(int N, int K, int H, int W, float sigmargb, float sigmaxy, void *
 
 int lattice_phase(const float *images, int N, Plan &pl, hipStream_t st)
 {
-    COSA_REQUIRE(images, "bilateral: null image pointer");
+    COSA_REQUIRE(images || PD == 2, "bilateral: null image pointer");
     LatticeParams &P = pl.P;
     ImageBuffers &B = pl.B;
     const size_t cap = (size_t)P.cap_mask + 1;
@@ -733,6 +745,22 @@ __global__ __launch_bounds__(256) void half_denorm_kernel(const float *__restric
 
 using namespace cosa;
 
+#if COSA_PD == 2
+// ---- position-only Gaussian kernel (2-D lattice) of the dense-CRF post-processing ------------------------------------------------------
+extern "C" size_t cosa_lattice_filter_d2_workspace_bytes(int N, int K, int H, int W)
+{
+    if (N <= 0 || K <= 0 || H <= 0 || W <= 0) return 0;
+    Plan pl;
+    return plan_layout(N, K, H, W, nullptr, &pl);
+}
+
+extern "C" int cosa_lattice_filter_d2(const float *ins, float *outs, int N, int K, int H, int W, float sigmaxy, void *workspace,
+                                      size_t workspace_bytes, void *stream)
+{
+    return run_filter(nullptr, ins, outs, N, K, H, W, 1.0f, sigmaxy, nullptr, nullptr, nullptr, nullptr, nullptr, workspace, workspace_bytes,
+                      as_stream(stream));
+}
+#else
 extern "C" size_t cosa_bilateral_workspace_bytes(int N, int K, int H, int W)
 {
     if (N <= 0 || K <= 0 || H <= 0 || W <= 0) return 0;
@@ -844,3 +872,4 @@ extern "C" void bilateralfilter_batch(float *images, int len_images, float *ins,
     if (host_filter(images, ins, outs, N, K, H, W, sigmargb, sigmaxy) != COSA_OK)
         fprintf(stderr, "cosa bilateralfilter_batch: %s\n", cosa_last_error());
 }
+#endif

@@ -13,6 +13,10 @@ Same call surface and return values as the reference's `evaluate`.  What changes
 high = 1 - t, low = t) of the main and the auxiliary CAMs at the ground truth's resolution, scored with `pseudo_scores` (pixels labelled
 255 are dropped) into rows `cam_<t>` / `camaux_<t>` of the table.
 
+`getcrf` (evaluation_engine.py:204-211,247-250; `finaleval` passes it): per image the validated logits at the ground truth's resolution ->
+softmax -> one mean-field step of the dense CRF (`seg_helper.crf_inference_infv2`: two permutohedral-lattice filters on the device) ->
+argmax, scored as the row `Seg_crf`.  Parity of that row with pydensecrf is unpinned (see seg_helper.DenseCRF).
+
 Not built: image / CAM dumps (`save_result`, `save_rawcam`); asking for them raises NotImplementedError.
 """
 import torch
@@ -56,8 +60,6 @@ def evaluate(model, data_loader, args, df=None, save_result=False, save_rawcam=F
              s_or_t='t', get_camiou=False, isfinal=False, class_list=None, use_graph=True, eval_group=4):
     if save_result or save_rawcam:
         raise NotImplementedError("evaluate: save_result / save_rawcam (image dumps) are not part of the device path")
-    if getcrf:
-        raise NotImplementedError("evaluate: dense-CRF (getcrf) is not built (SURVEY f-4)")
     threshold_filters = list(threshold_filters) if threshold_filters else []
     assert s_or_t in ['s', 't']
     distributed = dist.is_available() and dist.is_initialized()
@@ -67,6 +69,8 @@ def evaluate(model, data_loader, args, df=None, save_result=False, save_rawcam=F
         raise RuntimeError("evaluate runs on the GPU (HIP kernels); no CPU path")
     nc = args.num_classes
     meters = {k: evaluation.ConfusionMeter(nc, device) for k in ("cam", "cam_aux", "seg_ps", "seg_vd")}
+    if getcrf:
+        meters["seg_crf"] = evaluation.ConfusionMeter(nc, device)
     for thre in threshold_filters:                    # pseudo_scores' relabelling: a prediction of 255 drops the pixel (utils/evaluation.py:43-46)
         meters[f"cam_{thre}"] = evaluation.ConfusionMeter(nc, device, pseudo=True)
         meters[f"camaux_{thre}"] = evaluation.ConfusionMeter(nc, device, pseudo=True)
@@ -91,7 +95,7 @@ def evaluate(model, data_loader, args, df=None, save_result=False, save_rawcam=F
         nonlocal ap_cnt
         inputs = torch.cat([g[0] for g in group], dim=0)
         cams, cams_aux, seg_ps, cls_final, cls_aux = camseg(inputs)
-        for i, (_, labels, cls_label) in enumerate(group):
+        for i, (_, labels, cls_label, img_org) in enumerate(group):
             # classification AP of this item (:86-92; cls_* are sums over scales and flips, compared with every label row)
             for j, logit in enumerate((cls_final[i:i + 1], cls_aux[i:i + 1])):
                 ap, valid = torch_helper.average_precision(cls_label, torch.sigmoid(logit.float()).expand_as(cls_label))
@@ -105,6 +109,14 @@ def evaluate(model, data_loader, args, df=None, save_result=False, save_rawcam=F
             meters["cam_aux"].update(gt, cam_aux_label)
             meters["seg_ps"].update(gt, pred_ps)
             meters["seg_vd"].update(gt, pred_vd)
+            if getcrf:
+                # evaluation_engine.py:204-211: softmax of the validated logits at the ground truth's size, the de-normalised uint8 image,
+                # one mean-field step, argmax
+                rs = F.interpolate(seg_ps[i:i + 1], size=size, mode='bilinear', align_corners=False)
+                vd = seg_helper.seg_validation(rs, cls_label).softmax(dim=1)[0]
+                ori = torch_helper.denormalize_img_(img_org)[0].permute(1, 2, 0)
+                q = seg_helper.crf_inference_infv2(ori, vd.contiguous())
+                meters["seg_crf"].update(gt, q.argmax(dim=0, keepdim=True).to(torch.uint8))
             if threshold_filters:
                 # evaluation_engine.py:132-152: the CAMs resized to the ground truth's size, validated, then cam2mask with the box
                 # [0, -1, 0, -1] (Python slice semantics: the last row and column stay `ignore`, as in the reference) and no refine model
@@ -128,9 +140,9 @@ def evaluate(model, data_loader, args, df=None, save_result=False, save_rawcam=F
                 flush(group)
                 group = []
                 for i in range(inputs.shape[0]):
-                    flush([(inputs[i:i + 1], labels[i:i + 1], cls_label[i:i + 1])])
+                    flush([(inputs[i:i + 1], labels[i:i + 1], cls_label[i:i + 1], img_org[i:i + 1])])
                 continue
-            group.append((inputs, labels, cls_label))
+            group.append((inputs, labels, cls_label, img_org if getcrf else None))
             if len(group) >= max(1, int(eval_group)):
                 flush(group)
                 group = []
@@ -149,6 +161,8 @@ def evaluate(model, data_loader, args, df=None, save_result=False, save_rawcam=F
     metrics, names = [cam_score, cam_aux_score, seg_vd_score], ["CAM", "aux_CAM", "Seg_vd"]
     if isfinal:
         metrics, names = [seg_vd_score], ["Seg_vd"]
+    if getcrf:                                           # evaluation_engine.py:247-250
+        metrics, names = metrics + [meters["seg_crf"].scores()], names + ["Seg_crf"]
     if threshold_filters:                                # evaluation_engine.py:252-262: inserted after the first three rows
         tk = [f"cam_{t}" for t in threshold_filters] + [f"camaux_{t}" for t in threshold_filters]
         metrics = metrics[:3] + [meters[k].scores() for k in tk] + metrics[3:]
@@ -163,8 +177,9 @@ def evaluate(model, data_loader, args, df=None, save_result=False, save_rawcam=F
     df['mIoU'].extend(mioulist)
     df['Metrics'].extend(names)
     df['ST'].extend([s_or_t] * len(names))
-    # (as the reference, evaluation_engine.py:289: the LAST row -- with threshold_filters that is the last `camaux_<t>` row, not Seg_vd)
-    seg_vd_miou, cam_miou = mioulist[-1], mioulist[0]
+    # (as the reference, evaluation_engine.py:289: the last row, or the one before it with getcrf -- with threshold_filters that is a
+    # `cam_<t>` / `camaux_<t>` row, not Seg_vd)
+    seg_vd_miou, cam_miou = (mioulist[-1] if not getcrf else mioulist[-2]), mioulist[0]
     if get_camiou:
         return tab_results, seg_vd_miou, cam_miou, df, cls_aps
     return tab_results, seg_vd_miou, df, cls_aps

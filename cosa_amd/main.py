@@ -180,14 +180,15 @@ def main(args):
 
 @torch.no_grad()
 def finaleval(args):
-    """main.py:401-433: reload best_seg.pth (strict) into a fresh network and evaluate it on the validation split.  The reference adds
-    dense-CRF post-processing here (getcrf=True); that needs pydensecrf, which this image lacks, so the table is the pre-CRF one."""
+    """main.py:401-433: reload best_seg.pth (strict) into a fresh network and evaluate it on the test split with dense-CRF post-processing
+    (getcrf=True: rows Seg_vd and Seg_crf; the CRF is seg_helper.DenseCRF on the device lattice kernels)."""
     output_dir = Path(args.output_dir) if args.output_dir else Path(args.work_dir) / args.name
     device = torch.device("cuda", getattr(args, "gpu", 0))
     model = build_model(_trainer_args(args))
     torch_helper.load_best(model, args.bestseg_path, strict=True)
     model = model.to(device)
-    res = evaluate(model, build_test_loader(args), args, df=None, epoch='best1', isfinal=True)      # main.py:414: build_dataloader(is_train=False)
+    res = evaluate(model, build_test_loader(args), args, df=None, epoch='best1', isfinal=True, getcrf=True,   # main.py:414-425
+                   threshold_filters=None)
     if getattr(args, "rank", 0) == 0:
         print('Final Model Result:\n' + res[0], flush=True)
         with (output_dir / "log_val.txt").open("a") as f:

@@ -721,3 +721,76 @@ def cam_loss(cam, seg_ps, is_relu=True):
         cam = F.relu(cam)
     cam_flat = cam.float().permute(0, 2, 3, 1).reshape(B * H * W, C)
     return F.multilabel_soft_margin_loss(cam_flat, seg_ps_fg_flat)
+
+
+# --------------------------------------------------------------------------------------------
+# dense-CRF post-processing of the final evaluation  (utils/seg_helper.py:961-996)
+# --------------------------------------------------------------------------------------------
+class DenseCRF(object):
+    """utils/seg_helper.py:961-987, same constructor and call: `DenseCRF(...)(image [H,W,3] uint8, probmap [C,H,W])` -> Q [C,H,W].
+
+    The reference delegates to pydensecrf (DenseCRF2D: setUnaryEnergy(-log p), addPairwiseGaussian, addPairwiseBilateral, `iter_max`
+    mean-field steps).  That library is not in this image; its published algorithm (Kraehenbuehl & Koltun 2011) is two
+    permutohedral-lattice filters per step -- exactly what the bilateral regulariser of the training loop already runs on the device --
+    around a softmax:   Q <- softmax(-U + pos_w K_g(Q) + bi_w K_b(Q)),   K(v) = n F(n v),  n = 1 / sqrt(F(1) + 1e-20)  (symmetric
+    normalisation), F_g on the 2-D lattice of (x, y) / pos_xy_std, F_b on the 5-D lattice of (x, y) / bi_xy_std, rgb / bi_rgb_std.
+    Checked against oracle/crf_oracle.py (parity with pydensecrf itself is unpinned: no fixture of its output exists).
+    numpy in -> numpy out (the reference's types); CUDA tensors in -> CUDA tensor out."""
+
+    def __init__(self, iter_max, pos_w, pos_xy_std, bi_w, bi_xy_std, bi_rgb_std):
+        self.iter_max = iter_max
+        self.pos_w = pos_w
+        self.pos_xy_std = pos_xy_std
+        self.bi_w = bi_w
+        self.bi_xy_std = bi_xy_std
+        self.bi_rgb_std = bi_rgb_std
+
+    @staticmethod
+    def _filter_gauss(v, sxy):
+        K, H, W = v.shape
+        L = _C.lib()
+        ws = _C.workspace(L.cosa_lattice_filter_d2_workspace_bytes(1, K, H, W), v.device, "crf_d2")
+        out = torch.empty_like(v)
+        _C.check(L.cosa_lattice_filter_d2(_C.ptr(v), _C.ptr(out), 1, K, H, W, float(sxy), _C.ptr(ws), ws.numel(), _C.stream_ptr()),
+                 "cosa_lattice_filter_d2")
+        return out
+
+    @staticmethod
+    def _filter_bilateral(img, v, srgb, sxy):
+        K, H, W = v.shape
+        L = _C.lib()
+        ws = _C.workspace(L.cosa_bilateral_workspace_bytes(1, K, H, W), v.device, "bilateral")
+        out = torch.empty_like(v)
+        _C.check(L.cosa_bilateralfilter_batch_dev(_C.ptr(img), _C.ptr(v), _C.ptr(out), 1, K, H, W, float(srgb), float(sxy), None, _C.ptr(ws),
+                                                  ws.numel(), _C.stream_ptr()), "cosa_bilateralfilter_batch_dev")
+        return out
+
+    def __call__(self, image, probmap):
+        as_numpy = not torch.is_tensor(probmap)
+        dev = probmap.device if torch.is_tensor(probmap) and probmap.is_cuda else torch.device("cuda", torch.cuda.current_device())
+        prob = torch.as_tensor(np.ascontiguousarray(probmap) if as_numpy else probmap).to(dev).float().contiguous()
+        img = torch.as_tensor(np.ascontiguousarray(image) if not torch.is_tensor(image) else image).to(dev)
+        C, H, W = prob.shape
+        if img.shape != (H, W, 3):
+            raise ValueError("DenseCRF: image must be [H, W, 3] (the reference passes the de-normalised uint8 image, HWC)")
+        img = img.permute(2, 0, 1).float().contiguous()                                   # CHW planes 0..255, as the lattice kernels read them
+        U = -torch.log(prob.clamp(1e-5, 1.0))                                             # pydensecrf.utils.unary_from_softmax
+        one = torch.ones((1, H, W), device=dev)
+        n_g = torch.rsqrt(self._filter_gauss(one, self.pos_xy_std) + 1e-20)
+        n_b = torch.rsqrt(self._filter_bilateral(img, one, self.bi_rgb_std, self.bi_xy_std) + 1e-20)
+        Q = torch.softmax(-U, dim=0)
+        for _ in range(int(self.iter_max)):
+            t = -U + float(self.pos_w) * (n_g * self._filter_gauss((Q * n_g).contiguous(), self.pos_xy_std)) \
+                + float(self.bi_w) * (n_b * self._filter_bilateral(img, (Q * n_b).contiguous(), self.bi_rgb_std, self.bi_xy_std))
+            Q = torch.softmax(t, dim=0)
+        return Q.cpu().numpy() if as_numpy else Q
+
+
+crf_inference_infv2 = DenseCRF(       # utils/seg_helper.py:989-996
+    iter_max=1,
+    pos_xy_std=1,
+    pos_w=1,
+    bi_xy_std=121,
+    bi_rgb_std=5,
+    bi_w=4,
+)

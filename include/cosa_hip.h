@@ -326,6 +326,17 @@ int cosa_attn_fwd_bf16x3(const void *qkv_split, void *out_split, float *lse, int
                          int ldq, int ldo, void *stream);
 
 /* ---------------------------------------------------------------------------------------
+ * utils/seg_helper.py:961-996 (DenseCRF / crf_inference_infv2, final evaluation only): the position-only Gaussian kernel of the dense
+ * CRF -- pydensecrf's addPairwiseGaussian: features (x / sxy, y / sxy) -- as a permutohedral-lattice filter on a 2-D lattice (the lattice
+ * kernels of the bilateral filter, csrc/permuto_kernels.hip, compiled a second time with -DCOSA_PD=2).  ins / outs [N, K, H, W] fp32.
+ * The bilateral kernel of the CRF is cosa_bilateralfilter_batch_dev itself; the mean-field update around the two filters is host code
+ * (cosa_amd/utils/seg_helper.py: DenseCRF).  pydensecrf is not under the reference tree: parity of this row is unpinned (oracle/crf_oracle.py).
+ * ------------------------------------------------------------------------------------- */
+size_t cosa_lattice_filter_d2_workspace_bytes(int N, int K, int H, int W);
+int cosa_lattice_filter_d2(const float *ins, float *outs, int N, int K, int H, int W, float sigmaxy, void *workspace,
+                           size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------
  * fp16c8 operands: the parity-grade precision of the no-grad passes at 2x (not 3x) the MFMA work of the 16-bit path
  * (teacher pseudo-labels, utils/seg_helper.py:232-275; replaces the fp32 arithmetic of models/vit/vit.py:96-137 on the no-grad path).
  * A value v is carried as hi = fp16(v) plus two e5m2 bytes: hi8 = e5m2(hi) and lo8 = e5m2((v - hi) * 2^11); a product is

@@ -20,6 +20,9 @@ def build(force=False):
     src = os.path.join(_HERE, "cosa_oracle.c")
     if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
         subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
+    so2 = os.path.join(_HERE, "liboracle_d2.so")
+    if force or not os.path.exists(so2) or os.path.getmtime(so2) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "liboracle_d2.so"], stdout=subprocess.DEVNULL)
     ref_so = os.path.join(_HERE, "_ref", "libref_bilateral.so")
     if os.path.isdir("/root/reference") and (force or not os.path.exists(ref_so)):
         subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
@@ -150,6 +153,28 @@ def bilateralfilter_batch(images, ins, N, K, H, W, sigmargb, sigmaxy):
     if rc:
         raise RuntimeError("oracle: lattice key out of packable range")
     return outs.reshape(N, K, H, W), M
+
+
+_LIB2 = None
+
+
+def gaussian_filter_d2(ins, H, W, sigmaxy):
+    """position-only permutohedral filter (2-D lattice: the same C code as the bilateral filter, built with -DORC_PD=2): ins [K, H, W]"""
+    global _LIB2
+    if _LIB2 is None:
+        build()
+        _LIB2 = ctypes.CDLL(os.path.join(_HERE, "liboracle_d2.so"))
+        _LIB2.orc_bilateralfilter_batch.restype = ctypes.c_int
+        _LIB2.orc_bilateralfilter_batch.argtypes = [_f32p, _f32p, _f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                    ctypes.c_int, ctypes.c_float, ctypes.c_float, _i32p]
+    ins = _c(ins)
+    K = ins.shape[0]
+    outs = np.zeros_like(ins).reshape(-1)
+    M = np.zeros(1, np.int32)
+    dummy = np.zeros(3 * H * W, np.float32)
+    if _LIB2.orc_bilateralfilter_batch(dummy, ins.reshape(-1), outs, 1, K, H, W, 1.0, float(sigmaxy), M):
+        raise RuntimeError("oracle: lattice key out of packable range")
+    return outs.reshape(K, H, W), int(M[0])
 
 
 def dense_energy_forward(images, seg, roi, unlabel, sigmargb, sigmaxy):

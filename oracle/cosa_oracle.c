@@ -408,8 +408,15 @@ int orc_lowres_softmax_image(const float *cam, const float *label, int C, int S,
 /* lattice ids are assigned in first-touch order like the reference, so the   */
 /* splat summation order -- and therefore every output bit -- is the same.    */
 /* ------------------------------------------------------------------------- */
-#define PD 5            /* feature dimension */
-#define PD1 6
+/* The algorithm is dimension-generic.  ORC_PD = 5 (default) is the bilateral filter of the hot path: positions / sigma_xy and colours /
+ * sigma_rgb, pinned bit for bit by the reference's own C++ (tests/golden/bilateral.npz, oracle/_ref).  The SAME code built with -DORC_PD=2
+ * (liboracle_d2.so) is the position-only Gaussian kernel of the dense-CRF post-processing (utils/seg_helper.py:961-996 via pydensecrf's
+ * addPairwiseGaussian): features x / sxy, y / sxy.                                                                                  */
+#ifndef ORC_PD
+#define ORC_PD 5
+#endif
+#define PD ORC_PD       /* feature dimension */
+#define PD1 (ORC_PD + 1)
 
 typedef struct {
     int N, M;
@@ -468,14 +475,17 @@ int orc_lattice_init(orc_lattice *L, const float *image /* CHW 0..255 */, int H,
     }
     size_t hw = (size_t)H * W;
     for (int p = 0; p < Npad; p++) {
-        float f[PD] = {0, 0, 0, 0, 0};
+        float f[PD];
+        for (int i = 0; i < PD; i++) f[i] = 0.0f;
         if (p < N) {
             int xi = p % W, yj = p / W;
             f[0] = (float)xi / sigmaxy;
             f[1] = (float)yj / sigmaxy;
+#if ORC_PD == 5
             f[2] = image[p] / sigmargb;
             f[3] = image[hw + p] / sigmargb;
             f[4] = image[2 * hw + p] / sigmargb;
+#endif
         }
         float el[PD1], rem0[PD1], rank[PD1], bc[PD1 + 1];
         float sm = 0.0f;

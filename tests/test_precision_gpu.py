@@ -357,6 +357,7 @@ TEACHER_BARS = {
     "fp16": (4e-3, 0.9990, 0.995),
     "bf16x3": (1e-3, 0.999, 0.999),        # BASELINE.json north_star: 1e-3 relative on fp32 CAMs, mask IoU >= 0.999
     "fp16c8": (1e-3, 0.999, 0.999),        # the same bars at 2x (not 3x) the 16-bit MFMA work: the benchmarked parity-grade mode
+    "fp16c8-9": (1e-3, 0.999, 0.999),      # ... with the last three blocks on plain fp16 operands (measured margin: profiles/r03_accuracy_teacher.txt)
 }
 
 
@@ -381,7 +382,7 @@ def test_fused_teacher_vs_fp32_cpu_oracle(mode, S):
     for name, g, o, mg, mo in (("cam", cam, cam_o, masks[0], masks_o[0]), ("cam_aux", cam_aux, cam_aux_o, masks[1], masks_o[1])):
         rel = ((g.cpu() - o).abs().amax(dim=(2, 3)) / o.abs().amax(dim=(2, 3)).clamp_min(1e-6))[act].max().item()
         agree, iou = float(np.mean(mg == mo)), _miou(mg, mo)
-        lines.append(f"teacher {mode:7s} S={S} b=2 {name:8s}: normalised-CAM rel err {rel:.3e}  label agreement {agree:.5f}  mask mIoU {iou:.5f}")
+        lines.append(f"teacher {mode:8s} S={S} b=2 {name:8s}: normalised-CAM rel err {rel:.3e}  label agreement {agree:.5f}  mask mIoU {iou:.5f}")
         assert rel <= bar_rel and agree >= bar_agree and iou >= bar_iou, lines[-1]
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "r03_accuracy_teacher.txt"), "a") as f:
