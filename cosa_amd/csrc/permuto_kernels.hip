@@ -702,8 +702,8 @@ int filter_phase(const float *ins, float *outs, int N, int K, const float *roi, 
         hipLaunchKernelGGL(lattice_blur_kernel, dim3(gs, N), blk, 0, st, j, j & 1, P, B);
         COSA_LAUNCH_CHECK();
     }
-    // 6 passes: the result is back in val0
-    hipLaunchKernelGGL(lattice_slice_kernel, dim3((P.N + TP - 1) / TP, N), blk, lds, st, outs, K, 0, seg_for_energy, roi,
+    // d + 1 ping-pong passes: 6 (5-D lattice) leave the result in val0, 3 (2-D lattice) in val1
+    hipLaunchKernelGGL(lattice_slice_kernel, dim3((P.N + TP - 1) / TP, N), blk, lds, st, outs, K, PD1 & 1, seg_for_energy, roi,
                        unlabel, P, B);
     COSA_LAUNCH_CHECK();
     if (seg_for_energy) {
