@@ -153,6 +153,34 @@ __global__ __launch_bounds__(256) void c8_rows_kernel(const float *__restrict__ 
     c8_store_aug(d, K, lane, ones != 0, bias ? bias + row : nullptr);
 }
 
+// every weight matrix of a network in ONE launch (the teacher's c8 weight rows are rebuilt from the fp32 masters once per pass: 37 small
+// launches of ~9 us otherwise); a record per matrix, rows dealt to waves across all of them
+struct C8Rec {
+    const float *src;
+    const float *bias;
+    unsigned char *dst;
+    int rows, K, row0, pad;
+};
+
+__global__ __launch_bounds__(256) void c8_rows_batched_kernel(const C8Rec *__restrict__ recs, int nrec, int total_rows)
+{
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= total_rows) return;
+    const int lane = threadIdx.x & 63;
+    int r = 0;
+    while (r + 1 < nrec && recs[r + 1].row0 <= row) r++;
+    const C8Rec rec = recs[r];
+    const int lr = row - rec.row0, K = rec.K;
+    const float *s = rec.src + (size_t)lr * K;
+    unsigned char *d = rec.dst + (size_t)lr * (4 * K + 128);
+    for (int c = lane * 4; c < K; c += 256) {
+        const float4 f = *reinterpret_cast<const float4 *>(s + c);
+        const float v[4] = {f.x, f.y, f.z, f.w};
+        c8_store4(d, K, c, v);
+    }
+    c8_store_aug(d, K, lane, false, rec.bias ? rec.bias + lr : nullptr);
+}
+
 template <int D>
 __global__ __launch_bounds__(256) void layernorm_c8_kernel(const float *__restrict__ x, const float *__restrict__ g, const float *__restrict__ b,
                                                           unsigned char *__restrict__ y, float *__restrict__ y32, int rows, float eps)
@@ -233,6 +261,19 @@ extern "C" int cosa_layernorm_c8(const float *x, const float *gamma, const float
     COSA_REQUIRE(dim == 768, "cosa_layernorm_c8: dim must be 768 (ViT-B)");
     hipLaunchKernelGGL(layernorm_c8_kernel<768>, dim3((rows + 3) / 4), dim3(256), 0, as_stream(stream), x, gamma, beta,
                        static_cast<unsigned char *>(y_c8), y_f32, rows, eps);
+    COSA_LAUNCH_CHECK();
+    return COSA_OK;
+}
+
+/* c8 rows of several fp32 matrices (each [rows, K] contiguous, K % 128 == 0, optional bias [rows]) in one launch.  records: device array of
+ * { const float *src; const float *bias; void *dst; int rows, K, row0, pad } (cosa_c8_record_bytes() each), row0 = running sum of rows */
+extern "C" size_t cosa_c8_record_bytes(void) { return sizeof(C8Rec); }
+
+extern "C" int cosa_c8_rows_batched(const void *records, int n_records, int total_rows, void *stream)
+{
+    COSA_REQUIRE(records && n_records > 0 && total_rows > 0, "cosa_c8_rows_batched: bad arguments");
+    hipLaunchKernelGGL(c8_rows_batched_kernel, dim3((total_rows + 3) / 4), dim3(256), 0, as_stream(stream), static_cast<const C8Rec *>(records),
+                       n_records, total_rows);
     COSA_LAUNCH_CHECK();
     return COSA_OK;
 }

@@ -9,6 +9,7 @@
 //                          (no atomics) -- replaces layer_norm_grad_input + 2 gamma/beta kernels + the gradient add.
 // HBM-bound: 8 B per element forward, 8 B backward.  One wave per row, 12 elements per lane (D = 768).
 #include "kernels.hpp"
+#include "c8.hpp"
 #include <cstdlib>
 
 namespace cosa {
@@ -432,6 +433,52 @@ __global__ __launch_bounds__(256) void im2col_flip_kernel(const float *__restric
     reinterpret_cast<t8 *>(cols)[e] = o;
 }
 
+// the same rows as fp16c8 operand rows (c8.hpp: hi fp16 | lo8 | hi8 | aug = (1, 1, 0, ...)): the patch projection of the parity-grade teacher
+__global__ __launch_bounds__(256) void im2col_flip_c8_kernel(const float *__restrict__ x, unsigned char *__restrict__ rows, int B, int C, int H, int W, int P,
+                                                            int flips)
+{
+    const int h = H / P, w = W / P, KC = C * P * P, K8 = KC / 8;
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t total = (size_t)flips * B * h * w * K8;
+    if (e >= total) return;
+    const int k8 = (int)(e % K8), k = k8 * 8;
+    const size_t row_id = e / K8;
+    size_t row = row_id;
+    const int px = (int)(row % w);
+    row /= w;
+    const int py = (int)(row % h);
+    row /= h;
+    const int b = (int)(row % B), f = (int)(row / B);
+    const int c = k / (P * P), dy = (k - c * P * P) / P, dx = k % P;
+    const float *src = x + (((size_t)b * C + c) * H + (size_t)P * py + dy) * W;
+    const int x0 = P * px + dx;
+    float v[8];
+    if (!f) {
+        const float4 a = *reinterpret_cast<const float4 *>(src + x0), d = *reinterpret_cast<const float4 *>(src + x0 + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = d.x; v[5] = d.y; v[6] = d.z; v[7] = d.w;
+    } else {
+        const int xe = W - 8 - x0;
+        const float4 a = *reinterpret_cast<const float4 *>(src + xe), d = *reinterpret_cast<const float4 *>(src + xe + 4);
+        v[0] = d.w; v[1] = d.z; v[2] = d.y; v[3] = d.x; v[4] = a.w; v[5] = a.z; v[6] = a.y; v[7] = a.x;
+    }
+    unsigned char *r = rows + row_id * (size_t)(4 * KC + 128);
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    h8 hi;
+    unsigned lo8[2], hi8[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const float vv[4] = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+        _Float16 hh[4];
+        c8_split4(vv, hh, lo8[q], hi8[q]);
+#pragma unroll
+        for (int j = 0; j < 4; j++) hi[4 * q + j] = hh[j];
+    }
+    *reinterpret_cast<h8 *>(r + 2 * k) = hi;
+    *reinterpret_cast<uint2 *>(r + 2 * KC + k) = make_uint2(lo8[0], lo8[1]);
+    *reinterpret_cast<uint2 *>(r + 3 * KC + k) = make_uint2(hi8[0], hi8[1]);
+    if (k8 < 8) *reinterpret_cast<uint4 *>(r + 4 * KC + 16 * k8) = k8 == 0 ? make_uint4(0x3c003c00u, 0u, 0u, 0u) : make_uint4(0u, 0u, 0u, 0u);
+}
+
 // ---- token assembly of the no-grad encoder passes (vit.py:303-313: cat(cls, patch tokens) + pos_embed) straight into the fp32 residual
 // stream: out[b][0] = cls + pos[0], out[b][1 + i] = tok[b][i] + pos[1 + i], each sum rounded to the 16-bit operand type first (what the
 // 16-bit torch expression did) and then widened.  One pass instead of cat + add + float() + the concatenation of the scales.
@@ -639,10 +686,13 @@ extern "C" int cosa_im2col_flip(const float *x, void *cols, int B, int C, int H,
 {
     COSA_REQUIRE(x && cols && B > 0 && C > 0 && H > 0 && W > 0 && P > 0, "cosa_im2col_flip: bad arguments");
     COSA_REQUIRE(P % 8 == 0 && H % P == 0 && W % P == 0 && W % 4 == 0, "cosa_im2col_flip: patch size must be a multiple of 8 and divide H and W (got P=%d H=%d W=%d)", P, H, W);
-    COSA_REQUIRE((flips == 1 || flips == 2) && (dtype == 1 || dtype == 2), "cosa_im2col_flip: flips 1 | 2, dtype 1 (bf16) | 2 (fp16)");
+    COSA_REQUIRE((flips == 1 || flips == 2) && (dtype >= 1 && dtype <= 3), "cosa_im2col_flip: flips 1 | 2, dtype 1 (bf16) | 2 (fp16) | 3 (fp16c8 rows)");
+    COSA_REQUIRE(dtype != 3 || (C * P * P) % 128 == 0, "cosa_im2col_flip: fp16c8 rows need C*P*P %% 128 == 0");
     const size_t total = (size_t)flips * B * (H / P) * (W / P) * (C * P * P / 8);
     const unsigned grid = (unsigned)((total + 255) / 256);
-    if (dtype == 1)
+    if (dtype == 3)
+        hipLaunchKernelGGL(im2col_flip_c8_kernel, dim3(grid), dim3(256), 0, as_stream(stream), x, static_cast<unsigned char *>(cols), B, C, H, W, P, flips);
+    else if (dtype == 1)
         hipLaunchKernelGGL(im2col_flip_kernel<bf16>, dim3(grid), dim3(256), 0, as_stream(stream), x, static_cast<bf16 *>(cols), B, C, H, W, P, flips);
     else
         hipLaunchKernelGGL(im2col_flip_kernel<_Float16>, dim3(grid), dim3(256), 0, as_stream(stream), x, static_cast<_Float16 *>(cols), B, C, H, W, P, flips);

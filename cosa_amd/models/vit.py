@@ -189,7 +189,7 @@ class VisionTransformer(nn.Module):
         if self.precision == "bf16x3":
             return self._forward_features_x3_multi([torch.cat([x, x.flip(-1)], dim=0) for x in xs] if flip_pairs else xs)
         if self.precision == "fp16c8":
-            return self._forward_features_c8_multi([torch.cat([x, x.flip(-1)], dim=0) for x in xs] if flip_pairs else xs)
+            return self._forward_features_c8_multi(xs, flip_pairs)
         dt16 = self.compute_dtype                                # bf16, or fp16 (no-grad passes only: same kernels, fp16 operands)
         c = lambda p_: nn_ops.cast_param(p_, dt16)
         D = self.embed_dim
@@ -332,21 +332,32 @@ class VisionTransformer(nn.Module):
     # -- parity-grade no-grad path at 2x: fp16 operands + 8-bit correction terms (fp16c8; csrc/c8.hpp), fp32 residual / LayerNorm / CAM heads;
     #    attention on plain fp16 q, k, v (its OUTPUT leaves as c8 rows): tools/sim_precision_map.py is the sensitivity study behind this map
     def _c8_weights(self):
-        """c8 rows [N, 2K+64 fp16 units] (bias in the augmentation block) of the patch projection and the 48 block projections, rebuilt
-        from the fp32 masters on every pass (the teacher's masters move every step; part of the captured graph)"""
-        ws = self.__dict__.setdefault("_c8_w", {})
+        """c8 rows [N, 2K+64 fp16 units] (bias in the augmentation block) of the patch projection and the block projections, rebuilt from the
+        fp32 masters on every pass (the teacher's masters move every step; part of the captured graph) by ONE batched launch"""
+        import numpy as np
+        from .. import _C
         items = [("patch", self.patch_embed.proj.weight.reshape(self.embed_dim, -1), self.patch_embed.proj.bias)]
         for i, blk in enumerate(self.blocks):
             if self.c8_plain_from is not None and i >= self.c8_plain_from:
                 continue
             items += [(f"{i}.qkv", blk.attn.qkv.weight, blk.attn.qkv.bias), (f"{i}.proj", blk.attn.proj.weight, blk.attn.proj.bias),
                       (f"{i}.fc1", blk.mlp.fc1.weight, blk.mlp.fc1.bias), (f"{i}.fc2", blk.mlp.fc2.weight, blk.mlp.fc2.bias)]
-        for name, w, b in items:
-            buf = ws.get(name)
-            if buf is None or buf.device != w.device:
-                buf = ws[name] = torch.empty((w.shape[0], nn_ops.split_ld(w.shape[1])), device=w.device, dtype=torch.float16)
-            nn_ops.c8_rows(w.detach(), bias=b.detach(), out=buf)
-        return ws
+        ent = self.__dict__.get("_c8_w")
+        key = tuple((n, w.data_ptr(), b.data_ptr()) for n, w, b in items)
+        if ent is None or ent["key"] != key:
+            dev = items[0][1].device
+            bufs = {n: torch.empty((w.shape[0], nn_ops.split_ld(w.shape[1])), device=dev, dtype=torch.float16) for n, w, _ in items}
+            rec_dt = np.dtype([("src", "u8"), ("bias", "u8"), ("dst", "u8"), ("rows", "i4"), ("K", "i4"), ("row0", "i4"), ("pad", "i4")])
+            assert rec_dt.itemsize == _C.lib().cosa_c8_record_bytes()
+            rec, row0 = np.zeros(len(items), rec_dt), 0
+            for j, (n, w, b) in enumerate(items):
+                assert w.dtype == torch.float32 and w.is_contiguous() and w.shape[1] % 128 == 0
+                rec[j] = (w.data_ptr(), b.data_ptr(), bufs[n].data_ptr(), w.shape[0], w.shape[1], row0, 0)
+                row0 += w.shape[0]
+            ent = self.__dict__["_c8_w"] = {"key": key, "bufs": bufs, "rec": torch.from_numpy(rec.view(np.uint8).copy()).to(dev),
+                                            "n": len(items), "rows": row0}
+        _C.check(_C.lib().cosa_c8_rows_batched(_C.ptr(ent["rec"]), ent["n"], ent["rows"], _C.stream_ptr()), "cosa_c8_rows_batched")
+        return ent["bufs"]
 
     def _c8_buffers(self, M, dev):
         """persistent activations for M token rows; the (1, 1, 0, ...) augmentation block of the fc1 output is set once here (the GEMM
@@ -361,23 +372,34 @@ class VisionTransformer(nn.Module):
             bufs[(M, dev)] = ent
         return ent
 
-    def _forward_features_c8_multi(self, xs):
+    def _forward_features_c8_multi(self, xs, flip_pairs=False):
+        from .. import _C
         D, H = self.embed_dim, self.num_heads
         p = self.patch_size
         W = self._c8_weights()
-        cols, pos_rows, cls_rows, shapes = [], [], [], []
+        nf = 2 if flip_pairs else 1                                                     # flip_pairs: every batch stands for cat(x, x.flip(-1))
+        pos_rows, cls_rows, shapes, geo = [], [], [], []
         for x in xs:
             B, nc, Hh, Ww = x.shape
+            B *= nf
             h, w = Hh // p, Ww // p
-            cols.append(x.float().reshape(B, nc, h, p, w, p).permute(0, 2, 4, 1, 3, 5).reshape(B * h * w, nc * p * p))
             pos = self._pos_for_grid(h, w, torch.float32)                              # [1, n+1, D]
             pos_rows.append(pos[:, 1:].expand(B, -1, -1).reshape(B * h * w, D))         # residual operand of the patch GEMM: the position rows
             cls_rows.append((self.cls_token.detach().float() + pos[:, :1]).expand(B, -1, -1))
             shapes.append((B, h * w + 1))
-        # the patch projection of ALL scales in one launch (token-wise, like the block projections)
-        cols = cols[0].contiguous() if len(cols) == 1 else torch.cat(cols, 0)
+            geo.append(B * h * w)
+        # the patch projection of ALL scales in one launch (token-wise, like the block projections); its c8 operand rows (images and their
+        # mirror images) come straight from the im2col kernel
+        Kp = xs[0].shape[1] * p * p
+        cols = torch.empty((sum(geo), nn_ops.split_ld(Kp)), device=xs[0].device, dtype=torch.float16)
+        r0 = 0
+        for x, rows in zip(xs, geo):
+            xf = x.float().contiguous()
+            _C.check(_C.lib().cosa_im2col_flip(_C.ptr(xf), _C.ptr(cols[r0:r0 + rows]), x.shape[0], x.shape[1], x.shape[2], x.shape[3], p, nf, 3,
+                                               _C.stream_ptr()), "cosa_im2col_flip")
+            r0 += rows
         tok = pos_rows[0].contiguous() if len(pos_rows) == 1 else torch.cat(pos_rows, 0)
-        nn_ops.gemm_c8(nn_ops.c8_rows(cols, ones=True), W["patch"], cols.shape[0], D, cols.shape[1], nn_ops.EPI_RESIDUAL, residual=tok, out=tok)
+        nn_ops.gemm_c8(cols, W["patch"], cols.shape[0], D, Kp, nn_ops.EPI_RESIDUAL, residual=tok, out=tok)
         toks, r0 = [], 0
         for (B, N), cls in zip(shapes, cls_rows):
             toks.append(torch.cat((cls, tok[r0:r0 + B * (N - 1)].view(B, N - 1, D)), dim=1).reshape(-1, D))

@@ -734,7 +734,8 @@ class DenseCRF(object):
     permutohedral-lattice filters per step -- exactly what the bilateral regulariser of the training loop already runs on the device --
     around a softmax:   Q <- softmax(-U + pos_w K_g(Q) + bi_w K_b(Q)),   K(v) = n F(n v),  n = 1 / sqrt(F(1) + 1e-20)  (symmetric
     normalisation), F_g on the 2-D lattice of (x, y) / pos_xy_std, F_b on the 5-D lattice of (x, y) / bi_xy_std, rgb / bi_rgb_std.
-    Checked against oracle/crf_oracle.py (parity with pydensecrf itself is unpinned: no fixture of its output exists).
+    Checked in the test-suite against a CPU restatement of the same algorithm (parity with pydensecrf itself is unpinned: no fixture
+    of its output exists).
     numpy in -> numpy out (the reference's types); CUDA tensors in -> CUDA tensor out."""
 
     def __init__(self, iter_max, pos_w, pos_xy_std, bi_w, bi_xy_std, bi_rgb_std):

@@ -242,7 +242,8 @@ void cosa_gemm_set_grid_policy_f16(int balanced);
 void cosa_gemm_set_stamp_slot(void *slot);
 /* vit.py:254-262 (PatchEmbed: stride-16 conv) as a GEMM needs the image as im2col rows; the teacher's passes run every scale as
  * cat(x, x.flip(-1)) (seg_helper.py:241-246).  cols [flips*B*(H/P)*(W/P), C*P*P] in a 16-bit type (dtype 1 = bf16, 2 = fp16) from
- * x [B,C,H,W] fp32: rows of the images first, then (flips = 2) of their horizontal mirror images.  P % 8 == 0, P | H, P | W.        */
+ * x [B,C,H,W] fp32: rows of the images first, then (flips = 2) of their horizontal mirror images.  P % 8 == 0, P | H, P | W.
+ * dtype 3: the rows as fp16c8 operand rows (hi fp16 | lo8 | hi8 | aug = (1, 1, 0, ...), 4*C*P*P + 128 bytes each; see cosa_c8_rows).    */
 int cosa_im2col_flip(const float *x, void *cols, int B, int C, int H, int W, int P, int flips, int dtype, void *stream);
 /* vit.py:303-313 (prepare_tokens: cat(cls_token, patch tokens) + interpolated pos_embed) for the no-grad passes, written straight into
  * the fp32 residual stream: out [B, n+1, D] = (cls [D] | tok [B, n, D]) + pos [n+1, D]; tok / cls / pos share one 16-bit type
@@ -354,6 +355,8 @@ int cosa_lattice_filter_d2(const float *ins, float *outs, int N, int K, int H, i
  *                         block) for the c8 output projection; lse optional
  * ------------------------------------------------------------------------------------- */
 int cosa_c8_rows(const float *src, const float *bias, void *dst, int R, int K, long long src_ld, int ones, void *stream);
+size_t cosa_c8_record_bytes(void);       /* { const float *src; const float *bias; void *dst; int rows, K, row0, pad; } */
+int cosa_c8_rows_batched(const void *records /* device */, int n_records, int total_rows, void *stream);   /* all weight matrices, one launch */
 int cosa_layernorm_c8(const float *x, const float *gamma, const float *beta, void *y_c8, float *y_f32, int rows, int dim,
                       float eps, void *stream);
 int cosa_gemm_f16c8(const void *Xs, const void *Ws, const void *zeros, const float *residual, void *Y,

@@ -219,6 +219,37 @@ def test_c8_rows_and_layernorm_c8_fields():
     assert torch.equal(aug[:, :2].cpu(), torch.ones(1000, 2)) and aug[:, 2:].abs().max().item() == 0
 
 
+def test_im2col_c8_and_batched_weight_rows_equal_the_row_producer():
+    """cosa_im2col_flip(dtype 3) = c8_rows of the im2col view of cat(x, x.flip(-1)); cosa_c8_rows_batched (all weight matrices of a network in
+    one launch) = c8_rows per matrix -- both bit for bit"""
+    from cosa_amd import nn_ops, _C
+    from cosa_amd.models import build_model
+    from cosa_amd.train_step import default_args
+    L = _C.lib()
+    torch.manual_seed(5)
+    for B, H, W in ((3, 64, 96), (2, 224, 224), (1, 16, 16)):
+        x = torch.randn(B, 3, H, W, device="cuda") * 2
+        p = 16
+        h, w = H // p, W // p
+        for flips in (1, 2):
+            rows = torch.full((flips * B * h * w + 1, nn_ops.split_ld(768)), 7.0, device="cuda", dtype=torch.float16)      # one canary row
+            _C.check(L.cosa_im2col_flip(_C.ptr(x), _C.ptr(rows), B, 3, H, W, p, flips, 3, _C.stream_ptr()), "im2col")
+            xx = torch.cat([x, x.flip(-1)], 0) if flips == 2 else x
+            cols = xx.reshape(flips * B, 3, h, p, w, p).permute(0, 2, 4, 1, 3, 5).reshape(flips * B * h * w, 768).contiguous()
+            assert torch.equal(rows[:-1].view(torch.int16), nn_ops.c8_rows(cols, ones=True).view(torch.int16)) and torch.all(rows[-1] == 7.0)
+    net = build_model(default_args("VOC12", crop_size=64)).cuda().eval()
+    net.set_nograd_precision("fp16c8-9")
+    with torch.no_grad():
+        for q in net.parameters():
+            q.add_(torch.randn_like(q) * 0.01)                                        # (biases are zero-initialised)
+    ws = net.encoder._c8_weights()
+    assert len(ws) == 1 + 4 * 9 and "9.qkv" not in ws
+    blk = net.encoder.blocks[3]
+    for name, wgt, b in (("patch", net.encoder.patch_embed.proj.weight.reshape(768, -1), net.encoder.patch_embed.proj.bias),
+                         ("3.qkv", blk.attn.qkv.weight, blk.attn.qkv.bias), ("3.fc2", blk.mlp.fc2.weight, blk.mlp.fc2.bias)):
+        assert torch.equal(ws[name].view(torch.int16), nn_ops.c8_rows(wgt.detach().contiguous(), bias=b.detach()).view(torch.int16)), name
+
+
 @pytest.mark.parametrize("epi", [0, 1, 2])
 def test_gemm_f16c8_vs_fp64(epi):
     """fp16 x fp16 on the 16-bit MFMA + two e5m2 correction terms on the block-scaled MFMA (K = 128 per instruction, E8M0 scale 2^-11).
