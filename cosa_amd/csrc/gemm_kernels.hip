@@ -276,404 +276,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const op16 *__restric
 
 
 // =====================================================================================================
-// v2: 256 (tokens) x 128 (features) x 64 tile, 8 waves (4 x 2, each 64 x 64), THREE LDS stages.
-// One raw s_barrier per K-step and a counted s_waitcnt: the global_load_lds of the next stage stays in
-// flight across the barrier (the 2-stage kernel above drains vmcnt(0) every step).  One workgroup per CU
-// (144 KB LDS), two waves per SIMD.
-// =====================================================================================================
-constexpr int V2_BM = 256, V2_BN = 128;
-constexpr int V2_STAGE = (V2_BM + V2_BN) * 128;        // 48 KB: W tile (128 rows) then X tile (256 rows), 128 B per row
-constexpr int V2_CT_LD_BF16 = 272, V2_CT_LD_F32 = 528;
-
-__device__ __forceinline__ void stage_v2(const op16 *__restrict__ W, const op16 *__restrict__ X, int n0, int m0, int M, int K,
-                                         int k0, unsigned char *stage, int wave, int lane)
-{
-#pragma unroll
-    for (int i = 0; i < 6; i++) {
-        const int q = wave * 6 + i;                    // 48 one-KiB pieces: 0..15 -> W rows, 16..47 -> X rows
-        const int row = 8 * q + (lane >> 3);           // row inside the 384-row stage image
-        const int s = (lane & 7) ^ (row & 7);
-        const op16 *g;
-        if (q < 16) g = W + (size_t)(n0 + row) * K + k0 + s * 8;
-        else {
-            int gm = m0 + row - 128;
-            gm = gm < M ? gm : M - 1;
-            g = X + (size_t)gm * K + k0 + s * 8;
-        }
-        __builtin_amdgcn_global_load_lds((gbl_void *)g, (lds_void *)(stage + q * 1024), 16, 0, 0);
-    }
-}
-
-template <int EPI>
-__global__ __launch_bounds__(512, 1) void gemm_bf16_v2_kernel(const op16 *__restrict__ X, const op16 *__restrict__ W,
-                                                             const op16 *__restrict__ bias, const float *__restrict__ R,
-                                                             void *__restrict__ Yv, int M, int N, int K, int tiles_m, int tiles_n)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int nwg = tiles_m * tiles_n;
-    int wg = blockIdx.x;
-    {
-        const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7, idx = wg >> 3;
-        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int tm = wg / tiles_n, tn = wg - tm * tiles_n;
-    const int m0 = tm * V2_BM, n0 = tn * V2_BN;
-    const int wm = wave >> 1, wn = wave & 1;           // wave tile: tokens [wm*64,+64) x features [wn*64,+64)
-
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    const int nk = K / BK;
-    stage_v2(W, X, n0, m0, M, K, 0, smem, wave, lane);
-    if (nk > 1) stage_v2(W, X, n0, m0, M, K, BK, smem + V2_STAGE, wave, lane);
-
-    const int frow = lane & 15, fq = lane >> 4;
-    for (int kt = 0; kt < nk; kt++) {
-        // stage kt has landed once at most the 6 loads of stage kt+1 are still outstanding
-        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (kt + 2 < nk) stage_v2(W, X, n0, m0, M, K, (kt + 2) * BK, smem + ((kt + 2) % 3) * V2_STAGE, wave, lane);
-        const unsigned char *cur = smem + (kt % 3) * V2_STAGE;
-        const unsigned char *At = cur + (wn * 64) * 128;              // W rows (features)
-        const unsigned char *Bt = cur + 128 * 128 + (wm * 64) * 128;  // X rows (tokens)
-#pragma unroll
-        for (int ks = 0; ks < 2; ks++) {
-            op16x8 a[4], b[4];
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const int row = i * 16 + frow;
-                const int slot = ((fq + 4 * ks) ^ (row & 7)) << 4;
-                a[i] = *reinterpret_cast<const op16x8 *>(At + row * 128 + slot);
-                b[i] = *reinterpret_cast<const op16x8 *>(Bt + row * 128 + slot);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-#pragma unroll
-                for (int j = 0; j < 4; j++)
-                    acc[i][j] = COSA_MFMA_16x16x32(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
-    }
-    __syncthreads();      // every wave is done reading the last stage before the tile image is overwritten
-
-    // epilogue: acc[i][j][r] -> feature n = wn*64 + 16i + 4fq + r, token m = wm*64 + 16j + frow
-    unsigned char *Ct = smem;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int nl = wn * 64 + 16 * i + 4 * fq;
-        float bv[4];
-#pragma unroll
-        for (int r = 0; r < 4; r++) bv[r] = (float)bias[n0 + nl + r];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int ml = wm * 64 + 16 * j + frow;
-            if (EPI == EPI_RESIDUAL) {
-                f32x4 v;
-#pragma unroll
-                for (int r = 0; r < 4; r++) v[r] = acc[i][j][r] + bv[r];
-                *reinterpret_cast<f32x4 *>(Ct + ml * V2_CT_LD_F32 + nl * 4) = v;
-            } else {
-                op16x4 v;
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    float t = acc[i][j][r] + bv[r];
-                    if (EPI == EPI_GELU) t = gelu_erf(t);
-                    v[r] = (op16)t;
-                }
-                *reinterpret_cast<op16x4 *>(Ct + ml * V2_CT_LD_BF16 + nl * 2) = v;
-            }
-        }
-    }
-    __syncthreads();
-    if (EPI == EPI_RESIDUAL) {
-        float *Y = static_cast<float *>(Yv);
-#pragma unroll
-        for (int c = tid; c < V2_BM * 32; c += 512) {
-            const int ml = c >> 5, s = c & 31;
-            if (m0 + ml < M) {
-                const f32x4 v = *reinterpret_cast<const f32x4 *>(Ct + ml * V2_CT_LD_F32 + s * 16);
-                const size_t o = (size_t)(m0 + ml) * N + n0 + s * 4;
-                const f32x4 rv = *reinterpret_cast<const f32x4 *>(R + o);
-                *reinterpret_cast<f32x4 *>(Y + o) = v + rv;
-            }
-        }
-    } else {
-        op16 *Y = static_cast<op16 *>(Yv);
-#pragma unroll
-        for (int c = tid; c < V2_BM * 16; c += 512) {
-            const int ml = c >> 4, s = c & 15;
-            if (m0 + ml < M)
-                *reinterpret_cast<uint4 *>(Y + (size_t)(m0 + ml) * N + n0 + s * 8) =
-                    *reinterpret_cast<const uint4 *>(Ct + ml * V2_CT_LD_BF16 + s * 16);
-        }
-    }
-}
-
-constexpr size_t kLdsBytesV2 = 3 * V2_STAGE;      // 147456 >= 256*528 (fp32 epilogue tile)
-
-
-// =====================================================================================================
-// v3: 256 (features) x 256 (tokens) x 64 tile, 8 waves as 2 x 4, each wave 128 features x 64 tokens
-// (8 x 4 MFMA 16x16x32 accumulators).  Compared with the 128x128 kernel this halves the global->LDS
-// staging per flop and cuts LDS fragment reads per MFMA from 0.5 to 0.375 (12 ds_read_b128 per 32 MFMAs):
-// the 128^2 kernel sits at 37 % MFMA-busy with the LDS pipe about as busy as the matrix pipe.
-// Two LDS stages of 64 KB; one workgroup per CU; used for N >= 2304 where the tile count quantises well.
-// =====================================================================================================
-constexpr int V3_T = 256;
-constexpr int V3_STAGE = 2 * V3_T * 128;               // 64 KB: W tile (256 rows) then X tile (256 rows)
-
-__device__ __forceinline__ void stage_v3(const op16 *__restrict__ W, const op16 *__restrict__ X, int n0, int m0, int M, int K,
-                                         int k0, unsigned char *stage, int wave, int lane)
-{
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const int q = wave * 8 + i;                    // 64 one-KiB pieces: 0..31 -> W rows, 32..63 -> X rows
-        const int row = 8 * q + (lane >> 3);
-        const int s = (lane & 7) ^ (row & 7);
-        const op16 *g;
-        if (q < 32) g = W + (size_t)(n0 + row) * K + k0 + s * 8;
-        else {
-            int gm = m0 + row - V3_T;
-            gm = gm < M ? gm : M - 1;
-            g = X + (size_t)gm * K + k0 + s * 8;
-        }
-        __builtin_amdgcn_global_load_lds((gbl_void *)g, (lds_void *)(stage + q * 1024), 16, 0, 0);
-    }
-}
-
-template <int EPI>
-__global__ __launch_bounds__(512, 1) void gemm_bf16_v3_kernel(const op16 *__restrict__ X, const op16 *__restrict__ W,
-                                                             const op16 *__restrict__ bias, const float *__restrict__ R,
-                                                             void *__restrict__ Yv, int M, int N, int K, int tiles_m, int tiles_n)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int nwg = tiles_m * tiles_n;
-    int wg = blockIdx.x;
-    {
-        const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7, idx = wg >> 3;
-        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int tm = wg / tiles_n, tn = wg - tm * tiles_n;
-    const int m0 = tm * V3_T, n0 = tn * V3_T;
-    const int wa = wave >> 2, wb = wave & 3;           // features [wa*128,+128) x tokens [wb*64,+64)
-
-    f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; i++)
-#pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    const int nk = K / BK;
-    stage_v3(W, X, n0, m0, M, K, 0, smem, wave, lane);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    const int frow = lane & 15, fq = lane >> 4;
-    for (int kt = 0; kt < nk; kt++) {
-        const unsigned char *cur = smem + (kt & 1) * V3_STAGE;
-        if (kt + 1 < nk) stage_v3(W, X, n0, m0, M, K, (kt + 1) * BK, smem + ((kt + 1) & 1) * V3_STAGE, wave, lane);
-        const unsigned char *At = cur + (wa * 128) * 128;
-        const unsigned char *Bt = cur + V3_T * 128 + (wb * 64) * 128;
-#pragma unroll
-        for (int ks = 0; ks < 2; ks++) {
-            op16x8 a[8], b[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int row = j * 16 + frow;
-                b[j] = *reinterpret_cast<const op16x8 *>(Bt + row * 128 + (((fq + 4 * ks) ^ (row & 7)) << 4));
-            }
-#pragma unroll
-            for (int i = 0; i < 8; i++) {
-                const int row = i * 16 + frow;
-                a[i] = *reinterpret_cast<const op16x8 *>(At + row * 128 + (((fq + 4 * ks) ^ (row & 7)) << 4));
-            }
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int i = 0; i < 8; i++)
-#pragma unroll
-                for (int j = 0; j < 4; j++)
-                    acc[i][j] = COSA_MFMA_16x16x32(a[i], b[j], acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    }
-
-    // epilogue.  acc[i][j][r]: feature n = wa*128 + 16i + 4fq + r, token m = wb*64 + 16j + frow.
-    if (EPI == EPI_RESIDUAL) {
-        // fp32 out: each lane holds 4 consecutive features of a token = one 16-byte residual load + store, no LDS round trip
-        float *Y = static_cast<float *>(Yv);
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const int n = n0 + wa * 128 + 16 * i + 4 * fq;
-            const f32x4 bv = {(float)bias[n], (float)bias[n + 1], (float)bias[n + 2], (float)bias[n + 3]};
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int m = m0 + wb * 64 + 16 * j + frow;
-                if (m < M) {
-                    const size_t o = (size_t)m * N + n;
-                    const f32x4 rv = *reinterpret_cast<const f32x4 *>(R + o);
-                    *reinterpret_cast<f32x4 *>(Y + o) = acc[i][j] + bv + rv;
-                }
-            }
-        }
-    } else {
-        // op16 out through LDS in two 128-feature halves (the wave row wa owns one half each)
-        op16 *Y = static_cast<op16 *>(Yv);
-        unsigned char *Ct = smem;
-#pragma unroll
-        for (int half = 0; half < 2; half++) {
-            if (wa == half) {
-#pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    const int nl = 16 * i + 4 * fq;
-                    float bv[4];
-#pragma unroll
-                    for (int r = 0; r < 4; r++) bv[r] = (float)bias[n0 + half * 128 + nl + r];
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const int ml = wb * 64 + 16 * j + frow;
-                        op16x4 v;
-#pragma unroll
-                        for (int r = 0; r < 4; r++) {
-                            float t = acc[i][j][r] + bv[r];
-                            if (EPI == EPI_GELU) t = gelu_erf(t);
-                            v[r] = (op16)t;
-                        }
-                        *reinterpret_cast<op16x4 *>(Ct + ml * CT_LD + nl * 2) = v;
-                    }
-                }
-            }
-            __syncthreads();
-#pragma unroll
-            for (int c = tid; c < V3_T * 16; c += 512) {
-                const int ml = c >> 4, s = c & 15;
-                if (m0 + ml < M)
-                    *reinterpret_cast<uint4 *>(Y + (size_t)(m0 + ml) * N + n0 + half * 128 + s * 8) =
-                        *reinterpret_cast<const uint4 *>(Ct + ml * CT_LD + s * 16);
-            }
-            __syncthreads();
-        }
-    }
-}
-
-
-// =====================================================================================================
-// v4: the v3 tile (256 x 256 x 64, 8 waves of 128 x 64) as a PERSISTENT kernel: one workgroup per CU walks its
-// tiles, and the first K-stage of the next tile is fetched (global_load_lds) during the last K-step of the
-// current one, so neither the first-stage latency nor the tile index arithmetic sits between two tiles.  The
-// epilogue goes straight from the accumulators to memory (each lane owns 4 consecutive features of a token:
-// 8-byte op16 / 16-byte fp32 stores), which leaves LDS free for that prefetch.  With K = 768 a tile is only
-// 12 K-steps long, and the non-persistent kernels spend ~25 % of their time in pro/epilogue.
-// =====================================================================================================
-template <int EPI>
-__global__ __launch_bounds__(512, 1) void gemm_bf16_v4_kernel(const op16 *__restrict__ X, const op16 *__restrict__ W,
-                                                             const op16 *__restrict__ bias, const float *__restrict__ R,
-                                                             void *__restrict__ Yv, int M, int N, int K, int tiles_m, int tiles_n)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int ntiles = tiles_m * tiles_n;
-    const int G = gridDim.x;
-    const int wa = wave >> 2, wb = wave & 3;
-    const int frow = lane & 15, fq = lane >> 4;
-    const int nk = K / BK;
-    // tile order: every XCD (blockIdx & 7) walks a contiguous chunk of the (m-panel major) tile list
-    const int cq = ntiles >> 3, cr = ntiles & 7;
-    auto tile_of = [&](int o, int &m0, int &n0) {
-        const int xcd = o & 7, idx = o >> 3;
-        const int t = (xcd < cr ? xcd * (cq + 1) : cr * (cq + 1) + (xcd - cr) * cq) + idx;
-        const int tm = t / tiles_n;
-        m0 = tm * V3_T;
-        n0 = (t - tm * tiles_n) * V3_T;
-    };
-    int o = blockIdx.x;
-    if (o >= ntiles) return;
-    int m0, n0;
-    tile_of(o, m0, n0);
-    int g = 0;                                           // LDS stage that holds the K-step about to be consumed
-    stage_v3(W, X, n0, m0, M, K, 0, smem, wave, lane);
-    while (true) {
-        f32x4 acc[8][4];
-#pragma unroll
-        for (int i = 0; i < 8; i++)
-#pragma unroll
-            for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const int o_next = o + G;
-        int m1 = 0, n1 = 0;
-        const bool has_next = o_next < ntiles;
-        if (has_next) tile_of(o_next, m1, n1);
-        for (int kt = 0; kt < nk; kt++) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            unsigned char *nxt = smem + (g ^ 1) * V3_STAGE;
-            if (kt + 1 < nk) stage_v3(W, X, n0, m0, M, K, (kt + 1) * BK, nxt, wave, lane);
-            else if (has_next) stage_v3(W, X, n1, m1, M, K, 0, nxt, wave, lane);
-            const unsigned char *cur = smem + g * V3_STAGE;
-            const unsigned char *At = cur + (wa * 128) * 128;
-            const unsigned char *Bt = cur + V3_T * 128 + (wb * 64) * 128;
-#pragma unroll
-            for (int ks = 0; ks < 2; ks++) {
-                op16x8 a[8], b[4];
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const int row = j * 16 + frow;
-                    b[j] = *reinterpret_cast<const op16x8 *>(Bt + row * 128 + (((fq + 4 * ks) ^ (row & 7)) << 4));
-                }
-#pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    const int row = i * 16 + frow;
-                    a[i] = *reinterpret_cast<const op16x8 *>(At + row * 128 + (((fq + 4 * ks) ^ (row & 7)) << 4));
-                }
-#pragma unroll
-                for (int i = 0; i < 8; i++)
-#pragma unroll
-                    for (int j = 0; j < 4; j++)
-                        acc[i][j] = COSA_MFMA_16x16x32(a[i], b[j], acc[i][j], 0, 0, 0);
-            }
-            g ^= 1;
-        }
-        // epilogue from registers: acc[i][j][r] -> feature n0 + wa*128 + 16i + 4fq + r, token m0 + wb*64 + 16j + frow
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const int n = n0 + wa * 128 + 16 * i + 4 * fq;
-            const f32x4 bv = {(float)bias[n], (float)bias[n + 1], (float)bias[n + 2], (float)bias[n + 3]};
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int m = m0 + wb * 64 + 16 * j + frow;
-                if (m < M) {
-                    const size_t off = (size_t)m * N + n;
-                    if (EPI == EPI_RESIDUAL) {
-                        float *Y = static_cast<float *>(Yv);
-                        const f32x4 rv = *reinterpret_cast<const f32x4 *>(R + off);
-                        *reinterpret_cast<f32x4 *>(Y + off) = acc[i][j] + bv + rv;
-                    } else {
-                        op16 *Y = static_cast<op16 *>(Yv);
-                        op16x4 v;
-#pragma unroll
-                        for (int r = 0; r < 4; r++) {
-                            float t = acc[i][j][r] + bv[r];
-                            if (EPI == EPI_GELU) t = gelu_erf(t);
-                            v[r] = (op16)t;
-                        }
-                        *reinterpret_cast<op16x4 *>(Y + off) = v;
-                    }
-                }
-            }
-        }
-        if (!has_next) break;
-        o = o_next; m0 = m1; n0 = n1;
-    }
-}
-
-
-// =====================================================================================================
-// v5: 256 x 256 x 64 tile, 8 waves, FOUR-PHASE-PER-K-TILE ping-pong schedule (MI355X guide, "256^2 8-phase").
+// The phase stream of the 256 x 256 x 64 kernel: 8 waves, FOUR-PHASE-PER-K-TILE ping-pong schedule (MI355X guide, "256^2 8-phase").
+// (Rounds 1-2 kept its measured predecessors -- 256x128 3-stage, 256x256 plain / persistent with an LDS epilogue, and this schedule as a
+// one-tile-per-workgroup kernel -- in the library as variants 2-5; round 3 removed them: the persistent kernel below is the one that runs.)
 //
 // Each operand K-tile is two 16-KB half-tiles (128 rows x 64 k): X0 | W0 | X1 | W1, two K-tiles deep = 128 KB of LDS.
 // Wave (wr, wc) = (wave >> 2, wave & 3) owns features  n0 + {0,128} + wr*64 + [0,64)  and tokens
@@ -703,220 +308,10 @@ constexpr size_t kLdsBytesV5 = 2 * V5_BUF;             // 128 KB; also holds the
         V5_FENCE();                           \
     } while (0)
 
-template <int EPI, int ABL = 0>      // ABL: timing ablations only (1 no DMA in the loop, 2 no fragment reads, 4 no barriers) -- wrong results
-__global__ __launch_bounds__(512, 1) void gemm_bf16_v5_kernel(const op16 *__restrict__ X, const op16 *__restrict__ W,
-                                                             const op16 *__restrict__ bias, const float *__restrict__ R,
-                                                             void *__restrict__ Yv, int M, int N, int K, int tiles_m, int tiles_n)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int nwg = tiles_m * tiles_n;
-    int wg = blockIdx.x;
-    {
-        const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7, idx = wg >> 3;
-        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int tm = wg / tiles_n, tn = wg - tm * tiles_n;
-    const int m0 = tm * 256, n0 = tn * 256;
-    const int wr = wave >> 2, wc = wave & 3;
-    const int frow = lane & 15, fq = lane >> 4;
-    const int nk = K / BK;
-
-    __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void *)X, 0, (int)((size_t)M * K * 2), 0x00020000);
-    __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void *)W, 0, (int)((size_t)N * K * 2), 0x00020000);
-    // LDS-DMA: this wave fills the 1-KiB pieces 2*wave and 2*wave+1 (8 rows each) of every half-tile; the XOR swizzle
-    // (16-B slot ^ (row & 7)) is applied to the per-lane source offset because the LDS image of a piece is lane-linear
-    unsigned voX[2][2], voW[2][2];
-    {
-        const int sw = ((lane & 7) ^ (lane >> 3)) * 8;
-#pragma unroll
-        for (int h = 0; h < 2; h++)
-#pragma unroll
-            for (int i = 0; i < 2; i++) {
-                const int row = h * 128 + 8 * (2 * wave + i) + (lane >> 3);
-                voX[h][i] = (unsigned)(((m0 + row) * K + sw) * 2);     // rows >= M are past num_records -> zeros
-                voW[h][i] = (unsigned)(((n0 + row) * K + sw) * 2);
-            }
-    }
-    // which: 0 X0, 1 W0, 2 X1, 3 W1
-#define V5_STAGE(which, kt, bsel)                                                                                          \
-    if (!(ABL & 1) || (kt) < 2) {                                                                                          \
-        const int kt_ = (kt);                                                                                              \
-        const bool ok_ = kt_ < nk;                                                                                         \
-        unsigned char *dst_ = smem + (bsel) * V5_BUF + (which) * V5_HALF + (2 * wave) * 1024;                              \
-        const unsigned v0_ = ok_ ? (((which) & 1) ? voW[(which) >> 1][0] : voX[(which) >> 1][0]) : 0x7ffffff0u;            \
-        const unsigned v1_ = ok_ ? (((which) & 1) ? voW[(which) >> 1][1] : voX[(which) >> 1][1]) : 0x7ffffff0u;            \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(((which) & 1) ? rsW : rsX, (lds_void *)dst_, 16, v0_, kt_ * 128, 0, 0);   \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(((which) & 1) ? rsW : rsX, (lds_void *)(dst_ + 1024), 16, v1_, kt_ * 128, 0, 0); \
-    }
-
-    f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; i++)
-#pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    // prologue: 7 half-tiles (tile 0 complete + X0, W0, X1 of tile 1), then tile 0 must have landed
-    V5_STAGE(0, 0, 0);
-    V5_STAGE(1, 0, 0);
-    V5_STAGE(2, 0, 0);
-    V5_STAGE(3, 0, 0);
-    V5_STAGE(0, 1, 1);
-    V5_STAGE(1, 1, 1);
-    V5_STAGE(2, 1, 1);
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    V5_BARRIER();
-    if (wr == 1) V5_BARRIER();                         // stagger: the wr = 1 group runs one barrier behind
-
-    // fragment addressing inside a half-tile: row = quarter base + 16*blk + frow, 16-B slot (fq + 4*ks) ^ (row & 7)
-    const int lo0 = frow * 128 + ((fq ^ (frow & 7)) << 4);
-    const int lo1 = lo0 ^ 64;                                          // ks = 1
-    const unsigned char *rdW0 = smem + V5_HALF + wr * 8192 + lo0, *rdW1 = smem + V5_HALF + wr * 8192 + lo1;
-    const unsigned char *rdX0 = smem + wc * 4096 + lo0, *rdX1 = smem + wc * 4096 + lo1;
-    op16x8 a[4][2], x0[2][2], x1[2][2];
-    if (ABL & 2) {
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-#pragma unroll
-            for (int k = 0; k < 2; k++) {
-                a[i][k] = (op16x8){};
-                x0[i & 1][k] = (op16x8){};
-                x1[i & 1][k] = (op16x8){};
-                asm volatile("" : "+v"(a[i][k]), "+v"(x0[i & 1][k]), "+v"(x1[i & 1][k]));
-            }
-    }
-
-#define V5_LDW(q, buf)                                                                                             \
-    if (!(ABL & 2)) _Pragma("unroll") for (int blk = 0; blk < 4; blk++) {                                                          \
-        const int o_ = (buf) * V5_BUF + (q) * 2 * V5_HALF + blk * 2048;                                            \
-        a[blk][0] = *reinterpret_cast<const op16x8 *>(rdW0 + o_);                                                  \
-        a[blk][1] = *reinterpret_cast<const op16x8 *>(rdW1 + o_);                                                  \
-    }
-#define V5_LDX(dst, q, buf)                                                                                        \
-    if (!(ABL & 2)) _Pragma("unroll") for (int blk = 0; blk < 2; blk++) {                                                          \
-        const int o_ = (buf) * V5_BUF + (q) * 2 * V5_HALF + blk * 2048;                                            \
-        dst[blk][0] = *reinterpret_cast<const op16x8 *>(rdX0 + o_);                                                \
-        dst[blk][1] = *reinterpret_cast<const op16x8 *>(rdX1 + o_);                                                \
-    }
-#define V5_MMA(qa, xf, qb)                                                                                         \
-    do {                                                                                                           \
-        V5_FENCE();                                                                                                \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                         \
-        __builtin_amdgcn_s_setprio(1);                                                                             \
-        _Pragma("unroll") for (int ks = 0; ks < 2; ks++)                                                           \
-            _Pragma("unroll") for (int i = 0; i < 4; i++)                                                          \
-                _Pragma("unroll") for (int j = 0; j < 2; j++)                                                      \
-                    acc[(qa) * 4 + i][(qb) * 2 + j] =                                                              \
-                        COSA_MFMA_16x16x32(a[i][ks], xf[j][ks], acc[(qa) * 4 + i][(qb) * 2 + j], 0, 0, 0); \
-        __builtin_amdgcn_s_setprio(0);                                                                             \
-    } while (0)
-
-    for (int t = 0; t < nk; t++) {
-        const int b = t & 1;
-        // ---- phase 1 ----
-        V5_LDX(x0, 0, b);
-        V5_FENCE();
-        V5_LDW(0, b);
-        V5_STAGE(3, t + 1, b ^ 1);
-        V5_FENCE();
-        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");       // the X0 reads (issued first) are done: X0 may be refilled in phase 2
-        V5_BARRIER();
-        V5_MMA(0, x0, 0);
-        V5_BARRIER();
-        // ---- phase 2 ----
-        V5_LDX(x1, 1, b);
-        V5_STAGE(0, t + 2, b);
-        V5_BARRIER();
-        V5_MMA(0, x1, 1);
-        V5_BARRIER();
-        // ---- phase 3 ----
-        V5_LDW(1, b);
-        V5_STAGE(1, t + 2, b);
-        V5_BARRIER();
-        V5_MMA(1, x1, 1);
-        V5_BARRIER();
-        // ---- phase 4 ----
-        V5_STAGE(2, t + 2, b);
-        V5_FENCE();
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");         // everything but the 3 newest half-tiles: tile t+1 has landed
-        V5_BARRIER();
-        V5_MMA(1, x0, 0);
-        V5_BARRIER();
-    }
-    if (wr == 0) V5_BARRIER();                         // re-align the two groups
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the out-of-range tail "loads" still write (zeros to) LDS
-    __syncthreads();
-#undef V5_STAGE
-#undef V5_LDW
-#undef V5_LDX
-#undef V5_MMA
-
-    // epilogue.  acc[i][j][r]: feature n = (i>>2)*128 + wr*64 + (i&3)*16 + 4fq + r, token m = (j>>1)*128 + wc*32 + (j&1)*16 + frow
-    if (ABL & 8) {                                     // ablation: no epilogue at all
-#pragma unroll
-        for (int i = 0; i < 8; i++)
-#pragma unroll
-            for (int j = 0; j < 4; j++) asm volatile("" ::"v"(acc[i][j]));
-        return;
-    }
-    if (EPI == EPI_RESIDUAL) {
-        float *Y = static_cast<float *>(Yv);
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const int n = n0 + (i >> 2) * 128 + wr * 64 + (i & 3) * 16 + 4 * fq;
-            const f32x4 bv = {(float)bias[n], (float)bias[n + 1], (float)bias[n + 2], (float)bias[n + 3]};
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int m = m0 + (j >> 1) * 128 + wc * 32 + (j & 1) * 16 + frow;
-                if (m < M) {
-                    const size_t o = (size_t)m * N + n;
-                    const f32x4 rv = *reinterpret_cast<const f32x4 *>(R + o);
-                    *reinterpret_cast<f32x4 *>(Y + o) = acc[i][j] + bv + rv;
-                }
-            }
-        }
-    } else {
-        // op16 out through LDS, one 128-feature half at a time: tile [256 tokens][128 features], 272-byte rows
-        op16 *Y = static_cast<op16 *>(Yv);
-        unsigned char *Ct = smem;
-#pragma unroll
-        for (int half = 0; half < 2; half++) {
-#pragma unroll
-            for (int ii = 0; ii < 4; ii++) {
-                const int i = half * 4 + ii;
-                const int nl = wr * 64 + ii * 16 + 4 * fq;
-                float bv[4];
-#pragma unroll
-                for (int r = 0; r < 4; r++) bv[r] = (float)bias[n0 + half * 128 + nl + r];
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const int ml = (j >> 1) * 128 + wc * 32 + (j & 1) * 16 + frow;
-                    op16x4 v;
-#pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        float tv = acc[i][j][r] + bv[r];
-                        if (EPI == EPI_GELU) tv = gelu_erf(tv);
-                        v[r] = (op16)tv;
-                    }
-                    *reinterpret_cast<op16x4 *>(Ct + ml * CT_LD + nl * 2) = v;
-                }
-            }
-            __syncthreads();
-#pragma unroll
-            for (int c = tid; c < 256 * 16; c += 512) {
-                const int ml = c >> 4, s = c & 15;
-                if (m0 + ml < M)
-                    *reinterpret_cast<uint4 *>(Y + (size_t)(m0 + ml) * N + n0 + half * 128 + s * 8) =
-                        *reinterpret_cast<const uint4 *>(Ct + ml * CT_LD + s * 16);
-            }
-            __syncthreads();
-        }
-    }
-}
-
+constexpr int ABL = 0;      // (the barrier macro's ablation switch of the removed one-tile kernel)
 
 // =====================================================================================================
-// v6: the v5 phase stream as a PERSISTENT kernel whose epilogue rides inside the next phases.
+// v6: that phase stream as a PERSISTENT kernel whose epilogue rides inside the next phases.
 //
 // One workgroup per CU walks its tiles (jobs).  The LDS-DMA stream never stops at a job boundary: the half-tiles
 // "7 ahead" simply belong to the next job (its operand panels are described by a second pair of buffer resources),
@@ -952,7 +347,6 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
     if (stamps && threadIdx.x == 0) atomicMin(&stamps[0], __builtin_amdgcn_s_memrealtime());
     constexpr bool RES = EPI == EPI_RESIDUAL;          // fp32 out = fp32 residual + X W^T + bias
     constexpr int ES = RES ? 4 : 2;
-    constexpr int ABL = 0;
     constexpr int FL = 0x00020000;
     static_assert(FR == 4 || (FR == 3 && SPLIT == 0), "FR: 16-feature fragments per wave and W half (tile width 64 FR)");
     constexpr bool C8 = SPLIT == 3;                    // fp16c8 operands (see c8_tile_x / c8_tile_w); 16-bit GELU outputs leave as c8 rows
@@ -1365,7 +759,6 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
 #undef V6_TILE
 }
 
-constexpr size_t kLdsBytesV3 = 2 * V3_STAGE;      // 131072 >= 256*272 epilogue half
 
 
 // =====================================================================================================
@@ -1797,51 +1190,6 @@ static int g_gemm_variant = env_variant();   // 0 = pick per shape (measured, to
 extern "C" void cosa_gemm_set_variant(int v) { g_gemm_variant = v; }
 extern "C" void cosa_gemm_set_grid_policy(int balanced) { g_gemm_balanced_grid = balanced; }
 
-template <int EPI>
-static int launch_v2(const op16 *x, const op16 *w, const op16 *b, const float *residual, void *Y, int M, int N, int K, hipStream_t st)
-{
-    static bool attr_done = false;
-    if (!attr_done) {
-        COSA_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_bf16_v2_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytesV2));
-        attr_done = true;
-    }
-    const int tiles_m = (M + V2_BM - 1) / V2_BM, tiles_n = N / V2_BN;
-    hipLaunchKernelGGL(gemm_bf16_v2_kernel<EPI>, dim3(tiles_m * tiles_n), dim3(512), kLdsBytesV2, st, x, w, b, residual, Y, M, N, K,
-                       tiles_m, tiles_n);
-    COSA_LAUNCH_CHECK();
-    return COSA_OK;
-}
-
-template <int EPI>
-static int launch_v3(const op16 *x, const op16 *w, const op16 *b, const float *residual, void *Y, int M, int N, int K, hipStream_t st)
-{
-    static bool attr_done = false;
-    if (!attr_done) {
-        COSA_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_bf16_v3_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytesV3));
-        attr_done = true;
-    }
-    const int tiles_m = (M + V3_T - 1) / V3_T, tiles_n = N / V3_T;
-    hipLaunchKernelGGL(gemm_bf16_v3_kernel<EPI>, dim3(tiles_m * tiles_n), dim3(512), kLdsBytesV3, st, x, w, b, residual, Y, M, N, K,
-                       tiles_m, tiles_n);
-    COSA_LAUNCH_CHECK();
-    return COSA_OK;
-}
-
-template <int EPI, int ABL = 0>
-static int launch_v5(const op16 *x, const op16 *w, const op16 *b, const float *residual, void *Y, int M, int N, int K, hipStream_t st)
-{
-    static bool attr_done = false;
-    if (!attr_done) {
-        COSA_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_bf16_v5_kernel<EPI, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytesV5));
-        attr_done = true;
-    }
-    const int tiles_m = (M + 255) / 256, tiles_n = N / 256;
-    hipLaunchKernelGGL((gemm_bf16_v5_kernel<EPI, ABL>), dim3(tiles_m * tiles_n), dim3(512), kLdsBytesV5, st, x, w, b, residual, Y, M, N, K,
-                       tiles_m, tiles_n);
-    COSA_LAUNCH_CHECK();
-    return COSA_OK;
-}
-
 template <int EPI, int ABL6 = 0, int AUX = 0, int SPLIT = 0, int FR = 4>
 static int launch_v6(const op16 *x, const op16 *w, const op16 *b, const float *residual, void *Y, int M, int N, int K, hipStream_t st,
                      int ld = 0, int ldy = 0, void *Y2 = nullptr)
@@ -1911,22 +1259,6 @@ static int launch_v6(const op16 *x, const op16 *w, const op16 *b, const float *r
     return COSA_OK;
 }
 
-template <int EPI>
-static int launch_v4(const op16 *x, const op16 *w, const op16 *b, const float *residual, void *Y, int M, int N, int K, hipStream_t st)
-{
-    static bool attr_done = false;
-    if (!attr_done) {
-        COSA_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_bf16_v4_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytesV3));
-        attr_done = true;
-    }
-    const int tiles_m = (M + V3_T - 1) / V3_T, tiles_n = N / V3_T;
-    const int ntiles = tiles_m * tiles_n;
-    const int grid = ntiles < 256 ? ntiles : 256;          // one persistent workgroup per CU
-    hipLaunchKernelGGL(gemm_bf16_v4_kernel<EPI>, dim3(grid), dim3(512), kLdsBytesV3, st, x, w, b, residual, Y, M, N, K, tiles_m, tiles_n);
-    COSA_LAUNCH_CHECK();
-    return COSA_OK;
-}
-
 extern "C" int cosa_gemm_bf16(const void *X, const void *W, const void *bias, const float *residual, void *Y,
                               int M, int N, int K, int epilogue, void *stream)
 {
@@ -1940,23 +1272,9 @@ extern "C" int cosa_gemm_bf16(const void *X, const void *W, const void *bias, co
     const dim3 grid(tiles_m * tiles_n), blk(256);
     hipStream_t st = as_stream(stream);
     const op16 *x = static_cast<const op16 *>(X), *w = static_cast<const op16 *>(W), *b = static_cast<const op16 *>(bias);
-    // shape rule from the measurements in profiles/r01_gemm_variants.txt: the 256x256 tile wins whenever its tile count
-    // quantises well on 256 CUs (wide N, or >= 2 full rounds of tiles); otherwise the 128x128 kernel at 2 workgroups/CU
-    const long tiles256 = (long)((M + V3_T - 1) / V3_T) * (N / V3_T);
+    // shape rule (measured, profiles/r01_gemm_variants.txt): the persistent 256-wide kernel from 4096 rows up, the 128 x 128 kernel (two
+    // workgroups per CU) below that and for operands beyond the 2-GiB reach of its buffer descriptors
     const bool fits_v5 = N % 256 == 0 && M >= 256 && (size_t)(M + 256) * K * 2 < 0x7fffffffull && (size_t)N * K * 2 < 0x7fffffffull;
-    if (g_gemm_variant >= 50 && g_gemm_variant < 60 && fits_v5) {      // timing ablations of v5 (tools/bench_gemm.py), bias epilogue only
-        switch (g_gemm_variant - 50) {
-        case 1: return launch_v5<EPI_BIAS, 1>(x, w, b, residual, Y, M, N, K, st);
-        case 2: return launch_v5<EPI_BIAS, 2>(x, w, b, residual, Y, M, N, K, st);
-        case 3: return launch_v5<EPI_BIAS, 3>(x, w, b, residual, Y, M, N, K, st);
-        case 4: return launch_v5<EPI_BIAS, 4>(x, w, b, residual, Y, M, N, K, st);
-        case 6: return launch_v5<EPI_BIAS, 6>(x, w, b, residual, Y, M, N, K, st);
-        case 7: return launch_v5<EPI_BIAS, 7>(x, w, b, residual, Y, M, N, K, st);
-        case 8: return launch_v5<EPI_BIAS, 8>(x, w, b, residual, Y, M, N, K, st);
-        case 9: return launch_v5<EPI_BIAS, 9>(x, w, b, residual, Y, M, N, K, st);
-        default: break;
-        }
-    }
     static const int big_m = [] { const char *e = getenv("COSA_GEMM_BIG_M"); return e ? atoi(e) : 4096; }();   // experiments: rows from which the 256 x 256 kernels are used
     const bool fits_v6 = fits_v5 && K >= 128 && (epilogue != EPI_RESIDUAL || g_gemm_variant == 6 || g_gemm_variant == 9 || g_gemm_variant == 0);
     if (g_gemm_variant >= 61 && g_gemm_variant <= 65 && fits_v6) {     // timing ablations of v6 (tools/bench_gemm_abl.py)
@@ -1995,35 +1313,6 @@ extern "C" int cosa_gemm_bf16(const void *X, const void *W, const void *bias, co
     if (fits_v6 && g_gemm_variant == 8) {                              // nt + sc0 + sc1 stores
         if (epilogue == EPI_BIAS) return launch_v6<EPI_BIAS, 0, 19>(x, w, b, residual, Y, M, N, K, st);
         return launch_v6<EPI_GELU, 0, 19>(x, w, b, residual, Y, M, N, K, st);
-    }
-    if ((g_gemm_variant == 5 || (g_gemm_variant == 0 && M >= big_m)) && fits_v5) {
-        switch (epilogue) {
-        case EPI_BIAS: return launch_v5<EPI_BIAS>(x, w, b, residual, Y, M, N, K, st);
-        case EPI_GELU: return launch_v5<EPI_GELU>(x, w, b, residual, Y, M, N, K, st);
-        default: return launch_v5<EPI_RESIDUAL>(x, w, b, residual, Y, M, N, K, st);
-        }
-    }
-    if (g_gemm_variant == 4 && N % V3_T == 0) {
-        switch (epilogue) {
-        case EPI_BIAS: return launch_v4<EPI_BIAS>(x, w, b, residual, Y, M, N, K, st);
-        case EPI_GELU: return launch_v4<EPI_GELU>(x, w, b, residual, Y, M, N, K, st);
-        default: return launch_v4<EPI_RESIDUAL>(x, w, b, residual, Y, M, N, K, st);
-        }
-    }
-    const bool pick_v3 = g_gemm_variant == 3 || (g_gemm_variant == 0 && M >= big_m && (N >= 2304 || tiles256 >= 512));
-    if (pick_v3 && M >= 1024 && N % V3_T == 0) {
-        switch (epilogue) {
-        case EPI_BIAS: return launch_v3<EPI_BIAS>(x, w, b, residual, Y, M, N, K, st);
-        case EPI_GELU: return launch_v3<EPI_GELU>(x, w, b, residual, Y, M, N, K, st);
-        default: return launch_v3<EPI_RESIDUAL>(x, w, b, residual, Y, M, N, K, st);
-        }
-    }
-    if (g_gemm_variant == 2 && M >= 1024) {
-        switch (epilogue) {
-        case EPI_BIAS: return launch_v2<EPI_BIAS>(x, w, b, residual, Y, M, N, K, st);
-        case EPI_GELU: return launch_v2<EPI_GELU>(x, w, b, residual, Y, M, N, K, st);
-        default: return launch_v2<EPI_RESIDUAL>(x, w, b, residual, Y, M, N, K, st);
-        }
     }
     static bool attr_done = false;
     if (!attr_done) {

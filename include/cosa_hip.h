@@ -228,8 +228,8 @@ int cosa_conv3x3_dilated_nhwc(const void *X, const void *Wt, void *Y, int B, int
 int cosa_conv3x3_dilated_wgrad(const void *dY, const void *X, float *dW9, int B, int h, int w, int Cin, int Cout, int dilation,
                                int img_rows, int row_off, int ldx, int zero_first, void *workspace, size_t workspace_bytes,
                                void *stream);      /* workspace: cosa_gemm_wgrad_workspace_bytes(B*h*w, Cout, 9*Cin) */
-void cosa_gemm_set_variant(int v);   /* 0 (default): per-shape choice; 1: 128x128 2-stage; 2: 256x128 3-stage; 3: 256x256 8-wave;
-                                      * 5: 256x256 4-phase ping-pong; 6: the same, persistent with the epilogue in the MFMA shadow      */
+void cosa_gemm_set_variant(int v);   /* 0 (default): per-shape choice; 1: the 128x128 two-stage kernel; 6: the persistent 256x256 kernel;
+                                      * 9: the same on 256x192 jobs; 7 / 8 / 61-65: store-policy and timing variants of it (tools/) */
 /* persistent-grid policy of cosa_gemm_bf16: 0 (default) one workgroup per CU; 1 the workgroups balanced over the rounds the launch needs
  * anyway (600 jobs: 200 workgroups x 3 instead of 256 x 2.3; launches of fewer than 40 000 rows, i.e. the student's), which leaves CUs to
  * concurrently running kernels -- RCCL's channels when the

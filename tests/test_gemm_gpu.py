@@ -21,7 +21,7 @@ def _ref(x, w, b, epi, r):
     return y
 
 
-@pytest.mark.parametrize("variant", [0, 1, 3, 5, 6])
+@pytest.mark.parametrize("variant", [0, 1, 6])
 @pytest.mark.parametrize("epi", [0, 1, 2])
 def test_gemm_bf16_variants_vs_fp32(variant, epi):
     from cosa_amd import nn_ops, _C
@@ -42,26 +42,6 @@ def test_gemm_bf16_variants_vs_fp32(variant, epi):
             assert err <= tol, (variant, epi, M, N, K, err, tol)
     finally:
         _C.lib().cosa_gemm_set_variant(0)
-
-
-def test_gemm_variants_agree_bitwise_on_bias_epilogue():
-    """same products, same fp32 accumulation order per output (k ascending in steps of 32 inside one MFMA chain):
-    the tile shape must not change a single bit of the bf16 result (v6 starts its accumulation FROM the bias instead of
-    adding it last, so it is not part of this check)"""
-    from cosa_amd import nn_ops, _C
-    torch.manual_seed(3)
-    M, N, K = 4700, 768, 768
-    x = torch.randn(M, K, device="cuda").bfloat16()
-    w = (torch.randn(N, K, device="cuda") * 0.03).bfloat16()
-    b = torch.randn(N, device="cuda").bfloat16()
-    outs = []
-    try:
-        for v in (1, 3, 5):
-            _C.lib().cosa_gemm_set_variant(v)
-            outs.append(nn_ops.gemm_bf16(x, w, b, 0).clone())
-    finally:
-        _C.lib().cosa_gemm_set_variant(0)
-    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
 
 @pytest.mark.parametrize("M,N,K", [(12560, 768, 768), (1000, 256, 128), (63, 128, 128), (4097, 2304, 768)])
@@ -111,7 +91,7 @@ def test_layernorm_vs_torch():
     assert (y16.float() - ref).abs().max().item() <= 2.0 ** -8 * ref.abs().max().item()
 
 
-@pytest.mark.parametrize("variant", [5, 6])
+@pytest.mark.parametrize("variant", [6])
 def test_gemm_pipelined_kernels_are_run_to_run_deterministic(variant):
     """race screen for the counted-vmcnt / staggered-barrier schedules: no atomics are involved, so any run-to-run difference of the
     output bits would be an LDS-DMA data race (a buffer read before its DMA landed, or refilled while still being read)"""
