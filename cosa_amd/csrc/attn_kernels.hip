@@ -570,18 +570,30 @@ __global__ __launch_bounds__(128, 2) void attn_fwd2_kernel(const op16 *__restric
 #if COSA_OP_F16
             const int D = H * HD;
             unsigned char *row = reinterpret_cast<unsigned char *>(out) + ((size_t)b * N + q) * (size_t)(4 * D + 128);
+            // a lane holds 4-column chunks (8g + 4hh); v_permlane32_swap with its partner lane (same query, other half) turns two of them into
+            // 8 consecutive columns: lanes 0-31 take chunk pair g = 2gp, lanes 32-63 g = 2gp + 1 -- 16-byte fp16 stores, 8-byte stores of the planes
 #pragma unroll
-            for (int g = 0; g < 4; g++)
+            for (int gp = 0; gp < 2; gp++)
 #pragma unroll
                 for (int d = 0; d < 2; d++) {
-                    const int col = h * HD + 32 * d + 8 * g + 4 * hh;
-                    const float v[4] = {o[u][d][4 * g] * inv, o[u][d][4 * g + 1] * inv, o[u][d][4 * g + 2] * inv, o[u][d][4 * g + 3] * inv};
-                    _Float16 hi[4];
-                    unsigned lo8, hi8;
-                    c8_split4(v, hi, lo8, hi8);
-                    *reinterpret_cast<op16x4 *>(row + 2 * col) = (op16x4){hi[0], hi[1], hi[2], hi[3]};
-                    *reinterpret_cast<unsigned *>(row + 2 * D + col) = lo8;
-                    *reinterpret_cast<unsigned *>(row + 3 * D + col) = hi8;
+                    unsigned hiw[2][2], lo8[2], hi8[2];
+#pragma unroll
+                    for (int e = 0; e < 2; e++) {
+                        const int g = 2 * gp + e;
+                        const float v[4] = {o[u][d][4 * g] * inv, o[u][d][4 * g + 1] * inv, o[u][d][4 * g + 2] * inv, o[u][d][4 * g + 3] * inv};
+                        _Float16 hi[4];
+                        c8_split4(v, hi, lo8[e], hi8[e]);
+                        hiw[e][0] = __builtin_bit_cast(unsigned, (op16x2){hi[0], hi[1]});
+                        hiw[e][1] = __builtin_bit_cast(unsigned, (op16x2){hi[2], hi[3]});
+                    }
+                    const auto a0 = __builtin_amdgcn_permlane32_swap(hiw[0][0], hiw[1][0], false, false);
+                    const auto a1 = __builtin_amdgcn_permlane32_swap(hiw[0][1], hiw[1][1], false, false);
+                    const auto bl = __builtin_amdgcn_permlane32_swap(lo8[0], lo8[1], false, false);
+                    const auto bh = __builtin_amdgcn_permlane32_swap(hi8[0], hi8[1], false, false);
+                    const int col = h * HD + 32 * d + 8 * (2 * gp + hh);
+                    *reinterpret_cast<uint4 *>(row + 2 * col) = make_uint4(a0[0], a1[0], a0[1], a1[1]);
+                    *reinterpret_cast<uint2 *>(row + 2 * D + col) = make_uint2(bl[0], bl[1]);
+                    *reinterpret_cast<uint2 *>(row + 3 * D + col) = make_uint2(bh[0], bh[1]);
                 }
             if (h == 0) {                       // augmentation block (1, 1, 0, ...): 64 fp16, a half per lane half
                 uint4 z = {0u, 0u, 0u, 0u}, one = {0x3c003c00u, 0u, 0u, 0u};

@@ -433,7 +433,8 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
     // FR == 3, 16-bit output: the third fragment of a wave has no partner to swap with; its lane keeps features 4fq .. 4fq + 3 (8-byte stores)
     const unsigned voY3 = (unsigned)((32 + 4 * fq - (fq & 1) * 16 - 4 * (fq & 2)) * 2);
     // c8 rows out: the lane's feature offset inside the tile in BYTES of an 8-bit plane (voY holds it doubled, for the fp16 plane)
-    const unsigned fo8 = (unsigned)(wr * WN + (fq & 1) * 16 + 4 * (fq & 2));
+    // (the combined 16-byte store: byte offset of the lane's 16 features in an 8-bit plane, minus twice its offset in the fp16 plane, which voY carries)
+    const unsigned fo16m = (unsigned)((wr * WN + 16 * (fq & 1) + 32 * (fq >> 1)) - 2 * (wr * WN + (fq & 1) * 16 + 4 * (fq & 2)));
 
     int o = blockIdx.x;
     // Optional start stagger (experiment, off by default): workgroups that have one job fewer than the busiest ones start
@@ -548,7 +549,8 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
                                                        voY[(qb) * 2 + jj] + ((qa) * HN + ii * 16) * 4, 0, AUX);     \
             }                                                                                                       \
         }                                                                                                           \
-    } else                                                                                                          \
+    } else {                                                                                                        \
+    unsigned c8l_[2][2], c8h_[2][2];      /* c8 rows out: the 8-bit planes of both fragment pairs, stored together */  \
     _Pragma("unroll") for (int jj = 0; jj < 2; jj++) _Pragma("unroll") for (int pr = 0; pr < 2; pr++) {             \
         if (FR == 3 && pr == 1) {         /* the unpaired third fragment */                                         \
             f32x4 v2_ = acc[(qa) * 4 + 2][(qb) * 2 + jj];                                                           \
@@ -599,11 +601,20 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
             const unsigned lB_ = c8_pack4((v1_[0] - h4_) * kC8LoScale, (v1_[1] - h5_) * kC8LoScale, (v1_[2] - h6_) * kC8LoScale, (v1_[3] - h7_) * kC8LoScale); \
             const auto th_ = __builtin_amdgcn_permlane16_swap(hA_, hB_, false, false);                              \
             const auto tl_ = __builtin_amdgcn_permlane16_swap(lA_, lB_, false, false);                              \
-            const int jn0_ = (&rsY == &pY) ? pn0 : n0;                                                              \
-            const unsigned v8_ = voY[(qb) * 2 + jj] - fo8;                                                          \
-            __builtin_amdgcn_raw_buffer_store_b64((u32x2){tl_[0], tl_[1]}, rsY, v8_, 2 * N - jn0_ + (qa) * HN + pr * 32, AUX); \
-            __builtin_amdgcn_raw_buffer_store_b64((u32x2){th_[0], th_[1]}, rsY, v8_, 3 * N - jn0_ + (qa) * HN + pr * 32, AUX); \
+            c8l_[pr][0] = tl_[0]; c8l_[pr][1] = tl_[1]; c8h_[pr][0] = th_[0]; c8h_[pr][1] = th_[1];                 \
+            if (pr == 1) {      /* a lane owns 8 consecutive features of each fragment pair; v_permlane32_swap makes that 16 of ONE pair: lanes   \
+                                   0-31 take pair 0 (own 8 + those of lane + 32), lanes 32-63 pair 1: one 16-byte store per plane */             \
+                const auto l0_ = __builtin_amdgcn_permlane32_swap(c8l_[0][0], c8l_[1][0], false, false);            \
+                const auto l1_ = __builtin_amdgcn_permlane32_swap(c8l_[0][1], c8l_[1][1], false, false);            \
+                const auto g0_ = __builtin_amdgcn_permlane32_swap(c8h_[0][0], c8h_[1][0], false, false);            \
+                const auto g1_ = __builtin_amdgcn_permlane32_swap(c8h_[0][1], c8h_[1][1], false, false);            \
+                const int jn0_ = (&rsY == &pY) ? pn0 : n0;                                                          \
+                const unsigned v16_ = voY[(qb) * 2 + jj] + fo16m;                                                   \
+                __builtin_amdgcn_raw_buffer_store_b128((u32x4){l0_[0], l1_[0], l0_[1], l1_[1]}, rsY, v16_, 2 * N - jn0_ + (qa) * HN, AUX); \
+                __builtin_amdgcn_raw_buffer_store_b128((u32x4){g0_[0], g1_[0], g0_[1], g1_[1]}, rsY, v16_, 3 * N - jn0_ + (qa) * HN, AUX); \
+            }                                                                                                       \
         }                                                                                                           \
+    }                                                                                                               \
     }
     // 16 MFMAs of quadrant (qa, qb); FIRST: the accumulation starts from the bias
 #define V6_MMA(qa, xf, qb, FIRST, F8)                                                                               \
@@ -692,7 +703,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
         V6_STAGE(2, (t) + 2, b_);                                                                                   \
         V5_FENCE();                                                                                                 \
         if ((LAST) && RES) { if (FR == 4) V6_WAIT(38); else V6_WAIT(30); }                                          \
-        else if ((LAST) && C8OUT) V6_WAIT(30);                                                                      \
+        else if ((LAST) && C8OUT) V6_WAIT(22);      /* 6 DMA + 2 x (4 + 4) stores */                                         \
         else if (LAST) V6_WAIT(14);                                                                                 \
         else V6_WAIT(6);                                                                                            \
         V6_MSECTION_BEGIN();                                                                                        \
