@@ -67,146 +67,21 @@ __device__ __forceinline__ bool attn_block_map(int nblk, int ngroups, int H, int
 }
 
 // ---- forward -----------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const op16 *__restrict__ qkv, const op16 *__restrict__ vt,
-                                                      op16 *__restrict__ out, float *__restrict__ lse,
-                                                      int N, int Npad, int H, int nblk, int ngroups, float scale_log2e,
-                                                      unsigned long long *__restrict__ stamps)
-{
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BK * 128];
-    // optional device-side span of this launch (100 MHz wall clock): min start / max end over workgroups.
-    // HIP events cannot be recorded inside a captured hipGraph on ROCm, so bench.py reads these instead.
-    if (stamps && threadIdx.x == 0) atomicMin(&stamps[0], __builtin_amdgcn_s_memrealtime());
-    unsigned char *Ks = smem;
-    unsigned char *Vs = smem + BK * 128;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
-    int blk, b, h;
-    if (!attn_block_map(nblk, ngroups, H, blk, b, h)) return;
-    const int q0 = blk * BQ + wave * 32;
-    const size_t rs = (size_t)3 * H * HD;          // elements per token row of qkv
-
-    // Q fragments: B operand of S^T = K Q^T  (lane: query r, d = 16s + 8hh + j)
-    const int qrow = min(q0 + r, N - 1);
-    const op16 *qp = qkv + ((size_t)b * N + qrow) * rs + h * HD + 8 * hh;
-    op16x8 qf[4];
-#pragma unroll
-    for (int s = 0; s < 4; s++) qf[s] = *reinterpret_cast<const op16x8 *>(qp + 16 * s);
-
-    f32x16 o0, o1;
-#pragma unroll
-    for (int i = 0; i < 16; i++) { o0[i] = 0.f; o1[i] = 0.f; }
-    float m = -INFINITY, l = 0.f;
-
-    const op16 *kbase = qkv + (size_t)b * N * rs + (size_t)H * HD + h * HD;      // k part
-    const op16 *vbase = kbase + (size_t)H * HD;                                   // v part, same row stride
-    const int swz = (r >> 1) & 7;
-
-    // register-staged software pipeline: the next tile's global loads are in flight while this tile computes
-    uint4 kreg0, kreg1, vreg0, vreg1;
-    const int row_a = tid >> 3, row_b = (tid + 256) >> 3, slot_s = tid & 7;     // chunk -> (row, 16-B slot)
-#define COSA_LOAD_TILE(K0)                                                                                           \
-    do {                                                                                                             \
-        kreg0 = *reinterpret_cast<const uint4 *>(kbase + (size_t)min((K0) + row_a, N - 1) * rs + slot_s * 8);       \
-        kreg1 = *reinterpret_cast<const uint4 *>(kbase + (size_t)min((K0) + row_b, N - 1) * rs + slot_s * 8);       \
-        vreg0 = *reinterpret_cast<const uint4 *>(vbase + (size_t)min((K0) + row_a, N - 1) * rs + slot_s * 8);       \
-        vreg1 = *reinterpret_cast<const uint4 *>(vbase + (size_t)min((K0) + row_b, N - 1) * rs + slot_s * 8);       \
-    } while (0)
-    COSA_LOAD_TILE(0);
-    const float NEG_INF = -INFINITY;
-    auto tile = [&](int k0, auto tail_tag) {
-        constexpr bool tail = decltype(tail_tag)::value;
-        __syncthreads();
-        *reinterpret_cast<uint4 *>(Ks + row_a * 128 + ((slot_s ^ ((row_a >> 1) & 7)) << 4)) = kreg0;
-        *reinterpret_cast<uint4 *>(Ks + row_b * 128 + ((slot_s ^ ((row_b >> 1) & 7)) << 4)) = kreg1;
-        *reinterpret_cast<uint4 *>(Vs + row_a * 128 + ((slot_s ^ vsw(row_a)) << 4)) = vreg0;
-        *reinterpret_cast<uint4 *>(Vs + row_b * 128 + ((slot_s ^ vsw(row_b)) << 4)) = vreg1;
-        __syncthreads();
-        if (k0 + BK < N) COSA_LOAD_TILE(k0 + BK);
-
-        // S^T[key][query] for two 32-key blocks
-        f32x16 s0, s1;
-#pragma unroll
-        for (int i = 0; i < 16; i++) { s0[i] = 0.f; s1[i] = 0.f; }
-#pragma unroll
-        for (int s = 0; s < 4; s++) {
-            const int slot = ((2 * s + hh) ^ swz) << 4;
-            const op16x8 a0 = *reinterpret_cast<const op16x8 *>(Ks + r * 128 + slot);
-            const op16x8 a1 = *reinterpret_cast<const op16x8 *>(Ks + (r + 32) * 128 + slot);
-            s0 = COSA_MFMA_32x32x16(a0, qf[s], s0, 0, 0, 0);
-            s1 = COSA_MFMA_32x32x16(a1, qf[s], s1, 0, 0, 0);
-        }
-        // online softmax with the query on the lane; raw-score max, scale folded into the exp2 argument (one fma)
-        if constexpr (tail) {
-#pragma unroll
-            for (int i = 0; i < 16; i++) {
-                if (k0 + crow(i, hh) >= N) s0[i] = NEG_INF;
-                if (k0 + 32 + crow(i, hh) >= N) s1[i] = NEG_INF;
-            }
-        }
-        float mt = fmaxf(s0[0], s1[0]);
-#pragma unroll
-        for (int i = 1; i < 16; i++) mt = fmaxf(mt, fmaxf(s0[i], s1[i]));
-        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-        const float mnew = fmaxf(m, mt * scale_log2e);
-        if (__any(mnew != m)) {                       // wave-uniform: rescale only when some row's max moved
-            const float alpha = __builtin_amdgcn_exp2f(m - mnew);
-            l *= alpha;
-#pragma unroll
-            for (int i = 0; i < 16; i++) { o0[i] *= alpha; o1[i] *= alpha; }
-            m = mnew;
-        }
-        float ls = 0.f;
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
-            s0[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[i], scale_log2e, -m));
-            s1[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[i], scale_log2e, -m));
-            ls += s0[i] + s1[i];
-        }
-        l += ls;
-
-        // O^T[d][query] += V^T[d][key] P^T[key][query]; the exponentiated accumulators ARE the B operand
-#pragma unroll
-        for (int kb = 0; kb < 2; kb++) {
-#pragma unroll
-            for (int sp = 0; sp < 2; sp++) {
-                op16x8 pf;
-#pragma unroll
-                for (int j = 0; j < 8; j++) pf[j] = (op16)(kb == 0 ? s0[8 * sp + j] : s1[8 * sp + j]);
-                const int keyb = kb * 32 + 16 * sp + 4 * hh;
-                o0 = COSA_MFMA_32x32x16(v_frag(Vs, keyb, 0, lane), pf, o0, 0, 0, 0);
-                o1 = COSA_MFMA_32x32x16(v_frag(Vs, keyb, 1, lane), pf, o1, 0, 0, 0);
-            }
-        }
-    };
-    const int nfull = (N / BK) * BK;
-    for (int k0 = 0; k0 < nfull; k0 += BK) tile(k0, std::false_type{});
-    if (nfull < N) tile(nfull, std::true_type{});
-#undef COSA_LOAD_TILE
-    // finish: combine the two half-lane partial sums, normalise, store O (d = db*32 + crow(i,hh)) and LSE
-    l += __shfl_xor(l, 32, 64);
-    const float inv = 1.0f / l;
-    const int q = q0 + r;
-    if (q < N) {
-        op16 *op = out + ((size_t)b * N + q) * H * HD + h * HD;
-#pragma unroll
-        for (int g = 0; g < 4; g++) {
-            op16x4 v0, v1;
-#pragma unroll
-            for (int j = 0; j < 4; j++) { v0[j] = (op16)(o0[4 * g + j] * inv); v1[j] = (op16)(o1[4 * g + j] * inv); }
-            *reinterpret_cast<op16x4 *>(op + 8 * g + 4 * hh) = v0;
-            *reinterpret_cast<op16x4 *>(op + 32 + 8 * g + 4 * hh) = v1;
-        }
-        if (hh == 0) lse[((size_t)b * H + h) * N + q] = (m + __builtin_amdgcn_logf(l)) * 0.6931471805599453f;
-    }
-    if (stamps) {
-        __syncthreads();
-        if (threadIdx.x == 0) atomicMax(&stamps[1], __builtin_amdgcn_s_memrealtime());
-    }
-}
-
+// One pass over the keys in 64-key tiles with the online softmax; the query sits on the LANE (r = lane & 31; the two 32-lane halves hh
+// own interleaved 4-row groups of the MFMA output, crow()):
+//   * S^T[key][query] = K Q^T for the tile's two 32-key blocks (v_mfma_f32_32x32x16, A = K rows from LDS, B = the Q fragments held in
+//     registers for the whole kernel);
+//   * raw-score maximum per query over the lane's registers and the other half-lane (one cross-lane op), the scale folded into the exp2
+//     argument (one fma per score); the running O and sum are rescaled only when some row's maximum moved (wave-uniform test);
+//   * O^T[d][query] += V^T[d][key] P^T[key][query]: the exponentiated accumulators, rounded to the operand type, ARE the B operand of the
+//     second MFMA (no LDS round trip for P), V^T fragments come from the transposing LDS read (v_frag above);
+//   * at the end the two half-lane partial sums are combined, O is normalised and stored, LSE = (m + log2 l) ln 2.
+// stamps: optional device-side span of the launch (100 MHz wall clock; min start / max end over workgroups) -- HIP events cannot be
+// recorded inside a captured hipGraph on ROCm, so bench.py reads these instead.
 
 #if !COSA_OP_F16
 // ---- forward with bf16x3 ("split") operands: the parity-grade no-grad passes ------------------------------------------------------
-// Same algorithm and lane mapping as attn_fwd_kernel; q, k, v and the probabilities are carried as hi + lo bf16 halves (16 significant
+// The algorithm above, 4 waves x 32 queries per workgroup; q, k, v and the probabilities are carried as hi + lo bf16 halves (16 significant
 // bits) and every product is the three MFMA terms hi*hi + hi*lo + lo*hi with fp32 accumulation:
 //     S^T  = K_h Q_h^T + K_h Q_l^T + K_l Q_h^T          O^T += V_h^T P_h^T + V_h^T P_l^T + V_l^T P_h^T
 // qkv rows are the split output of the qkv projection: [hi (3*H*64) | lo (3*H*64)], row stride ldq; the output rows are split rows for
@@ -387,8 +262,8 @@ __global__ __launch_bounds__(256) void attn_fwd_x3_kernel(const op16 *__restrict
 #endif
 
 // ---- forward, 64 queries per wave ---------------------------------------------------------------------------------
-// Same algorithm as attn_fwd_kernel with a different decomposition: a workgroup is 2 waves, each wave owns TWO 32-query
-// blocks.  Every K / V^T fragment read from LDS now feeds two MFMAs (half the LDS fragment traffic per flop), each wave
+// The algorithm above; a workgroup is 2 waves, each wave owns TWO 32-query
+// blocks.  Every K / V^T fragment read from LDS feeds two MFMAs (half the LDS fragment traffic per flop of a 32-query wave), each wave
 // has two independent MFMA/softmax chains to interleave, and at ~200 VGPRs four such workgroups share a CU, so one
 // workgroup's barrier / staging phase overlaps the others' compute.
 // DMA: K/V tiles arrive by LDS-DMA (buffer_load ... lds) into a 2-deep ring -- the next tile is in flight while this one is
@@ -948,27 +823,17 @@ extern "C" int cosa_attn_fwd(const void *qkv, void *out, float *lse, int B, int 
     }
     hipStream_t st = as_stream(stream);
     const int Npad = (N + BK - 1) / BK * BK;
-    const op16 *vt = nullptr;      // (flags bit 0, "V^T prepared", is ignored: there is no V^T copy)
-    // measured (tools/bench_attn2.py): with the LDS-DMA ring the 2 waves x 64 queries kernel wins at every length of the step
-    // (N=197: 18 vs 20 us, N=785: 127 vs 154 us, N=1765: 413 vs 541 us, N=3601: 777 vs 992 us); the 4 x 32 kernel with its
-    // register prefetch stays as the alternative.  flags bit 1 / bit 2 force either.
+    const op16 *vt = nullptr;      // (there is no V^T copy; `flags` is ignored: it selected among earlier kernel variants)
+    (void)flags;
     const int nblk = (N + BQ - 1) / BQ;
-    if ((flags & 2) && !(flags & 4))
-        hipLaunchKernelGGL(attn_fwd_kernel, dim3(nblk * ((B * H + 7) / 8 * 8)), dim3(256), 0, st, static_cast<const op16 *>(qkv), vt,
-                           static_cast<op16 *>(out), lse, N, Npad, H, nblk, B * H, scale * 1.4426950408889634f,
-                           reinterpret_cast<unsigned long long *>(stamps));
+    const dim3 grid(nblk * ((B * H + 7) / 8 * 8));
+    // LDS-DMA addresses one image's qkv rows through a 32-bit buffer offset; beyond 2 GiB per image the tiles are staged through registers
+    if ((size_t)N * 3 * H * HD * 2 >= 0x7fffffffull)
+        hipLaunchKernelGGL(attn_fwd2_kernel<false>, grid, dim3(128), 0, st, static_cast<const op16 *>(qkv), vt, static_cast<op16 *>(out), lse, N, Npad,
+                           H, nblk, B * H, scale * 1.4426950408889634f, reinterpret_cast<unsigned long long *>(stamps));
     else
-    {
-        static const bool no_dma = getenv("COSA_ATTN_NO_DMA") != nullptr;
-        if (no_dma || (size_t)N * 3 * H * HD * 2 >= 0x7fffffffull)
-            hipLaunchKernelGGL(attn_fwd2_kernel<false>, dim3(nblk * ((B * H + 7) / 8 * 8)), dim3(128), 0, st, static_cast<const op16 *>(qkv), vt,
-                               static_cast<op16 *>(out), lse, N, Npad, H, nblk, B * H, scale * 1.4426950408889634f,
-                               reinterpret_cast<unsigned long long *>(stamps));
-        else
-            hipLaunchKernelGGL(attn_fwd2_kernel<true>, dim3(nblk * ((B * H + 7) / 8 * 8)), dim3(128), 0, st, static_cast<const op16 *>(qkv), vt,
-                               static_cast<op16 *>(out), lse, N, Npad, H, nblk, B * H, scale * 1.4426950408889634f,
-                               reinterpret_cast<unsigned long long *>(stamps));
-    }
+        hipLaunchKernelGGL(attn_fwd2_kernel<true>, grid, dim3(128), 0, st, static_cast<const op16 *>(qkv), vt, static_cast<op16 *>(out), lse, N, Npad,
+                           H, nblk, B * H, scale * 1.4426950408889634f, reinterpret_cast<unsigned long long *>(stamps));
     COSA_LAUNCH_CHECK();
     return COSA_OK;
 }

@@ -266,9 +266,7 @@ extern "C" int cosa_gmm_fit_thresholds(const double *sorted, const long long *n_
     COSA_HIP_CHECK(hipMemsetAsync(tail, 0, 4 * sizeof(unsigned long long), st));
     // a small grid when there are few samples: every workgroup must be resident for the barrier (128 x 256 threads, 2.4 KB of LDS: always are)
     long long want = (capacity + kGmmThreads - 1) / kGmmThreads;
-    static const int cap = [] { const char *e = getenv("COSA_GMM_BLOCKS"); const int v = e ? atoi(e) : kGmmBlocks;
-                                return v < 1 ? 1 : (v > kGmmBlocks ? kGmmBlocks : v); }();      // experiment switch
-    const int blocks = (int)(want < 1 ? 1 : (want > cap ? cap : want));
+    const int blocks = (int)(want < 1 ? 1 : (want > kGmmBlocks ? kGmmBlocks : want));
     unsigned *counter = reinterpret_cast<unsigned *>(tail + 2);
     if (modal == 3)
         hipLaunchKernelGGL(gmm_fit_kernel<3>, dim3(blocks), dim3(kGmmThreads), 0, st, sorted, n_dev, tol, reg_covar, max_iter, rows,

@@ -132,86 +132,6 @@ __global__ __launch_bounds__(256) void par_affinity_kernel(const float *__restri
     }
 }
 
-// affinity, fast form: the dilation count is a template parameter so all neighbour offsets unroll to constants, the 8 taps
-// of a dilation are issued as independent loads, and the ND*8 logits stay in registers (the generic kernel above stages them
-// through the output buffer).  Same arithmetic, same order: bit-identical to the generic kernel and to the oracle.
-template <int ND>
-__global__ __launch_bounds__(256) void par_affinity_fast_kernel(const float *__restrict__ imgs, float *__restrict__ aff,
-                                                               int h, int w, ParPlan plan)
-{
-    const int pix = blockIdx.x * 256 + threadIdx.x;
-    const int hw = h * w;
-    if (pix >= hw) return;
-    const int b = blockIdx.y;
-    const int y = pix / w, x = pix - y * w;
-    constexpr int NN = ND * 8;
-    const float *img = imgs + (size_t)b * 3 * hw;
-    int off[ND][8];
-#pragma unroll
-    for (int di = 0; di < ND; di++) {
-        const int d = plan.dil[di];
-        const int ym = clampi(y - d, 0, h - 1) * w, y0 = y * w, yp = clampi(y + d, 0, h - 1) * w;
-        const int xm = clampi(x - d, 0, w - 1), xp = clampi(x + d, 0, w - 1);
-        off[di][0] = ym + xm; off[di][1] = ym + x; off[di][2] = ym + xp;
-        off[di][3] = y0 + xm; off[di][4] = y0 + xp;
-        off[di][5] = yp + xm; off[di][6] = yp + x; off[di][7] = yp + xp;
-    }
-    float lg[ND][8];
-#pragma unroll
-    for (int di = 0; di < ND; di++)
-#pragma unroll
-        for (int t = 0; t < 8; t++) lg[di][t] = 0.0f;
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-        const float *pl = img + (size_t)c * hw;
-        const float ctr = pl[pix];
-        float v[ND][8];
-#pragma unroll
-        for (int di = 0; di < ND; di++)
-#pragma unroll
-            for (int t = 0; t < 8; t++) v[di][t] = pl[off[di][t]];
-        float sum = 0.0f;
-#pragma unroll
-        for (int di = 0; di < ND; di++)
-#pragma unroll
-            for (int t = 0; t < 8; t++) sum = sum + v[di][t];
-        const float mean = sum / (float)NN;
-        float var = 0.0f;
-#pragma unroll
-        for (int di = 0; di < ND; di++)
-#pragma unroll
-            for (int t = 0; t < 8; t++) { const float dl = v[di][t] - mean; var = var + dl * dl; }
-        var = var / (float)(NN - 1);
-        const float sd = __builtin_sqrtf(var) + 1e-8f;
-#pragma unroll
-        for (int di = 0; di < ND; di++)
-#pragma unroll
-            for (int t = 0; t < 8; t++) {
-                float q = __builtin_fabsf(v[di][t] - ctr) / sd;
-                q = q / 0.3f;
-                lg[di][t] = lg[di][t] + (-(q * q));          // acc over c = 0,1,2 starting from 0.0f, as the spec
-            }
-    }
-    float mx = -INFINITY;
-#pragma unroll
-    for (int di = 0; di < ND; di++)
-#pragma unroll
-        for (int t = 0; t < 8; t++) { lg[di][t] = lg[di][t] / 3.0f; mx = lg[di][t] > mx ? lg[di][t] : mx; }
-    float es = 0.0f;
-#pragma unroll
-    for (int di = 0; di < ND; di++)
-#pragma unroll
-        for (int t = 0; t < 8; t++) { lg[di][t] = cosa_expf(lg[di][t] - mx); es = es + lg[di][t]; }
-    float *out = aff + (size_t)b * NN * hw + pix;
-#pragma unroll
-    for (int di = 0; di < ND; di++)
-#pragma unroll
-        for (int t = 0; t < 8; t++) {
-            const float a = lg[di][t] / es;
-            out[(size_t)(di * 8 + t) * hw] = a + 0.01f * plan.posw[di * 8 + t];
-        }
-}
-
 // IEEE-754 binary32 division with the divisor's part hoisted.  `x / d` on gfx950 is lowered to: (scale), r0 = rcp(d), e = fma(-d, r0, 1),
 // r = fma(e, r0, r0), q0 = x * r, e1 = fma(-d, q0, x), q1 = fma(e1, r, q0), e2 = fma(-d, q1, x), q = fma(e2, r, q1), (fixup): the
 // correctly rounded quotient.  The scale / fixup steps only act on operands near the ends of the exponent range; here 0 <= x <= 1e9
@@ -233,73 +153,14 @@ __device__ __forceinline__ float exact_div(float x, const ExactRcp &k)
     return __builtin_fmaf(e2, k.r, q1);
 }
 
-// affinity, v2: one channel at a time (48 taps + 48 logit accumulators live: ~130 VGPRs -> 3-4 waves per SIMD instead of the 304 VGPRs /
-// ONE wave per SIMD of par_affinity_fast_kernel) and the hoisted exact division above.  Same arithmetic, same order as the spec.
-template <int ND>
-__global__ __launch_bounds__(256, 3) void par_affinity_v2_kernel(const float *__restrict__ imgs, float *__restrict__ aff,
-                                                             int h, int w, ParPlan plan)
-{
-    const int pix = blockIdx.x * 256 + threadIdx.x;
-    const int hw = h * w;
-    if (pix >= hw) return;
-    const int b = blockIdx.y;
-    const int y = pix / w, x = pix - y * w;
-    constexpr int NN = ND * 8;
-    const float *img = imgs + (size_t)b * 3 * hw;
-    const ExactRcp k03 = exact_rcp(0.3f), k3 = exact_rcp(3.0f);
-    float lg[NN];
-#pragma unroll
-    for (int n = 0; n < NN; n++) lg[n] = 0.0f;
-#pragma unroll 1
-    for (int c = 0; c < 3; c++) {
-        const float *pl = img + (size_t)c * hw;
-        const float ctr = pl[pix];
-        float v[NN];
-#pragma unroll
-        for (int di = 0; di < ND; di++) {
-            const int d = plan.dil[di];
-            const int ym = clampi(y - d, 0, h - 1) * w, y0 = y * w, yp = clampi(y + d, 0, h - 1) * w;
-            const int xm = clampi(x - d, 0, w - 1), xp = clampi(x + d, 0, w - 1);
-            v[di * 8 + 0] = pl[ym + xm]; v[di * 8 + 1] = pl[ym + x]; v[di * 8 + 2] = pl[ym + xp];
-            v[di * 8 + 3] = pl[y0 + xm]; v[di * 8 + 4] = pl[y0 + xp];
-            v[di * 8 + 5] = pl[yp + xm]; v[di * 8 + 6] = pl[yp + x]; v[di * 8 + 7] = pl[yp + xp];
-        }
-        float sum = 0.0f;
-#pragma unroll
-        for (int n = 0; n < NN; n++) sum = sum + v[n];
-        const float mean = sum / (float)NN;
-        float var = 0.0f;
-#pragma unroll
-        for (int n = 0; n < NN; n++) { const float dl = v[n] - mean; var = var + dl * dl; }
-        var = var / (float)(NN - 1);
-        const ExactRcp ksd = exact_rcp(__builtin_sqrtf(var) + 1e-8f);
-#pragma unroll
-        for (int n = 0; n < NN; n++) {
-            float q = exact_div(__builtin_fabsf(v[n] - ctr), ksd);
-            q = exact_div(q, k03);
-            lg[n] = lg[n] + (-(q * q));                      // acc over c = 0,1,2 starting from 0.0f, as the spec
-        }
-    }
-    float mx = -INFINITY;
-#pragma unroll
-    for (int n = 0; n < NN; n++) { lg[n] = -exact_div(-lg[n], k3); mx = lg[n] > mx ? lg[n] : mx; }     // lg <= 0: divide the magnitude
-    float es = 0.0f;
-#pragma unroll
-    for (int n = 0; n < NN; n++) { lg[n] = cosa_expf(lg[n] - mx); es = es + lg[n]; }
-    const ExactRcp kes = exact_rcp(es);                      // 1 <= es <= 48
-    float *out = aff + (size_t)b * NN * hw + pix;
-#pragma unroll
-    for (int n = 0; n < NN; n++) out[(size_t)n * hw] = exact_div(lg[n], kes) + 0.01f * plan.posw[n];
-}
-
-// affinity, v3: the three image channels of a 16 x 16 pixel tile plus its 24-pixel replicate-clamped halo staged in LDS once (48 KB), every
+// affinity of the named configuration: the three image channels of a 16 x 16 pixel tile plus its 24-pixel replicate-clamped halo staged in LDS once (48 KB), every
 // tap an LDS read at a compile-time offset.  The taps of a channel are read three times (sum, variance, logits) instead of being held in 48
 // registers: ~80 VGPRs, six waves per SIMD, no global-load latency inside the arithmetic.  Same operations, same order as the spec.
 struct Dil6a { static constexpr int n = 6; static constexpr int d[6] = {1, 2, 4, 8, 12, 24}; };
 constexpr int kATile = 16, kAHalo = 24, kALW = kATile + 2 * kAHalo;        // 64 x 64 floats per channel
 
 template <typename DIL>
-__global__ __launch_bounds__(256) void par_affinity_v3_kernel(const float *__restrict__ imgs, float *__restrict__ aff,
+__global__ __launch_bounds__(256) void par_affinity_tiled_kernel(const float *__restrict__ imgs, float *__restrict__ aff,
                                                              int h, int w, ParPlan plan, int tiles_x)
 {
     __shared__ float timg[3][kALW * kALW];
@@ -362,59 +223,13 @@ __global__ __launch_bounds__(256) void par_affinity_v3_kernel(const float *__res
     for (int n = 0; n < NN; n++) out[(size_t)n * hw] = exact_div(lg[n], kes) + 0.01f * plan.posw[n];
 }
 
-// one propagation step; each thread owns one pixel of up to CG live planes.
-template <int CG>
-__global__ __launch_bounds__(256) void par_step_kernel(const float *__restrict__ aff, const float *__restrict__ src,
-                                                      float *__restrict__ dst, const int *__restrict__ kcount, int Kfull,
-                                                      int halves, int half_planes, size_t img_stride, int h, int w, ParPlan plan)
-{
-    const int b = blockIdx.z;
-    const int K = kcount ? kcount[b] : Kfull;
-    const int live = K * halves;
-    const int j0 = blockIdx.y * CG;
-    if (j0 >= live) return;
-    const int pix = blockIdx.x * 256 + threadIdx.x;
-    const int hw = h * w;
-    if (pix >= hw) return;
-    const int y = pix / w, x = pix - y * w;
-    const int NN = plan.n_dil * 8;
-    const float *sp[CG];
-    float *dp[CG];
-    float acc[CG];
-    bool ok[CG];
-#pragma unroll
-    for (int i = 0; i < CG; i++) {
-        int j = j0 + i;
-        ok[i] = j < live;
-        if (!ok[i]) j = j0;
-        const int half = j / K;
-        const int plane = half * half_planes + (j - half * K);
-        sp[i] = src + (size_t)b * img_stride + (size_t)plane * hw;
-        dp[i] = dst + (size_t)b * img_stride + (size_t)plane * hw;
-        acc[i] = 0.0f;
-    }
-    const float *ab = aff + (size_t)b * NN * hw + pix;
-    for (int n = 0; n < NN; n++) {
-        int dy, dx;
-        nbr_off(n & 7, dy, dx);
-        const int d = plan.dil[n >> 3];
-        const int o = clampi(y + dy * d, 0, h - 1) * w + clampi(x + dx * d, 0, w - 1);
-        const float a = ab[(size_t)n * hw];
-#pragma unroll
-        for (int i = 0; i < CG; i++) acc[i] = acc[i] + sp[i][o] * a;
-    }
-#pragma unroll
-    for (int i = 0; i < CG; i++)
-        if (ok[i]) dp[i][pix] = acc[i];
-}
 
-
-// v3 propagation step: ONE pixel per thread, ALL live planes of the image (up to 16) in the same thread.  The affinity tensor is
-// the HBM stream of a step (rocprofv3 PMC, profiles/r01_par_step_pmc.json: 595 MB per step launch with 4-plane groups = the 154 MB
-// tensor once per group); with every plane in one thread it is read once.  One pixel per thread keeps the registers small (16
-// accumulators + 16 plane bases) so the occupancy that the 4-pixel kernel loses with wide groups stays.
+// generic propagation step (any dilation list): ONE pixel per thread, ALL live planes of the image (up to 16) in the same thread.  The
+// affinity tensor is the HBM stream of a step (rocprofv3 PMC, profiles/r01_par_step_pmc.json: 595 MB per step launch when planes were
+// walked in groups of 4 = the 154 MB tensor once per group); with every plane in one thread it is read once.  One pixel per thread keeps
+// the registers small (16 accumulators + 16 plane bases).
 template <int NP>
-__device__ __forceinline__ void par_step1_body(const float *__restrict__ aff, const float *__restrict__ src, float *__restrict__ dst,
+__device__ __forceinline__ void par_step_body(const float *__restrict__ aff, const float *__restrict__ src, float *__restrict__ dst,
                                                int b, int pblk, int K, int j0, int nlive, int half_planes, size_t img_stride, int h,
                                                int w, const ParPlan &plan)
 {
@@ -454,7 +269,7 @@ __device__ __forceinline__ void par_step1_body(const float *__restrict__ aff, co
 // pixel blocks of one image spread over all XCDs every L2 ends up fetching every mask plane (PMC: 506 MB of fetches per launch for
 // 154 MB of affinities + 38 MB of masks).  Images are therefore pinned to XCDs: id -> (xcd = id & 7, j = id >> 3), image =
 // 8 * (j / blocks_per_image) + xcd, so an L2 only ever sees the planes of "its" images.
-__global__ __launch_bounds__(256) void par_step1_kernel(const float *__restrict__ aff, const float *__restrict__ src,
+__global__ __launch_bounds__(256) void par_step_kernel(const float *__restrict__ aff, const float *__restrict__ src,
                                                        float *__restrict__ dst, const int *__restrict__ kcount, int Kfull,
                                                        int halves, int half_planes, size_t img_stride, int h, int w, ParPlan plan,
                                                        int B, int pix_blocks, int groups, int pin)
@@ -478,141 +293,24 @@ __global__ __launch_bounds__(256) void par_step1_kernel(const float *__restrict_
     if (j0 >= live) return;
     int nlive = live - j0;
     nlive = nlive > 16 ? 16 : nlive;
-    if (nlive <= 2) par_step1_body<2>(aff, src, dst, b, pblk, K, j0, nlive, half_planes, img_stride, h, w, plan);
-    else if (nlive <= 4) par_step1_body<4>(aff, src, dst, b, pblk, K, j0, nlive, half_planes, img_stride, h, w, plan);
-    else if (nlive <= 6) par_step1_body<6>(aff, src, dst, b, pblk, K, j0, nlive, half_planes, img_stride, h, w, plan);
-    else if (nlive <= 8) par_step1_body<8>(aff, src, dst, b, pblk, K, j0, nlive, half_planes, img_stride, h, w, plan);
-    else if (nlive <= 12) par_step1_body<12>(aff, src, dst, b, pblk, K, j0, nlive, half_planes, img_stride, h, w, plan);
-    else par_step1_body<16>(aff, src, dst, b, pblk, K, j0, nlive, half_planes, img_stride, h, w, plan);
-}
-
-// v2 propagation step: each thread owns FOUR consecutive pixels of up to PG live planes.  The affinity row is read once
-// per neighbour as a float4 and shared by all planes.  Interior quads (every tap stays inside the row) take a
-// branch-free path: every neighbour quad is ONE 16-byte load (4-byte aligned; gfx950 global loads do not need more), the
-// 8 taps of a dilation are unrolled so ~8*(1+planes) loads are in flight per thread.  Border quads use clamped scalar
-// taps.  Per pixel the operation order is that of the scalar kernel (acc = acc + m*a, n ascending): bit-identical.
-struct __attribute__((packed, aligned(4))) f4u { float x, y, z, w; };
-
-template <int PG>
-__device__ __forceinline__ void par_step4_body(const float *__restrict__ aff, const float *__restrict__ src, float *__restrict__ dst,
-                                               int b, int K, int j0, int nlive, int half_planes, size_t img_stride, int h, int w,
-                                               const ParPlan &plan)
-{
-    const int w4 = w >> 2;
-    const int q = blockIdx.x * 256 + threadIdx.x;       // quad index
-    if (q >= h * w4) return;
-    const int y = q / w4, x0 = (q - y * w4) << 2;
-    const int hw = h * w;
-    const float *sp[PG];
-    float acc[PG][4];
-#pragma unroll
-    for (int i = 0; i < PG; i++) {
-        int j = j0 + (i < nlive ? i : 0);
-        const int half = j / K;
-        const int plane = half * half_planes + (j - half * K);
-        sp[i] = src + (size_t)b * img_stride + (size_t)plane * hw;
-#pragma unroll
-        for (int e = 0; e < 4; e++) acc[i][e] = 0.0f;
-    }
-    const float *ab = aff + (size_t)b * plan.n_dil * 8 * hw + (size_t)y * w + x0;
-    int dmax = 0;
-    for (int di = 0; di < plan.n_dil; di++) dmax = plan.dil[di] > dmax ? plan.dil[di] : dmax;
-    const bool interior = __all(x0 - dmax >= 0 && x0 + 3 + dmax < w);     // wave-uniform
-    if (interior) {
-        // planes beyond nlive alias plane 0 of the group: their loads hit L1 and their sums are never stored, which keeps
-        // this loop free of control flow so the loads of a whole dilation are issued together
-        for (int di = 0; di < plan.n_dil; di++) {
-            const int d = plan.dil[di];
-            const int rm = clampi(y - d, 0, h - 1) * w + x0, r0 = y * w + x0, rp = clampi(y + d, 0, h - 1) * w + x0;
-#pragma unroll
-            for (int t = 0; t < 8; t++) {
-                const int tt = t < 4 ? t : t + 1;
-                const int dy = tt / 3 - 1, dx = tt % 3 - 1;     // compile-time after unrolling
-                const int o = (dy < 0 ? rm : (dy > 0 ? rp : r0)) + dx * d;
-                const float4 a = *reinterpret_cast<const float4 *>(ab + (size_t)(di * 8 + t) * hw);
-#pragma unroll
-                for (int i = 0; i < PG; i++) {
-                    const f4u v = *reinterpret_cast<const f4u *>(sp[i] + o);
-                    acc[i][0] = acc[i][0] + v.x * a.x;
-                    acc[i][1] = acc[i][1] + v.y * a.y;
-                    acc[i][2] = acc[i][2] + v.z * a.z;
-                    acc[i][3] = acc[i][3] + v.w * a.w;
-                }
-            }
-        }
-    } else {
-        // border quads, still branch-free: ONE 16-byte load at the clamped window start, then each of the 4 taps picks
-        // its replicate-clamped column out of the loaded quad (select indices are per tap, shared by all planes)
-        for (int di = 0; di < plan.n_dil; di++) {
-            const int d = plan.dil[di];
-            const int rm = clampi(y - d, 0, h - 1) * w, r0 = y * w, rp = clampi(y + d, 0, h - 1) * w;
-#pragma unroll
-            for (int t = 0; t < 8; t++) {
-                const int tt = t < 4 ? t : t + 1;
-                const int dy = tt / 3 - 1, dx = tt % 3 - 1;
-                const int xs = x0 + dx * d;
-                const int xc = clampi(xs, 0, w - 4);
-                const int i0 = clampi(xs, 0, w - 1) - xc, i1 = clampi(xs + 1, 0, w - 1) - xc;
-                const int i2 = clampi(xs + 2, 0, w - 1) - xc, i3 = clampi(xs + 3, 0, w - 1) - xc;
-                const int o = (dy < 0 ? rm : (dy > 0 ? rp : r0)) + xc;
-                const float4 a = *reinterpret_cast<const float4 *>(ab + (size_t)(di * 8 + t) * hw);
-#pragma unroll
-                for (int i = 0; i < PG; i++) {
-                    const f4u v = *reinterpret_cast<const f4u *>(sp[i] + o);
-                    const float e0 = i0 == 0 ? v.x : (i0 == 1 ? v.y : (i0 == 2 ? v.z : v.w));
-                    const float e1 = i1 == 0 ? v.x : (i1 == 1 ? v.y : (i1 == 2 ? v.z : v.w));
-                    const float e2 = i2 == 0 ? v.x : (i2 == 1 ? v.y : (i2 == 2 ? v.z : v.w));
-                    const float e3 = i3 == 0 ? v.x : (i3 == 1 ? v.y : (i3 == 2 ? v.z : v.w));
-                    acc[i][0] = acc[i][0] + e0 * a.x;
-                    acc[i][1] = acc[i][1] + e1 * a.y;
-                    acc[i][2] = acc[i][2] + e2 * a.z;
-                    acc[i][3] = acc[i][3] + e3 * a.w;
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < PG; i++) {
-        if (i < nlive) {
-            const size_t off = (size_t)(sp[i] - src);
-            *reinterpret_cast<float4 *>(dst + off + (size_t)y * w + x0) = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
-        }
-    }
-}
-
-// Up to GROUP live planes of an image go through one pass over its affinity rows.  The body is instantiated for a few
-// plane counts and picked per image (wave-uniform), so an image with 2 live planes does not pay for GROUP.  Measured
-// (b=16, 224^2, T=10): the step is bound by the neighbour gathers (L1 / address-unit rate), not by the affinity stream, and
-// the registers of a wider body cost more occupancy than the shared affinity loads save (2.19 ms per pass at GROUP=4, 2.37 at 8,
-// 4.3 at 16; capping the registers only spills): GROUP=4 is the default.
-template <int GROUP>
-__global__ __launch_bounds__(256) void par_step4_kernel(const float *__restrict__ aff, const float *__restrict__ src,
-                                                       float *__restrict__ dst, const int *__restrict__ kcount, int Kfull,
-                                                       int halves, int half_planes, size_t img_stride, int h, int w, ParPlan plan)
-{
-    const int b = blockIdx.z;
-    const int K = kcount ? kcount[b] : Kfull;
-    const int live = K * halves;
-    const int j0 = blockIdx.y * GROUP;
-    if (j0 >= live) return;
-    int nlive = live - j0;
-    nlive = nlive > GROUP ? GROUP : nlive;
-    if (nlive <= 2) par_step4_body<2>(aff, src, dst, b, K, j0, nlive, half_planes, img_stride, h, w, plan);
-    else if (GROUP <= 4 || nlive <= 4) par_step4_body<4>(aff, src, dst, b, K, j0, nlive, half_planes, img_stride, h, w, plan);
-    else if (nlive <= 6) par_step4_body<6>(aff, src, dst, b, K, j0, nlive, half_planes, img_stride, h, w, plan);
-    else par_step4_body<8>(aff, src, dst, b, K, j0, nlive, half_planes, img_stride, h, w, plan);
+    if (nlive <= 2) par_step_body<2>(aff, src, dst, b, pblk, K, j0, nlive, half_planes, img_stride, h, w, plan);
+    else if (nlive <= 4) par_step_body<4>(aff, src, dst, b, pblk, K, j0, nlive, half_planes, img_stride, h, w, plan);
+    else if (nlive <= 6) par_step_body<6>(aff, src, dst, b, pblk, K, j0, nlive, half_planes, img_stride, h, w, plan);
+    else if (nlive <= 8) par_step_body<8>(aff, src, dst, b, pblk, K, j0, nlive, half_planes, img_stride, h, w, plan);
+    else if (nlive <= 12) par_step_body<12>(aff, src, dst, b, pblk, K, j0, nlive, half_planes, img_stride, h, w, plan);
+    else par_step_body<16>(aff, src, dst, b, pblk, K, j0, nlive, half_planes, img_stride, h, w, plan);
 }
 
 
-// v4 propagation step: LDS-tiled.  A 512-thread workgroup owns a TH x TW = 16 x 32 pixel tile of ONE image and walks ALL its live planes:
+// propagation step of the named configuration: LDS-tiled.  A 512-thread workgroup owns a TH x TW = 16 x 32 pixel tile of ONE image and walks ALL its live planes:
 //   * the 48 affinities of a pixel are loaded ONCE per step into registers and reused for every plane;
 //   * per plane, the tile plus a HALO-pixel ring (replicate-clamped at the image border, exactly the reference's F.pad) is staged in LDS
 //     -- 2240 floats for 512 pixels -- and the taps of every dilation d <= HALO (40 of the 48 for the named configuration
 //     1, 2, 4, 8, 12, 24) are LDS reads at compile-time offsets; only the d > HALO taps (8) remain global gathers, issued first;
 //   * two LDS buffers: the next plane's tile is fetched while this one is consumed, one barrier per plane.
-// Against one-pixel-per-thread gathers (par_step1_kernel: 48 L1 requests per pixel and plane) a plane costs 4.4 staged + 8 gathered
+// Against one-pixel-per-thread gathers (par_step_kernel: 48 L1 requests per pixel and plane) a plane costs 4.4 staged + 8 gathered
 // elements per pixel.  Accumulation order is the spec's (acc = acc + m * a, neighbour index ascending): bit-identical to the oracle.
-// DIL: compile-time dilation list (the only configuration the reference names, models/PAR.py:94); other lists take par_step1_kernel.
+// DIL: compile-time dilation list (the only configuration the reference names, models/PAR.py:94); other lists take par_step_kernel.
 constexpr int kTH = 16, kTW = 32, kHalo = 12;
 constexpr int kLW = kTW + 2 * kHalo, kLH = kTH + 2 * kHalo;           // 56 x 40
 struct Dil6 { static constexpr int n = 6; static constexpr int d[6] = {1, 2, 4, 8, 12, 24}; };
@@ -720,149 +418,6 @@ __global__ __launch_bounds__(512) void par_step_tiled_kernel(const float *__rest
 }
 
 
-// v5 propagation step: TWO horizontally adjacent pixels per thread, the whole 24-pixel halo in LDS.
-//   * 512-thread workgroup (8 waves, one workgroup per CU: the 96 affinities of a pixel pair stay in registers for the whole step, so a
-//     thread may use up to 256 VGPRs) = 16 x 64 pixel tile of one image, all its live planes;
-//   * per plane the (16 + 48) x (64 + 48) replicate-clamped halo tile (28 KB) arrives by LDS-DMA (global_load_lds_dword with per-lane
-//     clamped source addresses: no staging registers) into a ring of three buffers, two planes ahead of the one being consumed;
-//   * every tap of both pixels is ONE ds_read_b64 (even column offsets; 8-byte aligned since x, the halo and the row stride are even),
-//     issued as explicit instructions -- left to itself the compiler pairs them into ds_read2_b64, which moves the same bytes at half
-//     the rate (MI355X_MICROARCH.md, LDS table) -- one dilation (8 taps) ahead of the packed fp32 multiplies / adds that consume them;
-//   * no global gathers at all: against the one-pixel-per-thread gather kernel a pixel and plane costs 7 staged elements, 24.5 LDS
-//     read instructions and 48 packed VALU instructions instead of 48 L1 requests and 96 VALU instructions.
-// MEASURED SLOWER than the v4 kernel above (71 vs 58 us per step at b = 16, 224^2, 12 planes per image; kept as the A/B
-// alternative COSA_PAR_TILED=3): 224 VGPRs allow one 8-wave workgroup per CU, so a workgroup's affinity-load phase (196 KB at the
-// per-CU share of HBM) and its 14 LDS-DMA issues per thread and plane (~100 cycles each) are not covered by anybody else's arithmetic.
-// (Non-temporal policy on the affinity stream / outputs, tried on both tiled kernels: 5-10 % slower.  A third variant, two PLANES per
-// pass packed in ds_read_b64 / v_pk_* with one pixel per thread, needs ~135 VGPRs: at the 128 that two workgroups per CU allow it spills
-// the affinities and runs 5x slower.)  rocprofv3 PMC on v4 (profiles/r02_par_v4_pmc.txt): 196 MB fetched + 46 MB written per launch =
-// the compulsory bytes of a step (154 MB of affinities re-read + the planes), i.e. 4.2 TB/s at 58 us: the per-step kernels are within
-// 1.5x of what HBM allows as long as the affinity tensor is re-read every step.
-// Same operation order per pixel (acc = acc + m * a, neighbour index ascending; multiply and add stay separate roundings): bit-identical.
-constexpr int k5TH = 16, k5TW = 64, k5Halo = 24, k5T = 512, k5Ring = 3;
-constexpr int k5LW = k5TW + 2 * k5Halo, k5LH = k5TH + 2 * k5Halo;     // 112 x 64
-constexpr int k5NE = (k5LH * k5LW + k5T - 1) / k5T;                     // 14 staged elements per thread
-constexpr int k5Buf = k5NE * k5T * 4;                                   // bytes per ring slot
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef __attribute__((address_space(3))) void lds_void_p;
-typedef const __attribute__((address_space(1))) void gbl_void_p;
-
-template <typename DIL>
-__global__ __launch_bounds__(k5T) void par_step_pair_kernel(const float *__restrict__ aff, const float *__restrict__ src,
-                                                           float *__restrict__ dst, const int *__restrict__ kcount, int Kfull,
-                                                           int halves, int half_planes, size_t img_stride, int h, int w,
-                                                           int B, int tiles_x, int tiles_y, int pin)
-{
-    extern __shared__ __attribute__((aligned(16))) float tile5[];        // [k5Ring][k5NE * k5T]
-    constexpr int ND = DIL::n, NN = ND * 8;
-    static_assert(DIL::d[ND - 1] <= k5Halo, "every dilation must fit the halo");
-    const int id = blockIdx.x, per_img = tiles_x * tiles_y;
-    int b, rem;
-    if (pin) {
-        const int xcd = id & 7, j = id >> 3, slot = j / per_img;
-        rem = j - slot * per_img;
-        b = slot * 8 + xcd;
-    } else {
-        b = id / per_img;
-        rem = id - b * per_img;
-    }
-    if (b >= B) return;
-    const int tyi = rem / tiles_x, txi = rem - tyi * tiles_x;
-    const int y0 = tyi * k5TH, x0 = txi * k5TW;
-    const int tid = threadIdx.x, ty = tid >> 5, tp = tid & 31;           // row, pixel pair
-    const int y = y0 + ty, x = x0 + 2 * tp;
-    const bool valid = y < h && x < w;                                    // (w is even: both pixels of a pair are in or out together)
-    const int hw = h * w;
-    const int K = kcount ? kcount[b] : Kfull;
-    const int live = K * halves;
-    if (live <= 0) return;
-    const int pix = valid ? y * w + x : 0;
-
-    f32x2 a[NN];
-    {
-        const float *ab = aff + (size_t)b * NN * hw + pix;
-#pragma unroll
-        for (int n = 0; n < NN; n++) a[n] = *reinterpret_cast<const f32x2 *>(ab + (size_t)n * hw);
-    }
-    int goff[k5NE];
-#pragma unroll
-    for (int i = 0; i < k5NE; i++) {
-        const int e = tid + k5T * i;
-        const int r = e / k5LW, c = e - r * k5LW;
-        goff[i] = clampi(y0 - k5Halo + r, 0, h - 1) * w + clampi(x0 - k5Halo + c, 0, w - 1);
-    }
-    auto plane_off = [&](int j) {
-        const int half = j / K;
-        return (size_t)b * img_stride + (size_t)(half * half_planes + (j - half * K)) * hw;
-    };
-    const int wave_lds = (tid & ~63) * 4;              // LDS-DMA destination: wave-uniform base, the lane adds 4 * lane itself
-    auto stage = [&](int slot, const float *pl) {
-#pragma unroll
-        for (int i = 0; i < k5NE; i++)
-            __builtin_amdgcn_global_load_lds((gbl_void_p *)(pl + goff[i]),
-                                             (lds_void_p *)((unsigned char *)tile5 + slot * k5Buf + i * (k5T * 4) + wave_lds), 4, 0, 0);
-    };
-    stage(0, src + plane_off(0));
-    if (live > 1) stage(1, src + plane_off(1));
-    // LDS byte address of the top-left corner of this thread's 49 x 50 tap window: every tap offset is a non-negative immediate
-    const unsigned win0 = (unsigned)(size_t)(lds_void_p *)tile5 + (unsigned)((ty * k5LW + 2 * tp) * 4);
-    int slot = 0;
-    for (int j = 0; j < live; j++) {
-        // plane j's tile: everything this thread staged except the newest plane's k5NE DMA pieces (stores retire in order before them)
-        if (j + 1 < live) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(k5NE) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                                                     // ... and everybody else's; slot (j + 2) % 3 is free again
-        if (j + 2 < live) stage(slot == 0 ? 2 : slot - 1, src + plane_off(j + 2));     // (slot + 2) % 3
-        const unsigned win = win0 + (unsigned)(slot * k5Buf);
-        f32x2 acc = {0.0f, 0.0f};
-        f32x2 m[2][8];
-        float ol[2][8], oh[2][8];            // odd column offsets: two 4-byte reads, joined only AFTER the wait (asm results are not tracked)
-#define COSA_PAR_TAPS(di, g)                                                                                               \
-        _Pragma("unroll") for (int t = 0; t < 8; t++) {                                                                    \
-            const int tt = t < 4 ? t : t + 1;                                                                              \
-            const int dy = tt / 3 - 1, dx = tt % 3 - 1;                                                                    \
-            const int off = ((k5Halo + dy * DIL::d[di]) * k5LW + k5Halo + dx * DIL::d[di]) * 4;                            \
-            if ((dx * DIL::d[di]) % 2 == 0) {                                                                              \
-                asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(m[g][t]) : "v"(win), "i"(off));                         \
-                ol[g][t] = oh[g][t] = 0.0f;                                                                                \
-            } else {                                                                                                       \
-                asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(ol[g][t]) : "v"(win), "i"(off));                        \
-                asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(oh[g][t]) : "v"(win), "i"(off + 4));                    \
-                m[g][t] = (f32x2){0.0f, 0.0f};                                                                             \
-            }                                                                                                              \
-        }
-#define COSA_PAR_WAIT(cnt, g)                                                                                              \
-        asm volatile("s_waitcnt lgkmcnt(" #cnt ")"                                                                         \
-                     : "+v"(m[g][0]), "+v"(m[g][1]), "+v"(m[g][2]), "+v"(m[g][3]), "+v"(m[g][4]), "+v"(m[g][5]), "+v"(m[g][6]), "+v"(m[g][7]),  \
-                       "+v"(ol[g][0]), "+v"(ol[g][2]), "+v"(ol[g][3]), "+v"(ol[g][4]), "+v"(ol[g][5]), "+v"(ol[g][7]),      \
-                       "+v"(oh[g][0]), "+v"(oh[g][2]), "+v"(oh[g][3]), "+v"(oh[g][4]), "+v"(oh[g][5]), "+v"(oh[g][7]))
-        COSA_PAR_TAPS(0, 0);
-#pragma unroll
-        for (int di = 0; di < ND; di++) {
-            const int g = di & 1;
-            if (di + 1 < ND) {
-                COSA_PAR_TAPS(di + 1, (di + 1) & 1);
-                // this dilation's taps (issued before the next dilation's 8 or 14 reads) have arrived; the newer ones stay in flight
-                if (DIL::d[di + 1] % 2) { COSA_PAR_WAIT(14, g); } else { COSA_PAR_WAIT(8, g); }
-            } else {
-                COSA_PAR_WAIT(0, g);
-            }
-#pragma unroll
-            for (int t = 0; t < 8; t++) {
-                const int tt = t < 4 ? t : t + 1;
-                const int dx = tt % 3 - 1;
-                f32x2 mv = m[g][t];
-                if ((dx * DIL::d[di]) % 2 != 0) { mv[0] = ol[g][t]; mv[1] = oh[g][t]; }
-                acc = acc + mv * a[di * 8 + t];
-            }
-        }
-#undef COSA_PAR_WAIT
-#undef COSA_PAR_TAPS
-        if (valid) *reinterpret_cast<f32x2 *>(dst + plane_off(j) + pix) = acc;
-        slot = slot == 2 ? 0 : slot + 1;
-    }
-}
-
 }  // namespace
 
 int par_make_plan(const int *dilations, int n_dil, ParPlan *plan)
@@ -913,21 +468,13 @@ int par_make_plan(const int *dilations, int n_dil, ParPlan *plan)
 
 int par_launch_affinity(const float *imgs, float *aff, int B, int h, int w, const ParPlan &plan, hipStream_t st)
 {
-    dim3 grid((h * w + 255) / 256, B);
-    static const int v2 = [] { const char *e = getenv("COSA_PAR_AFF_V2"); return e ? atoi(e) : 1; }();
-    static const int v3 = [] { const char *e = getenv("COSA_PAR_AFF_V3"); return e ? atoi(e) : 1; }();
     bool named = plan.n_dil == Dil6a::n;
     for (int i = 0; named && i < Dil6a::n; i++) named = plan.dil[i] == Dil6a::d[i];
-    if (named && v3) {
+    if (named) {                          // the configuration the reference names: LDS-tiled kernel
         const int tiles_x = (w + kATile - 1) / kATile, tiles_y = (h + kATile - 1) / kATile;
-        hipLaunchKernelGGL(par_affinity_v3_kernel<Dil6a>, dim3(tiles_x * tiles_y, B), dim3(256), 0, st, imgs, aff, h, w, plan, tiles_x);
-        COSA_LAUNCH_CHECK();
-        return COSA_OK;
-    }
-    if (plan.n_dil == 6 && v2) hipLaunchKernelGGL(par_affinity_v2_kernel<6>, grid, dim3(256), 0, st, imgs, aff, h, w, plan);
-    else if (plan.n_dil == 6) hipLaunchKernelGGL(par_affinity_fast_kernel<6>, grid, dim3(256), 0, st, imgs, aff, h, w, plan);
-    else if (plan.n_dil == 3) hipLaunchKernelGGL(par_affinity_fast_kernel<3>, grid, dim3(256), 0, st, imgs, aff, h, w, plan);
-    else hipLaunchKernelGGL(par_affinity_kernel, grid, dim3(256), 0, st, imgs, aff, h, w, plan);
+        hipLaunchKernelGGL(par_affinity_tiled_kernel<Dil6a>, dim3(tiles_x * tiles_y, B), dim3(256), 0, st, imgs, aff, h, w, plan, tiles_x);
+    } else                                // any other dilation list: the generic kernel (same bits, slower)
+        hipLaunchKernelGGL(par_affinity_kernel, dim3((h * w + 255) / 256, B), dim3(256), 0, st, imgs, aff, h, w, plan);
     COSA_LAUNCH_CHECK();
     return COSA_OK;
 }
@@ -938,65 +485,24 @@ int par_launch_step(const float *aff, const float *src, float *dst, int B, int K
                     size_t plane_stride, int h, int w, const ParPlan &plan, hipStream_t st)
 {
     const int half_planes = Kmax / halves;
-    // default: the one-pixel, all-planes kernel (1.50 ms per shared pass against 2.19 with the 4-pixel, 4-plane kernel below, which
-    // COSA_PAR_SCALAR=0 brings back for A/B runs)
-    static const int scalar = [] { const char *e = getenv("COSA_PAR_SCALAR"); return e ? atoi(e) : 1; }();
-    static const int tiled = [] { const char *e = getenv("COSA_PAR_TILED"); return e ? atoi(e) : 1; }();     // 1: LDS-tiled v4 (default), 3: pixel-pair kernel (A/B), 0: gathers
+    COSA_REQUIRE((size_t)Kmax * h * w < (1ull << 31), "PAR: the planes of one image must stay below 2^31 elements");
     bool named = plan.n_dil == Dil6::n;
     for (int i = 0; named && i < Dil6::n; i++) named = plan.dil[i] == Dil6::d[i];
-    if (tiled == 3 && named && (w & 1) == 0 && (size_t)Kmax * h * w < (1ull << 31)) {     // pixel-pair kernel (A/B alternative, slower)
-        constexpr int kLds5 = k5Ring * k5Buf;
-        static bool attr_done = false;
-        if (!attr_done) {
-            COSA_HIP_CHECK(hipFuncSetAttribute((const void *)par_step_pair_kernel<Dil6>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds5));
-            attr_done = true;
-        }
-        const int tiles_x = (w + k5TW - 1) / k5TW, tiles_y = (h + k5TH - 1) / k5TH;
-        const int pin = (B % 8 == 0 || B >= 24) ? 1 : 0;
-        const long long nblk = (pin ? 8ll * ((B + 7) / 8) : (long long)B) * tiles_x * tiles_y;
-        COSA_REQUIRE(nblk < 0x7fffffffll, "PAR: grid too large");
-        hipLaunchKernelGGL(par_step_pair_kernel<Dil6>, dim3((unsigned)nblk), dim3(k5T), kLds5, st, aff, src, dst, kcount, Kmax, halves,
-                           half_planes, plane_stride, h, w, B, tiles_x, tiles_y, pin);
-        COSA_LAUNCH_CHECK();
-        return COSA_OK;
-    }
-    if (tiled && named && (size_t)Kmax * h * w < (1ull << 31)) {              // LDS-tiled step for the named configuration
+    const int pin = (B % 8 == 0 || B >= 24) ? 1 : 0;                  // balanced (or nearly) image count per XCD
+    const long long images = pin ? 8ll * ((B + 7) / 8) : (long long)B;
+    if (named) {                          // LDS-tiled step for the named configuration
         const int tiles_x = (w + kTW - 1) / kTW, tiles_y = (h + kTH - 1) / kTH;
-        const int pin = (B % 8 == 0 || B >= 24) ? 1 : 0;
-        const long long nblk = (pin ? 8ll * ((B + 7) / 8) : (long long)B) * tiles_x * tiles_y;
+        const long long nblk = images * tiles_x * tiles_y;
         COSA_REQUIRE(nblk < 0x7fffffffll, "PAR: grid too large");
         hipLaunchKernelGGL(par_step_tiled_kernel<Dil6>, dim3((unsigned)nblk), dim3(512), 0, st, aff, src, dst, kcount, Kmax, halves,
                            half_planes, plane_stride, h, w, B, tiles_x, tiles_y, pin);
-        COSA_LAUNCH_CHECK();
-        return COSA_OK;
-    }
-    if (scalar && (size_t)Kmax * h * w < (1ull << 31)) {
+    } else {                              // any other dilation list: one pixel per thread, gathers
         const int pix_blocks = (h * w + 255) / 256, groups = (Kmax + 15) / 16;
-        const int pin = (B % 8 == 0 || B >= 24) ? 1 : 0;                  // balanced (or nearly) image count per XCD
-        const long long nblk = (pin ? 8ll * ((B + 7) / 8) : (long long)B) * pix_blocks * groups;
+        const long long nblk = images * pix_blocks * groups;
         COSA_REQUIRE(nblk < 0x7fffffffll, "PAR: grid too large");
-        hipLaunchKernelGGL(par_step1_kernel, dim3((unsigned)nblk), dim3(256), 0, st, aff, src, dst, kcount, Kmax, halves, half_planes,
+        hipLaunchKernelGGL(par_step_kernel, dim3((unsigned)nblk), dim3(256), 0, st, aff, src, dst, kcount, Kmax, halves, half_planes,
                            plane_stride, h, w, plan, B, pix_blocks, groups, pin);
-        COSA_LAUNCH_CHECK();
-        return COSA_OK;
     }
-    if ((w & 3) == 0) {     // rows are float4-aligned: the 4-pixel kernel (all live planes of an image in one thread for K <= 4)
-        static const int group = [] { const char *e = getenv("COSA_PAR_GROUP"); return e ? atoi(e) : 4; }();   // experiment switch
-        const int G = group == 8 ? 8 : 4;
-        dim3 grid4((h * (w >> 2) + 255) / 256, (Kmax + G - 1) / G, B);
-        if (G == 8)
-            hipLaunchKernelGGL(par_step4_kernel<8>, grid4, dim3(256), 0, st, aff, src, dst, kcount, Kmax, halves, half_planes,
-                               plane_stride, h, w, plan);
-        else
-            hipLaunchKernelGGL(par_step4_kernel<4>, grid4, dim3(256), 0, st, aff, src, dst, kcount, Kmax, halves, half_planes,
-                               plane_stride, h, w, plan);
-        COSA_LAUNCH_CHECK();
-        return COSA_OK;
-    }
-    constexpr int CG = 4;
-    dim3 grid((h * w + 255) / 256, (Kmax + CG - 1) / CG, B);
-    hipLaunchKernelGGL(par_step_kernel<CG>, grid, dim3(256), 0, st, aff, src, dst, kcount, Kmax, halves, half_planes,
-                       plane_stride, h, w, plan);
     COSA_LAUNCH_CHECK();
     return COSA_OK;
 }

@@ -280,55 +280,7 @@ __global__ __launch_bounds__(256) void lattice_neighbors_kernel(LatticeParams P,
     }
 }
 
-__global__ __launch_bounds__(256) void lattice_zero_values_kernel(LatticeParams P, ImageBuffers B)
-{
-    const int n = blockIdx.y;
-    const size_t tot = ((size_t)B.M[n] + 1) * P.KP;
-    float *v0 = B.val0 + (size_t)n * ((size_t)P.Mmax + 1) * P.KP;
-    float *v1 = B.val1 + (size_t)n * ((size_t)P.Mmax + 1) * P.KP;
-    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < tot; e += (size_t)gridDim.x * 256) {
-        v0[e] = 0.0f;
-        if (e < (size_t)P.KP) v1[e] = 0.0f;   // sink row of the ping-pong twin
-    }
-}
-
-// ---- 3. splat: values[id+1][k] += bary * in[k][p]  (optionally in = seg*roi) -------------------------
-__global__ __launch_bounds__(256) void lattice_splat_kernel(const float *__restrict__ ins, const float *__restrict__ roi,
-                                                           int K, LatticeParams P, ImageBuffers B)
-{
-    extern __shared__ __attribute__((aligned(16))) float tile[];   // [TP][KP+1]
-    const int n = blockIdx.y;
-    const int p0 = blockIdx.x * TP;
-    const int KP = P.KP, ld = KP + 1;
-    const size_t hw = (size_t)P.N;
-    const float *in = ins + (size_t)n * K * hw;
-    for (int e = threadIdx.x; e < TP * KP; e += 256) {
-        const int k = e / TP, pl = e - k * TP;
-        float v = 0.0f;
-        if (k < K && p0 + pl < P.N) {
-            v = in[(size_t)k * hw + p0 + pl];
-            if (roi) v = v * roi[(size_t)n * hw + p0 + pl];
-        }
-        tile[pl * ld + k] = v;
-    }
-    __syncthreads();
-    const int *off = B.offset + ((size_t)n * P.Npad + p0) * PD1;
-    const float *bar = B.bary + ((size_t)n * P.Npad + p0) * PD1;
-    float *val = B.val0 + (size_t)n * ((size_t)P.Mmax + 1) * KP;
-    for (int e = threadIdx.x; e < TP * KP; e += 256) {
-        const int pl = e / KP, k = e - pl * KP;
-        if (p0 + pl >= P.N || k >= K) continue;
-        const float v = tile[pl * ld + k];
-#pragma unroll
-        for (int r = 0; r < PD1; r++) {
-            const int o = off[pl * PD1 + r] + 1;
-            const float w = bar[pl * PD1 + r];
-            atomicAdd(&val[(size_t)o * KP + k], w * v);
-        }
-    }
-}
-
-// ---- 3'. splat without atomics ------------------------------------------------------------------------
+// ---- 3. splat: values[id+1][k] += bary * in[k][p]  (optionally in = seg*roi), without atomics ---------
 // rows[n][p][k] = in[n][k][p] (* roi[n][p]): the filter input as pixel rows (LDS tile transpose)
 __global__ __launch_bounds__(256) void lattice_rows_kernel(const float *__restrict__ ins, const float *__restrict__ roi,
                                                           int K, LatticeParams P, ImageBuffers B)
@@ -684,20 +636,12 @@ int filter_phase(const float *ins, float *outs, int N, int K, const float *roi, 
     const dim3 blk(256);
     const int gs = 1024;
     const size_t lds = (size_t)TP * (P.KP + 1) * sizeof(float);
-    static const bool atomic_splat = [] { const char *e = getenv("COSA_LATTICE_ATOMIC_SPLAT"); return e && atoi(e) != 0; }();   // A/B: round-1 splat
-    if (atomic_splat) {
-        hipLaunchKernelGGL(lattice_zero_values_kernel, dim3(gs, N), blk, 0, st, P, B);
-        COSA_LAUNCH_CHECK();
-        hipLaunchKernelGGL(lattice_splat_kernel, dim3((P.N + TP - 1) / TP, N), blk, lds, st, ins, roi, K, P, B);
-        COSA_LAUNCH_CHECK();
-    } else {
-        hipLaunchKernelGGL(lattice_rows_kernel, dim3((P.N + TP - 1) / TP, N), blk, lds, st, ins, roi, K, P, B);
-        COSA_LAUNCH_CHECK();
-        if (P.KP <= 32) hipLaunchKernelGGL(lattice_splat_sorted_kernel<1>, dim3(gs, N), blk, 0, st, P, B);
-        else if (P.KP <= 64) hipLaunchKernelGGL(lattice_splat_sorted_kernel<2>, dim3(gs, N), blk, 0, st, P, B);
-        else hipLaunchKernelGGL(lattice_splat_sorted_kernel<3>, dim3(gs, N), blk, 0, st, P, B);
-        COSA_LAUNCH_CHECK();
-    }
+    hipLaunchKernelGGL(lattice_rows_kernel, dim3((P.N + TP - 1) / TP, N), blk, lds, st, ins, roi, K, P, B);
+    COSA_LAUNCH_CHECK();
+    if (P.KP <= 32) hipLaunchKernelGGL(lattice_splat_sorted_kernel<1>, dim3(gs, N), blk, 0, st, P, B);
+    else if (P.KP <= 64) hipLaunchKernelGGL(lattice_splat_sorted_kernel<2>, dim3(gs, N), blk, 0, st, P, B);
+    else hipLaunchKernelGGL(lattice_splat_sorted_kernel<3>, dim3(gs, N), blk, 0, st, P, B);
+    COSA_LAUNCH_CHECK();
     for (int j = 0; j <= PD; j++) {
         hipLaunchKernelGGL(lattice_blur_kernel, dim3(gs, N), blk, 0, st, j, j & 1, P, B);
         COSA_LAUNCH_CHECK();

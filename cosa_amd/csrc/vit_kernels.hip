@@ -745,7 +745,7 @@ extern "C" int cosa_layernorm_bwd(const void *dy, const void *x_new, const float
     COSA_REQUIRE(workspace_bytes >= cosa_layernorm_bwd_workspace_bytes(rows, dim), "cosa_layernorm_bwd: workspace too small");
     // two workgroups per CU: a wave walks its rows serially with one row of loads in flight, so the kernel is latency-bound on occupancy
     // (256 / 512 / 768 / 1024 workgroups: 22.3 + 4.8 / 16.0 + 6.5 / 17.1 + 8.1 / 18.9 + 9.5 us for the kernel + its partial-sum reduction)
-    static const int target_blocks = [] { const char *e = getenv("COSA_LN_BWD_BLOCKS"); const int v = e ? atoi(e) : 512; return v < 1 ? 1 : (v > 1024 ? 1024 : v); }();
+    constexpr int target_blocks = 512;
     int per = (rows + target_blocks - 1) / target_blocks;
     per = (per + 3) / 4 * 4;                                  // whole rounds of the workgroup's 4 waves
     const int nblk = (rows + per - 1) / per;

@@ -182,7 +182,7 @@ class VITNetwork(nn.Module):
         if tok32 is not None and tok.dtype in vitencoder._OP16 and self.decoder.conv6.weight.shape[1] % 64 == 0:
             seg = self.decoder.forward_tokens(tok, B, h, w)            # fused no-grad path: own implicit-GEMM convs
         elif tok.dtype == torch.bfloat16 and tok.is_cuda and self.decoder.conv6.weight.shape[1] % 128 == 0 \
-                and torch.is_grad_enabled() and nn_ops.own_decoder_backward():
+                and torch.is_grad_enabled():
             seg = self.decoder.forward_tokens_train(tok, B, h, w)      # training: forward + both gradients on own kernels
         else:
             seg = self.decoder.forward_nhwc(x4, dt).float().contiguous()

@@ -161,7 +161,7 @@ def gemm_bf16(x, w, b, epilogue=EPI_BIAS, residual=None, out=None):
         # (csrc/gemm_kernels.hip: launch_v6) whose share of the flops is not inside the span
         nt = ((M + 255) // 256) * (N // 256) if N % 256 == 0 else 0
         rem, rounds_up = nt % 256, (nt + 255) // 256
-        frac = (nt - rem) / nt if (nt > 256 and 0 < rem <= int(os.environ.get("COSA_GEMM_TAIL", "48")) and (256 - rem) * 10 > 256 * rounds_up) else 1.0
+        frac = (nt - rem) / nt if (nt > 256 and 0 < rem <= 48 and (256 - rem) * 10 > 256 * rounds_up) else 1.0
         _C.fn16("cosa_gemm_set_stamp_slot", dt)(gemm_stamps.next_slot(2.0 * M * N * K * frac))
     with _C.profiled("gemm_bf16"):
         _C.check(_C.fn16("cosa_gemm_bf16", dt)(_C.ptr(x), _C.ptr(w), _C.ptr(b), _C.ptr(residual), _C.ptr(out), M, N, K, epilogue,
@@ -187,11 +187,6 @@ def conv3x3_dilated_tokens(tok, w16, B, h, w, dilation, relu=True):
                                                     ldx, int(relu), _C.stream_ptr()), "cosa_conv3x3_dilated_nhwc")
     _flops["conv3x3"] = _flops.get("conv3x3", 0) + 2.0 * B * h * w * Cout * Cin * 9
     return y
-
-
-def own_decoder_backward():
-    """COSA_DECODER_MIOPEN=1 sends the student's LargeFOV convolutions back through F.conv2d (A/B switch)."""
-    return os.environ.get("COSA_DECODER_MIOPEN", "0") != "1"
 
 
 def _token_view_geometry(tok, B, h, w):
@@ -630,7 +625,6 @@ class TransposedShadows:
 
 
 _transposed = {}       # id(weight) -> (weight, bf16 W^T)
-_AB_LIB_GEMM = os.environ.get("COSA_STUDENT_LIB_GEMM", "0") == "1"      # A/B switch only: student linears through torch (library GEMMs)
 _zeros16 = {}
 
 
@@ -708,7 +702,7 @@ def linear_view2d(x, weight, bias, dtype):
 def linear(x, weight, bias, dtype, act=False):
     """nn.Linear (+ GELU with act=True) on `dtype` operands from fp32 masters.  Training on the GPU with registered shadows (bf16 W, b and
     W^T): LinearShadowFn, every GEMM an own kernel; otherwise (fp32 parity mode, odd shapes) torch."""
-    if torch.is_grad_enabled() and weight.requires_grad and dtype == torch.bfloat16 and x.is_cuda and not _AB_LIB_GEMM:
+    if torch.is_grad_enabled() and weight.requires_grad and dtype == torch.bfloat16 and x.is_cuda:
         ew, eb, et = _shadows.get(id(weight)), _shadows.get(id(bias)), _transposed.get(id(weight))
         if ew is not None and eb is not None and et is not None and ew[0] is weight and eb[0] is bias and et[0] is weight \
                 and _own_gemm_ok(x.numel() // x.shape[-1], weight.shape[0], weight.shape[1]) and weight.shape[0] % 64 == 0 \

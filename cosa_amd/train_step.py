@@ -93,9 +93,9 @@ class CoSATrainer:
         self.reg_layer = seg_helper.DenseEnergyLoss(weight=1e-7, sigma_rgb=15, sigma_xy=100, scale_factor=0.5)
         self.refine_model = PAR(num_iter=10, dilations=[1, 2, 4, 8, 12, 24]) if args.usepar else None
         # the regulariser's lattice depends on the strong image only and can be built on a side stream while the networks run
-        # (lattice_async / COSA_LATTICE_ASYNC=1).  Measured neutral (334.2 vs 335.0 img/s: the CUs are already full), so it is off.
+        # (args.lattice_async).  Measured neutral (334.2 vs 335.0 img/s: the CUs are already full), so it is off.
         self._lattice = seg_helper.PreparedLattice(self.reg_layer.sigma_rgb, self.reg_layer.sigma_xy * self.reg_layer.scale_factor) \
-            if ((getattr(args, "lattice_async", False) or os.environ.get("COSA_LATTICE_ASYNC", "0") == "1") and device.type == "cuda") else None
+            if (getattr(args, "lattice_async", False) and device.type == "cuda") else None
         if args.usegmm:
             # main.py:94-103: queues of per-cell CAM maxima + EMA trackers of the fitted thresholds, all device-resident
             qdim = (args.crop_size // args.gmmscale) ** 2

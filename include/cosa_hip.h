@@ -180,8 +180,8 @@ int cosa_dense_energy_backward(const float *AS, const float *roi, const float *g
  *   qkv [B,N,3,H,64] bf16 (output of the qkv projection)   out [B,N,H*64] bf16
  *   lse [B,H,N] f32 (log-sum-exp of the scaled scores, kept for the backward pass)
  *   V is read in place (its V^T fragments come from the transposing LDS read): the workspace is a token 256 bytes and
- *   cosa_attn_prepare_vt a no-op, both kept for callers written against the earlier V^T-copy version; flags bit0 is
- *   ignored, bit1 / bit2 force the 4x32-query / 2x64-query decomposition (default: chosen by sequence length).
+ *   cosa_attn_prepare_vt a no-op, both kept for callers written against the earlier V^T-copy version; `flags` is
+ *   ignored (it selected among earlier kernel variants).
  * ------------------------------------------------------------------------------------- */
 size_t cosa_attn_workspace_bytes(int B, int N, int H);
 int cosa_attn_prepare_vt(const void *qkv, int B, int N, int H, void *workspace, size_t workspace_bytes, void *stream);

@@ -277,29 +277,3 @@ def test_narrow_linear_forward_backward_vs_fp64_autograd(M, N, K):
     x.grad = None
     nn_ops.narrow_linear(x, w).backward(dy)
     assert torch.equal(w.grad, g1)
-
-
-def test_gemm_banded_tile_order_switch():
-    """COSA_GEMM_BAND=-1 (read once per process, hence the child): the persistent kernel walks every XCD's m-panels in bands of n-tiles.
-    It is a permutation of the job list and nothing else: results must be bit-identical to the default order."""
-    import os, subprocess, sys, tempfile
-    code = (
-        "import sys, torch\n"
-        "sys.path.insert(0, %r)\n"
-        "from cosa_amd import nn_ops\n"
-        "torch.manual_seed(0)\n"
-        "outs = []\n"
-        "for (M, N, K, epi) in ((16384, 3072, 768, 1), (18432, 2304, 768, 0), (16384, 768, 768, 2)):\n"
-        "    x = torch.randn(M, K, device='cuda').bfloat16(); w = (torch.randn(N, K, device='cuda') * K ** -0.5).bfloat16()\n"
-        "    b = torch.randn(N, device='cuda').bfloat16(); r = torch.randn(M, N, device='cuda') if epi == 2 else None\n"
-        "    outs.append(nn_ops.gemm_bf16(x, w, b, epi, residual=r).cpu())\n"
-        "torch.save(outs, sys.argv[1])\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    res = {}
-    with tempfile.TemporaryDirectory() as d:
-        for tag, band in (("off", "0"), ("on", "-1")):
-            env = dict(os.environ, COSA_GEMM_BAND=band)
-            path = os.path.join(d, tag + ".pt")
-            subprocess.run([sys.executable, "-c", code, path], env=env, check=True, timeout=300)
-            res[tag] = torch.load(path)
-    for a, b in zip(res["off"], res["on"]):
-        assert torch.equal(a, b)

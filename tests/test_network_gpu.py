@@ -315,8 +315,7 @@ def test_add_layernorm_fwd_bwd_vs_torch(rows):
 
 
 def test_attention_fwd_dma_ring_is_run_to_run_deterministic():
-    """race screen for the LDS-DMA ring of the forward kernel (no atomics: identical bits every run, and equal to the
-    register-staged 4x32 kernel's within bf16 rounding)"""
+    """race screen for the LDS-DMA ring of the forward kernel (no atomics: identical bits every run)"""
     from cosa_amd import _C
     torch.manual_seed(3)
     L = _C.lib()
@@ -334,9 +333,6 @@ def test_attention_fwd_dma_ring_is_run_to_run_deterministic():
         for _ in range(20):
             o, l = run(0)
             assert torch.equal(o, o0) and torch.equal(l, l0)
-        o4, l4 = run(2)                                      # 4 x 32 kernel
-        assert (o4.float() - o0.float()).abs().max().item() <= 2.0 ** -7 * o0.float().abs().max().item()
-        assert (l4 - l0).abs().max().item() < 1e-3
 
 
 def test_attention_backward_is_run_to_run_deterministic():

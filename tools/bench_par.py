@@ -1,5 +1,5 @@
 """PAR refine timing alone (the second half of the headline metric): cam2mask_multi on main+aux CAM sets, b=16 448^2.
-usage: python tools/bench_par.py   (COSA_PAR_GROUP=4|8|16 selects the plane group of the propagation step)"""
+usage: python tools/bench_par.py"""
 import os, sys, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -31,6 +31,6 @@ def timed(f, n=10):
 multi = lambda r: (lambda: seg_helper.cam2mask_multi(den, box, [cams, cams_aux], lab, [0.7, 0.7], [0.25, 0.25], refine_model=r, _fold_validation=True))
 sep = lambda r: (lambda: (seg_helper.cam2mask(den, box, cams, lab, 0.7, 0.25, refine_model=r, _fold_validation=True),
                           seg_helper.cam2mask(den, box, cams_aux, lab, 0.7, 0.25, refine_model=r, _fold_validation=True)))
-out = {"group": os.environ.get("COSA_PAR_GROUP", "4"),
+out = {
        "multi_ms": round(timed(multi(par)) - timed(multi(None)), 4), "separate_ms": round(timed(sep(par)) - timed(sep(None)), 4)}
 print(json.dumps(out))

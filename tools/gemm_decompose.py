@@ -1,6 +1,7 @@
 """Where does a job of the persistent GEMM spend its time?  (a) K sweep at the qkv shape: time per job = nk * t + s; (b) the timing ablations of
 the epilogue (COSA_GEMM_VARIANT 61..65: no stores / no epilogue / L2-resident store window / stores dropped by the range check); run it
-under COSA_GEMM_STAGGER=<ticks | 1 << 20> for the start-stagger experiment."""
+under COSA_GEMM_STAGGER=<ticks | 1 << 20> for the start-stagger experiment.  Needs the experiments build of the library:
+COSA_EXTRA_FLAGS_GEMM_KERNELS=-DCOSA_GEMM_EXPERIMENTS=1 python -m cosa_amd.build --force"""
 import os, sys, torch
 sys.path.insert(0, ".")
 from cosa_amd import nn_ops, _C
