@@ -443,7 +443,7 @@ def main():
                     "hip_event_avg_ms_eager_launches": round(ev_ms / ev_n, 4) if ev_n else None}
         fams = [family(nn_ops.gemm_stamps, "gemm_bf16_v6_kernel (persistent 256x256 MFMA GEMM: qkv / proj+residual / fc1+GELU / fc2+residual)",
                        "r02_gemm_v6_pmc.json", "gemm_bf16"),
-                family(nn_ops.stamps, "attn_fwd_kernel / attn_fwd2_kernel (fused attention forward)", "r02_attn_fwd_pmc.json", "attn_fwd")]
+                family(nn_ops.stamps, "attn_fwd2_kernel (fused attention forward)", "r02_attn_fwd_pmc.json", "attn_fwd")]
         fams = sorted([f for f in fams if f], key=lambda f: -f["share_of_step"])
         roof = fams[0] if fams else None
         # the remaining legs time their own launches: stamping off (the buffers stay alive: the teacher's captured launches still write to them)
