@@ -302,27 +302,35 @@ __global__ __launch_bounds__(256) void par_step_kernel(const float *__restrict__
 }
 
 
-// propagation step of the named configuration: LDS-tiled.  A 512-thread workgroup owns a TH x TW = 16 x 32 pixel tile of ONE image and walks ALL its live planes:
+// propagation step of the named configuration: LDS-tiled, two planes per pass.  A 256-thread workgroup owns a TH x TW = 8 x 32 pixel tile
+// of ONE image and walks ALL its live planes in PAIRS:
 //   * the 48 affinities of a pixel are loaded ONCE per step into registers and reused for every plane;
-//   * per plane, the tile plus a HALO-pixel ring (replicate-clamped at the image border, exactly the reference's F.pad) is staged in LDS
-//     -- 2240 floats for 512 pixels -- and the taps of every dilation d <= HALO (40 of the 48 for the named configuration
-//     1, 2, 4, 8, 12, 24) are LDS reads at compile-time offsets; only the d > HALO taps (8) remain global gathers, issued first;
-//   * two LDS buffers: the next plane's tile is fetched while this one is consumed, one barrier per plane.
-// Against one-pixel-per-thread gathers (par_step_kernel: 48 L1 requests per pixel and plane) a plane costs 4.4 staged + 8 gathered
-// elements per pixel.  Accumulation order is the spec's (acc = acc + m * a, neighbour index ascending): bit-identical to the oracle.
+//   * per plane pair, the tile plus a HALO-pixel ring (replicate-clamped at the image border, exactly the reference's F.pad) is staged in LDS
+//     as (plane j, plane j + 1) float pairs -- 1792 pairs for 256 pixels -- and the taps of every dilation d <= HALO (40 of the 48 for the
+//     named configuration 1, 2, 4, 8, 12, 24) are ds_read_b64 at compile-time offsets: one LDS instruction serves both planes at twice the
+//     bytes per clock of ds_read_b32 (the single-plane form of this kernel spent 2.0 of its 3.9 us per plane in the LDS pipe), and the
+//     multiply / add of the two planes are one packed instruction each (v_pk_mul_f32 with the affinity broadcast, v_pk_add_f32: separate
+//     IEEE roundings per half, as the spec's mul-then-sum); only the d > HALO taps (8) remain global gathers, issued first;
+//   * the reads are explicit instructions (left to itself the compiler joins neighbours into ds_read2_b64, which moves the same bytes at
+//     half the rate) issued one dilation ahead of the arithmetic that consumes them;
+//   * two LDS buffers: the next pair's tile is fetched while this one is consumed, one barrier per pair.
+// An odd plane count walks its last plane twice (second copy not stored).  Accumulation order is the spec's (acc = acc + m * a, neighbour
+// index ascending): bit-identical to the oracle.
 // DIL: compile-time dilation list (the only configuration the reference names, models/PAR.py:94); other lists take par_step_kernel.
-constexpr int kTH = 16, kTW = 32, kHalo = 12;
-constexpr int kLW = kTW + 2 * kHalo, kLH = kTH + 2 * kHalo;           // 56 x 40
+constexpr int kTH = 8, kTW = 32, kHalo = 12, kStepThreads = kTH * kTW;      // 256 threads: ~135 registers per thread -> three workgroups per CU
+constexpr int kLW = kTW + 2 * kHalo, kLH = kTH + 2 * kHalo;           // 56 x 32
 struct Dil6 { static constexpr int n = 6; static constexpr int d[6] = {1, 2, 4, 8, 12, 24}; };
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) void lds_void_p;
 
 template <typename DIL>
-__global__ __launch_bounds__(512) void par_step_tiled_kernel(const float *__restrict__ aff, const float *__restrict__ src,
-                                                            float *__restrict__ dst, const int *__restrict__ kcount, int Kfull,
-                                                            int halves, int half_planes, size_t img_stride, int h, int w,
-                                                            int B, int tiles_x, int tiles_y, int pin)
+__global__ __launch_bounds__(kStepThreads, 3) void par_step_tiled_kernel(const float *__restrict__ aff, const float *__restrict__ src,
+                                                               float *__restrict__ dst, const int *__restrict__ kcount, int Kfull,
+                                                               int halves, int half_planes, size_t img_stride, int h, int w,
+                                                               int B, int tiles_x, int tiles_y, int pin)
 {
-    constexpr int NE = (kLH * kLW + 511) / 512;        // staged elements per thread (5)
-    __shared__ float tile[2][NE * 512];                // kLH x kLW halo tile, padded so that every thread stages NE elements unconditionally
+    constexpr int NE = (kLH * kLW + kStepThreads - 1) / kStepThreads;        // staged positions per thread (7)
+    __shared__ __attribute__((aligned(16))) f32x2 tile[2][NE * kStepThreads];   // kLH x kLW halo tile of plane pairs, padded so that every thread stages NE positions unconditionally
     constexpr int ND = DIL::n, NN = ND * 8;
     const int id = blockIdx.x, per_img = tiles_x * tiles_y;
     int b, rem;
@@ -341,19 +349,37 @@ __global__ __launch_bounds__(512) void par_step_tiled_kernel(const float *__rest
     const int y = y0 + ty, x = x0 + tx;
     const bool valid = y < h && x < w;
     const int hw = h * w;
-    const int K = kcount ? kcount[b] : Kfull;
+    const int K = __builtin_amdgcn_readfirstlane(kcount ? kcount[b] : Kfull);     // (uniform: keeps the plane offsets in scalar registers)
     const int live = K * halves;
     if (live <= 0) return;
     const int pix = valid ? y * w + x : 0;
 
-    float a[NN];
+    // affinities n = 2k, 2k + 1 share a register pair: the packed multiply broadcasts either half (op_sel), so the 48 cost 48 registers
+    // (written as `m * a` the compiler wants every broadcast operand in the low half of a pair of its own: 96 registers, spills)
+    // (global accesses go through buffer descriptors: a 32-bit lane offset + a wave-uniform plane offset per access instead of a 64-bit
+    // address computed in two more registers each; the launcher checks that every operand stays below 4 GiB)
+    const __amdgpu_buffer_rsrc_t rs_aff = __builtin_amdgcn_make_buffer_rsrc((void *)aff, 0, (unsigned)((size_t)B * NN * hw * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc((void *)src, 0, (unsigned)((size_t)B * img_stride * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_dst = __builtin_amdgcn_make_buffer_rsrc((void *)dst, 0, (unsigned)((size_t)B * img_stride * 4), 0x00020000);
+    auto ld = [&](const __amdgpu_buffer_rsrc_t &rs, unsigned lane_off, unsigned uni_off) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, lane_off, uni_off, 0));
+    };
+    f32x2 ap[NN / 2];
     {
-        const float *ab = aff + (size_t)b * NN * hw + pix;
+        const unsigned ab = (unsigned)(b * NN * hw) * 4u;
 #pragma unroll
-        for (int n = 0; n < NN; n++) a[n] = ab[(size_t)n * hw];
+        for (int n = 0; n < NN / 2; n++) ap[n] = (f32x2){ld(rs_aff, pix * 4, ab + (unsigned)(2 * n * hw) * 4u), ld(rs_aff, pix * 4, ab + (unsigned)((2 * n + 1) * hw) * 4u)};
     }
+    // acc = acc + (mv[0] * a[n], mv[1] * a[n]), n a compile-time constant after unrolling: one asm statement (multiply, then add: two
+    // roundings), volatile so that it stays between the LDS reads it is written between -- left free, the scheduler issues all the reads
+    // first and keeps all 40 products in registers
+    auto mul_add = [&](f32x2 &acc, const f32x2 &mv, int n) {
+        f32x2 p;
+        if (n & 1) asm volatile("v_pk_mul_f32 %1, %2, %3 op_sel:[0,1] op_sel_hi:[1,1]\n\tv_pk_add_f32 %0, %0, %1" : "+v"(acc), "=&v"(p) : "v"(mv), "v"(ap[n >> 1]));
+        else asm volatile("v_pk_mul_f32 %1, %2, %3 op_sel_hi:[1,0]\n\tv_pk_add_f32 %0, %0, %1" : "+v"(acc), "=&v"(p) : "v"(mv), "v"(ap[n >> 1]));
+    };
     // global offsets of the far taps (d > kHalo), clamped; shared by all planes
-    int ofar[8];
+    unsigned ofar[8];
     {
         constexpr int df = DIL::d[ND - 1];
         const int yc = valid ? y : 0, xc = valid ? x : 0;
@@ -361,58 +387,84 @@ __global__ __launch_bounds__(512) void par_step_tiled_kernel(const float *__rest
         const int xm = clampi(xc - df, 0, w - 1), xp = clampi(xc + df, 0, w - 1);
         ofar[0] = rm + xm; ofar[1] = rm + xc; ofar[2] = rm + xp; ofar[3] = r0 + xm; ofar[4] = r0 + xp;
         ofar[5] = rp + xm; ofar[6] = rp + xc; ofar[7] = rp + xp;
+#pragma unroll
+        for (int t = 0; t < 8; t++) ofar[t] *= 4u;                                     // byte offsets
     }
     static_assert(DIL::d[ND - 1] > kHalo && DIL::d[ND - 2] <= kHalo, "exactly the last dilation is gathered, the others are staged");
-    // staging map of this thread: elements e = tid, tid + 512, ... of the (kLH x kLW) halo tile -> clamped image offsets
-    int goff[NE];
+    // staging map of this thread: positions e = tid, tid + 256, ... of the (kLH x kLW) halo tile -> clamped image offsets
+    unsigned goff[NE];
 #pragma unroll
     for (int i = 0; i < NE; i++) {
-        const int e = tid + 512 * i;                   // (elements past the tile land in the padding: any valid address will do)
+        const int e = tid + kStepThreads * i;                   // (positions past the tile land in the padding: any valid address will do)
         const int r = e / kLW, c = e - r * kLW;
-        goff[i] = clampi(y0 - kHalo + r, 0, h - 1) * w + clampi(x0 - kHalo + c, 0, w - 1);
+        goff[i] = (unsigned)(clampi(y0 - kHalo + r, 0, h - 1) * w + clampi(x0 - kHalo + c, 0, w - 1)) * 4u;        // byte offsets
     }
-    auto plane_off = [&](int j) {
+    auto plane_off = [&](int j) {                      // byte offset of live plane j of this image (wave-uniform)
+        j = j < live ? j : live - 1;                   // the partner of an odd count's last plane is that plane again
         const int half = j / K;
-        return (size_t)b * img_stride + (size_t)(half * half_planes + (j - half * K)) * hw;
+        return (unsigned)(((size_t)b * img_stride + (size_t)(half * half_planes + (j - half * K)) * hw) * 4);
     };
-    // staging in two halves so that all NE loads of a thread are in flight together: fetch -> registers, (compute), registers -> LDS
-    float sv[NE];
-    auto fetch = [&](const float *pl) {
+    // staging: fetch -> registers, (compute), registers -> LDS, so that all loads of a thread are in flight together
+    f32x2 sv[NE];
+    auto fetch = [&](int q) {
+        const unsigned p0 = plane_off(2 * q), p1 = plane_off(2 * q + 1);
 #pragma unroll
-        for (int i = 0; i < NE; i++) sv[i] = pl[goff[i]];
+        for (int i = 0; i < NE; i++) sv[i] = (f32x2){ld(rs_src, goff[i], p0), ld(rs_src, goff[i], p1)};
     };
     auto commit = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < NE; i++) tile[buf][tid + 512 * i] = sv[i];
+        for (int i = 0; i < NE; i++) tile[buf][tid + kStepThreads * i] = sv[i];
     };
-    fetch(src + plane_off(0));
+    fetch(0);
     commit(0);
     __syncthreads();
-    const float *ctr = &tile[0][(ty + kHalo) * kLW + tx + kHalo];
-    for (int j = 0; j < live; j++) {
-        const float *pl = src + plane_off(j);
-        float far[8];
+    // LDS byte address of the top-left corner of this thread's 25 x 25 tap window: every tap offset is a non-negative immediate
+    const unsigned win0 = (unsigned)(size_t)(lds_void_p *)&tile[0][0] + (unsigned)((ty * kLW + tx) * 8);
+    const int npairs = (live + 1) >> 1;
+    for (int q = 0; q < npairs; q++) {
+        const unsigned p0 = plane_off(2 * q), p1 = plane_off(2 * q + 1);
+        f32x2 far[8];
 #pragma unroll
-        for (int t = 0; t < 8; t++) far[t] = pl[ofar[t]];                       // the gathers go first: their latency hides under the LDS taps
-        const bool more = j + 1 < live;                                        // (wave-uniform)
-        if (more) fetch(src + plane_off(j + 1));                               // next plane's tile: in flight during this plane's taps
-        const float *c = ctr + (j & 1) * (NE * 512);
-        float acc = 0.0f;
-#pragma unroll
-        for (int di = 0; di < ND - 1; di++) {
-            constexpr int dummy = 0; (void)dummy;
-            const int d = DIL::d[di];
-#pragma unroll
-            for (int t = 0; t < 8; t++) {
-                const int tt = t < 4 ? t : t + 1;
-                const int dy = tt / 3 - 1, dx = tt % 3 - 1;
-                acc = acc + c[dy * d * kLW + dx * d] * a[di * 8 + t];
-            }
+        for (int t = 0; t < 8; t++) far[t] = (f32x2){ld(rs_src, ofar[t], p0), ld(rs_src, ofar[t], p1)};         // the gathers go first: their latency hides under the LDS taps
+        const bool more = q + 1 < npairs;                                              // (wave-uniform)
+        if (more) fetch(q + 1);                                                        // next pair's tile: in flight during this pair's taps
+        const unsigned win = win0 + (unsigned)((q & 1) * (NE * kStepThreads * 8));
+        f32x2 acc = {0.0f, 0.0f};
+        // taps in groups of four (half a dilation), two groups in flight: group G = 2 di + hf covers t = 4 hf .. 4 hf + 3 of dilation di
+        f32x2 m[2][4];
+#define COSA_PAR_TAPS(G)                                                                                                   \
+        _Pragma("unroll") for (int u = 0; u < 4; u++) {                                                                    \
+            const int di = (G) >> 1, t = 4 * ((G) & 1) + u;                                                                \
+            const int tt = t < 4 ? t : t + 1;                                                                              \
+            const int dy = tt / 3 - 1, dx = tt % 3 - 1;                                                                    \
+            const int off = ((kHalo + dy * DIL::d[di]) * kLW + kHalo + dx * DIL::d[di]) * 8;                               \
+            asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(m[(G) & 1][u]) : "v"(win), "i"(off));                       \
         }
+        // asm results are not tracked by the compiler's wait insertion: the wait names the registers it covers
+#define COSA_PAR_WAIT(cnt, g) asm volatile("s_waitcnt lgkmcnt(" #cnt ")" : "+v"(m[g][0]), "+v"(m[g][1]), "+v"(m[g][2]), "+v"(m[g][3]))
+        constexpr int NG = 2 * (ND - 1);
+        COSA_PAR_TAPS(0);
 #pragma unroll
-        for (int t = 0; t < 8; t++) acc = acc + far[t] * a[(ND - 1) * 8 + t];
-        if (valid) dst[plane_off(j) + pix] = acc;
-        if (more) commit((j + 1) & 1);                                         // the other buffer: nobody reads it during this iteration
+        for (int G = 0; G < NG; G++) {
+            if (G + 1 < NG) {
+                COSA_PAR_TAPS(G + 1);
+                COSA_PAR_WAIT(4, G & 1);          // this group's taps (issued before the next group's 4 reads) have arrived; the newer ones stay in flight
+            } else {
+                COSA_PAR_WAIT(0, G & 1);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) mul_add(acc, m[G & 1][u], 4 * G + u);
+        }
+#undef COSA_PAR_WAIT
+#undef COSA_PAR_TAPS
+#pragma unroll
+        for (int t = 0; t < 8; t++) mul_add(acc, far[t], (ND - 1) * 8 + t);
+        if (valid) {
+            const float r0 = acc[0], r1 = acc[1];        // (bit_cast of a vector ELEMENT lvalue reads element 0 whatever the index: copy out first)
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, r0), rs_dst, pix * 4, p0, 0);
+            if (2 * q + 1 < live) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, r1), rs_dst, pix * 4, p1, 0);
+        }
+        if (more) commit((q + 1) & 1);                                         // the other buffer: nobody reads it during this iteration
         __syncthreads();                                                       // next tile staged, this one no longer read
     }
 }
@@ -490,11 +542,13 @@ int par_launch_step(const float *aff, const float *src, float *dst, int B, int K
     for (int i = 0; named && i < Dil6::n; i++) named = plan.dil[i] == Dil6::d[i];
     const int pin = (B % 8 == 0 || B >= 24) ? 1 : 0;                  // balanced (or nearly) image count per XCD
     const long long images = pin ? 8ll * ((B + 7) / 8) : (long long)B;
+    // (the tiled kernel addresses its operands through 32-bit buffer offsets)
+    named = named && (size_t)B * plane_stride * sizeof(float) < (1ull << 32) && (size_t)B * Dil6::n * 8 * h * w * sizeof(float) < (1ull << 32);
     if (named) {                          // LDS-tiled step for the named configuration
         const int tiles_x = (w + kTW - 1) / kTW, tiles_y = (h + kTH - 1) / kTH;
         const long long nblk = images * tiles_x * tiles_y;
         COSA_REQUIRE(nblk < 0x7fffffffll, "PAR: grid too large");
-        hipLaunchKernelGGL(par_step_tiled_kernel<Dil6>, dim3((unsigned)nblk), dim3(512), 0, st, aff, src, dst, kcount, Kmax, halves,
+        hipLaunchKernelGGL(par_step_tiled_kernel<Dil6>, dim3((unsigned)nblk), dim3(kStepThreads), 0, st, aff, src, dst, kcount, Kmax, halves,
                            half_planes, plane_stride, h, w, B, tiles_x, tiles_y, pin);
     } else {                              // any other dilation list: one pixel per thread, gathers
         const int pix_blocks = (h * w + 255) / 256, groups = (Kmax + 15) / 16;
