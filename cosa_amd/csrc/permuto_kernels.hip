@@ -181,6 +181,10 @@ __global__ __launch_bounds__(256) void lattice_build_kernel(const float *__restr
     unsigned long long *pkey = B.pkey + (size_t)n * P.Mmax;
     int *Mp = B.M + n;
     bool bad = false;
+    // slots this lane claimed (a new lattice point), their keys, one flag per r: the dense ids are handed out after the loop
+    unsigned new_slot[PD1];
+    unsigned long long new_key[PD1];
+    bool won[PD1];
 #pragma unroll
     for (int r = 0; r <= PD; r++) {
         int key[PD];
@@ -193,29 +197,67 @@ __global__ __launch_bounds__(256) void lattice_build_kernel(const float *__restr
         }
         unsigned long long pk;
         if (!pack_key(key, pk)) bad = true;
+        // Wave-level de-duplication first: on smooth images the 64 consecutive pixels of a wave share a handful of lattice points per r
+        // (M / N = 0.08), so one lane per distinct key (the first that holds it) probes / inserts and the others take its slot by a
+        // cross-lane read: an order of magnitude fewer random accesses into the table.  The grouping loop is ballots and scalar
+        // compares only (one round per distinct key); the probes of all leaders then run concurrently.
+        const int lane = threadIdx.x & 63;
+        const unsigned pk_lo = (unsigned)pk, pk_hi = (unsigned)(pk >> 32);
+        int leader = lane;
+        for (unsigned long long rem = __ballot(1); rem != 0;) {
+            const int l = __ffsll((long long)rem) - 1;                                 // (wave-uniform)
+            const unsigned llo = __builtin_amdgcn_readlane(pk_lo, l), lhi = __builtin_amdgcn_readlane(pk_hi, l);
+            const bool mine = pk_lo == llo && pk_hi == lhi;
+            if (mine) leader = l;                                                      // (a later round cannot match again: the key is gone from rem)
+            rem &= ~__ballot(mine);
+        }
         unsigned s = (unsigned)hmix(pk) & P.cap_mask;
+        won[r] = false;
+        if (leader == lane)
         for (;;) {
             // test before test-and-set: a slot only ever goes kEmpty -> key, so a plain (possibly stale) load can at worst still show
-            // kEmpty, in which case the CAS below decides.  On smooth images ~13 pixels share a lattice point (M/N = 0.08): most
-            // attempts end here with an L2 hit instead of a memory-side 64-bit atomic on a contended address (0.85 -> 0.64 ms per
-            // step).  Tried and dropped: de-duplicating a workgroup's 1536 keys in an LDS hash first (1.20 ms) and pre-aggregating the
-            // splat contributions of a workgroup in LDS rows (0.75 vs 0.71 ms) -- both kernels are bound by the latency of random
-            // accesses into the 128-MB table / value rows, which the occupancy lost to the LDS tables (8 -> 3 workgroups per CU) hides.
+            // kEmpty, in which case the CAS below decides: most attempts end here with an L2 hit instead of a memory-side 64-bit atomic
+            // on a contended address.  Tried and dropped: de-duplicating a workgroup's 1536 keys in an LDS hash first (1.20 ms) and
+            // pre-aggregating the splat contributions of a workgroup in LDS rows (0.75 vs 0.71 ms) -- the occupancy lost to the LDS tables
+            // (8 -> 3 workgroups per CU) cost more than they saved.
             const unsigned long long seen = __builtin_nontemporal_load(&keys[s]);
             if (seen == pk) break;
             if (seen != kEmpty) { s = (s + 1) & P.cap_mask; continue; }
             const unsigned long long prev = atomicCAS(&keys[s], kEmpty, pk);
-            if (prev == kEmpty) {
-                const int id = atomicAdd(Mp, 1);
-                slot_id[s] = id;
-                pkey[id] = pk;
-                break;
-            }
+            if (prev == kEmpty) { won[r] = true; break; }
             if (prev == pk) break;
             s = (s + 1) & P.cap_mask;
         }
+        new_slot[r] = s;
+        new_key[r] = pk;
+        s = (unsigned)__shfl((int)s, leader, 64);
         B.offset[((size_t)n * P.Npad + p) * PD1 + r] = (int)s;   // slot for now; remapped to the dense id next
         B.bary[((size_t)n * P.Npad + p) * PD1 + r] = bc[r];
+    }
+    // Dense ids: ONE add to the image's counter per wave for all the points its lanes created (ranked by ballot), not one per point:
+    // the per-image counter is a single address, and same-address atomics serialise at ~20 ns each -- with one add per new point they
+    // were 430 of this kernel's 630 us (b = 16, 224^2, ~25 k points per image).
+    {
+        const int lane = threadIdx.x & 63;
+        unsigned long long wm[PD1];
+        int total = 0;
+#pragma unroll
+        for (int r = 0; r <= PD; r++) { wm[r] = __ballot(won[r]); total += __popcll(wm[r]); }
+        if (total) {                                                                   // (wave-uniform)
+            const int first = __ffsll((long long)__ballot(1)) - 1;
+            int base = 0;
+            if (lane == first) base = atomicAdd(Mp, total);
+            base = __shfl(base, first, 64);
+#pragma unroll
+            for (int r = 0; r <= PD; r++) {
+                if (won[r]) {
+                    const int id = base + __popcll(wm[r] & ((1ull << lane) - 1ull));
+                    slot_id[new_slot[r]] = id;
+                    pkey[id] = new_key[r];
+                }
+                base += __popcll(wm[r]);
+            }
+        }
     }
     if (bad) atomicExch(B.err, 1);
 }

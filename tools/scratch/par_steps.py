@@ -21,6 +21,6 @@ def run(K, T):
         f()
     e.record(); torch.cuda.synchronize()
     return a.elapsed_time(e) / 10 * 1000
-for K in (4, 12):
+for K in (2, 4, 8, 12, 16):
     t10, t20 = run(K, 10), run(K, 20)
     print(f"K={K:2d}: T=10 {t10:7.1f} us  T=20 {t20:7.1f} us  per step {(t20 - t10) / 10:6.2f} us  affinity+rest {t10 - (t20 - t10):6.1f} us", flush=True)
