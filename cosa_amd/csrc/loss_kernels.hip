@@ -422,6 +422,79 @@ __global__ __launch_bounds__(256) void cam_target_kernel(SegScales sc, const flo
     }
 }
 
+
+// ---- softmax over the classes + the regulariser's half-resolution resize, fused (the drop-in get_energy_loss path) -------------------
+// utils/seg_helper.py:210-230 hands the full-resolution logits to F.softmax and DenseEnergyLoss.forward resizes the probabilities by 0.5
+// (bilinear, align_corners=False: at exactly 0.5 that is the mean of each 2x2 quad, written as torch's kernel writes it).  Through torch that
+// is four passes over [b,K,S,S] forward and four backward (1.2 of the 3.2 ms of a b=16, K=21, S=448 forward + backward); here a thread owns
+// one half-resolution pixel: per class-loop it reads its quad as two 8-byte loads, nothing of size [b,K,S,S] is written forward, and the
+// backward writes d logits once.  Channel loops run in class order (as torch's SpatialSoftMax kernels do).
+__global__ __launch_bounds__(256) void softmax_half_fwd_kernel(const float *__restrict__ logit, float *__restrict__ out, int K, int H, int W)
+{
+    const int Wq = W >> 1, Hq = H >> 1;
+    const int xq = blockIdx.x * 64 + (threadIdx.x & 63), yq = blockIdx.y * 4 + (threadIdx.x >> 6), b = blockIdx.z;
+    if (xq >= Wq || yq >= Hq) return;
+    const size_t plane = (size_t)H * W;
+    const float *base = logit + (size_t)b * K * plane + (size_t)(2 * yq) * W + 2 * xq;
+    float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    for (int k = 0; k < K; k++) {
+        const float2 r0 = *reinterpret_cast<const float2 *>(base + k * plane), r1 = *reinterpret_cast<const float2 *>(base + k * plane + W);
+        m[0] = fmaxf(m[0], r0.x); m[1] = fmaxf(m[1], r0.y); m[2] = fmaxf(m[2], r1.x); m[3] = fmaxf(m[3], r1.y);
+    }
+    float sum[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < K; k++) {
+        const float2 r0 = *reinterpret_cast<const float2 *>(base + k * plane), r1 = *reinterpret_cast<const float2 *>(base + k * plane + W);
+        sum[0] += expf(r0.x - m[0]); sum[1] += expf(r0.y - m[1]); sum[2] += expf(r1.x - m[2]); sum[3] += expf(r1.y - m[3]);
+    }
+    float *o = out + ((size_t)b * K * Hq + yq) * Wq + xq;
+    for (int k = 0; k < K; k++) {
+        const float2 r0 = *reinterpret_cast<const float2 *>(base + k * plane), r1 = *reinterpret_cast<const float2 *>(base + k * plane + W);
+        const float p00 = expf(r0.x - m[0]) / sum[0], p01 = expf(r0.y - m[1]) / sum[1], p10 = expf(r1.x - m[2]) / sum[2], p11 = expf(r1.y - m[3]) / sum[3];
+        o[(size_t)k * Hq * Wq] = 0.5f * (0.5f * p00 + 0.5f * p01) + 0.5f * (0.5f * p10 + 0.5f * p11);
+    }
+}
+
+// d logits [b,K,H,W] from g = d loss / d (half-resolution probabilities): every pixel of a quad receives 0.25 g (the resize's transpose),
+// then the softmax backward p (dp - sum_k dp p) with p recomputed from the logits
+__global__ __launch_bounds__(256) void softmax_half_bwd_kernel(const float *__restrict__ logit, const float *__restrict__ g, float *__restrict__ dlogit,
+                                                             int K, int H, int W)
+{
+    const int Wq = W >> 1, Hq = H >> 1;
+    const int xq = blockIdx.x * 64 + (threadIdx.x & 63), yq = blockIdx.y * 4 + (threadIdx.x >> 6), b = blockIdx.z;
+    if (xq >= Wq || yq >= Hq) return;
+    const size_t plane = (size_t)H * W, qplane = (size_t)Hq * Wq;
+    const size_t off = (size_t)b * K * plane + (size_t)(2 * yq) * W + 2 * xq;
+    const float *base = logit + off;
+    const float *gq = g + ((size_t)b * K * Hq + yq) * Wq + xq;
+    float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    for (int k = 0; k < K; k++) {
+        const float2 r0 = *reinterpret_cast<const float2 *>(base + k * plane), r1 = *reinterpret_cast<const float2 *>(base + k * plane + W);
+        m[0] = fmaxf(m[0], r0.x); m[1] = fmaxf(m[1], r0.y); m[2] = fmaxf(m[2], r1.x); m[3] = fmaxf(m[3], r1.y);
+    }
+    float sum[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < K; k++) {
+        const float2 r0 = *reinterpret_cast<const float2 *>(base + k * plane), r1 = *reinterpret_cast<const float2 *>(base + k * plane + W);
+        sum[0] += expf(r0.x - m[0]); sum[1] += expf(r0.y - m[1]); sum[2] += expf(r1.x - m[2]); sum[3] += expf(r1.y - m[3]);
+    }
+    float dot[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < K; k++) {
+        const float2 r0 = *reinterpret_cast<const float2 *>(base + k * plane), r1 = *reinterpret_cast<const float2 *>(base + k * plane + W);
+        const float dp = 0.25f * gq[k * qplane];
+        dot[0] += dp * (expf(r0.x - m[0]) / sum[0]); dot[1] += dp * (expf(r0.y - m[1]) / sum[1]);
+        dot[2] += dp * (expf(r1.x - m[2]) / sum[2]); dot[3] += dp * (expf(r1.y - m[3]) / sum[3]);
+    }
+    float *d = dlogit + off;
+    for (int k = 0; k < K; k++) {
+        const float2 r0 = *reinterpret_cast<const float2 *>(base + k * plane), r1 = *reinterpret_cast<const float2 *>(base + k * plane + W);
+        const float dp = 0.25f * gq[k * qplane];
+        float2 o0, o1;
+        o0.x = (dp - dot[0]) * (expf(r0.x - m[0]) / sum[0]); o0.y = (dp - dot[1]) * (expf(r0.y - m[1]) / sum[1]);
+        o1.x = (dp - dot[2]) * (expf(r1.x - m[2]) / sum[2]); o1.y = (dp - dot[3]) * (expf(r1.y - m[3]) / sum[3]);
+        *reinterpret_cast<float2 *>(d + k * plane) = o0;
+        *reinterpret_cast<float2 *>(d + k * plane + W) = o1;
+    }
+}
+
 }  // namespace
 }  // namespace cosa
 
@@ -527,6 +600,26 @@ extern "C" int cosa_cam_loss_targets(const float *const *seg_scales, const int *
     const int total = B * oh * ow;
     hipLaunchKernelGGL(cam_target_kernel, dim3((total + 3) / 4), dim3(256), 0, as_stream(stream), sc, labels, out, B, K, S, oh, ow,
                        1.0f / temperature);
+    COSA_LAUNCH_CHECK();
+    return COSA_OK;
+}
+
+/* softmax over the classes of full-resolution logits [B,K,H,W] followed by DenseEnergyLoss's resize by 0.5 (H, W even), and its backward */
+extern "C" int cosa_softmax_halfres_forward(const float *logit, float *out, int B, int K, int H, int W, void *stream)
+{
+    COSA_REQUIRE(logit && out && B > 0 && K > 0 && H > 0 && W > 0 && B <= 65535, "cosa_softmax_halfres_forward: bad arguments");
+    COSA_REQUIRE(H % 2 == 0 && W % 2 == 0, "cosa_softmax_halfres_forward: H and W must be even");
+    hipLaunchKernelGGL(softmax_half_fwd_kernel, dim3((W / 2 + 63) / 64, (H / 2 + 3) / 4, B), dim3(256), 0, as_stream(stream), logit, out, K, H, W);
+    COSA_LAUNCH_CHECK();
+    return COSA_OK;
+}
+
+extern "C" int cosa_softmax_halfres_backward(const float *logit, const float *grad_out, float *grad_logit, int B, int K, int H, int W, void *stream)
+{
+    COSA_REQUIRE(logit && grad_out && grad_logit && B > 0 && K > 0 && H > 0 && W > 0 && B <= 65535, "cosa_softmax_halfres_backward: bad arguments");
+    COSA_REQUIRE(H % 2 == 0 && W % 2 == 0, "cosa_softmax_halfres_backward: H and W must be even");
+    hipLaunchKernelGGL(softmax_half_bwd_kernel, dim3((W / 2 + 63) / 64, (H / 2 + 3) / 4, B), dim3(256), 0, as_stream(stream), logit, grad_out, grad_logit,
+                       K, H, W);
     COSA_LAUNCH_CHECK();
     return COSA_OK;
 }

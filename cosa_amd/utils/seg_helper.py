@@ -619,16 +619,50 @@ def _crop_mask_from_boxes(img_box, b, h, w, device):
     return inside.float()
 
 
+class SoftmaxHalfRes(Function):
+    """F.softmax(logit, dim=1) followed by DenseEnergyLoss.forward's resize of the probabilities by 0.5 (utils/seg_helper.py:199-203, 224),
+    forward and backward in one kernel each: nothing of the logits' size is written forward."""
+
+    @staticmethod
+    def forward(ctx, logit):
+        logit = logit.contiguous().float()
+        B, K, H, W = logit.shape
+        out = torch.empty((B, K, H // 2, W // 2), device=logit.device, dtype=torch.float32)
+        _C.check(_C.lib().cosa_softmax_halfres_forward(_C.ptr(logit), _C.ptr(out), B, K, H, W, _C.stream_ptr()), "cosa_softmax_halfres_forward")
+        ctx.save_for_backward(logit)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (logit,) = ctx.saved_tensors
+        B, K, H, W = logit.shape
+        g = grad_out.contiguous().float()
+        grad = torch.empty_like(logit)
+        _C.check(_C.lib().cosa_softmax_halfres_backward(_C.ptr(logit), _C.ptr(g), _C.ptr(grad), B, K, H, W, _C.stream_ptr()),
+                 "cosa_softmax_halfres_backward")
+        return grad
+
+
 def get_energy_loss(img, logit, label, img_box, loss_layer, mean=[123.675, 116.28, 103.53], std=[58.395, 57.12, 57.375]):
-    """utils/seg_helper.py:210-230 (box mask built with one broadcast compare instead of a Python loop)."""
-    pred_prob = F.softmax(logit.float(), dim=1)
-    b, _, h, w = pred_prob.shape
-    crop_mask = _crop_mask_from_boxes(img_box, b, h, w, pred_prob.device)
+    """utils/seg_helper.py:210-230 (box mask built with one broadcast compare instead of a Python loop).  With the reference's
+    scale_factor = 0.5 on the GPU the softmax and the layer's resize of the probabilities are one kernel (SoftmaxHalfRes)."""
+    b, _, h, w = logit.shape
+    crop_mask = _crop_mask_from_boxes(img_box, b, h, w, logit.device)
     mean_t = torch.tensor(mean, device=img.device, dtype=torch.float32)[None, :, None, None]
     std_t = torch.tensor(std, device=img.device, dtype=torch.float32)[None, :, None, None]
     _img = img * std_t + mean_t
-    loss = loss_layer(_img, pred_prob, crop_mask, label.type(torch.uint8).unsqueeze(1))
-    return loss
+    seg_label = label.type(torch.uint8).unsqueeze(1)
+    if logit.is_cuda and loss_layer.scale_factor == 0.5 and h % 2 == 0 and w % 2 == 0:
+        sf = loss_layer.scale_factor
+        scaled_segs = SoftmaxHalfRes.apply(logit)
+        scaled_images = F.interpolate(_img, scale_factor=sf, recompute_scale_factor=True)
+        scaled_ROIs = F.interpolate(crop_mask.unsqueeze(1), scale_factor=sf, recompute_scale_factor=True).squeeze(1)
+        scaled_seg_label = F.interpolate(seg_label.float(), scale_factor=sf, mode='nearest', recompute_scale_factor=True)
+        unlabel_region = (scaled_seg_label.long() == 255).squeeze(1)
+        return loss_layer.weight * DenseEnergyLossFunction.apply(scaled_images, scaled_segs, loss_layer.sigma_rgb,
+                                                                 loss_layer.sigma_xy * sf, scaled_ROIs, unlabel_region)
+    pred_prob = F.softmax(logit.float(), dim=1)
+    return loss_layer(_img, pred_prob, crop_mask, seg_label)
 
 
 # --------------------------------------------------------------------------------------------

@@ -396,6 +396,11 @@ int cosa_msm_loss(const float *x, const float *y, float *grad, float *loss, void
  *   out [B, K-1, oh, ow]                                                                                                      */
 int cosa_cam_loss_targets(const float *const *seg_scales, const int *hs, const int *ws, int n_scales, const float *labels,
                           float *out, int B, int K, int S, int oh, int ow, float temperature, void *stream);
+/* utils/seg_helper.py:210-230 (get_energy_loss: F.softmax over the classes of the full-resolution logits) + :199-203 (DenseEnergyLoss.forward:
+ * bilinear resize of the probabilities by 0.5 = the mean of each 2x2 quad) in one pass, and the backward of the pair:
+ *   logit [B,K,H,W] (H, W even)   out / grad_out [B,K,H/2,W/2]   grad_logit [B,K,H,W]                                                     */
+int cosa_softmax_halfres_forward(const float *logit, float *out, int B, int K, int H, int W, void *stream);
+int cosa_softmax_halfres_backward(const float *logit, const float *grad_out, float *grad_logit, int B, int K, int H, int W, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * utils/torch_helper.py:261-293 (AdamW with the scheduled LR) + main.py:250-252 (teacher EMA) + the bf16 shadow
