@@ -82,6 +82,7 @@ _SIGS = {
                       c_size_t, c_void_p]),
     "cosa_gemm_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "cosa_gemm_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "cosa_gemm_wgrad_batched": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "cosa_gemm_wgrad_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "cosa_conv3x3_dilated_nhwc": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 10 + [c_void_p]),
     "cosa_head_gemm": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, ctypes.c_longlong, c_int, c_int, c_int, c_int,

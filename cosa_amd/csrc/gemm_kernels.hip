@@ -813,24 +813,14 @@ constexpr int WG_IMG = 16384;                 // one [64 tokens][128 columns] bf
 constexpr int WG_STAGE = 3 * WG_IMG;          // dY features [0,128) | dY features [128,256) | X
 constexpr int WG_LDS = 3 * WG_STAGE;          // 144 KB: three stages; the fp32 [256][128] epilogue tile (128 KB) reuses them
 
+// one job: the [256 x 128] tile `tile` (n-major) of dW over the token stages [split * stages_per_split, +stages_per_split) -> out (+ split slab)
 template <bool CONV>
-__global__ __launch_bounds__(512, 1) void gemm_wgrad_kernel(const op16 *__restrict__ dY, const op16 *__restrict__ X,
-                                                           float *__restrict__ out, float *__restrict__ dbp, int M, int N, int K,
-                                                           int tiles_k, int stages_per_split, int nstages, int ntiles, int tiles_per_xcd,
-                                                           ConvGeom cg, int x_bytes, long long slab_elems, int direct_accumulate)
+__device__ __forceinline__ void wgrad_job(unsigned char *smem, const op16 *__restrict__ dY, const op16 *__restrict__ X,
+                                          float *__restrict__ out, float *__restrict__ dbp, int M, int N, int K,
+                                          int tiles_k, int stages_per_split, int nstages, int tile, int split,
+                                          const ConvGeom &cg, int x_bytes, long long slab_elems, int direct_accumulate)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    // Workgroup -> (tile, split).  Workgroups that read the same operand slabs are the tiles of ONE split (the dY slab of an n-tile is
-    // shared by its tiles_k k-tiles, the X slab of a k-tile by all n-tiles); ids are dealt round-robin to the 8 XCDs, so give every XCD a
-    // contiguous chunk of the n-major tile list (for each split) and its L2 serves the re-reads.
-    int tile, split;
-    {
-        const int id = blockIdx.x, xcd = id & 7, j = id >> 3;
-        split = j / tiles_per_xcd;
-        tile = xcd * tiles_per_xcd + (j - split * tiles_per_xcd);
-        if (tile >= ntiles) return;
-    }
     const int tn = tile / tiles_k, tk = tile - tn * tiles_k;
     const int n0 = tn * 256, k0 = tk * 128;
     const int st0 = split * stages_per_split;
@@ -988,6 +978,50 @@ __global__ __launch_bounds__(512, 1) void gemm_wgrad_kernel(const op16 *__restri
             if (direct_accumulate) v = v + *reinterpret_cast<const f32x4 *>(d);
             *reinterpret_cast<f32x4 *>(d) = v;
         }
+    }
+}
+
+template <bool CONV>
+__global__ __launch_bounds__(512, 1) void gemm_wgrad_kernel(const op16 *__restrict__ dY, const op16 *__restrict__ X,
+                                                           float *__restrict__ out, float *__restrict__ dbp, int M, int N, int K,
+                                                           int tiles_k, int stages_per_split, int nstages, int ntiles, int tiles_per_xcd,
+                                                           ConvGeom cg, int x_bytes, long long slab_elems, int direct_accumulate)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // Workgroup -> (tile, split).  Workgroups that read the same operand slabs are the tiles of ONE split (the dY slab of an n-tile is
+    // shared by its tiles_k k-tiles, the X slab of a k-tile by all n-tiles); ids are dealt round-robin to the 8 XCDs, so give every XCD a
+    // contiguous chunk of the n-major tile list (for each split) and its L2 serves the re-reads.
+    const int id = blockIdx.x, xcd = id & 7, j = id >> 3;
+    const int split = j / tiles_per_xcd;
+    const int tile = xcd * tiles_per_xcd + (j - split * tiles_per_xcd);
+    if (tile >= ntiles) return;
+    wgrad_job<CONV>(smem, dY, X, out, dbp, M, N, K, tiles_k, stages_per_split, nstages, tile, split, cg, x_bytes, slab_elems, direct_accumulate);
+}
+
+// Many weight gradients in ONE persistent launch (the student's encoder: 48 linears, 2592 tiles): with that many tiles no launch needs
+// split-K, so every job runs the whole token loop (197 stages at M = 12 560) and writes dW once -- no partial slabs, no reduction
+// kernels, and the fixed cost of a launch (ring fill, 128-KB epilogue per workgroup, slab reduction: ~39 of the 53-92 us of a single
+// launch) is paid per job of ~190 us instead of per ~15-56 stages.  256 workgroups (one per CU) walk the n-major job list in groups of 32
+// consecutive jobs per XCD (workgroup ids are dealt round-robin to the XCDs): the 32 jobs of a group share a few dY / X panels, which
+// their L2 then fetches once.
+struct WgradBatchRec { const op16 *dY, *X; float *dW, *db; int N, K, job0, tiles_k; };
+constexpr int kWgradBatchMax = 48;
+struct WgradBatch { int n, total_jobs, M, pad; WgradBatchRec r[kWgradBatchMax]; };
+
+__global__ __launch_bounds__(512, 1) void gemm_wgrad_batched_kernel(WgradBatch B)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int xcd = blockIdx.x & 7, l = blockIdx.x >> 3;          // 256 workgroups: 32 per XCD
+    const int nstages = (B.M + 63) / 64;
+    for (int it = 0; (it * 8 + xcd) * 32 < B.total_jobs; it++) {
+        const int job = (it * 8 + xcd) * 32 + l;
+        if (job < B.total_jobs) {                                 // (workgroup-uniform)
+            int ri = 0;
+            while (ri + 1 < B.n && job >= B.r[ri + 1].job0) ri++;
+            const WgradBatchRec &R = B.r[ri];
+            wgrad_job<false>(smem, R.dY, R.X, R.dW, R.db, B.M, R.N, R.K, R.tiles_k, nstages, nstages, job - R.job0, 0, ConvGeom{}, 0, 0, 0);
+        }
+        __syncthreads();                                          // the next job's first stage overwrites the epilogue tile
     }
 }
 
@@ -1542,6 +1576,39 @@ extern "C" int cosa_gemm_wgrad_bf16(const void *dY, const void *X, float *dW, fl
     return launch_wgrad<false>(static_cast<const op16 *>(dY), static_cast<const op16 *>(X), dW, db, M, N, K, zero_first, workspace, workspace_bytes,
                                as_stream(stream), ConvGeom{}, 0, "cosa_gemm_wgrad_bf16");
 }
+
+#if !COSA_OP_F16
+// items: host array of {dY [M,N] bf16, X [M,K] bf16, dW [N,K] f32 (overwritten), db [N] f32 or null (overwritten), N, K}; every item shares M
+extern "C" int cosa_gemm_wgrad_batched(const CosaWgradItem *items, int n_items, int M, void *stream)
+{
+    COSA_REQUIRE(items && n_items > 0 && M > 0, "cosa_gemm_wgrad_batched: bad arguments");
+    static bool attr_done = false;
+    if (!attr_done) {
+        COSA_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_wgrad_batched_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WG_LDS));
+        attr_done = true;
+    }
+    for (int i0 = 0; i0 < n_items; i0 += kWgradBatchMax) {
+        WgradBatch B;
+        B.n = n_items - i0 < kWgradBatchMax ? n_items - i0 : kWgradBatchMax;
+        B.M = M;
+        B.pad = 0;
+        int jobs = 0;
+        for (int i = 0; i < B.n; i++) {
+            const CosaWgradItem &it = items[i0 + i];
+            COSA_REQUIRE(it.dY && it.X && it.dW && it.N > 0 && it.K > 0, "cosa_gemm_wgrad_batched: bad item %d", i0 + i);
+            COSA_REQUIRE(it.N % 128 == 0 && it.K % 128 == 0, "cosa_gemm_wgrad_batched: N and K must be multiples of 128 (item %d: %d, %d)", i0 + i, it.N, it.K);
+            COSA_REQUIRE((size_t)M * it.N * 2 < 0x7fffffffull && (size_t)M * it.K * 2 < 0x7fffffffull, "cosa_gemm_wgrad_batched: operand beyond 2 GiB");
+            B.r[i] = WgradBatchRec{static_cast<const op16 *>(it.dY), static_cast<const op16 *>(it.X), it.dW, it.db, it.N, it.K, jobs, it.K / 128};
+            jobs += ((it.N + 255) / 256) * (it.K / 128);
+        }
+        for (int i = B.n; i < kWgradBatchMax; i++) B.r[i] = WgradBatchRec{nullptr, nullptr, nullptr, nullptr, 0, 0, jobs, 1};
+        B.total_jobs = jobs;
+        hipLaunchKernelGGL(gemm_wgrad_batched_kernel, dim3(256), dim3(512), WG_LDS, as_stream(stream), B);
+        COSA_LAUNCH_CHECK();
+    }
+    return COSA_OK;
+}
+#endif
 
 // weight gradient of cosa_conv3x3_dilated_nhwc:  dW9[Cout][9*Cin] (fp32, tap-major columns: t*Cin + c) = (zero_first ? 0 : dW9) +
 // dY[B*h*w, Cout]^T im2col(X); X is addressed exactly as in the forward call (strided token view, image b at row b*img_rows + row_off).

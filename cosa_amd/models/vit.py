@@ -476,10 +476,16 @@ class VisionTransformer(nn.Module):
         if self.compute_dtype == torch.bfloat16 and x.is_cuda and self.embed_dim == 768 and x.dtype == torch.bfloat16:
             # student training path: the stream is (x, pending delta); x + delta materialises inside the next LayerNorm kernel
             delta = None
-            for i, blk in enumerate(self.blocks):
-                x_in, x, delta = self._block_fused_ln(blk, x, delta)
-                if i - 1 == aux_idx:
-                    aux = x_in                                              # output of block aux_idx, materialised in this block's norm1
+            # the 48 weight gradients of the blocks are computed in one batched launch when the backward pass reaches this point
+            # (nn_ops.DeferredWgrad) instead of 48 split-K launches + 48 reductions
+            defer = torch.is_grad_enabled() and x.requires_grad and getattr(self, "defer_wgrad", True)
+            if defer:
+                x, coll = nn_ops.defer_wgrads(x, [m for blk in self.blocks for m in (blk.attn.qkv, blk.attn.proj, blk.mlp.fc1, blk.mlp.fc2)])
+            with nn_ops.collecting(coll if defer else None):
+                for i, blk in enumerate(self.blocks):
+                    x_in, x, delta = self._block_fused_ln(blk, x, delta)
+                    if i - 1 == aux_idx:
+                        aux = x_in                                          # output of block aux_idx, materialised in this block's norm1
             x, xn = nn_ops.add_layernorm(x, delta, self.norm.weight, self.norm.bias, self.norm.eps)
             if aux_idx == depth - 1:
                 aux = xn

@@ -594,6 +594,111 @@ def gemm_wgrad(dy2, x2, want_bias=False):
     return (dw, db) if want_bias else dw
 
 
+class _WgradItem(ctypes.Structure):
+    _fields_ = [("dY", ctypes.c_void_p), ("X", ctypes.c_void_p), ("dW", ctypes.c_void_p), ("db", ctypes.c_void_p), ("N", ctypes.c_int),
+                ("K", ctypes.c_int)]
+
+
+def gemm_wgrad_batched(pairs):
+    """[(dy2 [M,N] bf16, x2 [M,K] bf16, want_bias)] -> [(dW [N,K] fp32, db [N] fp32 or None)]: every weight gradient in ONE persistent launch
+    (cosa_gemm_wgrad_batched): with hundreds of tiles no item needs split-K, every tile runs the whole token loop and writes dW once."""
+    outs, by_m = [None] * len(pairs), {}
+    for i, (dy2, x2, want_bias) in enumerate(pairs):
+        assert dy2.dtype == torch.bfloat16 and x2.dtype == torch.bfloat16 and dy2.is_contiguous() and x2.is_contiguous()
+        M, N = dy2.shape
+        K = x2.shape[1]
+        dw = _wgrad_alloc(N * K, dy2.device)
+        dw = dw.view(N, K) if dw is not None else torch.empty((N, K), device=dy2.device, dtype=torch.float32)
+        db = None
+        if want_bias:
+            db = _wgrad_alloc(N, dy2.device)
+            db = db if db is not None else torch.empty((N,), device=dy2.device, dtype=torch.float32)
+        outs[i] = (dw, db)
+        by_m.setdefault(M, []).append(i)
+    for M, idx in by_m.items():
+        arr = (_WgradItem * len(idx))()
+        for j, i in enumerate(idx):
+            dy2, x2, _ = pairs[i]
+            dw, db = outs[i]
+            arr[j] = _WgradItem(dy2.data_ptr(), x2.data_ptr(), dw.data_ptr(), db.data_ptr() if db is not None else None, dy2.shape[1], x2.shape[1])
+        with _C.profiled("gemm_wgrad"):
+            _C.check(_C.lib().cosa_gemm_wgrad_batched(ctypes.cast(arr, ctypes.c_void_p), len(idx), M, _C.stream_ptr()), "cosa_gemm_wgrad_batched")
+    return outs
+
+
+class WgradCollector:
+    """The (dY, X) pairs of the linears whose weight gradients are computed together (DeferredWgrad): LinearShadowFn.backward adds its pair
+    instead of launching its own weight-gradient GEMM when its master weight is one of `params`."""
+
+    def __init__(self, params):
+        self.keys = {id(p) for p in params}
+        self.pending = {}
+
+    def add(self, w, dy2, x2):
+        if id(w) in self.pending:
+            raise RuntimeError("WgradCollector: a weight was used twice inside one deferred region (not supported)")
+        self.pending[id(w)] = (dy2, x2)
+
+
+_wgrad_collector = None
+
+
+class collecting:
+    """with collecting(c): linears run inside add their weight-gradient work to c"""
+
+    def __init__(self, c):
+        self.c = c
+
+    def __enter__(self):
+        global _wgrad_collector
+        self.prev, _wgrad_collector = _wgrad_collector, self.c
+        return self.c
+
+    def __exit__(self, *exc):
+        global _wgrad_collector
+        _wgrad_collector = self.prev
+        return False
+
+
+class DeferredWgrad(Function):
+    """Identity on x, placed at the INPUT of a run of layers: its backward executes after theirs (autograd reaches the input last), launches
+    the collected weight gradients in one batch and hands them to the masters (`params` = w0, b0, w1, b1, ...: AccumulateGrad -- and with it
+    DistributedDataParallel's bucket hooks -- see them exactly as if each linear had returned its own)."""
+
+    @staticmethod
+    def forward(ctx, x, collector, *params):
+        ctx.collector = collector
+        ctx.ids = [id(p) for p in params]
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, gx):
+        c = ctx.collector
+        jobs, slots = [], []
+        for j in range(0, len(ctx.ids), 2):                  # (weight, bias) pairs
+            ent = c.pending.pop(ctx.ids[j], None)
+            if ent is not None:
+                jobs.append((ent[0], ent[1], True))
+                slots.append(j)
+        grads = [None] * len(ctx.ids)
+        if jobs:
+            for j, (dw, db) in zip(slots, gemm_wgrad_batched(jobs)):
+                grads[j], grads[j + 1] = dw, db
+        if c.pending:
+            raise RuntimeError("DeferredWgrad: collected a weight that is not among its parameters")
+        return (gx, None) + tuple(grads)
+
+
+def defer_wgrads(x, linears):
+    """x -> (x', collector): route the weight / bias gradients of the nn.Linear modules `linears` (those that run on LinearShadowFn) through
+    one batched launch that executes when the backward pass reaches x.  Use: x, c = defer_wgrads(x, mods); with collecting(c): ..."""
+    params = []
+    for m in linears:
+        params += [m.weight, m.bias]
+    c = WgradCollector(params[0::2])
+    return DeferredWgrad.apply(x, c, *params), c
+
+
 class TransposedShadows:
     """bf16 W^T copies of the student's projection weights, rebuilt from the fp32 masters by ONE batched launch per step (after the
     optimizer).  With them the input-gradient GEMM dX = dY W of an nn.Linear is the forward GEMM kernel applied to W^T: no NN kernel
@@ -664,6 +769,8 @@ class LinearShadowFn(Function):
             y = gemm_bf16(x2, w16, b16, EPI_BIAS)
         ctx.save_for_backward(x2, wT16, h)
         ctx.xshape = x.shape
+        c = _wgrad_collector
+        ctx.collect = (c, w) if (c is not None and id(w) in c.keys) else None
         return y.view(*x.shape[:-1], N)
 
     @staticmethod
@@ -684,7 +791,10 @@ class LinearShadowFn(Function):
         # (running the weight-gradient GEMM on a side stream next to the input-gradient GEMM, which often leaves CUs idle, was measured
         #  on one box in both issue orders: 324.4 / 322.3 img/s against 323.0 -- no gain, not kept)
         if ctx.needs_input_grad[1]:
-            dw, db = gemm_wgrad(dy2, x2, want_bias=True)
+            if ctx.collect is not None:
+                ctx.collect[0].add(ctx.collect[1], dy2, x2)                 # computed with the others when the backward reaches DeferredWgrad
+            else:
+                dw, db = gemm_wgrad(dy2, x2, want_bias=True)
         return dx, dw, db, None, None, None, None
 
 

@@ -217,6 +217,12 @@ int cosa_gemm_bf16(const void *X, const void *W, const void *bias, const float *
 size_t cosa_gemm_wgrad_workspace_bytes(int M, int N, int K);
 int cosa_gemm_wgrad_bf16(const void *dY, const void *X, float *dW, float *db, int M, int N, int K, int zero_first,
                          void *workspace, size_t workspace_bytes, void *stream);
+/* The same weight / bias gradients for MANY linears that share M, in one persistent launch (the student's encoder: autograd of
+ * models/vit/vit.py:96-137 for all twelve blocks, launched when the backward pass has produced every dY).  With hundreds of 256 x 128 tiles
+ * no item needs split-K: every tile runs the whole token loop and writes dW (and db) once -- overwritten, never accumulated; no workspace,
+ * no atomics, the same bits every run.  `items`: host array, read during the call.                                                        */
+typedef struct CosaWgradItem { const void *dY, *X; float *dW, *db; int N, K; } CosaWgradItem;
+int cosa_gemm_wgrad_batched(const CosaWgradItem *items, int n_items, int M, void *stream);
 /* models/decoder/conv_head.py:11-41  LargeFOV's 3x3 dilated, bias-free convolution on NHWC tokens (implicit GEMM, optional ReLU):
  *   X: image b = rows [b*img_rows + row_off, +h*w) of a [*, ldx] bf16 matrix (so the token tensor minus its cls row needs no copy)
  *   Wt [9][Cout][Cin] bf16 (tap-major: t = ky*3 + kx);  Y [B*h*w, Cout] bf16;  padding = dilation                               */

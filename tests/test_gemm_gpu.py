@@ -277,3 +277,48 @@ def test_narrow_linear_forward_backward_vs_fp64_autograd(M, N, K):
     x.grad = None
     nn_ops.narrow_linear(x, w).backward(dy)
     assert torch.equal(w.grad, g1)
+
+
+def test_gemm_wgrad_batched_vs_fp32_and_single_launches():
+    """the batched weight-gradient launch (one persistent kernel over the tiles of many linears, no split-K) against fp32 references, against
+    the single-launch kernel (same products, different summation tree: fp32 rounding only) and run to run (bit-identical)"""
+    from cosa_amd import nn_ops
+    torch.manual_seed(11)
+    shapes = [(2304, 768), (768, 768), (3072, 768), (768, 3072), (128, 256), (384, 128)]
+    for M in (12560, 197, 64):
+        pairs = []
+        for (N, K) in shapes * (2 if M == 12560 else 1):
+            pairs.append((torch.randn(M, N, device="cuda").bfloat16(), torch.randn(M, K, device="cuda").bfloat16(), True))
+        outs = [(w.clone(), b.clone()) for (w, b) in nn_ops.gemm_wgrad_batched(pairs)]
+        for (dy, x, _), (dw, db) in zip(pairs, outs):
+            ref_w, ref_b = dy.float().t() @ x.float(), dy.float().sum(0)
+            assert (dw - ref_w).abs().max().item() <= 2e-4 * ref_w.abs().max().item() + 1e-3
+            assert (db - ref_b).abs().max().item() <= 2e-4 * ref_b.abs().max().item() + 1e-3
+            sw, sb = nn_ops.gemm_wgrad(dy, x, want_bias=True)
+            assert (dw - sw).abs().max().item() <= 2e-5 * ref_w.abs().max().item() + 1e-4
+        for _ in range(3):
+            again = nn_ops.gemm_wgrad_batched(pairs)
+            assert all(torch.equal(a[0], o[0]) and torch.equal(a[1], o[1]) for a, o in zip(again, outs))
+
+
+def test_deferred_wgrad_gives_the_same_gradients_as_per_layer_launches():
+    """student ViT-B blocks, bf16: the gradients of every parameter with the weight gradients deferred to one batched launch
+    (nn_ops.DeferredWgrad, the default) against the per-linear launches (defer_wgrad = False)"""
+    from cosa_amd.train_step import CoSATrainer, default_args, synthetic_batch
+    dev = torch.device("cuda", 0)
+    args = default_args("VOC12", crop_size=224, batch_size=2, teacher_async=False)
+    tr = CoSATrainer(args, dev, seed=0)
+    enc = tr.student.encoder
+    x = torch.randn(2, 3, 224, 224, device=dev)
+    grads = {}
+    for defer in (True, False):
+        enc.defer_wgrad = defer
+        tr.student.zero_grad(set_to_none=True)
+        cls, tok, aux = enc.forward_features(x.bfloat16())[:3]
+        (tok.float().square().mean() + aux.float().mean() + cls.float().sum() * 1e-3).backward()
+        grads[defer] = {n: p.grad.clone() for n, p in enc.named_parameters() if p.grad is not None}
+    enc.defer_wgrad = True
+    assert grads[True].keys() == grads[False].keys() and any("blocks.11.mlp.fc2.weight" in k for k in grads[True])
+    for k, g in grads[True].items():
+        ref = grads[False][k]
+        assert (g - ref).abs().max().item() <= 2e-5 * ref.abs().max().item() + 1e-7, k
