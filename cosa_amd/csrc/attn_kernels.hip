@@ -280,7 +280,7 @@ __global__ __launch_bounds__(128, 2) void attn_fwd2_kernel(const op16 *__restric
                                                        unsigned long long *__restrict__ stamps)
 {
     __shared__ __attribute__((aligned(16))) unsigned char smem[(DMA ? 4 : 2) * BK * 128];
-    if (stamps && threadIdx.x == 0) atomicMin(&stamps[0], __builtin_amdgcn_s_memrealtime());
+    if (stamps && threadIdx.x == 0) atomicMin(&stamps[2 * (blockIdx.x & 63)], __builtin_amdgcn_s_memrealtime());     // 64 shards: one address would serialise the workgroups' atomics
     unsigned char *Ks = smem;
     unsigned char *Vs = smem + BK * 128;
     (void)vt;
@@ -492,7 +492,7 @@ __global__ __launch_bounds__(128, 2) void attn_fwd2_kernel(const op16 *__restric
     }
     if (stamps) {
         __syncthreads();
-        if (threadIdx.x == 0) atomicMax(&stamps[1], __builtin_amdgcn_s_memrealtime());
+        if (threadIdx.x == 0) atomicMax(&stamps[2 * (blockIdx.x & 63) + 1], __builtin_amdgcn_s_memrealtime());
     }
 }
 

@@ -348,7 +348,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
 {
     // optional device-side span of this launch (100 MHz wall clock; min start / max end over workgroups): HIP events cannot be
     // recorded inside a captured hipGraph on ROCm, so bench.py's roofline leg reads these (cosa_gemm_set_stamp_slot)
-    if (stamps && threadIdx.x == 0) atomicMin(&stamps[0], __builtin_amdgcn_s_memrealtime());
+    if (stamps && threadIdx.x == 0) atomicMin(&stamps[2 * (blockIdx.x & 63)], __builtin_amdgcn_s_memrealtime());     // 64 shards: one address would serialise the workgroups' atomics
     constexpr bool RES = EPI == EPI_RESIDUAL;          // fp32 out = fp32 residual + X W^T + bias
     constexpr int ES = RES ? 4 : 2;
     constexpr int FL = 0x00020000;
@@ -760,7 +760,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
     V6_EPI(1, 0, cY);
     if (wr == 0) V5_BARRIER();                         // re-align the two groups
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the dead-descriptor DMA of the last K-tiles still writes (zeros) to LDS
-    if (stamps && threadIdx.x == 0) atomicMax(&stamps[1], __builtin_amdgcn_s_memrealtime());
+    if (stamps && threadIdx.x == 0) atomicMax(&stamps[2 * (blockIdx.x & 63) + 1], __builtin_amdgcn_s_memrealtime());
 #undef V6_LOAD_BIAS
 #undef V6_RLOAD
 #undef V6_WAIT

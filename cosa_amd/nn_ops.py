@@ -27,10 +27,12 @@ class KernelStamps:
 
     HIP events cannot be recorded inside a captured hipGraph on ROCm ("External events are disallowed"), so the attention
     forward kernel can stamp the 100 MHz device wall clock itself: min start / max end over its workgroups, into a slot
-    fixed at launch-issue (= capture) time.  `reset()` is a device op, so it is captured too and re-arms every replay."""
+    fixed at launch-issue (= capture) time.  `reset()` is a device op, so it is captured too and re-arms every replay.
+    A slot is 64 (start, end) shards (workgroup id & 63): thousands of atomics on ONE address serialise at ~20 ns each."""
+    SHARDS = 64
 
     def __init__(self, device, max_launches=4096):
-        self.buf = torch.zeros((max_launches, 2), dtype=torch.int64, device=device)
+        self.buf = torch.zeros((max_launches, self.SHARDS, 2), dtype=torch.int64, device=device)
         self.half = max_launches // 2
         self.n = 0                  # slots [0, half): launches of the teacher section (captured in its hipGraph, re-armed by the captured reset)
         self.flops = []
@@ -40,8 +42,8 @@ class KernelStamps:
 
     def reset(self):
         """re-arm the teacher section's slots (a device op: captured with the section and replayed with it)"""
-        self.buf[: self.half, 0] = torch.iinfo(torch.int64).max
-        self.buf[: self.half, 1] = 0
+        self.buf[: self.half, :, 0] = torch.iinfo(torch.int64).max
+        self.buf[: self.half, :, 1] = 0
 
     def begin_eager(self):
         """the teacher section has been issued: the launches that follow are eager ones on the current stream.  Their slots are re-armed
@@ -50,8 +52,8 @@ class KernelStamps:
         self.eager = True
         self.n_eager = 0
         self.flops_eager = []
-        self.buf[self.half:, 0] = torch.iinfo(torch.int64).max
-        self.buf[self.half:, 1] = 0
+        self.buf[self.half:, :, 0] = torch.iinfo(torch.int64).max
+        self.buf[self.half:, :, 1] = 0
 
     def begin_section(self):
         self.eager = False
@@ -68,11 +70,12 @@ class KernelStamps:
             self.n += 1
             self.flops.append(flops)
         assert i < self.buf.shape[0] and (self.eager or i < self.half), "KernelStamps: out of slots"
-        return ctypes.c_void_p(self.buf.data_ptr() + 16 * i)
+        return ctypes.c_void_p(self.buf.data_ptr() + 16 * self.SHARDS * i)
 
     def read(self):
         """-> (n_launches, total_seconds, total_flops) of the launches stamped since the last re-arm (after a sync)"""
-        b = torch.cat([self.buf[: self.n], self.buf[self.half: self.half + self.n_eager]]).cpu()
+        b = torch.cat([self.buf[: self.n], self.buf[self.half: self.half + self.n_eager]])
+        b = torch.stack([b[:, :, 0].amin(1), b[:, :, 1].amax(1)], 1).cpu()          # min start / max end over the shards
         fl_all = list(self.flops) + list(self.flops_eager)
         ok = (b[:, 1] > 0) & (b[:, 0] < b[:, 1])
         ticks = (b[:, 1] - b[:, 0])[ok]

@@ -186,7 +186,7 @@ int cosa_dense_energy_backward(const float *AS, const float *roi, const float *g
 size_t cosa_attn_workspace_bytes(int B, int N, int H);
 int cosa_attn_prepare_vt(const void *qkv, int B, int N, int H, void *workspace, size_t workspace_bytes, void *stream);
 int cosa_attn_fwd(const void *qkv, void *out, float *lse, int B, int N, int H, int head_dim, float scale,
-                  int flags, uint64_t *stamps /* NULL, or {min start, max end} 100 MHz device ticks of this launch */,
+                  int flags, uint64_t *stamps /* NULL, or 64 x {min start, max end} 100 MHz device ticks of this launch (workgroup id & 63 picks the pair) */,
                   void *workspace, size_t workspace_bytes, void *stream);
 
 /* Backward of the same attention (autograd of vit.py:128-134): dqkv [B,N,3,H,64] bf16 from
@@ -243,7 +243,8 @@ void cosa_gemm_set_variant(int v);   /* 0 (default): per-shape choice; 1: the 12
 void cosa_gemm_set_grid_policy(int balanced);
 void cosa_gemm_set_grid_policy_f16(int balanced);
 /* measurement hook: the NEXT cosa_gemm_bf16 launch (persistent 256x256 kernel only) writes its device-clock span
- * (100 MHz s_memrealtime: min start / max end over workgroups) to slot[0..1] (uint64, caller-initialised to max / 0).
+ * (100 MHz s_memrealtime: min start / max end over workgroups) to 64 pairs slot[2s], slot[2s + 1] (uint64, s = workgroup id & 63,
+ * caller-initialised to max / 0: the span is the min over the starts and the max over the ends).
  * One-shot; used by bench.py because HIP events cannot be recorded inside a captured hipGraph.                       */
 void cosa_gemm_set_stamp_slot(void *slot);
 /* vit.py:254-262 (PatchEmbed: stride-16 conv) as a GEMM needs the image as im2col rows; the teacher's passes run every scale as

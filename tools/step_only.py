@@ -1,5 +1,6 @@
 """N training steps of the bench configuration and nothing else (for rocprofv3 --kernel-trace --stats: per-step kernel shares without bench.py's
-extra legs).  usage: python tools/step_only.py [steps=10] [teacher_precision=bf16] [dataset=VOC12]; the first 4 steps are set-up (graph capture)."""
+extra legs).  usage: python tools/step_only.py [steps=10] [teacher_precision=bf16] [dataset=VOC12] [nodefer]; the first 4 steps are set-up (graph capture);
+"nodefer": the student's weight gradients as one launch per linear instead of the batched deferred launch (A/B)."""
 import os, sys, json, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -15,6 +16,8 @@ try:
 except TypeError:        # a round-1 checkout (same-box comparisons): no precision switch
     args = default_args(dataset, **kw)
 tr = CoSATrainer(args, dev, seed=0)
+if len(sys.argv) > 4 and sys.argv[4] == "nodefer":
+    tr.student.encoder.defer_wgrad = False
 wimg, simg, lab, box = synthetic_batch(16, 448, 80 if dataset == "COCO" else 20, dev, seed=1234)
 n_iter = args.warmup_iters + 1
 for _ in range(4):
@@ -25,4 +28,4 @@ for _ in range(steps):
     tr.step(wimg, simg, lab, box, n_iter)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps
-print(json.dumps({"ms_per_step": round(dt * 1e3, 3), "images_per_s": round(16 / dt, 2), "steps": steps, "setup_steps": 4, "teacher": prec}))
+print(json.dumps({"ms_per_step": round(dt * 1e3, 3), "images_per_s": round(16 / dt, 2), "steps": steps, "setup_steps": 4, "teacher": prec, "wgrad": "per-linear" if (len(sys.argv) > 4 and sys.argv[4] == "nodefer") else "batched"}))
