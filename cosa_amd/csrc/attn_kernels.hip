@@ -273,8 +273,11 @@ __global__ __launch_bounds__(256) void attn_fwd_x3_kernel(const op16 *__restrict
 // for the c8 output projection: q, k, v and P stay plain fp16 (the pseudo labels are insensitive to 11-bit attention operands, but not to
 // an 11-bit attention OUTPUT: at near-uniform attention the output is a large common mean plus a small token-specific part that the
 // projection must still see -- tools/sim_precision_map.py)
-template <bool DMA, bool C8OUT = false>
-__global__ __launch_bounds__(128, 2) void attn_fwd2_kernel(const op16 *__restrict__ qkv, const op16 *__restrict__ vt,
+// NW: waves per workgroup (64 queries each) sharing one K/V tile stream.  Every LDS-DMA instruction costs its wave 100-185 issue cycles
+// (timing ablation at N = 1765: the DMA issue was a quarter of the kernel) and a tile is 16 of them whatever the workgroup size: with
+// NW = 4 a wave issues 4 per tile instead of 8.  Long sequences take NW = 4 (two workgroups per CU), short ones NW = 2 (finer query blocks).
+template <bool DMA, bool C8OUT = false, int NW = 2>
+__global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const op16 *__restrict__ qkv, const op16 *__restrict__ vt,
                                                        op16 *__restrict__ out, float *__restrict__ lse,
                                                        int N, int Npad, int H, int nblk, int ngroups, float scale_log2e,
                                                        unsigned long long *__restrict__ stamps)
@@ -287,7 +290,7 @@ __global__ __launch_bounds__(128, 2) void attn_fwd2_kernel(const op16 *__restric
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
     int blk, b, h;
     if (!attn_block_map(nblk, ngroups, H, blk, b, h)) return;
-    const int q0 = blk * BQ + wave * 64;
+    const int q0 = blk * (64 * NW) + wave * 64;
     const size_t rs = (size_t)3 * H * HD;
     op16x8 qf[2][4];
 #pragma unroll
@@ -308,28 +311,29 @@ __global__ __launch_bounds__(128, 2) void attn_fwd2_kernel(const op16 *__restric
     const op16 *kbase = qkv + (size_t)b * N * rs + (size_t)H * HD + h * HD;
     const op16 *vbase = kbase + (size_t)H * HD;
     const int swz = (r >> 1) & 7;
-    // 128 threads stage 512 + 512 16-byte chunks per tile (4 + 4 per thread).  No register prefetch here: four of these
+    // the 64 NW threads stage 512 + 512 16-byte chunks per tile (8 / NW + 8 / NW per thread).  No register prefetch here: several of these
     // workgroups share a CU, so another workgroup computes while this one waits for its tile.
-    const int srow = tid >> 3, sslot = tid & 7;          // chunk c = tid + 128*i -> row srow + 16*i, slot sslot
-    // DMA staging: wave w fills the 1-KiB pieces 4w .. 4w+3 (8 rows each) of the K tile and of the V tile
+    const int srow = tid >> 3, sslot = tid & 7;          // chunk c = tid + 64 NW i -> row srow + 8 NW i, slot sslot
+    constexpr int PW = 8 / NW;                            // 1-KiB pieces of the K tile (and of the V tile) per wave
+    // DMA staging: wave w fills the 1-KiB pieces PW w .. PW w + PW - 1 (8 rows each) of the K tile and of the V tile
     __amdgpu_buffer_rsrc_t rsK, rsV;
-    unsigned voK[4], voV[4];
+    unsigned voK[4], voV[4];                             // (PW of them used; a dependent array size here loses the host stub of the kernel: hipcc 7.2)
     if (DMA) {
         const int nbytes = (int)(((size_t)(N - 1) * rs + HD) * 2);                 // last valid byte of this (batch, head)'s K / V rows
         rsK = __builtin_amdgcn_make_buffer_rsrc((void *)kbase, 0, nbytes, 0x00020000);
         rsV = __builtin_amdgcn_make_buffer_rsrc((void *)vbase, 0, nbytes, 0x00020000);
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int row = 8 * (4 * wave + i) + (lane >> 3), ps = lane & 7;
+        for (int i = 0; i < PW; i++) {
+            const int row = 8 * (PW * wave + i) + (lane >> 3), ps = lane & 7;
             voK[i] = (unsigned)((row * rs + (ps ^ ((row >> 1) & 7)) * 8) * 2);
             voV[i] = (unsigned)((row * rs + (ps ^ vsw(row)) * 8) * 2);
         }
     }
     auto dma_tile = [&](int k0, int buf) {
         const unsigned ko = (unsigned)((size_t)k0 * rs * 2);
-        unsigned char *kd = smem + buf * 2 * BK * 128 + (4 * wave) * 1024;
+        unsigned char *kd = smem + buf * 2 * BK * 128 + (PW * wave) * 1024;
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
+        for (int i = 0; i < PW; i++) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (lds_void_a *)(kd + i * 1024), 16, voK[i] + ko, 0, 0, 0);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (lds_void_a *)(kd + BK * 128 + i * 1024), 16, voV[i] + ko, 0, 0, 0);
         }
@@ -349,8 +353,8 @@ __global__ __launch_bounds__(128, 2) void attn_fwd2_kernel(const op16 *__restric
         }
         if (!DMA) __syncthreads();
 #pragma unroll
-        for (int i = 0; i < (DMA ? 0 : 4); i++) {
-            const int row = srow + 16 * i;
+        for (int i = 0; i < (DMA ? 0 : PW); i++) {
+            const int row = srow + 8 * NW * i;
             const uint4 kv = *reinterpret_cast<const uint4 *>(kbase + (size_t)min(k0 + row, N - 1) * rs + sslot * 8);
             const uint4 vv = *reinterpret_cast<const uint4 *>(vbase + (size_t)min(k0 + row, N - 1) * rs + sslot * 8);
             *reinterpret_cast<uint4 *>(Ks + row * 128 + ((sslot ^ ((row >> 1) & 7)) << 4)) = kv;
@@ -811,6 +815,19 @@ extern "C" int cosa_attn_prepare_vt(const void *qkv, int B, int N, int H, void *
     return COSA_OK;
 }
 
+// Waves per workgroup of the forward kernel (2 = 128 queries, 4 = 256 queries per workgroup; eight waves per CU either way): a wave's work
+// per query block is the same in both, so the launch with fewer rounds of the chip wins -- 1024 resident 2-wave workgroups against 512
+// 4-wave ones -- and on a tie the wider workgroup, whose waves issue half the LDS-DMA instructions per tile (measured, b = 32 x 12 heads:
+// N = 1765 380 -> 371 us, N = 785 115 -> 112, b = 16 N = 785 64 -> 58, N = 3601 (b = 8) 400 -> 379; N = 1601, where 256-query blocks pad
+// more, 319 vs 333: stays narrow).
+static bool attn_wide(int B, int N, int H)
+{
+    if (N <= 512) return false;
+    const long groups = (long)(B * H + 7) / 8 * 8;
+    const long r2 = (groups * ((N + 127) / 128) + 1023) / 1024, r4 = (groups * ((N + 255) / 256) + 511) / 512;
+    return r4 <= r2;
+}
+
 extern "C" int cosa_attn_fwd(const void *qkv, void *out, float *lse, int B, int N, int H, int head_dim, float scale,
                              int flags, uint64_t *stamps, void *workspace, size_t workspace_bytes, void *stream)
 {
@@ -823,17 +840,25 @@ extern "C" int cosa_attn_fwd(const void *qkv, void *out, float *lse, int B, int 
     }
     hipStream_t st = as_stream(stream);
     const int Npad = (N + BK - 1) / BK * BK;
-    const op16 *vt = nullptr;      // (there is no V^T copy; `flags` is ignored: it selected among earlier kernel variants)
-    (void)flags;
-    const int nblk = (N + BQ - 1) / BQ;
+    const op16 *vt = nullptr;      // (there is no V^T copy)
+    bool wide = attn_wide(B, N, H);
+    if (flags & 0x100) wide = true;          // flags bits 8 / 9 force 4 / 2 waves per workgroup (measurements); the other bits selected among
+    if (flags & 0x200) wide = false;         // earlier kernel variants and are ignored
+    const int bq = wide ? 256 : 128;
+    const int nblk = (N + bq - 1) / bq;
     const dim3 grid(nblk * ((B * H + 7) / 8 * 8));
+    const float sl2 = scale * 1.4426950408889634f;
+    unsigned long long *stp = reinterpret_cast<unsigned long long *>(stamps);
+    const op16 *q = static_cast<const op16 *>(qkv);
+    op16 *o = static_cast<op16 *>(out);
     // LDS-DMA addresses one image's qkv rows through a 32-bit buffer offset; beyond 2 GiB per image the tiles are staged through registers
     if ((size_t)N * 3 * H * HD * 2 >= 0x7fffffffull)
-        hipLaunchKernelGGL(attn_fwd2_kernel<false>, grid, dim3(128), 0, st, static_cast<const op16 *>(qkv), vt, static_cast<op16 *>(out), lse, N, Npad,
-                           H, nblk, B * H, scale * 1.4426950408889634f, reinterpret_cast<unsigned long long *>(stamps));
+        hipLaunchKernelGGL(attn_fwd2_kernel<false>, dim3(((N + 127) / 128) * ((B * H + 7) / 8 * 8)), dim3(128), 0, st, q, vt, o, lse, N, Npad, H, (N + 127) / 128,
+                           B * H, sl2, stp);
+    else if (wide)
+        hipLaunchKernelGGL((attn_fwd2_kernel<true, false, 4>), grid, dim3(256), 0, st, q, vt, o, lse, N, Npad, H, nblk, B * H, sl2, stp);
     else
-        hipLaunchKernelGGL(attn_fwd2_kernel<true>, grid, dim3(128), 0, st, static_cast<const op16 *>(qkv), vt, static_cast<op16 *>(out), lse, N, Npad,
-                           H, nblk, B * H, scale * 1.4426950408889634f, reinterpret_cast<unsigned long long *>(stamps));
+        hipLaunchKernelGGL(attn_fwd2_kernel<true>, grid, dim3(128), 0, st, q, vt, o, lse, N, Npad, H, nblk, B * H, sl2, stp);
     COSA_LAUNCH_CHECK();
     return COSA_OK;
 }
@@ -849,10 +874,16 @@ extern "C" int cosa_attn_fwd_f16c8(const void *qkv, void *out_c8, float *lse, in
     COSA_REQUIRE(B > 0 && N > 0 && H > 0 && B <= 65535 && H <= 65535, "cosa_attn_fwd_f16c8: bad shape");
     COSA_REQUIRE((size_t)N * 3 * H * HD * 2 < 0x7fffffffull, "cosa_attn_fwd_f16c8: one image's qkv rows must stay below 2 GiB (buffer addressing)");
     const int Npad = (N + BK - 1) / BK * BK;
-    const int nblk = (N + BQ - 1) / BQ;
-    hipLaunchKernelGGL((attn_fwd2_kernel<true, true>), dim3(nblk * ((B * H + 7) / 8 * 8)), dim3(128), 0, as_stream(stream), static_cast<const op16 *>(qkv),
-                       static_cast<const op16 *>(nullptr), static_cast<op16 *>(out_c8), lse, N, Npad, H, nblk, B * H, scale * 1.4426950408889634f,
-                       reinterpret_cast<unsigned long long *>(stamps));
+    const bool wide = attn_wide(B, N, H);
+    const int nblk = wide ? (N + 255) / 256 : (N + 127) / 128;
+    if (wide)
+        hipLaunchKernelGGL((attn_fwd2_kernel<true, true, 4>), dim3(nblk * ((B * H + 7) / 8 * 8)), dim3(256), 0, as_stream(stream), static_cast<const op16 *>(qkv),
+                           static_cast<const op16 *>(nullptr), static_cast<op16 *>(out_c8), lse, N, Npad, H, nblk, B * H, scale * 1.4426950408889634f,
+                           reinterpret_cast<unsigned long long *>(stamps));
+    else
+        hipLaunchKernelGGL((attn_fwd2_kernel<true, true>), dim3(nblk * ((B * H + 7) / 8 * 8)), dim3(128), 0, as_stream(stream), static_cast<const op16 *>(qkv),
+                           static_cast<const op16 *>(nullptr), static_cast<op16 *>(out_c8), lse, N, Npad, H, nblk, B * H, scale * 1.4426950408889634f,
+                           reinterpret_cast<unsigned long long *>(stamps));
     COSA_LAUNCH_CHECK();
     return COSA_OK;
 }

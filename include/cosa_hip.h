@@ -180,8 +180,8 @@ int cosa_dense_energy_backward(const float *AS, const float *roi, const float *g
  *   qkv [B,N,3,H,64] bf16 (output of the qkv projection)   out [B,N,H*64] bf16
  *   lse [B,H,N] f32 (log-sum-exp of the scaled scores, kept for the backward pass)
  *   V is read in place (its V^T fragments come from the transposing LDS read): the workspace is a token 256 bytes and
- *   cosa_attn_prepare_vt a no-op, both kept for callers written against the earlier V^T-copy version; `flags` is
- *   ignored (it selected among earlier kernel variants).
+ *   cosa_attn_prepare_vt a no-op, both kept for callers written against the earlier V^T-copy version; `flags` bits 8 / 9
+ *   force 4 / 2 waves per workgroup (default: by the number of rounds, attn_kernels.hip), the other bits are ignored.
  * ------------------------------------------------------------------------------------- */
 size_t cosa_attn_workspace_bytes(int B, int N, int H);
 int cosa_attn_prepare_vt(const void *qkv, int B, int N, int H, void *workspace, size_t workspace_bytes, void *stream);
