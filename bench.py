@@ -426,8 +426,10 @@ def main():
                 return None
             traffic = None
             try:        # HBM bytes of the dominant launch shape from the committed PMC passes (profiles/, separate --pmc runs)
-                if not os.path.exists(os.path.join(ROOT, "profiles", pmc_file)):
-                    pmc_file = pmc_file.replace("r02_", "r01_")
+                for rnd in ("r03_", "r02_", "r01_"):                  # the newest committed PMC summary of this kernel
+                    if os.path.exists(os.path.join(ROOT, "profiles", pmc_file.replace("r02_", rnd))):
+                        pmc_file = pmc_file.replace("r02_", rnd)
+                        break
                 pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
                 traffic = {"hbm_bytes": pmc["hbm_bytes_per_launch"], "algorithmic_bytes": pmc["algorithmic_bytes_per_launch"],
                            "launch": pmc["launch"], "source": "profiles/" + pmc_file}
