@@ -312,12 +312,13 @@ __global__ __launch_bounds__(256) void par_step_kernel(const float *__restrict__
 //     multiply / add of the two planes are one packed instruction each (v_pk_mul_f32 with the affinity broadcast, v_pk_add_f32: separate
 //     IEEE roundings per half, as the spec's mul-then-sum); only the d > HALO taps (8) remain global gathers, issued first;
 //   * the reads are explicit instructions (left to itself the compiler joins neighbours into ds_read2_b64, which moves the same bytes at
-//     half the rate) issued one dilation ahead of the arithmetic that consumes them;
+//     half the rate) issued four taps ahead of the arithmetic that consumes them; reads, multiplies and adds are volatile asm, which keeps
+//     that interleave (the scheduler otherwise issues all 40 reads first and holds 40 products in registers);
 //   * two LDS buffers: the next pair's tile is fetched while this one is consumed, one barrier per pair.
 // An odd plane count walks its last plane twice (second copy not stored).  Accumulation order is the spec's (acc = acc + m * a, neighbour
 // index ascending): bit-identical to the oracle.
 // DIL: compile-time dilation list (the only configuration the reference names, models/PAR.py:94); other lists take par_step_kernel.
-constexpr int kTH = 8, kTW = 32, kHalo = 12, kStepThreads = kTH * kTW;      // 256 threads: ~135 registers per thread -> three workgroups per CU
+constexpr int kTH = 8, kTW = 32, kHalo = 12, kStepThreads = kTH * kTW;      // 256 threads, 119 registers per thread: four workgroups per CU
 constexpr int kLW = kTW + 2 * kHalo, kLH = kTH + 2 * kHalo;           // 56 x 32
 struct Dil6 { static constexpr int n = 6; static constexpr int d[6] = {1, 2, 4, 8, 12, 24}; };
 typedef float f32x2 __attribute__((ext_vector_type(2)));
