@@ -63,3 +63,82 @@ def test_world_size_2_gloo():
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
     assert len(ret) == 2 and ret[0] != ret[1]                            # the two ranks really saw different shards
+
+
+class _CollectingLinear(torch.autograd.Function):
+    """stand-in for nn_ops.LinearShadowFn on the CPU: same contract towards the collector (backward hands (w, dY, X) over and returns no
+    weight / bias gradient of its own)"""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        from cosa_amd import nn_ops
+        ctx.save_for_backward(x, w)
+        c = nn_ops._wgrad_collector
+        ctx.collect = (c, w) if (c is not None and id(w) in c.keys) else None
+        return x @ w.t() + b
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        assert ctx.collect is not None
+        ctx.collect[0].add(ctx.collect[1], dy.reshape(-1, dy.shape[-1]).contiguous(), x.reshape(-1, x.shape[-1]).contiguous())
+        return dy @ w, None, None
+
+
+class _DeferredMLP(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.inp = torch.nn.Linear(8, 16)
+        self.l1, self.l2, self.l3 = torch.nn.Linear(16, 16), torch.nn.Linear(16, 16), torch.nn.Linear(16, 4)
+
+    def forward(self, x, defer):
+        from cosa_amd import nn_ops
+        h = torch.tanh(self.inp(x))
+        if not defer:
+            return self.l3(torch.tanh(self.l2(torch.tanh(self.l1(h)))))
+        h, c = nn_ops.defer_wgrads(h, [self.l1, self.l2, self.l3])
+        with nn_ops.collecting(c):
+            for i, m in enumerate((self.l1, self.l2, self.l3)):
+                h = _CollectingLinear.apply(h, m.weight, m.bias)
+                if i < 2:
+                    h = torch.tanh(h)
+        return h
+
+
+def _worker_deferred(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cosa_amd import nn_ops
+        from cosa_amd.train_step import rank_seed, wrap_ddp
+        # the batched kernel needs a GPU: its torch equivalent (fp32) stands in, everything around it is the product's code
+        nn_ops.gemm_wgrad_batched = lambda pairs: [(dy.float().t() @ x.float(), dy.float().sum(0) if wb else None) for dy, x, wb in pairs]
+        torch.manual_seed(0)
+        model = _DeferredMLP()
+        ref = _DeferredMLP()
+        ref.load_state_dict(model.state_dict())
+        ddp = wrap_ddp(model, torch.device("cpu"))
+        x = torch.randn(6, 8, generator=torch.Generator().manual_seed(rank_seed(77, rank)))
+        for it in range(3):                                      # three iterations: DDP rebuilds its buckets after the first
+            model.zero_grad(set_to_none=True)
+            ddp(x, True).square().mean().backward()
+            ref.zero_grad(set_to_none=True)
+            ref(x, False).square().mean().backward()
+            for (n, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
+                g = q.grad.clone()
+                dist.all_reduce(g)
+                assert p.grad is not None and torch.allclose(p.grad, g / world, atol=1e-6), (it, n)
+        ret[rank] = True
+    finally:
+        dist.destroy_process_group()
+
+
+def test_deferred_weight_gradients_reach_ddp_world_size_2_gloo():
+    """nn_ops.DeferredWgrad under DistributedDataParallel: the gradients of the collected linears come out of ONE autograd node at the
+    region's input; DDP must still see every parameter once per iteration and average it over the ranks (run on CPU over gloo, the batched
+    kernel replaced by its torch equivalent)"""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_deferred, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert len(ret) == 2
