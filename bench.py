@@ -156,7 +156,9 @@ def par_refine_ms_per_img(trainer, simg, lab, box, dev, opt, C):
         def f():
             loss = seg_helper.get_energy_loss(img, logit, mask, box, layer)
             loss.backward()
-        f()
+        for _ in range(3):                    # (allocator growth and the lattice workspace settle in the first calls)
+            f()
+        torch.cuda.synchronize()
         a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         for _ in range(n):
