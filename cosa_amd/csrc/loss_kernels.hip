@@ -151,12 +151,19 @@ __global__ __launch_bounds__(256) void seg_loss_fwd_kernel(const float *__restri
         if (lane == 0) red[wave][i] = v;
     }
     __syncthreads();
-    if (tid < 8) atomicAdd(&sums[tid], fix32(red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid]));
+    // 64 shards of the 8 sums (workgroup number & 63): thousands of workgroups adding to the same 8 addresses serialise at ~20 ns per add;
+    // integer addition is associative, so the total does not depend on the sharding either
+    const unsigned wg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    if (tid < 8) atomicAdd(&sums[(wg & 63u) * 8 + tid], fix32(red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid]));
 }
 
 __global__ void seg_loss_sums_kernel(const unsigned long long *__restrict__ fix, float *__restrict__ sums)
 {
-    if (threadIdx.x < 8) sums[threadIdx.x] = (float)((double)(long long)fix[threadIdx.x] * (1.0 / 4294967296.0));
+    if (threadIdx.x < 8) {
+        unsigned long long t = 0;
+        for (int sh = 0; sh < 64; sh++) t += fix[sh * 8 + threadIdx.x];
+        sums[threadIdx.x] = (float)((double)(long long)t * (1.0 / 4294967296.0));
+    }
 }
 
 // ---- backward ---------------------------------------------------------------------------------------------------
@@ -512,7 +519,7 @@ static int check_shapes(int B, int K, int hs, int ws, int S)
 extern "C" size_t cosa_seg_loss_workspace_bytes(int B, int K, int hs, int ws)
 {
     if (B <= 0 || K <= 0 || hs <= 0 || ws <= 0) return 0;
-    return align_up((size_t)B * K * hs * ws * sizeof(unsigned long long) + 64, 256);
+    return align_up((size_t)B * K * hs * ws * sizeof(unsigned long long) + 64 * 8 * sizeof(unsigned long long), 256);     // gradient cells + 64 shards of the 8 forward sums
 }
 
 extern "C" int cosa_seg_loss_forward(const float *seg_lr, const float *maskA, const float *maskB, const float *simg,
@@ -522,13 +529,13 @@ extern "C" int cosa_seg_loss_forward(const float *seg_lr, const float *maskA, co
     COSA_REQUIRE(seg_lr && maskA && maskB && simg && boxes && sums && s_seg && s_img && roi && unlabel && workspace, "cosa_seg_loss_forward: null pointer");
     int rc = check_shapes(B, K, hs, ws, S);
     if (rc) return rc;
-    if (workspace_bytes < 64) {
+    if (workspace_bytes < 64 * 8 * sizeof(unsigned long long)) {
         set_error("cosa_seg_loss_forward: workspace too small");
         return COSA_ENOMEM;
     }
     hipStream_t st = as_stream(stream);
     unsigned long long *fix = static_cast<unsigned long long *>(workspace);
-    COSA_HIP_CHECK(hipMemsetAsync(fix, 0, 8 * sizeof(unsigned long long), st));
+    COSA_HIP_CHECK(hipMemsetAsync(fix, 0, 64 * 8 * sizeof(unsigned long long), st));
     const dim3 grid((S + 31) / 32, (S + 31) / 32, B), blk(16, 16);
     const size_t lds = (size_t)K * TC * TC * sizeof(float);
     hipLaunchKernelGGL(seg_loss_fwd_kernel, grid, blk, lds, st, seg_lr, maskA, maskB, simg, boxes, fix, s_seg, s_img, roi, unlabel, K,
@@ -552,7 +559,7 @@ extern "C" int cosa_seg_loss_backward(const float *seg_lr, const float *maskA, c
         return COSA_ENOMEM;
     }
     hipStream_t st = as_stream(stream);
-    unsigned long long *fix = static_cast<unsigned long long *>(workspace) + 8;
+    unsigned long long *fix = static_cast<unsigned long long *>(workspace) + 64 * 8;
     COSA_HIP_CHECK(hipMemsetAsync(fix, 0, n * sizeof(unsigned long long), st));
     const dim3 grid((S + 31) / 32, (S + 31) / 32, B), blk(16, 16);
     const size_t lds = (size_t)((K * TC * TC + 1) & ~1) * sizeof(float) + (size_t)K * TC * TC * sizeof(unsigned long long);
