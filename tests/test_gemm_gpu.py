@@ -299,6 +299,14 @@ def test_gemm_wgrad_batched_vs_fp32_and_single_launches():
         for _ in range(3):
             again = nn_ops.gemm_wgrad_batched(pairs)
             assert all(torch.equal(a[0], o[0]) and torch.equal(a[1], o[1]) for a, o in zip(again, outs))
+    # more items than one launch's table holds (48): the entry point cuts the list into several launches
+    many = [(torch.randn(200, 128, device="cuda").bfloat16(), torch.randn(200, 128 * (1 + i % 2), device="cuda").bfloat16(), i % 3 == 0) for i in range(101)]
+    for (dy, x, wb), (dw, db) in zip(many, nn_ops.gemm_wgrad_batched(many)):
+        ref_w = dy.float().t() @ x.float()
+        assert (dw - ref_w).abs().max().item() <= 2e-4 * ref_w.abs().max().item() + 1e-3
+        assert (db is None) == (not wb)
+        if wb:
+            assert (db - dy.float().sum(0)).abs().max().item() <= 1e-3
 
 
 def test_deferred_wgrad_gives_the_same_gradients_as_per_layer_launches():
