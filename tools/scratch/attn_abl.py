@@ -1,4 +1,12 @@
-import sys, os, torch
+"""Timing ablations of attn_fwd2_kernel.  NOT runnable against the shipped library: the numbers were taken with a temporary
+build in which the kernel took an `abl` argument (flags >> 8) that switched off, one at a time, the S MFMAs (bit 0), the exponentials (bit 1:
+the fma kept), the PV MFMAs (bit 2), the vmcnt(0) + barrier at the end of a tile (bit 3) and the K/V LDS-DMA (bit 4); the runtime branches
+themselves slowed that build down (539 us against 380 us for the shipped kernel at B = 32, N = 1765), so only the differences mean anything.
+In the shipped library flags bits 8 / 9 select 4 / 2 waves per workgroup instead."""
+import sys
+if "--i-have-the-ablation-build" not in sys.argv:
+    sys.exit(__doc__)
+import os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from cosa_amd import _C
 B, N, H = 32, 1765, 12

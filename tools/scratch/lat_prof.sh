@@ -1,4 +1,7 @@
 #!/bin/bash
+# rocprofv3 kernel stats of the dense-energy prepare (tools/scratch/lat_build.py).  The COSA_LAT_ABL values quoted in profiles/r03_results.md
+# (1 = no hash probing, 2 = no offset / weight stores, 4 = ids not taken from the per-image counter) belonged to a temporary build of
+# lattice_build_kernel; the shipped library ignores the variable (run with the loop reduced to a single pass).
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?}" || exit 1
 for a in 0; do
   export COSA_LAT_ABL=$a
