@@ -71,6 +71,8 @@ _SIGS = {
     "cosa_layernorm_bwd_workspace_bytes": (c_size_t, [c_int, c_int]),
     "cosa_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                    c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "cosa_layernorm_bwd_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                       c_float, c_void_p, c_size_t, c_void_p]),
     "cosa_eval_labels": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p,
                                  c_void_p]),
     "cosa_cam_to_label": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int, c_float, c_float,

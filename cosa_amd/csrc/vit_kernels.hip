@@ -160,6 +160,119 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16 *__restrict__ dy
     }
 }
 
+// ---- fp32 residual stream (round 4): the student's stream is fp32 like the reference's (main.py:124-246 runs without autocast) --------
+// Forward of a block's LayerNorm is the teacher's layernorm_kernel (fp32 row in, bf16 row out); the residual add happens in the
+// projection GEMM's fp32 epilogue.  Backward: dx (fp32) = LayerNorm'(dy) + dskip (fp32: the gradient that reaches the same stream
+// tensor through the skip connection), plus a bf16 copy dx16 of that sum -- the dY operand of the previous projection's input- and
+// weight-gradient GEMMs -- so the sum is formed once, in fp32, and never re-read for a cast.  mean / rstd are recomputed from the fp32
+// row with the forward kernel's own operation order (the row is in registers anyway), so nothing but the stream itself is saved.
+// Traffic: 2 (dy) + 4 (x) + 4 (dskip) in, 4 (dx) + 2 (dx16) out = 16 B per element.
+// DY32: dy is fp32 (the final norm of the training path, whose output gradient is the fp32 sum of the decoder's and the heads' gradients)
+template <bool DY32>
+__global__ __launch_bounds__(256) void ln_bwd_f32_kernel(const void *__restrict__ dyv, const float *__restrict__ x,
+                                                        const bf16 *__restrict__ g, const float *__restrict__ dskip,
+                                                        float *__restrict__ dx, bf16 *__restrict__ dx16, float *__restrict__ part,
+                                                        int rows, int rows_per_wg, float eps)
+{
+    __shared__ float red[4][2][D];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r0 = blockIdx.x * rows_per_wg;
+    int r1 = r0 + rows_per_wg;
+    r1 = r1 < rows ? r1 : rows;
+    float gam[PER][4], dg[PER][4], db[PER][4];
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+        const bf16x4 gg = *reinterpret_cast<const bf16x4 *>(g + (lane + 64 * i) * 4);
+#pragma unroll
+        for (int j = 0; j < 4; j++) { gam[i][j] = (float)gg[j]; dg[i][j] = 0.f; db[i][j] = 0.f; }
+    }
+    float4 ndy[PER];
+    float4 nx[PER], nsk[PER];
+    auto load_row = [&](int row) {
+        const size_t base = (size_t)row * D;
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+            const int c0 = (lane + 64 * i) * 4;
+            if (DY32) {
+                ndy[i] = *reinterpret_cast<const float4 *>(static_cast<const float *>(dyv) + base + c0);
+            } else {
+                const bf16x4 t = *reinterpret_cast<const bf16x4 *>(static_cast<const bf16 *>(dyv) + base + c0);
+                ndy[i] = make_float4((float)t[0], (float)t[1], (float)t[2], (float)t[3]);
+            }
+            nx[i] = *reinterpret_cast<const float4 *>(x + base + c0);
+            if (dskip) nsk[i] = *reinterpret_cast<const float4 *>(dskip + base + c0);
+        }
+    };
+    int row = r0 + wave;
+    if (row < r1) load_row(row);
+    for (; row < r1; row += 4) {
+        const size_t base = (size_t)row * D;
+        float4 cdy[PER];
+        float4 cx[PER], csk[PER];
+#pragma unroll
+        for (int i = 0; i < PER; i++) { cdy[i] = ndy[i]; cx[i] = nx[i]; csk[i] = nsk[i]; }
+        if (row + 4 < r1) load_row(row + 4);
+        // the forward kernel's statistics, operation for operation (layernorm_kernel, gemm_kernels.hip)
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < PER; i++) s += cx[i].x + cx[i].y + cx[i].z + cx[i].w;
+        const float mu = wave_sum(s) * (1.0f / D);
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+            const float a = cx[i].x - mu, c = cx[i].y - mu, d = cx[i].z - mu, e = cx[i].w - mu;
+            q += a * a + c * c + d * d + e * e;
+        }
+        const float rs = rsqrtf(wave_sum(q) * (1.0f / D) + eps);
+        float xh[PER][4], gy[PER][4];
+        float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+            const float xv[4] = {cx[i].x, cx[i].y, cx[i].z, cx[i].w};
+            const float dv[4] = {cdy[i].x, cdy[i].y, cdy[i].z, cdy[i].w};
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float d = dv[j];
+                xh[i][j] = (xv[j] - mu) * rs;
+                gy[i][j] = d * gam[i][j];
+                c1 += gy[i][j];
+                c2 += gy[i][j] * xh[i][j];
+                dg[i][j] += d * xh[i][j];
+                db[i][j] += d;
+            }
+        }
+        c1 = wave_sum(c1) * (1.0f / D);
+        c2 = wave_sum(c2) * (1.0f / D);
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+            const int c0 = (lane + 64 * i) * 4;
+            float o[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) o[j] = (gy[i][j] - c1 - xh[i][j] * c2) * rs;
+            if (dskip) { o[0] += csk[i].x; o[1] += csk[i].y; o[2] += csk[i].z; o[3] += csk[i].w; }
+            *reinterpret_cast<float4 *>(dx + base + c0) = make_float4(o[0], o[1], o[2], o[3]);
+            if (dx16) {
+                bf16x4 ov;
+#pragma unroll
+                for (int j = 0; j < 4; j++) ov[j] = (bf16)o[j];
+                *reinterpret_cast<bf16x4 *>(dx16 + base + c0) = ov;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < PER; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            red[wave][0][(lane + 64 * i) * 4 + j] = dg[i][j];
+            red[wave][1][(lane + 64 * i) * 4 + j] = db[i][j];
+        }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 2 * D; c += 256) {
+        const int k = c / D, col = c - k * D;
+        part[((size_t)blockIdx.x * 2 + k) * D + col] = red[0][k][col] + red[1][k][col] + red[2][k][col] + red[3][k][col];
+    }
+}
+
 // dgamma / dbeta [D] = sum over the workgroup partials, in a fixed order (deterministic).  grid = 2*D/8, 256 threads:
 // 8 columns x 32 slices of the partial list (8 serial loads per thread), slices combined through LDS.
 __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float *__restrict__ part, int nblk, float *__restrict__ dgamma,
@@ -753,6 +866,31 @@ extern "C" int cosa_layernorm_bwd(const void *dy, const void *x_new, const float
     hipLaunchKernelGGL(ln_bwd_kernel, dim3(nblk), dim3(256), 0, st, static_cast<const bf16 *>(dy), static_cast<const bf16 *>(x_new), mean,
                        rstd, static_cast<const bf16 *>(gamma), static_cast<const bf16 *>(dskip), static_cast<bf16 *>(dx),
                        static_cast<float *>(workspace), rows, per);
+    COSA_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(2 * D / 8), dim3(256), 0, st, static_cast<const float *>(workspace), nblk, dgamma, dbeta,
+                       accumulate);
+    COSA_LAUNCH_CHECK();
+    return COSA_OK;
+}
+
+extern "C" int cosa_layernorm_bwd_f32(const void *dy, int dy_is_f32, const float *x, const void *gamma, const float *dskip, float *dx, void *dx16,
+                                      float *dgamma, float *dbeta, int accumulate, int rows, int dim, float eps, void *workspace,
+                                      size_t workspace_bytes, void *stream)
+{
+    COSA_REQUIRE(dy && x && gamma && dx && dgamma && dbeta && workspace && rows > 0, "cosa_layernorm_bwd_f32: bad arguments");
+    COSA_REQUIRE(dim == D, "cosa_layernorm_bwd_f32: dim must be 768 (ViT-B)");
+    COSA_REQUIRE(workspace_bytes >= cosa_layernorm_bwd_workspace_bytes(rows, dim), "cosa_layernorm_bwd_f32: workspace too small");
+    constexpr int target_blocks = 512;
+    int per = (rows + target_blocks - 1) / target_blocks;
+    per = (per + 3) / 4 * 4;
+    const int nblk = (rows + per - 1) / per;
+    hipStream_t st = as_stream(stream);
+    if (dy_is_f32)
+        hipLaunchKernelGGL(ln_bwd_f32_kernel<true>, dim3(nblk), dim3(256), 0, st, dy, x, static_cast<const bf16 *>(gamma), dskip,
+                           dx, static_cast<bf16 *>(dx16), static_cast<float *>(workspace), rows, per, eps);
+    else
+        hipLaunchKernelGGL(ln_bwd_f32_kernel<false>, dim3(nblk), dim3(256), 0, st, dy, x, static_cast<const bf16 *>(gamma), dskip,
+                           dx, static_cast<bf16 *>(dx16), static_cast<float *>(workspace), rows, per, eps);
     COSA_LAUNCH_CHECK();
     hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(2 * D / 8), dim3(256), 0, st, static_cast<const float *>(workspace), nblk, dgamma, dbeta,
                        accumulate);

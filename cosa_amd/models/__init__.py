@@ -35,6 +35,7 @@ class LargeFOV(nn.Module):
         w8 = c(self.conv8.weight, dt).reshape(self.conv8.weight.shape[0], -1)
         seg = nn_ops.head_linear(y.view(B, h * w, -1), w8.contiguous(), round_bf16=True)
         if seg is None:
+            nn_ops.torch_fallback(f"LargeFOV.conv8 ({tuple(w8.shape)}, {dt})")
             seg = F.linear(y, w8).float()
         return seg.view(B, h, w, -1).permute(0, 3, 1, 2).contiguous()
 
@@ -47,6 +48,7 @@ class LargeFOV(nn.Module):
         y = nn_ops.DilatedConvReluFn.apply(y.view(B, h * w, -1), self.conv7.weight, B, h, w, self.dilation)
         seg = nn_ops.narrow_linear(y, self.conv8.weight)
         if seg is None:
+            nn_ops.torch_fallback(f"LargeFOV.conv8 with autograd ({tuple(self.conv8.weight.shape)})")
             w8 = nn_ops.cast_param(self.conv8.weight, torch.bfloat16).reshape(self.conv8.weight.shape[0], -1)
             seg = F.linear(y, w8).float()
         return seg.view(B, h, w, -1).permute(0, 3, 1, 2).contiguous()
@@ -127,6 +129,8 @@ class VITNetwork(nn.Module):
         elif tok.is_cuda and dt == torch.bfloat16:
             cam = nn_ops.narrow_linear(tok.reshape(-1, tok.shape[-1]).contiguous(), weight.detach() if detach_w else weight)
         if cam is None:
+            if tok.is_cuda:
+                nn_ops.torch_fallback(f"CAM head ({tuple(weight.shape)}, tokens {dt})")
             wgt = nn_ops.cast_param(weight, dt).reshape(weight.shape[0], -1)
             cam = F.linear(tok, wgt.detach() if detach_w else wgt).float()
         return cam.reshape(B, h, w, -1).permute(0, 3, 1, 2).contiguous()
@@ -140,6 +144,8 @@ class VITNetwork(nn.Module):
         elif pooled.is_cuda and dt == torch.bfloat16:
             y = nn_ops.narrow_linear(pooled.to(dt).contiguous(), weight)
         if y is None:
+            if pooled.is_cuda:
+                nn_ops.torch_fallback(f"classification head ({tuple(weight.shape)}, {dt})")
             y = F.linear(pooled.to(dt), nn_ops.cast_param(weight, dt).reshape(weight.shape[0], -1)).float()
         return y
 
@@ -172,7 +178,33 @@ class VITNetwork(nn.Module):
             self.refresh_shadows()
         return self._heads(x, self.encoder.features_ex(x), cam_only, seg_only, detach)
 
+    def _heads_train_f32(self, x, feats, cam_only, seg_only, detach):
+        """the heads of the training path on the fp32 residual stream (models/__init__.py:163-206): every consumer of the final tokens
+        (decoder, CAM head, pooled classification head) and of the auxiliary tokens (aux CAM head, aux classification head) takes its own
+        bf16 view of ONE cast (nn_ops.fanout_bf16), whose backward adds the consumers' gradients in fp32"""
+        B = x.shape[0]
+        p = self.encoder.patch_size
+        h, w = x.shape[-2] // p, x.shape[-1] // p
+        t_dec, t_cam, t_cls = nn_ops.fanout_bf16(feats.final, 3)
+        a_cam, a_cls = nn_ops.fanout_bf16(feats.aux, 2)
+        x4 = t_dec[:, 1:].reshape(B, h, w, -1).permute(0, 3, 1, 2)
+        seg = self.decoder.forward_tokens_train(t_dec[:, 1:], B, h, w)
+        if seg_only:
+            return seg
+        cam = self._cam(t_cam[:, 1:], self.classifier.weight, B, h, w, detach == 'feat', detach == 'cls')
+        cam_aux = self._cam(a_cam[:, 1:], self.aux_classifier.weight, B, h, w, detach == 'feat', detach == 'cls')
+        if detach == 'all':
+            cam, cam_aux = cam.detach(), cam_aux.detach()
+        if cam_only:
+            return cam, cam_aux
+        dt = self.compute_dtype
+        cls_x4 = self._cls_head(self._pool(t_cls[:, 1:]), self.classifier.weight, dt)
+        cls_aux = self._cls_head(self._pool(a_cls[:, 1:]), self.aux_classifier.weight, dt)
+        return cls_x4, cls_aux, x4, seg, cam, cam_aux
+
     def _heads(self, x, feats, cam_only, seg_only, detach, need_cls=True):
+        if isinstance(feats, vitencoder.FP32Tokens):
+            return self._heads_train_f32(x, feats, cam_only, seg_only, detach)
         dt = self.compute_dtype
         B = x.shape[0]
         _, tok, tok_aux, tok32 = feats
@@ -185,6 +217,8 @@ class VITNetwork(nn.Module):
                 and torch.is_grad_enabled():
             seg = self.decoder.forward_tokens_train(tok, B, h, w)      # training: forward + both gradients on own kernels
         else:
+            if tok.is_cuda:
+                nn_ops.torch_fallback(f"LargeFOV decoder ({dt}, {self.decoder.conv6.weight.shape[1]} channels, grad {torch.is_grad_enabled()})")
             seg = self.decoder.forward_nhwc(x4, dt).float().contiguous()
         if seg_only:
             return seg

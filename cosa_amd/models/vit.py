@@ -23,6 +23,14 @@ from .. import nn_ops
 _OP16 = (torch.bfloat16, torch.float16)       # MFMA operand types of the HIP path (fp16: no-grad passes only)
 
 
+class FP32Tokens:
+    """what the training path on the fp32 residual stream hands to VITNetwork._heads instead of the (cls, tokens, aux tokens, fp32 tokens)
+    tuple: the final norm's output and the auxiliary layer's output, both fp32 [B, N, 768] including the class-token row"""
+
+    def __init__(self, final, aux):
+        self.final, self.aux = final, aux
+
+
 class Mlp(nn.Module):
     def __init__(self, in_features, hidden_features):
         super().__init__()
@@ -83,6 +91,12 @@ class VisionTransformer(nn.Module):
         self.head = nn.Linear(embed_dim, num_classes) if num_classes > 0 else nn.Identity()   # unused by the path (vit.py:257,325)
         self.compute_dtype = compute_dtype
         self.precision = None          # "bf16x3" / "fp16c8": parity-grade operand representations of the no-grad passes
+        # residual stream of the TRAINING path: "fp32" (default since round 4: the reference trains in fp32, main.py:124-246 -- the sums
+        # x + attn(..), x + mlp(..) and the gradient sums of the skip connections are formed and kept in fp32; MFMA operands stay bf16) or
+        # "bf16" (rounds 1-3: the stream itself rounded to 8 significant bits after every add; kept for A/B measurements)
+        self.residual_stream = "fp32"
+        self.defer_wgrad = True        # the blocks' weight gradients in batched launches (nn_ops.DeferredWgrad) ...
+        self.defer_groups = None       # ... one launch per group of depth / defer_groups blocks; None: 1 on a single GPU, 4 under data parallelism
         self.c8_plain_from = None      # fp16c8 only: blocks with index >= this run on plain fp16 operands ("fp16c8-9": the last three)
         self._pos_cache = {}
         _trunc_normal_(self.pos_embed)
@@ -130,7 +144,9 @@ class VisionTransformer(nn.Module):
                 grid = ent["mat"] @ src
             return torch.cat((pe[0, :1, :].float(), grid), dim=0).unsqueeze(0).to(dtype)
 
-    def prepare_tokens(self, x):
+    def prepare_tokens(self, x, stream_f32=False):
+        """stream_f32 (training on the fp32 residual stream): class token, position rows and their sum in fp32; the patch projection itself
+        runs on bf16 operands like every other projection"""
         B, nc, H, W = x.shape
         p = self.patch_size
         h, w = H // p, W // p
@@ -147,7 +163,12 @@ class VisionTransformer(nn.Module):
             # training: the same GEMM kernels with autograd (LinearShadowFn on the [768, 3*16*16] view of the conv weight)
             tok = nn_ops.linear_view2d(cols, self.patch_embed.proj.weight, self.patch_embed.proj.bias, dt)
         else:
+            if x.is_cuda:
+                nn_ops.torch_fallback(f"patch projection ({dt}, embed {self.embed_dim})")
             tok = F.linear(cols, wgt, bias)
+        if stream_f32:
+            tok = torch.cat((self.cls_token.float().expand(B, -1, -1), tok.float()), dim=1)
+            return tok + self._pos_for_grid(h, w, torch.float32), h, w
         cls = nn_ops.cast_param(self.cls_token, dt).expand(B, -1, -1)
         tok = torch.cat((cls, tok), dim=1)
         return tok + self._pos_for_grid(h, w, dt), h, w
@@ -458,17 +479,72 @@ class VisionTransformer(nn.Module):
             outs.append((a32[:, 0], a16[:, 1:], ax[:, 1:], a32[:, 1:]))
         return outs
 
+    def _n_defer_groups(self):
+        g = self.defer_groups
+        if g is None:
+            import torch.distributed as dist
+            g = 4 if (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) else 1
+        return max(1, min(int(g), len(self.blocks)))
+
+    def _features_train_f32(self, img):
+        """training forward on the fp32 residual stream (vit.py:302-321 with autograd): per block
+            qkv = Linear(y); o = attention(qkv); (x, y) = x + proj(o), norm2(.);  h = gelu(fc1(y)); (x, y) = x + fc2(h), next norm1(.)
+        every (projection + residual add, following LayerNorm) pair is ONE autograd node (nn_ops.ResidualLinearLNFn).  The blocks' weight
+        gradients are computed per group of blocks by one batched launch when the backward pass leaves the group: the DeferredWgrad node
+        sits on the group's first LayerNorm OUTPUT, whose gradient (from the qkv projection) is the last thing the group's backward
+        produces."""
+        dt = self.compute_dtype
+        x, h, w = self.prepare_tokens(img, stream_f32=True)
+        depth = len(self.blocks)
+        aux_idx = self.aux_layer % depth
+        aux = None
+        defer = torch.is_grad_enabled() and x.requires_grad and self.defer_wgrad
+        groups = self._n_defer_groups() if defer else 0
+        per = -(-depth // groups) if groups else depth
+        n1 = self.blocks[0].norm1
+        x, y = nn_ops.stream_layernorm(x, n1.weight, n1.bias, n1.eps)
+        scope = None
+        try:
+            for i, blk in enumerate(self.blocks):
+                if groups and i % per == 0:
+                    if scope is not None:
+                        scope.__exit__(None, None, None)
+                    mods = [m for b_ in self.blocks[i:i + per] for m in (b_.attn.qkv, b_.attn.proj, b_.mlp.fc1, b_.mlp.fc2)]
+                    y, coll = nn_ops.defer_wgrads(y, mods)
+                    scope = nn_ops.collecting(coll)
+                    scope.__enter__()
+                qkv = nn_ops.linear(y, blk.attn.qkv.weight, blk.attn.qkv.bias, dt)
+                o = nn_ops.attention(qkv, self.num_heads)
+                x, y = nn_ops.residual_linear_ln(o, x, blk.attn.proj, blk.norm2)
+                hmid = nn_ops.linear(y, blk.mlp.fc1.weight, blk.mlp.fc1.bias, dt, act=True)
+                last = i + 1 == depth
+                x, y = nn_ops.residual_linear_ln(hmid, x, blk.mlp.fc2, self.norm if last else self.blocks[i + 1].norm1, y_f32=last)
+                if i == aux_idx and not last:
+                    aux = x
+        finally:
+            if scope is not None:
+                scope.__exit__(None, None, None)
+        xn = y                                                  # the final norm's output, FP32: its consumers (decoder, CAM head, pooled
+        aux = xn if aux is None else aux                        # classification head) take bf16 copies through nn_ops.fanout_bf16, so that
+        return FP32Tokens(xn, aux)                              # their gradients are summed in fp32; aux = block aux_idx's output, pre-norm
+
     def use_fused(self, x):
         return (not torch.is_grad_enabled()) and self.compute_dtype in _OP16 and x.is_cuda and self.embed_dim == 768
 
     # -- vit.py:302-321: returns cls token, final tokens, aux-layer tokens (pre final norm unless aux is the last) --
     def forward_features(self, x):
-        return self.features_ex(x)[:3]
+        f = self.features_ex(x)
+        if isinstance(f, FP32Tokens):
+            return f.final[:, 0], f.final[:, 1:], f.aux[:, 1:]
+        return f[:3]
 
     def features_ex(self, x):
         """-> (cls, tokens, aux tokens, fp32 tokens or None).  No-grad bf16 passes take the fused HIP path."""
         if self.use_fused(x):
             return self._forward_features_fused(x)
+        if self.compute_dtype == torch.bfloat16 and x.is_cuda and self.embed_dim == 768 and self.residual_stream == "fp32" \
+                and torch.is_grad_enabled():
+            return self._features_train_f32(x)
         x, h, w = self.prepare_tokens(x)
         depth = len(self.blocks)
         aux_idx = self.aux_layer % depth
@@ -478,7 +554,7 @@ class VisionTransformer(nn.Module):
             delta = None
             # the 48 weight gradients of the blocks are computed in one batched launch when the backward pass reaches this point
             # (nn_ops.DeferredWgrad) instead of 48 split-K launches + 48 reductions
-            defer = torch.is_grad_enabled() and x.requires_grad and getattr(self, "defer_wgrad", True)
+            defer = torch.is_grad_enabled() and x.requires_grad and self.defer_wgrad
             if defer:
                 x, coll = nn_ops.defer_wgrads(x, [m for blk in self.blocks for m in (blk.attn.qkv, blk.attn.proj, blk.mlp.fc1, blk.mlp.fc2)])
             with nn_ops.collecting(coll if defer else None):
@@ -490,6 +566,8 @@ class VisionTransformer(nn.Module):
             if aux_idx == depth - 1:
                 aux = xn
             return xn[:, 0], xn[:, 1:], aux[:, 1:], None
+        if x.is_cuda:        # not ViT-B on 16-bit operands: only torch's operators could run this (a test-only mode, nn_ops.torch_reference_ops)
+            nn_ops.torch_fallback(f"VisionTransformer (embed {self.embed_dim}, {self.compute_dtype}) outside the HIP path's envelope")
         for i, blk in enumerate(self.blocks):
             x = self._block(blk, x)
             if i == aux_idx:

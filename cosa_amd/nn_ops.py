@@ -1,8 +1,8 @@
 """Differentiable building blocks of the ViT hot path, backed by the HIP kernels in libcosa_hip.so.
 
 Every op here is an explicit torch.autograd.Function around C-ABI calls (no tracing compiler, no
-Triton).  Plain library GEMMs (F.linear -> hipBLASLt) are used only where a bare GEMM is all
-there is to do; everything fused or attention-shaped is hand-written HIP.
+Triton, no library GEMM).  Shapes / dtypes outside the HIP kernels' envelope RAISE; torch's own
+operators stand in only inside `with torch_reference_ops():`, a test-only mode (see below).
 """
 import ctypes
 import math
@@ -20,6 +20,36 @@ from . import _C
 # attention  (models/vit/vit.py:119-137)
 # --------------------------------------------------------------------------------------------
 _flops = {}   # algorithmic FLOPs issued per profiled kernel (read by bench.py)
+
+
+# --------------------------------------------------------------------------------------------
+# torch reference operators: a TEST-ONLY mode
+# --------------------------------------------------------------------------------------------
+# The product path is ViT-B (embed 768) on 16-bit MFMA operands; every operator of it is a kernel of this repository.  Shapes / dtypes
+# outside that envelope (fp32 "parity mode", the 128-wide toy encoders of the golden vectors) can only run on torch's own operators --
+# which is a second backend, so it is OFF unless a test asks for it (`with nn_ops.torch_reference_ops():`); the tests that do check
+# host logic (module wiring, state-dict names, the loss algebra), not HIP kernels, and say so.  With the switch off every such site
+# raises CosaError instead of silently computing on ATen / hipBLASLt.
+_torch_reference = [0]
+
+
+class torch_reference_ops:
+    """`with torch_reference_ops():` -- allow the torch (ATen) reference operators for shapes / dtypes the HIP path does not cover (tests only)"""
+
+    def __enter__(self):
+        _torch_reference[0] += 1
+        return self
+
+    def __exit__(self, *exc):
+        _torch_reference[0] -= 1
+        return False
+
+
+def torch_fallback(what):
+    """called at every site that would leave the HIP path: raises unless the test-only switch is on"""
+    if not _torch_reference[0]:
+        raise _C.CosaError(f"{what}: no HIP kernel covers this shape / dtype and cosa_amd has no second backend "
+                           "(the torch reference operators are a test-only mode: nn_ops.torch_reference_ops())")
 
 
 class KernelStamps:
@@ -139,6 +169,7 @@ def attention(qkv, H):
     """qkv [B,N,3*H*64].  bf16 -> HIP kernel; fp32 (parity mode) -> exact fp32 math in torch."""
     if qkv.dtype == torch.bfloat16:
         return FusedAttention.apply(qkv, H)
+    torch_fallback(f"attention on {qkv.dtype} operands")
     B, N, _ = qkv.shape
     q, k, v = qkv.view(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
     att = torch.matmul(q, k.transpose(-1, -2)) * 0.125
@@ -636,6 +667,10 @@ class WgradCollector:
     def __init__(self, params):
         self.keys = {id(p) for p in params}
         self.pending = {}
+        self.used = set()            # weights whose linear ran in the forward pass (each owes a pair)
+
+    def mark_used(self, w):
+        self.used.add(id(w))
 
     def add(self, w, dy2, x2):
         if id(w) in self.pending:
@@ -683,6 +718,11 @@ class DeferredWgrad(Function):
             if ent is not None:
                 jobs.append((ent[0], ent[1], True))
                 slots.append(j)
+            elif ctx.needs_input_grad[2 + j] and ctx.ids[j] in c.used:
+                # the linear ran in the forward pass but its backward has not happened yet: this node sits on a tensor whose gradient is
+                # complete BEFORE the group's last backward -- its weight gradient would be lost without a word
+                raise RuntimeError("DeferredWgrad: reached before the backward of a linear it collects for (place it on the tensor whose "
+                                   "gradient the group's backward produces last)")
         grads = [None] * len(ctx.ids)
         if jobs:
             for j, (dw, db) in zip(slots, gemm_wgrad_batched(jobs)):
@@ -774,6 +814,8 @@ class LinearShadowFn(Function):
         ctx.xshape = x.shape
         c = _wgrad_collector
         ctx.collect = (c, w) if (c is not None and id(w) in c.keys) else None
+        if ctx.collect is not None:
+            c.mark_used(w)
         return y.view(*x.shape[:-1], N)
 
     @staticmethod
@@ -809,6 +851,7 @@ def linear_view2d(x, weight, bias, dtype):
     if ew is not None and eb is not None and et is not None and ew[0] is weight and eb[0] is bias and et[0] is weight \
             and w2.shape[0] % 128 == 0 and w2.shape[1] % 128 == 0:
         return LinearShadowFn.apply(x, w2, bias, ew[1].view(w2.shape), eb[1], et[1], False)
+    torch_fallback(f"linear_view2d (weight {tuple(w2.shape)}, {dtype}; shadows registered: {ew is not None and et is not None})")
     return F.linear(x, cast_param(weight, dtype).view(w2.shape), cast_param(bias, dtype))
 
 
@@ -821,6 +864,7 @@ def linear(x, weight, bias, dtype, act=False):
                 and _own_gemm_ok(x.numel() // x.shape[-1], weight.shape[0], weight.shape[1]) and weight.shape[0] % 64 == 0 \
                 and weight.shape[0] % 128 == 0 and weight.shape[1] % 128 == 0:
             return LinearShadowFn.apply(x, weight, bias, ew[1], eb[1], et[1], bool(act))
+    torch_fallback(f"linear (weight {tuple(weight.shape)}, {dtype}, grad {torch.is_grad_enabled()})")
     y = F.linear(x, cast_param(weight, dtype), cast_param(bias, dtype))
     return F.gelu(y) if act else y
 
@@ -902,3 +946,152 @@ def add_layernorm(x, delta, weight, bias, eps):
     return AddLayerNormFn.apply(x, delta, weight, bias, w16, b16, eps)
 
 
+# --------------------------------------------------------------------------------------------
+# student blocks on an fp32 residual stream (round 4; the reference trains in fp32, main.py:124-246):
+#   x' = x + Linear(a)   -> the projection GEMM's fp32 residual epilogue (cosa_gemm_bf16, epilogue 2): the sum is formed in fp32 from the
+#                           fp32 accumulators, never rounded to 16 bits
+#   y  = LayerNorm(x')   -> cosa_layernorm (fp32 row in, bf16 row out: the next GEMM's operand)
+# and ONE autograd node per (projection, following LayerNorm) pair, so that its backward sees both gradients of x' -- through the
+# LayerNorm and through the skip connection -- and adds them in fp32 inside the LayerNorm-backward kernel (cosa_layernorm_bwd_f32), which
+# also emits the bf16 copy that the projection's input- / weight-gradient GEMMs take as dY.
+# --------------------------------------------------------------------------------------------
+def _gamma16(weight, bias):
+    ew, eb = _shadows.get(id(weight)), _shadows.get(id(bias))
+    if ew is not None and eb is not None and ew[0] is weight and eb[0] is bias and ew[1].dtype == torch.bfloat16:
+        return ew[1], eb[1]
+    return weight.detach().to(torch.bfloat16), bias.detach().to(torch.bfloat16)
+
+
+def _ln_backward_f32(dy, x, g16, eps, dskip, want16):
+    """-> (dx fp32, dx16 bf16 | None, dgamma, dbeta) for y = LayerNorm(x) with x fp32 [rows, 768], dy bf16, dskip fp32 | None"""
+    rows = x.numel() // 768
+    dy = dy.contiguous()
+    dx = torch.empty((rows, 768), device=x.device, dtype=torch.float32)
+    dx16 = torch.empty((rows, 768), device=x.device, dtype=torch.bfloat16) if want16 else None
+    dgamma = torch.empty(768, device=x.device, dtype=torch.float32)
+    dbeta = torch.empty_like(dgamma)
+    L = _C.lib()
+    ws = _C.workspace(L.cosa_layernorm_bwd_workspace_bytes(rows, 768), x.device, "ln_bwd")
+    assert dy.dtype in (torch.bfloat16, torch.float32)
+    _C.check(L.cosa_layernorm_bwd_f32(_C.ptr(dy), int(dy.dtype == torch.float32), _C.ptr(x), _C.ptr(g16),
+                                      _C.ptr(dskip.contiguous() if dskip is not None else None),
+                                      _C.ptr(dx), _C.ptr(dx16), _C.ptr(dgamma), _C.ptr(dbeta), 0, rows, 768, float(eps), _C.ptr(ws),
+                                      ws.numel(), _C.stream_ptr()), "cosa_layernorm_bwd_f32")
+    return dx, dx16, dgamma, dbeta
+
+
+class StreamLayerNormFn(Function):
+    """x (fp32 stream) -> (x itself, y = LayerNorm(x) in bf16).  Returning the stream from the same node lets the backward fold the
+    gradient that reaches x through the skip connection into the LayerNorm-backward pass (no separate fp32 add)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, w16, b16, eps):
+        x = x.contiguous()
+        y, _ = layernorm_f32(x.view(-1, 768), w16, b16, eps)
+        ctx.save_for_backward(x, w16)
+        ctx.eps = eps
+        return x.view_as(x), y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dx_skip, dy):
+        x, w16 = ctx.saved_tensors
+        if dy is None:
+            return dx_skip, None, None, None, None, None
+        dx, _, dgamma, dbeta = _ln_backward_f32(dy, x, w16, ctx.eps, dx_skip, False)
+        return dx.view(x.shape), dgamma, dbeta, None, None, None
+
+
+def stream_layernorm(x, weight, bias, eps):
+    """fp32 stream x [.., 768] -> (x, LayerNorm(x) bf16)"""
+    w16, b16 = _gamma16(weight, bias)
+    return StreamLayerNormFn.apply(x, weight, bias, w16, b16, eps)
+
+
+class ResidualLinearLNFn(Function):
+    """(a bf16 [.., K], x fp32 [.., 768]) -> (x' = x + a W^T + b  (fp32), y = LayerNorm(x'; gamma, beta) (bf16)).
+    models/vit/vit.py:154-158: `x = x + attn(...)` / `x = x + mlp(...)` followed by the next norm.  Forward: the persistent GEMM with the
+    fp32 residual epilogue + the fp32 -> bf16 LayerNorm kernel; backward: LayerNorm' + skip gradient in fp32 (one kernel, which also writes
+    the bf16 dY), dA = dY W on the transposed shadow, dW / db on the TN kernel (or handed to the group's DeferredWgrad)."""
+
+    @staticmethod
+    def forward(ctx, a, x, w, b, w16, b16, wT16, gw, gb, gw16, gb16, eps, y_f32=False):
+        K = a.shape[-1]
+        a2 = a.reshape(-1, K)
+        if not a2.is_contiguous():
+            a2 = a2.contiguous()
+        x2 = x.reshape(-1, x.shape[-1])
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        xn = gemm_bf16(a2, w16, b16, EPI_RESIDUAL, residual=x2)                  # fp32 [M, N], a fresh buffer: x stays what earlier nodes saved
+        # y_f32: the final norm -- its output feeds the decoder and the heads, whose gradients must meet in fp32 (fanout_bf16)
+        y16, y32 = layernorm_f32(xn, gw16, gb16, eps, want_bf16=not y_f32, want_f32=y_f32)
+        y = y32 if y_f32 else y16
+        ctx.save_for_backward(a2, wT16, xn, gw16)
+        ctx.eps = eps
+        ctx.ashape, ctx.xshape = a.shape, x.shape
+        c = _wgrad_collector
+        ctx.collect = (c, w) if (c is not None and id(w) in c.keys) else None
+        if ctx.collect is not None:
+            c.mark_used(w)
+        return xn.view(x.shape), y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, g_x, g_y):
+        a2, wT16, xn, gw16 = ctx.saved_tensors
+        dgamma = dbeta = None
+        if g_y is not None:
+            dxt, dxt16, dgamma, dbeta = _ln_backward_f32(g_y, xn, gw16, ctx.eps, g_x, True)
+        else:                                   # the LayerNorm output was not used: only the skip gradient flows
+            dxt = g_x.reshape(-1, g_x.shape[-1]).contiguous()
+            dxt16 = dxt.to(torch.bfloat16)
+        K = a2.shape[1]
+        da = dw = db = None
+        if ctx.needs_input_grad[0]:
+            da = gemm_bf16(dxt16, wT16, _zero_bias16(K, dxt16.device)[:K], EPI_BIAS).view(ctx.ashape)
+        if ctx.needs_input_grad[2]:
+            if ctx.collect is not None:
+                ctx.collect[0].add(ctx.collect[1], dxt16, a2)
+            else:
+                dw, db = gemm_wgrad(dxt16, a2, want_bias=True)
+        return da, dxt.view(ctx.xshape), dw, db, None, None, None, dgamma, dbeta, None, None, None, None
+
+
+def residual_linear_ln(a, x, lin, norm, y_f32=False):
+    """x' = x + lin(a) on the fp32 stream and y = norm(x') (bf16; fp32 with y_f32) -> (x', y); `lin` an nn.Linear with registered shadows,
+    `norm` an nn.LayerNorm"""
+    weight, bias = lin.weight, lin.bias
+    ew, eb, et = _shadows.get(id(weight)), _shadows.get(id(bias)), _transposed.get(id(weight))
+    if not (ew is not None and eb is not None and et is not None and ew[0] is weight and eb[0] is bias and et[0] is weight
+            and ew[1].dtype == torch.bfloat16 and weight.shape[0] % 128 == 0 and weight.shape[1] % 128 == 0):
+        raise _C.CosaError("residual_linear_ln: the projection needs registered bf16 shadows (W, b, W^T) and 128-aligned shapes "
+                           "(CoSATrainer / nn_ops.ensure_shadows + TransposedShadows register them)")
+    gw16, gb16 = _gamma16(norm.weight, norm.bias)
+    return ResidualLinearLNFn.apply(a, x, weight, bias, ew[1], eb[1], et[1], norm.weight, norm.bias, gw16, gb16, norm.eps, bool(y_f32))
+
+
+class FanoutBf16Fn(Function):
+    """fp32 x -> n bf16 copies (one cast, n views of it), one per consumer; the consumers' bf16 gradients are added up in FP32.  With a
+    single bf16 tensor feeding several consumers autograd would form that sum in bf16 -- and the sum at the final norm's output (decoder +
+    CAM head + classification head) goes straight into LayerNorm', which subtracts its row mean: the bf16 rounding of the sum survives
+    that cancellation as a few per cent of the result (measured in round 3: weight-gradient cosine 0.995 in the LAST block already)."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        x16 = x.to(torch.bfloat16)
+        return tuple(x16.view_as(x16) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        acc = None
+        for g in gs:
+            if g is None:
+                continue
+            if acc is None:
+                acc = g.float()
+            else:
+                acc += g                      # fp32 += bf16: one kernel, the sum stays fp32
+        return acc, None
+
+
+def fanout_bf16(x, n):
+    return FanoutBf16Fn.apply(x, n)

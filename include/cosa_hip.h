@@ -434,6 +434,13 @@ size_t cosa_layernorm_bwd_workspace_bytes(int rows, int dim);
 int cosa_layernorm_bwd(const void *dy, const void *x_new, const float *mean, const float *rstd, const void *gamma,
                        const void *dskip, void *dx, float *dgamma, float *dbeta, int accumulate, int rows, int dim,
                        void *workspace, size_t workspace_bytes, void *stream);
+/* fp32 residual stream (the student's default since round 4; the reference trains in fp32, main.py:124-246): the forward of a block's
+ * LayerNorm is cosa_layernorm on the fp32 stream, the residual add is cosa_gemm_bf16's fp32 residual epilogue, and the backward is
+ *   cosa_layernorm_bwd_f32: dx (fp32) = dLayerNorm(dy: bf16, or fp32 with dy_is_f32; x fp32, gamma bf16, eps) + dskip (fp32, optional), dx16 (optional) = bf16(dx)
+ *     -- the dY operand of the preceding projection's gradient GEMMs; mean / rstd are recomputed from x; dgamma / dbeta as above. */
+int cosa_layernorm_bwd_f32(const void *dy, int dy_is_f32, const float *x, const void *gamma, const float *dskip, float *dx, void *dx16,
+                           float *dgamma, float *dbeta, int accumulate, int rows, int dim, float eps, void *workspace,
+                           size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * Evaluation path (SURVEY f-1; evaluation_engine.py:96-126,198-200, utils/seg_helper.py:515-546,581-591,

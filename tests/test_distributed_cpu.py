@@ -75,6 +75,8 @@ class _CollectingLinear(torch.autograd.Function):
         ctx.save_for_backward(x, w)
         c = nn_ops._wgrad_collector
         ctx.collect = (c, w) if (c is not None and id(w) in c.keys) else None
+        if ctx.collect is not None:
+            c.mark_used(w)
         return x @ w.t() + b
 
     @staticmethod
@@ -91,17 +93,21 @@ class _DeferredMLP(torch.nn.Module):
         self.inp = torch.nn.Linear(8, 16)
         self.l1, self.l2, self.l3 = torch.nn.Linear(16, 16), torch.nn.Linear(16, 16), torch.nn.Linear(16, 4)
 
-    def forward(self, x, defer):
+    def forward(self, x, defer, groups=1):
+        """groups: the collected linears in `groups` runs, each with its own DeferredWgrad node at the run's input (the trainer's form
+        under data parallelism: VisionTransformer.defer_groups)"""
         from cosa_amd import nn_ops
         h = torch.tanh(self.inp(x))
         if not defer:
             return self.l3(torch.tanh(self.l2(torch.tanh(self.l1(h)))))
-        h, c = nn_ops.defer_wgrads(h, [self.l1, self.l2, self.l3])
-        with nn_ops.collecting(c):
-            for i, m in enumerate((self.l1, self.l2, self.l3)):
-                h = _CollectingLinear.apply(h, m.weight, m.bias)
-                if i < 2:
-                    h = torch.tanh(h)
+        runs = {1: [[self.l1, self.l2, self.l3]], 2: [[self.l1], [self.l2, self.l3]], 3: [[self.l1], [self.l2], [self.l3]]}[groups]
+        for run in runs:
+            h, c = nn_ops.defer_wgrads(h, run)
+            with nn_ops.collecting(c):
+                for m in run:
+                    h = _CollectingLinear.apply(h, m.weight, m.bias)
+                    if m is not self.l3:
+                        h = torch.tanh(h)
         return h
 
 
@@ -119,9 +125,9 @@ def _worker_deferred(rank, world, port, ret):
         ref.load_state_dict(model.state_dict())
         ddp = wrap_ddp(model, torch.device("cpu"))
         x = torch.randn(6, 8, generator=torch.Generator().manual_seed(rank_seed(77, rank)))
-        for it in range(3):                                      # three iterations: DDP rebuilds its buckets after the first
+        for it in range(6):                                      # DDP rebuilds its buckets after the first iteration; iterations 3-5 in the grouped forms
             model.zero_grad(set_to_none=True)
-            ddp(x, True).square().mean().backward()
+            ddp(x, True, (1, 1, 1, 2, 3, 3)[it]).square().mean().backward()
             ref.zero_grad(set_to_none=True)
             ref(x, False).square().mean().backward()
             for (n, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
@@ -135,10 +141,34 @@ def _worker_deferred(rank, world, port, ret):
 
 def test_deferred_weight_gradients_reach_ddp_world_size_2_gloo():
     """nn_ops.DeferredWgrad under DistributedDataParallel: the gradients of the collected linears come out of ONE autograd node at the
-    region's input; DDP must still see every parameter once per iteration and average it over the ranks (run on CPU over gloo, the batched
-    kernel replaced by its torch equivalent)"""
+    region's input -- or, grouped (VisionTransformer.defer_groups, the trainer's form when world > 1), out of one node per run of layers;
+    DDP must still see every parameter exactly once per iteration and average it over the ranks (run on CPU over gloo, the batched kernel
+    replaced by its torch equivalent)"""
     world = 2
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_worker_deferred, args=(world, _free_port(), ret), nprocs=world, join=True)
     assert len(ret) == 2
+
+
+def test_deferred_wgrad_node_in_the_wrong_place_raises():
+    """a DeferredWgrad node whose backward runs BEFORE the backward of a linear it collects for would drop that weight gradient silently:
+    it raises instead (nn_ops.DeferredWgrad)"""
+    from cosa_amd import nn_ops
+    old = nn_ops.gemm_wgrad_batched
+    nn_ops.gemm_wgrad_batched = lambda pairs: [(dy.float().t() @ x.float(), dy.float().sum(0) if wb else None) for dy, x, wb in pairs]
+    try:
+        torch.manual_seed(0)
+        l1, l2 = torch.nn.Linear(8, 8), torch.nn.Linear(8, 8)
+        x = torch.randn(4, 8, requires_grad=True)
+        h = _CollectingLinear.apply(x, l1.weight, l1.bias) if False else x
+        # the node sits BEHIND l1 (on l1's output) although it collects for l1 too: its backward comes first
+        c = nn_ops.WgradCollector([l1.weight, l2.weight])
+        with nn_ops.collecting(c):
+            h = _CollectingLinear.apply(h, l1.weight, l1.bias)
+            h = nn_ops.DeferredWgrad.apply(h, c, l1.weight, l1.bias, l2.weight, l2.bias)
+            h = _CollectingLinear.apply(h, l2.weight, l2.bias)
+        with pytest.raises(RuntimeError, match="DeferredWgrad"):
+            h.square().mean().backward()
+    finally:
+        nn_ops.gemm_wgrad_batched = old

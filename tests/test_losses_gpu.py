@@ -88,18 +88,28 @@ def _cos(a, b):
     return float((a @ b) / (a.norm() * b.norm() + 1e-300))
 
 
-def test_bf16_student_step_vs_cpu_oracle_vitb():
-    """The student's forward / backward through this repository's own kernels (bf16 GEMMs with fused epilogues, fused attention forward /
-    backward, add+LayerNorm, dilated convs, narrow heads, fused losses) at ViT-B against oracle/cpu_step.py (fp32 CPU) on identical
-    weights and inputs, S = 224, b = 2, all five losses live.  The teacher runs in the parity-grade mode (fp16c8), so both sides see the
-    same pseudo labels; what is compared is the student: losses within 3e-3 relative (measured: <= 9e-4), weight gradients by cosine:
-    >= 0.99 for decoder convs / CAM heads, >= 0.98 for encoder weights (bf16 operands and a bf16 stream: 8 significant bits per value)."""
+# weight-gradient cosine bars of the student against the fp32 CPU oracle, per residual-stream mode (measured values: profiles/r04_student_vs_oracle_*.txt)
+#   fp32 stream (the default): what is left is the rounding of the MFMA operands (bf16 activations / weights / dY, 8 significant bits)
+#   bf16 stream (rounds 1-3, kept for A/B): the stream and every gradient sum rounded to 8 bits as well
+STUDENT_BARS = {"fp32": dict(enc=0.995, qk=0.99, dec=0.999, loss=1e-3), "bf16": dict(enc=0.98, qk=0.97, dec=0.99, loss=3e-3)}
+
+
+@pytest.mark.parametrize("S,stream", [(224, "fp32"), (448, "fp32"), (224, "bf16")])
+def test_bf16_student_step_vs_cpu_oracle_vitb(S, stream):
+    """The student's forward / backward through this repository's own kernels (bf16-operand GEMMs with fused epilogues -- the projections
+    that close a residual branch add into the FP32 stream in their epilogue --, fused attention forward / backward, LayerNorm forward /
+    backward on the fp32 stream, dilated convs, narrow heads, fused losses) at ViT-B against oracle/cpu_step.py (fp32 CPU) on identical
+    weights and inputs, b = 2, all five losses live, at S = 224 and at the benchmark's S = 448.  The teacher runs in the parity-grade mode
+    (fp16c8), so both sides see the same pseudo labels; what is compared is the student: the five losses within BASELINE.json's 1e-3
+    relative, weight gradients by cosine (bars: STUDENT_BARS)."""
     from cosa_amd.train_step import CoSATrainer, default_args, synthetic_batch
     from oracle.cpu_step import CpuStep
     dev = torch.device("cuda", 0)
-    S, b, C = 224, 2, 20
+    b, C = 2, 20
+    bars = STUDENT_BARS[stream]
     args = default_args("VOC12", crop_size=S, teacher_precision="fp16c8", teacher_graph=False, teacher_async=False)
     tr = CoSATrainer(args, dev, seed=3)
+    tr.student.encoder.residual_stream = stream
     sd = {k: v.detach().cpu().clone() for k, v in tr.student.state_dict().items()}
     wimg, simg, lab, box = synthetic_batch(b, S, C, dev, seed=5)
     n_iter = args.warmup_iters + 1
@@ -113,7 +123,7 @@ def test_bf16_student_step_vs_cpu_oracle_vitb():
     for k in ("cls_loss", "cls_aux_loss", "seg_loss", "cam_loss", "reg_loss", "overall_loss"):
         a, c = float(logs[k]), float(clogs[k])
         lines.append(f"{k}: hip {a:.6f} oracle {c:.6f}")
-        assert a == pytest.approx(c, rel=3e-3, abs=1e-4), (k, a, c)
+        assert a == pytest.approx(c, rel=bars["loss"], abs=2e-5), (k, a, c)
     tr.optimizer.zero_grad(set_to_none=True)
     loss.backward()
     cpu.opt.zero_grad(set_to_none=True)
@@ -135,13 +145,74 @@ def test_bf16_student_step_vs_cpu_oracle_vitb():
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(root, "gpurun_out", "r03_student_vs_oracle.txt"), "w") as f:
+    with open(os.path.join(root, "gpurun_out", f"r04_student_vs_oracle_{stream}_{S}.txt"), "w") as f:
+        f.write(f"# student ({stream} residual stream, bf16 MFMA operands) vs oracle/cpu_step.py (fp32 CPU), ViT-B, S = {S}, b = 2, one step\n")
         f.write("\n".join(lines) + "\n")
     for name, cs, ratio in checks:
-        # measured (profiles/r03_student_vs_oracle.txt): decoder / heads >= 0.999, encoder blocks 0.9856 (block 0) ... 0.9994 (block 11): the
-        # bf16 residual stream and 16-bit saved activations add ~1.5 % per layer to the back-propagated error at random initialisation
-        bar = 0.97 if name.endswith((":q", ":k")) else (0.98 if "encoder.blocks" in name or "patch_embed" in name else 0.99)
-        assert cs >= bar and 0.9 <= ratio <= 1.1, (name, cs, ratio)
+        bar = bars["qk"] if name.endswith((":q", ":k")) else (bars["enc"] if "encoder.blocks" in name or "patch_embed" in name else bars["dec"])
+        assert cs >= bar and 0.95 <= ratio <= 1.05, (name, cs, ratio)
+
+
+def test_ten_step_trajectory_vs_cpu_oracle():
+    """Ten optimizer steps of the real trainer (fp32-stream student, parity-grade teacher, fused AdamW + EMA kernel) next to ten steps of
+    oracle/cpu_step.py on the same weights and the same batch (S = 224, b = 2, post-warm-up loss weights, the LR schedule from step 0):
+    per-step losses within 1e-2 relative, and the accumulated parameter update theta_10 - theta_0 compared by cosine.  AdamW's update is
+    m / sqrt(v) -- sign-like in the first steps -- so an element whose gradient is smaller than the rounding noise flips: the update cosine
+    is far more sensitive than the gradient cosine (gradient cosine 0.999 = 4.5 % noise -> ~1.4 % flipped signs -> update cosine ~0.97).
+    Bars per layer kind below; measured values in profiles/r04_trajectory_vs_oracle.txt."""
+    from cosa_amd.train_step import CoSATrainer, default_args, synthetic_batch
+    from oracle.cpu_step import CpuStep
+    dev = torch.device("cuda", 0)
+    S, b, C, steps = 224, 2, 20, 10
+    args = default_args("VOC12", crop_size=S, teacher_precision="fp16c8", teacher_graph=False, teacher_async=False)
+    tr = CoSATrainer(args, dev, seed=3)
+    sd = {k: v.detach().cpu().clone() for k, v in tr.student.state_dict().items()}
+    wimg, simg, lab, box = synthetic_batch(b, S, C, dev, seed=5)
+    cw, cs_, cl, cb = wimg.cpu(), simg.cpu(), lab.cpu(), box.numpy()
+    torch.set_num_threads(max(1, min(16, torch.get_num_threads())))
+    cpu = CpuStep(sd, num_classes=21, aux_layer=-4)
+    names = ("encoder.blocks.0.attn.qkv.weight", "encoder.blocks.5.mlp.fc1.weight", "encoder.blocks.11.mlp.fc2.weight",
+             "encoder.patch_embed.proj.weight", "decoder.conv6.weight", "classifier.weight", "aux_classifier.weight", "encoder.norm.weight")
+    named = dict(tr.student.named_parameters())
+    t_named = dict(tr.model_AN.named_parameters())
+    th0 = {n: sd[n].double() for n in names}
+    gsum_h = {n: torch.zeros_like(sd[n], dtype=torch.float64) for n in names}
+    gsum_c = {n: torch.zeros_like(sd[n], dtype=torch.float64) for n in names}
+    lines = [f"# ten steps, S = {S}, b = {b}: trainer (HIP, fp32 stream) vs oracle/cpu_step.py"]
+    n0 = args.warmup_iters + 1
+    for it in range(steps):
+        logs = tr.step(wimg, simg, lab, box, n0 + it)
+        clogs = cpu.step(cw, cs_, cl, cb, n0 + it)
+        for n in names:
+            gsum_h[n] += named[n].grad.detach().double().cpu()
+            gsum_c[n] += cpu.student.p(n).grad.double()
+        row = []
+        for k in ("cls_loss", "cls_aux_loss", "seg_loss", "cam_loss", "reg_loss", "overall_loss"):
+            a, c = float(logs[k]), float(clogs[k])
+            row.append(f"{k} {a:.6f}/{c:.6f}")
+            assert a == pytest.approx(c, rel=1e-2, abs=1e-4), (it, k, a, c)
+        agree = (logs["mask"].cpu().numpy() == clogs["mask"].numpy()).mean()
+        assert agree >= 0.999, (it, agree)
+        lines.append(f"step {it}: " + "  ".join(row) + f"  label agreement {agree:.5f}")
+    checks = []
+    for n in names:
+        dh = named[n].detach().double().cpu() - th0[n]
+        dc = cpu.student.p(n).detach().double() - th0[n]
+        cu, cg = _cos(dh, dc), _cos(gsum_h[n], gsum_c[n])
+        ratio = float(dh.norm() / (dc.norm() + 1e-300))
+        te = float((t_named[n].detach().double().cpu() - cpu.teacher.p(n).detach().double()).abs().max())
+        lines.append(f"{n}: update cosine {cu:.5f} (norm ratio {ratio:.4f}, |update| {float(dc.norm()):.3e}); summed-gradient cosine {cg:.5f}; "
+                     f"teacher (EMA) max |diff| {te:.2e}")
+        checks.append((n, cu, cg, ratio))
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(root, "gpurun_out", "r04_trajectory_vs_oracle.txt"), "w") as f:
+        f.write("\n".join(lines) + "\n")
+    for n, cu, cg, ratio in checks:
+        head = n.startswith(("decoder.", "classifier", "aux_classifier"))
+        assert cg >= (0.999 if head else 0.995), (n, "summed gradient", cg)
+        assert cu >= (0.99 if head else 0.95) and 0.95 <= ratio <= 1.05, (n, "update", cu, ratio)
 
 
 def test_training_step_loss_and_gradients_are_bit_identical_run_to_run():

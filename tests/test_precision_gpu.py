@@ -361,16 +361,17 @@ def _miou(a, b, n=21):
 _ORACLE = {}
 
 
-def _oracle_pass(S):
-    """fp32 CPU oracle (oracle/torch_oracle.py + cosa_oracle.c) on seed-3 ViT-B weights and the seed-5 synthetic batch, cached per S"""
-    if S not in _ORACLE:
+def _oracle_pass(S, seed=3):
+    """fp32 CPU oracle (oracle/torch_oracle.py + cosa_oracle.c) on ViT-B weights drawn with `seed` and the synthetic batch of seed + 2
+    (seed 3 / batch 5 are the rounds 2-3 pair), cached per (S, seed)"""
+    if (S, seed) not in _ORACLE:
         from oracle import torch_oracle as to, c_oracle
         from cosa_amd.models import build_model
         from cosa_amd.train_step import default_args, synthetic_batch
-        torch.manual_seed(3)
+        torch.manual_seed(seed)
         net = build_model(default_args("VOC12", crop_size=S, compute_dtype=torch.float32))
         sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
-        wimg, _, lab, box = synthetic_batch(2, S, 20, torch.device("cpu"), seed=5)
+        wimg, _, lab, box = synthetic_batch(2, S, 20, torch.device("cpu"), seed=seed + 2)
         m = to.OracleViT(num_classes=21, aux_layer=-4)
         m.load_named(sd)
         torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
@@ -378,27 +379,32 @@ def _oracle_pass(S):
             cam, cam_aux, _ = to.multi_scale_camseg(m, wimg, [1.0, 0.5, 1.5])
         bx = np.asarray(box.numpy(), np.int32)
         masks = [c_oracle.cam2mask(None, bx, c.numpy(), lab.numpy(), 0.7, 0.25, 2, par=None) for c in (cam, cam_aux)]
-        _ORACLE[S] = (sd, wimg, lab, box, cam, cam_aux, masks)
-    return _ORACLE[S]
+        _ORACLE[(S, seed)] = (sd, wimg, lab, box, cam, cam_aux, masks)
+    return _ORACLE[(S, seed)]
 
 
-# mode -> (max normalised-CAM relative error, min label agreement, min mask IoU); bf16x3 carries the north-star bars
+# mode -> (max normalised-CAM relative error, min label agreement, min mask IoU); the conforming modes carry the north-star bars
+NORTH_STAR = (1e-3, 0.999, 0.999)      # BASELINE.json north_star: 1e-3 relative on fp32 CAMs, mask IoU >= 0.999
 TEACHER_BARS = {
     "bf16": (3e-2, 0.99, 0.97),
     "fp16": (4e-3, 0.9990, 0.995),
-    "bf16x3": (1e-3, 0.999, 0.999),        # BASELINE.json north_star: 1e-3 relative on fp32 CAMs, mask IoU >= 0.999
-    "fp16c8": (1e-3, 0.999, 0.999),        # the same bars at 2x (not 3x) the 16-bit MFMA work: the benchmarked parity-grade mode
-    "fp16c8-9": (1e-3, 0.999, 0.999),      # ... with the last three blocks on plain fp16 operands (measured margin: profiles/r03_accuracy_teacher.txt)
+    "bf16x3": NORTH_STAR,
+    "fp16c8": NORTH_STAR,          # the same bars at 2x (not 3x) the 16-bit MFMA work
+    "fp16c8-9": NORTH_STAR,        # ... with the last three blocks on plain fp16 operands: the benchmarked (headline) mode of bench.py
 }
+# the modes bench.py may run as its headline are checked on three independent weight / batch draws; bench.py reports the WORST of these
+# lines (profiles/r04_accuracy_teacher.txt, copied from gpurun_out/ after the GPU run) and derives `tolerance_met` from them
+CONFORMING_SEEDS = (3, 11, 29)
+_CASES = [(m, 3) for m in TEACHER_BARS] + [(m, sd_) for m in ("fp16c8", "fp16c8-9") for sd_ in CONFORMING_SEEDS[1:]]
 
 
 @pytest.mark.parametrize("S", [224, 448])
-@pytest.mark.parametrize("mode", list(TEACHER_BARS))
-def test_fused_teacher_vs_fp32_cpu_oracle(mode, S):
+@pytest.mark.parametrize("mode,seed", _CASES)
+def test_fused_teacher_vs_fp32_cpu_oracle(mode, seed, S):
     from cosa_amd.models import build_model
     from cosa_amd.train_step import default_args
     from cosa_amd.utils import seg_helper
-    sd, wimg, lab, box, cam_o, cam_aux_o, masks_o = _oracle_pass(S)
+    sd, wimg, lab, box, cam_o, cam_aux_o, masks_o = _oracle_pass(S, seed)
     args = default_args("VOC12", crop_size=S)
     net = build_model(args).cuda().eval()
     net.load_state_dict(sd)
@@ -413,8 +419,10 @@ def test_fused_teacher_vs_fp32_cpu_oracle(mode, S):
     for name, g, o, mg, mo in (("cam", cam, cam_o, masks[0], masks_o[0]), ("cam_aux", cam_aux, cam_aux_o, masks[1], masks_o[1])):
         rel = ((g.cpu() - o).abs().amax(dim=(2, 3)) / o.abs().amax(dim=(2, 3)).clamp_min(1e-6))[act].max().item()
         agree, iou = float(np.mean(mg == mo)), _miou(mg, mo)
-        lines.append(f"teacher {mode:8s} S={S} b=2 {name:8s}: normalised-CAM rel err {rel:.3e}  label agreement {agree:.5f}  mask mIoU {iou:.5f}")
-        assert rel <= bar_rel and agree >= bar_agree and iou >= bar_iou, lines[-1]
+        lines.append(f"teacher {mode:8s} S={S} b=2 seed={seed:<2d} {name:8s}: normalised-CAM rel err {rel:.3e}  label agreement {agree:.5f}  mask mIoU {iou:.5f}")
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", "r03_accuracy_teacher.txt"), "a") as f:
+    with open(os.path.join(ROOT, "gpurun_out", "r04_accuracy_teacher.txt"), "a") as f:          # (written before the asserts: a failing mode is on record too)
         f.write("\n".join(lines) + "\n")
+    for ln in lines:
+        rel, agree, iou = (float(ln.split(k)[1].split()[0]) for k in ("rel err", "label agreement", "mask mIoU"))
+        assert rel <= bar_rel and agree >= bar_agree and iou >= bar_iou, ln

@@ -14,6 +14,8 @@ operands are represented:
   h8w     only the weight-side correction
   h5      as h8 with e5m2 corrections and FIXED scales (1 for the hi copies, 2^11 for the lo parts): no statistics needed
   h4      as h8 with e2m1 (fp4) corrections and one shared exponent per 32 elements along k:  1.5 term-equivalents
+  h4i     the fp16c4 rows of round 4: e2m1 corrections; the 16 lo parts (x 2^11) and the 16 hi copies of the same 16 features form one
+          32-element MX block with one shared power-of-two scale:  1.5 term-equivalents
 
 usage: python tools/sim_precision_map.py S "name=site:scheme,site:scheme,...;name2=..."   (unlisted sites: default scheme `def:`)
 """
@@ -66,6 +68,26 @@ def q4_block(t):
     return y.reshape(*sh[:-1], K + pad)[..., :K]
 
 
+def q4_pair(p, q):
+    """e2m1 for BOTH tensors with one power-of-two scale per (16 elements of p, the same 16 elements of q) along the last dim: the MX block
+    of the fp16c4 rows (csrc/c4.hpp) holds the 16 lo' values and the 16 hi copies of the same 16 features.  Scale: the smallest power of
+    two s with amax / s <= 6 (no clamping); round to nearest even on the e2m1 grid."""
+    sh = p.shape
+    K = sh[-1]
+    pad = (-K) % 16
+    P = F.pad(p, (0, pad)).reshape(-1, 16)
+    Q = F.pad(q, (0, pad)).reshape(-1, 16)
+    m = torch.maximum(P.abs().amax(1, keepdim=True), Q.abs().amax(1, keepdim=True)).clamp_min(1e-30)
+    s = 2.0 ** torch.ceil(torch.log2(m / 6.0))
+
+    def rne(t):
+        a = (t / s).abs().clamp(max=6.0)
+        r = torch.where(a < 2.0, torch.round(a * 2) / 2, torch.where(a < 4.0, torch.round(a), torch.round(a / 2) * 2))
+        return torch.sign(t) * r * s
+    back = lambda t: t.reshape(*sh[:-1], K + pad)[..., :K]
+    return back(rne(P)), back(rne(Q))
+
+
 def split(t, dt):
     h = t.to(dt).float()
     return h, t - h
@@ -98,6 +120,10 @@ def prod(a, b, scheme):
         return y + mm(q8(al), q5(bh)) + mm(q5(ah), q8(bl))
     if scheme == "h4":
         return y + mm(q4_block(al), q4_block(bh)) + mm(q4_block(ah), q4_block(bl))
+    if scheme == "h4i":         # fp16c4: e2m1 corrections, lo' = lo * 2^11 and the hi copy of the same 16 features share one MX scale
+        al4, ah4 = q4_pair(al * 2048.0, ah)
+        bl4, bh4 = q4_pair(bl * 2048.0, bh)
+        return y + (mm(al4, bh4) + mm(ah4, bl4)) / 2048.0
     raise ValueError(scheme)
 
 
