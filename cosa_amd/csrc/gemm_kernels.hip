@@ -16,6 +16,7 @@
 #include "kernels.hpp"
 #include "op16.hpp"
 #include "c8.hpp"
+#include "c4.hpp"
 #include <cstdlib>
 
 #ifndef COSA_GEMM_EXPERIMENTS
@@ -110,6 +111,35 @@ __device__ __forceinline__ c8_i32x8 c8_cat(op16x8 lo, op16x8 hi)
 constexpr int kC8ScaleW = 0x7f7f7f7f;       // E8M0 2^0 in every byte (A operand: weight rows)
 constexpr int kC8ScaleX = 0x74747474;       // E8M0 2^-11 (B operand: token rows): both correction terms carry one lo8 factor = x 2^11
 #define COSA_MFMA_C8(a8, b8, c) __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8, b8, c, 1, 1, 0, kC8ScaleW, 0, kC8ScaleX)
+
+// ---- fp16c4 operands (c4.hpp): fp16 hi x fp16 hi on the 16-bit MFMA + BOTH correction terms as one stream of FP4 (e2m1) MX blocks ------
+// Row layout in 128-byte column tiles (Kp = K / 64, Kq = K / 128): hi [0, Kp) | c4 [Kp, Kp + Kq) | (unused) | aug 2 Kp.  K loop:
+//     tiles [0, Kp)              X hi  x W hi    (fp16 MFMA, 64 k per tile)
+//     tile   Kp                  X aug x W aug   (fp16: the bias)
+//     tiles (Kp, Kp + Kq]        X c4  x W c4    (e2m1 MFMA: a 128-byte row of a tile = 8 blocks of [16 lo' | 16 hi] (X) / [16 hi | 16 lo'] (W);
+//                                                 a lane's 16-byte fragment of k-step ks is block fq + 4 ks = the 32 values of ONE instruction)
+// Kp + 1 + Kq tiles of equal MFMA time (a 16x16x128 e2m1 MFMA takes the cycles of one 16x16x32 fp16 one): 1.58x the plain path at K = 768,
+// fp16c8 is 2.08x.  The E8M0 scale of every (row, block) comes from the operand's scale tensor through a small LDS ring (see the kernel).
+template <int OA, int OB>
+__device__ __forceinline__ f32x4 mfma_c4(c8_i32x8 a4, c8_i32x8 b4, f32x4 c, int sa, int sb)
+{
+    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a4, b4, c, 4, 4, OA, sa, OB, sb);
+}
+__device__ __forceinline__ c8_i32x8 c4_op(op16x8 v)
+{
+    const c8_i32x4 t = __builtin_bit_cast(c8_i32x4, v);
+    return (c8_i32x8){t[0], t[1], t[2], t[3], 0, 0, 0, 0};           // (the backend keeps only the four registers the fp4 format reads)
+}
+// maximum over the four lanes lane, lane ^ 16, lane ^ 32, lane ^ 48 of a non-negative float (VALU lane swaps, no LDS traffic)
+__device__ __forceinline__ float c4_max4(float v)
+{
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    const unsigned m = a[0] > a[1] ? a[0] : a[1];                     // (non-negative floats order like their bit patterns)
+    const auto b = __builtin_amdgcn_permlane32_swap(m, m, false, false);
+    return __builtin_bit_cast(float, b[0] > b[1] ? b[0] : b[1]);
+}
+constexpr int kC4ScaleLds = 16384;          // two 8-KB chunks (X and W scales of two c4 tiles each) behind the 128-KB operand ring
 
 template <int EPI, int SPLIT = 0>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const op16 *__restrict__ X, const op16 *__restrict__ W,
@@ -344,7 +374,8 @@ template <int EPI, int ABL6 = 0, int AUX = 0, int SPLIT = 0, int FR = 4>
 __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__restrict__ X, const op16 *__restrict__ W,
                                                              const op16 *__restrict__ bias, const float *__restrict__ R,
                                                              void *__restrict__ Yv, int M, int N, int K, int tiles_m, int tiles_n,
-                                                             int stagger_ticks, unsigned long long *__restrict__ stamps, int ld, int ldy, void *__restrict__ Y2v, int ntiles_run, int band)
+                                                             int stagger_ticks, unsigned long long *__restrict__ stamps, int ld, int ldy, void *__restrict__ Y2v, int ntiles_run, int band,
+                                                             const unsigned char *__restrict__ xsc, const unsigned char *__restrict__ wsc, unsigned char *__restrict__ ysc)
 {
     // optional device-side span of this launch (100 MHz wall clock; min start / max end over workgroups): HIP events cannot be
     // recorded inside a captured hipGraph on ROCm, so bench.py's roofline leg reads these (cosa_gemm_set_stamp_slot)
@@ -355,13 +386,18 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
     static_assert(FR == 4 || (FR == 3 && SPLIT == 0), "FR: 16-feature fragments per wave and W half (tile width 64 FR)");
     constexpr bool C8 = SPLIT == 3;                    // fp16c8 operands (see c8_tile_x / c8_tile_w); 16-bit GELU outputs leave as c8 rows
     constexpr bool C8OUT = C8 && EPI == EPI_GELU;
+    constexpr bool C4 = SPLIT == 4;                    // fp16c4 operands (c4.hpp); 16-bit GELU outputs leave as c4 rows + scale bytes
+    constexpr bool C4OUT = C4 && EPI == EPI_GELU;
+    constexpr bool CX = C8 || C4;                      // either: the bias rides in the augmentation tile, two loop bodies
+    static_assert(!C4 || FR == 4, "fp16c4: 256-wide jobs only (the scale tensors are laid out for them)");
     constexpr int TN = 64 * FR, HN = 32 * FR, WN = 16 * FR;     // features per tile / per W half / per wave inside a half
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wr = wave >> 2, wc = wave & 3;
     const int frow = lane & 15, fq = lane >> 4;
     const int Kp = K / BK;
-    const int nk = SPLIT == 1 ? 3 * Kp + 1 : (C8 ? 2 * Kp + 1 : Kp);
+    const int Kq = Kp >> 1;                            // fp16c4: c4 tiles per row
+    const int nk = SPLIT == 1 ? 3 * Kp + 1 : (C8 ? 2 * Kp + 1 : (C4 ? Kp + 1 + Kq : Kp));
     const int ntiles = tiles_m * tiles_n, G = gridDim.x;
     const int cq = ntiles >> 3, cr = ntiles & 7;
     unsigned char *Yb = static_cast<unsigned char *>(Yv);
@@ -410,6 +446,37 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
     };
     const __amdgpu_buffer_rsrc_t dead = __builtin_amdgcn_make_buffer_rsrc((void *)X, 0, 0, FL);   // every access out of range
 
+    // fp16c4: the E8M0 scale bytes of a job's blocks travel through a ring of two 8-KB chunks behind the operand ring; a chunk holds the X and
+    // the W scales of two consecutive c4 tiles (2 KB each, in the order the lanes read them: c4.hpp) and is ONE LDS-DMA instruction per wave
+    // (waves 0-3: the X half, 4-7: the W half), issued two tiles before its first use, in phase 1 IN FRONT of that phase's operand DMA -- so
+    // the counted vmcnt waits, which leave only what was issued after phase 1's operand DMA in flight, retire it without a changed count.
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);          // scalar copy: selects the chunk half's descriptor without a waterfall
+    __amdgpu_buffer_rsrc_t sXr = dead, sWr = dead, sYr = dead;
+    if (C4) {
+        sXr = __builtin_amdgcn_make_buffer_rsrc((void *)xsc, 0, tiles_m * Kq * 2048, FL);
+        sWr = __builtin_amdgcn_make_buffer_rsrc((void *)wsc, 0, tiles_n * Kq * 2048, FL);
+        if (C4OUT) sYr = __builtin_amdgcn_make_buffer_rsrc((void *)ysc, 0, tiles_m * (N >> 7) * 2048, FL);
+    }
+    const unsigned sc_rd_x = (unsigned)(((wc * 16 + frow) * 4 + fq) * 8), sc_rd_w = (unsigned)(4096 + ((wr * 16 + frow) * 4 + fq) * 16);
+    // c4 rows out (GELU epilogue): after the lane swaps a lane owns block j = wr 4 + (fq & 1) + 2 (fq >> 1) of the tile n0 / 128 + qa
+    const unsigned sc_wr_y = (unsigned)((((wc * 16 + frow) * 4 + (fq & 1) + 2 * (fq >> 1)) * 8) + wr);
+    u32x2 sxv = {0, 0};
+    u32x4 swv = {0, 0, 0, 0};
+#define V6_SCDMA(c)                                                                                                    \
+    do {                                                                                                               \
+        const int c_ = (c);                                                                                            \
+        const __amdgpu_buffer_rsrc_t rs_ = wave_u < 4 ? sXr : sWr;                                                     \
+        const int so_ = wave_u < 4 ? (((m0 >> 8) * Kq + 2 * c_) * 2048 + wave_u * 1024) : (((n0 >> 8) * Kq + 2 * c_) * 2048 + (wave_u - 4) * 1024); \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_, (lds_void *)(smem + kLdsBytesV5 + (c_ & 1) * 8192 + wave_u * 1024), 16, lane * 16, so_, 0, 0); \
+    } while (0)
+    // the lane's scales of c4 tile q: X: 8 bytes [qb][jj][ks], W: 16 bytes [qa][i][ks]
+#define V6_LDSC(q)                                                                                                     \
+    do {                                                                                                               \
+        const unsigned char *sb_ = smem + kLdsBytesV5 + (((q) >> 1) & 1) * 8192 + ((q) & 1) * 2048;                    \
+        sxv = *reinterpret_cast<const u32x2 *>(sb_ + sc_rd_x);                                                         \
+        swv = *reinterpret_cast<const u32x4 *>(sb_ + sc_rd_w);          /* (sc_rd_w includes the chunk's 4-KB X half) */  \
+    } while (0)
+
     // job-independent per-lane offsets: DMA source inside a 256-row operand panel (same for X and W when FR == 4) ...
     // FR == 3: a W half has 96 rows; the DMA slots of rows 96 .. 127 of a half get an out-of-range offset (nothing fetched, zeros land
     // in LDS rows that no fragment read touches), so that every wave still issues the same number of VMEM operations
@@ -455,7 +522,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
             __syncthreads();
         }
     }
-    int m0, n0, m1 = 0, n1 = 0, pn0 = 0;
+    int m0, n0, m1 = 0, n1 = 0, pn0 = 0, pm0 = 0;
     tile_of(o, m0, n0);
     bool has_next = o + G < ntiles_run;      // (ntiles_run <= ntiles: the jobs past it are left to a tail launch, cosa_gemm_bf16)
     if (has_next) tile_of(o + G, m1, n1);
@@ -474,7 +541,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
     u32x2 bb[2][4];
     const unsigned bias_lane = (unsigned)((wr * WN + 4 * fq) * 2);        // scalar base + 32-bit lane offset: no 64-bit per-lane pointer to keep alive
 #define V6_LOAD_BIAS(nbase)                                                                               \
-    if (!C8) _Pragma("unroll") for (int a_ = 0; a_ < 2; a_++) _Pragma("unroll") for (int i_ = 0; i_ < FR; i_++) {  \
+    if (!CX) _Pragma("unroll") for (int a_ = 0; a_ < 2; a_++) _Pragma("unroll") for (int i_ = 0; i_ < FR; i_++) {  \
         const op16 *p_ = bias + (nbase) + a_ * HN + i_ * 16;                                              \
         asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(bb[a_][i_]) : "v"(bias_lane), "s"(p_) : "memory"); \
     }
@@ -487,7 +554,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
         const __amdgpu_buffer_rsrc_t rs_ = ((which) & 1) ? (own_ ? cW : nW) : (own_ ? cX : nX);                        \
         const int t_ = own_ ? kt_ : kt_ - nk;                                                                          \
         const int so_ = (SPLIT == 1 ? (((which) & 1) ? split_tile_w(t_, Kp) : split_tile_x(t_, Kp))                       \
-                         : (C8 ? (((which) & 1) ? c8_tile_w(t_, Kp) : c8_tile_x(t_, Kp)) : t_)) * 128;                         \
+                         : (C8 ? (((which) & 1) ? c8_tile_w(t_, Kp) : c8_tile_x(t_, Kp)) : (C4 ? c8_tile_x(t_, Kp) : t_))) * 128;   \
         unsigned char *dst_ = smem + (bsel) * V5_BUF + (which) * V5_HALF + (2 * wave) * 1024;                          \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_, (lds_void *)dst_, 16, ((which) & 1) ? voW[(which) >> 1][0] : vo[(which) >> 1][0], so_, 0, 0);           \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_, (lds_void *)(dst_ + 1024), 16, ((which) & 1) ? voW[(which) >> 1][1] : vo[(which) >> 1][1], so_, 0, 0);  \
@@ -545,8 +612,8 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
             asm volatile("" ::"v"(acc[(qa) * 4 + i_][(qb) * 2 + j_]));                                              \
     } else if (RES) {                                                                                               \
         _Pragma("unroll") for (int ii = 0; ii < FR; ii++) {                                                         \
-            const unsigned lo_ = C8 ? 0u : bb[qa][ii][0], hi_ = C8 ? 0u : bb[qa][ii][1];                            \
-            const f32x4 bv_ = C8 ? (f32x4){0.f, 0.f, 0.f, 0.f} : (f32x4){op16_lo(lo_), op16_hi(lo_), op16_lo(hi_), op16_hi(hi_)};  \
+            const unsigned lo_ = CX ? 0u : bb[qa][ii][0], hi_ = CX ? 0u : bb[qa][ii][1];                            \
+            const f32x4 bv_ = CX ? (f32x4){0.f, 0.f, 0.f, 0.f} : (f32x4){op16_lo(lo_), op16_hi(lo_), op16_lo(hi_), op16_hi(hi_)};  \
             _Pragma("unroll") for (int jj = 0; jj < 2; jj++) {                                                      \
                 const f32x4 o4_ = acc[(qa) * 4 + ii][(qb) * 2 + jj] + bv_;                                          \
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o4_), rsY,                         \
@@ -555,6 +622,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
         }                                                                                                           \
     } else {                                                                                                        \
     unsigned c8l_[2][2], c8h_[2][2];      /* c8 rows out: the 8-bit planes of both fragment pairs, stored together */  \
+    unsigned c4d_[2][2]; int c4e_[2][2];  /* c4 rows out: packed (lo' x 4 | hi x 4) nibbles and block exponents of both fragment pairs */ \
     _Pragma("unroll") for (int jj = 0; jj < 2; jj++) _Pragma("unroll") for (int pr = 0; pr < 2; pr++) {             \
         if (FR == 3 && pr == 1) {         /* the unpaired third fragment */                                         \
             f32x4 v2_ = acc[(qa) * 4 + 2][(qb) * 2 + jj];                                                           \
@@ -618,12 +686,60 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
                 __builtin_amdgcn_raw_buffer_store_b128((u32x4){g0_[0], g1_[0], g0_[1], g1_[1]}, rsY, v16_, 3 * N - jn0_ + (qa) * HN, AUX); \
             }                                                                                                       \
         }                                                                                                           \
+        if (C4OUT) {       /* c4 rows: the 16 features 16 i + 4 fq + r (fq = 0..3) of fragment i of one token are ONE block, spread over the four   \
+                              lanes frow + 16 fq: their maximum meets by lane swaps, every lane converts its four values with the shared scale  \
+                              into 16 + 16 bits, and the c8 path's swap network then hands a lane the four dwords of one whole block */          \
+            const float hA_[4] = {(float)p0_[0], (float)p0_[1], (float)p1_[0], (float)p1_[1]};                      \
+            const float hB_[4] = {(float)p2_[0], (float)p2_[1], (float)p3_[0], (float)p3_[1]};                      \
+            float lA_[4], lB_[4], mA_ = 0.f, mB_ = 0.f;                                                              \
+            _Pragma("unroll") for (int r = 0; r < 4; r++) {                                                         \
+                lA_[r] = (v0_[r] - hA_[r]) * kC4LoScale;                                                            \
+                lB_[r] = (v1_[r] - hB_[r]) * kC4LoScale;                                                            \
+                mA_ = __builtin_fmaxf(mA_, __builtin_fmaxf(__builtin_fabsf(hA_[r]), __builtin_fabsf(lA_[r])));      \
+                mB_ = __builtin_fmaxf(mB_, __builtin_fmaxf(__builtin_fabsf(hB_[r]), __builtin_fabsf(lB_[r])));      \
+            }                                                                                                       \
+            const int eA_ = c4_block_exp(c4_max4(mA_)), eB_ = c4_block_exp(c4_max4(mB_));                           \
+            const float sA_ = c4_pow2(eA_), sB_ = c4_pow2(eB_);                                                     \
+            unsigned dA_ = 0, dB_ = 0;                                                                              \
+            dA_ = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(dA_, lA_[0], lA_[1], sA_, 0);                            \
+            dA_ = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(dA_, lA_[2], lA_[3], sA_, 1);                            \
+            dA_ = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(dA_, hA_[0], hA_[1], sA_, 2);                            \
+            dA_ = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(dA_, hA_[2], hA_[3], sA_, 3);                            \
+            dB_ = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(dB_, lB_[0], lB_[1], sB_, 0);                            \
+            dB_ = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(dB_, lB_[2], lB_[3], sB_, 1);                            \
+            dB_ = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(dB_, hB_[0], hB_[1], sB_, 2);                            \
+            dB_ = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(dB_, hB_[2], hB_[3], sB_, 3);                            \
+            const auto td_ = __builtin_amdgcn_permlane16_swap(dA_, dB_, false, false);                              \
+            c4d_[pr][0] = td_[0]; c4d_[pr][1] = td_[1]; c4e_[pr][0] = eA_; c4e_[pr][1] = eB_;                       \
+            if (pr == 1) {      /* lanes fq = 0 / 1: block A / B of pair 0, fq = 2 / 3: block A / B of pair 1 (as the c8 stores above) */   \
+                const auto x0_ = __builtin_amdgcn_permlane32_swap(c4d_[0][0], c4d_[1][0], false, false);            \
+                const auto x1_ = __builtin_amdgcn_permlane32_swap(c4d_[0][1], c4d_[1][1], false, false);            \
+                const unsigned g0_ = x0_[0], g1_ = x1_[0], g2_ = x0_[1], g3_ = x1_[1];      /* features 0-3, 4-7, 8-11, 12-15 of the block */ \
+                const u32x4 blk_ = {(g0_ & 0xffffu) | (g1_ << 16), (g2_ & 0xffffu) | (g3_ << 16),                    \
+                                    (g0_ >> 16) | (g1_ & 0xffff0000u), (g2_ >> 16) | (g3_ & 0xffff0000u)};          \
+                const int jn0_ = (&rsY == &pY) ? pn0 : n0, jm0_ = (&rsY == &pY) ? pm0 : m0;                         \
+                __builtin_amdgcn_raw_buffer_store_b128(blk_, rsY, voY[(qb) * 2 + jj] + fo16m, 2 * N - jn0_ + (qa) * HN, AUX); \
+                const int el_ = fq == 0 ? c4e_[0][0] : (fq == 1 ? c4e_[0][1] : (fq == 2 ? c4e_[1][0] : c4e_[1][1])); \
+                __builtin_amdgcn_raw_buffer_store_b8((unsigned char)c4_scale_byte(el_, 0), sYr, sc_wr_y + ((qb) * 2 + jj) * 2, \
+                                                     (((jm0_ >> 8) * (N >> 7) + (jn0_ >> 7) + (qa)) << 11), AUX);   \
+            }                                                                                                       \
+        }                                                                                                           \
     }                                                                                                               \
     }
     // 16 MFMAs of quadrant (qa, qb); FIRST: the accumulation starts from the bias
+#define V6_C4ROW(qa, xf, qb, i, ks)                                                                                 \
+    do {                                                                                                            \
+        const c8_i32x8 a4_ = c4_op(a[i][ks]);                                                                       \
+        const int sa_ = (int)swv[(qa) * 2 + ((i) >> 1)], sb_ = (int)sxv[qb];                                        \
+        acc[(qa) * 4 + (i)][(qb) * 2] = mfma_c4<((i) & 1) * 2 + (ks), (ks)>(a4_, c4_op(xf[0][ks]), acc[(qa) * 4 + (i)][(qb) * 2], sa_, sb_);             \
+        acc[(qa) * 4 + (i)][(qb) * 2 + 1] = mfma_c4<((i) & 1) * 2 + (ks), 2 + (ks)>(a4_, c4_op(xf[1][ks]), acc[(qa) * 4 + (i)][(qb) * 2 + 1], sa_, sb_); \
+    } while (0)
 #define V6_MMA(qa, xf, qb, FIRST, F8)                                                                               \
     do {                                                                                                            \
-        if (F8) {      /* one 16x16x128 e5m2 MFMA per accumulator: the two 16-byte fragments of a row side by side */ \
+        if ((F8) == 2) {      /* fp16c4: two 16x16x128 e2m1 MFMAs per accumulator (k-steps = blocks fq, fq + 4), scale bytes picked by op_sel */ \
+            V6_C4ROW(qa, xf, qb, 0, 0); V6_C4ROW(qa, xf, qb, 1, 0); V6_C4ROW(qa, xf, qb, 2, 0); V6_C4ROW(qa, xf, qb, 3, 0);  \
+            V6_C4ROW(qa, xf, qb, 0, 1); V6_C4ROW(qa, xf, qb, 1, 1); V6_C4ROW(qa, xf, qb, 2, 1); V6_C4ROW(qa, xf, qb, 3, 1);  \
+        } else if (F8) {      /* one 16x16x128 e5m2 MFMA per accumulator: the two 16-byte fragments of a row side by side */ \
             _Pragma("unroll") for (int i = 0; i < FR; i++) {                                                        \
                 const c8_i32x8 a8_ = c8_cat(a[i][0], a[i][1]);                                                      \
                 _Pragma("unroll") for (int j = 0; j < 2; j++)                                                       \
@@ -634,7 +750,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
             _Pragma("unroll") for (int i = 0; i < FR; i++) {                                                        \
                 f32x4 cb_;                                                                                          \
                 if ((FIRST) && ks == 0 && !RES) {                                                                   \
-                    const unsigned lo_ = C8 ? 0u : bb[qa][i][0], hi_ = C8 ? 0u : bb[qa][i][1];      /* c8: the bias rides in the aug tile */ \
+                    const unsigned lo_ = CX ? 0u : bb[qa][i][0], hi_ = CX ? 0u : bb[qa][i][1];      /* c8 / c4: the bias rides in the aug tile */ \
                     cb_[0] = op16_lo(lo_);                                                                          \
                     cb_[1] = op16_hi(lo_);                                                                          \
                     cb_[2] = op16_lo(hi_);                                                                          \
@@ -665,11 +781,17 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
     do {                                                                                                            \
         const int b_ = g & 1;                                                                                       \
         /* ---- phase 1 ---- */                                                                                     \
+        if ((F8) == 2) { V6_LDSC((t) - Kp - 1); V5_FENCE(); }                                                       \
         V6_LDX(x0, 0, b_);                                                                                          \
         V5_FENCE();                                                                                                 \
         V6_LDW(0, b_);                                                                                              \
         if (!RES && (LAST) && has_next) { V6_LOAD_BIAS(n1); }                                                       \
         V5_FENCE();                                                                                                 \
+        if (C4 && !(FIRST) && !(LAST)) {     /* scale chunk c (c4 tiles 2c, 2c + 1) leaves two tiles ahead of its first use */ \
+            const int d_ = (t) - (Kp - 1);                                                                          \
+            if (d_ >= 0 && !(d_ & 1) && (d_ >> 1) < (Kq >> 1)) V6_SCDMA(d_ >> 1);                                   \
+            V5_FENCE();                                                                                             \
+        }                                                                                                           \
         V6_STAGE(3, (t) + 1, b_ ^ 1);                                                                               \
         V5_FENCE();                                                                                                 \
         asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");                                                          \
@@ -707,7 +829,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
         V6_STAGE(2, (t) + 2, b_);                                                                                   \
         V5_FENCE();                                                                                                 \
         if ((LAST) && RES) { if (FR == 4) V6_WAIT(38); else V6_WAIT(30); }                                          \
-        else if ((LAST) && C8OUT) V6_WAIT(22);      /* 6 DMA + 2 x (4 + 4) stores */                                         \
+        else if ((LAST) && (C8OUT || C4OUT)) V6_WAIT(22);      /* 6 DMA + 2 x (4 + 4) stores (c4: 4 fp16 + 2 block + 2 scale-byte stores) */ \
         else if (LAST) V6_WAIT(14);                                                                                 \
         else V6_WAIT(6);                                                                                            \
         V6_MSECTION_BEGIN();                                                                                        \
@@ -727,6 +849,11 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
             for (int t = 1; t <= Kp; t++) V6_TILE(t, 0, 0, 0);
             for (int t = Kp + 1; t < nk - 1; t++) V6_TILE(t, 0, 0, 1);
             V6_TILE(nk - 1, 0, 1, 1);
+        } else if (C4) {  // Kp + 1 fp16 tiles, then Kq e2m1 tiles
+            V6_TILE(0, 1, 0, 0);
+            for (int t = 1; t <= Kp; t++) V6_TILE(t, 0, 0, 0);
+            for (int t = Kp + 1; t < nk - 1; t++) V6_TILE(t, 0, 0, 2);
+            V6_TILE(nk - 1, 0, 1, 2);
         } else {
             V6_TILE(0, 1, 0, 0);
             for (int t = 1; t < nk - 1; t++) V6_TILE(t, 0, 0, 0);
@@ -735,6 +862,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
         if (!has_next) break;
         // next job becomes the running one
         pn0 = n0;
+        pm0 = m0;
         pY = cY;
         pY2 = cY2;
         have_prev = true;
@@ -769,6 +897,9 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
 #undef V6_LDX
 #undef V6_EPI
 #undef V6_MMA
+#undef V6_C4ROW
+#undef V6_SCDMA
+#undef V6_LDSC
 #undef V6_MSECTION_BEGIN
 #undef V6_MSECTION_END
 #undef V6_TILE
@@ -1226,6 +1357,7 @@ using namespace cosa;
 #define cosa_conv3x3_dilated_nhwc cosa_conv3x3_dilated_nhwc_f16
 #endif
 
+static size_t cosa_c4_scale_bytes_(int rows, int K) { return (size_t)((rows + 255) / 256) * (size_t)(K / 128) * 2048; }
 static unsigned long long *g_gemm_stamp_slot = nullptr;
 extern "C" void cosa_gemm_set_stamp_slot(void *slot) { g_gemm_stamp_slot = static_cast<unsigned long long *>(slot); }
 
@@ -1250,11 +1382,13 @@ extern "C" void cosa_gemm_set_grid_policy(int balanced) { g_gemm_balanced_grid =
 
 template <int EPI, int ABL6 = 0, int AUX = 0, int SPLIT = 0, int FR = 4>
 static int launch_v6(const op16 *x, const op16 *w, const op16 *b, const float *residual, void *Y, int M, int N, int K, hipStream_t st,
-                     int ld = 0, int ldy = 0, void *Y2 = nullptr)
+                     int ld = 0, int ldy = 0, void *Y2 = nullptr, const unsigned char *xsc = nullptr, const unsigned char *wsc = nullptr,
+                     unsigned char *ysc = nullptr)
 {
+    constexpr size_t lds_bytes = kLdsBytesV5 + (SPLIT == 4 ? kC4ScaleLds : 0);      // fp16c4: + the scale ring
     static bool attr_done = false;
     if (!attr_done) {
-        COSA_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_bf16_v6_kernel<EPI, ABL6, AUX, SPLIT, FR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytesV5));
+        COSA_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_bf16_v6_kernel<EPI, ABL6, AUX, SPLIT, FR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         attr_done = true;
     }
     const int tiles_m = (M + 255) / 256, tiles_n = N / (64 * FR);
@@ -1299,8 +1433,8 @@ static int launch_v6(const op16 *x, const op16 *w, const op16 *b, const float *r
         grid_b = ((run + rounds - 1) / rounds + 7) / 8 * 8;
         grid_b = grid_b > 256 ? 256 : grid_b;
     }
-    hipLaunchKernelGGL((gemm_bf16_v6_kernel<EPI, ABL6, AUX, SPLIT, FR>), dim3(grid_b), dim3(512), kLdsBytesV5, st, x, w, b, residual, Y, M, N, K, tiles_m, tiles_n, stagger,
-                       g_gemm_stamp_slot, ld ? ld : K, ldy ? ldy : N, Y2, run, band);
+    hipLaunchKernelGGL((gemm_bf16_v6_kernel<EPI, ABL6, AUX, SPLIT, FR>), dim3(grid_b), dim3(512), lds_bytes, st, x, w, b, residual, Y, M, N, K, tiles_m, tiles_n, stagger,
+                       g_gemm_stamp_slot, ld ? ld : K, ldy ? ldy : N, Y2, run, band, xsc, wsc, ysc);
     g_gemm_stamp_slot = nullptr;                            // one-shot
     COSA_LAUNCH_CHECK();
     if (run < ntiles) {
@@ -1466,6 +1600,35 @@ extern "C" int cosa_gemm_f16c8(const void *Xs, const void *Ws, const void *zeros
     if (epilogue == EPI_BIAS) return launch_v6<EPI_BIAS, 0, 0, 3>(x, w, b, residual, Y, M, N, K, st, ld, ldy);
     if (epilogue == EPI_GELU) return launch_v6<EPI_GELU, 0, 0, 3>(x, w, b, residual, Y, M, N, K, st, ld, ldy);
     return launch_v6<EPI_RESIDUAL, 0, 0, 3>(x, w, b, residual, Y, M, N, K, st, ld, ldy);
+}
+#endif
+
+#if COSA_OP_F16
+// Y = X W^T (+ bias, carried by the augmentation block) with fp16c4 operands (c4.hpp): rows as for cosa_gemm_f16c8 (same stride; the 8-bit
+// planes replaced by the c4 blocks) plus the operands' scale tensors (cosa_c4_scale_bytes; activation / weight layouts).
+//   epilogue 0: Y fp16 [M, ldy >= N];  1: GELU, Y = c4 rows [M, ldy = 2N + 64 fp16 units] + Yscales (activation layout, for the next GEMM;
+//   the augmentation block is the consumer's to set);  2: Y fp32 [M, N] = residual + .
+extern "C" int cosa_gemm_f16c4(const void *Xs, const void *Xscales, const void *Ws, const void *Wscales, const void *zeros, const float *residual,
+                               void *Y, void *Yscales, int M, int N, int K, int epilogue, int ldy, void *stream)
+{
+    struct ClearSlot { ~ClearSlot() { g_gemm_stamp_slot = nullptr; } } clear_slot_;
+    COSA_REQUIRE(Xs && Xscales && Ws && Wscales && zeros && Y, "cosa_gemm_f16c4: null pointer");
+    COSA_REQUIRE(M > 0 && N > 0 && K >= 256 && N % 256 == 0 && K % 256 == 0, "cosa_gemm_f16c4: N %% 256 == 0 and K %% 256 == 0 required (got M=%d N=%d K=%d)", M, N, K);
+    COSA_REQUIRE(epilogue >= 0 && epilogue <= 2, "cosa_gemm_f16c4: unknown epilogue");
+    COSA_REQUIRE(epilogue != EPI_RESIDUAL || residual, "cosa_gemm_f16c4: residual epilogue needs the residual pointer");
+    COSA_REQUIRE(epilogue != EPI_GELU || Yscales, "cosa_gemm_f16c4: the GELU epilogue writes c4 rows and needs their scale tensor");
+    COSA_REQUIRE(epilogue == EPI_RESIDUAL ? ldy == N : (epilogue == EPI_GELU ? ldy == 2 * N + 64 : (ldy >= N && ldy % 8 == 0)),
+                 "cosa_gemm_f16c4: ldy must be N (fp32 out), 2N + 64 (c4 rows out) or >= N (fp16 out)");
+    const int ld = 2 * K + 64;
+    COSA_REQUIRE((size_t)256 * ld * 2 < 0x7fffffffull && (size_t)N * ld * 2 < 0x7fffffffull && (size_t)256 * ldy * 4 < 0x7fffffffull, "cosa_gemm_f16c4: panel beyond 2 GiB");
+    COSA_REQUIRE(cosa_c4_scale_bytes_(M, K) < 0x7fffffffull && cosa_c4_scale_bytes_(M, N) < 0x7fffffffull, "cosa_gemm_f16c4: scale tensor beyond 2 GiB");
+    hipStream_t st = as_stream(stream);
+    const op16 *x = static_cast<const op16 *>(Xs), *w = static_cast<const op16 *>(Ws), *b = static_cast<const op16 *>(zeros);
+    const unsigned char *xs = static_cast<const unsigned char *>(Xscales), *ws = static_cast<const unsigned char *>(Wscales);
+    unsigned char *ys = static_cast<unsigned char *>(Yscales);
+    if (epilogue == EPI_BIAS) return launch_v6<EPI_BIAS, 0, 0, 4>(x, w, b, residual, Y, M, N, K, st, ld, ldy, nullptr, xs, ws, ys);
+    if (epilogue == EPI_GELU) return launch_v6<EPI_GELU, 0, 0, 4>(x, w, b, residual, Y, M, N, K, st, ld, ldy, nullptr, xs, ws, ys);
+    return launch_v6<EPI_RESIDUAL, 0, 0, 4>(x, w, b, residual, Y, M, N, K, st, ld, ldy, nullptr, xs, ws, ys);
 }
 #endif
 

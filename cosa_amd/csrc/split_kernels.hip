@@ -11,6 +11,7 @@
 //   cosa_layernorm_split   nn.LayerNorm(768, eps) over the fp32 residual stream with fp32 gamma / beta -> split rows (and/or fp32)
 #include "kernels.hpp"
 #include "c8.hpp"
+#include "c4.hpp"
 
 namespace cosa {
 namespace {
@@ -219,10 +220,186 @@ __global__ __launch_bounds__(256) void layernorm_c8_kernel(const float *__restri
     if (yr) c8_store_aug(yr, D, lane, true, nullptr);
 }
 
+// ---- fp16c4 rows (c4.hpp): [hi fp16 (2K bytes) | c4 blocks (K) | unused (K) | aug fp16 (128)] + a scale tensor ---------------------------
+// one 16-feature block per lane and trip: 64 contiguous source bytes in, 32 bytes of fp16 + one 16-byte block + one scale byte out
+__device__ __forceinline__ void c4_store_block(unsigned char *row, unsigned char *scales, int K, int r, int b, const float (&v)[16], bool weight)
+{
+    f16 hi[16];
+    unsigned blk[4];
+    int e;
+    c4_block16(v, hi, blk, e, weight);
+    f16x8 h0, h1;
+#pragma unroll
+    for (int j = 0; j < 8; j++) { h0[j] = hi[j]; h1[j] = hi[8 + j]; }
+    *reinterpret_cast<f16x8 *>(row + 32 * b) = h0;
+    *reinterpret_cast<f16x8 *>(row + 32 * b + 16) = h1;
+    *reinterpret_cast<uint4 *>(row + 2 * K + 16 * b) = make_uint4(blk[0], blk[1], blk[2], blk[3]);
+    const int Kq = K >> 7;
+    scales[weight ? c4_scale_off_w(r, b >> 3, b & 7, Kq) : c4_scale_off_x(r, b >> 3, b & 7, Kq)] =
+        (unsigned char)c4_scale_byte(e, weight ? kC4WeightExpBias : 0);
+}
+
+__device__ __forceinline__ void c4_row_from_f32(const float *s, unsigned char *d, unsigned char *scales, int K, int r, int lane, bool weight)
+{
+    for (int b = lane; b < (K >> 4); b += 64) {
+        float v[16];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const float4 f = *reinterpret_cast<const float4 *>(s + 16 * b + 4 * c);
+            v[4 * c] = f.x; v[4 * c + 1] = f.y; v[4 * c + 2] = f.z; v[4 * c + 3] = f.w;
+        }
+        c4_store_block(d, scales, K, r, b, v, weight);
+    }
+}
+
+// one wave per row; K % 256 == 0
+__global__ __launch_bounds__(256) void c4_rows_kernel(const float *__restrict__ src, const float *__restrict__ bias, unsigned char *__restrict__ dst,
+                                                     unsigned char *__restrict__ scales, int R, int K, long long src_ld, int ones, int weight)
+{
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= R) return;
+    const int lane = threadIdx.x & 63;
+    unsigned char *d = dst + (size_t)row * (4 * K + 128);
+    c4_row_from_f32(src + (size_t)row * src_ld, d, scales, K, row, lane, weight != 0);
+    c8_store_aug(d, K, lane, ones != 0, bias ? bias + row : nullptr);
+}
+
+struct C4Rec {
+    const float *src;
+    const float *bias;
+    unsigned char *dst;
+    unsigned char *scales;
+    int rows, K, row0, pad;
+};
+
+// the weight matrices of a network in one launch (weight block order, 2^-11 in the scale bytes, bias in the augmentation block)
+__global__ __launch_bounds__(256) void c4_rows_batched_kernel(const C4Rec *__restrict__ recs, int nrec, int total_rows)
+{
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= total_rows) return;
+    const int lane = threadIdx.x & 63;
+    int r = 0;
+    while (r + 1 < nrec && recs[r + 1].row0 <= row) r++;
+    const C4Rec rec = recs[r];
+    const int lr = row - rec.row0, K = rec.K;
+    unsigned char *d = rec.dst + (size_t)lr * (4 * K + 128);
+    c4_row_from_f32(rec.src + (size_t)lr * K, d, rec.scales, K, lr, lane, true);
+    c8_store_aug(d, K, lane, false, rec.bias ? rec.bias + lr : nullptr);
+}
+
+// LayerNorm(768) over the fp32 stream -> c4 rows (activation block order).  The row sits in registers as float4 (lane + 64 i): a 16-feature
+// block is the float4s of four consecutive lanes, so the block's amax meets in the quad by two DPP quad permutes, each lane converts its own
+// four values with the shared scale and stores 8 bytes of fp16, 2 + 2 bytes of the block and (lane 0 of the quad) the scale byte.
+template <int D>
+__global__ __launch_bounds__(256) void layernorm_c4_kernel(const float *__restrict__ x, const float *__restrict__ g, const float *__restrict__ b,
+                                                          unsigned char *__restrict__ y, unsigned char *__restrict__ scales,
+                                                          float *__restrict__ y32, int rows, float eps)
+{
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    constexpr int PER = D / 64 / 4;
+    constexpr int Kq = D / 128;
+    const float4 *xr = reinterpret_cast<const float4 *>(x + (size_t)row * D);
+    float4 v[PER];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < PER; i++) { v[i] = xr[lane + 64 * i]; s += v[i].x + v[i].y + v[i].z + v[i].w; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float mean = s * (1.0f / D);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+        const float a = v[i].x - mean, c = v[i].y - mean, d = v[i].z - mean, e = v[i].w - mean;
+        q += a * a + c * c + d * d + e * e;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+    const float rstd = rsqrtf(q * (1.0f / D) + eps);
+    unsigned char *yr = y ? y + (size_t)row * (4 * D + 128) : nullptr;
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+        const int c0 = (lane + 64 * i) * 4;
+        const float4 gg = *reinterpret_cast<const float4 *>(g + c0), bb = *reinterpret_cast<const float4 *>(b + c0);
+        const float o[4] = {(v[i].x - mean) * rstd * gg.x + bb.x, (v[i].y - mean) * rstd * gg.y + bb.y,
+                            (v[i].z - mean) * rstd * gg.z + bb.z, (v[i].w - mean) * rstd * gg.w + bb.w};
+        if (y32) *reinterpret_cast<float4 *>(y32 + (size_t)row * D + c0) = make_float4(o[0], o[1], o[2], o[3]);
+        if (!yr) continue;
+        f16 hi[4];
+        float h[4], l[4];
+        float amax = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            hi[j] = (f16)o[j];
+            h[j] = (float)hi[j];
+            l[j] = (o[j] - h[j]) * kC4LoScale;
+            amax = __builtin_fmaxf(amax, __builtin_fmaxf(__builtin_fabsf(h[j]), __builtin_fabsf(l[j])));
+        }
+        // quad maximum: lanes 4k .. 4k+3 hold the block's 16 features
+        int ai = __builtin_bit_cast(int, amax);          // (non-negative floats order like their bit patterns)
+        int t = __builtin_amdgcn_update_dpp(0, ai, 0xB1, 0xf, 0xf, false);      // quad_perm [1,0,3,2]
+        ai = ai > t ? ai : t;
+        t = __builtin_amdgcn_update_dpp(0, ai, 0x4E, 0xf, 0xf, false);          // quad_perm [2,3,0,1]
+        ai = ai > t ? ai : t;
+        const int e = c4_block_exp(__builtin_bit_cast(float, ai));
+        const float sc = c4_pow2(e);
+        unsigned pl = 0, ph = 0;
+        pl = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(pl, l[0], l[1], sc, 0);
+        pl = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(pl, l[2], l[3], sc, 1);
+        ph = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(ph, h[0], h[1], sc, 0);
+        ph = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(ph, h[2], h[3], sc, 1);
+        *reinterpret_cast<f16x4 *>(yr + 2 * c0) = (f16x4){hi[0], hi[1], hi[2], hi[3]};
+        const int blk = c0 >> 4, sub = lane & 3;                                 // block index in the row, the lane's place in its quad
+        unsigned char *bp = yr + 2 * D + 16 * blk;
+        *reinterpret_cast<unsigned short *>(bp + 2 * sub) = (unsigned short)pl;          // lo' half: bytes [0, 8)
+        *reinterpret_cast<unsigned short *>(bp + 8 + 2 * sub) = (unsigned short)ph;      // hi half:  bytes [8, 16)
+        if (sub == 0) scales[c4_scale_off_x(row, blk >> 3, blk & 7, Kq)] = (unsigned char)c4_scale_byte(e, 0);
+    }
+    if (yr) c8_store_aug(yr, D, lane, true, nullptr);
+}
+
 }  // namespace
 }  // namespace cosa
 
 using namespace cosa;
+
+// ---- fp16c4 producers (c4.hpp; include/cosa_hip.h) ---------------------------------------------------------------------------------
+extern "C" size_t cosa_c4_scale_bytes(int rows, int K) { return rows > 0 && K > 0 ? (size_t)((rows + 255) / 256) * (size_t)(K / 128) * 2048 : 0; }
+
+extern "C" int cosa_c4_rows(const float *src, const float *bias, void *dst, void *scales, int R, int K, long long src_ld, int ones, int weight,
+                            void *stream)
+{
+    COSA_REQUIRE(src && dst && scales && R > 0 && K > 0 && K % 256 == 0 && src_ld >= K && src_ld % 4 == 0, "cosa_c4_rows: bad arguments (K %% 256 == 0)");
+    hipLaunchKernelGGL(c4_rows_kernel, dim3((R + 3) / 4), dim3(256), 0, as_stream(stream), src, bias, static_cast<unsigned char *>(dst),
+                       static_cast<unsigned char *>(scales), R, K, src_ld, ones, weight);
+    COSA_LAUNCH_CHECK();
+    return COSA_OK;
+}
+
+extern "C" size_t cosa_c4_record_bytes(void) { return sizeof(C4Rec); }
+
+/* c4 WEIGHT rows of several fp32 matrices (each [rows, K] contiguous, rows % 256 == 0, K % 256 == 0, optional bias [rows]) in one launch.
+ * records: device array of { const float *src; const float *bias; void *dst; void *scales; int rows, K, row0, pad } */
+extern "C" int cosa_c4_rows_batched(const void *records, int n_records, int total_rows, void *stream)
+{
+    COSA_REQUIRE(records && n_records > 0 && total_rows > 0, "cosa_c4_rows_batched: bad arguments");
+    hipLaunchKernelGGL(c4_rows_batched_kernel, dim3((total_rows + 3) / 4), dim3(256), 0, as_stream(stream), static_cast<const C4Rec *>(records),
+                       n_records, total_rows);
+    COSA_LAUNCH_CHECK();
+    return COSA_OK;
+}
+
+extern "C" int cosa_layernorm_c4(const float *x, const float *gamma, const float *beta, void *y_c4, void *y_scales, float *y_f32, int rows, int dim,
+                                 float eps, void *stream)
+{
+    COSA_REQUIRE(x && gamma && beta && (y_c4 || y_f32) && (!y_c4 || y_scales) && rows > 0, "cosa_layernorm_c4: bad arguments");
+    COSA_REQUIRE(dim == 768, "cosa_layernorm_c4: dim must be 768 (ViT-B)");
+    hipLaunchKernelGGL(layernorm_c4_kernel<768>, dim3((rows + 3) / 4), dim3(256), 0, as_stream(stream), x, gamma, beta,
+                       static_cast<unsigned char *>(y_c4), static_cast<unsigned char *>(y_scales), y_f32, rows, eps);
+    COSA_LAUNCH_CHECK();
+    return COSA_OK;
+}
 
 extern "C" int cosa_split_rows(const float *src, const float *bias, void *dst, int R, int K, long long src_ld, int ones, void *stream)
 {
