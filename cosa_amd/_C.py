@@ -126,6 +126,13 @@ _SIGS.update({
     "cosa_layernorm_c8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     "cosa_gemm_f16c8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "cosa_attn_fwd_f16c8": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
+    "cosa_c4_scale_bytes": (c_size_t, [c_int, c_int]),
+    "cosa_c4_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, ctypes.c_longlong, c_int, c_int, c_void_p]),
+    "cosa_c4_record_bytes": (c_size_t, []),
+    "cosa_c4_rows_batched": (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    "cosa_layernorm_c4": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
+    "cosa_gemm_f16c4": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                c_int, c_void_p]),
 })
 
 # the fp16-operand builds of the GEMM / attention translation units export the same signatures under *_f16 names

@@ -93,12 +93,13 @@ class VITNetwork(nn.Module):
 
     def set_nograd_precision(self, mode):
         """operand precision of the no-grad passes (teacher pseudo-labels, evaluation): "bf16" (8 significant bits), "fp16" (11; the
-        same kernels built for fp16 operands), "bf16x3" (16; hi + lo bf16 halves, three MFMA terms) or "fp16c8" (fp16 + 8-bit correction
-        terms on the block-scaled MFMA, ~14 bits at twice the 16-bit work; attention operands plain fp16): DESIGN.md section 3"""
+        same kernels built for fp16 operands), "bf16x3" (16; hi + lo bf16 halves, three MFMA terms), "fp16c8" (fp16 + 8-bit correction
+        terms on the block-scaled MFMA, ~14 bits at twice the 16-bit work; attention operands plain fp16) or "fp16c4" (the same with FP4 MX-block
+        correction terms at 4x the fp16 rate: ~1.6x the 16-bit work); "-n" suffix: blocks from index n on plain fp16: DESIGN.md section 3"""
         base, _, tail = mode.partition("-")              # "fp16c8-9": fp16c8 with the blocks from index 9 on plain fp16 operands
-        assert base in ("bf16", "fp16", "bf16x3", "fp16c8") and (not tail or (base == "fp16c8" and tail.isdigit())), mode
-        self.set_compute_dtype(torch.float16 if base in ("fp16", "fp16c8") else torch.bfloat16)
-        self.encoder.precision = base if base in ("bf16x3", "fp16c8") else None
+        assert base in ("bf16", "fp16", "bf16x3", "fp16c8", "fp16c4") and (not tail or (base in ("fp16c8", "fp16c4") and tail.isdigit())), mode
+        self.set_compute_dtype(torch.float16 if base in ("fp16", "fp16c8", "fp16c4") else torch.bfloat16)
+        self.encoder.precision = base if base in ("bf16x3", "fp16c8", "fp16c4") else None
         self.encoder.c8_plain_from = int(tail) if tail else None
         return self
 

@@ -90,14 +90,14 @@ class VisionTransformer(nn.Module):
         self.norm = nn.LayerNorm(embed_dim, eps=eps)
         self.head = nn.Linear(embed_dim, num_classes) if num_classes > 0 else nn.Identity()   # unused by the path (vit.py:257,325)
         self.compute_dtype = compute_dtype
-        self.precision = None          # "bf16x3" / "fp16c8": parity-grade operand representations of the no-grad passes
+        self.precision = None          # "bf16x3" / "fp16c8" / "fp16c4": parity-grade operand representations of the no-grad passes
         # residual stream of the TRAINING path: "fp32" (default since round 4: the reference trains in fp32, main.py:124-246 -- the sums
         # x + attn(..), x + mlp(..) and the gradient sums of the skip connections are formed and kept in fp32; MFMA operands stay bf16) or
         # "bf16" (rounds 1-3: the stream itself rounded to 8 significant bits after every add; kept for A/B measurements)
         self.residual_stream = "fp32"
         self.defer_wgrad = True        # the blocks' weight gradients in batched launches (nn_ops.DeferredWgrad) ...
         self.defer_groups = None       # ... one launch per group of depth / defer_groups blocks; None: 1 on a single GPU, 4 under data parallelism
-        self.c8_plain_from = None      # fp16c8 only: blocks with index >= this run on plain fp16 operands ("fp16c8-9": the last three)
+        self.c8_plain_from = None      # fp16c8 / fp16c4: blocks with index >= this run on plain fp16 operands ("fp16c8-9": the last three)
         self._pos_cache = {}
         _trunc_normal_(self.pos_embed)
         _trunc_normal_(self.cls_token)
@@ -209,7 +209,7 @@ class VisionTransformer(nn.Module):
         the packed qkv buffer."""
         if self.precision == "bf16x3":
             return self._forward_features_x3_multi([torch.cat([x, x.flip(-1)], dim=0) for x in xs] if flip_pairs else xs)
-        if self.precision == "fp16c8":
+        if self.precision in ("fp16c8", "fp16c4"):
             return self._forward_features_c8_multi(xs, flip_pairs)
         dt16 = self.compute_dtype                                # bf16, or fp16 (no-grad passes only: same kernels, fp16 operands)
         c = lambda p_: nn_ops.cast_param(p_, dt16)
@@ -361,6 +361,9 @@ class VisionTransformer(nn.Module):
         for i, blk in enumerate(self.blocks):
             if self.c8_plain_from is not None and i >= self.c8_plain_from:
                 continue
+            if self.precision == "fp16c4":          # qkv / fc1 / fc2 run on fp16c4 operands (_c4_weights)
+                items += [(f"{i}.proj", blk.attn.proj.weight, blk.attn.proj.bias)]
+                continue
             items += [(f"{i}.qkv", blk.attn.qkv.weight, blk.attn.qkv.bias), (f"{i}.proj", blk.attn.proj.weight, blk.attn.proj.bias),
                       (f"{i}.fc1", blk.mlp.fc1.weight, blk.mlp.fc1.bias), (f"{i}.fc2", blk.mlp.fc2.weight, blk.mlp.fc2.bias)]
         ent = self.__dict__.get("_c8_w")
@@ -380,6 +383,36 @@ class VisionTransformer(nn.Module):
         _C.check(_C.lib().cosa_c8_rows_batched(_C.ptr(ent["rec"]), ent["n"], ent["rows"], _C.stream_ptr()), "cosa_c8_rows_batched")
         return ent["bufs"]
 
+    def _c4_weights(self):
+        """fp16c4 weight rows + scale tensors (csrc/c4.hpp) of the projections that run on fp16c4 operands -- qkv, fc1, fc2 of the corrected
+        blocks; proj and the patch projection stay fp16c8 (their activation operands come out of the attention / im2col kernels as c8 rows,
+        and they are 10 % of the projection work) -- rebuilt from the fp32 masters on every pass by ONE batched launch"""
+        import numpy as np
+        from .. import _C
+        items = []
+        for i, blk in enumerate(self.blocks):
+            if self.c8_plain_from is not None and i >= self.c8_plain_from:
+                continue
+            items += [(f"{i}.qkv", blk.attn.qkv.weight, blk.attn.qkv.bias), (f"{i}.fc1", blk.mlp.fc1.weight, blk.mlp.fc1.bias),
+                      (f"{i}.fc2", blk.mlp.fc2.weight, blk.mlp.fc2.bias)]
+        ent = self.__dict__.get("_c4_w")
+        key = tuple((n, w.data_ptr(), b.data_ptr()) for n, w, b in items)
+        if ent is None or ent["key"] != key:
+            dev = items[0][1].device
+            bufs = {n: (torch.zeros((w.shape[0], nn_ops.split_ld(w.shape[1])), device=dev, dtype=torch.float16),
+                        nn_ops.c4_scales(w.shape[0], w.shape[1], dev)) for n, w, _ in items}
+            rec_dt = np.dtype([("src", "u8"), ("bias", "u8"), ("dst", "u8"), ("sc", "u8"), ("rows", "i4"), ("K", "i4"), ("row0", "i4"), ("pad", "i4")])
+            assert rec_dt.itemsize == _C.lib().cosa_c4_record_bytes()
+            rec, row0 = np.zeros(len(items), rec_dt), 0
+            for j, (n, w, b) in enumerate(items):
+                assert w.dtype == torch.float32 and w.is_contiguous() and w.shape[1] % 256 == 0 and w.shape[0] % 256 == 0
+                rec[j] = (w.data_ptr(), b.data_ptr(), bufs[n][0].data_ptr(), bufs[n][1].data_ptr(), w.shape[0], w.shape[1], row0, 0)
+                row0 += w.shape[0]
+            ent = self.__dict__["_c4_w"] = {"key": key, "bufs": bufs, "rec": torch.from_numpy(rec.view(np.uint8).copy()).to(dev),
+                                            "n": len(items), "rows": row0}
+        _C.check(_C.lib().cosa_c4_rows_batched(_C.ptr(ent["rec"]), ent["n"], ent["rows"], _C.stream_ptr()), "cosa_c4_rows_batched")
+        return ent["bufs"]
+
     def _c8_buffers(self, M, dev):
         """persistent activations for M token rows; the (1, 1, 0, ...) augmentation block of the fc1 output is set once here (the GEMM
         epilogue writes hi | lo8 | hi8 only), the other c8 buffers get theirs from their producing kernels"""
@@ -390,6 +423,8 @@ class VisionTransformer(nn.Module):
             mk = lambda cols: torch.zeros((M, cols), device=dev, dtype=torch.float16)
             ent = {"y": mk(nn_ops.split_ld(D)), "qkv": mk(3 * D), "o": mk(nn_ops.split_ld(D)), "h": mk(nn_ops.split_ld(Hd))}
             ent["h"][:, 2 * Hd:2 * Hd + 2] = 1
+            if self.precision == "fp16c4":          # the scale tensors of the c4 activation operands (LayerNorm output, GELU output)
+                ent["y_sc"], ent["h_sc"] = nn_ops.c4_scales(M, D, dev), nn_ops.c4_scales(M, Hd, dev)
             bufs[(M, dev)] = ent
         return ent
 
@@ -398,6 +433,8 @@ class VisionTransformer(nn.Module):
         D, H = self.embed_dim, self.num_heads
         p = self.patch_size
         W = self._c8_weights()
+        c4 = self.precision == "fp16c4"
+        W4 = self._c4_weights() if c4 else None
         nf = 2 if flip_pairs else 1                                                     # flip_pairs: every batch stands for cat(x, x.flip(-1))
         pos_rows, cls_rows, shapes, geo = [], [], [], []
         for x in xs:
@@ -456,16 +493,28 @@ class VisionTransformer(nn.Module):
                 if i == aux_idx and aux_idx != depth - 1:
                     aux = xr
                 continue
-            nn_ops.layernorm_c8(xr, f(blk.norm1.weight), f(blk.norm1.bias), blk.norm1.eps, out=bf["y"])
-            nn_ops.gemm_c8(bf["y"], W[f"{i}.qkv"], M, 3 * D, D, nn_ops.EPI_BIAS, out=bf["qkv"], ldy=3 * D)
+            if c4:
+                # fp16c4: LayerNorm and the GELU epilogue write c4 rows + scale bytes; qkv / fc1 / fc2 on the FP4 block-scaled MFMA.  The
+                # output projection stays fp16c8 (its operand is the attention kernel's c8 output)
+                nn_ops.layernorm_c4(xr, f(blk.norm1.weight), f(blk.norm1.bias), blk.norm1.eps, out=bf["y"], scales=bf["y_sc"])
+                nn_ops.gemm_c4(bf["y"], bf["y_sc"], *W4[f"{i}.qkv"], M, 3 * D, D, nn_ops.EPI_BIAS, out=bf["qkv"], ldy=3 * D)
+            else:
+                nn_ops.layernorm_c8(xr, f(blk.norm1.weight), f(blk.norm1.bias), blk.norm1.eps, out=bf["y"])
+                nn_ops.gemm_c8(bf["y"], W[f"{i}.qkv"], M, 3 * D, D, nn_ops.EPI_BIAS, out=bf["qkv"], ldy=3 * D)
             for (B, N), o0, o1 in zip(shapes, offs[:-1], offs[1:]):
                 nn_ops.attn_fwd_c8(bf["qkv"][o0:o1].view(B, N, 3 * D), B, N, H, bf["o"][o0:o1])
             xn = torch.empty_like(xr) if aux is xr else xr              # right after the auxiliary layer: keep its output, no clone
             nn_ops.gemm_c8(bf["o"], W[f"{i}.proj"], M, D, D, nn_ops.EPI_RESIDUAL, residual=xr, out=xn)
             xr = xn
-            nn_ops.layernorm_c8(xr, f(blk.norm2.weight), f(blk.norm2.bias), blk.norm2.eps, out=bf["y"])
-            nn_ops.gemm_c8(bf["y"], W[f"{i}.fc1"], M, Hd, D, nn_ops.EPI_GELU, out=bf["h"], ldy=nn_ops.split_ld(Hd))
-            nn_ops.gemm_c8(bf["h"], W[f"{i}.fc2"], M, D, Hd, nn_ops.EPI_RESIDUAL, residual=xr, out=xr)
+            if c4:
+                nn_ops.layernorm_c4(xr, f(blk.norm2.weight), f(blk.norm2.bias), blk.norm2.eps, out=bf["y"], scales=bf["y_sc"])
+                nn_ops.gemm_c4(bf["y"], bf["y_sc"], *W4[f"{i}.fc1"], M, Hd, D, nn_ops.EPI_GELU, out=bf["h"], out_scales=bf["h_sc"],
+                               ldy=nn_ops.split_ld(Hd))
+                nn_ops.gemm_c4(bf["h"], bf["h_sc"], *W4[f"{i}.fc2"], M, D, Hd, nn_ops.EPI_RESIDUAL, residual=xr, out=xr)
+            else:
+                nn_ops.layernorm_c8(xr, f(blk.norm2.weight), f(blk.norm2.bias), blk.norm2.eps, out=bf["y"])
+                nn_ops.gemm_c8(bf["y"], W[f"{i}.fc1"], M, Hd, D, nn_ops.EPI_GELU, out=bf["h"], ldy=nn_ops.split_ld(Hd))
+                nn_ops.gemm_c8(bf["h"], W[f"{i}.fc2"], M, D, Hd, nn_ops.EPI_RESIDUAL, residual=xr, out=xr)
             if i == aux_idx and aux_idx != depth - 1:
                 aux = xr
         yfin = torch.empty_like(bf["y"])

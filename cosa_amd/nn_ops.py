@@ -467,6 +467,64 @@ def gemm_c8(xs, ws, M, N, K, epilogue=EPI_BIAS, residual=None, out=None, ldy=Non
     return out
 
 
+# --------------------------------------------------------------------------------------------
+# fp16c4 operands (round 4; csrc/c4.hpp): fp16 + FP4 (e2m1) correction terms in MX blocks -- ~1.58x the 16-bit MFMA work instead of fp16c8's ~2.08x
+#   an operand = (rows [R, 2K + 64] fp16 units: hi | 16-byte blocks | unused | aug,  scales uint8 [c4_scale_bytes(R, K)])
+# --------------------------------------------------------------------------------------------
+def c4_scales(R, K, device):
+    """zero-initialised scale tensor of a c4 operand with R rows of logical width K"""
+    return torch.zeros(int(_C.lib().cosa_c4_scale_bytes(R, K)), device=device, dtype=torch.uint8)
+
+
+def c4_rows(src, bias=None, ones=False, weight=False, out=None, scales=None):
+    """fp32 [R, K] (K % 256 == 0) -> (c4 rows [R, 2K + 64] fp16 units, scales); weight: weight block order ([hi | lo']) and the 2^-11 of the
+    correction terms in the scale bytes; aug block = (bias_hi, bias_lo, 0..) per row, (1, 1, 0..) with ones=True, zeros otherwise"""
+    R, K = src.shape
+    assert src.dtype == torch.float32 and src.stride(1) == 1 and K % 256 == 0
+    if out is None:
+        out = torch.zeros((R, split_ld(K)), device=src.device, dtype=torch.float16)
+    if scales is None:
+        scales = c4_scales(R, K, src.device)
+    _C.check(_C.lib().cosa_c4_rows(_C.ptr(src), _C.ptr(bias), _C.ptr(out), _C.ptr(scales), R, K, src.stride(0), int(ones), int(weight),
+                                   _C.stream_ptr()), "cosa_c4_rows")
+    return out, scales
+
+
+def layernorm_c4(x, g, b, eps, out=None, scales=None, want_f32=False):
+    """LayerNorm(768) over the fp32 stream with fp32 gamma / beta -> (c4 rows | None, fp32 | None); scales written beside the rows"""
+    rows, D = x.shape
+    y32 = torch.empty((rows, D), device=x.device, dtype=torch.float32) if want_f32 else None
+    _C.check(_C.lib().cosa_layernorm_c4(_C.ptr(x), _C.ptr(g), _C.ptr(b), _C.ptr(out), _C.ptr(scales), _C.ptr(y32), rows, D, float(eps),
+                                        _C.stream_ptr()), "cosa_layernorm_c4")
+    return out, y32
+
+
+def gemm_c4(xs, xsc, ws, wsc, M, N, K, epilogue=EPI_BIAS, residual=None, out=None, out_scales=None, ldy=None):
+    """xs [M, 2K+64] / ws [N, 2K+64] c4 rows with their scale tensors (bias inside ws).  epilogue 0: plain fp16 [M, ldy >= N]; 1 (GELU):
+    c4 rows [M, 2N + 64] + out_scales (c4_scales(M, N)); 2: fp32 [M, N] = residual + . (in place allowed)"""
+    dev = xs.device
+    z = _c8_zero_bias.get(dev)
+    if z is None:
+        z = _c8_zero_bias[dev] = torch.zeros(8192, device=dev, dtype=torch.float16)
+    if epilogue == EPI_RESIDUAL:
+        ldy = N
+        if out is None:
+            out = torch.empty((M, N), device=dev, dtype=torch.float32)
+    else:
+        ldy = ldy or (split_ld(N) if epilogue == EPI_GELU else N)
+        if out is None:
+            out = torch.zeros((M, ldy), device=dev, dtype=torch.float16)
+        if epilogue == EPI_GELU and out_scales is None:
+            out_scales = c4_scales(M, N, dev)
+    if gemm_stamps is not None and M >= 4096:
+        _C.lib().cosa_gemm_set_stamp_slot_f16(gemm_stamps.next_slot(2.0 * M * N * K))
+    with _C.profiled("gemm_c4"):
+        _C.check(_C.lib().cosa_gemm_f16c4(_C.ptr(xs), _C.ptr(xsc), _C.ptr(ws), _C.ptr(wsc), _C.ptr(z), _C.ptr(residual), _C.ptr(out),
+                                          _C.ptr(out_scales), M, N, K, epilogue, ldy, _C.stream_ptr()), "cosa_gemm_f16c4")
+    _flops["gemm_c4"] = _flops.get("gemm_c4", 0) + 2.0 * M * N * K * (K // 64 + 1 + K // 128) / (K // 64)
+    return (out, out_scales) if epilogue == EPI_GELU else out
+
+
 def attn_fwd_c8(qkv, B, N, H, out_c8, lse=None):
     """attention on plain fp16 qkv [B, N, 3 H 64] -> c8 rows out_c8 [B*N, 2 H 64 + 64 fp16 units] (hi | lo8 | hi8 | aug)"""
     assert qkv.dtype == torch.float16 and qkv.is_contiguous() and out_c8.stride(0) == split_ld(H * 64)

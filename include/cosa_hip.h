@@ -372,6 +372,29 @@ int cosa_attn_fwd_f16c8(const void *qkv, void *out_c8, float *lse, int B, int N,
                         uint64_t *stamps, void *stream);
 
 /* ---------------------------------------------------------------------------------------
+ * fp16c4 operands (round 4; csrc/c4.hpp): the fp16c8 scheme with FP4 (e2m1) correction terms in MX blocks -- both terms
+ * 2^-11 (x_lo' w_hi + x_hi w_lo') in ONE stream of block-scaled MFMAs at 4x the fp16 rate (e5m2: 2x): ~1.58x instead of ~2.08x the MFMA work
+ * of the plain 16-bit path at K = 768.  Same purpose and call sites as fp16c8 (the teacher's no-grad projections, models/vit/vit.py:96-137).
+ * A c4 operand is a PAIR: rows [R][4K + 128 bytes] = [hi fp16 (2K) | 16-byte blocks (K) | unused (K) | aug fp16 (128)] -- the c8 stride; a
+ * block holds the 16 lo' = (v - hi) 2^11 and the 16 hi copies of 16 consecutive features as e2m1 nibbles ([lo' | hi] for activations,
+ * [hi | lo'] for weights) -- and a scale tensor of cosa_c4_scale_bytes(R, K) bytes with one E8M0 byte per block (smallest 2^e with
+ * amax / 2^e <= 6; weights carry the 2^-11), laid out per 256-row panel and 128-feature tile as the GEMM's lanes read it (c4.hpp).  K % 256 == 0.
+ *   cosa_c4_rows          src fp32 [R, K] (+ bias fp32 [R] | ones) -> rows + scales; weight != 0: weight block order / scale bias
+ *   cosa_c4_rows_batched  the weight matrices of a network in one launch ({src, bias, dst, scales, rows, K, row0, pad} records)
+ *   cosa_layernorm_c4     nn.LayerNorm(768, eps), fp32 gamma / beta, over the fp32 residual stream -> c4 rows + scales and/or fp32
+ *   cosa_gemm_f16c4       Y = Xs Ws^T (bias inside Ws); N % 256 == 0.  epilogue 0: Y fp16 [M, ldy >= N]; 1 (GELU): Y = c4 rows [M, ldy = 2N + 64
+ *                         fp16 units] + Yscales (activation layout; the augmentation block left to the caller); 2: Y fp32 [M, N] = residual + .
+ * ------------------------------------------------------------------------------------- */
+size_t cosa_c4_scale_bytes(int rows, int K);
+int cosa_c4_rows(const float *src, const float *bias, void *dst, void *scales, int R, int K, long long src_ld, int ones, int weight, void *stream);
+size_t cosa_c4_record_bytes(void);       /* { const float *src; const float *bias; void *dst; void *scales; int rows, K, row0, pad; } */
+int cosa_c4_rows_batched(const void *records /* device */, int n_records, int total_rows, void *stream);
+int cosa_layernorm_c4(const float *x, const float *gamma, const float *beta, void *y_c4, void *y_scales, float *y_f32, int rows, int dim,
+                      float eps, void *stream);
+int cosa_gemm_f16c4(const void *Xs, const void *Xscales, const void *Ws, const void *Wscales, const void *zeros, const float *residual,
+                    void *Y, void *Yscales, int M, int N, int K, int epilogue, int ldy, void *stream);
+
+/* ---------------------------------------------------------------------------------------
  * main.py:167-212 + utils/seg_helper.py:800-813,199-230  the student's dense losses, fused:
  *   seg_loss(main) and seg_loss(aux) of the bilinearly up-sampled logits, and the inputs of the
  *   dense-energy regulariser (softmax -> x0.5, ROI from boxes, nearest image / label), without
