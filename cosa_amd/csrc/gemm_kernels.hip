@@ -19,10 +19,6 @@
 #include "c4.hpp"
 #include <cstdlib>
 
-#ifndef COSA_GEMM_EXPERIMENTS
-#define COSA_GEMM_EXPERIMENTS 0       // 1: environment switches, timing ablations and alternative policies (see env_int below)
-#endif
-
 namespace cosa {
 namespace {
 
@@ -338,11 +334,9 @@ constexpr size_t kLdsBytesV5 = 2 * V5_BUF;             // 128 KB; also holds the
 #define V5_BARRIER()                          \
     do {                                      \
         V5_FENCE();                           \
-        if (!(ABL & 4)) __builtin_amdgcn_s_barrier(); \
+        __builtin_amdgcn_s_barrier();         \
         V5_FENCE();                           \
     } while (0)
-
-constexpr int ABL = 0;      // (the barrier macro's ablation switch of the removed one-tile kernel)
 
 // =====================================================================================================
 // v6: that phase stream as a PERSISTENT kernel whose epilogue rides inside the next phases.
@@ -362,19 +356,17 @@ constexpr int ABL = 0;      // (the barrier macro's ablation switch of the remov
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-// AUX: cache policy of the output stores (bit 1 = nt, bit 0 = sc0, bit 4 = sc1).  Plain stores allocate in L2: one round of
-// epilogues of an XCD's 32 CUs is 4 MB = the whole L2, which throws out the W panel and the X panels the DMA stream is
-// about to hit (stand-alone: plain 304 us, nt 287 us, nt+sc0+sc1 276 us, no stores 249 us on the qkv projection).  Inside the
-// training step the consumer kernel runs next and wants the output in L2 / MALL: there plain stores win (qkv 293 us vs 347 us
-// with nt+sc0+sc1; v5 314 us), so 0 is the default.
-// ABL6 (timing only): 1 = epilogue without the stores, 2 = no epilogue work, 3 = L2-resident store window, 4 = stores dropped
+// Output stores use the default cache policy: stand-alone, non-temporal stores are faster (qkv projection: plain 304 us, nt 287 us), but in the
+// training step the consumer kernel runs next and wants the tile in L2 / the Infinity Cache (plain 293 us vs 347 us with nt + sc0 + sc1).
+// (Rounds 2-3 carried the timing ablations behind these numbers -- store policies, epilogue without stores, an L2-resident store window, banded
+// tile orders, start staggers -- as template parameters and environment switches of this kernel; round 4 removed them: HISTORY.md has the numbers.)
 // SPLIT: bf16x3 operands (see split_tile_x / split_tile_w above): K is the logical contraction length, operand rows have stride ld
 // (= 2K + 64), the K loop has 3K/64 + 1 tiles, 16-bit outputs are written as [hi | lo] halves of rows with stride ldy.
-template <int EPI, int ABL6 = 0, int AUX = 0, int SPLIT = 0, int FR = 4>
+template <int EPI, int SPLIT = 0, int FR = 4>
 __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__restrict__ X, const op16 *__restrict__ W,
                                                              const op16 *__restrict__ bias, const float *__restrict__ R,
                                                              void *__restrict__ Yv, int M, int N, int K, int tiles_m, int tiles_n,
-                                                             int stagger_ticks, unsigned long long *__restrict__ stamps, int ld, int ldy, void *__restrict__ Y2v, int ntiles_run, int band,
+                                                             unsigned long long *__restrict__ stamps, int ld, int ldy, void *__restrict__ Y2v, int ntiles_run,
                                                              const unsigned char *__restrict__ xsc, const unsigned char *__restrict__ wsc, unsigned char *__restrict__ ysc)
 {
     // optional device-side span of this launch (100 MHz wall clock; min start / max end over workgroups): HIP events cannot be
@@ -404,14 +396,6 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
 
     auto tile_of = [&](int o, int &m0_, int &n0_) {      // every XCD (o & 7) walks a contiguous chunk of the m-panel-major tile list
         const int xcd = o & 7, idx = o >> 3;
-        if (COSA_GEMM_EXPERIMENTS && band > 0) {          // an XCD owns tiles_m / 8 whole m-panels and walks them in bands of `band` n-tiles (m-panel-major inside a band):
-            const int rows_per = tiles_m >> 3, per_band = rows_per * band;          // the band's W panels stay in its L2 while the X panels stream
-            const int bi = idx / per_band, j = idx - bi * per_band;
-            const int rr = j / band;
-            m0_ = (xcd * rows_per + rr) * 256;
-            n0_ = (bi * band + (j - rr * band)) * TN;
-            return;
-        }
         const int t = (xcd < cr ? xcd * (cq + 1) : cr * (cq + 1) + (xcd - cr) * cq) + idx;
         const int tm = t / tiles_n;
         m0_ = tm * 256;
@@ -431,8 +415,6 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
         return __builtin_amdgcn_make_buffer_rsrc((void *)(static_cast<unsigned char *>(Y2v) + ((size_t)m0_ * ldy + n0_) * 2), 0, (rows * ldy - n0_) * 2, FL);
     };
     auto descY = [&](int m0_, int n0_) {
-        if (ABL6 == 3) { m0_ = (int)blockIdx.x * 256 % (M - 256); n0_ = 0; }     // timing only: every job of a workgroup rewrites one L2-resident window
-        if (ABL6 == 4) return __builtin_amdgcn_make_buffer_rsrc((void *)Yb, 0, 0, FL);   // timing only: every store is out of range (dropped)
         int rows = M - m0_;
         rows = rows > 256 ? 256 : rows;
         return __builtin_amdgcn_make_buffer_rsrc((void *)(Yb + ((size_t)m0_ * ldy + n0_) * ES), 0, (rows * ldy - n0_) * ES, FL);
@@ -508,20 +490,6 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
     const unsigned fo16m = (unsigned)((wr * WN + 16 * (fq & 1) + 32 * (fq >> 1)) - 2 * (wr * WN + (fq & 1) * 16 + 4 * (fq & 2)));
 
     int o = blockIdx.x;
-    // Optional start stagger (experiment build only): workgroups that have one job fewer than the busiest ones start
-    // late by a pseudo-random fraction of stagger_ticks (100 MHz).  The idea was to spread the 256 simultaneous epilogues;
-    // measured to make no difference (the store cost is L2 capacity, not burstiness).
-    if (COSA_GEMM_EXPERIMENTS && stagger_ticks > 0) {
-        const int njobs = (ntiles - o + G - 1) / G, njobs_max = (ntiles + G - 1) / G;
-        if (njobs < njobs_max || stagger_ticks >= (1 << 20)) {
-            const unsigned long long wait = (unsigned long long)((o * 37) & 63) * (unsigned)(stagger_ticks & 0xfffff) >> 6;
-            if (wave == 0) {
-                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-                while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(32);
-            }
-            __syncthreads();
-        }
-    }
     int m0, n0, m1 = 0, n1 = 0, pn0 = 0, pm0 = 0;
     tile_of(o, m0, n0);
     bool has_next = o + G < ntiles_run;      // (ntiles_run <= ntiles: the jobs past it are left to a tail launch, cosa_gemm_bf16)
@@ -607,17 +575,14 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
     }
     // quadrant (qa, qb) out: acc[qa*4 + ii][qb*2 + jj][r] = feature qa*128 + wr*64 + ii*16 + 4fq + r, token qb*128 + wc*32 + jj*16 + frow
 #define V6_EPI(qa, qb, rsY)                                                                                         \
-    if (ABL6 == 2) {                                                                                                \
-        _Pragma("unroll") for (int i_ = 0; i_ < 4; i_++) _Pragma("unroll") for (int j_ = 0; j_ < 2; j_++)           \
-            asm volatile("" ::"v"(acc[(qa) * 4 + i_][(qb) * 2 + j_]));                                              \
-    } else if (RES) {                                                                                               \
+    if (RES) {                                                                                                      \
         _Pragma("unroll") for (int ii = 0; ii < FR; ii++) {                                                         \
             const unsigned lo_ = CX ? 0u : bb[qa][ii][0], hi_ = CX ? 0u : bb[qa][ii][1];                            \
             const f32x4 bv_ = CX ? (f32x4){0.f, 0.f, 0.f, 0.f} : (f32x4){op16_lo(lo_), op16_hi(lo_), op16_lo(hi_), op16_hi(hi_)};  \
             _Pragma("unroll") for (int jj = 0; jj < 2; jj++) {                                                      \
                 const f32x4 o4_ = acc[(qa) * 4 + ii][(qb) * 2 + jj] + bv_;                                          \
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o4_), rsY,                         \
-                                                       voY[(qb) * 2 + jj] + ((qa) * HN + ii * 16) * 4, 0, AUX);     \
+                                                       voY[(qb) * 2 + jj] + ((qa) * HN + ii * 16) * 4, 0, 0);     \
             }                                                                                                       \
         }                                                                                                           \
     } else {                                                                                                        \
@@ -629,7 +594,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
             if (EPI == EPI_GELU) { _Pragma("unroll") for (int r = 0; r < 4; r++) v2_[r] = gelu_erf(v2_[r]); }       \
             const op16x2 s0_ = {(op16)v2_[0], (op16)v2_[1]}, s1_ = {(op16)v2_[2], (op16)v2_[3]};                    \
             const u32x2 o2_ = {__builtin_bit_cast(unsigned, s0_), __builtin_bit_cast(unsigned, s1_)};               \
-            __builtin_amdgcn_raw_buffer_store_b64(o2_, rsY, voY[(qb) * 2 + jj] + voY3 + (qa) * HN * 2, 0, AUX);     \
+            __builtin_amdgcn_raw_buffer_store_b64(o2_, rsY, voY[(qb) * 2 + jj] + voY3 + (qa) * HN * 2, 0, 0);     \
             continue;                                                                                               \
         }                                                                                                           \
         f32x4 v0_ = acc[(qa) * 4 + 2 * pr][(qb) * 2 + jj], v1_ = acc[(qa) * 4 + 2 * pr + 1][(qb) * 2 + jj];        \
@@ -639,7 +604,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
             const auto u0_ = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, r0_), __builtin_bit_cast(unsigned, r2_), false, false); \
             const auto u1_ = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, r1_), __builtin_bit_cast(unsigned, r3_), false, false); \
             const u32x4 raw_ = {u0_[0], u1_[0], u0_[1], u1_[1]};                                                    \
-            __builtin_amdgcn_raw_buffer_store_b128(raw_, rsY, voY[(qb) * 2 + jj] + ((qa) * HN + pr * 32) * 2, 0, AUX); \
+            __builtin_amdgcn_raw_buffer_store_b128(raw_, rsY, voY[(qb) * 2 + jj] + ((qa) * HN + pr * 32) * 2, 0, 0); \
         }                                                                                                           \
         if (EPI == EPI_GELU) {                                                                                      \
             _Pragma("unroll") for (int r = 0; r < 4; r++) {                                                         \
@@ -652,9 +617,8 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
         const auto s0_ = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, p0_), __builtin_bit_cast(unsigned, p2_), false, false); \
         const auto s1_ = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, p1_), __builtin_bit_cast(unsigned, p3_), false, false); \
         const u32x4 out_ = {s0_[0], s1_[0], s0_[1], s1_[1]};                                                        \
-        if (SPLIT == 2) __builtin_amdgcn_raw_buffer_store_b128(out_, (&rsY == &pY) ? pY2 : cY2, voY[(qb) * 2 + jj] + ((qa) * HN + pr * 32) * 2, 0, AUX); \
-        else if (ABL6 == 0 || ABL6 == 3 || ABL6 == 4) __builtin_amdgcn_raw_buffer_store_b128(out_, rsY, voY[(qb) * 2 + jj] + ((qa) * HN + pr * 32) * 2, 0, AUX); \
-        else asm volatile("" ::"v"(out_));                                                                          \
+        if (SPLIT == 2) __builtin_amdgcn_raw_buffer_store_b128(out_, (&rsY == &pY) ? pY2 : cY2, voY[(qb) * 2 + jj] + ((qa) * HN + pr * 32) * 2, 0, 0); \
+        else __builtin_amdgcn_raw_buffer_store_b128(out_, rsY, voY[(qb) * 2 + jj] + ((qa) * HN + pr * 32) * 2, 0, 0); \
         if (SPLIT == 1) {          /* the lo halves: what the 16-bit rounding above dropped, at column N + n */              \
             const op16x2 q0_ = {(op16)(v0_[0] - (float)p0_[0]), (op16)(v0_[1] - (float)p0_[1])};                    \
             const op16x2 q1_ = {(op16)(v0_[2] - (float)p1_[0]), (op16)(v0_[3] - (float)p1_[1])};                    \
@@ -663,7 +627,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
             const auto t0_ = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, q0_), __builtin_bit_cast(unsigned, q2_), false, false); \
             const auto t1_ = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, q1_), __builtin_bit_cast(unsigned, q3_), false, false); \
             const u32x4 lo4_ = {t0_[0], t1_[0], t0_[1], t1_[1]};                                                    \
-            __builtin_amdgcn_raw_buffer_store_b128(lo4_, rsY, voY[(qb) * 2 + jj] + (N + (qa) * HN + pr * 32) * 2, 0, AUX); \
+            __builtin_amdgcn_raw_buffer_store_b128(lo4_, rsY, voY[(qb) * 2 + jj] + (N + (qa) * HN + pr * 32) * 2, 0, 0); \
         }                                                                                                           \
         if (C8OUT) {       /* c8 rows: lo8 at byte 2N + n, hi8 at byte 3N + n of the row (the window starts at byte 2 n0 of it) */   \
             const float h0_ = (float)p0_[0], h1_ = (float)p0_[1], h2_ = (float)p1_[0], h3_ = (float)p1_[1];        \
@@ -682,8 +646,8 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
                 const auto g1_ = __builtin_amdgcn_permlane32_swap(c8h_[0][1], c8h_[1][1], false, false);            \
                 const int jn0_ = (&rsY == &pY) ? pn0 : n0;                                                          \
                 const unsigned v16_ = voY[(qb) * 2 + jj] + fo16m;                                                   \
-                __builtin_amdgcn_raw_buffer_store_b128((u32x4){l0_[0], l1_[0], l0_[1], l1_[1]}, rsY, v16_, 2 * N - jn0_ + (qa) * HN, AUX); \
-                __builtin_amdgcn_raw_buffer_store_b128((u32x4){g0_[0], g1_[0], g0_[1], g1_[1]}, rsY, v16_, 3 * N - jn0_ + (qa) * HN, AUX); \
+                __builtin_amdgcn_raw_buffer_store_b128((u32x4){l0_[0], l1_[0], l0_[1], l1_[1]}, rsY, v16_, 2 * N - jn0_ + (qa) * HN, 0); \
+                __builtin_amdgcn_raw_buffer_store_b128((u32x4){g0_[0], g1_[0], g0_[1], g1_[1]}, rsY, v16_, 3 * N - jn0_ + (qa) * HN, 0); \
             }                                                                                                       \
         }                                                                                                           \
         if (C4OUT) {       /* c4 rows: the 16 features 16 i + 4 fq + r (fq = 0..3) of fragment i of one token are ONE block, spread over the four   \
@@ -718,10 +682,10 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
                 const u32x4 blk_ = {(g0_ & 0xffffu) | (g1_ << 16), (g2_ & 0xffffu) | (g3_ << 16),                    \
                                     (g0_ >> 16) | (g1_ & 0xffff0000u), (g2_ >> 16) | (g3_ & 0xffff0000u)};          \
                 const int jn0_ = (&rsY == &pY) ? pn0 : n0, jm0_ = (&rsY == &pY) ? pm0 : m0;                         \
-                __builtin_amdgcn_raw_buffer_store_b128(blk_, rsY, voY[(qb) * 2 + jj] + fo16m, 2 * N - jn0_ + (qa) * HN, AUX); \
+                __builtin_amdgcn_raw_buffer_store_b128(blk_, rsY, voY[(qb) * 2 + jj] + fo16m, 2 * N - jn0_ + (qa) * HN, 0); \
                 const int el_ = fq == 0 ? c4e_[0][0] : (fq == 1 ? c4e_[0][1] : (fq == 2 ? c4e_[1][0] : c4e_[1][1])); \
                 __builtin_amdgcn_raw_buffer_store_b8((unsigned char)c4_scale_byte(el_, 0), sYr, sc_wr_y + ((qb) * 2 + jj) * 2, \
-                                                     (((jm0_ >> 8) * (N >> 7) + (jn0_ >> 7) + (qa)) << 11), AUX);   \
+                                                     (((jm0_ >> 8) * (N >> 7) + (jn0_ >> 7) + (qa)) << 11), 0);   \
             }                                                                                                       \
         }                                                                                                           \
     }                                                                                                               \
@@ -1361,26 +1325,12 @@ static size_t cosa_c4_scale_bytes_(int rows, int K) { return (size_t)((rows + 25
 static unsigned long long *g_gemm_stamp_slot = nullptr;
 extern "C" void cosa_gemm_set_stamp_slot(void *slot) { g_gemm_stamp_slot = static_cast<unsigned long long *>(slot); }
 
-// Experiment switches (environment variables read once per process, timing ablations, alternative store policies and tile orders) are
-// compiled only with -DCOSA_GEMM_EXPERIMENTS=1 (COSA_EXTRA_FLAGS_GEMM_KERNELS of cosa_amd/build.py): the measurements quoted in the
-// comments and in DESIGN.md section 7 were made with such a build; the shipped library takes the measured defaults.
-static int env_int(const char *name, int dflt)
-{
-#if COSA_GEMM_EXPERIMENTS
-    const char *e = getenv(name);
-    return e ? atoi(e) : dflt;
-#else
-    (void)name;
-    return dflt;
-#endif
-}
-static int env_variant() { return env_int("COSA_GEMM_VARIANT", 0); }
 static int g_gemm_balanced_grid = 0;          // see launch_v6
-static int g_gemm_variant = env_variant();   // 0 = pick per shape (measured, tools/bench_gemm.py); 1..9 force a kernel (experiments; 9 = v6 on 256 x 192 jobs)
+static int g_gemm_variant = 0;               // 0 = pick per shape (measured, tools/bench_gemm.py); 1 = the 128 x 128 kernel, 6 / 9 = the persistent kernel on 256- / 192-wide jobs (tests)
 extern "C" void cosa_gemm_set_variant(int v) { g_gemm_variant = v; }
 extern "C" void cosa_gemm_set_grid_policy(int balanced) { g_gemm_balanced_grid = balanced; }
 
-template <int EPI, int ABL6 = 0, int AUX = 0, int SPLIT = 0, int FR = 4>
+template <int EPI, int SPLIT = 0, int FR = 4>
 static int launch_v6(const op16 *x, const op16 *w, const op16 *b, const float *residual, void *Y, int M, int N, int K, hipStream_t st,
                      int ld = 0, int ldy = 0, void *Y2 = nullptr, const unsigned char *xsc = nullptr, const unsigned char *wsc = nullptr,
                      unsigned char *ysc = nullptr)
@@ -1388,7 +1338,7 @@ static int launch_v6(const op16 *x, const op16 *w, const op16 *b, const float *r
     constexpr size_t lds_bytes = kLdsBytesV5 + (SPLIT == 4 ? kC4ScaleLds : 0);      // fp16c4: + the scale ring
     static bool attr_done = false;
     if (!attr_done) {
-        COSA_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_bf16_v6_kernel<EPI, ABL6, AUX, SPLIT, FR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        COSA_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_bf16_v6_kernel<EPI, SPLIT, FR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         attr_done = true;
     }
     const int tiles_m = (M + 255) / 256, tiles_n = N / (64 * FR);
@@ -1398,43 +1348,28 @@ static int launch_v6(const op16 *x, const op16 *w, const op16 *b, const float *r
     // FIVE rounds, the last with 8 busy CUs.  When the remainder is small, the persistent kernel stops after the full rounds and the
     // leftover 256 x 256 jobs run as 128 x 128 quarters on the two-stage kernel (4 workgroups per job, 2 per CU): a few per cent of a
     // round instead of a whole one.  Same products, same fp32 accumulation order per output element (k ascending) as the jobs it replaces.
-    static const int tail_max = env_int("COSA_GEMM_TAIL", 48);
+    constexpr int tail_max = 48;
     int run = ntiles;
     // ... when it pays: the idle share of the last round must be a sizeable part of the whole launch (> 10 % of its rounds).  The teacher's
     // N = 768 projections (4.03 rounds) qualify; its 12.09- and 16.1-round launches do not -- measured in the step: tail for all three
     // 45.83 / 45.96 ms, for the 4.03-round launches only 45.66 / 45.65, none 46.05 / 46.22
     const int rem = ntiles % 256, rounds_up = (ntiles + 255) / 256;
-    if (FR == 4 && SPLIT == 0 && ABL6 == 0 && AUX == 0 && ntiles > 256 && rem != 0 && rem <= tail_max && (256 - rem) * 10 > 256 * rounds_up)
+    if (FR == 4 && SPLIT == 0 && ntiles > 256 && rem != 0 && rem <= tail_max && (256 - rem) * 10 > 256 * rounds_up)
         run = ntiles - rem;
-    // Tile order inside an XCD: with all n-tiles of an m-panel in flight the W panels of a wide layer (fc1: 12 x 393 KB = 4.7 MB) cycle
-    // through a 4-MB L2 and are re-fetched every round.  Bands of n-tiles whose W panels total <= 2.4 MB keep them resident (X is then read
-    // once per band): PMC on the fc1 launch 864 -> 632 MB fetched (1.41 -> 1.17 GB in total).  Time does not improve -- stand-alone equal, in
-    // the step 44.78 / 44.81 ms against 44.65 / 44.74 (the re-fetches are served by the Infinity Cache off the critical path) -- so it is
-    // OFF by default; COSA_GEMM_BAND=-1 picks the band width as described, COSA_GEMM_BAND=n forces n.
-    static const int band_env = env_int("COSA_GEMM_BAND", 0);
-    int band = 0;
-    if (tiles_m % 8 == 0 && run == ntiles && band_env != 0) {
-        const size_t panel = (size_t)64 * FR * (size_t)(ld ? ld : K) * 2;
-        for (int cand = tiles_n - 1; cand >= 2; cand--)
-            if (tiles_n % cand == 0 && (band_env > 0 ? cand == band_env : cand * panel <= (size_t)2400 * 1024)) { band = cand; break; }
-    }
-    // start stagger (see the kernel): measured to make no difference, off
-    static const int stagger = env_int("COSA_GEMM_STAGGER", 0);
     // The persistent grid is balanced over the rounds it needs anyway: 600 jobs are three rounds on 256 workgroups and on 200, and 200
     // leave 56 CUs to whatever else is running (the other stream's kernels, RCCL's channels under DDP: a 256-workgroup launch that finds
     // only 224 free CUs runs its last 32 workgroups AFTER the others -- twice the time).  Multiples of 8 keep a workgroup on one XCD chunk.
     // Single GPU: 0.25 % slower than the full grid (44.57 / 44.74 vs 44.46 / 44.62 ms per step), so it is switched on by the trainer only
-    // when the process is one rank of several (cosa_gemm_set_grid_policy), or by COSA_GEMM_BALANCED_GRID=1.
-    static const int balanced_env = env_int("COSA_GEMM_BALANCED_GRID", -1);
-    const bool balanced = balanced_env >= 0 ? balanced_env != 0 : g_gemm_balanced_grid != 0;
+    // when the process is one rank of several (cosa_gemm_set_grid_policy).
+    const bool balanced = g_gemm_balanced_grid != 0;
     int grid_b = grid;
-    if (balanced && run > 256 && (balanced_env >= 0 || M < 40000)) {       // (policy 1: the student's launches -- the ones a backward pass overlaps with all-reduces)
+    if (balanced && run > 256 && M < 40000) {       // (policy 1: the student's launches -- the ones a backward pass overlaps with all-reduces)
         const int rounds = (run + 255) / 256;
         grid_b = ((run + rounds - 1) / rounds + 7) / 8 * 8;
         grid_b = grid_b > 256 ? 256 : grid_b;
     }
-    hipLaunchKernelGGL((gemm_bf16_v6_kernel<EPI, ABL6, AUX, SPLIT, FR>), dim3(grid_b), dim3(512), lds_bytes, st, x, w, b, residual, Y, M, N, K, tiles_m, tiles_n, stagger,
-                       g_gemm_stamp_slot, ld ? ld : K, ldy ? ldy : N, Y2, run, band, xsc, wsc, ysc);
+    hipLaunchKernelGGL((gemm_bf16_v6_kernel<EPI, SPLIT, FR>), dim3(grid_b), dim3(512), lds_bytes, st, x, w, b, residual, Y, M, N, K, tiles_m, tiles_n,
+                       g_gemm_stamp_slot, ld ? ld : K, ldy ? ldy : N, Y2, run, xsc, wsc, ysc);
     g_gemm_stamp_slot = nullptr;                            // one-shot
     COSA_LAUNCH_CHECK();
     if (run < ntiles) {
@@ -1466,32 +1401,20 @@ extern "C" int cosa_gemm_bf16(const void *X, const void *W, const void *bias, co
     // shape rule (measured, profiles/r01_gemm_variants.txt): the persistent 256-wide kernel from 4096 rows up, the 128 x 128 kernel (two
     // workgroups per CU) below that and for operands beyond the 2-GiB reach of its buffer descriptors
     const bool fits_v5 = N % 256 == 0 && M >= 256 && (size_t)(M + 256) * K * 2 < 0x7fffffffull && (size_t)N * K * 2 < 0x7fffffffull;
-    static const int big_m = env_int("COSA_GEMM_BIG_M", 4096);   // rows from which the 256 x 256 kernels are used
+    constexpr int big_m = 4096;                                  // rows from which the 256 x 256 kernels are used
     const bool fits_v6 = fits_v5 && K >= 128 && (epilogue != EPI_RESIDUAL || g_gemm_variant == 6 || g_gemm_variant == 9 || g_gemm_variant == 0);
-#if COSA_GEMM_EXPERIMENTS
-    if (g_gemm_variant >= 61 && g_gemm_variant <= 65 && fits_v6) {     // timing ablations of v6 (tools/bench_gemm_abl.py)
-        switch (g_gemm_variant) {
-        case 61: return launch_v6<EPI_BIAS, 1>(x, w, b, residual, Y, M, N, K, st);
-        case 62: return launch_v6<EPI_BIAS, 2>(x, w, b, residual, Y, M, N, K, st);
-        case 63: return launch_v6<EPI_GELU, 1>(x, w, b, residual, Y, M, N, K, st);
-        case 64: return launch_v6<EPI_BIAS, 3>(x, w, b, residual, Y, M, N, K, st);
-        default: return launch_v6<EPI_BIAS, 4>(x, w, b, residual, Y, M, N, K, st);
-        }
-    }
-#endif
     // 192-wide tiles (FR = 3) when they quantise better on the 256 CUs: the student's N = 768 projections (M = 12 560) are 150 jobs of
     // 256 x 256 -- one round at 59 % of the CUs -- but 200 jobs of 256 x 192, one round of 3/4 the length.  Cost model: rounds x job
     // length, the narrow job taken as 0.78 of the wide one (0.75 of the MFMA work, the X panel traffic per MFMA is 4/3).
     if (fits_v6 && N % 192 == 0 && (g_gemm_variant == 9 || (g_gemm_variant == 0 && M >= big_m))) {
-        static const int wide_max = env_int("COSA_GEMM_TAIL", 48);
+        constexpr int wide_max = 48;
         const long tm = (M + 255) / 256, n4 = tm * (N / 256), n3 = tm * (N / 192);
         const double r4 = (n4 > 256 && n4 % 256 != 0 && n4 % 256 <= wide_max) ? (double)(n4 / 256) + 0.1 : (double)((n4 + 255) / 256);
         const double r3 = 0.78 * (double)((n3 + 255) / 256);
-        static const bool allow3 = env_int("COSA_GEMM_FR3", 1) != 0;
-        if (g_gemm_variant == 9 || (allow3 && r3 < r4 - 0.05)) {
-            if (epilogue == EPI_BIAS) return launch_v6<EPI_BIAS, 0, 0, 0, 3>(x, w, b, residual, Y, M, N, K, st);
-            if (epilogue == EPI_GELU) return launch_v6<EPI_GELU, 0, 0, 0, 3>(x, w, b, residual, Y, M, N, K, st);
-            return launch_v6<EPI_RESIDUAL, 0, 0, 0, 3>(x, w, b, residual, Y, M, N, K, st);
+        if (g_gemm_variant == 9 || r3 < r4 - 0.05) {
+            if (epilogue == EPI_BIAS) return launch_v6<EPI_BIAS, 0, 3>(x, w, b, residual, Y, M, N, K, st);
+            if (epilogue == EPI_GELU) return launch_v6<EPI_GELU, 0, 3>(x, w, b, residual, Y, M, N, K, st);
+            return launch_v6<EPI_RESIDUAL, 0, 3>(x, w, b, residual, Y, M, N, K, st);
         }
     }
     if (fits_v6 && (g_gemm_variant == 6 || (g_gemm_variant == 0 && M >= big_m))) {       // plain stores
@@ -1499,16 +1422,6 @@ extern "C" int cosa_gemm_bf16(const void *X, const void *W, const void *bias, co
         if (epilogue == EPI_GELU) return launch_v6<EPI_GELU>(x, w, b, residual, Y, M, N, K, st);
         return launch_v6<EPI_RESIDUAL>(x, w, b, residual, Y, M, N, K, st);
     }
-#if COSA_GEMM_EXPERIMENTS
-    if (fits_v6 && g_gemm_variant == 7) {                              // nt stores
-        if (epilogue == EPI_BIAS) return launch_v6<EPI_BIAS, 0, 2>(x, w, b, residual, Y, M, N, K, st);
-        return launch_v6<EPI_GELU, 0, 2>(x, w, b, residual, Y, M, N, K, st);
-    }
-    if (fits_v6 && g_gemm_variant == 8) {                              // nt + sc0 + sc1 stores
-        if (epilogue == EPI_BIAS) return launch_v6<EPI_BIAS, 0, 19>(x, w, b, residual, Y, M, N, K, st);
-        return launch_v6<EPI_GELU, 0, 19>(x, w, b, residual, Y, M, N, K, st);
-    }
-#endif
     static bool attr_done = false;
     if (!attr_done) {
         COSA_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_bf16_kernel<EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes));
@@ -1548,9 +1461,9 @@ extern "C" int cosa_gemm_bf16x3(const void *Xs, const void *Ws, const void *zero
     hipStream_t st = as_stream(stream);
     const op16 *x = static_cast<const op16 *>(Xs), *w = static_cast<const op16 *>(Ws), *b = static_cast<const op16 *>(zeros);
     if (N % 256 == 0 && M >= 4096 && (size_t)(M + 256) * ld * 2 < 0x7fffffffull * 8 && (size_t)N * ld * 2 < 0x7fffffffull) {
-        if (epilogue == EPI_BIAS) return launch_v6<EPI_BIAS, 0, 0, 1>(x, w, b, residual, Y, M, N, K, st, ld, ldy);
-        if (epilogue == EPI_GELU) return launch_v6<EPI_GELU, 0, 0, 1>(x, w, b, residual, Y, M, N, K, st, ld, ldy);
-        return launch_v6<EPI_RESIDUAL, 0, 0, 1>(x, w, b, residual, Y, M, N, K, st, ld, ldy);
+        if (epilogue == EPI_BIAS) return launch_v6<EPI_BIAS, 1>(x, w, b, residual, Y, M, N, K, st, ld, ldy);
+        if (epilogue == EPI_GELU) return launch_v6<EPI_GELU, 1>(x, w, b, residual, Y, M, N, K, st, ld, ldy);
+        return launch_v6<EPI_RESIDUAL, 1>(x, w, b, residual, Y, M, N, K, st, ld, ldy);
     }
     constexpr int kLdsSplit = 2 * BM * CT_LD > (int)kLdsBytes ? 2 * BM * CT_LD : (int)kLdsBytes;
     static bool attr_done = false;
@@ -1597,9 +1510,9 @@ extern "C" int cosa_gemm_f16c8(const void *Xs, const void *Ws, const void *zeros
     COSA_REQUIRE((size_t)256 * ld * 2 < 0x7fffffffull && (size_t)N * ld * 2 < 0x7fffffffull && (size_t)256 * ldy * 4 < 0x7fffffffull, "cosa_gemm_f16c8: panel beyond 2 GiB");
     hipStream_t st = as_stream(stream);
     const op16 *x = static_cast<const op16 *>(Xs), *w = static_cast<const op16 *>(Ws), *b = static_cast<const op16 *>(zeros);
-    if (epilogue == EPI_BIAS) return launch_v6<EPI_BIAS, 0, 0, 3>(x, w, b, residual, Y, M, N, K, st, ld, ldy);
-    if (epilogue == EPI_GELU) return launch_v6<EPI_GELU, 0, 0, 3>(x, w, b, residual, Y, M, N, K, st, ld, ldy);
-    return launch_v6<EPI_RESIDUAL, 0, 0, 3>(x, w, b, residual, Y, M, N, K, st, ld, ldy);
+    if (epilogue == EPI_BIAS) return launch_v6<EPI_BIAS, 3>(x, w, b, residual, Y, M, N, K, st, ld, ldy);
+    if (epilogue == EPI_GELU) return launch_v6<EPI_GELU, 3>(x, w, b, residual, Y, M, N, K, st, ld, ldy);
+    return launch_v6<EPI_RESIDUAL, 3>(x, w, b, residual, Y, M, N, K, st, ld, ldy);
 }
 #endif
 
@@ -1626,9 +1539,9 @@ extern "C" int cosa_gemm_f16c4(const void *Xs, const void *Xscales, const void *
     const op16 *x = static_cast<const op16 *>(Xs), *w = static_cast<const op16 *>(Ws), *b = static_cast<const op16 *>(zeros);
     const unsigned char *xs = static_cast<const unsigned char *>(Xscales), *ws = static_cast<const unsigned char *>(Wscales);
     unsigned char *ys = static_cast<unsigned char *>(Yscales);
-    if (epilogue == EPI_BIAS) return launch_v6<EPI_BIAS, 0, 0, 4>(x, w, b, residual, Y, M, N, K, st, ld, ldy, nullptr, xs, ws, ys);
-    if (epilogue == EPI_GELU) return launch_v6<EPI_GELU, 0, 0, 4>(x, w, b, residual, Y, M, N, K, st, ld, ldy, nullptr, xs, ws, ys);
-    return launch_v6<EPI_RESIDUAL, 0, 0, 4>(x, w, b, residual, Y, M, N, K, st, ld, ldy, nullptr, xs, ws, ys);
+    if (epilogue == EPI_BIAS) return launch_v6<EPI_BIAS, 4>(x, w, b, residual, Y, M, N, K, st, ld, ldy, nullptr, xs, ws, ys);
+    if (epilogue == EPI_GELU) return launch_v6<EPI_GELU, 4>(x, w, b, residual, Y, M, N, K, st, ld, ldy, nullptr, xs, ws, ys);
+    return launch_v6<EPI_RESIDUAL, 4>(x, w, b, residual, Y, M, N, K, st, ld, ldy, nullptr, xs, ws, ys);
 }
 #endif
 
@@ -1643,7 +1556,7 @@ extern "C" int cosa_gemm_bf16_dual_gelu(const void *X, const void *W, const void
     hipStream_t st = as_stream(stream);
     const op16 *x = static_cast<const op16 *>(X), *w = static_cast<const op16 *>(W), *b = static_cast<const op16 *>(bias);
     if (N % 256 == 0 && M >= 4096 && K >= 128 && (size_t)(M + 256) * K * 2 < 0x7fffffffull && (size_t)N * K * 2 < 0x7fffffffull)
-        return launch_v6<EPI_GELU, 0, 0, 2>(x, w, b, nullptr, H, M, N, K, st, K, N, A);
+        return launch_v6<EPI_GELU, 2>(x, w, b, nullptr, H, M, N, K, st, K, N, A);
     constexpr int kLdsDual = 2 * BM * CT_LD > (int)kLdsBytes ? 2 * BM * CT_LD : (int)kLdsBytes;
     static bool attr_done = false;
     if (!attr_done) {
