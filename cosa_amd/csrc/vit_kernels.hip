@@ -548,7 +548,7 @@ __global__ __launch_bounds__(256) void im2col_flip_kernel(const float *__restric
 
 // the same rows as fp16c8 operand rows (c8.hpp: hi fp16 | lo8 | hi8 | aug = (1, 1, 0, ...)): the patch projection of the parity-grade teacher
 __global__ __launch_bounds__(256) void im2col_flip_c8_kernel(const float *__restrict__ x, unsigned char *__restrict__ rows, int B, int C, int H, int W, int P,
-                                                            int flips)
+                                                            int flips, int cls_rows)
 {
     const int h = H / P, w = W / P, KC = C * P * P, K8 = KC / 8;
     const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -574,7 +574,10 @@ __global__ __launch_bounds__(256) void im2col_flip_c8_kernel(const float *__rest
         const float4 a = *reinterpret_cast<const float4 *>(src + xe), d = *reinterpret_cast<const float4 *>(src + xe + 4);
         v[0] = d.w; v[1] = d.z; v[2] = d.y; v[3] = d.x; v[4] = a.w; v[5] = a.z; v[6] = a.y; v[7] = a.x;
     }
-    unsigned char *r = rows + row_id * (size_t)(4 * KC + 128);
+    // cls_rows: the output leaves room for that many (zero) rows in front of every image's patch rows -- the class-token slots of the token
+    // matrix, so that the patch projection's residual epilogue writes the residual stream in place (cosa_im2col_flip_c8_tokens)
+    const size_t out_row = row_id + (size_t)cls_rows * ((size_t)(f * B + b) + 1);
+    unsigned char *r = rows + out_row * (size_t)(4 * KC + 128);
     typedef _Float16 h8 __attribute__((ext_vector_type(8)));
     h8 hi;
     unsigned lo8[2], hi8[2];
@@ -804,11 +807,26 @@ extern "C" int cosa_im2col_flip(const float *x, void *cols, int B, int C, int H,
     const size_t total = (size_t)flips * B * (H / P) * (W / P) * (C * P * P / 8);
     const unsigned grid = (unsigned)((total + 255) / 256);
     if (dtype == 3)
-        hipLaunchKernelGGL(im2col_flip_c8_kernel, dim3(grid), dim3(256), 0, as_stream(stream), x, static_cast<unsigned char *>(cols), B, C, H, W, P, flips);
+        hipLaunchKernelGGL(im2col_flip_c8_kernel, dim3(grid), dim3(256), 0, as_stream(stream), x, static_cast<unsigned char *>(cols), B, C, H, W, P, flips, 0);
     else if (dtype == 1)
         hipLaunchKernelGGL(im2col_flip_kernel<bf16>, dim3(grid), dim3(256), 0, as_stream(stream), x, static_cast<bf16 *>(cols), B, C, H, W, P, flips);
     else
         hipLaunchKernelGGL(im2col_flip_kernel<_Float16>, dim3(grid), dim3(256), 0, as_stream(stream), x, static_cast<_Float16 *>(cols), B, C, H, W, P, flips);
+    COSA_LAUNCH_CHECK();
+    return COSA_OK;
+}
+
+// fp16c8 rows of the im2col view of cat(x, x.flip(-1)) (flips = 2) written INTO a token matrix: image (f, b)'s patch rows start at row
+// (f B + b) (n + cls_rows) + cls_rows, n = (H/P)(W/P); the cls_rows rows in front of them are not touched (the caller keeps them zero, incl. the
+// augmentation block, so the patch GEMM adds nothing there, not even the bias)
+extern "C" int cosa_im2col_flip_c8_tokens(const float *x, void *rows, int B, int C, int H, int W, int P, int flips, int cls_rows, void *stream)
+{
+    COSA_REQUIRE(x && rows && B > 0 && C > 0 && H > 0 && W > 0 && P > 0 && cls_rows >= 0, "cosa_im2col_flip_c8_tokens: bad arguments");
+    COSA_REQUIRE(P % 8 == 0 && H % P == 0 && W % P == 0 && W % 4 == 0, "cosa_im2col_flip_c8_tokens: patch size must be a multiple of 8 and divide H and W");
+    COSA_REQUIRE((flips == 1 || flips == 2) && (C * P * P) % 128 == 0, "cosa_im2col_flip_c8_tokens: flips 1 | 2, C*P*P %% 128 == 0");
+    const size_t total = (size_t)flips * B * (H / P) * (W / P) * (C * P * P / 8);
+    hipLaunchKernelGGL(im2col_flip_c8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), x, static_cast<unsigned char *>(rows), B, C, H, W, P,
+                       flips, cls_rows);
     COSA_LAUNCH_CHECK();
     return COSA_OK;
 }

@@ -436,39 +436,35 @@ class VisionTransformer(nn.Module):
         c4 = self.precision == "fp16c4"
         W4 = self._c4_weights() if c4 else None
         nf = 2 if flip_pairs else 1                                                     # flip_pairs: every batch stands for cat(x, x.flip(-1))
-        pos_rows, cls_rows, shapes, geo = [], [], [], []
-        for x in xs:
-            B, nc, Hh, Ww = x.shape
-            B *= nf
-            h, w = Hh // p, Ww // p
-            pos = self._pos_for_grid(h, w, torch.float32)                              # [1, n+1, D]
-            pos_rows.append(pos[:, 1:].expand(B, -1, -1).reshape(B * h * w, D))         # residual operand of the patch GEMM: the position rows
-            cls_rows.append((self.cls_token.detach().float() + pos[:, :1]).expand(B, -1, -1))
-            shapes.append((B, h * w + 1))
-            geo.append(B * h * w)
-        # the patch projection of ALL scales in one launch (token-wise, like the block projections); its c8 operand rows (images and their
-        # mirror images) come straight from the im2col kernel
-        Kp = xs[0].shape[1] * p * p
-        cols = torch.empty((sum(geo), nn_ops.split_ld(Kp)), device=xs[0].device, dtype=torch.float16)
-        r0 = 0
-        for x, rows in zip(xs, geo):
-            xf = x.float().contiguous()
-            _C.check(_C.lib().cosa_im2col_flip(_C.ptr(xf), _C.ptr(cols[r0:r0 + rows]), x.shape[0], x.shape[1], x.shape[2], x.shape[3], p, nf, 3,
-                                               _C.stream_ptr()), "cosa_im2col_flip")
-            r0 += rows
-        tok = pos_rows[0].contiguous() if len(pos_rows) == 1 else torch.cat(pos_rows, 0)
-        nn_ops.gemm_c8(cols, W["patch"], cols.shape[0], D, Kp, nn_ops.EPI_RESIDUAL, residual=tok, out=tok)
-        toks, r0 = [], 0
-        for (B, N), cls in zip(shapes, cls_rows):
-            toks.append(torch.cat((cls, tok[r0:r0 + B * (N - 1)].view(B, N - 1, D)), dim=1).reshape(-1, D))
-            r0 += B * (N - 1)
-        xr = toks[0].contiguous() if len(toks) == 1 else torch.cat(toks, 0)
+        # token assembly without concatenations: the residual stream xr [sum_i B_i (n_i + 1), D] starts as (cls + pos_0 | pos rows) per image, the
+        # im2col kernel writes the c8 rows of the patches (images and their mirror images) into a token-shaped operand whose class-token rows
+        # stay zero (augmentation block included: no bias there), and the patch projection of ALL scales -- one launch, token-wise like the
+        # block projections -- adds into xr in place through its fp32 residual epilogue
+        shapes = [(nf * x.shape[0], (x.shape[2] // p) * (x.shape[3] // p) + 1) for x in xs]
         offs = [0]
         for B, N in shapes:
             offs.append(offs[-1] + B * N)
         M = offs[-1]
-        bf = self._c8_buffers(M, xr.device)
+        dev = xs[0].device
+        Kp = xs[0].shape[1] * p * p
+        bf = self._c8_buffers(M, dev)
+        cols = bf.get("cols")
+        if cols is None or cols.shape[1] != nn_ops.split_ld(Kp):
+            cols = bf["cols"] = torch.zeros((M, nn_ops.split_ld(Kp)), device=dev, dtype=torch.float16)      # (class-token rows: zero for good)
+        xr = torch.empty((M, D), device=dev, dtype=torch.float32)
+        cls = self.cls_token.detach().float().reshape(1, 1, D)
+        for x, (B, N), o0, o1 in zip(xs, shapes, offs[:-1], offs[1:]):
+            h, w = x.shape[2] // p, x.shape[3] // p
+            pos = self._pos_for_grid(h, w, torch.float32)                              # [1, n+1, D]
+            first = torch.cat((pos[:, :1] + cls, pos[:, 1:]), dim=1)                    # (a [n+1, D] tensor: small)
+            xr[o0:o1].view(B, N, D).copy_(first.expand(B, N, D))
+            xf = x.float().contiguous()
+            _C.check(_C.lib().cosa_im2col_flip_c8_tokens(_C.ptr(xf), _C.ptr(cols[o0:o1]), x.shape[0], x.shape[1], x.shape[2], x.shape[3], p, nf, 1,
+                                                         _C.stream_ptr()), "cosa_im2col_flip_c8_tokens")
+        nn_ops.gemm_c8(cols, W["patch"], M, D, Kp, nn_ops.EPI_RESIDUAL, residual=xr, out=xr)
         Hd = self.blocks[0].mlp.fc1.weight.shape[0]
+        if c4 and "y_sc" not in bf:                  # (the buffers were created under another precision setting)
+            bf["y_sc"], bf["h_sc"] = nn_ops.c4_scales(M, D, dev), nn_ops.c4_scales(M, Hd, dev)
         depth = len(self.blocks)
         aux_idx = self.aux_layer % depth
         aux = None

@@ -252,6 +252,9 @@ void cosa_gemm_set_stamp_slot(void *slot);
  * x [B,C,H,W] fp32: rows of the images first, then (flips = 2) of their horizontal mirror images.  P % 8 == 0, P | H, P | W.
  * dtype 3: the rows as fp16c8 operand rows (hi fp16 | lo8 | hi8 | aug = (1, 1, 0, ...), 4*C*P*P + 128 bytes each; see cosa_c8_rows).    */
 int cosa_im2col_flip(const float *x, void *cols, int B, int C, int H, int W, int P, int flips, int dtype, void *stream);
+/* the dtype-3 form writing into a token matrix with cls_rows free rows in front of every image's patch rows (kept zero by the caller): the
+ * patch projection's fp32 residual epilogue then produces the residual stream [images, 1 + n, D] in place, without concatenations */
+int cosa_im2col_flip_c8_tokens(const float *x, void *rows, int B, int C, int H, int W, int P, int flips, int cls_rows, void *stream);
 /* vit.py:303-313 (prepare_tokens: cat(cls_token, patch tokens) + interpolated pos_embed) for the no-grad passes, written straight into
  * the fp32 residual stream: out [B, n+1, D] = (cls [D] | tok [B, n, D]) + pos [n+1, D]; tok / cls / pos share one 16-bit type
  * (dtype 1 = bf16, 2 = fp16), each sum is rounded to that type before it is widened (the 16-bit torch expression's value); D % 8 == 0. */
