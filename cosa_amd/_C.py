@@ -132,6 +132,7 @@ _SIGS.update({
     "cosa_c4_record_bytes": (c_size_t, []),
     "cosa_c4_rows_batched": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "cosa_layernorm_c4": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
+    "cosa_attn_fwd_f16c4": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
     "cosa_gemm_f16c4": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                 c_int, c_void_p]),
 })

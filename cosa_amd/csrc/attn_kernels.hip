@@ -17,6 +17,7 @@
 #include "kernels.hpp"
 #include "op16.hpp"
 #include "c8.hpp"
+#include "c4.hpp"
 #include <type_traits>
 #include <cstdlib>
 
@@ -276,12 +277,17 @@ __global__ __launch_bounds__(256) void attn_fwd_x3_kernel(const op16 *__restrict
 // NW: waves per workgroup (64 queries each) sharing one K/V tile stream.  Every LDS-DMA instruction costs its wave 100-185 issue cycles
 // (timing ablation at N = 1765: the DMA issue was a quarter of the kernel) and a tile is 16 of them whatever the workgroup size: with
 // NW = 4 a wave issues 4 per tile instead of 8.  Long sequences take NW = 4 (two workgroups per CU), short ones NW = 2 (finer query blocks).
-template <bool DMA, bool C8OUT = false, int NW = 2>
+// OUTM = 2 (fp16 build): the output leaves as fp16c4 rows (c4.hpp): the 16 columns 32 d + 16 gp .. + 15 of a query are one MX block, held by
+// the query's two lanes (hh = 0 / 1): their maxima meet by one lane swap, every lane converts its eight values with the shared scale, a
+// second swap hands the hh = 0 lane the block's lo' half and the hh = 1 lane its hi half (8-byte stores), the hh = 0 lane stores the scale
+// byte at the row's place in the operand's scale tensor (row0 = first row of this launch's images in that operand).
+template <bool DMA, int OUTM = 0, int NW = 2>
 __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const op16 *__restrict__ qkv, const op16 *__restrict__ vt,
                                                        op16 *__restrict__ out, float *__restrict__ lse,
                                                        int N, int Npad, int H, int nblk, int ngroups, float scale_log2e,
-                                                       unsigned long long *__restrict__ stamps)
+                                                       unsigned long long *__restrict__ stamps, unsigned char *__restrict__ out_scales = nullptr, int row0 = 0)
 {
+    constexpr bool C8OUT = OUTM == 1, C4OUT = OUTM == 2;
     __shared__ __attribute__((aligned(16))) unsigned char smem[(DMA ? 4 : 2) * BK * 128];
     if (stamps && threadIdx.x == 0) atomicMin(&stamps[2 * (blockIdx.x & 63)], __builtin_amdgcn_s_memrealtime());     // 64 shards: one address would serialise the workgroups' atomics
     unsigned char *Ks = smem;
@@ -445,7 +451,64 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const op16 *__restric
         float lt = l[u] + __shfl_xor(l[u], 32, 64);
         const float inv = 1.0f / lt;
         const int q = q0 + 32 * u + r;
-        if (q < N && C8OUT) {
+        if (q < N && C4OUT) {
+#if COSA_OP_F16
+            const int D = H * HD;
+            unsigned char *row = reinterpret_cast<unsigned char *>(out) + ((size_t)b * N + q) * (size_t)(4 * D + 128);
+            const int rabs = row0 + b * N + q, Kq = D >> 7;
+#pragma unroll
+            for (int gp = 0; gp < 2; gp++)
+#pragma unroll
+                for (int d = 0; d < 2; d++) {
+                    unsigned hiw[2][2];
+                    float hv[2][4], lv[2][4], amax = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 2; e++) {
+                        const int g = 2 * gp + e;
+                        _Float16 hi[4];
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            const float v = o[u][d][4 * g + j] * inv;
+                            hi[j] = (_Float16)v;
+                            hv[e][j] = (float)hi[j];
+                            lv[e][j] = (v - hv[e][j]) * kC4LoScale;
+                            amax = __builtin_fmaxf(amax, __builtin_fmaxf(__builtin_fabsf(hv[e][j]), __builtin_fabsf(lv[e][j])));
+                        }
+                        hiw[e][0] = __builtin_bit_cast(unsigned, (op16x2){hi[0], hi[1]});
+                        hiw[e][1] = __builtin_bit_cast(unsigned, (op16x2){hi[2], hi[3]});
+                    }
+                    const unsigned au = __builtin_bit_cast(unsigned, amax);
+                    const auto am = __builtin_amdgcn_permlane32_swap(au, au, false, false);          // (non-negative floats order like their bits)
+                    const int ex = c4_block_exp(__builtin_bit_cast(float, am[0] > am[1] ? am[0] : am[1]));
+                    const float sc = c4_pow2(ex);
+                    unsigned LO = 0, HI = 0;                 // [chunk e = 0 (16 bits) | chunk e = 1 (16 bits)]
+                    LO = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(LO, lv[0][0], lv[0][1], sc, 0);
+                    LO = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(LO, lv[0][2], lv[0][3], sc, 1);
+                    LO = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(LO, lv[1][0], lv[1][1], sc, 2);
+                    LO = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(LO, lv[1][2], lv[1][3], sc, 3);
+                    HI = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(HI, hv[0][0], hv[0][1], sc, 0);
+                    HI = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(HI, hv[0][2], hv[0][3], sc, 1);
+                    HI = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(HI, hv[1][0], hv[1][1], sc, 2);
+                    HI = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(HI, hv[1][2], hv[1][3], sc, 3);
+                    const auto a0 = __builtin_amdgcn_permlane32_swap(hiw[0][0], hiw[1][0], false, false);
+                    const auto a1 = __builtin_amdgcn_permlane32_swap(hiw[0][1], hiw[1][1], false, false);
+                    // hh = 0: P = own LO, Q = the partner's LO;  hh = 1: P = the partner's HI, Q = own HI  (columns 0-3 | 4-7 | 8-11 | 12-15 of the block
+                    // are chunk e = 0 of hh = 0, e = 0 of hh = 1, e = 1 of hh = 0, e = 1 of hh = 1)
+                    const auto pq = __builtin_amdgcn_permlane32_swap(LO, HI, false, false);
+                    const unsigned w0 = (pq[0] & 0xffffu) | (pq[1] << 16), w1 = (pq[0] >> 16) | (pq[1] & 0xffff0000u);
+                    const int col = h * HD + 32 * d + 16 * gp;
+                    *reinterpret_cast<uint4 *>(row + 2 * (col + 8 * hh)) = make_uint4(a0[0], a1[0], a0[1], a1[1]);
+                    *reinterpret_cast<uint2 *>(row + 2 * D + col + 8 * hh) = make_uint2(w0, w1);
+                    if (hh == 0) out_scales[c4_scale_off_x(rabs, col >> 7, (col & 127) >> 4, Kq)] = (unsigned char)c4_scale_byte(ex, 0);
+                }
+            if (h == 0) {                       // augmentation block (1, 1, 0, ...)
+                uint4 z = {0u, 0u, 0u, 0u}, one = {0x3c003c00u, 0u, 0u, 0u};
+#pragma unroll
+                for (int c = 0; c < 4; c++) *reinterpret_cast<uint4 *>(row + 4 * D + 64 * hh + 16 * c) = (hh == 0 && c == 0) ? one : z;
+            }
+            if (hh == 0 && lse) lse[((size_t)b * H + h) * N + q] = (m[u] + __builtin_amdgcn_logf(lt)) * 0.6931471805599453f;
+#endif
+        } else if (q < N && C8OUT) {
 #if COSA_OP_F16
             const int D = H * HD;
             unsigned char *row = reinterpret_cast<unsigned char *>(out) + ((size_t)b * N + q) * (size_t)(4 * D + 128);
@@ -856,7 +919,7 @@ extern "C" int cosa_attn_fwd(const void *qkv, void *out, float *lse, int B, int 
         hipLaunchKernelGGL(attn_fwd2_kernel<false>, dim3(((N + 127) / 128) * ((B * H + 7) / 8 * 8)), dim3(128), 0, st, q, vt, o, lse, N, Npad, H, (N + 127) / 128,
                            B * H, sl2, stp);
     else if (wide)
-        hipLaunchKernelGGL((attn_fwd2_kernel<true, false, 4>), grid, dim3(256), 0, st, q, vt, o, lse, N, Npad, H, nblk, B * H, sl2, stp);
+        hipLaunchKernelGGL((attn_fwd2_kernel<true, 0, 4>), grid, dim3(256), 0, st, q, vt, o, lse, N, Npad, H, nblk, B * H, sl2, stp);
     else
         hipLaunchKernelGGL(attn_fwd2_kernel<true>, grid, dim3(128), 0, st, q, vt, o, lse, N, Npad, H, nblk, B * H, sl2, stp);
     COSA_LAUNCH_CHECK();
@@ -877,13 +940,40 @@ extern "C" int cosa_attn_fwd_f16c8(const void *qkv, void *out_c8, float *lse, in
     const bool wide = attn_wide(B, N, H);
     const int nblk = wide ? (N + 255) / 256 : (N + 127) / 128;
     if (wide)
-        hipLaunchKernelGGL((attn_fwd2_kernel<true, true, 4>), dim3(nblk * ((B * H + 7) / 8 * 8)), dim3(256), 0, as_stream(stream), static_cast<const op16 *>(qkv),
+        hipLaunchKernelGGL((attn_fwd2_kernel<true, 1, 4>), dim3(nblk * ((B * H + 7) / 8 * 8)), dim3(256), 0, as_stream(stream), static_cast<const op16 *>(qkv),
                            static_cast<const op16 *>(nullptr), static_cast<op16 *>(out_c8), lse, N, Npad, H, nblk, B * H, scale * 1.4426950408889634f,
                            reinterpret_cast<unsigned long long *>(stamps));
     else
-        hipLaunchKernelGGL((attn_fwd2_kernel<true, true>), dim3(nblk * ((B * H + 7) / 8 * 8)), dim3(128), 0, as_stream(stream), static_cast<const op16 *>(qkv),
+        hipLaunchKernelGGL((attn_fwd2_kernel<true, 1>), dim3(nblk * ((B * H + 7) / 8 * 8)), dim3(128), 0, as_stream(stream), static_cast<const op16 *>(qkv),
                            static_cast<const op16 *>(nullptr), static_cast<op16 *>(out_c8), lse, N, Npad, H, nblk, B * H, scale * 1.4426950408889634f,
                            reinterpret_cast<unsigned long long *>(stamps));
+    COSA_LAUNCH_CHECK();
+    return COSA_OK;
+}
+#endif
+
+#if COSA_OP_F16
+// attention on plain fp16 qkv rows -> fp16c4 rows out_c4 [B*N, 4 H HD + 128 bytes] + their scale bytes in out_scales, the scale tensor of the
+// WHOLE operand the rows belong to (cosa_c4_scale_bytes(rows of that operand, H HD)); row0 = index of out_c4's first row in that operand
+extern "C" int cosa_attn_fwd_f16c4(const void *qkv, void *out_c4, void *out_scales, int row0, float *lse, int B, int N, int H, int head_dim,
+                                   float scale, uint64_t *stamps, void *stream)
+{
+    COSA_REQUIRE(qkv && out_c4 && out_scales && row0 >= 0, "cosa_attn_fwd_f16c4: null pointer");
+    COSA_REQUIRE(head_dim == HD, "cosa_attn_fwd_f16c4: head_dim must be 64");
+    COSA_REQUIRE(B > 0 && N > 0 && H > 0 && B <= 65535 && H <= 65535 && (H * HD) % 256 == 0, "cosa_attn_fwd_f16c4: bad shape (H * 64 %% 256 == 0)");
+    COSA_REQUIRE((size_t)N * 3 * H * HD * 2 < 0x7fffffffull, "cosa_attn_fwd_f16c4: one image's qkv rows must stay below 2 GiB (buffer addressing)");
+    const int Npad = (N + BK - 1) / BK * BK;
+    const bool wide = attn_wide(B, N, H);
+    const int nblk = wide ? (N + 255) / 256 : (N + 127) / 128;
+    unsigned char *sc = static_cast<unsigned char *>(out_scales);
+    if (wide)
+        hipLaunchKernelGGL((attn_fwd2_kernel<true, 2, 4>), dim3(nblk * ((B * H + 7) / 8 * 8)), dim3(256), 0, as_stream(stream), static_cast<const op16 *>(qkv),
+                           static_cast<const op16 *>(nullptr), static_cast<op16 *>(out_c4), lse, N, Npad, H, nblk, B * H, scale * 1.4426950408889634f,
+                           reinterpret_cast<unsigned long long *>(stamps), sc, row0);
+    else
+        hipLaunchKernelGGL((attn_fwd2_kernel<true, 2>), dim3(nblk * ((B * H + 7) / 8 * 8)), dim3(128), 0, as_stream(stream), static_cast<const op16 *>(qkv),
+                           static_cast<const op16 *>(nullptr), static_cast<op16 *>(out_c4), lse, N, Npad, H, nblk, B * H, scale * 1.4426950408889634f,
+                           reinterpret_cast<unsigned long long *>(stamps), sc, row0);
     COSA_LAUNCH_CHECK();
     return COSA_OK;
 }

@@ -98,6 +98,10 @@ class VisionTransformer(nn.Module):
         self.defer_wgrad = True        # the blocks' weight gradients in batched launches (nn_ops.DeferredWgrad) ...
         self.defer_groups = None       # ... one launch per group of depth / defer_groups blocks; None: 1 on a single GPU, 4 under data parallelism
         self.c8_plain_from = None      # fp16c8 / fp16c4: blocks with index >= this run on plain fp16 operands ("fp16c8-9": the last three)
+        # fp16c4: the output projection too on fp16c4 operands (the attention kernel then writes c4 rows)?  Measured (round 4, three seeds, 448^2):
+        # the auxiliary CAM's worst error goes from 4.5e-4 to 5.1e-4 (margin on the 1e-3 bar 2.2x -> 1.95x) for 0.15 ms per step, so it is off:
+        # proj stays on fp16c8 operands (e5m2 corrections), 10 % of the projection work
+        self.c4_proj = False
         self._pos_cache = {}
         _trunc_normal_(self.pos_embed)
         _trunc_normal_(self.cls_token)
@@ -361,8 +365,9 @@ class VisionTransformer(nn.Module):
         for i, blk in enumerate(self.blocks):
             if self.c8_plain_from is not None and i >= self.c8_plain_from:
                 continue
-            if self.precision == "fp16c4":          # qkv / fc1 / fc2 run on fp16c4 operands (_c4_weights)
-                items += [(f"{i}.proj", blk.attn.proj.weight, blk.attn.proj.bias)]
+            if self.precision == "fp16c4":          # qkv / fc1 / fc2 (and proj with c4_proj) run on fp16c4 operands (_c4_weights)
+                if not self.c4_proj:
+                    items += [(f"{i}.proj", blk.attn.proj.weight, blk.attn.proj.bias)]
                 continue
             items += [(f"{i}.qkv", blk.attn.qkv.weight, blk.attn.qkv.bias), (f"{i}.proj", blk.attn.proj.weight, blk.attn.proj.bias),
                       (f"{i}.fc1", blk.mlp.fc1.weight, blk.mlp.fc1.bias), (f"{i}.fc2", blk.mlp.fc2.weight, blk.mlp.fc2.bias)]
@@ -385,8 +390,8 @@ class VisionTransformer(nn.Module):
 
     def _c4_weights(self):
         """fp16c4 weight rows + scale tensors (csrc/c4.hpp) of the projections that run on fp16c4 operands -- qkv, fc1, fc2 of the corrected
-        blocks; proj and the patch projection stay fp16c8 (their activation operands come out of the attention / im2col kernels as c8 rows,
-        and they are 10 % of the projection work) -- rebuilt from the fp32 masters on every pass by ONE batched launch"""
+        blocks (and proj with `c4_proj`); the patch projection stays fp16c8 (its operand comes out of the im2col kernel as c8 rows) --
+        rebuilt from the fp32 masters on every pass by ONE batched launch"""
         import numpy as np
         from .. import _C
         items = []
@@ -395,6 +400,8 @@ class VisionTransformer(nn.Module):
                 continue
             items += [(f"{i}.qkv", blk.attn.qkv.weight, blk.attn.qkv.bias), (f"{i}.fc1", blk.mlp.fc1.weight, blk.mlp.fc1.bias),
                       (f"{i}.fc2", blk.mlp.fc2.weight, blk.mlp.fc2.bias)]
+            if self.c4_proj:
+                items.append((f"{i}.proj", blk.attn.proj.weight, blk.attn.proj.bias))
         ent = self.__dict__.get("_c4_w")
         key = tuple((n, w.data_ptr(), b.data_ptr()) for n, w, b in items)
         if ent is None or ent["key"] != key:
@@ -423,8 +430,8 @@ class VisionTransformer(nn.Module):
             mk = lambda cols: torch.zeros((M, cols), device=dev, dtype=torch.float16)
             ent = {"y": mk(nn_ops.split_ld(D)), "qkv": mk(3 * D), "o": mk(nn_ops.split_ld(D)), "h": mk(nn_ops.split_ld(Hd))}
             ent["h"][:, 2 * Hd:2 * Hd + 2] = 1
-            if self.precision == "fp16c4":          # the scale tensors of the c4 activation operands (LayerNorm output, GELU output)
-                ent["y_sc"], ent["h_sc"] = nn_ops.c4_scales(M, D, dev), nn_ops.c4_scales(M, Hd, dev)
+            if self.precision == "fp16c4":          # the scale tensors of the c4 activation operands (LayerNorm, attention and GELU outputs)
+                ent["y_sc"], ent["o_sc"], ent["h_sc"] = nn_ops.c4_scales(M, D, dev), nn_ops.c4_scales(M, D, dev), nn_ops.c4_scales(M, Hd, dev)
             bufs[(M, dev)] = ent
         return ent
 
@@ -464,7 +471,7 @@ class VisionTransformer(nn.Module):
         nn_ops.gemm_c8(cols, W["patch"], M, D, Kp, nn_ops.EPI_RESIDUAL, residual=xr, out=xr)
         Hd = self.blocks[0].mlp.fc1.weight.shape[0]
         if c4 and "y_sc" not in bf:                  # (the buffers were created under another precision setting)
-            bf["y_sc"], bf["h_sc"] = nn_ops.c4_scales(M, D, dev), nn_ops.c4_scales(M, Hd, dev)
+            bf["y_sc"], bf["o_sc"], bf["h_sc"] = nn_ops.c4_scales(M, D, dev), nn_ops.c4_scales(M, D, dev), nn_ops.c4_scales(M, Hd, dev)
         depth = len(self.blocks)
         aux_idx = self.aux_layer % depth
         aux = None
@@ -490,17 +497,23 @@ class VisionTransformer(nn.Module):
                     aux = xr
                 continue
             if c4:
-                # fp16c4: LayerNorm and the GELU epilogue write c4 rows + scale bytes; qkv / fc1 / fc2 on the FP4 block-scaled MFMA.  The
-                # output projection stays fp16c8 (its operand is the attention kernel's c8 output)
+                # fp16c4: LayerNorm and the GELU epilogue (and, with c4_proj, the attention kernel) write c4 rows + scale bytes; qkv / fc1 /
+                # fc2 run on the FP4 block-scaled MFMA, the output projection on fp16c8 operands unless c4_proj
                 nn_ops.layernorm_c4(xr, f(blk.norm1.weight), f(blk.norm1.bias), blk.norm1.eps, out=bf["y"], scales=bf["y_sc"])
                 nn_ops.gemm_c4(bf["y"], bf["y_sc"], *W4[f"{i}.qkv"], M, 3 * D, D, nn_ops.EPI_BIAS, out=bf["qkv"], ldy=3 * D)
             else:
                 nn_ops.layernorm_c8(xr, f(blk.norm1.weight), f(blk.norm1.bias), blk.norm1.eps, out=bf["y"])
                 nn_ops.gemm_c8(bf["y"], W[f"{i}.qkv"], M, 3 * D, D, nn_ops.EPI_BIAS, out=bf["qkv"], ldy=3 * D)
-            for (B, N), o0, o1 in zip(shapes, offs[:-1], offs[1:]):
-                nn_ops.attn_fwd_c8(bf["qkv"][o0:o1].view(B, N, 3 * D), B, N, H, bf["o"][o0:o1])
             xn = torch.empty_like(xr) if aux is xr else xr              # right after the auxiliary layer: keep its output, no clone
-            nn_ops.gemm_c8(bf["o"], W[f"{i}.proj"], M, D, D, nn_ops.EPI_RESIDUAL, residual=xr, out=xn)
+            for (B, N), o0, o1 in zip(shapes, offs[:-1], offs[1:]):
+                if c4 and self.c4_proj:
+                    nn_ops.attn_fwd_c4(bf["qkv"][o0:o1].view(B, N, 3 * D), B, N, H, bf["o"][o0:o1], bf["o_sc"], o0)
+                else:
+                    nn_ops.attn_fwd_c8(bf["qkv"][o0:o1].view(B, N, 3 * D), B, N, H, bf["o"][o0:o1])
+            if c4 and self.c4_proj:
+                nn_ops.gemm_c4(bf["o"], bf["o_sc"], *W4[f"{i}.proj"], M, D, D, nn_ops.EPI_RESIDUAL, residual=xr, out=xn)
+            else:
+                nn_ops.gemm_c8(bf["o"], W[f"{i}.proj"], M, D, D, nn_ops.EPI_RESIDUAL, residual=xr, out=xn)
             xr = xn
             if c4:
                 nn_ops.layernorm_c4(xr, f(blk.norm2.weight), f(blk.norm2.bias), blk.norm2.eps, out=bf["y"], scales=bf["y_sc"])

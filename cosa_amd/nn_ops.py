@@ -525,6 +525,19 @@ def gemm_c4(xs, xsc, ws, wsc, M, N, K, epilogue=EPI_BIAS, residual=None, out=Non
     return (out, out_scales) if epilogue == EPI_GELU else out
 
 
+def attn_fwd_c4(qkv, B, N, H, out_c4, out_scales, row0, lse=None):
+    """attention on plain fp16 qkv [B, N, 3 H 64] -> c4 rows out_c4 [B*N, 2 H 64 + 64 fp16 units] (a row slice of an operand) + the scale bytes of
+    those rows in out_scales, the scale tensor of the whole operand; row0 = index of out_c4's first row in that operand"""
+    assert qkv.dtype == torch.float16 and qkv.is_contiguous() and out_c4.stride(0) == split_ld(H * 64)
+    fl = 4.0 * B * H * N * N * 64
+    st = stamps.next_slot(fl) if stamps is not None else None
+    with _C.profiled("attn_fwd"):
+        _C.check(_C.lib().cosa_attn_fwd_f16c4(_C.ptr(qkv), _C.ptr(out_c4), _C.ptr(out_scales), int(row0), _C.ptr(lse), B, N, H, 64, 0.125, st,
+                                              _C.stream_ptr()), "cosa_attn_fwd_f16c4")
+    _flops["attn_fwd"] = _flops.get("attn_fwd", 0) + fl
+    return out_c4
+
+
 def attn_fwd_c8(qkv, B, N, H, out_c8, lse=None):
     """attention on plain fp16 qkv [B, N, 3 H 64] -> c8 rows out_c8 [B*N, 2 H 64 + 64 fp16 units] (hi | lo8 | hi8 | aug)"""
     assert qkv.dtype == torch.float16 and qkv.is_contiguous() and out_c8.stride(0) == split_ld(H * 64)

@@ -396,6 +396,10 @@ int cosa_layernorm_c4(const float *x, const float *gamma, const float *beta, voi
                       float eps, void *stream);
 int cosa_gemm_f16c4(const void *Xs, const void *Xscales, const void *Ws, const void *Wscales, const void *zeros, const float *residual,
                     void *Y, void *Yscales, int M, int N, int K, int epilogue, int ldy, void *stream);
+/* attention on plain fp16 qkv rows [B, N, 3, H, 64] -> fp16c4 rows [B*N, 4*H*64 + 128 bytes] (incl. the augmentation block) for the c4 output
+ * projection; out_scales = the scale tensor of the WHOLE operand these rows belong to, row0 = the index of out_c4's first row in it */
+int cosa_attn_fwd_f16c4(const void *qkv, void *out_c4, void *out_scales, int row0, float *lse, int B, int N, int H, int head_dim, float scale,
+                        uint64_t *stamps, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * main.py:167-212 + utils/seg_helper.py:800-813,199-230  the student's dense losses, fused:

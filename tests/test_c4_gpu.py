@@ -227,3 +227,40 @@ def test_gemm_c4_is_bit_identical_run_to_run_and_more_accurate_than_fp16():
     y16 = nn_ops.gemm_bf16(x.cuda().half(), w.cuda().half(), b.cuda().half(), 2, residual=res)
     e4, e16 = (a.cpu().double() - exact).abs().max().item(), (y16.cpu().double() - exact).abs().max().item()
     assert e4 < 0.3 * e16, (e4, e16)
+
+
+@pytest.mark.parametrize("B,N,row0", [(2, 197, 0), (3, 785, 512), (1, 300, 77)])
+def test_attention_c4_output_rows(B, N, row0):
+    """cosa_attn_fwd_f16c4 against cosa_attn_fwd_f16c8 on the same fp16 qkv: the fp16 hi parts are the same bits (same attention arithmetic),
+    the blocks are well-formed (scale bytes -- at the rows' place in the whole operand's scale tensor, offset row0 -- and hi nibbles follow
+    from the stored hi parts bit for bit), and the lo' nibbles agree with the c8 rows' e5m2 lo bytes within their quantisation steps"""
+    from cosa_amd import nn_ops
+    H, D = 12, 768
+    g = torch.Generator().manual_seed(B * N)
+    qkv = (torch.randn(B, N, 3 * D, generator=g) * 0.7).cuda().half()
+    o8 = torch.zeros((B * N, nn_ops.split_ld(D)), device="cuda", dtype=torch.float16)
+    nn_ops.attn_fwd_c8(qkv, B, N, H, o8)
+    R = row0 + B * N + 5
+    full = torch.zeros((R, nn_ops.split_ld(D)), device="cuda", dtype=torch.float16)
+    sc = nn_ops.c4_scales(R, D, "cuda")
+    nn_ops.attn_fwd_c4(qkv, B, N, H, full[row0:row0 + B * N], sc, row0)
+    torch.cuda.synchronize()
+    hi4_, blocks, aug = split_fields(full, R, D)
+    raw8 = o8.view(torch.uint8).reshape(B * N, 4 * D + 128).cpu().numpy()
+    hi8rows = raw8[:, :2 * D].copy().view(np.float16)
+    sl = slice(row0, row0 + B * N)
+    assert np.array_equal(hi4_[sl].view(np.uint16), hi8rows.view(np.uint16))
+    want_aug = np.zeros((B * N, 64), np.float16)
+    want_aug[:, :2] = 1
+    assert np.array_equal(aug[sl].view(np.uint16), want_aug.view(np.uint16))
+    yh, yl, yh4, sb = decode_operand(full, sc, R, D, False)
+    hb = yh[sl].astype(np.float32).reshape(B * N, D // 16, 16)
+    e = _block_exp(np.abs(hb).max(2))
+    assert np.array_equal(sb[sl], np.clip(e + 127, 0, 254))
+    scale = (2.0 ** e)[..., None]
+    assert np.array_equal(yh4[sl].reshape(B * N, D // 16, 16), _decode(_e2m1_codes(hb, scale)) * scale)
+    lo8 = torch.from_numpy(raw8[:, 2 * D:3 * D].copy()).view(torch.float8_e5m2).float().numpy()          # (v - hi) * 2^11 in e5m2
+    lo4 = yl[sl].reshape(B * N, D // 16, 16)
+    step = np.maximum(scale * 2.0, np.abs(lo8.reshape(B * N, D // 16, 16)) * 0.26)                           # e2m1 step <= 2 scale; e5m2 step 25 %
+    assert (np.abs(lo4 - lo8.reshape(B * N, D // 16, 16)) <= step + 1e-12).all()
+    assert (sc.cpu().numpy()[scale_offsets(R, D, False)][:row0] == 0).all()                                  # rows outside the launch untouched
