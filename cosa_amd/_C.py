@@ -127,6 +127,8 @@ _SIGS.update({
     "cosa_layernorm_c8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     "cosa_gemm_f16c8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "cosa_attn_fwd_f16c8": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
+    "cosa_radix_sort_workspace_bytes": (c_size_t, [ctypes.c_longlong]),
+    "cosa_radix_sort_pairs": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_longlong, c_int, c_void_p, c_size_t, c_void_p]),
     "cosa_c4_scale_bytes": (c_size_t, [c_int, c_int]),
     "cosa_c4_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, ctypes.c_longlong, c_int, c_int, c_void_p]),
     "cosa_c4_record_bytes": (c_size_t, []),

@@ -89,15 +89,26 @@ __device__ __forceinline__ float wave_sum(float v)
 // run (round 2 used float atomics in LDS and in global memory here: the last source of run-to-run differences in the student's
 // gradients, together with the weight-gradient GEMM's).  Forward sums (up to ~1e7): 32 fractional bits; gradient cells (|sum| < 32):
 // 52 fractional bits, i.e. finer than fp32's own resolution for every value above 2^-28.
-__device__ __forceinline__ unsigned long long fix32(float v) { return (unsigned long long)(long long)__builtin_rint((double)v * 4294967296.0); }
-__device__ __forceinline__ unsigned long long fix52(float v) { return (unsigned long long)(long long)__builtin_rint((double)v * 4503599627370496.0); }
+// A value the fixed-point form cannot carry -- NaN, an infinity (a diverged loss), or a magnitude beyond the range that keeps the 64-bit sum from
+// wrapping (forward sums: |v| < 2^31; gradient cells: at most 1024 adds of |v| < 1 each stay inside 52 + 11 bits) -- contributes nothing and
+// sets a sticky flag word instead; the kernels that convert the sums back to fp32 then write NaN, as the float atomics of round 2 would have.
+__device__ __forceinline__ unsigned long long fix32(float v, unsigned long long *flag)
+{
+    if (!(__builtin_fabsf(v) < 2147483648.0f)) { atomicOr(flag, 1ull); return 0ull; }
+    return (unsigned long long)(long long)__builtin_rint((double)v * 4294967296.0);
+}
+__device__ __forceinline__ unsigned long long fix52(float v, unsigned long long *flag)
+{
+    if (!(__builtin_fabsf(v) < 1.0f)) { atomicOr(flag, 1ull); return 0ull; }
+    return (unsigned long long)(long long)__builtin_rint((double)v * 4503599627370496.0);
+}
 
 // ---- forward ---------------------------------------------------------------------------------------------------
 // sums[8] = {bgA_sum, bgA_cnt, fgA_sum, fgA_cnt, bgB_sum, bgB_cnt, fgB_sum, fgB_cnt}
 __global__ __launch_bounds__(256) void seg_loss_fwd_kernel(const float *__restrict__ seg_lr, const float *__restrict__ maskA,
                                                           const float *__restrict__ maskB, const float *__restrict__ simg,
                                                           const int32_t *__restrict__ boxes, unsigned long long *__restrict__ sums,
-                                                          float *__restrict__ s_seg, float *__restrict__ s_img,
+                                                          unsigned long long *__restrict__ flag, float *__restrict__ s_seg, float *__restrict__ s_img,
                                                           float *__restrict__ roi, unsigned char *__restrict__ unlabel,
                                                           int K, int hs, int ws, int S, float sy, float sx)
 {
@@ -154,15 +165,15 @@ __global__ __launch_bounds__(256) void seg_loss_fwd_kernel(const float *__restri
     // 64 shards of the 8 sums (workgroup number & 63): thousands of workgroups adding to the same 8 addresses serialise at ~20 ns per add;
     // integer addition is associative, so the total does not depend on the sharding either
     const unsigned wg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-    if (tid < 8) atomicAdd(&sums[(wg & 63u) * 8 + tid], fix32(red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid]));
+    if (tid < 8) atomicAdd(&sums[(wg & 63u) * 8 + tid], fix32(red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid], flag));
 }
 
-__global__ void seg_loss_sums_kernel(const unsigned long long *__restrict__ fix, float *__restrict__ sums)
+__global__ void seg_loss_sums_kernel(const unsigned long long *__restrict__ fix, const unsigned long long *__restrict__ flag, float *__restrict__ sums)
 {
     if (threadIdx.x < 8) {
         unsigned long long t = 0;
         for (int sh = 0; sh < 64; sh++) t += fix[sh * 8 + threadIdx.x];
-        sums[threadIdx.x] = (float)((double)(long long)t * (1.0 / 4294967296.0));
+        sums[threadIdx.x] = *flag ? __builtin_nanf("") : (float)((double)(long long)t * (1.0 / 4294967296.0));
     }
 }
 
@@ -173,8 +184,8 @@ __global__ __launch_bounds__(256) void seg_loss_bwd_kernel(const float *__restri
                                                           const float *__restrict__ maskB, const float *__restrict__ sums,
                                                           const float *__restrict__ AS, const float *__restrict__ roi,
                                                           const float *__restrict__ g_seg, const float *__restrict__ g_regw,
-                                                          unsigned long long *__restrict__ grad, int B, int K, int hs, int ws, int S,
-                                                          float sy, float sx)
+                                                          unsigned long long *__restrict__ grad, unsigned long long *__restrict__ flag,
+                                                          int B, int K, int hs, int ws, int S, float sy, float sx)
 {
     extern __shared__ __attribute__((aligned(16))) float tile[];       // [K][TC][TC] logits, then [K][TC][TC] gradient cells (64-bit fixed point)
     const int b = blockIdx.z;
@@ -252,23 +263,23 @@ __global__ __launch_bounds__(256) void seg_loss_bwd_kernel(const float *__restri
                     v11 += __shfl_xor(v11, x, 64);
                 }
                 if (((threadIdx.y * 16 + threadIdx.x) & 0x33) == 0) {
-                    atomicAdd(gp + c.t[0].o00, fix52(v00));
-                    atomicAdd(gp + c.t[0].o01, fix52(v01));
-                    atomicAdd(gp + c.t[0].o10, fix52(v10));
-                    atomicAdd(gp + c.t[0].o11, fix52(v11));
+                    atomicAdd(gp + c.t[0].o00, fix52(v00, flag));
+                    atomicAdd(gp + c.t[0].o01, fix52(v01, flag));
+                    atomicAdd(gp + c.t[0].o10, fix52(v10, flag));
+                    atomicAdd(gp + c.t[0].o11, fix52(v11, flag));
                 }
             } else if (same) {       // the quad's four pixels share their four low-res cells (always true for S = 16 h)
-                atomicAdd(gp + c.t[0].o00, fix52(dz[0] * c.t[0].w00 + dz[1] * c.t[1].w00 + dz[2] * c.t[2].w00 + dz[3] * c.t[3].w00));
-                atomicAdd(gp + c.t[0].o01, fix52(dz[0] * c.t[0].w01 + dz[1] * c.t[1].w01 + dz[2] * c.t[2].w01 + dz[3] * c.t[3].w01));
-                atomicAdd(gp + c.t[0].o10, fix52(dz[0] * c.t[0].w10 + dz[1] * c.t[1].w10 + dz[2] * c.t[2].w10 + dz[3] * c.t[3].w10));
-                atomicAdd(gp + c.t[0].o11, fix52(dz[0] * c.t[0].w11 + dz[1] * c.t[1].w11 + dz[2] * c.t[2].w11 + dz[3] * c.t[3].w11));
+                atomicAdd(gp + c.t[0].o00, fix52(dz[0] * c.t[0].w00 + dz[1] * c.t[1].w00 + dz[2] * c.t[2].w00 + dz[3] * c.t[3].w00, flag));
+                atomicAdd(gp + c.t[0].o01, fix52(dz[0] * c.t[0].w01 + dz[1] * c.t[1].w01 + dz[2] * c.t[2].w01 + dz[3] * c.t[3].w01, flag));
+                atomicAdd(gp + c.t[0].o10, fix52(dz[0] * c.t[0].w10 + dz[1] * c.t[1].w10 + dz[2] * c.t[2].w10 + dz[3] * c.t[3].w10, flag));
+                atomicAdd(gp + c.t[0].o11, fix52(dz[0] * c.t[0].w11 + dz[1] * c.t[1].w11 + dz[2] * c.t[2].w11 + dz[3] * c.t[3].w11, flag));
             } else {
 #pragma unroll
                 for (int p = 0; p < 4; p++) {
-                    atomicAdd(gp + c.t[p].o00, fix52(dz[p] * c.t[p].w00));
-                    atomicAdd(gp + c.t[p].o01, fix52(dz[p] * c.t[p].w01));
-                    atomicAdd(gp + c.t[p].o10, fix52(dz[p] * c.t[p].w10));
-                    atomicAdd(gp + c.t[p].o11, fix52(dz[p] * c.t[p].w11));
+                    atomicAdd(gp + c.t[p].o00, fix52(dz[p] * c.t[p].w00, flag));
+                    atomicAdd(gp + c.t[p].o01, fix52(dz[p] * c.t[p].w01, flag));
+                    atomicAdd(gp + c.t[p].o10, fix52(dz[p] * c.t[p].w10, flag));
+                    atomicAdd(gp + c.t[p].o11, fix52(dz[p] * c.t[p].w11, flag));
                 }
             }
         }
@@ -284,10 +295,11 @@ __global__ __launch_bounds__(256) void seg_loss_bwd_kernel(const float *__restri
     }
 }
 
-__global__ __launch_bounds__(256) void seg_loss_grad_kernel(const unsigned long long *__restrict__ fix, float *__restrict__ grad, size_t n)
+__global__ __launch_bounds__(256) void seg_loss_grad_kernel(const unsigned long long *__restrict__ fix, const unsigned long long *__restrict__ flag,
+                                                           float *__restrict__ grad, size_t n)
 {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) grad[i] = (float)((double)(long long)fix[i] * (1.0 / 4503599627370496.0));
+    if (i < n) grad[i] = *flag ? __builtin_nanf("") : (float)((double)(long long)fix[i] * (1.0 / 4503599627370496.0));
 }
 
 
@@ -519,7 +531,8 @@ static int check_shapes(int B, int K, int hs, int ws, int S)
 extern "C" size_t cosa_seg_loss_workspace_bytes(int B, int K, int hs, int ws)
 {
     if (B <= 0 || K <= 0 || hs <= 0 || ws <= 0) return 0;
-    return align_up((size_t)B * K * hs * ws * sizeof(unsigned long long) + 64 * 8 * sizeof(unsigned long long), 256);     // gradient cells + 64 shards of the 8 forward sums
+    // 64 shards of the 8 forward sums + gradient cells + the sticky "not representable" flag word
+    return align_up((size_t)B * K * hs * ws * sizeof(unsigned long long) + (64 * 8 + 1) * sizeof(unsigned long long), 256);
 }
 
 extern "C" int cosa_seg_loss_forward(const float *seg_lr, const float *maskA, const float *maskB, const float *simg,
@@ -529,19 +542,21 @@ extern "C" int cosa_seg_loss_forward(const float *seg_lr, const float *maskA, co
     COSA_REQUIRE(seg_lr && maskA && maskB && simg && boxes && sums && s_seg && s_img && roi && unlabel && workspace, "cosa_seg_loss_forward: null pointer");
     int rc = check_shapes(B, K, hs, ws, S);
     if (rc) return rc;
-    if (workspace_bytes < 64 * 8 * sizeof(unsigned long long)) {
-        set_error("cosa_seg_loss_forward: workspace too small");
+    if (workspace_bytes < cosa_seg_loss_workspace_bytes(B, K, hs, ws)) {
+        set_error("cosa_seg_loss_forward: workspace too small (size it with cosa_seg_loss_workspace_bytes)");
         return COSA_ENOMEM;
     }
     hipStream_t st = as_stream(stream);
     unsigned long long *fix = static_cast<unsigned long long *>(workspace);
+    unsigned long long *flag = fix + 64 * 8 + (size_t)B * K * hs * ws;            // reset here, read by both conversions (a forward always precedes its backward)
     COSA_HIP_CHECK(hipMemsetAsync(fix, 0, 64 * 8 * sizeof(unsigned long long), st));
+    COSA_HIP_CHECK(hipMemsetAsync(flag, 0, sizeof(unsigned long long), st));
     const dim3 grid((S + 31) / 32, (S + 31) / 32, B), blk(16, 16);
     const size_t lds = (size_t)K * TC * TC * sizeof(float);
-    hipLaunchKernelGGL(seg_loss_fwd_kernel, grid, blk, lds, st, seg_lr, maskA, maskB, simg, boxes, fix, s_seg, s_img, roi, unlabel, K,
+    hipLaunchKernelGGL(seg_loss_fwd_kernel, grid, blk, lds, st, seg_lr, maskA, maskB, simg, boxes, fix, flag, s_seg, s_img, roi, unlabel, K,
                        hs, ws, S, (float)hs / (float)S, (float)ws / (float)S);
     COSA_LAUNCH_CHECK();
-    hipLaunchKernelGGL(seg_loss_sums_kernel, dim3(1), dim3(64), 0, st, fix, sums);
+    hipLaunchKernelGGL(seg_loss_sums_kernel, dim3(1), dim3(64), 0, st, fix, flag, sums);
     COSA_LAUNCH_CHECK();
     return COSA_OK;
 }
@@ -560,6 +575,7 @@ extern "C" int cosa_seg_loss_backward(const float *seg_lr, const float *maskA, c
     }
     hipStream_t st = as_stream(stream);
     unsigned long long *fix = static_cast<unsigned long long *>(workspace) + 64 * 8;
+    unsigned long long *flag = fix + n;
     COSA_HIP_CHECK(hipMemsetAsync(fix, 0, n * sizeof(unsigned long long), st));
     const dim3 grid((S + 31) / 32, (S + 31) / 32, B), blk(16, 16);
     const size_t lds = (size_t)((K * TC * TC + 1) & ~1) * sizeof(float) + (size_t)K * TC * TC * sizeof(unsigned long long);
@@ -568,10 +584,10 @@ extern "C" int cosa_seg_loss_backward(const float *seg_lr, const float *maskA, c
         COSA_HIP_CHECK(hipFuncSetAttribute((const void *)seg_loss_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         lds_set = lds;
     }
-    hipLaunchKernelGGL(seg_loss_bwd_kernel, grid, blk, lds, st, seg_lr, maskA, maskB, sums, AS, roi, g_seg, g_regw, fix, B, K, hs,
+    hipLaunchKernelGGL(seg_loss_bwd_kernel, grid, blk, lds, st, seg_lr, maskA, maskB, sums, AS, roi, g_seg, g_regw, fix, flag, B, K, hs,
                        ws, S, (float)hs / (float)S, (float)ws / (float)S);
     COSA_LAUNCH_CHECK();
-    hipLaunchKernelGGL(seg_loss_grad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, fix, grad_seg_lr, n);
+    hipLaunchKernelGGL(seg_loss_grad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, fix, flag, grad_seg_lr, n);
     COSA_LAUNCH_CHECK();
     return COSA_OK;
 }

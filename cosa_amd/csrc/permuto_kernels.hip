@@ -15,7 +15,7 @@
 //     so splat / blur / slice touch whole rows instead of re-streaming the lattice K times.
 //   * planar [K][H*W] <-> row [pixel][KP] transposes go through LDS tiles.
 //   * splat without float atomics: the (pixel, vertex) pairs of an image are sorted by vertex once per lattice (stable LSD radix sort,
-//     rocPRIM's device primitive; the pairs are generated in pixel order, so a vertex's list is in ascending pixel order), and a
+//     radix_sort.hpp; the pairs are generated in pixel order, so a vertex's list is in ascending pixel order), and a
 //     half-wave per vertex adds its list up in that order -- the order of the reference's serial splat loop (permutohedral.cpp:507-530),
 //     so the value rows are bit-identical to the CPU's and the same from run to run.
 // Compiled with -ffp-contract=off (lattice coordinates must match the CPU oracle bit for bit).
@@ -23,7 +23,7 @@
 #include <cmath>
 #include <cstring>
 #include <vector>
-#include <rocprim/device/device_radix_sort.hpp>
+#include "radix_sort.hpp"
 
 namespace cosa {
 namespace {
@@ -66,7 +66,7 @@ struct ImageBuffers {   // per-image strides (in elements) into the workspace ar
     int *seg_lo, *seg_hi;       // [N][Mmax] range of a vertex's pairs in cent1 (lo == hi == 0: none)
     float *rows;                // [N][Npix][KP] the input of a filter pass as pixel rows (x roi)
     double *loss_part;          // [N * ceil(Npix / TP)] per-workgroup partial sums of the energy
-    void *sort_tmp;             // rocPRIM's temporary storage
+    void *sort_tmp;             // the radix sort's digit counts (radix_sort.hpp)
     size_t sort_tmp_bytes;
     int id_bits;
 };
@@ -594,18 +594,7 @@ size_t plan_layout(int N, int K, int H, int W, void *ws, Plan *pl)
     B.loss_part = cv.take<double>((size_t)N * ((P.N + TP - 1) / TP));
     B.id_bits = 1;
     while ((1u << B.id_bits) <= (unsigned)P.Mmax) B.id_bits++;          // ids 0 .. Mmax (Mmax = "padding pixel")
-    {
-        static size_t cached_pairs = 0, cached_bytes = 0;               // the size query launches nothing
-        if (cached_pairs != pairs) {
-            size_t bytes = 0;
-            (void)rocprim::radix_sort_pairs(nullptr, bytes, (unsigned *)nullptr, (unsigned *)nullptr, (unsigned *)nullptr, (unsigned *)nullptr,
-                                            pairs, 0u, 32u, (hipStream_t) nullptr);
-            if (bytes == 0) bytes = pairs * 16 + (1u << 20);            // no device to ask (CPU-only host): an upper bound of the same layout
-            cached_pairs = pairs;
-            cached_bytes = bytes;
-        }
-        B.sort_tmp_bytes = cached_bytes;
-    }
+    B.sort_tmp_bytes = rs_scratch_bytes(pairs);
     B.sort_tmp = cv.take<char>(B.sort_tmp_bytes);
     (void)head; (void)keys_end;
     pl->bytes = cv.off;
@@ -660,9 +649,12 @@ int lattice_phase(const float *images, int N, Plan &pl, hipStream_t st)
     const size_t pairs = (size_t)N * P.Npad * PD1;
     int nbits = 0;
     while ((1 << nbits) < N) nbits++;
-    size_t tmp_bytes = B.sort_tmp_bytes;
-    COSA_HIP_CHECK(rocprim::radix_sort_pairs(B.sort_tmp, tmp_bytes, B.ckey0, B.ckey1, B.cent0, B.cent1, pairs, 0u,
-                                             (unsigned)(B.id_bits + nbits), st));
+    const int where = rs_sort_pairs(B.ckey0, B.cent0, B.ckey1, B.cent1, pairs, B.id_bits + nbits, B.sort_tmp, st);
+    COSA_REQUIRE(where >= 0, "bilateral: radix sort launch failed");
+    if (where == 0) {       // an even number of 8-bit passes (small images): the consumers read buffer 1
+        COSA_HIP_CHECK(hipMemcpyAsync(B.ckey1, B.ckey0, pairs * sizeof(unsigned), hipMemcpyDeviceToDevice, st));
+        COSA_HIP_CHECK(hipMemcpyAsync(B.cent1, B.cent0, pairs * sizeof(unsigned), hipMemcpyDeviceToDevice, st));
+    }
     COSA_HIP_CHECK(hipMemsetAsync(B.seg_lo, 0, (char *)B.rows - (char *)B.seg_lo, st));        // seg_lo and seg_hi are adjacent
     hipLaunchKernelGGL(lattice_bounds_kernel, dim3((unsigned)((pairs + 255) / 256)), blk, 0, st, pairs, P, B);
     COSA_LAUNCH_CHECK();
@@ -747,6 +739,24 @@ extern "C" int cosa_lattice_filter_d2(const float *ins, float *outs, int N, int 
                       as_stream(stream));
 }
 #else
+// the lattice's stable LSD radix sort on its own (csrc/radix_sort.hpp), for the test-suite: n pairs sorted by the low `bits` bits of the key into
+// (keys_out, vals_out); keys_in / vals_in are scratch afterwards; workspace >= cosa_radix_sort_workspace_bytes(n)
+extern "C" size_t cosa_radix_sort_workspace_bytes(long long n) { return n > 0 ? rs_scratch_bytes((size_t)n) : 0; }
+extern "C" int cosa_radix_sort_pairs(uint32_t *keys_in, uint32_t *vals_in, uint32_t *keys_out, uint32_t *vals_out, long long n, int bits,
+                                     void *workspace, size_t workspace_bytes, void *stream)
+{
+    COSA_REQUIRE(keys_in && vals_in && keys_out && vals_out && workspace && n > 0 && n < (1ll << 32) && bits > 0 && bits <= 32, "cosa_radix_sort_pairs: bad arguments");
+    COSA_REQUIRE(workspace_bytes >= rs_scratch_bytes((size_t)n), "cosa_radix_sort_pairs: workspace too small");
+    hipStream_t st = as_stream(stream);
+    const int where = rs_sort_pairs(keys_in, vals_in, keys_out, vals_out, (size_t)n, bits, workspace, st);
+    COSA_REQUIRE(where >= 0, "cosa_radix_sort_pairs: launch failed");
+    if (where == 0) {
+        COSA_HIP_CHECK(hipMemcpyAsync(keys_out, keys_in, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
+        COSA_HIP_CHECK(hipMemcpyAsync(vals_out, vals_in, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
+    }
+    return COSA_OK;
+}
+
 extern "C" size_t cosa_bilateral_workspace_bytes(int N, int K, int H, int W)
 {
     if (N <= 0 || K <= 0 || H <= 0 || W <= 0) return 0;

@@ -179,6 +179,9 @@ def evaluate(model, data_loader, args, df=None, save_result=False, save_rawcam=F
     df['ST'].extend([s_or_t] * len(names))
     # (as the reference, evaluation_engine.py:289: the last row, or the one before it with getcrf -- with threshold_filters that is a
     # `cam_<t>` / `camaux_<t>` row, not Seg_vd)
+    # evaluation_engine.py:287-290 of the reference: the "seg" score handed back is the LAST row of the table (second to last with the CRF row).
+    # With `threshold_filters` that row is a pseudo-label sweep row (camaux_<t>), not Seg_vd -- the reference's behaviour, kept so that
+    # best-checkpoint selection in main.py follows the reference run for run (README: "--eval_threshold_filters").
     seg_vd_miou, cam_miou = (mioulist[-1] if not getcrf else mioulist[-2]), mioulist[0]
     if get_camiou:
         return tab_results, seg_vd_miou, cam_miou, df, cls_aps

@@ -279,6 +279,9 @@ def _cam2mask_generic(images, img_boxes, cams, cls_labels, threshold_high, thres
     return mask
 
 
+_BOX_SIZE_CACHE = {}       # (h, w, device, dtype) -> [h, h, w, w] on that device (cam2mask_multi: negative box bounds)
+
+
 def cam2mask_multi(images, img_boxes, cams_list, cls_labels, thresholds_high, thresholds_low, refine_model=None, ignore_index=255,
                    downscale=2, _fold_validation=False):
     """cam2mask for several CAM sets of the SAME images (the training step's main and auxiliary CAMs, main.py:137-166) in
@@ -311,7 +314,10 @@ def cam2mask_multi(images, img_boxes, cams_list, cls_labels, thresholds_high, th
     if not torch.is_tensor(img_boxes):
         img_boxes = torch.as_tensor(img_boxes)
     if img_boxes.is_cuda or bool((img_boxes < 0).any()):
-        size = torch.tensor([h, h, w, w], device=img_boxes.device, dtype=img_boxes.dtype)
+        key = (h, w, img_boxes.device, img_boxes.dtype)
+        size = _BOX_SIZE_CACHE.get(key)
+        if size is None:           # (built once per geometry: a fresh torch.tensor(..., device=cuda) is a pageable host-to-device copy on every call)
+            size = _BOX_SIZE_CACHE[key] = torch.tensor([h, h, w, w], device=img_boxes.device, dtype=img_boxes.dtype)
         img_boxes = torch.where(img_boxes < 0, img_boxes + size, img_boxes)
     boxes = _boxes_to_device(img_boxes, dev)
     if boxes.shape != (b, 4):

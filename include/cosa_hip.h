@@ -343,6 +343,10 @@ int cosa_attn_fwd_bf16x3(const void *qkv_split, void *out_split, float *lse, int
  * The bilateral kernel of the CRF is cosa_bilateralfilter_batch_dev itself; the mean-field update around the two filters is host code
  * (cosa_amd/utils/seg_helper.py: DenseCRF).  pydensecrf is not under the reference tree: parity of this row is unpinned (oracle/crf_oracle.py).
  * ------------------------------------------------------------------------------------- */
+/* the lattice's own stable LSD radix sort of (key, value) pairs by the low `bits` bits of the key (csrc/radix_sort.hpp; exported for the tests) */
+size_t cosa_radix_sort_workspace_bytes(long long n);
+int cosa_radix_sort_pairs(uint32_t *keys_in, uint32_t *vals_in, uint32_t *keys_out, uint32_t *vals_out, long long n, int bits,
+                          void *workspace, size_t workspace_bytes, void *stream);
 size_t cosa_lattice_filter_d2_workspace_bytes(int N, int K, int H, int W);
 int cosa_lattice_filter_d2(const float *ins, float *outs, int N, int K, int H, int W, float sigmaxy, void *workspace,
                            size_t workspace_bytes, void *stream);

@@ -370,3 +370,23 @@ def test_multi_scale_camseg_persistent_buffers_track_the_active_planes(golden):
         # stateless reference: normalise all planes, then zero the absent ones -- the normalisation is per plane, so the live planes agree
         m = labels[:, :, None, None]
         assert torch.equal(cam, ref_cam * m) and torch.equal(aux, ref_aux * m)
+
+
+@pytest.mark.parametrize("n,bits", [(1, 8), (2047, 5), (2048, 8), (2049, 16), (100_003, 23), (4_816_896, 23), (300_000, 32)])
+def test_radix_sort_is_a_stable_sort(n, bits):
+    """the lattice's own LSD radix sort (csrc/radix_sort.hpp; round 4: replaces rocPRIM) against numpy's stable argsort on keys with many
+    duplicates -- equal keys must keep their input order (the bit-exactness of the bilateral filter rests on it)"""
+    import torch
+    from cosa_amd import _C
+    rng = np.random.default_rng(n)
+    hi = (1 << bits) - 1
+    keys = (rng.integers(0, min(hi, 5000) + 1, n, dtype=np.uint64) * max(1, hi // 5000)).astype(np.uint32) & np.uint32(hi)
+    vals = np.arange(n, dtype=np.uint32)
+    dk, dv = torch.from_numpy(keys.view(np.int32)).cuda(), torch.from_numpy(vals.view(np.int32)).cuda()
+    ok, ov = torch.empty_like(dk), torch.empty_like(dv)
+    L = _C.lib()
+    ws = torch.empty(int(L.cosa_radix_sort_workspace_bytes(n)), dtype=torch.uint8, device="cuda")
+    _C.check(L.cosa_radix_sort_pairs(_C.ptr(dk), _C.ptr(dv), _C.ptr(ok), _C.ptr(ov), n, bits, _C.ptr(ws), ws.numel(), _C.stream_ptr()), "sort")
+    order = np.argsort(keys, kind="stable")
+    assert np.array_equal(ok.cpu().numpy().view(np.uint32), keys[order])
+    assert np.array_equal(ov.cpu().numpy().view(np.uint32), vals[order])

@@ -7,6 +7,8 @@
   * the whole bf16 training step at ViT-B          vs oracle/cpu_step.py (fp32 CPU) on identical weights and inputs: five losses and the
                                                    gradients of qkv / fc1 / conv6 / classifier weights
 """
+import math
+
 import numpy as np
 import pytest
 import torch
@@ -286,3 +288,29 @@ def test_get_energy_loss_fused_softmax_path_equals_layer_path():
     (gref,) = torch.autograd.grad(ref, logit2)
     assert float(loss) == pytest.approx(float(ref), rel=1e-5)
     assert torch.allclose(g, gref, rtol=1e-4, atol=1e-12)
+
+
+@pytest.mark.gpu
+def test_seg_loss_non_finite_input_gives_nan_not_garbage():
+    """the 64-bit fixed-point sums of the fused seg loss cannot carry NaN / Inf / out-of-range values: a sticky flag word makes the
+    loss and its gradient NaN (what float atomics would have propagated) instead of a finite wrong number"""
+    from cosa_amd.utils import seg_helper
+    from cosa_amd.train_step import synthetic_batch
+    dev = torch.device("cuda", 0)
+    B, K, S = 2, 21, 224
+    wimg, simg, lab, box = synthetic_batch(B, S, 20, dev, seed=3)
+    g = torch.Generator().manual_seed(0)
+    mk = lambda: torch.randint(0, 21, (B, S, S), generator=g).float().to(dev)
+    layer = seg_helper.DenseEnergyLoss(weight=1e-7, sigma_rgb=15, sigma_xy=100, scale_factor=0.5)
+    for poison in (float("nan"), float("inf")):
+        seg = torch.randn(B, K, S // 16, S // 16, generator=g).to(dev)
+        seg[1, 3, 2, 5] = poison
+        seg.requires_grad_(True)
+        l_seg, l_reg = seg_helper.fused_seg_and_energy_loss(seg, mk(), mk(), simg, box, layer)
+        (l_seg + l_reg).backward()
+        assert not math.isfinite(float(l_seg)), poison
+        assert torch.isnan(seg.grad).all() or not torch.isfinite(seg.grad).all()
+    seg = torch.randn(B, K, S // 16, S // 16, generator=g).to(dev).requires_grad_(True)          # and a clean input right after: flag re-armed
+    l_seg, l_reg = seg_helper.fused_seg_and_energy_loss(seg, mk(), mk(), simg, box, layer)
+    (l_seg + l_reg).backward()
+    assert math.isfinite(float(l_seg)) and torch.isfinite(seg.grad).all()
