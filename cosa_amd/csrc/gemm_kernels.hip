@@ -1099,6 +1099,154 @@ __global__ __launch_bounds__(512, 1) void gemm_wgrad_kernel(const op16 *__restri
 // launch) is paid per job of ~190 us instead of per ~15-56 stages.  256 workgroups (one per CU) walk the n-major job list in groups of 32
 // consecutive jobs per XCD (workgroup ids are dealt round-robin to the XCDs): the 32 jobs of a group share a few dY / X panels, which
 // their L2 then fetches once.
+// ---- round 4: 256 x 256 tiles for the batched launch ---------------------------------------------------------------------------------------
+// One job = a [256 features] x [256 inputs] tile of dW over ALL tokens; 8 waves as 4 x 2, each 64 features x 128 inputs = 4 x 8 accumulators
+// (128 registers, the forward kernel's budget).  Against the 256 x 128 job above a 32-token k-step now feeds 32 MFMAs per wave from 4 LDS-DMA
+// instructions and 24 transposing fragment reads (before: 16 MFMAs from 3 and 16) behind one barrier: the token loop's fixed costs per flop
+// halve -- that, not operand traffic, is what held the 256 x 128 loop at ~0.45 of the MFMA rate (profiles/r04_wgrad_traffic_probe.txt:
+// 12x less distinct operand data bought 5 %).  LDS: a ring of FOUR 32-token k-step buffers of 32 KB ([32][128] images dY0 | dY1 | X0 | X1),
+// the DMA runs three k-steps ahead of the reads behind counted vmcnt waits, one raw barrier per k-step.  The products reach every output
+// element in the same order as before (32-token k-steps in ascending token order), so the result is bit-identical to the 256 x 128 job's.
+constexpr int WW_IMG = 8192;                  // one [32 tokens][128 columns] bf16 image
+constexpr int WW_STEP = 4 * WW_IMG;           // dY features [0,128) | [128,256) | X inputs [0,128) | [128,256)
+constexpr int WW_LDS = 4 * WW_STEP;           // 128 KB ring; the fp32 epilogue half-tile [128][256] reuses it
+
+__device__ __forceinline__ void wgrad_job_wide(unsigned char *smem, const op16 *__restrict__ dY, const op16 *__restrict__ X,
+                                               float *__restrict__ dW, float *__restrict__ db, int M, int N, int K, int tiles_k, int tile)
+{
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tn = tile / tiles_k, tk = tile - tn * tiles_k;
+    const int n0 = tn * 256, k0 = tk * 256;
+    const int nsteps = (M + 31) / 32;
+    const int wr = wave >> 1, wc = wave & 1;          // wave tile: features [wr*64, +64) x inputs [wc*128, +128)
+    __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc((void *)dY, 0, (int)((size_t)M * N * 2), 0x00020000);
+    __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void *)X, 0, (int)((size_t)M * K * 2), 0x00020000);
+    // this wave's 1-KiB piece of each image: token rows 4 wave .. 4 wave + 3 of the k-step (fixed per-lane source offsets; halves past N / K: zeros)
+    int voY[2], voX[2];
+    {
+        const int r = 4 * wave + (lane >> 4), ch = (lane & 15) ^ tr_sw(r);
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            voY[j] = n0 + j * 128 < N ? (r * N + n0 + j * 128 + ch * 8) * 2 : 0x7ffffff0;
+            voX[j] = k0 + j * 128 < K ? (r * K + k0 + j * 128 + ch * 8) * 2 : 0x7ffffff0;
+        }
+    }
+    auto stage = [&](int st) {
+        unsigned char *buf = smem + (st & 3) * WW_STEP + wave * 1024;
+        const int soY = st * 32 * N * 2, soX = st * 32 * K * 2;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsY, (lds_void *)buf, 16, voY[0], soY, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsY, (lds_void *)(buf + WW_IMG), 16, voY[1], soY, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_void *)(buf + 2 * WW_IMG), 16, voX[0], soX, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_void *)(buf + 3 * WW_IMG), 16, voX[1], soX, 0, 0);
+    };
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bool do_bias = db != nullptr && tk == 0 && wc == 0;
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+    // fragment addressing (as in wgrad_job): lane (nn = l & 15, g = l >> 4) supplies token row 8g + 4h + q (q = nn >> 2), columns 4p .. 4p + 3 (p = nn & 3)
+    const int nn = lane & 15, g = lane >> 4, q = nn >> 2, p = nn & 3;
+    unsigned offA[2][4], offB[2][8];          // byte offsets inside a k-step buffer, per half h of a fragment
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const int r = 8 * g + 4 * h + q, sw = tr_sw(r);
+#pragma unroll
+        for (int i = 0; i < 4; i++) offA[h][i] = (unsigned)((wr >> 1) * WW_IMG + r * 256 + ((((wr & 1) * 8 + 2 * i + (p >> 1)) ^ sw) << 4) + 8 * (p & 1));
+#pragma unroll
+        for (int j = 0; j < 8; j++) offB[h][j] = (unsigned)((2 + wc) * WW_IMG + r * 256 + (((2 * j + (p >> 1)) ^ sw) << 4) + 8 * (p & 1));
+    }
+    stage(0);
+    if (nsteps > 1) stage(1);
+    if (nsteps > 2) stage(2);
+    for (int s = 0; s < nsteps; s++) {
+        // this wave's pieces of k-step s have landed (4 DMA per k-step; those of the next two may stay in flight) ...
+        if (s + 2 < nsteps) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (s + 1 < nsteps) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // ... and so have everybody's; every wave is also done reading k-step s - 1, whose buffer k-step s + 3 reuses
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 3 < nsteps) stage(s + 3);
+        const unsigned cur = (unsigned)(s & 3) * WW_STEP;
+        op16x8 a[4], b[8];
+        // (inline asm reads: behind a pending LDS-DMA hipcc puts vmcnt(0) in front of the ds_read_tr16_b64 builtin -- see wgrad_job)
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                s16x4 v;
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(cur + offA[h][i]));
+                reinterpret_cast<s16x4 *>(&a[i])[h] = v;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                s16x4 v;
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(cur + offB[h][j]));
+                reinterpret_cast<s16x4 *>(&b[j])[h] = v;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+        // the second half of the X fragments is requested before the first 16 MFMAs are issued (they land in their shadow)
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+#pragma unroll
+            for (int j = 4; j < 8; j++) {
+                s16x4 v;
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(cur + offB[h][j]));
+                reinterpret_cast<s16x4 *>(&b[j])[h] = v;
+            }
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[i][j] = COSA_MFMA_16x16x32(a[i], b[j], acc[i][j], 0, 0, 0);
+        if (do_bias) {
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int e = 0; e < 8; e++) bsum[i] += (float)a[i][e];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]));
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 4; j < 8; j++) acc[i][j] = COSA_MFMA_16x16x32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (do_bias) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            float v = bsum[i];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            const int n = n0 + wr * 64 + 16 * i + nn;
+            if (g == 0 && n < N) db[n] = v;
+        }
+    }
+    // acc[i][j][r]: feature n = wr*64 + 16i + 4g + r, input k' = wc*128 + 16j + nn.  Two halves of 128 features through a [128][256] fp32 LDS tile,
+    // then whole 1-KB rows.
+    float *Ct = reinterpret_cast<float *>(smem);
+#pragma unroll
+    for (int hf = 0; hf < 2; hf++) {
+        __syncthreads();                                  // (every wave is done with the last k-step's fragments / the previous half's rows)
+        if ((wr >> 1) == hf) {
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 8; j++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) Ct[((wr & 1) * 64 + 16 * i + 4 * g + r) * 256 + wc * 128 + 16 * j + nn] = acc[i][j][r];
+        }
+        __syncthreads();
+        for (int e = tid; e < 128 * 64; e += 512) {
+            const int row = e >> 6, c4 = e & 63;
+            const int n = n0 + hf * 128 + row, k = k0 + 4 * c4;
+            if (n < N && k < K) *reinterpret_cast<f32x4 *>(dW + (size_t)n * K + k) = *reinterpret_cast<const f32x4 *>(Ct + row * 256 + 4 * c4);
+        }
+    }
+}
+
 struct WgradBatchRec { const op16 *dY, *X; float *dW, *db; int N, K, job0, tiles_k; };
 constexpr int kWgradBatchMax = 48;
 struct WgradBatch { int n, total_jobs, M, pad; WgradBatchRec r[kWgradBatchMax]; };
@@ -1107,16 +1255,15 @@ __global__ __launch_bounds__(512, 1) void gemm_wgrad_batched_kernel(WgradBatch B
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int xcd = blockIdx.x & 7, l = blockIdx.x >> 3;          // 256 workgroups: 32 per XCD
-    const int nstages = (B.M + 63) / 64;
     for (int it = 0; (it * 8 + xcd) * 32 < B.total_jobs; it++) {
         const int job = (it * 8 + xcd) * 32 + l;
         if (job < B.total_jobs) {                                 // (workgroup-uniform)
             int ri = 0;
             while (ri + 1 < B.n && job >= B.r[ri + 1].job0) ri++;
             const WgradBatchRec &R = B.r[ri];
-            wgrad_job<false>(smem, R.dY, R.X, R.dW, R.db, B.M, R.N, R.K, R.tiles_k, nstages, nstages, job - R.job0, 0, ConvGeom{}, 0, 0, 0);
+            wgrad_job_wide(smem, R.dY, R.X, R.dW, R.db, B.M, R.N, R.K, R.tiles_k, job - R.job0);
         }
-        __syncthreads();                                          // the next job's first stage overwrites the epilogue tile
+        __syncthreads();                                          // the next job's first k-step overwrites the epilogue tile
     }
 }
 
@@ -1660,7 +1807,7 @@ extern "C" int cosa_gemm_wgrad_batched(const CosaWgradItem *items, int n_items, 
     COSA_REQUIRE(items && n_items > 0 && M > 0, "cosa_gemm_wgrad_batched: bad arguments");
     static bool attr_done = false;
     if (!attr_done) {
-        COSA_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_wgrad_batched_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WG_LDS));
+        COSA_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_wgrad_batched_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WW_LDS));
         attr_done = true;
     }
     for (int i0 = 0; i0 < n_items; i0 += kWgradBatchMax) {
@@ -1674,12 +1821,12 @@ extern "C" int cosa_gemm_wgrad_batched(const CosaWgradItem *items, int n_items, 
             COSA_REQUIRE(it.dY && it.X && it.dW && it.N > 0 && it.K > 0, "cosa_gemm_wgrad_batched: bad item %d", i0 + i);
             COSA_REQUIRE(it.N % 128 == 0 && it.K % 128 == 0, "cosa_gemm_wgrad_batched: N and K must be multiples of 128 (item %d: %d, %d)", i0 + i, it.N, it.K);
             COSA_REQUIRE((size_t)M * it.N * 2 < 0x7fffffffull && (size_t)M * it.K * 2 < 0x7fffffffull, "cosa_gemm_wgrad_batched: operand beyond 2 GiB");
-            B.r[i] = WgradBatchRec{static_cast<const op16 *>(it.dY), static_cast<const op16 *>(it.X), it.dW, it.db, it.N, it.K, jobs, it.K / 128};
-            jobs += ((it.N + 255) / 256) * (it.K / 128);
+            B.r[i] = WgradBatchRec{static_cast<const op16 *>(it.dY), static_cast<const op16 *>(it.X), it.dW, it.db, it.N, it.K, jobs, (it.K + 255) / 256};
+            jobs += ((it.N + 255) / 256) * ((it.K + 255) / 256);
         }
         for (int i = B.n; i < kWgradBatchMax; i++) B.r[i] = WgradBatchRec{nullptr, nullptr, nullptr, nullptr, 0, 0, jobs, 1};
         B.total_jobs = jobs;
-        hipLaunchKernelGGL(gemm_wgrad_batched_kernel, dim3(256), dim3(512), WG_LDS, as_stream(stream), B);
+        hipLaunchKernelGGL(gemm_wgrad_batched_kernel, dim3(256), dim3(512), WW_LDS, as_stream(stream), B);
         COSA_LAUNCH_CHECK();
     }
     return COSA_OK;
