@@ -56,7 +56,7 @@ def parse():
     ap.add_argument("--student-stream", default="fp32", choices=["fp32", "bf16"],
                     help="residual stream of the student's training path: fp32 like the reference (default) or the bf16 stream of rounds 1-3")
     ap.add_argument("--defer-groups", type=int, default=0,
-                    help="weight gradients of the student's blocks in this many batched launches (0: the trainer's choice -- 1 on one GPU, 4 under "
+                    help="weight gradients of the student's blocks in this many batched launches (0: the trainer's choice -- 1 on one GPU, 6 under "
                          "data parallelism so that the gradient buckets fill while the backward pass is still running)")
     ap.add_argument("--grid-policy", type=int, default=-1, choices=[-1, 0, 1],
                     help="persistent-GEMM grid under DDP: 1 = balanced over the rounds (leaves CUs to RCCL's channels; the trainer's default when "

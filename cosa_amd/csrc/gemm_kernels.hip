@@ -144,6 +144,11 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const op16 *__restric
                                                           int ld, int ldy, void *__restrict__ Y2v, int tail_o0 = -1)
 {
     // SPLIT: K is the LOGICAL contraction length; operand rows have stride ld = 2K + 64, 16-bit outputs go to [hi | lo] rows of stride ldy
+    // SPLIT == 3 (fp16c8 operands): tail mode with the residual epilogue only -- the leftover jobs of the persistent kernel's output projection
+    // (N = 768: 1032 jobs = 4 x 256 + 8), same tile order and MFMA sequence per output element, hence the same bits.  (Measured and not kept for
+    // fp16c4's fc2, K = 3072: a 128 x 128 quarter-job pays ~1.35 us per tile -- 8 LDS-DMA issues per wave and tile, whatever the ring depth --,
+    // so its 73 tiles take 99 us, as long as the lone fifth round of the persistent kernel they would replace.)
+    static_assert(SPLIT < 3 || (SPLIT == 3 && EPI == EPI_RESIDUAL), "fp16c8 operands: residual epilogue (tail mode) only; fp16c4: not supported here");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     int m0, n0;
@@ -194,7 +199,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const op16 *__restric
         }
 
     const int Kp = K / BK;
-    const int nk = SPLIT == 1 ? 3 * Kp + 1 : Kp;
+    const int nk = SPLIT == 1 ? 3 * Kp + 1 : (SPLIT == 3 ? 2 * Kp + 1 : Kp);
+    auto tile_x = [&](int kt) { return SPLIT == 1 ? split_tile_x(kt, Kp) : (SPLIT == 3 ? c8_tile_x(kt, Kp) : kt); };
+    auto tile_w = [&](int kt) { return SPLIT == 1 ? split_tile_w(kt, Kp) : (SPLIT == 3 ? c8_tile_w(kt, Kp) : kt); };
     stage_tile(W, n0, N, ld, 0, smem, wave, lane);
     stage_tile(X, m0, M, ld, 0, smem + TILE_BYTES, wave, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -205,11 +212,31 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const op16 *__restric
         unsigned char *cur = smem + (kt & 1) * STAGE_BYTES;
         unsigned char *nxt = smem + ((kt + 1) & 1) * STAGE_BYTES;
         if (kt + 1 < nk) {
-            stage_tile(W, n0, N, ld, (SPLIT == 1 ? split_tile_w(kt + 1, Kp) : kt + 1) * BK, nxt, wave, lane);
-            stage_tile(X, m0, M, ld, (SPLIT == 1 ? split_tile_x(kt + 1, Kp) : kt + 1) * BK, nxt + TILE_BYTES, wave, lane);
+            stage_tile(W, n0, N, ld, tile_w(kt + 1) * BK, nxt, wave, lane);
+            stage_tile(X, m0, M, ld, tile_x(kt + 1) * BK, nxt + TILE_BYTES, wave, lane);
         }
         const unsigned char *At = cur + (wr * 64) * 128;
         const unsigned char *Bt = cur + TILE_BYTES + (wc * 64) * 128;
+        if (SPLIT == 3 && kt > Kp) {
+            // e5m2 correction tiles: one 16x16x128 MFMA per accumulator on both 16-byte fragments of a row (as the persistent kernel)
+            op16x8 a2[4][2], b2[4][2];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int row = i * 16 + frow;
+#pragma unroll
+                for (int ks = 0; ks < 2; ks++) {
+                    const int slot = ((fq + 4 * ks) ^ (row & 7)) << 4;
+                    a2[i][ks] = *reinterpret_cast<const op16x8 *>(At + row * 128 + slot);
+                    b2[i][ks] = *reinterpret_cast<const op16x8 *>(Bt + row * 128 + slot);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const c8_i32x8 a8 = c8_cat(a2[i][0], a2[i][1]);
+#pragma unroll
+                for (int j = 0; j < 4; j++) acc[i][j] = COSA_MFMA_C8(a8, c8_cat(b2[j][0], b2[j][1]), acc[i][j]);
+            }
+        } else
 #pragma unroll
         for (int ks = 0; ks < 2; ks++) {
             op16x8 a[4], b[4];
@@ -1501,7 +1528,9 @@ static int launch_v6(const op16 *x, const op16 *w, const op16 *b, const float *r
     // N = 768 projections (4.03 rounds) qualify; its 12.09- and 16.1-round launches do not -- measured in the step: tail for all three
     // 45.83 / 45.96 ms, for the 4.03-round launches only 45.66 / 45.65, none 46.05 / 46.22
     const int rem = ntiles % 256, rounds_up = (ntiles + 255) / 256;
-    if (FR == 4 && SPLIT == 0 && ntiles > 256 && rem != 0 && rem <= tail_max && (256 - rem) * 10 > 256 * rounds_up)
+    // (fp16c8 operands: the 128 x 128 kernel knows their tile sequence for the residual epilogue -- the output projection, N = 768)
+    constexpr bool can_tail = FR == 4 && (SPLIT == 0 || (SPLIT == 3 && EPI == EPI_RESIDUAL));
+    if (can_tail && ntiles > 256 && rem != 0 && rem <= tail_max && (256 - rem) * 10 > 256 * rounds_up)
         run = ntiles - rem;
     // The persistent grid is balanced over the rounds it needs anyway: 600 jobs are three rounds on 256 workgroups and on 200, and 200
     // leave 56 CUs to whatever else is running (the other stream's kernels, RCCL's channels under DDP: a 256-workgroup launch that finds
@@ -1519,15 +1548,17 @@ static int launch_v6(const op16 *x, const op16 *w, const op16 *b, const float *r
                        g_gemm_stamp_slot, ld ? ld : K, ldy ? ldy : N, Y2, run, xsc, wsc, ysc);
     g_gemm_stamp_slot = nullptr;                            // one-shot
     COSA_LAUNCH_CHECK();
-    if (run < ntiles) {
-        static bool tail_attr = false;
-        if (!tail_attr) {
-            COSA_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_bf16_kernel<EPI, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes));
-            tail_attr = true;
+    if constexpr (can_tail) {
+        if (run < ntiles) {
+            static bool tail_attr = false;
+            if (!tail_attr) {
+                COSA_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_bf16_kernel<EPI, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes));
+                tail_attr = true;
+            }
+            hipLaunchKernelGGL((gemm_bf16_kernel<EPI, SPLIT>), dim3(4 * (ntiles - run)), dim3(256), kLdsBytes, st, x, w, b, residual, Y, M, N, K, tiles_m, tiles_n,
+                               ld ? ld : K, ldy ? ldy : N, static_cast<void *>(nullptr), run);
+            COSA_LAUNCH_CHECK();
         }
-        hipLaunchKernelGGL((gemm_bf16_kernel<EPI, 0>), dim3(4 * (ntiles - run)), dim3(256), kLdsBytes, st, x, w, b, residual, Y, M, N, K, tiles_m, tiles_n,
-                           K, N, static_cast<void *>(nullptr), run);
-        COSA_LAUNCH_CHECK();
     }
     return COSA_OK;
 }

@@ -96,7 +96,7 @@ class VisionTransformer(nn.Module):
         # "bf16" (rounds 1-3: the stream itself rounded to 8 significant bits after every add; kept for A/B measurements)
         self.residual_stream = "fp32"
         self.defer_wgrad = True        # the blocks' weight gradients in batched launches (nn_ops.DeferredWgrad) ...
-        self.defer_groups = None       # ... one launch per group of depth / defer_groups blocks; None: 1 on a single GPU, 4 under data parallelism
+        self.defer_groups = None       # ... one launch per group of depth / defer_groups blocks; None: 1 on a single GPU, 6 under data parallelism
         self.c8_plain_from = None      # fp16c8 / fp16c4: blocks with index >= this run on plain fp16 operands ("fp16c8-9": the last three)
         # fp16c4: the output projection too on fp16c4 operands (the attention kernel then writes c4 rows)?  Measured (round 4, three seeds, 448^2):
         # the auxiliary CAM's worst error goes from 4.5e-4 to 5.1e-4 (margin on the 1e-3 bar 2.2x -> 1.95x) for 0.15 ms per step, so it is off:
@@ -541,7 +541,10 @@ class VisionTransformer(nn.Module):
         g = self.defer_groups
         if g is None:
             import torch.distributed as dist
-            g = 4 if (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) else 1
+            # under data parallelism the gradient buckets must fill while the backward pass is still running: 6 groups of 2 blocks.
+            # A block is 108 jobs of 256 x 256, so 1, 2, 3 and 6 groups all cost the same six rounds of the 256 CUs (1296 jobs = 5.06 rounds -> 6;
+            # 216 jobs per group -> one round each); 4 groups would cost eight, 12 groups twelve (tools/step_only.py ... groupsN)
+            g = 6 if (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) else 1
         return max(1, min(int(g), len(self.blocks)))
 
     def _features_train_f32(self, img):

@@ -264,3 +264,31 @@ def test_attention_c4_output_rows(B, N, row0):
     step = np.maximum(scale * 2.0, np.abs(lo8.reshape(B * N, D // 16, 16)) * 0.26)                           # e2m1 step <= 2 scale; e5m2 step 25 %
     assert (np.abs(lo4 - lo8.reshape(B * N, D // 16, 16)) <= step + 1e-12).all()
     assert (sc.cpu().numpy()[scale_offsets(R, D, False)][:row0] == 0).all()                                  # rows outside the launch untouched
+
+
+@pytest.mark.parametrize("fmt,K", [("c4", 768), ("c4", 3072), ("c8", 768)])
+def test_tail_jobs_of_the_n768_launches_are_bit_identical_to_the_persistent_kernel(fmt, K):
+    """The teacher's N = 768 projections are 1032 jobs = 4 x 256 + 8.  For fp16c8 operands (the output projection) the persistent kernel stops
+    after four full rounds and the eight leftover 256 x 256 jobs run as 128 x 128 quarters on the two-stage kernel (round 4); fp16c4 launches
+    run all 1032 jobs on the persistent kernel.  Either way a row's result may not depend on the launch geometry: the same rows through a
+    launch without leftovers (fewer rows) are the same bits."""
+    from cosa_amd import nn_ops
+    M, N, M2 = 87904, 768, 83808           # 1032 jobs (tail of 8) vs 984 jobs (no tail)
+    g = torch.Generator().manual_seed(K)
+    x = torch.randn(M, K, generator=g).cuda()
+    w = (torch.randn(N, K, generator=g) * 0.04).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    res = torch.randn(M, N, generator=g).cuda()
+    if fmt == "c4":
+        xs, xsc = nn_ops.c4_rows(x, ones=True)
+        ws, wsc = nn_ops.c4_rows(w, bias=b, weight=True)
+        full = nn_ops.gemm_c4(xs, xsc, ws, wsc, M, N, K, 2, residual=res)
+        part = nn_ops.gemm_c4(xs[:M2], xsc, ws, wsc, M2, N, K, 2, residual=res[:M2].contiguous())
+    else:
+        xs, ws = nn_ops.c8_rows(x, ones=True), nn_ops.c8_rows(w, bias=b)
+        full = nn_ops.gemm_c8(xs, ws, M, N, K, 2, residual=res)
+        part = nn_ops.gemm_c8(xs[:M2], ws, M2, N, K, 2, residual=res[:M2].contiguous())
+    torch.cuda.synchronize()
+    assert torch.equal(full[:M2], part)
+    exact = x[:4096].double() @ w.double().t() + b.double() + res[:4096].double()
+    assert float((full[:4096].double() - exact).abs().max()) <= 3e-4 * float(exact.abs().max())
