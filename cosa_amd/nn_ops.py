@@ -65,7 +65,7 @@ class KernelStamps:
         self.buf = torch.zeros((max_launches, self.SHARDS, 2), dtype=torch.int64, device=device)
         self.half = max_launches // 2
         self.n = 0                  # slots [0, half): launches of the teacher section (captured in its hipGraph, re-armed by the captured reset)
-        self.flops = []
+        self.flops = []             # per slot: (algorithmic FLOPs, issued MFMA FLOPs -- more for operand formats with correction terms)
         self.eager = False          # slots [half, ..): the step's eager launches (student), re-armed on their own stream by begin_eager()
         self.n_eager = 0
         self.flops_eager = []
@@ -90,15 +90,16 @@ class KernelStamps:
         self.n = 0
         self.flops = []
 
-    def next_slot(self, flops):
+    def next_slot(self, flops, issued=None):
+        ent = (flops, flops if issued is None else issued)
         if self.eager:
             i = self.half + self.n_eager
             self.n_eager += 1
-            self.flops_eager.append(flops)
+            self.flops_eager.append(ent)
         else:
             i = self.n
             self.n += 1
-            self.flops.append(flops)
+            self.flops.append(ent)
         assert i < self.buf.shape[0] and (self.eager or i < self.half), "KernelStamps: out of slots"
         return ctypes.c_void_p(self.buf.data_ptr() + 16 * self.SHARDS * i)
 
@@ -109,7 +110,8 @@ class KernelStamps:
         fl_all = list(self.flops) + list(self.flops_eager)
         ok = (b[:, 1] > 0) & (b[:, 0] < b[:, 1])
         ticks = (b[:, 1] - b[:, 0])[ok]
-        fl = sum(f for f, k in zip(fl_all, ok.tolist()) if k)
+        fl = sum(f[0] for f, k in zip(fl_all, ok.tolist()) if k)
+        self.last_issued = sum(f[1] for f, k in zip(fl_all, ok.tolist()) if k)
         return int(ok.sum()), float(ticks.sum()) * 1e-8, fl
 
 
@@ -399,7 +401,7 @@ def gemm_x3(xs, ws, M, N, K, epilogue=EPI_BIAS, residual=None, out=None, ldy=Non
         if out is None:
             out = torch.empty((M, ldy), device=dev, dtype=torch.bfloat16)
     if gemm_stamps is not None and M >= 4096:
-        _C.lib().cosa_gemm_set_stamp_slot(gemm_stamps.next_slot(6.0 * M * N * K))
+        _C.lib().cosa_gemm_set_stamp_slot(gemm_stamps.next_slot(2.0 * M * N * K, 2.0 * M * N * K * (3 * (K // 64) + 1) / (K // 64)))
     with _C.profiled("gemm_x3"):
         _C.check(_C.lib().cosa_gemm_bf16x3(_C.ptr(xs), _C.ptr(ws), _C.ptr(z), _C.ptr(residual), _C.ptr(out), M, N, K, epilogue, ldy,
                                            _C.stream_ptr()), "cosa_gemm_bf16x3")
@@ -459,7 +461,7 @@ def gemm_c8(xs, ws, M, N, K, epilogue=EPI_BIAS, residual=None, out=None, ldy=Non
         if out is None:
             out = torch.empty((M, ldy), device=dev, dtype=torch.float16)
     if gemm_stamps is not None and M >= 4096:
-        _C.lib().cosa_gemm_set_stamp_slot_f16(gemm_stamps.next_slot(2.0 * M * N * K))        # algorithmic FLOPs: one product per (m, n, k)
+        _C.lib().cosa_gemm_set_stamp_slot_f16(gemm_stamps.next_slot(2.0 * M * N * K, 2.0 * M * N * K * (2 * (K // 64) + 1) / (K // 64)))
     with _C.profiled("gemm_c8"):
         _C.check(_C.lib().cosa_gemm_f16c8(_C.ptr(xs), _C.ptr(ws), _C.ptr(z), _C.ptr(residual), _C.ptr(out), M, N, K, epilogue, ldy,
                                           _C.stream_ptr()), "cosa_gemm_f16c8")
@@ -517,7 +519,7 @@ def gemm_c4(xs, xsc, ws, wsc, M, N, K, epilogue=EPI_BIAS, residual=None, out=Non
         if epilogue == EPI_GELU and out_scales is None:
             out_scales = c4_scales(M, N, dev)
     if gemm_stamps is not None and M >= 4096:
-        _C.lib().cosa_gemm_set_stamp_slot_f16(gemm_stamps.next_slot(2.0 * M * N * K))
+        _C.lib().cosa_gemm_set_stamp_slot_f16(gemm_stamps.next_slot(2.0 * M * N * K, 2.0 * M * N * K * (K // 64 + 1 + K // 128) / (K // 64)))
     with _C.profiled("gemm_c4"):
         _C.check(_C.lib().cosa_gemm_f16c4(_C.ptr(xs), _C.ptr(xsc), _C.ptr(ws), _C.ptr(wsc), _C.ptr(z), _C.ptr(residual), _C.ptr(out),
                                           _C.ptr(out_scales), M, N, K, epilogue, ldy, _C.stream_ptr()), "cosa_gemm_f16c4")
