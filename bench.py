@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--usepar", action="store_true", help="PAR(T=10, 6 dilations) as cam2mask's refine_model")
     ap.add_argument("--usegmm", action="store_true", help="adaptive thresholds: 3-component mixture fitted to the CAM queue every step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--teacher-precision", default="fp16c4-10", choices=["bf16", "fp16", "bf16x3", "fp16c8", "fp16c8-9", "fp16c4", "fp16c4-11", "fp16c4-10"],
+    ap.add_argument("--teacher-precision", default="fp16c4-8", choices=["bf16", "fp16", "bf16x3", "fp16c8", "fp16c8-9", "fp16c4", "fp16c4-10", "fp16c4-9", "fp16c4-8", "fp16c4-12m8"],
                     help="MFMA operand precision of the teacher's no-grad passes in the HEADLINE run (DESIGN.md section 3).  The default is the "
                          "cheapest mode that meets BASELINE.json's tolerance (1e-3 relative on fp32 CAMs, mask IoU >= 0.999) with a 2x margin; "
                          "`bf16` is BASELINE configs[1] read literally and does not meet it (measured beside the headline as `fast_mode`)")
@@ -308,7 +308,8 @@ def vit_forward_roofline(trainer, wimg, dev, crop):
     # fp16c4: qkv / fc1 / fc2 (per block 171 + 228 + 219 of 693 tile-units) at 19 / 12 resp. 73 / 48 tiles, proj at 25 / 12: 693 / 432 overall
     mult = {"bf16x3": 3.0, "fp16c8": 0.854 * 25 / 12 + 0.146, "fp16c4": 0.854 * 693 / 432 + 0.146}.get(trainer.model_AN.encoder.precision, 1.0)
     if trainer.model_AN.encoder.precision in ("fp16c8", "fp16c4") and trainer.model_AN.encoder.c8_plain_from is not None:
-        frac8 = trainer.model_AN.encoder.c8_plain_from / 12.0
+        pa, pm = trainer.model_AN.encoder._plain_from()
+        frac8 = (pa + 2 * pm) / 36.0              # (an MLP half is two thirds of a block's projection work)
         mult = frac8 * mult + (1.0 - frac8)
     ach = flop_img * x.shape[0] / (ms * 1e-3) / 1e12
     return {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": round(ach * 1e12 / PEAK_BF16, 4),
@@ -326,8 +327,10 @@ MODE_TEXT = {
     "fp16c8-9": "fp16c8 in blocks 0-8, plain fp16 operands in blocks 9-11",
     "fp16c4": "fp16c4 (fp16 x fp16 + both correction terms as FP4 (e2m1) MX blocks on the block-scaled MFMA at 4x the fp16 rate in qkv / fc1 / "
               "fc2, fp32 accumulation; output projection fp16c8, attention operands fp16)",
-    "fp16c4-11": "fp16c4 in blocks 0-10, plain fp16 operands in block 11",
     "fp16c4-10": "fp16c4 in blocks 0-9, plain fp16 operands in blocks 10-11",
+    "fp16c4-9": "fp16c4 in blocks 0-8, plain fp16 operands in blocks 9-11",
+    "fp16c4-8": "fp16c4 in blocks 0-7, plain fp16 operands in blocks 8-11",
+    "fp16c4-12m8": "fp16c4 attention halves (qkv, output projection) in all blocks, fp16c4 MLP halves in blocks 0-7, plain fp16 MLPs in blocks 8-11",
 }
 
 
@@ -365,7 +368,8 @@ def configure_student(trainer, opt):
 
 def secondary_modes(opt, dev, C, wimg, simg, lab, box, n_iter):
     """`fast_mode`: the bf16-operand teacher (configs[1] literally; out of tolerance) -- or, when the headline itself is that mode, the
-    conforming default; `other_conforming_modes`: the uniform fp16c4 map (every block corrected) and round 3's fp16c8-9 (e5m2 corrections)"""
+    conforming default; `other_conforming_modes`: fp16c4-9 (one more corrected block: 2.4x instead of 2.0x inside the accuracy bar), the uniform
+    fp16c4 map (every block corrected) and round 3's fp16c8-9 (e5m2 corrections)"""
     from cosa_amd import nn_ops
     st, gst = nn_ops.stamps, nn_ops.gemm_stamps
     nn_ops.stamps = nn_ops.gemm_stamps = None
@@ -374,8 +378,8 @@ def secondary_modes(opt, dev, C, wimg, simg, lab, box, n_iter):
         if opt.teacher_precision != "bf16":
             out["fast_mode"] = secondary_run(opt, dev, C, wimg, simg, lab, box, n_iter, "bf16")
         else:
-            out["conforming_mode"] = secondary_run(opt, dev, C, wimg, simg, lab, box, n_iter, "fp16c4-10")
-        others = [m for m in ("fp16c4", "fp16c8-9") if m != opt.teacher_precision]
+            out["conforming_mode"] = secondary_run(opt, dev, C, wimg, simg, lab, box, n_iter, "fp16c4-8")
+        others = [m for m in ("fp16c4-9", "fp16c4", "fp16c8-9") if m != opt.teacher_precision]
         out["other_conforming_modes"] = {m: {k: v for k, v in secondary_run(opt, dev, C, wimg, simg, lab, box, n_iter, m).items() if k != "vit_forward"}
                                          for m in others}
     finally:

@@ -50,6 +50,22 @@ __device__ __forceinline__ op16x8 v_frag(const unsigned char *Vs, int keyb, int 
 }
 
 constexpr float kDeferLog2 = 6.0f;
+// max of three floats in one instruction (fmaxf chains compile to v_max_f32 plus a canonicalising v_max x, x per input)
+__device__ __forceinline__ float max3f(float a, float b, float c)
+{
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// c + p[0] + p[1] of a packed pair of probabilities, fp32 accumulation (v_dot2c_f32_f16 / _bf16 with the constant (1, 1))
+__device__ __forceinline__ float pair_sum(op16x2 p, float c)
+{
+#if COSA_OP_F16
+    return __builtin_amdgcn_fdot2(p, (op16x2){(op16)1.f, (op16)1.f}, c, false);
+#else
+    return __builtin_amdgcn_fdot2_f32_bf16(p, (op16x2){(op16)1.f, (op16)1.f}, c, false);
+#endif
+}
 __device__ __forceinline__ int crow(int i, int hh) { return (i & 3) + 8 * (i >> 2) + 4 * hh; }
 
 // Workgroup -> (query/key block, batch, head).  Workgroups are dealt round-robin to the 8 XCDs (id & 7), each with a private L2;
@@ -281,7 +297,12 @@ __global__ __launch_bounds__(256) void attn_fwd_x3_kernel(const op16 *__restrict
 // the query's two lanes (hh = 0 / 1): their maxima meet by one lane swap, every lane converts its eight values with the shared scale, a
 // second swap hands the hh = 0 lane the block's lo' half and the hh = 1 lane its hi half (8-byte stores), the hh = 0 lane stores the scale
 // byte at the row's place in the operand's scale tensor (row0 = first row of this launch's images in that operand).
-template <bool DMA, int OUTM = 0, int NW = 2>
+// AUGM (round 4): the softmax's "scale and subtract the running maximum" leaves the VALU.  Q is held pre-multiplied by scale * log2(e), and
+// the running reference m[u] of a query enters the score MFMAs as a 65th contraction index (K side: 1 for every key, Q side: -m, a register
+// constant per query that changes only when the reference moves): the accumulators come out as  s * scale * log2 e - m, ready for v_exp.
+// m is kept representable in the operand type, so the same value is subtracted everywhere (the factor 2^m cancels between O and l).  One
+// more MFMA per 32 x 32 score block (4 on 16) for 64 fewer VALU fmas per lane and tile: the kernel is VALU-issue bound.
+template <bool DMA, int OUTM = 0, int NW = 2, bool AUGM = false>
 __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const op16 *__restrict__ qkv, const op16 *__restrict__ vt,
                                                        op16 *__restrict__ out, float *__restrict__ lse,
                                                        int N, int Npad, int H, int nblk, int ngroups, float scale_log2e,
@@ -306,6 +327,18 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const op16 *__restric
 #pragma unroll
         for (int s = 0; s < 4; s++) qf[u][s] = *reinterpret_cast<const op16x8 *>(qp + 16 * s);
     }
+    op16x8 a_aug, qaug[2];
+#pragma unroll
+    for (int j = 0; j < 8; j++) { a_aug[j] = (op16)0.f; qaug[0][j] = (op16)0.f; qaug[1][j] = (op16)0.f; }
+    if (AUGM) {
+        if (hh == 0) a_aug[0] = (op16)1.f;
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+#pragma unroll
+            for (int s = 0; s < 4; s++)
+#pragma unroll
+                for (int j = 0; j < 8; j++) qf[u][s][j] = (op16)((float)qf[u][s][j] * scale_log2e);
+    }
     f32x16 o[2][2];
 #pragma unroll
     for (int u = 0; u < 2; u++)
@@ -313,7 +346,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const op16 *__restric
         for (int d = 0; d < 2; d++)
 #pragma unroll
             for (int i = 0; i < 16; i++) o[u][d][i] = 0.f;
-    float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.f, 0.f};
+    float m[2] = {AUGM ? 0.f : -INFINITY, AUGM ? 0.f : -INFINITY}, l[2] = {0.f, 0.f};
     const op16 *kbase = qkv + (size_t)b * N * rs + (size_t)H * HD + h * HD;
     const op16 *vbase = kbase + (size_t)H * HD;
     const int swz = (r >> 1) & 7;
@@ -368,6 +401,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const op16 *__restric
         }
         if (!DMA) __syncthreads();
 
+        op16x2 pk[2][2][8];
         f32x16 sc[2][2];
 #pragma unroll
         for (int u = 0; u < 2; u++)
@@ -376,6 +410,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const op16 *__restric
 #pragma unroll
                 for (int i = 0; i < 16; i++) sc[u][kb][i] = 0.f;
         __builtin_amdgcn_s_setprio(1);
+        if (AUGM) {
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                sc[u][0] = COSA_MFMA_32x32x16(a_aug, qaug[u], sc[u][0], 0, 0, 0);
+                sc[u][1] = COSA_MFMA_32x32x16(a_aug, qaug[u], sc[u][1], 0, 0, 0);
+            }
+        }
 #pragma unroll
         for (int s = 0; s < 4; s++) {
             const int slot = ((2 * s + hh) ^ swz) << 4;
@@ -397,28 +438,67 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const op16 *__restric
                     if (k0 + 32 + crow(i, hh) >= N) sc[u][1][i] = -INFINITY;
                 }
             }
-            float mt = fmaxf(sc[u][0][0], sc[u][1][0]);
+            float mt = max3f(sc[u][0][0], sc[u][1][0], sc[u][0][1]);
+            mt = fmaxf(mt, sc[u][1][1]);
 #pragma unroll
-            for (int i = 1; i < 16; i++) mt = fmaxf(mt, fmaxf(sc[u][0][i], sc[u][1][i]));
+            for (int i = 2; i < 16; i++) mt = max3f(mt, sc[u][0][i], sc[u][1][i]);
             mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-            const float mnew = fmaxf(m[u], mt * scale_log2e);
-            // deferred rescale: the running reference m only moves when some row's max has outgrown it by more than 2^DEFER (probabilities
-            // then reach at most 2^DEFER, far inside fp32 / op16 range; l and O carry the same factor, so the result is unchanged)
-            if (__any(mnew > m[u] + kDeferLog2)) {
-                const float alpha = __builtin_amdgcn_exp2f(m[u] - mnew);
-                l[u] *= alpha;
+            if constexpr (AUGM) {
+                // the accumulators are already  s * scale * log2 e - m[u]; the reference moves (rarely: deferred as below) by a correction of
+                // the accumulators, the running sums and the Q-side constant of the 65th index.  First tile: m = 0 is not a maximum yet.
+                const bool first = k0 == 0;
+                if (first || __any(mt > kDeferLog2)) {
+                    const float mq = (float)(op16)(first ? mt : m[u] + fmaxf(mt, 0.f));
+                    const float delta = mq - m[u];
+                    if (!first) {
+                        const float alpha = __builtin_amdgcn_exp2f(-delta);
+                        l[u] *= alpha;
 #pragma unroll
-                for (int i = 0; i < 16; i++) { o[u][0][i] *= alpha; o[u][1][i] *= alpha; }
-                m[u] = mnew;
-            }
-            float ls = 0.f;
+                        for (int i = 0; i < 16; i++) { o[u][0][i] *= alpha; o[u][1][i] *= alpha; }
+                    }
+                    m[u] = mq;
+                    if (hh == 0) qaug[u][0] = (op16)(-mq);
 #pragma unroll
-            for (int i = 0; i < 16; i++) {
-                sc[u][0][i] = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[u][0][i], scale_log2e, -m[u]));
-                sc[u][1][i] = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[u][1][i], scale_log2e, -m[u]));
-                ls += sc[u][0][i] + sc[u][1][i];
+                    for (int i = 0; i < 16; i++) { sc[u][0][i] -= delta; sc[u][1][i] -= delta; }
+                }
+            } else {
+                const float mnew = fmaxf(m[u], mt * scale_log2e);
+                // deferred rescale: the running reference m only moves when some row's max has outgrown it by more than 2^DEFER (probabilities
+                // then reach at most 2^DEFER, far inside fp32 / op16 range; l and O carry the same factor, so the result is unchanged)
+                if (__any(mnew > m[u] + kDeferLog2)) {
+                    const float alpha = __builtin_amdgcn_exp2f(m[u] - mnew);
+                    l[u] *= alpha;
+#pragma unroll
+                    for (int i = 0; i < 16; i++) { o[u][0][i] *= alpha; o[u][1][i] *= alpha; }
+                    m[u] = mnew;
+                }
             }
-            l[u] += ls;
+            // probabilities: exp2, rounded to the operand type in pairs (they are the B operand of the PV MFMAs as they stand).  Row sum: fp32
+            // over the unrounded values in the order rounds 1-3 fixed (the passes that keep LSE for a backward: the student's results do not
+            // move when this kernel is touched), or -- AUGM, no-grad passes -- over the ROUNDED values, what the PV product weights V with, two
+            // per instruction
+            if constexpr (AUGM) {
+#pragma unroll
+                for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+                    for (int t = 0; t < 8; t++) {
+                        pk[u][kb][t] = (op16x2){(op16)__builtin_amdgcn_exp2f(sc[u][kb][2 * t]), (op16)__builtin_amdgcn_exp2f(sc[u][kb][2 * t + 1])};
+                        l[u] = pair_sum(pk[u][kb][t], l[u]);
+                    }
+            } else {
+                float ls = 0.f;
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    sc[u][0][i] = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[u][0][i], scale_log2e, -m[u]));
+                    sc[u][1][i] = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[u][1][i], scale_log2e, -m[u]));
+                    ls += sc[u][0][i] + sc[u][1][i];
+                }
+                l[u] += ls;
+#pragma unroll
+                for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+                    for (int t = 0; t < 8; t++) pk[u][kb][t] = (op16x2){(op16)sc[u][kb][2 * t], (op16)sc[u][kb][2 * t + 1]};
+            }
         }
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -429,9 +509,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const op16 *__restric
                 const op16x8 v0 = v_frag(Vs, keyb, 0, lane), v1 = v_frag(Vs, keyb, 1, lane);
 #pragma unroll
                 for (int u = 0; u < 2; u++) {
-                    op16x8 pf;
-#pragma unroll
-                    for (int j = 0; j < 8; j++) pf[j] = (op16)sc[u][kb][8 * sp + j];
+                    const op16x8 pf = __builtin_shufflevector(__builtin_shufflevector(pk[u][kb][4 * sp], pk[u][kb][4 * sp + 1], 0, 1, 2, 3),
+                                                              __builtin_shufflevector(pk[u][kb][4 * sp + 2], pk[u][kb][4 * sp + 3], 0, 1, 2, 3),
+                                                              0, 1, 2, 3, 4, 5, 6, 7);
                     o[u][0] = COSA_MFMA_32x32x16(v0, pf, o[u][0], 0, 0, 0);
                     o[u][1] = COSA_MFMA_32x32x16(v1, pf, o[u][1], 0, 0, 0);
                 }
@@ -918,8 +998,12 @@ extern "C" int cosa_attn_fwd(const void *qkv, void *out, float *lse, int B, int 
     if ((size_t)N * 3 * H * HD * 2 >= 0x7fffffffull)
         hipLaunchKernelGGL(attn_fwd2_kernel<false>, dim3(((N + 127) / 128) * ((B * H + 7) / 8 * 8)), dim3(128), 0, st, q, vt, o, lse, N, Npad, H, (N + 127) / 128,
                            B * H, sl2, stp);
+    else if (wide && (flags & 0x400))          // bit 10: a no-grad pass -- Q may be pre-scaled in the operand type (AUGM above)
+        hipLaunchKernelGGL((attn_fwd2_kernel<true, 0, 4, true>), grid, dim3(256), 0, st, q, vt, o, lse, N, Npad, H, nblk, B * H, sl2, stp);
     else if (wide)
         hipLaunchKernelGGL((attn_fwd2_kernel<true, 0, 4>), grid, dim3(256), 0, st, q, vt, o, lse, N, Npad, H, nblk, B * H, sl2, stp);
+    else if (flags & 0x400)
+        hipLaunchKernelGGL((attn_fwd2_kernel<true, 0, 2, true>), grid, dim3(128), 0, st, q, vt, o, lse, N, Npad, H, nblk, B * H, sl2, stp);
     else
         hipLaunchKernelGGL(attn_fwd2_kernel<true>, grid, dim3(128), 0, st, q, vt, o, lse, N, Npad, H, nblk, B * H, sl2, stp);
     COSA_LAUNCH_CHECK();
@@ -940,11 +1024,11 @@ extern "C" int cosa_attn_fwd_f16c8(const void *qkv, void *out_c8, float *lse, in
     const bool wide = attn_wide(B, N, H);
     const int nblk = wide ? (N + 255) / 256 : (N + 127) / 128;
     if (wide)
-        hipLaunchKernelGGL((attn_fwd2_kernel<true, 1, 4>), dim3(nblk * ((B * H + 7) / 8 * 8)), dim3(256), 0, as_stream(stream), static_cast<const op16 *>(qkv),
+        hipLaunchKernelGGL((attn_fwd2_kernel<true, 1, 4, true>), dim3(nblk * ((B * H + 7) / 8 * 8)), dim3(256), 0, as_stream(stream), static_cast<const op16 *>(qkv),
                            static_cast<const op16 *>(nullptr), static_cast<op16 *>(out_c8), lse, N, Npad, H, nblk, B * H, scale * 1.4426950408889634f,
                            reinterpret_cast<unsigned long long *>(stamps));
     else
-        hipLaunchKernelGGL((attn_fwd2_kernel<true, 1>), dim3(nblk * ((B * H + 7) / 8 * 8)), dim3(128), 0, as_stream(stream), static_cast<const op16 *>(qkv),
+        hipLaunchKernelGGL((attn_fwd2_kernel<true, 1, 2, true>), dim3(nblk * ((B * H + 7) / 8 * 8)), dim3(128), 0, as_stream(stream), static_cast<const op16 *>(qkv),
                            static_cast<const op16 *>(nullptr), static_cast<op16 *>(out_c8), lse, N, Npad, H, nblk, B * H, scale * 1.4426950408889634f,
                            reinterpret_cast<unsigned long long *>(stamps));
     COSA_LAUNCH_CHECK();
@@ -967,11 +1051,11 @@ extern "C" int cosa_attn_fwd_f16c4(const void *qkv, void *out_c4, void *out_scal
     const int nblk = wide ? (N + 255) / 256 : (N + 127) / 128;
     unsigned char *sc = static_cast<unsigned char *>(out_scales);
     if (wide)
-        hipLaunchKernelGGL((attn_fwd2_kernel<true, 2, 4>), dim3(nblk * ((B * H + 7) / 8 * 8)), dim3(256), 0, as_stream(stream), static_cast<const op16 *>(qkv),
+        hipLaunchKernelGGL((attn_fwd2_kernel<true, 2, 4, true>), dim3(nblk * ((B * H + 7) / 8 * 8)), dim3(256), 0, as_stream(stream), static_cast<const op16 *>(qkv),
                            static_cast<const op16 *>(nullptr), static_cast<op16 *>(out_c4), lse, N, Npad, H, nblk, B * H, scale * 1.4426950408889634f,
                            reinterpret_cast<unsigned long long *>(stamps), sc, row0);
     else
-        hipLaunchKernelGGL((attn_fwd2_kernel<true, 2>), dim3(nblk * ((B * H + 7) / 8 * 8)), dim3(128), 0, as_stream(stream), static_cast<const op16 *>(qkv),
+        hipLaunchKernelGGL((attn_fwd2_kernel<true, 2, 2, true>), dim3(nblk * ((B * H + 7) / 8 * 8)), dim3(128), 0, as_stream(stream), static_cast<const op16 *>(qkv),
                            static_cast<const op16 *>(nullptr), static_cast<op16 *>(out_c4), lse, N, Npad, H, nblk, B * H, scale * 1.4426950408889634f,
                            reinterpret_cast<unsigned long long *>(stamps), sc, row0);
     COSA_LAUNCH_CHECK();

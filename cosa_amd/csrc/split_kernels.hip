@@ -113,6 +113,14 @@ typedef _Float16 f16;
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
+// the fp32 product, rounded -- opaque to the optimizer, which otherwise folds the multiply into the fp16 conversion that follows
+// (v_fma_mix: one rounding) and into the subtraction of the split (fma): the rows must be those of the pre-multiplied matrix
+__device__ __forceinline__ float mul_rounded(float a, float b)
+{
+    float r;
+    asm("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 __device__ __forceinline__ void c8_store4(unsigned char *row, int K, int c, const float (&v)[4])
 {
     f16 hi[4];
@@ -123,7 +131,7 @@ __device__ __forceinline__ void c8_store4(unsigned char *row, int K, int c, cons
     *reinterpret_cast<unsigned *>(row + 3 * K + c) = hi8;
 }
 
-__device__ __forceinline__ void c8_store_aug(unsigned char *row, int K, int lane, bool ones, const float *bias_of_row)
+__device__ __forceinline__ void c8_store_aug(unsigned char *row, int K, int lane, bool ones, const float *bias_of_row, float bias_factor = 1.0f)
 {
     if (lane < 8) {                                   // augmentation block: 8 lanes x 8 fp16
         f16x8 a;
@@ -131,7 +139,7 @@ __device__ __forceinline__ void c8_store_aug(unsigned char *row, int K, int lane
         for (int j = 0; j < 8; j++) a[j] = (f16)0.f;
         if (lane == 0) {
             if (ones) { a[0] = (f16)1.f; a[1] = (f16)1.f; }
-            else if (bias_of_row) { const float b = *bias_of_row; a[0] = (f16)b; a[1] = (f16)(b - (float)a[0]); }
+            else if (bias_of_row) { const float b = mul_rounded(*bias_of_row, bias_factor); a[0] = (f16)b; a[1] = (f16)(b - (float)a[0]); }
         }
         *reinterpret_cast<f16x8 *>(row + 4 * K + lane * 16) = a;
     }
@@ -156,11 +164,14 @@ __global__ __launch_bounds__(256) void c8_rows_kernel(const float *__restrict__ 
 
 // every weight matrix of a network in ONE launch (the teacher's c8 weight rows are rebuilt from the fp32 masters once per pass: 37 small
 // launches of ~9 us otherwise); a record per matrix, rows dealt to waves across all of them
+// qrows: the first qrows rows (and their bias entries) are multiplied by kAttnPrescale before the conversion -- the q third of a qkv
+// projection whose attention kernel takes q pre-scaled (attn_kernels.hip: AUGM): folded into the weights, the factor costs no rounding
+constexpr float kAttnPrescale = 0.125f * 1.4426950408889634f;        // head_dim^-0.5 log2(e), head_dim = 64
 struct C8Rec {
     const float *src;
     const float *bias;
     unsigned char *dst;
-    int rows, K, row0, pad;
+    int rows, K, row0, qrows;
 };
 
 __global__ __launch_bounds__(256) void c8_rows_batched_kernel(const C8Rec *__restrict__ recs, int nrec, int total_rows)
@@ -174,12 +185,13 @@ __global__ __launch_bounds__(256) void c8_rows_batched_kernel(const C8Rec *__res
     const int lr = row - rec.row0, K = rec.K;
     const float *s = rec.src + (size_t)lr * K;
     unsigned char *d = rec.dst + (size_t)lr * (4 * K + 128);
+    const float f0 = lr < rec.qrows ? kAttnPrescale : 1.0f;
     for (int c = lane * 4; c < K; c += 256) {
         const float4 f = *reinterpret_cast<const float4 *>(s + c);
-        const float v[4] = {f.x, f.y, f.z, f.w};
+        const float v[4] = {mul_rounded(f.x, f0), mul_rounded(f.y, f0), mul_rounded(f.z, f0), mul_rounded(f.w, f0)};      // (rounded products: not to be fused into the split)
         c8_store4(d, K, c, v);
     }
-    c8_store_aug(d, K, lane, false, rec.bias ? rec.bias + lr : nullptr);
+    c8_store_aug(d, K, lane, false, rec.bias ? rec.bias + lr : nullptr, f0);
 }
 
 template <int D>
@@ -239,14 +251,15 @@ __device__ __forceinline__ void c4_store_block(unsigned char *row, unsigned char
         (unsigned char)c4_scale_byte(e, weight ? kC4WeightExpBias : 0);
 }
 
-__device__ __forceinline__ void c4_row_from_f32(const float *s, unsigned char *d, unsigned char *scales, int K, int r, int lane, bool weight)
+__device__ __forceinline__ void c4_row_from_f32(const float *s, unsigned char *d, unsigned char *scales, int K, int r, int lane, bool weight,
+                                                float factor = 1.0f)
 {
     for (int b = lane; b < (K >> 4); b += 64) {
         float v[16];
 #pragma unroll
         for (int c = 0; c < 4; c++) {
             const float4 f = *reinterpret_cast<const float4 *>(s + 16 * b + 4 * c);
-            v[4 * c] = f.x; v[4 * c + 1] = f.y; v[4 * c + 2] = f.z; v[4 * c + 3] = f.w;
+            v[4 * c] = mul_rounded(f.x, factor); v[4 * c + 1] = mul_rounded(f.y, factor); v[4 * c + 2] = mul_rounded(f.z, factor); v[4 * c + 3] = mul_rounded(f.w, factor);
         }
         c4_store_block(d, scales, K, r, b, v, weight);
     }
@@ -269,7 +282,7 @@ struct C4Rec {
     const float *bias;
     unsigned char *dst;
     unsigned char *scales;
-    int rows, K, row0, pad;
+    int rows, K, row0, qrows;          // qrows: as in C8Rec
 };
 
 // the weight matrices of a network in one launch (weight block order, 2^-11 in the scale bytes, bias in the augmentation block)
@@ -283,8 +296,9 @@ __global__ __launch_bounds__(256) void c4_rows_batched_kernel(const C4Rec *__res
     const C4Rec rec = recs[r];
     const int lr = row - rec.row0, K = rec.K;
     unsigned char *d = rec.dst + (size_t)lr * (4 * K + 128);
-    c4_row_from_f32(rec.src + (size_t)lr * K, d, rec.scales, K, lr, lane, true);
-    c8_store_aug(d, K, lane, false, rec.bias ? rec.bias + lr : nullptr);
+    const float f0 = lr < rec.qrows ? kAttnPrescale : 1.0f;
+    c4_row_from_f32(rec.src + (size_t)lr * K, d, rec.scales, K, lr, lane, true, f0);
+    c8_store_aug(d, K, lane, false, rec.bias ? rec.bias + lr : nullptr, f0);
 }
 
 // LayerNorm(768) over the fp32 stream -> c4 rows (activation block order).  The row sits in registers as float4 (lane + 64 i): a 16-feature

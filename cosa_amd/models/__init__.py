@@ -4,6 +4,8 @@ Reference: models/__init__.py:13-79 (build_model), :82-206 (VITNetwork), models/
 (LargeFOV).  state_dict keys are identical to the reference: encoder.* (timm ViT names),
 decoder.conv6/7/8.weight, classifier.weight, aux_classifier.weight.
 """
+import re
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -95,12 +97,15 @@ class VITNetwork(nn.Module):
         """operand precision of the no-grad passes (teacher pseudo-labels, evaluation): "bf16" (8 significant bits), "fp16" (11; the
         same kernels built for fp16 operands), "bf16x3" (16; hi + lo bf16 halves, three MFMA terms), "fp16c8" (fp16 + 8-bit correction
         terms on the block-scaled MFMA, ~14 bits at twice the 16-bit work; attention operands plain fp16) or "fp16c4" (the same with FP4 MX-block
-        correction terms at 4x the fp16 rate: ~1.6x the 16-bit work); "-n" suffix: blocks from index n on plain fp16: DESIGN.md section 3"""
-        base, _, tail = mode.partition("-")              # "fp16c8-9": fp16c8 with the blocks from index 9 on plain fp16 operands
-        assert base in ("bf16", "fp16", "bf16x3", "fp16c8", "fp16c4") and (not tail or (base in ("fp16c8", "fp16c4") and tail.isdigit())), mode
+        correction terms at 4x the fp16 rate: ~1.6x the 16-bit work); "-n" suffix: blocks from index n on plain fp16, "-nmk": their MLP halves (fc1, fc2) from
+        block k <= n on: DESIGN.md section 3"""
+        base, _, tail = mode.partition("-")              # "fp16c8-9": fp16c8 with the blocks from index 9 on plain fp16 operands;
+        m = re.fullmatch(r"(\d+)(?:m(\d+))?", tail) if tail else None        # "fp16c4-9m7": ... and the MLP halves already from block 7 on
+        assert base in ("bf16", "fp16", "bf16x3", "fp16c8", "fp16c4") and (not tail or (base in ("fp16c8", "fp16c4") and m)), mode
         self.set_compute_dtype(torch.float16 if base in ("fp16", "fp16c8", "fp16c4") else torch.bfloat16)
         self.encoder.precision = base if base in ("bf16x3", "fp16c8", "fp16c4") else None
-        self.encoder.c8_plain_from = int(tail) if tail else None
+        self.encoder.c8_plain_from = int(m.group(1)) if m else None
+        self.encoder.c8_plain_mlp_from = int(m.group(2)) if m and m.group(2) else None
         return self
 
     def get_param_groups(self):

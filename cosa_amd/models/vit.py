@@ -98,6 +98,7 @@ class VisionTransformer(nn.Module):
         self.defer_wgrad = True        # the blocks' weight gradients in batched launches (nn_ops.DeferredWgrad) ...
         self.defer_groups = None       # ... one launch per group of depth / defer_groups blocks; None: 1 on a single GPU, 6 under data parallelism
         self.c8_plain_from = None      # fp16c8 / fp16c4: blocks with index >= this run on plain fp16 operands ("fp16c8-9": the last three)
+        self.c8_plain_mlp_from = None  # ... their MLP halves (norm2, fc1, fc2) already from this block on (None: as c8_plain_from)
         # fp16c4: the output projection too on fp16c4 operands (the attention kernel then writes c4 rows)?  Measured (round 4, three seeds, 448^2):
         # the auxiliary CAM's worst error goes from 4.5e-4 to 5.1e-4 (margin on the 1e-3 bar 2.2x -> 1.95x) for 0.15 ms per step, so it is off:
         # proj stays on fp16c8 operands (e5m2 corrections), 10 % of the projection work
@@ -256,7 +257,7 @@ class VisionTransformer(nn.Module):
             y, _ = nn_ops.layernorm_f32(xr, c(blk.norm1.weight), c(blk.norm1.bias), blk.norm1.eps)
             qkv = nn_ops.gemm_bf16(y, c(blk.attn.qkv.weight), c(blk.attn.qkv.bias), nn_ops.EPI_BIAS)
             for (B, N), o0, o1 in zip(shapes, offs[:-1], offs[1:]):
-                nn_ops._attn_fwd(qkv[o0:o1].view(B, N, 3 * D), B, N, self.num_heads, out=o[o0:o1].view(B, N, D))
+                nn_ops._attn_fwd(qkv[o0:o1].view(B, N, 3 * D), B, N, self.num_heads, out=o[o0:o1].view(B, N, D), nograd=True)
             # the stream is updated in place, except right after the auxiliary layer: its output stays where it is (it IS the aux
             # feature) and the next residual GEMM writes the stream to a fresh buffer -- no 270-MB clone
             xn = torch.empty_like(xr) if aux is xr else xr
@@ -356,32 +357,41 @@ class VisionTransformer(nn.Module):
 
     # -- parity-grade no-grad path at 2x: fp16 operands + 8-bit correction terms (fp16c8; csrc/c8.hpp), fp32 residual / LayerNorm / CAM heads;
     #    attention on plain fp16 q, k, v (its OUTPUT leaves as c8 rows): tools/sim_precision_map.py is the sensitivity study behind this map
+    def _plain_from(self):
+        """(first block whose attention half, first block whose MLP half) runs on plain fp16 operands in the fp16c8 / fp16c4 modes"""
+        depth = len(self.blocks)
+        a = self.c8_plain_from if self.c8_plain_from is not None else depth
+        m = self.c8_plain_mlp_from if self.c8_plain_mlp_from is not None else a
+        return a, m
+
     def _c8_weights(self):
         """c8 rows [N, 2K+64 fp16 units] (bias in the augmentation block) of the patch projection and the block projections, rebuilt from the
         fp32 masters on every pass (the teacher's masters move every step; part of the captured graph) by ONE batched launch"""
         import numpy as np
         from .. import _C
         items = [("patch", self.patch_embed.proj.weight.reshape(self.embed_dim, -1), self.patch_embed.proj.bias)]
+        pa, pm = self._plain_from()
         for i, blk in enumerate(self.blocks):
-            if self.c8_plain_from is not None and i >= self.c8_plain_from:
-                continue
             if self.precision == "fp16c4":          # qkv / fc1 / fc2 (and proj with c4_proj) run on fp16c4 operands (_c4_weights)
-                if not self.c4_proj:
+                if not self.c4_proj and i < pa:
                     items += [(f"{i}.proj", blk.attn.proj.weight, blk.attn.proj.bias)]
                 continue
-            items += [(f"{i}.qkv", blk.attn.qkv.weight, blk.attn.qkv.bias), (f"{i}.proj", blk.attn.proj.weight, blk.attn.proj.bias),
-                      (f"{i}.fc1", blk.mlp.fc1.weight, blk.mlp.fc1.bias), (f"{i}.fc2", blk.mlp.fc2.weight, blk.mlp.fc2.bias)]
+            if i < pa:
+                items += [(f"{i}.qkv", blk.attn.qkv.weight, blk.attn.qkv.bias), (f"{i}.proj", blk.attn.proj.weight, blk.attn.proj.bias)]
+            if i < pm:
+                items += [(f"{i}.fc1", blk.mlp.fc1.weight, blk.mlp.fc1.bias), (f"{i}.fc2", blk.mlp.fc2.weight, blk.mlp.fc2.bias)]
         ent = self.__dict__.get("_c8_w")
         key = tuple((n, w.data_ptr(), b.data_ptr()) for n, w, b in items)
         if ent is None or ent["key"] != key:
             dev = items[0][1].device
             bufs = {n: torch.empty((w.shape[0], nn_ops.split_ld(w.shape[1])), device=dev, dtype=torch.float16) for n, w, _ in items}
-            rec_dt = np.dtype([("src", "u8"), ("bias", "u8"), ("dst", "u8"), ("rows", "i4"), ("K", "i4"), ("row0", "i4"), ("pad", "i4")])
+            rec_dt = np.dtype([("src", "u8"), ("bias", "u8"), ("dst", "u8"), ("rows", "i4"), ("K", "i4"), ("row0", "i4"), ("qrows", "i4")])
             assert rec_dt.itemsize == _C.lib().cosa_c8_record_bytes()
             rec, row0 = np.zeros(len(items), rec_dt), 0
             for j, (n, w, b) in enumerate(items):
                 assert w.dtype == torch.float32 and w.is_contiguous() and w.shape[1] % 128 == 0
-                rec[j] = (w.data_ptr(), b.data_ptr(), bufs[n].data_ptr(), w.shape[0], w.shape[1], row0, 0)
+                # (qkv: the attention scale is folded into the q rows -- the attention kernel is then called with scale = ln 2, nn_ops.LN2)
+                rec[j] = (w.data_ptr(), b.data_ptr(), bufs[n].data_ptr(), w.shape[0], w.shape[1], row0, w.shape[0] // 3 if n.endswith(".qkv") else 0)
                 row0 += w.shape[0]
             ent = self.__dict__["_c8_w"] = {"key": key, "bufs": bufs, "rec": torch.from_numpy(rec.view(np.uint8).copy()).to(dev),
                                             "n": len(items), "rows": row0}
@@ -395,25 +405,27 @@ class VisionTransformer(nn.Module):
         import numpy as np
         from .. import _C
         items = []
+        pa, pm = self._plain_from()
         for i, blk in enumerate(self.blocks):
-            if self.c8_plain_from is not None and i >= self.c8_plain_from:
-                continue
-            items += [(f"{i}.qkv", blk.attn.qkv.weight, blk.attn.qkv.bias), (f"{i}.fc1", blk.mlp.fc1.weight, blk.mlp.fc1.bias),
-                      (f"{i}.fc2", blk.mlp.fc2.weight, blk.mlp.fc2.bias)]
-            if self.c4_proj:
-                items.append((f"{i}.proj", blk.attn.proj.weight, blk.attn.proj.bias))
+            if i < pa:
+                items.append((f"{i}.qkv", blk.attn.qkv.weight, blk.attn.qkv.bias))
+                if self.c4_proj:
+                    items.append((f"{i}.proj", blk.attn.proj.weight, blk.attn.proj.bias))
+            if i < pm:
+                items += [(f"{i}.fc1", blk.mlp.fc1.weight, blk.mlp.fc1.bias), (f"{i}.fc2", blk.mlp.fc2.weight, blk.mlp.fc2.bias)]
         ent = self.__dict__.get("_c4_w")
         key = tuple((n, w.data_ptr(), b.data_ptr()) for n, w, b in items)
         if ent is None or ent["key"] != key:
             dev = items[0][1].device
             bufs = {n: (torch.zeros((w.shape[0], nn_ops.split_ld(w.shape[1])), device=dev, dtype=torch.float16),
                         nn_ops.c4_scales(w.shape[0], w.shape[1], dev)) for n, w, _ in items}
-            rec_dt = np.dtype([("src", "u8"), ("bias", "u8"), ("dst", "u8"), ("sc", "u8"), ("rows", "i4"), ("K", "i4"), ("row0", "i4"), ("pad", "i4")])
+            rec_dt = np.dtype([("src", "u8"), ("bias", "u8"), ("dst", "u8"), ("sc", "u8"), ("rows", "i4"), ("K", "i4"), ("row0", "i4"), ("qrows", "i4")])
             assert rec_dt.itemsize == _C.lib().cosa_c4_record_bytes()
             rec, row0 = np.zeros(len(items), rec_dt), 0
             for j, (n, w, b) in enumerate(items):
                 assert w.dtype == torch.float32 and w.is_contiguous() and w.shape[1] % 256 == 0 and w.shape[0] % 256 == 0
-                rec[j] = (w.data_ptr(), b.data_ptr(), bufs[n][0].data_ptr(), bufs[n][1].data_ptr(), w.shape[0], w.shape[1], row0, 0)
+                rec[j] = (w.data_ptr(), b.data_ptr(), bufs[n][0].data_ptr(), bufs[n][1].data_ptr(), w.shape[0], w.shape[1], row0,
+                          w.shape[0] // 3 if n.endswith(".qkv") else 0)          # (q rows pre-scaled: see _c8_weights)
                 row0 += w.shape[0]
             ent = self.__dict__["_c4_w"] = {"key": key, "bufs": bufs, "rec": torch.from_numpy(rec.view(np.uint8).copy()).to(dev),
                                             "n": len(items), "rows": row0}
@@ -477,45 +489,44 @@ class VisionTransformer(nn.Module):
         aux = None
         f = lambda t: t.detach()
         c16 = lambda p_: nn_ops.cast_param(p_, torch.float16)
-        plain_from = self.c8_plain_from if self.c8_plain_from is not None else depth
-        o16 = torch.empty((M, D), device=xr.device, dtype=torch.float16) if plain_from < depth else None
+        pa, pm = self._plain_from()
+        o16 = torch.empty((M, D), device=xr.device, dtype=torch.float16) if pa < depth else None
         for i, blk in enumerate(self.blocks):
-            if i >= plain_from:
+            # ---- attention half ----
+            xn = torch.empty_like(xr) if aux is xr else xr              # right after the auxiliary layer: keep its output, no clone
+            if i >= pa:
                 # the last blocks on plain fp16 operands (the fused 1x path on the same fp32 stream): rounding injected here passes through
                 # the fewest layers and never reaches the auxiliary CAM (tools/sim_precision_map.py, `from:` maps)
                 y, _ = nn_ops.layernorm_f32(xr, c16(blk.norm1.weight), c16(blk.norm1.bias), blk.norm1.eps)
                 qkv = nn_ops.gemm_bf16(y, c16(blk.attn.qkv.weight), c16(blk.attn.qkv.bias), nn_ops.EPI_BIAS)
                 for (B, N), o0, o1 in zip(shapes, offs[:-1], offs[1:]):
-                    nn_ops._attn_fwd(qkv[o0:o1].view(B, N, 3 * D), B, N, H, out=o16[o0:o1].view(B, N, D))
-                xn = torch.empty_like(xr) if aux is xr else xr
+                    nn_ops._attn_fwd(qkv[o0:o1].view(B, N, 3 * D), B, N, H, out=o16[o0:o1].view(B, N, D), nograd=True)
                 nn_ops.gemm_bf16(o16, c16(blk.attn.proj.weight), c16(blk.attn.proj.bias), nn_ops.EPI_RESIDUAL, residual=xr, out=xn)
-                xr = xn
+            else:
+                if c4:
+                    # fp16c4: LayerNorm and the GELU epilogue (and, with c4_proj, the attention kernel) write c4 rows + scale bytes; qkv / fc1 /
+                    # fc2 run on the FP4 block-scaled MFMA, the output projection on fp16c8 operands unless c4_proj
+                    nn_ops.layernorm_c4(xr, f(blk.norm1.weight), f(blk.norm1.bias), blk.norm1.eps, out=bf["y"], scales=bf["y_sc"])
+                    nn_ops.gemm_c4(bf["y"], bf["y_sc"], *W4[f"{i}.qkv"], M, 3 * D, D, nn_ops.EPI_BIAS, out=bf["qkv"], ldy=3 * D)
+                else:
+                    nn_ops.layernorm_c8(xr, f(blk.norm1.weight), f(blk.norm1.bias), blk.norm1.eps, out=bf["y"])
+                    nn_ops.gemm_c8(bf["y"], W[f"{i}.qkv"], M, 3 * D, D, nn_ops.EPI_BIAS, out=bf["qkv"], ldy=3 * D)
+                for (B, N), o0, o1 in zip(shapes, offs[:-1], offs[1:]):
+                    if c4 and self.c4_proj:
+                        nn_ops.attn_fwd_c4(bf["qkv"][o0:o1].view(B, N, 3 * D), B, N, H, bf["o"][o0:o1], bf["o_sc"], o0, q_prescaled=True)
+                    else:
+                        nn_ops.attn_fwd_c8(bf["qkv"][o0:o1].view(B, N, 3 * D), B, N, H, bf["o"][o0:o1], q_prescaled=True)
+                if c4 and self.c4_proj:
+                    nn_ops.gemm_c4(bf["o"], bf["o_sc"], *W4[f"{i}.proj"], M, D, D, nn_ops.EPI_RESIDUAL, residual=xr, out=xn)
+                else:
+                    nn_ops.gemm_c8(bf["o"], W[f"{i}.proj"], M, D, D, nn_ops.EPI_RESIDUAL, residual=xr, out=xn)
+            xr = xn
+            # ---- MLP half ----
+            if i >= pm:
                 y, _ = nn_ops.layernorm_f32(xr, c16(blk.norm2.weight), c16(blk.norm2.bias), blk.norm2.eps)
                 hmid = nn_ops.gemm_bf16(y, c16(blk.mlp.fc1.weight), c16(blk.mlp.fc1.bias), nn_ops.EPI_GELU)
                 nn_ops.gemm_bf16(hmid, c16(blk.mlp.fc2.weight), c16(blk.mlp.fc2.bias), nn_ops.EPI_RESIDUAL, residual=xr, out=xr)
-                if i == aux_idx and aux_idx != depth - 1:
-                    aux = xr
-                continue
-            if c4:
-                # fp16c4: LayerNorm and the GELU epilogue (and, with c4_proj, the attention kernel) write c4 rows + scale bytes; qkv / fc1 /
-                # fc2 run on the FP4 block-scaled MFMA, the output projection on fp16c8 operands unless c4_proj
-                nn_ops.layernorm_c4(xr, f(blk.norm1.weight), f(blk.norm1.bias), blk.norm1.eps, out=bf["y"], scales=bf["y_sc"])
-                nn_ops.gemm_c4(bf["y"], bf["y_sc"], *W4[f"{i}.qkv"], M, 3 * D, D, nn_ops.EPI_BIAS, out=bf["qkv"], ldy=3 * D)
-            else:
-                nn_ops.layernorm_c8(xr, f(blk.norm1.weight), f(blk.norm1.bias), blk.norm1.eps, out=bf["y"])
-                nn_ops.gemm_c8(bf["y"], W[f"{i}.qkv"], M, 3 * D, D, nn_ops.EPI_BIAS, out=bf["qkv"], ldy=3 * D)
-            xn = torch.empty_like(xr) if aux is xr else xr              # right after the auxiliary layer: keep its output, no clone
-            for (B, N), o0, o1 in zip(shapes, offs[:-1], offs[1:]):
-                if c4 and self.c4_proj:
-                    nn_ops.attn_fwd_c4(bf["qkv"][o0:o1].view(B, N, 3 * D), B, N, H, bf["o"][o0:o1], bf["o_sc"], o0)
-                else:
-                    nn_ops.attn_fwd_c8(bf["qkv"][o0:o1].view(B, N, 3 * D), B, N, H, bf["o"][o0:o1])
-            if c4 and self.c4_proj:
-                nn_ops.gemm_c4(bf["o"], bf["o_sc"], *W4[f"{i}.proj"], M, D, D, nn_ops.EPI_RESIDUAL, residual=xr, out=xn)
-            else:
-                nn_ops.gemm_c8(bf["o"], W[f"{i}.proj"], M, D, D, nn_ops.EPI_RESIDUAL, residual=xr, out=xn)
-            xr = xn
-            if c4:
+            elif c4:
                 nn_ops.layernorm_c4(xr, f(blk.norm2.weight), f(blk.norm2.bias), blk.norm2.eps, out=bf["y"], scales=bf["y_sc"])
                 nn_ops.gemm_c4(bf["y"], bf["y_sc"], *W4[f"{i}.fc1"], M, Hd, D, nn_ops.EPI_GELU, out=bf["h"], out_scales=bf["h_sc"],
                                ldy=nn_ops.split_ld(Hd))

@@ -119,8 +119,10 @@ stamps = None     # set by bench.py to a KernelStamps to switch the stamping on 
 gemm_stamps = None   # likewise for the projection GEMMs (persistent 256x256 kernel)
 
 
-def _attn_fwd(qkv, B, N, H, out=None):
-    """fused attention forward on packed qkv [B,N,3,H,64] (bf16 or fp16 operands: the kernel build is picked by qkv's dtype)"""
+def _attn_fwd(qkv, B, N, H, out=None, nograd=False):
+    """fused attention forward on packed qkv [B,N,3,H,64] (bf16 or fp16 operands: the kernel build is picked by qkv's dtype).
+    nograd: a pass without backward (teacher, evaluation) -- flag bit 10 lets the kernel hold Q pre-scaled in the operand type and take the
+    softmax's running maximum through the score MFMAs (csrc/attn_kernels.hip: AUGM); the passes that keep LSE for a backward do not."""
     dt = qkv.dtype
     if out is None:
         out = torch.empty((B, N, H * 64), device=qkv.device, dtype=dt)
@@ -129,8 +131,8 @@ def _attn_fwd(qkv, B, N, H, out=None):
     fl = 4.0 * B * H * N * N * 64
     st = stamps.next_slot(fl) if stamps is not None else None
     with _C.profiled("attn_fwd"):
-        _C.check(_C.fn16("cosa_attn_fwd", dt)(_C.ptr(qkv), _C.ptr(out), _C.ptr(lse), B, N, H, 64, 0.125, 1, st, _C.ptr(ws), ws.numel(),
-                                              _C.stream_ptr()), "cosa_attn_fwd")
+        _C.check(_C.fn16("cosa_attn_fwd", dt)(_C.ptr(qkv), _C.ptr(out), _C.ptr(lse), B, N, H, 64, 0.125, 0x400 if nograd else 0, st,
+                                              _C.ptr(ws), ws.numel(), _C.stream_ptr()), "cosa_attn_fwd")
     _flops["attn_fwd"] = _flops.get("attn_fwd", 0) + fl
     return out, lse
 
@@ -527,27 +529,30 @@ def gemm_c4(xs, xsc, ws, wsc, M, N, K, epilogue=EPI_BIAS, residual=None, out=Non
     return (out, out_scales) if epilogue == EPI_GELU else out
 
 
-def attn_fwd_c4(qkv, B, N, H, out_c4, out_scales, row0, lse=None):
+def attn_fwd_c4(qkv, B, N, H, out_c4, out_scales, row0, lse=None, q_prescaled=False):
     """attention on plain fp16 qkv [B, N, 3 H 64] -> c4 rows out_c4 [B*N, 2 H 64 + 64 fp16 units] (a row slice of an operand) + the scale bytes of
     those rows in out_scales, the scale tensor of the whole operand; row0 = index of out_c4's first row in that operand"""
     assert qkv.dtype == torch.float16 and qkv.is_contiguous() and out_c4.stride(0) == split_ld(H * 64)
     fl = 4.0 * B * H * N * N * 64
     st = stamps.next_slot(fl) if stamps is not None else None
     with _C.profiled("attn_fwd"):
-        _C.check(_C.lib().cosa_attn_fwd_f16c4(_C.ptr(qkv), _C.ptr(out_c4), _C.ptr(out_scales), int(row0), _C.ptr(lse), B, N, H, 64, 0.125, st,
+        _C.check(_C.lib().cosa_attn_fwd_f16c4(_C.ptr(qkv), _C.ptr(out_c4), _C.ptr(out_scales), int(row0), _C.ptr(lse), B, N, H, 64, LN2 if q_prescaled else 0.125, st,
                                               _C.stream_ptr()), "cosa_attn_fwd_f16c4")
     _flops["attn_fwd"] = _flops.get("attn_fwd", 0) + fl
     return out_c4
 
 
-def attn_fwd_c8(qkv, B, N, H, out_c8, lse=None):
+LN2 = 0.6931471805599453          # attention scale to pass when q arrives pre-multiplied by 64^-0.5 log2(e) (weights folded: models/vit.py)
+
+
+def attn_fwd_c8(qkv, B, N, H, out_c8, lse=None, q_prescaled=False):
     """attention on plain fp16 qkv [B, N, 3 H 64] -> c8 rows out_c8 [B*N, 2 H 64 + 64 fp16 units] (hi | lo8 | hi8 | aug)"""
     assert qkv.dtype == torch.float16 and qkv.is_contiguous() and out_c8.stride(0) == split_ld(H * 64)
     fl = 4.0 * B * H * N * N * 64
     st = stamps.next_slot(fl) if stamps is not None else None
     with _C.profiled("attn_fwd"):
-        _C.check(_C.lib().cosa_attn_fwd_f16c8(_C.ptr(qkv), _C.ptr(out_c8), _C.ptr(lse), B, N, H, 64, 0.125, st, _C.stream_ptr()),
-                 "cosa_attn_fwd_f16c8")
+        _C.check(_C.lib().cosa_attn_fwd_f16c8(_C.ptr(qkv), _C.ptr(out_c8), _C.ptr(lse), B, N, H, 64, LN2 if q_prescaled else 0.125, st,
+                                              _C.stream_ptr()), "cosa_attn_fwd_f16c8")
     _flops["attn_fwd"] = _flops.get("attn_fwd", 0) + fl
     return out_c8
 

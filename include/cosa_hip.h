@@ -181,7 +181,10 @@ int cosa_dense_energy_backward(const float *AS, const float *roi, const float *g
  *   lse [B,H,N] f32 (log-sum-exp of the scaled scores, kept for the backward pass)
  *   V is read in place (its V^T fragments come from the transposing LDS read): the workspace is a token 256 bytes and
  *   cosa_attn_prepare_vt a no-op, both kept for callers written against the earlier V^T-copy version; `flags` bits 8 / 9
- *   force 4 / 2 waves per workgroup (default: by the number of rounds, attn_kernels.hip), the other bits are ignored.
+ *   force 4 / 2 waves per workgroup (default: by the number of rounds, attn_kernels.hip); bit 10 marks a pass WITHOUT backward (the
+ *   teacher's / evaluation's torch.no_grad() calls of the same module): the kernel may then hold q pre-multiplied by scale * log2(e) in
+ *   the operand type and feed the softmax's running maximum through the score MFMAs (one more rounding of q; lse is the log of the sum of
+ *   the ROUNDED probabilities); the other bits are ignored.
  * ------------------------------------------------------------------------------------- */
 size_t cosa_attn_workspace_bytes(int B, int N, int H);
 int cosa_attn_prepare_vt(const void *qkv, int B, int N, int H, void *workspace, size_t workspace_bytes, void *stream);
@@ -369,7 +372,9 @@ int cosa_lattice_filter_d2(const float *ins, float *outs, int N, int K, int H, i
  *                         block) for the c8 output projection; lse optional
  * ------------------------------------------------------------------------------------- */
 int cosa_c8_rows(const float *src, const float *bias, void *dst, int R, int K, long long src_ld, int ones, void *stream);
-size_t cosa_c8_record_bytes(void);       /* { const float *src; const float *bias; void *dst; int rows, K, row0, pad; } */
+size_t cosa_c8_record_bytes(void);       /* { const float *src; const float *bias; void *dst; int rows, K, row0, qrows; }: the first qrows rows and bias
+                                          * entries are multiplied by 64^-0.5 log2(e) first (the q third of a qkv projection, for cosa_attn_fwd_f16c8
+                                          * called with scale = ln 2: the attention scale folded into the weights, no extra rounding of q) */
 int cosa_c8_rows_batched(const void *records /* device */, int n_records, int total_rows, void *stream);   /* all weight matrices, one launch */
 int cosa_layernorm_c8(const float *x, const float *gamma, const float *beta, void *y_c8, float *y_f32, int rows, int dim,
                       float eps, void *stream);
@@ -387,14 +392,14 @@ int cosa_attn_fwd_f16c8(const void *qkv, void *out_c8, float *lse, int B, int N,
  * [hi | lo'] for weights) -- and a scale tensor of cosa_c4_scale_bytes(R, K) bytes with one E8M0 byte per block (smallest 2^e with
  * amax / 2^e <= 6; weights carry the 2^-11), laid out per 256-row panel and 128-feature tile as the GEMM's lanes read it (c4.hpp).  K % 256 == 0.
  *   cosa_c4_rows          src fp32 [R, K] (+ bias fp32 [R] | ones) -> rows + scales; weight != 0: weight block order / scale bias
- *   cosa_c4_rows_batched  the weight matrices of a network in one launch ({src, bias, dst, scales, rows, K, row0, pad} records)
+ *   cosa_c4_rows_batched  the weight matrices of a network in one launch ({src, bias, dst, scales, rows, K, row0, qrows} records; qrows as for cosa_c8_rows_batched)
  *   cosa_layernorm_c4     nn.LayerNorm(768, eps), fp32 gamma / beta, over the fp32 residual stream -> c4 rows + scales and/or fp32
  *   cosa_gemm_f16c4       Y = Xs Ws^T (bias inside Ws); N % 256 == 0.  epilogue 0: Y fp16 [M, ldy >= N]; 1 (GELU): Y = c4 rows [M, ldy = 2N + 64
  *                         fp16 units] + Yscales (activation layout; the augmentation block left to the caller); 2: Y fp32 [M, N] = residual + .
  * ------------------------------------------------------------------------------------- */
 size_t cosa_c4_scale_bytes(int rows, int K);
 int cosa_c4_rows(const float *src, const float *bias, void *dst, void *scales, int R, int K, long long src_ld, int ones, int weight, void *stream);
-size_t cosa_c4_record_bytes(void);       /* { const float *src; const float *bias; void *dst; void *scales; int rows, K, row0, pad; } */
+size_t cosa_c4_record_bytes(void);       /* { const float *src; const float *bias; void *dst; void *scales; int rows, K, row0, qrows; } */
 int cosa_c4_rows_batched(const void *records /* device */, int n_records, int total_rows, void *stream);
 int cosa_layernorm_c4(const float *x, const float *gamma, const float *beta, void *y_c4, void *y_scales, float *y_f32, int rows, int dim,
                       float eps, void *stream);

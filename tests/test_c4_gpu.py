@@ -125,18 +125,23 @@ def test_c4_rows_batched_equals_single_launches():
     g = torch.Generator().manual_seed(1)
     mats = [(torch.randn(256, 768, generator=g).cuda(), torch.randn(256, generator=g).cuda()),
             (torch.randn(768, 3072, generator=g).cuda() * 0.02, torch.randn(768, generator=g).cuda())]
-    rec_dt = np.dtype([("src", "u8"), ("bias", "u8"), ("dst", "u8"), ("sc", "u8"), ("rows", "i4"), ("K", "i4"), ("row0", "i4"), ("pad", "i4")])
+    rec_dt = np.dtype([("src", "u8"), ("bias", "u8"), ("dst", "u8"), ("sc", "u8"), ("rows", "i4"), ("K", "i4"), ("row0", "i4"), ("qrows", "i4")])
     assert rec_dt.itemsize == _C.lib().cosa_c4_record_bytes()
     rec, outs, row0 = np.zeros(len(mats), rec_dt), [], 0
+    qrows = [0, 256]                 # second matrix: the first 256 rows (and bias entries) leave multiplied by 64^-0.5 log2(e) (folded attention scale)
     for j, (w, b) in enumerate(mats):
         o = torch.zeros((w.shape[0], nn_ops.split_ld(w.shape[1])), device="cuda", dtype=torch.float16)
         sc = nn_ops.c4_scales(w.shape[0], w.shape[1], "cuda")
         outs.append((o, sc))
-        rec[j] = (w.data_ptr(), b.data_ptr(), o.data_ptr(), sc.data_ptr(), w.shape[0], w.shape[1], row0, 0)
+        rec[j] = (w.data_ptr(), b.data_ptr(), o.data_ptr(), sc.data_ptr(), w.shape[0], w.shape[1], row0, qrows[j])
         row0 += w.shape[0]
     d_rec = torch.from_numpy(rec.view(np.uint8).copy()).cuda()
     _C.check(_C.lib().cosa_c4_rows_batched(_C.ptr(d_rec), len(mats), row0, _C.stream_ptr()), "cosa_c4_rows_batched")
-    for (w, b), (o, sc) in zip(mats, outs):
+    c = torch.tensor(0.125, dtype=torch.float32) * torch.tensor(1.4426950408889634, dtype=torch.float32)
+    for (w, b), (o, sc), qr in zip(mats, outs, qrows):
+        w, b = w.clone(), b.clone()
+        w[:qr] *= c
+        b[:qr] *= c
         o1, sc1 = nn_ops.c4_rows(w, bias=b, weight=True)
         assert torch.equal(o.view(torch.int16), o1.view(torch.int16)) and torch.equal(sc, sc1)
 

@@ -485,3 +485,75 @@ def test_attention_fwd_two_and_four_wave_workgroups_are_bit_identical():
         assert not torch.isnan(res[0][0].float()).any() and not torch.isnan(res[0][1]).any()
         for out, lse in res[1:]:
             assert torch.equal(out, res[0][0]) and torch.equal(lse, res[0][1])
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,N,H", [(2, 197, 12), (1, 785, 12), (3, 64, 2), (2, 100, 3), (1, 1765, 2), (1, 1, 1), (1, 129, 1), (2, 513, 4)])
+def test_attention_fwd_nograd_variant_vs_fp32_reference(dt, B, N, H):
+    """flags bit 10 (the teacher's / evaluation's passes): q pre-scaled in the operand type, the running maximum fed through the score MFMAs
+    as a 65th contraction index, row sums over the rounded probabilities (attn_kernels.hip: AUGM).  Same bars as the training-side
+    kernel for the output (one more rounding of q: 2e-2 bf16 / 3e-3 fp16 of max|ref|); lse within the operand type's resolution of the
+    scores; 2 and 4 waves per workgroup bit-identical; identical bits run to run."""
+    from cosa_amd import _C
+    torch.manual_seed(N + H)
+    L = _C.lib()
+    f16 = dt == torch.float16
+    fwd = L.cosa_attn_fwd_f16 if f16 else L.cosa_attn_fwd
+    qkv = (torch.randn(B, N, 3 * H * 64, device="cuda") * 1.5).to(dt)
+    ws = _C.workspace((L.cosa_attn_workspace_bytes_f16 if f16 else L.cosa_attn_workspace_bytes)(B, N, H), qkv.device, "attn")
+    res = []
+    for flags in (0x400, 0x400 | 0x200, 0x400 | 0x100, 0x400):
+        out = torch.full((B, N, H * 64), float("nan"), device="cuda", dtype=dt)
+        lse = torch.full((B, H, N), float("nan"), device="cuda")
+        _C.check(fwd(_C.ptr(qkv), _C.ptr(out), _C.ptr(lse), B, N, H, 64, 0.125, flags, None, _C.ptr(ws), ws.numel(), _C.stream_ptr()), "cosa_attn_fwd")
+        res.append((out, lse))
+    for out, lse in res[1:]:
+        assert torch.equal(out, res[0][0]) and torch.equal(lse, res[0][1])
+    out, lse = res[0]
+    ref, lse_ref = _ref_attention(qkv.float(), H)
+    err = (out.float() - ref).abs().max().item()
+    assert err <= (3e-3 if f16 else 2.5e-2) * ref.abs().max().item() + 1e-3, err
+    assert (lse - lse_ref).abs().max().item() <= (4e-3 if f16 else 3e-2)
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_attention_fwd_nograd_variant_moves_its_reference(dt):
+    """the reference maximum of a query (kept representable in the operand type) has to follow: a dominant key late in the sequence, scores far
+    below zero from the first tile on (m = 0 must not be taken for a maximum), and a row whose maximum keeps growing tile after tile"""
+    from cosa_amd import _C
+    L = _C.lib()
+    f16 = dt == torch.float16
+    fwd = L.cosa_attn_fwd_f16 if f16 else L.cosa_attn_fwd
+    B, N, H = 1, 300, 1
+    torch.manual_seed(0)
+    qkv = torch.randn(B, N, 3 * 64, device="cuda") * 0.5
+    qkv[0, 250, 64:128] = qkv[0, 7, 0:64] * 40                       # key 250 aligned with query 7
+    qkv[0, :, 64:128] += -3.0 * qkv[0, 9, 0:64].sign()                # query 9: every score strongly negative
+    for t in range(4):                                                # query 11: its best key gets better in every 64-key tile
+        qkv[0, 64 * t + 5, 64:128] += qkv[0, 11, 0:64] * (6.0 * (t + 1))
+    qkv = qkv.to(dt)
+    ws = _C.workspace((L.cosa_attn_workspace_bytes_f16 if f16 else L.cosa_attn_workspace_bytes)(B, N, H), qkv.device, "attn")
+    out = torch.empty(B, N, H * 64, device="cuda", dtype=dt)
+    lse = torch.empty(B, H, N, device="cuda")
+    _C.check(fwd(_C.ptr(qkv), _C.ptr(out), _C.ptr(lse), B, N, H, 64, 0.125, 0x400, None, _C.ptr(ws), ws.numel(), _C.stream_ptr()), "cosa_attn_fwd")
+    ref, lse_ref = _ref_attention(qkv.float(), H)
+    assert torch.isfinite(out.float()).all() and torch.isfinite(lse).all()
+    assert (out.float() - ref).abs().max().item() <= (3e-3 if f16 else 2.5e-2) * ref.abs().max().item() + 1e-3
+    assert ((lse - lse_ref).abs() <= (4e-3 if f16 else 3e-2) + 2e-3 * lse_ref.abs()).all()
+
+
+# md5 of (out, lse) of the training-side forward kernel on a CPU-seeded input: the student's attention results are pinned bit for bit, so
+# that profiles/r04_student_vs_oracle_*.txt stays comparable from round to round (tests/test_losses_gpu.py: STUDENT_BARS explains why)
+_ATTN_PIN = {(2, 197, 12): ("4e46320de88aabd44c3036a58291d771", "50f0b198eb3949cab0420fb654f13b65"), (3, 513, 4): ("005181895da30926a8b7fbaf650f5146", "843976d3fe6279bc4c98ae4bb0763f69")}
+
+
+@pytest.mark.parametrize("B,N,H", list(_ATTN_PIN))
+def test_attention_fwd_training_kernel_is_bit_stable(B, N, H):
+    import hashlib
+    from cosa_amd import nn_ops
+    g = torch.Generator().manual_seed(1234 + N)
+    qkv = (torch.randn(B, N, 3 * H * 64, generator=g) * 0.8).bfloat16().cuda()
+    out, lse = nn_ops._attn_fwd(qkv, B, N, H)
+    md5 = lambda t: hashlib.md5(t.cpu().contiguous().view(torch.uint8).numpy().tobytes()).hexdigest()
+    got = (md5(out), md5(lse))
+    assert got == _ATTN_PIN[(B, N, H)], got

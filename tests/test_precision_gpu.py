@@ -247,7 +247,12 @@ def test_im2col_c8_and_batched_weight_rows_equal_the_row_producer():
     blk = net.encoder.blocks[3]
     for name, wgt, b in (("patch", net.encoder.patch_embed.proj.weight.reshape(768, -1), net.encoder.patch_embed.proj.bias),
                          ("3.qkv", blk.attn.qkv.weight, blk.attn.qkv.bias), ("3.fc2", blk.mlp.fc2.weight, blk.mlp.fc2.bias)):
-        assert torch.equal(ws[name].view(torch.int16), nn_ops.c8_rows(wgt.detach().contiguous(), bias=b.detach()).view(torch.int16)), name
+        wgt, b = wgt.detach().clone().contiguous(), b.detach().clone()
+        if name.endswith(".qkv"):          # the attention scale 64^-0.5 log2(e) is folded into the q rows (the attention kernel is called with ln 2)
+            c = torch.tensor(0.125, dtype=torch.float32) * torch.tensor(1.4426950408889634, dtype=torch.float32)
+            wgt[:768] *= c
+            b[:768] *= c
+        assert torch.equal(ws[name].view(torch.int16), nn_ops.c8_rows(wgt, bias=b).view(torch.int16)), name
 
 
 @pytest.mark.parametrize("epi", [0, 1, 2])
@@ -311,7 +316,7 @@ def test_attention_c8_output_rows(B, N, H):
     torch.manual_seed(N)
     D = H * 64
     qkv = (torch.randn(B, N, 3 * D, device="cuda") * 1.5).half()
-    plain, lse_p = nn_ops._attn_fwd(qkv, B, N, H)
+    plain, lse_p = nn_ops._attn_fwd(qkv, B, N, H, nograd=True)          # (the same no-grad variant of the kernel as the c8-output one)
     out = torch.zeros(B * N, 2 * D + 64, device="cuda", dtype=torch.float16)
     lse = torch.empty(B, H, N, device="cuda")
     nn_ops.attn_fwd_c8(qkv, B, N, H, out, lse)
@@ -392,13 +397,15 @@ TEACHER_BARS = {
     "fp16c8": NORTH_STAR,          # the same bars at 2x (not 3x) the 16-bit MFMA work
     "fp16c8-9": NORTH_STAR,        # ... with the last three blocks on plain fp16 operands (round 3's benchmarked mode)
     "fp16c4": NORTH_STAR,          # round 4: FP4 (e2m1, MX blocks) correction terms in qkv / fc1 / fc2: ~1.6x the 16-bit MFMA work
-    "fp16c4-11": NORTH_STAR,       # ... with the last block on plain fp16 operands: the benchmarked (headline) mode of bench.py
-    "fp16c4-10": NORTH_STAR,       # ... the last two blocks (measured for the margin table; not the default)
+    "fp16c4-10": NORTH_STAR,       # ... with the last two blocks on plain fp16 operands
+    "fp16c4-9": NORTH_STAR,        # ... the last three
+    "fp16c4-8": NORTH_STAR,        # ... the last four: the benchmarked (headline) mode of bench.py
+    "fp16c4-12m8": NORTH_STAR,     # per-half map: attention halves corrected in every block, MLP halves in blocks 0-7
 }
 # the modes bench.py may run as its headline are checked on three independent weight / batch draws; bench.py reports the WORST of these
 # lines (profiles/r04_accuracy_teacher.txt, copied from gpurun_out/ after the GPU run) and derives `tolerance_met` from them
 CONFORMING_SEEDS = (3, 11, 29)
-_CASES = [(m, 3) for m in TEACHER_BARS] + [(m, sd_) for m in ("fp16c8", "fp16c8-9", "fp16c4", "fp16c4-11", "fp16c4-10") for sd_ in CONFORMING_SEEDS[1:]]
+_CASES = [(m, 3) for m in TEACHER_BARS] + [(m, sd_) for m in ("fp16c8", "fp16c8-9", "fp16c4", "fp16c4-10", "fp16c4-9", "fp16c4-8", "fp16c4-12m8") for sd_ in CONFORMING_SEEDS[1:]]
 
 
 @pytest.mark.parametrize("S", [224, 448])
