@@ -16,6 +16,17 @@ bash tools/pmc_collect.sh attn4 tools/attn_one.py || exit 1
 python3 tools/pmc_summary.py gpurun_out/pmc_attn4 attn_fwd2_kernel 433766400 "B=32 N=1765 H=12 (teacher scale 1.5), 4 waves per workgroup" gpurun_out/r04_attn_fwd_pmc.json > /dev/null || exit 1
 rm -rf gpurun_out/pmc_attn4
 fi
+if [ "$which" = all ] || [ "$which" = gemmfc2 ]; then
+bash tools/pmc_collect.sh gemmc4f2 "tools/gemm_c4_one.py fc2" || exit 1
+# algorithmic bytes: X rows (hi 2K + blocks K) + scales, W rows, fp32 residual in and out
+python3 tools/pmc_summary.py gpurun_out/pmc_gemmc4f2 gemm_bf16_v6_kernel $((87904*3072*3 + 87904*3072/16 + 768*3072*3 + 87904*768*8)) "fc2 + residual M=87904 N=768 K=3072 (fp16c4 operands, fp32 stream in place)" gpurun_out/r04_gemm_c4_fc2_pmc.json > /dev/null || exit 1
+rm -rf gpurun_out/pmc_gemmc4f2
+fi
+if [ "$which" = all ] || [ "$which" = wgrad ]; then
+bash tools/pmc_collect.sh wgb4 tools/scratch/wgrad_batched_one.py || exit 1
+python3 tools/pmc_summary.py gpurun_out/pmc_wgb4 gemm_wgrad_batched 3708616704 "12 blocks x (qkv, proj, fc1, fc2) at M=12560: 1296 tiles of 256 x 256, one launch" gpurun_out/r04_wgrad_batched_pmc.json > /dev/null || exit 1
+rm -rf gpurun_out/pmc_wgb4
+fi
 if [ "$which" = all ] || [ "$which" = lattice ]; then
 bash tools/pmc_kernels.sh lattice4 tools/bench_bilateral.py "" > gpurun_out/pmc_lattice4.txt 2>&1 || exit 1
 python3 tools/lattice_pmc_summary.py gpurun_out/pmc_lattice4.json gpurun_out/r04_lattice_pmc.json 13 > gpurun_out/r04_lattice_pmc.txt || exit 1
