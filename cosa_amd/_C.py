@@ -102,6 +102,7 @@ _SIGS = {
     "cosa_gemm_set_variant": (None, [c_int]),
     "cosa_gemm_set_grid_policy": (None, [c_int]),
     "cosa_gemm_set_grid_policy_f16": (None, [c_int]),
+    "cosa_token_junction_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "cosa_gemm_set_stamp_slot": (None, [c_void_p]),
     "cosa_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     "cosa_attn_prepare_vt": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),

@@ -891,6 +891,51 @@ extern "C" int cosa_layernorm_bwd(const void *dy, const void *x_new, const float
     return COSA_OK;
 }
 
+// Junction of the training path's heads (models/__init__.py:163-206 + autograd): decoder, CAM head and pooled classification head all read the
+// patch tokens (the class token feeds nothing there) of ONE bf16 copy of the fp32 final tokens; their bf16 gradients [B, N - 1, D] meet here:
+// dx [B, N, D] fp32 = 0 in the class-token row, g0 + g1 + g2 (fp32 adds in that order; absent consumers are null) elsewhere -- one pass
+// instead of autograd's zero-fill + slice copy per consumer, a cast and the adds (round 4: ~20 ATen launches per step).
+__global__ __launch_bounds__(256) void token_junction_bwd_kernel(const bf16 *__restrict__ g0, const bf16 *__restrict__ g1, const bf16 *__restrict__ g2,
+                                                                float *__restrict__ dx, int N, long long total4)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;            // one float4 of dx
+    if (i >= total4) return;
+    constexpr int D4 = D / 4;
+    const long long row = i / D4;
+    const int c4 = (int)(i - row * D4), t = (int)(row % N);
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (t != 0) {
+        const long long b = row / N;
+        const size_t src = ((size_t)(b * (N - 1) + t - 1) * D4 + c4) * 4;
+        auto ld = [&](const bf16 *g, float (&v)[4]) {
+            const uint2 u = *reinterpret_cast<const uint2 *>(g + src);
+            v[0] = __builtin_bit_cast(float, u.x << 16); v[1] = __builtin_bit_cast(float, u.x & 0xffff0000u);
+            v[2] = __builtin_bit_cast(float, u.y << 16); v[3] = __builtin_bit_cast(float, u.y & 0xffff0000u);
+        };
+        float a[4] = {0.f, 0.f, 0.f, 0.f}, v[4];
+        bool first = true;
+        for (const bf16 *g : {g0, g1, g2}) {
+            if (!g) continue;
+            ld(g, v);
+            if (first) { a[0] = v[0]; a[1] = v[1]; a[2] = v[2]; a[3] = v[3]; first = false; }
+            else { a[0] += v[0]; a[1] += v[1]; a[2] += v[2]; a[3] += v[3]; }
+        }
+        o = make_float4(a[0], a[1], a[2], a[3]);
+    }
+    *reinterpret_cast<float4 *>(dx + i * 4) = o;
+}
+
+extern "C" int cosa_token_junction_bwd(const void *g0, const void *g1, const void *g2, float *dx, int B, int N, int dim, void *stream)
+{
+    COSA_REQUIRE((g0 || g1 || g2) && dx && B > 0 && N > 1, "cosa_token_junction_bwd: bad arguments");
+    COSA_REQUIRE(dim == D, "cosa_token_junction_bwd: dim must be 768 (ViT-B)");
+    const long long total4 = (long long)B * N * (D / 4);
+    hipLaunchKernelGGL(token_junction_bwd_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, as_stream(stream), static_cast<const bf16 *>(g0),
+                       static_cast<const bf16 *>(g1), static_cast<const bf16 *>(g2), dx, N, total4);
+    COSA_LAUNCH_CHECK();
+    return COSA_OK;
+}
+
 extern "C" int cosa_layernorm_bwd_f32(const void *dy, int dy_is_f32, const float *x, const void *gamma, const float *dskip, float *dx, void *dx16,
                                       float *dgamma, float *dbeta, int accumulate, int rows, int dim, float eps, void *workspace,
                                       size_t workspace_bytes, void *stream)

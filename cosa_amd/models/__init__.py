@@ -191,21 +191,21 @@ class VITNetwork(nn.Module):
         B = x.shape[0]
         p = self.encoder.patch_size
         h, w = x.shape[-2] // p, x.shape[-1] // p
-        t_dec, t_cam, t_cls = nn_ops.fanout_bf16(feats.final, 3)
-        a_cam, a_cls = nn_ops.fanout_bf16(feats.aux, 2)
-        x4 = t_dec[:, 1:].reshape(B, h, w, -1).permute(0, 3, 1, 2)
-        seg = self.decoder.forward_tokens_train(t_dec[:, 1:], B, h, w)
+        t_dec, t_cam, t_cls = nn_ops.patch_fanout_bf16(feats.final, 3)          # (patch tokens only: the class token feeds no head)
+        a_cam, a_cls = nn_ops.patch_fanout_bf16(feats.aux, 2)
+        x4 = t_dec.reshape(B, h, w, -1).permute(0, 3, 1, 2)
+        seg = self.decoder.forward_tokens_train(t_dec, B, h, w)
         if seg_only:
             return seg
-        cam = self._cam(t_cam[:, 1:], self.classifier.weight, B, h, w, detach == 'feat', detach == 'cls')
-        cam_aux = self._cam(a_cam[:, 1:], self.aux_classifier.weight, B, h, w, detach == 'feat', detach == 'cls')
+        cam = self._cam(t_cam, self.classifier.weight, B, h, w, detach == 'feat', detach == 'cls')
+        cam_aux = self._cam(a_cam, self.aux_classifier.weight, B, h, w, detach == 'feat', detach == 'cls')
         if detach == 'all':
             cam, cam_aux = cam.detach(), cam_aux.detach()
         if cam_only:
             return cam, cam_aux
         dt = self.compute_dtype
-        cls_x4 = self._cls_head(self._pool(t_cls[:, 1:]), self.classifier.weight, dt)
-        cls_aux = self._cls_head(self._pool(a_cls[:, 1:]), self.aux_classifier.weight, dt)
+        cls_x4 = self._cls_head(self._pool(t_cls), self.classifier.weight, dt)
+        cls_aux = self._cls_head(self._pool(a_cls), self.aux_classifier.weight, dt)
         return cls_x4, cls_aux, x4, seg, cam, cam_aux
 
     def _heads(self, x, feats, cam_only, seg_only, detach, need_cls=True):

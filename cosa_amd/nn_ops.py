@@ -1173,3 +1173,33 @@ class FanoutBf16Fn(Function):
 
 def fanout_bf16(x, n):
     return FanoutBf16Fn.apply(x, n)
+
+
+class PatchFanoutFn(Function):
+    """fp32 tokens x [B, N, 768] -> n views of ONE bf16 copy of the PATCH tokens [B, N - 1, 768] (the class token feeds none of the heads'
+    consumers: models/__init__.py:163-206); backward: the consumers' bf16 gradients are summed in fp32 (in consumer order, as FanoutBf16Fn
+    does) into dx with a zero class-token row by one kernel -- autograd's version of the same sum is a zero-fill and a slice copy per
+    consumer, a cast and the adds."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        assert x.dtype == torch.float32 and x.dim() == 3 and x.shape[2] == 768 and x.is_cuda
+        ctx.shape = x.shape
+        p16 = x[:, 1:].to(torch.bfloat16)                # one strided-read cast kernel
+        return tuple(p16.view_as(p16) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        B, N, D = ctx.shape
+        gs = [g.contiguous() if g is not None else None for g in gs]
+        live = [g for g in gs if g is not None]
+        assert 1 <= len(live) <= 3 and all(g.dtype == torch.bfloat16 and g.shape == (B, N - 1, D) for g in live)
+        live += [None] * (3 - len(live))
+        dx = torch.empty((B, N, D), device=live[0].device, dtype=torch.float32)
+        _C.check(_C.lib().cosa_token_junction_bwd(_C.ptr(live[0]), _C.ptr(live[1]), _C.ptr(live[2]), _C.ptr(dx), B, N, D, _C.stream_ptr()),
+                 "cosa_token_junction_bwd")
+        return dx, None
+
+
+def patch_fanout_bf16(x, n):
+    return PatchFanoutFn.apply(x, n)

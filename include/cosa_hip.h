@@ -480,6 +480,10 @@ int cosa_layernorm_bwd(const void *dy, const void *x_new, const float *mean, con
 int cosa_layernorm_bwd_f32(const void *dy, int dy_is_f32, const float *x, const void *gamma, const float *dskip, float *dx, void *dx16,
                            float *dgamma, float *dbeta, int accumulate, int rows, int dim, float eps, void *workspace,
                            size_t workspace_bytes, void *stream);
+/* models/__init__.py:163-206 + autograd: the gradient junction of the training path's heads.  g0, g1, g2: bf16 gradients [B, N - 1, dim] of the
+ * consumers of the patch tokens (decoder, CAM head, pooled classification head; NULL = consumer absent); dx [B, N, dim] fp32 = their sum in
+ * fp32 (order g0, g1, g2), zero in the class-token row.                                                                                   */
+int cosa_token_junction_bwd(const void *g0, const void *g1, const void *g2, float *dx, int B, int N, int dim, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * Evaluation path (SURVEY f-1; evaluation_engine.py:96-126,198-200, utils/seg_helper.py:515-546,581-591,

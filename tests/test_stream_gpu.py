@@ -107,6 +107,26 @@ def test_fanout_bf16_sums_gradients_in_fp32():
     assert x.grad.dtype == torch.float32 and torch.equal(x.grad, (ga.float() + gb.float()) + gc.float())
 
 
+@pytest.mark.parametrize("live", [(0, 1, 2), (0, 2), (1,)])
+def test_patch_fanout_equals_the_sliced_fanout(live):
+    """nn_ops.patch_fanout_bf16 (one bf16 copy of the patch tokens, the consumers' gradients summed by cosa_token_junction_bwd) against what it
+    replaced: fanout_bf16 of the whole token tensor + a [:, 1:] slice per consumer -- same forward bits, same gradient bits (fp32 adds in
+    consumer order, zero class-token row), also when some consumers take no part in the backward pass (ragged N)"""
+    from cosa_amd import nn_ops
+    dev = torch.device("cuda", 0)
+    B, N = 3, 198
+    x = torch.randn(B, N, 768, device=dev, requires_grad=True)
+    x2 = x.detach().clone().requires_grad_(True)
+    outs = nn_ops.patch_fanout_bf16(x, 3)
+    refs = [t[:, 1:] for t in nn_ops.fanout_bf16(x2, 3)]
+    assert all(o.shape == (B, N - 1, 768) and o.is_contiguous() and torch.equal(o, r) for o, r in zip(outs, refs))
+    assert outs[0].data_ptr() == outs[1].data_ptr() == outs[2].data_ptr()
+    gs = [torch.randn(B, N - 1, 768, device=dev).to(torch.bfloat16) for _ in range(3)]
+    torch.autograd.backward([outs[i] for i in live], [gs[i] for i in live])
+    torch.autograd.backward([refs[i] for i in live], [gs[i] for i in live])
+    assert x.grad.dtype == torch.float32 and torch.equal(x.grad, x2.grad) and float(x.grad[:, 0].abs().max()) == 0.0
+
+
 def _student_grads(tr, batch, n_iter, stream, groups):
     enc = tr.student.encoder
     enc.residual_stream, enc.defer_groups = stream, groups

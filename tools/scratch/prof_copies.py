@@ -5,7 +5,7 @@ import torch
 from torch.profiler import profile, ProfilerActivity
 from cosa_amd.train_step import CoSATrainer, default_args, synthetic_batch
 dev = torch.device("cuda", 0)
-args = default_args("VOC12", teacher_precision="bf16", crop_size=448, batch_size=16, teacher_async=False)
+args = default_args("VOC12", teacher_precision="fp16c4-8", crop_size=448, batch_size=16, teacher_async=False)
 tr = CoSATrainer(args, dev, seed=0)
 wimg, simg, lab, box = synthetic_batch(16, 448, 20, dev, seed=1234)
 n_iter = args.warmup_iters + 1
