@@ -318,6 +318,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const op16 *__restric
     int blk, b, h;
     if (!attn_block_map(nblk, ngroups, H, blk, b, h)) return;
     const int q0 = blk * (64 * NW) + wave * 64;
+    const bool busy = q0 < N;          // wave-uniform
     const size_t rs = (size_t)3 * H * HD;
     op16x8 qf[2][4];
 #pragma unroll
@@ -401,6 +402,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const op16 *__restric
         }
         if (!DMA) __syncthreads();
 
+        if (busy) {          // (a wave whose 64 queries all lie past N only stages its share of the K / V tiles and keeps the barriers)
         op16x2 pk[2][2][8];
         f32x16 sc[2][2];
 #pragma unroll
@@ -517,6 +519,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const op16 *__restric
                 }
             }
         __builtin_amdgcn_s_setprio(0);
+        }
         if (DMA) {                                     // the next tile has landed and nobody still reads this one
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
