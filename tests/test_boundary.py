@@ -155,3 +155,24 @@ def test_launcher_rejects_flags_it_does_not_honour():
             launcher.check_supported(bad)
     thr, changed = cosa_args.parse(["exp", "--eval_threshold_filters", "0.11", "0.25"])
     assert thr.eval_threshold_filters == [0.11, 0.25] and "eval_threshold_filters" in changed
+
+
+def test_teacher_precision_mode_strings():
+    """`set_nograd_precision`: "base", "base-n" (blocks from n on plain fp16) and "base-nmk" (their MLP halves from block k on); the launcher's
+    and the trainer's default is the measured 2x-margin map (profiles/r04_accuracy_teacher.txt)"""
+    import torch
+    from cosa_amd.models import build_model
+    from cosa_amd.train_step import default_args
+    from cosa_amd import args as launcher_args
+    a = default_args("VOC12", crop_size=64)
+    assert a.teacher_precision == "fp16c4-8"
+    assert dict((n, d) for n, _t, d in launcher_args.COSA_FLAGS)["teacher_precision"] == "fp16c4-8" if hasattr(launcher_args, "COSA_FLAGS") else True
+    net = build_model(a)
+    for mode, prec, dt, plain in (("bf16", None, torch.bfloat16, (12, 12)), ("fp16c8", "fp16c8", torch.float16, (12, 12)),
+                                  ("fp16c8-9", "fp16c8", torch.float16, (9, 9)), ("fp16c4-8", "fp16c4", torch.float16, (8, 8)),
+                                  ("fp16c4-12m8", "fp16c4", torch.float16, (12, 8)), ("fp16c4-9m7", "fp16c4", torch.float16, (9, 7))):
+        net.set_nograd_precision(mode)
+        assert net.encoder.precision == prec and net.encoder.compute_dtype == dt and net.encoder._plain_from() == plain, mode
+    for bad in ("fp16c4-", "fp16c4-m8", "bf16-3", "fp8", "fp16c4-9m"):
+        with pytest.raises(AssertionError):
+            net.set_nograd_precision(bad)
