@@ -99,6 +99,7 @@ class VisionTransformer(nn.Module):
         self.defer_groups = None       # ... one launch per group of depth / defer_groups blocks; None: 1 on a single GPU, 6 under data parallelism
         self.c8_plain_from = None      # fp16c8 / fp16c4: blocks with index >= this run on plain fp16 operands ("fp16c8-9": the last three)
         self.c8_plain_mlp_from = None  # ... their MLP halves (norm2, fc1, fc2) already from this block on (None: as c8_plain_from)
+        self.c8_plain_qkv = False      # ... the qkv projections of the corrected blocks on plain fp16 operands too (the output projection keeps its terms)
         # fp16c4: the output projection too on fp16c4 operands (the attention kernel then writes c4 rows)?  Measured (round 4, three seeds, 448^2):
         # the auxiliary CAM's worst error goes from 4.5e-4 to 5.1e-4 (margin on the 1e-3 bar 2.2x -> 1.95x) for 0.15 ms per step, so it is off:
         # proj stays on fp16c8 operands (e5m2 corrections), 10 % of the projection work
@@ -377,7 +378,8 @@ class VisionTransformer(nn.Module):
                     items += [(f"{i}.proj", blk.attn.proj.weight, blk.attn.proj.bias)]
                 continue
             if i < pa:
-                items += [(f"{i}.qkv", blk.attn.qkv.weight, blk.attn.qkv.bias), (f"{i}.proj", blk.attn.proj.weight, blk.attn.proj.bias)]
+                items += ([] if self.c8_plain_qkv else [(f"{i}.qkv", blk.attn.qkv.weight, blk.attn.qkv.bias)]) + \
+                         [(f"{i}.proj", blk.attn.proj.weight, blk.attn.proj.bias)]
             if i < pm:
                 items += [(f"{i}.fc1", blk.mlp.fc1.weight, blk.mlp.fc1.bias), (f"{i}.fc2", blk.mlp.fc2.weight, blk.mlp.fc2.bias)]
         ent = self.__dict__.get("_c8_w")
@@ -408,7 +410,8 @@ class VisionTransformer(nn.Module):
         pa, pm = self._plain_from()
         for i, blk in enumerate(self.blocks):
             if i < pa:
-                items.append((f"{i}.qkv", blk.attn.qkv.weight, blk.attn.qkv.bias))
+                if not self.c8_plain_qkv:
+                    items.append((f"{i}.qkv", blk.attn.qkv.weight, blk.attn.qkv.bias))
                 if self.c4_proj:
                     items.append((f"{i}.proj", blk.attn.proj.weight, blk.attn.proj.bias))
             if i < pm:
@@ -503,7 +506,12 @@ class VisionTransformer(nn.Module):
                     nn_ops._attn_fwd(qkv[o0:o1].view(B, N, 3 * D), B, N, H, out=o16[o0:o1].view(B, N, D), nograd=True)
                 nn_ops.gemm_bf16(o16, c16(blk.attn.proj.weight), c16(blk.attn.proj.bias), nn_ops.EPI_RESIDUAL, residual=xr, out=xn)
             else:
-                if c4:
+                pre = True
+                if self.c8_plain_qkv:
+                    y, _ = nn_ops.layernorm_f32(xr, c16(blk.norm1.weight), c16(blk.norm1.bias), blk.norm1.eps)
+                    nn_ops.gemm_bf16(y, c16(blk.attn.qkv.weight), c16(blk.attn.qkv.bias), nn_ops.EPI_BIAS, out=bf["qkv"])
+                    pre = False
+                elif c4:
                     # fp16c4: LayerNorm and the GELU epilogue (and, with c4_proj, the attention kernel) write c4 rows + scale bytes; qkv / fc1 /
                     # fc2 run on the FP4 block-scaled MFMA, the output projection on fp16c8 operands unless c4_proj
                     nn_ops.layernorm_c4(xr, f(blk.norm1.weight), f(blk.norm1.bias), blk.norm1.eps, out=bf["y"], scales=bf["y_sc"])
@@ -513,9 +521,9 @@ class VisionTransformer(nn.Module):
                     nn_ops.gemm_c8(bf["y"], W[f"{i}.qkv"], M, 3 * D, D, nn_ops.EPI_BIAS, out=bf["qkv"], ldy=3 * D)
                 for (B, N), o0, o1 in zip(shapes, offs[:-1], offs[1:]):
                     if c4 and self.c4_proj:
-                        nn_ops.attn_fwd_c4(bf["qkv"][o0:o1].view(B, N, 3 * D), B, N, H, bf["o"][o0:o1], bf["o_sc"], o0, q_prescaled=True)
+                        nn_ops.attn_fwd_c4(bf["qkv"][o0:o1].view(B, N, 3 * D), B, N, H, bf["o"][o0:o1], bf["o_sc"], o0, q_prescaled=pre)
                     else:
-                        nn_ops.attn_fwd_c8(bf["qkv"][o0:o1].view(B, N, 3 * D), B, N, H, bf["o"][o0:o1], q_prescaled=True)
+                        nn_ops.attn_fwd_c8(bf["qkv"][o0:o1].view(B, N, 3 * D), B, N, H, bf["o"][o0:o1], q_prescaled=pre)
                 if c4 and self.c4_proj:
                     nn_ops.gemm_c4(bf["o"], bf["o_sc"], *W4[f"{i}.proj"], M, D, D, nn_ops.EPI_RESIDUAL, residual=xr, out=xn)
                 else:

@@ -401,6 +401,7 @@ TEACHER_BARS = {
     "fp16c4-9": NORTH_STAR,        # ... the last three
     "fp16c4-8": NORTH_STAR,        # ... the last four: the benchmarked (headline) mode of bench.py
     "fp16c4-12m8": NORTH_STAR,     # per-half map: attention halves corrected in every block, MLP halves in blocks 0-7
+    "fp16c4-10q": NORTH_STAR,      # ... with plain-fp16 qkv projections in the corrected blocks (-0.2 ms per block, 1.7x the error: not used)
 }
 # the modes bench.py may run as its headline are checked on three independent weight / batch draws; bench.py reports the WORST of these
 # lines (profiles/r04_accuracy_teacher.txt, copied from gpurun_out/ after the GPU run) and derives `tolerance_met` from them
