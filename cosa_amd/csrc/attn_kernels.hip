@@ -440,10 +440,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const op16 *__restric
                     if (k0 + 32 + crow(i, hh) >= N) sc[u][1][i] = -INFINITY;
                 }
             }
-            float mt = max3f(sc[u][0][0], sc[u][1][0], sc[u][0][1]);
-            mt = fmaxf(mt, sc[u][1][1]);
+            // (four independent chains: a single chain of 16 dependent v_max3 stalls on its own latency with two waves per SIMD)
+            float mc[4];
 #pragma unroll
-            for (int i = 2; i < 16; i++) mt = max3f(mt, sc[u][0][i], sc[u][1][i]);
+            for (int c = 0; c < 4; c++) {
+                mc[c] = max3f(sc[u][0][4 * c], sc[u][1][4 * c], sc[u][0][4 * c + 1]);
+                mc[c] = max3f(mc[c], sc[u][1][4 * c + 1], sc[u][0][4 * c + 2]);
+                mc[c] = max3f(mc[c], sc[u][1][4 * c + 2], sc[u][0][4 * c + 3]);
+            }
+            float mt = max3f(max3f(mc[0], sc[u][1][3], sc[u][1][7]), max3f(mc[1], sc[u][1][11], sc[u][1][15]), max3f(mc[2], mc[3], mc[0]));
             mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
             if constexpr (AUGM) {
                 // the accumulators are already  s * scale * log2 e - m[u]; the reference moves (rarely: deferred as below) by a correction of
@@ -480,13 +485,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const op16 *__restric
             // move when this kernel is touched), or -- AUGM, no-grad passes -- over the ROUNDED values, what the PV product weights V with, two
             // per instruction
             if constexpr (AUGM) {
+                float lp[4] = {0.f, 0.f, 0.f, 0.f};          // (four partial sums: independent v_dot2c chains)
 #pragma unroll
                 for (int kb = 0; kb < 2; kb++)
 #pragma unroll
                     for (int t = 0; t < 8; t++) {
                         pk[u][kb][t] = (op16x2){(op16)__builtin_amdgcn_exp2f(sc[u][kb][2 * t]), (op16)__builtin_amdgcn_exp2f(sc[u][kb][2 * t + 1])};
-                        l[u] = pair_sum(pk[u][kb][t], l[u]);
+                        lp[t & 3] = pair_sum(pk[u][kb][t], lp[t & 3]);
                     }
+                l[u] += (lp[0] + lp[1]) + (lp[2] + lp[3]);
             } else {
                 float ls = 0.f;
 #pragma unroll
