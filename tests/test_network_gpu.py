@@ -557,3 +557,20 @@ def test_attention_fwd_training_kernel_is_bit_stable(B, N, H):
     md5 = lambda t: hashlib.md5(t.cpu().contiguous().view(torch.uint8).numpy().tobytes()).hexdigest()
     got = (md5(out), md5(lse))
     assert got == _ATTN_PIN[(B, N, H)], got
+
+
+# md5 of dqkv of the fused attention backward (forward by the training kernel) on CPU-seeded inputs, taken from the kernels of commit 4d0c7f1
+# BEFORE the padding / masked-half-tile skips of round 4: those skips drop exact zeros only
+_ATTN_BWD_PIN = {(2, 197, 12): "b18caf3d9cc9859023b68243102b959c", (3, 785, 4): "ba733a5e6cb50f35b41f896448eef03b",
+                 (2, 130, 3): "18055a14c4ecb591cf271a30bf76e000"}
+
+
+@pytest.mark.parametrize("B,N,H", list(_ATTN_BWD_PIN))
+def test_attention_backward_is_bit_stable(B, N, H):
+    import hashlib
+    from cosa_amd import nn_ops
+    g = torch.Generator().manual_seed(99 + N)
+    qkv = (torch.randn(B, N, 3 * H * 64, generator=g) * 0.8).bfloat16().cuda().requires_grad_(True)
+    go = (torch.randn(B, N, H * 64, generator=g) * 0.01).bfloat16().cuda()
+    nn_ops.attention(qkv, H).backward(go)
+    assert hashlib.md5(qkv.grad.cpu().contiguous().view(torch.uint8).numpy().tobytes()).hexdigest() == _ATTN_BWD_PIN[(B, N, H)]
