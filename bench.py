@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--usepar", action="store_true", help="PAR(T=10, 6 dilations) as cam2mask's refine_model")
     ap.add_argument("--usegmm", action="store_true", help="adaptive thresholds: 3-component mixture fitted to the CAM queue every step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--teacher-precision", default="fp16c4-8", choices=["bf16", "fp16", "bf16x3", "fp16c8", "fp16c8-9", "fp16c4", "fp16c4-10", "fp16c4-9", "fp16c4-8", "fp16c4-12m8"],
+    ap.add_argument("--teacher-precision", default="auto", choices=["auto", "bf16", "fp16", "bf16x3", "fp16c8", "fp16c8-9", "fp16c4", "fp16c4-10", "fp16c4-9", "fp16c4-8", "fp16c4-12m8"],
                     help="MFMA operand precision of the teacher's no-grad passes in the HEADLINE run (DESIGN.md section 3).  The default is the "
                          "cheapest mode that meets BASELINE.json's tolerance (1e-3 relative on fp32 CAMs, mask IoU >= 0.999) with a 2x margin; "
                          "`bf16` is BASELINE configs[1] read literally and does not meet it (measured beside the headline as `fast_mode`)")
@@ -66,7 +66,12 @@ def parse():
                          "kernel spans in `roofline` are then undisturbed by co-running kernels")
     ap.add_argument("--cpu-batch", type=int, default=2, help="batch of the CPU-baseline sample (configs[0]: 2)")
     ap.add_argument("--cpu-steps", type=int, default=5, help="timed CPU-baseline steps after one warm-up step (BASELINE.md: >= 5)")
-    return ap.parse_args()
+    opt = ap.parse_args()
+    if opt.teacher_precision == "auto":          # the trainer's rule: fp16c4-8 up to 448^2, fp16c8 above (the margins at 640^2: DESIGN.md section 3)
+        sys.path.insert(0, ROOT)
+        from cosa_amd.train_step import resolve_teacher_precision
+        opt.teacher_precision = resolve_teacher_precision("auto", opt.crop)
+    return opt
 
 
 def newest_profile(name):
@@ -378,7 +383,8 @@ def secondary_modes(opt, dev, C, wimg, simg, lab, box, n_iter):
         if opt.teacher_precision != "bf16":
             out["fast_mode"] = secondary_run(opt, dev, C, wimg, simg, lab, box, n_iter, "bf16")
         else:
-            out["conforming_mode"] = secondary_run(opt, dev, C, wimg, simg, lab, box, n_iter, "fp16c4-8")
+            from cosa_amd.train_step import resolve_teacher_precision
+            out["conforming_mode"] = secondary_run(opt, dev, C, wimg, simg, lab, box, n_iter, resolve_teacher_precision("auto", opt.crop))
         others = [m for m in ("fp16c4-9", "fp16c4", "fp16c8-9") if m != opt.teacher_precision]
         out["other_conforming_modes"] = {m: {k: v for k, v in secondary_run(opt, dev, C, wimg, simg, lab, box, n_iter, m).items() if k != "vit_forward"}
                                          for m in others}

@@ -37,7 +37,7 @@ def default_args(dataset="VOC12", **over):
              high_thre=0.7, high_thre_aux=0.7, low_thre=0.25, low_thre_aux=0.25, bkg_thre=0.5, par_downscale=2, usepar=False,
              aux_cam2seg=True, aux_cam2seg_alpha=0.5, aux_seg2cam=False, aux_seg2cam_alpha=0.5, after_softmax=False,
              detach='none', use_cammix=False, usegmm=False, usegmmaux=False, gmmscale=16, gmmfilter_thre=0.05, gmmemadecay=0.99,
-             queue_update_ratio=100, compute_dtype=torch.bfloat16, teacher_precision="fp16c4-8", teacher_graph=True, teacher_async=True, lattice_async=False, fused_losses=True, fused_optimizer=True)
+             queue_update_ratio=100, compute_dtype=torch.bfloat16, teacher_precision="auto", teacher_graph=True, teacher_async=True, lattice_async=False, fused_losses=True, fused_optimizer=True)
     if dataset == "VOC12":
         a.update(aux_layer=-4, max_iters=32000)            # run_voc.sh:9-11
     elif dataset == "COCO":
@@ -57,6 +57,16 @@ def wrap_ddp(module, device):
 def rank_seed(base, rank):
     """per-rank synthetic-data seed (SURVEY d-2): distinct shards, no data-path collective"""
     return base + rank
+
+
+def resolve_teacher_precision(mode, crop_size):
+    """"auto" -> the cheapest operand mode of the teacher's no-grad passes that keeps BASELINE.json's tolerance (1e-3 on normalised CAMs,
+    mask IoU >= 0.999 against the fp32 reference) with a 2x margin on three weight seeds at this crop size (profiles/r04_accuracy_teacher.txt,
+    tests/test_precision_gpu.py): fp16c4-8 up to 448^2 (5.0e-4); at 640^2 the longer sequences cost every mode accuracy -- fp16c4-8 9.8e-4,
+    fp16c4 6.7e-4, fp16c8 3.0e-4 -- so larger crops take fp16c8.  "bf16" is faster and out of tolerance."""
+    if mode != "auto":
+        return mode
+    return "fp16c4-8" if crop_size <= 448 else "fp16c8"
 
 
 class CoSATrainer:
@@ -112,7 +122,8 @@ class CoSATrainer:
         on = args.compute_dtype == torch.bfloat16 and device.type == "cuda"
         # teacher_precision: operand precision of the teacher's no-grad passes (VITNetwork.set_nograd_precision).  The student, which
         # needs bf16's range for its gradients, stays bf16.
-        tp = getattr(args, "teacher_precision", "fp16c4-8")      # the default meets BASELINE.json's tolerance; "bf16" is faster and does not
+        tp = resolve_teacher_precision(getattr(args, "teacher_precision", "auto"), args.crop_size)
+        args.teacher_precision = tp
         if on:
             self.model_AN.set_nograd_precision(tp)
         tdt = self.model_AN.compute_dtype if on else args.compute_dtype

@@ -164,9 +164,11 @@ def test_teacher_precision_mode_strings():
     from cosa_amd.models import build_model
     from cosa_amd.train_step import default_args
     from cosa_amd import args as launcher_args
+    from cosa_amd.train_step import resolve_teacher_precision
     a = default_args("VOC12", crop_size=64)
-    assert a.teacher_precision == "fp16c4-8"
-    assert dict((n, d) for n, _t, d in launcher_args.COSA_FLAGS)["teacher_precision"] == "fp16c4-8" if hasattr(launcher_args, "COSA_FLAGS") else True
+    assert a.teacher_precision == "auto"
+    assert [resolve_teacher_precision("auto", c) for c in (224, 448, 512, 640)] == ["fp16c4-8", "fp16c4-8", "fp16c8", "fp16c8"]
+    assert resolve_teacher_precision("bf16", 640) == "bf16"
     net = build_model(a)
     for mode, prec, dt, plain in (("bf16", None, torch.bfloat16, (12, 12)), ("fp16c8", "fp16c8", torch.float16, (12, 12)),
                                   ("fp16c8-9", "fp16c8", torch.float16, (9, 9)), ("fp16c4-8", "fp16c4", torch.float16, (8, 8)),

@@ -412,6 +412,26 @@ _CASES = [(m, 3) for m in TEACHER_BARS] + [(m, sd_) for m in ("fp16c8", "fp16c8-
 @pytest.mark.parametrize("S", [224, 448])
 @pytest.mark.parametrize("mode,seed", _CASES)
 def test_fused_teacher_vs_fp32_cpu_oracle(mode, seed, S):
+    _check_teacher(mode, seed, S)
+
+
+# at 640^2 (3601 tokens at scale 1.5) every mode loses accuracy: the maps with plain-fp16 blocks that conform at 448^2 come within a few per cent
+# of the bar or cross it (fp16c8-9: 1.06e-3 on one seed), so the trainer's "auto" default takes fp16c8 there; the first three are on record only
+MODES_640 = (("fp16c4-8", False), ("fp16c4-10", False), ("fp16c8-9", False), ("fp16c4", True), ("fp16c8", True))
+
+
+@pytest.mark.parametrize("seed", CONFORMING_SEEDS)
+def test_fused_teacher_vs_fp32_cpu_oracle_640(seed):
+    """the crop of BASELINE configs[4] (COCO, 640^2: 1601 / 401 / 3601 tokens per image and scale), so that a bench line at --crop 640 has its
+    accuracy evidence too"""
+    try:
+        for mode, must_conform in MODES_640:
+            _check_teacher(mode, seed, 640, bars=None if must_conform else (2e-3, 0.999, 0.998))
+    finally:
+        _ORACLE.pop((640, seed), None)          # (7-MB CAM sets and their inputs: not needed again)
+
+
+def _check_teacher(mode, seed, S, bars=None):
     from cosa_amd.models import build_model
     from cosa_amd.train_step import default_args
     from cosa_amd.utils import seg_helper
@@ -425,7 +445,7 @@ def test_fused_teacher_vs_fp32_cpu_oracle(mode, seed, S):
         cam, cam_aux, _ = seg_helper.multi_scale_camseg(net, wimg.cuda(), args.pseudo_scales)
         masks = [seg_helper.cam2mask(wimg.cuda(), box, c * lab.cuda()[:, :, None, None], lab.cuda(), 0.7, 0.25).cpu().numpy() for c in (cam, cam_aux)]
     act = lab.bool()
-    bar_rel, bar_agree, bar_iou = TEACHER_BARS[mode]
+    bar_rel, bar_agree, bar_iou = bars or TEACHER_BARS[mode]
     lines = []
     for name, g, o, mg, mo in (("cam", cam, cam_o, masks[0], masks_o[0]), ("cam_aux", cam_aux, cam_aux_o, masks[1], masks_o[1])):
         rel = ((g.cpu() - o).abs().amax(dim=(2, 3)) / o.abs().amax(dim=(2, 3)).clamp_min(1e-6))[act].max().item()
