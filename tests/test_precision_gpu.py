@@ -457,3 +457,38 @@ def _check_teacher(mode, seed, S, bars=None):
     for ln in lines:
         rel, agree, iou = (float(ln.split(k)[1].split()[0]) for k in ("rel err", "label agreement", "mask mIoU"))
         assert rel <= bar_rel and agree >= bar_agree and iou >= bar_iou, ln
+
+
+@pytest.mark.parametrize("seed", CONFORMING_SEEDS)
+def test_teacher_masks_through_par_vs_fp32_cpu_oracle(seed):
+    """--usepar: the label maps after PAR refinement (PAR.py:64-91: ten affinity-propagation steps over the CAMs) from the fused HIP teacher in
+    the default mode against the oracle's (fp32 CAMs, oracle/cosa_oracle.c PAR) on the same denormalised images: the refinement must not
+    amplify the teacher's operand rounding past the mask bar (IoU >= 0.999, agreement >= 0.999), S = 448"""
+    from cosa_amd.models import build_model
+    from cosa_amd.models.PAR import PAR
+    from cosa_amd.train_step import default_args, resolve_teacher_precision
+    from cosa_amd.utils import seg_helper, torch_helper
+    from oracle import c_oracle
+    S, DIL = 448, [1, 2, 4, 8, 12, 24]
+    sd, wimg, lab, box, cam_o, cam_aux_o, _ = _oracle_pass(S, seed)
+    args = default_args("VOC12", crop_size=S)
+    net = build_model(args).cuda().eval()
+    net.load_state_dict(sd)
+    mode = resolve_teacher_precision("auto", S)
+    net.set_nograd_precision(mode)
+    img = torch_helper.denormalize_img(wimg.cuda())
+    bx = np.asarray(box.numpy(), np.int32)
+    with torch.no_grad():
+        cam, cam_aux, _ = seg_helper.multi_scale_camseg(net, wimg.cuda(), args.pseudo_scales)
+        par = PAR(num_iter=10, dilations=DIL).cuda()
+        got = [seg_helper.cam2mask(img, box, c * lab.cuda()[:, :, None, None], lab.cuda(), 0.7, 0.25, refine_model=par).cpu().numpy() for c in (cam, cam_aux)]
+    ref = [c_oracle.cam2mask(img.cpu().numpy(), bx, c.numpy(), lab.numpy(), 0.7, 0.25, 2, par=(DIL, 10)) for c in (cam_o, cam_aux_o)]
+    lines = []
+    for name, mg, mo in (("cam", got[0], ref[0]), ("cam_aux", got[1], ref[1])):
+        agree, iou = float(np.mean(mg == mo)), _miou(mg, mo)
+        lines.append(f"teacher+PAR {mode:8s} S={S} b=2 seed={seed:<2d} {name:8s}: label agreement {agree:.5f}  mask mIoU {iou:.5f}")
+    with open(os.path.join(ROOT, "gpurun_out", "r04_accuracy_teacher_par.txt"), "a") as f:
+        f.write("\n".join(lines) + "\n")
+    for ln in lines:
+        agree, iou = (float(ln.split(k)[1].split()[0]) for k in ("label agreement", "mask mIoU"))
+        assert agree >= 0.999 and iou >= 0.999, ln
