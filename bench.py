@@ -47,12 +47,12 @@ def parse():
     ap.add_argument("--usepar", action="store_true", help="PAR(T=10, 6 dilations) as cam2mask's refine_model")
     ap.add_argument("--usegmm", action="store_true", help="adaptive thresholds: 3-component mixture fitted to the CAM queue every step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--teacher-precision", default="auto", choices=["auto", "bf16", "fp16", "bf16x3", "fp16c8", "fp16c8-9", "fp16c4", "fp16c4-10", "fp16c4-9", "fp16c4-8", "fp16c4-12m8"],
+    ap.add_argument("--teacher-precision", default="auto", choices=["auto", "bf16", "fp16", "bf16x3", "fp16c8", "fp16c8-9", "fp16c4", "fp16c4-10", "fp16c4-9", "fp16c4-8", "fp16c4-12m8", "fp16c4-12m9"],
                     help="MFMA operand precision of the teacher's no-grad passes in the HEADLINE run (DESIGN.md section 3).  The default is the "
                          "cheapest mode that meets BASELINE.json's tolerance (1e-3 relative on fp32 CAMs, mask IoU >= 0.999) with a 2x margin; "
                          "`bf16` is BASELINE configs[1] read literally and does not meet it (measured beside the headline as `fast_mode`)")
     ap.add_argument("--no-secondary", "--no-parity-grade", dest="no_secondary", action="store_true",
-                    help="skip the secondary measurements (`fast_mode`: bf16-operand teacher; `other_conforming_modes`)")
+                    help="skip the secondary measurements (`fast_mode`: bf16-operand teacher; `other_modes`)")
     ap.add_argument("--student-stream", default="fp32", choices=["fp32", "bf16"],
                     help="residual stream of the student's training path: fp32 like the reference (default) or the bf16 stream of rounds 1-3")
     ap.add_argument("--defer-groups", type=int, default=0,
@@ -70,7 +70,7 @@ def parse():
     if opt.teacher_precision == "auto":          # the trainer's rule: fp16c4-8 up to 448^2, fp16c8 above (the margins at 640^2: DESIGN.md section 3)
         sys.path.insert(0, ROOT)
         from cosa_amd.train_step import resolve_teacher_precision
-        opt.teacher_precision = resolve_teacher_precision("auto", opt.crop)
+        opt.teacher_precision = resolve_teacher_precision("auto", opt.crop, opt.usepar)
     return opt
 
 
@@ -336,6 +336,7 @@ MODE_TEXT = {
     "fp16c4-9": "fp16c4 in blocks 0-8, plain fp16 operands in blocks 9-11",
     "fp16c4-8": "fp16c4 in blocks 0-7, plain fp16 operands in blocks 8-11",
     "fp16c4-12m8": "fp16c4 attention halves (qkv, output projection) in all blocks, fp16c4 MLP halves in blocks 0-7, plain fp16 MLPs in blocks 8-11",
+    "fp16c4-12m9": "fp16c4 attention halves (qkv; output projection fp16c8) in all blocks, fp16c4 MLPs in blocks 0-8, plain fp16 MLPs in blocks 9-11",
 }
 
 
@@ -373,8 +374,8 @@ def configure_student(trainer, opt):
 
 def secondary_modes(opt, dev, C, wimg, simg, lab, box, n_iter):
     """`fast_mode`: the bf16-operand teacher (configs[1] literally; out of tolerance) -- or, when the headline itself is that mode, the
-    conforming default; `other_conforming_modes`: fp16c4-9 (one more corrected block: 2.4x instead of 2.0x inside the accuracy bar), the uniform
-    fp16c4 map (every block corrected) and round 3's fp16c8-9 (e5m2 corrections)"""
+    conforming default; `other_modes`: fp16c4-8 (plain-fp16 last four blocks: 1 ms faster, fails the bar on one weight seed in seven -- its
+    own `tolerance_met` says so), the uniform fp16c4 map and fp16c8 (e5m2 corrections, >= 2.3x inside the bar on every seed)"""
     from cosa_amd import nn_ops
     st, gst = nn_ops.stamps, nn_ops.gemm_stamps
     nn_ops.stamps = nn_ops.gemm_stamps = None
@@ -384,9 +385,9 @@ def secondary_modes(opt, dev, C, wimg, simg, lab, box, n_iter):
             out["fast_mode"] = secondary_run(opt, dev, C, wimg, simg, lab, box, n_iter, "bf16")
         else:
             from cosa_amd.train_step import resolve_teacher_precision
-            out["conforming_mode"] = secondary_run(opt, dev, C, wimg, simg, lab, box, n_iter, resolve_teacher_precision("auto", opt.crop))
-        others = [m for m in ("fp16c4-9", "fp16c4", "fp16c8-9") if m != opt.teacher_precision]
-        out["other_conforming_modes"] = {m: {k: v for k, v in secondary_run(opt, dev, C, wimg, simg, lab, box, n_iter, m).items() if k != "vit_forward"}
+            out["conforming_mode"] = secondary_run(opt, dev, C, wimg, simg, lab, box, n_iter, resolve_teacher_precision("auto", opt.crop, opt.usepar))
+        others = [m for m in ("fp16c4-8", "fp16c4", "fp16c8") if m != opt.teacher_precision]
+        out["other_modes"] = {m: {k: v for k, v in secondary_run(opt, dev, C, wimg, simg, lab, box, n_iter, m).items() if k != "vit_forward"}
                                          for m in others}
     finally:
         nn_ops.stamps, nn_ops.gemm_stamps = st, gst

@@ -59,14 +59,17 @@ def rank_seed(base, rank):
     return base + rank
 
 
-def resolve_teacher_precision(mode, crop_size):
-    """"auto" -> the cheapest operand mode of the teacher's no-grad passes that keeps BASELINE.json's tolerance (1e-3 on normalised CAMs,
-    mask IoU >= 0.999 against the fp32 reference) with a 2x margin on three weight seeds at this crop size (profiles/r04_accuracy_teacher.txt,
-    tests/test_precision_gpu.py): fp16c4-8 up to 448^2 (5.0e-4); at 640^2 the longer sequences cost every mode accuracy -- fp16c4-8 9.8e-4,
-    fp16c4 6.7e-4, fp16c8 3.0e-4 -- so larger crops take fp16c8.  "bf16" is faster and out of tolerance."""
+def resolve_teacher_precision(mode, crop_size, usepar=False):
+    """"auto" -> the cheapest operand mode of the teacher's no-grad passes that kept BASELINE.json's tolerance (1e-3 on normalised CAMs, mask
+    IoU >= 0.999 against the fp32 reference) on EVERY weight / batch seed tried at this crop size (seven at 224^2 and 448^2, four to seven at
+    640^2: profiles/r04_accuracy_teacher.txt, tests/test_precision_gpu.py).  Up to 448^2: fp16c4-12m9 -- FP4-corrected attention halves in
+    every block, FP4-corrected MLPs in blocks 0-8 (worst 7.9e-4; maps with plain-fp16 attention in the last blocks, e.g. fp16c4-8, are 1 ms
+    faster and fail on one seed in seven).  Larger crops (longer sequences cost every mode accuracy): fp16c8 (worst 3.0e-4 at 640^2); also
+    with PAR refinement of the label maps (--usepar: it carries a label flip further -- fp16c4-12m9's mask IoU 0.99899 on one seed).
+    "bf16" is faster and out of tolerance."""
     if mode != "auto":
         return mode
-    return "fp16c4-8" if crop_size <= 448 else "fp16c8"
+    return "fp16c4-12m9" if crop_size <= 448 and not usepar else "fp16c8"
 
 
 class CoSATrainer:
@@ -122,7 +125,7 @@ class CoSATrainer:
         on = args.compute_dtype == torch.bfloat16 and device.type == "cuda"
         # teacher_precision: operand precision of the teacher's no-grad passes (VITNetwork.set_nograd_precision).  The student, which
         # needs bf16's range for its gradients, stays bf16.
-        tp = resolve_teacher_precision(getattr(args, "teacher_precision", "auto"), args.crop_size)
+        tp = resolve_teacher_precision(getattr(args, "teacher_precision", "auto"), args.crop_size, bool(getattr(args, "usepar", False)))
         args.teacher_precision = tp
         if on:
             self.model_AN.set_nograd_precision(tp)

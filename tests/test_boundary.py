@@ -167,8 +167,8 @@ def test_teacher_precision_mode_strings():
     from cosa_amd.train_step import resolve_teacher_precision
     a = default_args("VOC12", crop_size=64)
     assert a.teacher_precision == "auto"
-    assert [resolve_teacher_precision("auto", c) for c in (224, 448, 512, 640)] == ["fp16c4-8", "fp16c4-8", "fp16c8", "fp16c8"]
-    assert resolve_teacher_precision("bf16", 640) == "bf16"
+    assert [resolve_teacher_precision("auto", c) for c in (224, 448, 512, 640)] == ["fp16c4-12m9", "fp16c4-12m9", "fp16c8", "fp16c8"]
+    assert resolve_teacher_precision("bf16", 640) == "bf16" and resolve_teacher_precision("auto", 448, usepar=True) == "fp16c8"
     net = build_model(a)
     for mode, prec, dt, plain in (("bf16", None, torch.bfloat16, (12, 12)), ("fp16c8", "fp16c8", torch.float16, (12, 12)),
                                   ("fp16c8-9", "fp16c8", torch.float16, (9, 9)), ("fp16c4-8", "fp16c4", torch.float16, (8, 8)),

@@ -370,6 +370,8 @@ def _oracle_pass(S, seed=3):
     """fp32 CPU oracle (oracle/torch_oracle.py + cosa_oracle.c) on ViT-B weights drawn with `seed` and the synthetic batch of seed + 2
     (seed 3 / batch 5 are the rounds 2-3 pair), cached per (S, seed)"""
     if (S, seed) not in _ORACLE:
+        for k in [k for k in _ORACLE if k != (S, seed)]:          # (cases are ordered by oracle pass: one live entry is enough)
+            _ORACLE.pop(k)
         from oracle import torch_oracle as to, c_oracle
         from cosa_amd.models import build_model
         from cosa_amd.train_step import default_args, synthetic_batch
@@ -390,43 +392,45 @@ def _oracle_pass(S, seed=3):
 
 # mode -> (max normalised-CAM relative error, min label agreement, min mask IoU); the conforming modes carry the north-star bars
 NORTH_STAR = (1e-3, 0.999, 0.999)      # BASELINE.json north_star: 1e-3 relative on fp32 CAMs, mask IoU >= 0.999
+ON_RECORD = (2e-3, 0.999, 0.998)       # maps measured for the margin table: faster, but over the bar on at least one seed / crop
 TEACHER_BARS = {
     "bf16": (3e-2, 0.99, 0.97),
     "fp16": (4e-3, 0.9990, 0.995),
     "bf16x3": NORTH_STAR,
-    "fp16c8": NORTH_STAR,          # the same bars at 2x (not 3x) the 16-bit MFMA work
-    "fp16c8-9": NORTH_STAR,        # ... with the last three blocks on plain fp16 operands (round 3's benchmarked mode)
-    "fp16c4": NORTH_STAR,          # round 4: FP4 (e2m1, MX blocks) correction terms in qkv / fc1 / fc2: ~1.6x the 16-bit MFMA work
-    "fp16c4-10": NORTH_STAR,       # ... with the last two blocks on plain fp16 operands
-    "fp16c4-9": NORTH_STAR,        # ... the last three
-    "fp16c4-8": NORTH_STAR,        # ... the last four: the benchmarked (headline) mode of bench.py
-    "fp16c4-12m8": NORTH_STAR,     # per-half map: attention halves corrected in every block, MLP halves in blocks 0-7
-    "fp16c4-10q": NORTH_STAR,      # ... with plain-fp16 qkv projections in the corrected blocks (-0.2 ms per block, 1.7x the error: not used)
+    "fp16c8": NORTH_STAR,          # fp16 + two e5m2 correction terms (round 3): >= 2.3x inside the bar on every seed and crop tried
+    "fp16c4": NORTH_STAR,          # round 4: FP4 (e2m1, MX blocks) correction terms in qkv / fc1 / fc2 of every block
+    "fp16c4-12m9": NORTH_STAR,     # ... attention halves corrected in every block, MLP halves in blocks 0-8: the trainer's default up to 448^2
+    "fp16c8-9": ON_RECORD,         # round 3's benchmarked mode (last three blocks plain fp16): 1.06e-3 at 640^2 on one seed
+    "fp16c4-10": ON_RECORD, "fp16c4-9": ON_RECORD,
+    "fp16c4-8": ON_RECORD,         # last four blocks plain fp16: 2.0x inside the bar on seeds 3 / 11 / 29, mask IoU 0.9988 on seed 17
+    "fp16c4-12m8": ON_RECORD,      # MLP halves plain from block 8: the auxiliary CAM (block 8's output) reaches 9.4e-4 on seed 23
+    "fp16c4-10q": ON_RECORD,       # plain-fp16 qkv projections in the corrected blocks (-0.2 ms per block, 1.7x the error)
 }
-# the modes bench.py may run as its headline are checked on three independent weight / batch draws; bench.py reports the WORST of these
-# lines (profiles/r04_accuracy_teacher.txt, copied from gpurun_out/ after the GPU run) and derives `tolerance_met` from them
-CONFORMING_SEEDS = (3, 11, 29)
-_CASES = [(m, 3) for m in TEACHER_BARS] + [(m, sd_) for m in ("fp16c8", "fp16c8-9", "fp16c4", "fp16c4-10", "fp16c4-9", "fp16c4-8", "fp16c4-12m8") for sd_ in CONFORMING_SEEDS[1:]]
+# the modes a bench line may carry as its headline are checked on SEVEN independent weight / batch draws (three were not enough: the maps with
+# plain-fp16 attention in the last blocks pass seeds 3 / 11 / 29 with a 2x margin and fail seed 17); bench.py reports the WORST of these lines
+# (profiles/r04_accuracy_teacher.txt, copied from gpurun_out/ after the GPU run) and derives `tolerance_met` from them
+CONFORMING_SEEDS = (3, 11, 29, 5, 17, 23, 41)
+_MULTI = {448: ("fp16c4-12m9", "fp16c4", "fp16c8", "fp16c8-9", "fp16c4-8"), 224: ("fp16c4-12m9", "fp16c8")}
+_CASES = [(m, 3, S) for m in TEACHER_BARS for S in (224, 448)] + [(m, sd_, S) for S, ms in _MULTI.items() for m in ms for sd_ in CONFORMING_SEEDS[1:]]
 
 
-@pytest.mark.parametrize("S", [224, 448])
-@pytest.mark.parametrize("mode,seed", _CASES)
+@pytest.mark.parametrize("mode,seed,S", sorted(_CASES, key=lambda c: (c[2], c[1])))       # (grouped by oracle pass)
 def test_fused_teacher_vs_fp32_cpu_oracle(mode, seed, S):
     _check_teacher(mode, seed, S)
 
 
-# at 640^2 (3601 tokens at scale 1.5) every mode loses accuracy: the maps with plain-fp16 blocks that conform at 448^2 come within a few per cent
-# of the bar or cross it (fp16c8-9: 1.06e-3 on one seed), so the trainer's "auto" default takes fp16c8 there; the first three are on record only
-MODES_640 = (("fp16c4-8", False), ("fp16c4-10", False), ("fp16c8-9", False), ("fp16c4", True), ("fp16c8", True))
+# at 640^2 (3601 tokens at scale 1.5) the maps with plain-fp16 blocks lose most: fp16c4-8 9.8e-4, fp16c8-9 1.06e-3 on seed 11 -- on record only;
+# the trainer's "auto" default takes fp16c8 above 448^2
+MODES_640 = (("fp16c4-8", False), ("fp16c8-9", False), ("fp16c4-12m9", True), ("fp16c8", True))
 
 
-@pytest.mark.parametrize("seed", CONFORMING_SEEDS)
+@pytest.mark.parametrize("seed", (3, 11, 29, 17))
 def test_fused_teacher_vs_fp32_cpu_oracle_640(seed):
     """the crop of BASELINE configs[4] (COCO, 640^2: 1601 / 401 / 3601 tokens per image and scale), so that a bench line at --crop 640 has its
     accuracy evidence too"""
     try:
         for mode, must_conform in MODES_640:
-            _check_teacher(mode, seed, 640, bars=None if must_conform else (2e-3, 0.999, 0.998))
+            _check_teacher(mode, seed, 640, bars=NORTH_STAR if must_conform else ON_RECORD)
     finally:
         _ORACLE.pop((640, seed), None)          # (7-MB CAM sets and their inputs: not needed again)
 
@@ -459,7 +463,7 @@ def _check_teacher(mode, seed, S, bars=None):
         assert rel <= bar_rel and agree >= bar_agree and iou >= bar_iou, ln
 
 
-@pytest.mark.parametrize("seed", CONFORMING_SEEDS)
+@pytest.mark.parametrize("seed", (3, 17, 23))
 def test_teacher_masks_through_par_vs_fp32_cpu_oracle(seed):
     """--usepar: the label maps after PAR refinement (PAR.py:64-91: ten affinity-propagation steps over the CAMs) from the fused HIP teacher in
     the default mode against the oracle's (fp32 CAMs, oracle/cosa_oracle.c PAR) on the same denormalised images: the refinement must not
@@ -474,7 +478,7 @@ def test_teacher_masks_through_par_vs_fp32_cpu_oracle(seed):
     args = default_args("VOC12", crop_size=S)
     net = build_model(args).cuda().eval()
     net.load_state_dict(sd)
-    mode = resolve_teacher_precision("auto", S)
+    mode = resolve_teacher_precision("auto", S, usepar=True)          # (fp16c8: fp16c4-12m9 gives mask IoU 0.99899 on seed 17 after PAR)
     net.set_nograd_precision(mode)
     img = torch_helper.denormalize_img(wimg.cuda())
     bx = np.asarray(box.numpy(), np.int32)

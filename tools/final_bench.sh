@@ -5,7 +5,7 @@ R=${R:-r04}
 python bench.py > gpurun_out/${R}_bench_final.json 2> gpurun_out/${R}_bench_final.err || { tail -5 gpurun_out/${R}_bench_final.err; exit 1; }
 tail -c 400 gpurun_out/${R}_bench_final.json; echo
 python bench.py --usepar --no-cpu-baseline --no-secondary > gpurun_out/${R}_bench_usepar.json 2>/dev/null || exit 1
-python bench.py --teacher-precision fp16c8-9 --no-cpu-baseline --no-secondary > gpurun_out/${R}_bench_fp16c8teacher.json 2>/dev/null || exit 1
+python bench.py --teacher-precision fp16c8 --no-cpu-baseline --no-secondary > gpurun_out/${R}_bench_fp16c8teacher.json 2>/dev/null || exit 1
 python bench.py --dataset COCO --no-cpu-baseline --no-secondary > gpurun_out/${R}_bench_coco448.json 2>/dev/null || exit 1
 # configs[4]: global batch 64 over 8 ranks = 8 per rank
 python bench.py --dataset COCO --crop 640 --batch 8 --no-cpu-baseline --no-secondary > gpurun_out/${R}_bench_coco640.json 2>/dev/null || exit 1
