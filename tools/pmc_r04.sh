@@ -13,7 +13,7 @@ rm -rf gpurun_out/pmc_gemm4 gpurun_out/pmc_gemmc4
 fi
 if [ "$which" = all ] || [ "$which" = attn ]; then
 bash tools/pmc_collect.sh attn4 tools/attn_one.py || exit 1
-python3 tools/pmc_summary.py gpurun_out/pmc_attn4 attn_fwd2_kernel 433766400 "B=32 N=1765 H=12 (teacher scale 1.5), 4 waves per workgroup" gpurun_out/r04_attn_fwd_pmc.json > /dev/null || exit 1
+python3 tools/pmc_summary.py gpurun_out/pmc_attn4 attn_fwd2_kernel 433766400 "B=32 N=1765 H=12 (teacher scale 1.5), fp16 operands, no-grad variant (flag bit 10), 4 waves per workgroup" gpurun_out/r04_attn_fwd_pmc.json > /dev/null || exit 1
 rm -rf gpurun_out/pmc_attn4
 fi
 if [ "$which" = all ] || [ "$which" = gemmfc2 ]; then
