@@ -435,11 +435,17 @@ class VisionTransformer(nn.Module):
         _C.check(_C.lib().cosa_c4_rows_batched(_C.ptr(ent["rec"]), ent["n"], ent["rows"], _C.stream_ptr()), "cosa_c4_rows_batched")
         return ent["bufs"]
 
-    def _c8_buffers(self, M, dev):
+    _C8_BUFS_MAX = 8          # cached geometries (each holds ~M x 7 KB of activations): evaluation over many image sizes must not pin them all
+
+    def _c8_buffers(self, M, dev, geom=None):
         """persistent activations for M token rows; the (1, 1, 0, ...) augmentation block of the fc1 output is set once here (the GEMM
-        epilogue writes hi | lo8 | hi8 only), the other c8 buffers get theirs from their producing kernels"""
+        epilogue writes hi | lo8 | hi8 only), the other c8 buffers get theirs from their producing kernels.  Keyed on the FULL token geometry
+        (the (images, tokens) split per scale and the patch width), not on M alone: the token-shaped patch operand `cols` relies on its
+        class-token rows staying zero, and another split of the same M puts class tokens where stale patch rows sit.  Least
+        recently used geometries are dropped beyond _C8_BUFS_MAX, except those a captured hipGraph replays into."""
         bufs = self.__dict__.setdefault("_c8_bufs", {})
-        ent = bufs.get((M, dev))
+        key = (M, dev, geom)
+        ent = bufs.pop(key, None)
         if ent is None:
             D, Hd = self.embed_dim, self.blocks[0].mlp.fc1.weight.shape[0]
             mk = lambda cols: torch.zeros((M, cols), device=dev, dtype=torch.float16)
@@ -447,7 +453,12 @@ class VisionTransformer(nn.Module):
             ent["h"][:, 2 * Hd:2 * Hd + 2] = 1
             if self.precision == "fp16c4":          # the scale tensors of the c4 activation operands (LayerNorm, attention and GELU outputs)
                 ent["y_sc"], ent["o_sc"], ent["h_sc"] = nn_ops.c4_scales(M, D, dev), nn_ops.c4_scales(M, D, dev), nn_ops.c4_scales(M, Hd, dev)
-            bufs[(M, dev)] = ent
+        bufs[key] = ent                             # (re-inserted last: the dict is the LRU order)
+        if torch.cuda.is_current_stream_capturing():
+            ent["pinned"] = True
+        elif len(bufs) > self._C8_BUFS_MAX:
+            for k in [k for k, e in bufs.items() if not e.get("pinned") and k != key][:len(bufs) - self._C8_BUFS_MAX]:
+                del bufs[k]
         return ent
 
     def _forward_features_c8_multi(self, xs, flip_pairs=False):
@@ -469,7 +480,7 @@ class VisionTransformer(nn.Module):
         M = offs[-1]
         dev = xs[0].device
         Kp = xs[0].shape[1] * p * p
-        bf = self._c8_buffers(M, dev)
+        bf = self._c8_buffers(M, dev, geom=(tuple(shapes), Kp))
         cols = bf.get("cols")
         if cols is None or cols.shape[1] != nn_ops.split_ld(Kp):
             cols = bf["cols"] = torch.zeros((M, nn_ops.split_ld(Kp)), device=dev, dtype=torch.float16)      # (class-token rows: zero for good)

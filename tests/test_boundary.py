@@ -178,3 +178,28 @@ def test_teacher_precision_mode_strings():
     for bad in ("fp16c4-", "fp16c4-m8", "bf16-3", "fp8", "fp16c4-9m"):
         with pytest.raises(AssertionError):
             net.set_nograd_precision(bad)
+
+
+def test_auto_teacher_precision_is_backed_by_the_committed_accuracy_record():
+    """`resolve_teacher_precision("auto", ...)` may only name a mode whose every line in the newest committed accuracy record
+    (profiles/rNN_accuracy_teacher.txt: fused HIP teacher vs the fp32 CPU oracle, written on the GPU by tests/test_precision_gpu.py) keeps
+    BASELINE.json's bars; bench.py reads `tolerance_met` from the same record with the same parser and ties it to the kernel sources"""
+    import importlib.util
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    from cosa_amd.train_step import resolve_teacher_precision
+    src = open(os.path.join(root, "tests", "test_precision_gpu.py")).read()
+    names = re.search(r"TEACHER_CSRC = \(([^)]*)\)", src).group(1)
+    assert tuple(re.findall(r'"([^"]+)"', names)) == bench.TEACHER_CSRC            # one definition of "the teacher's kernels" on both sides
+    for crop in (224, 448, 640):
+        c = bench.conformance(resolve_teacher_precision("auto", crop), crop)
+        assert c.get("lines", 0) >= 8, (crop, c)
+        assert c["normalised_cam_rel_err_max"] <= 1e-3 and c["mask_miou_min"] >= 0.999, (crop, c)
+    rec = bench.newest_profile("accuracy_teacher.txt")
+    if os.path.basename(rec) >= "r05":          # from round 5 on: the wide sweep (VERDICT r4 item 2) and the bench's own batch size
+        c = bench.conformance(resolve_teacher_precision("auto", 448), 448)
+        assert c["lines"] >= 64 and c["seeds"] >= 32 and 16 in c["batch_sizes"], c

@@ -150,3 +150,22 @@ def test_product_poly_warmup_adamw_lr_vs_reference(golden):
         opt.step()
         assert opt.param_groups[0]["lr"] == lr, (st, opt.param_groups[0]["lr"], lr)
         assert th.poly_warmup_lr_mult(int(st), 1500, 32000, 1e-6, 0.9, 0.0) * 6e-5 == lr
+
+
+def test_oracle_vit_vs_reference_golden(golden):
+    """PIN of the yardstick behind every teacher-precision number (profiles/r0*_accuracy_teacher.txt) and behind oracle/cpu_step.py:
+    oracle/torch_oracle.py:OracleViT (fp32 torch-CPU restatement of models/vit/vit.py:86-181,219-330, models/__init__.py:82-206,
+    models/decoder/conv_head.py:11-41) against the six outputs the REFERENCE's own VITNetwork produced for the 128-wide toy encoder of
+    tests/golden/vit_tiny.npz (written by oracle/gen_golden.py from the reference loaded by path).  Measured difference: 0.0."""
+    from oracle.torch_oracle import OracleViT, load_golden_state
+    g = golden("vit_tiny")
+    m = OracleViT(num_classes=7, embed_dim=128, depth=3, num_heads=2, mlp_ratio=4.0, aux_layer=-2)
+    sd = {k: v for k, v in load_golden_state(g).items() if not k.startswith("encoder.head.")}   # (the dead ImageNet head has 10 rows there)
+    assert set(sd) == {k for k in m.named_state() if not k.startswith("encoder.head.")}         # every parameter of the oracle is set
+    m.load_named(sd)
+    with torch.no_grad():
+        out = m(torch.from_numpy(g["x"]))
+    for name, o in zip(["cls", "cls_aux", "x4", "seg", "cam", "cam_aux"], out):
+        ref = g[name]
+        assert o.shape == ref.shape, name
+        assert np.abs(o.numpy() - ref).max() <= 1e-6 * max(1.0, np.abs(ref).max()), (name, np.abs(o.numpy() - ref).max())

@@ -1,10 +1,10 @@
 """worst line per teacher mode and crop of an accuracy record (profiles/rNN_accuracy_teacher.txt or gpurun_out/...): max normalised-CAM rel. err,
 min mask mIoU, the seed it comes from, margin on the 1e-3 bar.   usage: python tools/accuracy_worst.py [file]"""
 import collections, re, sys
-f = sys.argv[1] if len(sys.argv) > 1 else "profiles/r04_accuracy_teacher.txt"
+f = sys.argv[1] if len(sys.argv) > 1 else "profiles/r05_accuracy_teacher.txt"
 w = collections.defaultdict(lambda: [0.0, 1.0, 0, "", set()])
 for ln in open(f):
-    m = re.match(r"teacher (\S+)\s+S=(\d+) b=2 seed=(\d+)\s+(\S+)\s*: .*rel err (\S+) .*mIoU (\S+)", ln)
+    m = re.match(r"teacher (\S+)\s+S=(\d+) b=\d+ seed=(\d+)\s+(\S+)\s*: .*rel err (\S+) .*mIoU (\S+)", ln)
     if m:
         k = (m.group(1), int(m.group(2)))
         r, iou = float(m.group(5)), float(m.group(6))
