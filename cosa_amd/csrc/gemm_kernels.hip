@@ -136,6 +136,9 @@ __device__ __forceinline__ float c4_max4(float v)
     return __builtin_bit_cast(float, b[0] > b[1] ? b[0] : b[1]);
 }
 constexpr int kC4ScaleLds = 16384;          // two 8-KB chunks (X and W scales of two c4 tiles each) behind the 128-KB operand ring
+// Round 5: the persistent kernel's output leaves through per-wave LDS staging rows behind the ring (and the scale ring): [16 tokens][128 B],
+// 2 KB per plane and wave, two planes unless fp16c4 operands (whose scale ring takes the other 16 KB): 160 KB of LDS in either case.
+constexpr int kStageLdsC4 = 16384, kStageLds = 32768;
 
 template <int EPI, int SPLIT = 0>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const op16 *__restrict__ X, const op16 *__restrict__ W,
@@ -516,6 +519,40 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
     // (the combined 16-byte store: byte offset of the lane's 16 features in an 8-bit plane, minus twice its offset in the fp16 plane, which voY carries)
     const unsigned fo16m = (unsigned)((wr * WN + 16 * (fq & 1) + 32 * (fq >> 1)) - 2 * (wr * WN + (fq & 1) * 16 + 4 * (fq & 2)));
 
+    // ---- coalesced output stores (round 5) ------------------------------------------------------------------------------------------
+    // An accumulator fragment has the token on lane & 15 and four features per lane: stored from the registers, ONE buffer_store_b128
+    // touches 16 token rows and leaves the CU as 64 separate 16-byte write requests (lanes of one row are 16 apart: nothing coalesces).
+    // Measured in round 3 as "the stores cost what their bytes take at HBM speed, with no overlap" (HISTORY section 7): it is the request
+    // count -- the store path of a CU took ~70 cycles per such instruction, and the LDS-DMA operand stream waits behind it.  Now a wave
+    // transposes 16 tokens x 128 B through 2 KB of its own LDS (one ds_write_b128 / ds_read_b128 pair per former store, 16-byte chunks
+    // XOR-ed by the row: conflict-free both ways; no barrier, a wave's LDS operations complete in order) and the same NUMBER of stores
+    // (the counted vmcnt waits are unchanged) each write 8 rows x 128 contiguous bytes: 8 requests instead of 64.
+    // Measured (tools/ab_gemm_libs.py, interleaved, same box): qkv -4 %, output projection / fc2 (fp32 rows) -2...5 %, fp16c4 qkv / fc2 -2...3 %;
+    // the GELU epilogues got 5 % SLOWER (their VALU work is the long pole of those phases and the LDS round trip adds to it): they keep the
+    // register stores, and so do the 192-wide jobs (their third fragment has no partner).
+    constexpr bool STG = FR == 4 && EPI != EPI_GELU;
+    constexpr int STGW = C4 ? 2048 : 4096;              // staging bytes per wave: one plane, or two (dual / bf16x3 outputs)
+    const unsigned stg0 = (unsigned)(kLdsBytesV5 + (C4 ? kC4ScaleLds : 0) + wave * STGW);
+    // write: token frow, 16-byte chunk c of the 128-byte row -- 16-bit outputs: c = 4 pr + 2 (fq & 1) + (fq >> 1) (8 features per lane after
+    // the lane swap), fp32 outputs: c = 4 (ii & 1) + fq (4 features per lane); pr / (ii & 1) toggle byte bit 6
+    const unsigned stg_w = stg0 + frow * 128 + ((((RES ? fq : (fq & 1) * 2 + (fq >> 1))) ^ (frow & 7)) << 4);
+    // read: lane l takes chunk l & 7 of row (l >> 3) (+ 8 for the second read), i.e. 8 lanes = one 128-byte row segment of the output
+    const unsigned stg_r = stg0 + (lane >> 3) * 128 + (((lane & 7) ^ ((lane >> 3) & 7)) << 4);
+    const unsigned voS = (unsigned)(((wc * 32 + (lane >> 3)) * ldy + wr * WN) * ES + (lane & 7) * 16);
+#define V6_STG_WR(u4, e, plane) *reinterpret_cast<u32x4 *>(smem + ((stg_w ^ ((e) * 64)) + (plane) * 2048)) = (u4)
+#define V6_STG_RD(it, plane) (*reinterpret_cast<const u32x4 *>(smem + (stg_r + (it) * 1024 + (plane) * 2048)))
+    // store offset of rows (qb, jj, it): the row part belongs in the VGPR offset (the part of the address the range check sees).  The add is
+    // volatile asm on a scalar product: left to the compiler, the eight loop-invariant sums are hoisted out of the job loop, spilled, and
+    // re-loaded from scratch behind `s_waitcnt vmcnt(0)` -- in the middle of the counted LDS-DMA stream.
+    const int ldy_es = __builtin_amdgcn_readfirstlane(ldy * ES);
+#define V6_STG_OFF(qb, jj, it)                                                                                       \
+    ({                                                                                                               \
+        unsigned r_ = voS;                                                                                           \
+        if ((qb) * 128 + (jj) * 16 + (it) * 8 != 0)                                                                  \
+            asm volatile("v_add_u32 %0, %1, %2" : "=v"(r_) : "s"(((qb) * 128 + (jj) * 16 + (it) * 8) * ldy_es), "v"(voS));  \
+        r_;                                                                                                          \
+    })
+
     int o = blockIdx.x;
     int m0, n0, m1 = 0, n1 = 0, pn0 = 0, pm0 = 0;
     tile_of(o, m0, n0);
@@ -602,7 +639,19 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
     }
     // quadrant (qa, qb) out: acc[qa*4 + ii][qb*2 + jj][r] = feature qa*128 + wr*64 + ii*16 + 4fq + r, token qb*128 + wc*32 + jj*16 + frow
 #define V6_EPI(qa, qb, rsY)                                                                                         \
-    if (RES) {                                                                                                      \
+    if (RES && STG) {     /* fp32 rows through the staging rows: a fragment pair (ii = 2 p, 2 p + 1) of 16 tokens is 16 x 128 B */     \
+        _Pragma("unroll") for (int jj = 0; jj < 2; jj++) _Pragma("unroll") for (int p2 = 0; p2 < 2; p2++) {         \
+            _Pragma("unroll") for (int e_ = 0; e_ < 2; e_++) {                                                      \
+                const int ii = 2 * p2 + e_;                                                                         \
+                const unsigned lo_ = CX ? 0u : bb[qa][ii][0], hi_ = CX ? 0u : bb[qa][ii][1];                        \
+                const f32x4 bv_ = CX ? (f32x4){0.f, 0.f, 0.f, 0.f} : (f32x4){op16_lo(lo_), op16_hi(lo_), op16_lo(hi_), op16_hi(hi_)};  \
+                const f32x4 o4_ = acc[(qa) * 4 + ii][(qb) * 2 + jj] + bv_;                                          \
+                V6_STG_WR(__builtin_bit_cast(u32x4, o4_), e_, 0);                                                   \
+            }                                                                                                       \
+            _Pragma("unroll") for (int it_ = 0; it_ < 2; it_++)                                                     \
+                __builtin_amdgcn_raw_buffer_store_b128(V6_STG_RD(it_, 0), rsY, V6_STG_OFF(qb, jj, it_) + ((qa) * HN + p2 * 32) * 4, 0, 0); \
+        }                                                                                                           \
+    } else if (RES) {                                                                                               \
         _Pragma("unroll") for (int ii = 0; ii < FR; ii++) {                                                         \
             const unsigned lo_ = CX ? 0u : bb[qa][ii][0], hi_ = CX ? 0u : bb[qa][ii][1];                            \
             const f32x4 bv_ = CX ? (f32x4){0.f, 0.f, 0.f, 0.f} : (f32x4){op16_lo(lo_), op16_hi(lo_), op16_lo(hi_), op16_hi(hi_)};  \
@@ -631,7 +680,8 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
             const auto u0_ = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, r0_), __builtin_bit_cast(unsigned, r2_), false, false); \
             const auto u1_ = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, r1_), __builtin_bit_cast(unsigned, r3_), false, false); \
             const u32x4 raw_ = {u0_[0], u1_[0], u0_[1], u1_[1]};                                                    \
-            __builtin_amdgcn_raw_buffer_store_b128(raw_, rsY, voY[(qb) * 2 + jj] + ((qa) * HN + pr * 32) * 2, 0, 0); \
+            if (STG) V6_STG_WR(raw_, pr, 1);                                                                        \
+            else __builtin_amdgcn_raw_buffer_store_b128(raw_, rsY, voY[(qb) * 2 + jj] + ((qa) * HN + pr * 32) * 2, 0, 0); \
         }                                                                                                           \
         if (EPI == EPI_GELU) {                                                                                      \
             _Pragma("unroll") for (int r = 0; r < 4; r++) {                                                         \
@@ -644,7 +694,8 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
         const auto s0_ = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, p0_), __builtin_bit_cast(unsigned, p2_), false, false); \
         const auto s1_ = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, p1_), __builtin_bit_cast(unsigned, p3_), false, false); \
         const u32x4 out_ = {s0_[0], s1_[0], s0_[1], s1_[1]};                                                        \
-        if (SPLIT == 2) __builtin_amdgcn_raw_buffer_store_b128(out_, (&rsY == &pY) ? pY2 : cY2, voY[(qb) * 2 + jj] + ((qa) * HN + pr * 32) * 2, 0, 0); \
+        if (STG) V6_STG_WR(out_, pr, 0);                                                                            \
+        else if (SPLIT == 2) __builtin_amdgcn_raw_buffer_store_b128(out_, (&rsY == &pY) ? pY2 : cY2, voY[(qb) * 2 + jj] + ((qa) * HN + pr * 32) * 2, 0, 0); \
         else __builtin_amdgcn_raw_buffer_store_b128(out_, rsY, voY[(qb) * 2 + jj] + ((qa) * HN + pr * 32) * 2, 0, 0); \
         if (SPLIT == 1) {          /* the lo halves: what the 16-bit rounding above dropped, at column N + n */              \
             const op16x2 q0_ = {(op16)(v0_[0] - (float)p0_[0]), (op16)(v0_[1] - (float)p0_[1])};                    \
@@ -654,7 +705,8 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
             const auto t0_ = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, q0_), __builtin_bit_cast(unsigned, q2_), false, false); \
             const auto t1_ = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, q1_), __builtin_bit_cast(unsigned, q3_), false, false); \
             const u32x4 lo4_ = {t0_[0], t1_[0], t0_[1], t1_[1]};                                                    \
-            __builtin_amdgcn_raw_buffer_store_b128(lo4_, rsY, voY[(qb) * 2 + jj] + (N + (qa) * HN + pr * 32) * 2, 0, 0); \
+            if (STG) V6_STG_WR(lo4_, pr, 1);                                                                        \
+            else __builtin_amdgcn_raw_buffer_store_b128(lo4_, rsY, voY[(qb) * 2 + jj] + (N + (qa) * HN + pr * 32) * 2, 0, 0); \
         }                                                                                                           \
         if (C8OUT) {       /* c8 rows: lo8 at byte 2N + n, hi8 at byte 3N + n of the row (the window starts at byte 2 n0 of it) */   \
             const float h0_ = (float)p0_[0], h1_ = (float)p0_[1], h2_ = (float)p1_[0], h3_ = (float)p1_[1];        \
@@ -713,6 +765,18 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
                 const int el_ = fq == 0 ? c4e_[0][0] : (fq == 1 ? c4e_[0][1] : (fq == 2 ? c4e_[1][0] : c4e_[1][1])); \
                 __builtin_amdgcn_raw_buffer_store_b8((unsigned char)c4_scale_byte(el_, 0), sYr, sc_wr_y + ((qb) * 2 + jj) * 2, \
                                                      (((jm0_ >> 8) * (N >> 7) + (jn0_ >> 7) + (qa)) << 11), 0);   \
+            }                                                                                                       \
+        }                                                                                                           \
+        if (STG && pr == 1) {      /* both fragment pairs of these 16 tokens are staged: 8 rows x 128 B per store */  \
+            _Pragma("unroll") for (int it_ = 0; it_ < 2; it_++) {                                                   \
+                const unsigned vo_ = V6_STG_OFF(qb, jj, it_) + (qa) * HN * 2;                                 \
+                if (SPLIT == 2) {      /* dual: plane 1 = the pre-activation (Y), plane 0 = gelu (Y2) */             \
+                    __builtin_amdgcn_raw_buffer_store_b128(V6_STG_RD(it_, 1), rsY, vo_, 0, 0);                      \
+                    __builtin_amdgcn_raw_buffer_store_b128(V6_STG_RD(it_, 0), (&rsY == &pY) ? pY2 : cY2, vo_, 0, 0); \
+                } else {                                                                                            \
+                    __builtin_amdgcn_raw_buffer_store_b128(V6_STG_RD(it_, 0), rsY, vo_, 0, 0);                      \
+                    if (SPLIT == 1) __builtin_amdgcn_raw_buffer_store_b128(V6_STG_RD(it_, 1), rsY, vo_ + N * 2, 0, 0); \
+                }                                                                                                   \
             }                                                                                                       \
         }                                                                                                           \
     }                                                                                                               \
@@ -891,6 +955,9 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
 #undef V6_C4ROW
 #undef V6_SCDMA
 #undef V6_LDSC
+#undef V6_STG_WR
+#undef V6_STG_RD
+#undef V6_STG_OFF
 #undef V6_MSECTION_BEGIN
 #undef V6_MSECTION_END
 #undef V6_TILE
@@ -1509,7 +1576,7 @@ static int launch_v6(const op16 *x, const op16 *w, const op16 *b, const float *r
                      int ld = 0, int ldy = 0, void *Y2 = nullptr, const unsigned char *xsc = nullptr, const unsigned char *wsc = nullptr,
                      unsigned char *ysc = nullptr)
 {
-    constexpr size_t lds_bytes = kLdsBytesV5 + (SPLIT == 4 ? kC4ScaleLds : 0);      // fp16c4: + the scale ring
+    constexpr size_t lds_bytes = kLdsBytesV5 + (SPLIT == 4 ? kC4ScaleLds + kStageLdsC4 : kStageLds);      // ring [+ fp16c4: scale ring] + output staging rows = 160 KB
     static bool attr_done = false;
     if (!attr_done) {
         COSA_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_bf16_v6_kernel<EPI, SPLIT, FR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));

@@ -99,6 +99,8 @@ class VisionTransformer(nn.Module):
         self.defer_groups = None       # ... one launch per group of depth / defer_groups blocks; None: 1 on a single GPU, 6 under data parallelism
         self.c8_plain_from = None      # fp16c8 / fp16c4: blocks with index >= this run on plain fp16 operands ("fp16c8-9": the last three)
         self.c8_plain_mlp_from = None  # ... their MLP halves (norm2, fc1, fc2) already from this block on (None: as c8_plain_from)
+        self.x3_until = None           # fp16c8 / fp16c4: blocks with index < this run on bf16x3 operands ("fp16c8-x6"); x3_mlp_until: their MLP halves
+        self.x3_mlp_until = None
         self.c8_plain_qkv = False      # ... the qkv projections of the corrected blocks on plain fp16 operands too (the output projection keeps its terms)
         # fp16c4: the output projection too on fp16c4 operands (the attention kernel then writes c4 rows)?  Measured (round 4, three seeds, 448^2):
         # the auxiliary CAM's worst error goes from 4.5e-4 to 5.1e-4 (margin on the 1e-3 bar 2.2x -> 1.95x) for 0.15 ms per step, so it is off:
@@ -279,14 +281,20 @@ class VisionTransformer(nn.Module):
         return outs
 
     # -- parity-grade no-grad path: every MFMA operand as hi + lo bf16 halves (bf16x3), fp32 residual / LayerNorm / CAM heads ----------
-    def _split_weights(self):
+    def _split_weights(self, until=None):
         """split rows [N, 2K+64] (bias in the augmentation block) of the patch projection and the 48 block projections, rebuilt from
-        the fp32 masters on every pass (the teacher's masters move every step; ~0.5 GB of traffic, part of the captured graph)"""
+        the fp32 masters on every pass (the teacher's masters move every step; ~0.5 GB of traffic, part of the captured graph).
+        until = (xa, xm): only the attention projections of blocks < xa and the MLP projections of blocks < xm (the mixed fp16c8-xN maps;
+        the patch projection then stays with the fp16c8 path)"""
         ws = self.__dict__.setdefault("_x3_w", {})
-        items = [("patch", self.patch_embed.proj.weight.reshape(self.embed_dim, -1), self.patch_embed.proj.bias)]
+        depth = len(self.blocks)
+        xa, xm = until if until is not None else (depth, depth)
+        items = [("patch", self.patch_embed.proj.weight.reshape(self.embed_dim, -1), self.patch_embed.proj.bias)] if until is None else []
         for i, blk in enumerate(self.blocks):
-            items += [(f"{i}.qkv", blk.attn.qkv.weight, blk.attn.qkv.bias), (f"{i}.proj", blk.attn.proj.weight, blk.attn.proj.bias),
-                      (f"{i}.fc1", blk.mlp.fc1.weight, blk.mlp.fc1.bias), (f"{i}.fc2", blk.mlp.fc2.weight, blk.mlp.fc2.bias)]
+            if i < xa:
+                items += [(f"{i}.qkv", blk.attn.qkv.weight, blk.attn.qkv.bias), (f"{i}.proj", blk.attn.proj.weight, blk.attn.proj.bias)]
+            if i < xm:
+                items += [(f"{i}.fc1", blk.mlp.fc1.weight, blk.mlp.fc1.bias), (f"{i}.fc2", blk.mlp.fc2.weight, blk.mlp.fc2.bias)]
         for name, w, b in items:
             buf = ws.get(name)
             if buf is None or buf.device != w.device:
@@ -365,6 +373,13 @@ class VisionTransformer(nn.Module):
         m = self.c8_plain_mlp_from if self.c8_plain_mlp_from is not None else a
         return a, m
 
+    def _x3_until(self):
+        """(xa, xm): the attention halves of blocks < xa and the MLP halves of blocks < xm of an fp16c8 / fp16c4 pass run on bf16x3 operands
+        (16 significant bits: "fp16c8-x6", "fp16c8-x6m4") -- the early blocks, whose rounding passes through the most layers"""
+        xa = self.x3_until if getattr(self, "x3_until", None) is not None else 0
+        xm = self.x3_mlp_until if getattr(self, "x3_mlp_until", None) is not None else xa
+        return xa, xm
+
     def _c8_weights(self):
         """c8 rows [N, 2K+64 fp16 units] (bias in the augmentation block) of the patch projection and the block projections, rebuilt from the
         fp32 masters on every pass (the teacher's masters move every step; part of the captured graph) by ONE batched launch"""
@@ -372,15 +387,16 @@ class VisionTransformer(nn.Module):
         from .. import _C
         items = [("patch", self.patch_embed.proj.weight.reshape(self.embed_dim, -1), self.patch_embed.proj.bias)]
         pa, pm = self._plain_from()
+        xa, xm = self._x3_until()
         for i, blk in enumerate(self.blocks):
             if self.precision == "fp16c4":          # qkv / fc1 / fc2 (and proj with c4_proj) run on fp16c4 operands (_c4_weights)
-                if not self.c4_proj and i < pa:
+                if not self.c4_proj and xa <= i < pa:
                     items += [(f"{i}.proj", blk.attn.proj.weight, blk.attn.proj.bias)]
                 continue
-            if i < pa:
+            if xa <= i < pa:
                 items += ([] if self.c8_plain_qkv else [(f"{i}.qkv", blk.attn.qkv.weight, blk.attn.qkv.bias)]) + \
                          [(f"{i}.proj", blk.attn.proj.weight, blk.attn.proj.bias)]
-            if i < pm:
+            if xm <= i < pm:
                 items += [(f"{i}.fc1", blk.mlp.fc1.weight, blk.mlp.fc1.bias), (f"{i}.fc2", blk.mlp.fc2.weight, blk.mlp.fc2.bias)]
         ent = self.__dict__.get("_c8_w")
         key = tuple((n, w.data_ptr(), b.data_ptr()) for n, w, b in items)
@@ -408,13 +424,14 @@ class VisionTransformer(nn.Module):
         from .. import _C
         items = []
         pa, pm = self._plain_from()
+        xa, xm = self._x3_until()
         for i, blk in enumerate(self.blocks):
-            if i < pa:
+            if xa <= i < pa:
                 if not self.c8_plain_qkv:
                     items.append((f"{i}.qkv", blk.attn.qkv.weight, blk.attn.qkv.bias))
                 if self.c4_proj:
                     items.append((f"{i}.proj", blk.attn.proj.weight, blk.attn.proj.bias))
-            if i < pm:
+            if xm <= i < pm:
                 items += [(f"{i}.fc1", blk.mlp.fc1.weight, blk.mlp.fc1.bias), (f"{i}.fc2", blk.mlp.fc2.weight, blk.mlp.fc2.bias)]
         ent = self.__dict__.get("_c4_w")
         key = tuple((n, w.data_ptr(), b.data_ptr()) for n, w, b in items)
@@ -504,11 +521,21 @@ class VisionTransformer(nn.Module):
         f = lambda t: t.detach()
         c16 = lambda p_: nn_ops.cast_param(p_, torch.float16)
         pa, pm = self._plain_from()
+        xa, xm = self._x3_until()
+        # mixed maps ("fp16c8-x6"): the early blocks on bf16x3 operands -- the bf16 build's split-row kernels on the same fp32 stream
+        W3 = self._split_weights(until=(xa, xm)) if max(xa, xm) > 0 else None
+        b3 = self._x3_buffers(M, dev) if W3 is not None else None
         o16 = torch.empty((M, D), device=xr.device, dtype=torch.float16) if pa < depth else None
         for i, blk in enumerate(self.blocks):
             # ---- attention half ----
             xn = torch.empty_like(xr) if aux is xr else xr              # right after the auxiliary layer: keep its output, no clone
-            if i >= pa:
+            if i < xa:
+                nn_ops.layernorm_split(xr, f(blk.norm1.weight), f(blk.norm1.bias), blk.norm1.eps, out=b3["y"])
+                nn_ops.gemm_x3(b3["y"], W3[f"{i}.qkv"], M, 3 * D, D, nn_ops.EPI_BIAS, out=b3["qkv"], ldy=2 * 3 * D)
+                for (B, N), o0, o1 in zip(shapes, offs[:-1], offs[1:]):
+                    nn_ops.attn_fwd_x3(b3["qkv"][o0:o1], B, N, H, b3["o"][o0:o1])
+                nn_ops.gemm_x3(b3["o"], W3[f"{i}.proj"], M, D, D, nn_ops.EPI_RESIDUAL, residual=xr, out=xn)
+            elif i >= pa:
                 # the last blocks on plain fp16 operands (the fused 1x path on the same fp32 stream): rounding injected here passes through
                 # the fewest layers and never reaches the auxiliary CAM (tools/sim_precision_map.py, `from:` maps)
                 y, _ = nn_ops.layernorm_f32(xr, c16(blk.norm1.weight), c16(blk.norm1.bias), blk.norm1.eps)
@@ -541,7 +568,11 @@ class VisionTransformer(nn.Module):
                     nn_ops.gemm_c8(bf["o"], W[f"{i}.proj"], M, D, D, nn_ops.EPI_RESIDUAL, residual=xr, out=xn)
             xr = xn
             # ---- MLP half ----
-            if i >= pm:
+            if i < xm:
+                nn_ops.layernorm_split(xr, f(blk.norm2.weight), f(blk.norm2.bias), blk.norm2.eps, out=b3["y"])
+                nn_ops.gemm_x3(b3["y"], W3[f"{i}.fc1"], M, Hd, D, nn_ops.EPI_GELU, out=b3["h"], ldy=b3["h"].shape[1])
+                nn_ops.gemm_x3(b3["h"], W3[f"{i}.fc2"], M, D, Hd, nn_ops.EPI_RESIDUAL, residual=xr, out=xr)
+            elif i >= pm:
                 y, _ = nn_ops.layernorm_f32(xr, c16(blk.norm2.weight), c16(blk.norm2.bias), blk.norm2.eps)
                 hmid = nn_ops.gemm_bf16(y, c16(blk.mlp.fc1.weight), c16(blk.mlp.fc1.bias), nn_ops.EPI_GELU)
                 nn_ops.gemm_bf16(hmid, c16(blk.mlp.fc2.weight), c16(blk.mlp.fc2.bias), nn_ops.EPI_RESIDUAL, residual=xr, out=xr)

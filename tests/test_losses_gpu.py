@@ -160,6 +160,54 @@ def test_bf16_student_step_vs_cpu_oracle_vitb(S, stream):
         assert cs >= bar and 0.95 <= ratio <= 1.05, (name, cs, ratio)
 
 
+STUDENT_SEEDS = (3, 7, 11, 19, 23)
+
+
+def test_student_gradient_cosines_over_seeds_vs_cpu_oracle():
+    """The student's weight-gradient cosines against oracle/cpu_step.py are ONE draw of the bf16 rounding noise per (weights, batch): a
+    single-draw bar pins the kernels' last bits rather than their accuracy.  This is the statistic instead: five
+    weight / batch seeds at S = 224 (394 tokens per gradient: the noisier crop), fp32 residual stream, the encoder weights of
+    test_bf16_student_step_vs_cpu_oracle_vitb -- MEAN and MINIMUM over the seeds per weight, losses within 1e-3 on every seed.  A kernel
+    change that re-rolls the noise moves single draws by a few 1e-3 and leaves these where they are; a real loss of accuracy does not."""
+    from cosa_amd.train_step import CoSATrainer, default_args, synthetic_batch
+    from oracle.cpu_step import CpuStep
+    dev = torch.device("cuda", 0)
+    S, b, C = 224, 2, 20
+    names = ("encoder.blocks.0.attn.qkv.weight", "encoder.blocks.6.attn.qkv.weight", "encoder.blocks.11.attn.qkv.weight",
+             "encoder.blocks.0.attn.proj.weight", "encoder.blocks.5.mlp.fc1.weight", "encoder.blocks.0.mlp.fc2.weight",
+             "encoder.blocks.11.mlp.fc2.weight", "encoder.patch_embed.proj.weight", "decoder.conv6.weight", "classifier.weight")
+    cos = {n: [] for n in names}
+    torch.set_num_threads(max(1, min(16, torch.get_num_threads())))
+    for seed in STUDENT_SEEDS:
+        args = default_args("VOC12", crop_size=S, teacher_precision="fp16c8", teacher_graph=False, teacher_async=False)
+        tr = CoSATrainer(args, dev, seed=seed)
+        sd = {k: v.detach().cpu().clone() for k, v in tr.student.state_dict().items()}
+        wimg, simg, lab, box = synthetic_batch(b, S, C, dev, seed=seed + 2)
+        n_iter = args.warmup_iters + 1
+        loss, logs = tr.forward_losses(wimg, simg, lab, box, n_iter)
+        cpu = CpuStep(sd, num_classes=21, aux_layer=-4)
+        closs, clogs = cpu.losses(wimg.cpu(), simg.cpu(), lab.cpu(), box.numpy(), n_iter)
+        for k in ("cls_loss", "cls_aux_loss", "seg_loss", "cam_loss", "overall_loss"):
+            assert float(logs[k]) == pytest.approx(float(clogs[k]), rel=1e-3, abs=2e-5), (seed, k, float(logs[k]), float(clogs[k]))
+        tr.optimizer.zero_grad(set_to_none=True)
+        loss.backward()
+        closs.backward()
+        named = dict(tr.student.named_parameters())
+        for n in names:
+            cos[n].append(_cos(named[n].grad.float().cpu(), cpu.student.p(n).grad))
+        del tr, cpu
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(root, "gpurun_out", "r05_student_cosines_over_seeds.txt"), "w") as f:
+        f.write(f"# weight-gradient cosines, HIP student (fp32 stream, bf16 MFMA operands) vs oracle/cpu_step.py, ViT-B, S = {S}, b = 2, seeds {STUDENT_SEEDS}\n")
+        for n in names:
+            f.write(f"{n}: mean {np.mean(cos[n]):.5f} min {np.min(cos[n]):.5f}  " + " ".join(f"{c:.5f}" for c in cos[n]) + "\n")
+    for n in names:
+        enc = "encoder" in n
+        assert np.mean(cos[n]) >= (0.994 if enc else 0.999) and np.min(cos[n]) >= (0.988 if enc else 0.998), (n, cos[n])
+
+
 def test_ten_step_trajectory_vs_cpu_oracle():
     """Ten optimizer steps of the real trainer (fp32-stream student, parity-grade teacher, fused AdamW + EMA kernel) next to ten steps of
     oracle/cpu_step.py on the same weights and the same batch (S = 224, b = 2, post-warm-up loss weights, the LR schedule from step 0):
