@@ -47,7 +47,8 @@ def parse():
     ap.add_argument("--usepar", action="store_true", help="PAR(T=10, 6 dilations) as cam2mask's refine_model")
     ap.add_argument("--usegmm", action="store_true", help="adaptive thresholds: 3-component mixture fitted to the CAM queue every step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--teacher-precision", default="auto", choices=["auto", "bf16", "fp16", "bf16x3", "fp16c8", "fp16c8-9", "fp16c4", "fp16c4-10", "fp16c4-9", "fp16c4-8", "fp16c4-12m8", "fp16c4-12m9"],
+    ap.add_argument("--teacher-precision", default="auto", type=_mode_arg,
+                    metavar="{auto,bf16,fp16,bf16x3,fp16c8[-N[mK]|-xN[mK]],fp16c4[...]}",
                     help="MFMA operand precision of the teacher's no-grad passes in the HEADLINE run (DESIGN.md section 3).  The default (`auto`) is the "
                          "cheapest mode that met BASELINE.json's tolerance (1e-3 relative on fp32 CAMs, mask IoU >= 0.999) on EVERY draw of the committed "
                          "accuracy record (train_step.resolve_teacher_precision; margins: DESIGN.md section 3); "
@@ -348,21 +349,46 @@ def vit_forward_roofline(trainer, wimg, dev, crop):
             "note": "algorithmic FLOPs of the fp32 reference / time; bf16x3 issues 3 MFMA terms per product, fp16c8 ~2.08 in the projections"}
 
 
-MODE_TEXT = {
+_BASE_TEXT = {
     "bf16": "bf16 operands (BASELINE configs[1] read literally; 8 significant bits)",
     "fp16": "fp16 operands (11 significant bits)",
-    "bf16x3": "bf16x3 (hi + lo bf16 halves, 3 MFMA terms, fp32 accumulation)",
+    "bf16x3": "bf16x3 (hi + lo bf16 halves, 3 MFMA terms, fp32 accumulation: 16 significant bits)",
     "fp16c8": "fp16c8 (fp16 x fp16 + two e5m2 correction terms on the block-scaled MFMA, fp32 accumulation; attention operands fp16, "
               "attention output fp16 + e5m2)",
-    "fp16c8-9": "fp16c8 in blocks 0-8, plain fp16 operands in blocks 9-11",
     "fp16c4": "fp16c4 (fp16 x fp16 + both correction terms as FP4 (e2m1) MX blocks on the block-scaled MFMA at 4x the fp16 rate in qkv / fc1 / "
               "fc2, fp32 accumulation; output projection fp16c8, attention operands fp16)",
-    "fp16c4-10": "fp16c4 in blocks 0-9, plain fp16 operands in blocks 10-11",
-    "fp16c4-9": "fp16c4 in blocks 0-8, plain fp16 operands in blocks 9-11",
-    "fp16c4-8": "fp16c4 in blocks 0-7, plain fp16 operands in blocks 8-11",
-    "fp16c4-12m8": "fp16c4 attention halves (qkv, output projection) in all blocks, fp16c4 MLP halves in blocks 0-7, plain fp16 MLPs in blocks 8-11",
-    "fp16c4-12m9": "fp16c4 attention halves (qkv; output projection fp16c8) in all blocks, fp16c4 MLPs in blocks 0-8, plain fp16 MLPs in blocks 9-11",
 }
+
+
+def mode_text(mode):
+    """plain-words description of a teacher-operand mode string (VITNetwork.set_nograd_precision)"""
+    import re
+    base, _, tail = mode.partition("-")
+    t = _BASE_TEXT[base]
+    m = re.fullmatch(r"(\d+)(?:m(\d+))?(q?)", tail) if tail else None
+    mx = re.fullmatch(r"x(\d+)(?:m(\d+))?", tail) if tail else None
+    if m:
+        a, k = int(m.group(1)), int(m.group(2)) if m.group(2) else int(m.group(1))
+        t += f"; attention halves from block {a} on and MLP halves from block {k} on: plain fp16 operands" + ("; qkv projections plain fp16" if m.group(3) else "")
+    if mx:
+        a, k = int(mx.group(1)), int(mx.group(2)) if mx.group(2) else int(mx.group(1))
+        t += f"; attention halves of blocks 0-{a - 1} and MLP halves of blocks 0-{k - 1}: bf16x3 operands (hi + lo bf16 halves, 3 MFMA terms)"
+    return t
+
+
+class _ModeText(dict):
+    def __missing__(self, mode):
+        return mode_text(mode)
+
+
+MODE_TEXT = _ModeText()
+
+
+def _mode_arg(v):
+    import re
+    if v == "auto" or v in _BASE_TEXT or re.fullmatch(r"fp16c[48]-(\d+(m\d+)?q?|x\d+(m\d+)?)", v):
+        return v
+    raise argparse.ArgumentTypeError(f"unknown teacher precision {v!r}")
 
 
 def secondary_run(opt, dev, C, wimg, simg, lab, box, n_iter, mode):

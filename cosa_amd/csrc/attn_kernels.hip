@@ -455,7 +455,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const op16 *__restric
                 // the accumulators, the running sums and the Q-side constant of the 65th index.  First tile: m = 0 is not a maximum yet.
                 const bool first = k0 == 0;
                 if (first || __any(mt > kDeferLog2)) {
-                    const float mq = (float)(op16)(first ? mt : m[u] + fmaxf(mt, 0.f));
+                    // The new reference must be an op16 value (it enters the score MFMAs as an operand) and must not round back BELOW its
+                    // target: with 8-bit operands and |m| >= 1024 the spacing (8) exceeds the deferral threshold, m + mt would round to m,
+                    // delta = 0, and the probabilities would keep growing past 2^kDeferLog2.  Adding half a unit of the
+                    // operand type's coarsest relative spacing before the rounding makes it round to >= the target, so every move
+                    // brings the row maxima back to <= 0.
+                    const float tgt = m[u] + fmaxf(mt, 0.f);
+                    const float mq = (float)(op16)(first ? mt : tgt + __builtin_fabsf(tgt) * kOp16HalfSpacing);
                     const float delta = mq - m[u];
                     if (!first) {
                         const float alpha = __builtin_amdgcn_exp2f(-delta);

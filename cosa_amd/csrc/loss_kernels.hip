@@ -87,20 +87,25 @@ __device__ __forceinline__ float wave_sum(float v)
 // Sums that meet from many threads / workgroups are kept in 64-bit FIXED POINT and added with integer atomics: integer addition is
 // associative, so the result does not depend on the order in which the adds land -- the loss and its gradient are the same bits every
 // run (round 2 used float atomics in LDS and in global memory here: the last source of run-to-run differences in the student's
-// gradients, together with the weight-gradient GEMM's).  Forward sums (up to ~1e7): 32 fractional bits; gradient cells (|sum| < 32):
-// 52 fractional bits, i.e. finer than fp32's own resolution for every value above 2^-28.
+// gradients, together with the weight-gradient GEMM's).  Forward sums (up to ~1e7): 32 fractional bits; gradient cells: 48 fractional bits,
+// i.e. finer than fp32's own resolution for every value above 2^-24 (a cell of the benchmark's step is 1e-6 ... 1e-2).
 // A value the fixed-point form cannot carry -- NaN, an infinity (a diverged loss), or a magnitude beyond the range that keeps the 64-bit sum from
-// wrapping (forward sums: |v| < 2^31; gradient cells: at most 1024 adds of |v| < 1 each stay inside 52 + 11 bits) -- contributes nothing and
-// sets a sticky flag word instead; the kernels that convert the sums back to fp32 then write NaN, as the float atomics of round 2 would have.
+// wrapping -- contributes nothing and sets a sticky flag word instead; the kernels that convert the sums back to fp32 then write NaN, as the
+// float atomics of round 2 would have.  Ranges: forward sums |v| < 2^31.  Gradient cells: a cell of the low-resolution logits receives at most
+// (2 S / h)^2 = 1024 adds at the configured 16x up-sampling (one per full-resolution pixel whose bilinear taps touch it; fewer when a wave or a
+// quad pre-sums its pixels), and one add is at most 0.5 g (the per-pixel gradient is 0.25 g / count per class group, summed over at most `count`
+// pixels of each of the two groups): |v| < 16 keeps 1024 adds inside 48 + 15 bits for every loss weight g < 32 (round 4 bounded |v| < 1 at 52
+// fractional bits, which a weight g >= 2 with few foreground pixels could trip: ADVICE r4).
 __device__ __forceinline__ unsigned long long fix32(float v, unsigned long long *flag)
 {
     if (!(__builtin_fabsf(v) < 2147483648.0f)) { atomicOr(flag, 1ull); return 0ull; }
     return (unsigned long long)(long long)__builtin_rint((double)v * 4294967296.0);
 }
-__device__ __forceinline__ unsigned long long fix52(float v, unsigned long long *flag)
+constexpr double kFixGrad = 281474976710656.0;          // 2^48
+__device__ __forceinline__ unsigned long long fix52(float v, unsigned long long *flag)      // (the name is round 3's: 48 fractional bits since round 5)
 {
-    if (!(__builtin_fabsf(v) < 1.0f)) { atomicOr(flag, 1ull); return 0ull; }
-    return (unsigned long long)(long long)__builtin_rint((double)v * 4503599627370496.0);
+    if (!(__builtin_fabsf(v) < 16.0f)) { atomicOr(flag, 1ull); return 0ull; }
+    return (unsigned long long)(long long)__builtin_rint((double)v * kFixGrad);
 }
 
 // ---- forward ---------------------------------------------------------------------------------------------------
@@ -299,7 +304,7 @@ __global__ __launch_bounds__(256) void seg_loss_grad_kernel(const unsigned long 
                                                            float *__restrict__ grad, size_t n)
 {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) grad[i] = *flag ? __builtin_nanf("") : (float)((double)(long long)fix[i] * (1.0 / 4503599627370496.0));
+    if (i < n) grad[i] = *flag ? __builtin_nanf("") : (float)((double)(long long)fix[i] * (1.0 / kFixGrad));
 }
 
 

@@ -15,6 +15,13 @@ typedef __bf16 op16;
 #define COSA_MFMA_16x16x32(a, b, c, x, y, z) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z)
 #define COSA_MFMA_32x32x16(a, b, c, x, y, z) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z)
 #endif
+// half of the type's coarsest relative spacing (one unit in the last place of a value just above a power of two, halved): x + |x| * this
+// rounds to an op16 value >= x
+#if COSA_OP_F16
+constexpr float kOp16HalfSpacing = 0.00048828125f;          // 2^-11
+#else
+constexpr float kOp16HalfSpacing = 0.00390625f;             // 2^-8
+#endif
 typedef op16 op16x8 __attribute__((ext_vector_type(8)));
 typedef op16 op16x4 __attribute__((ext_vector_type(4)));
 typedef op16 op16x2 __attribute__((ext_vector_type(2)));

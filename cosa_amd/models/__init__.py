@@ -37,8 +37,7 @@ class LargeFOV(nn.Module):
         w8 = c(self.conv8.weight, dt).reshape(self.conv8.weight.shape[0], -1)
         seg = nn_ops.head_linear(y.view(B, h * w, -1), w8.contiguous(), round_bf16=True)
         if seg is None:
-            nn_ops.torch_fallback(f"LargeFOV.conv8 ({tuple(w8.shape)}, {dt})")
-            seg = F.linear(y, w8).float()
+            seg = nn_ops.reference_op("linear", f"LargeFOV.conv8 ({tuple(w8.shape)}, {dt})", y, w8, None).float()
         return seg.view(B, h, w, -1).permute(0, 3, 1, 2).contiguous()
 
     def forward_tokens_train(self, tok, B, h, w):
@@ -50,19 +49,16 @@ class LargeFOV(nn.Module):
         y = nn_ops.DilatedConvReluFn.apply(y.view(B, h * w, -1), self.conv7.weight, B, h, w, self.dilation)
         seg = nn_ops.narrow_linear(y, self.conv8.weight)
         if seg is None:
-            nn_ops.torch_fallback(f"LargeFOV.conv8 with autograd ({tuple(self.conv8.weight.shape)})")
             w8 = nn_ops.cast_param(self.conv8.weight, torch.bfloat16).reshape(self.conv8.weight.shape[0], -1)
-            seg = F.linear(y, w8).float()
+            seg = nn_ops.reference_op("linear", f"LargeFOV.conv8 with autograd ({tuple(self.conv8.weight.shape)})", y, w8, None).float()
         return seg.view(B, h, w, -1).permute(0, 3, 1, 2).contiguous()
 
     def forward_nhwc(self, x, dt):
-        """x: [B,C,h,w] view with channels-last strides (tokens are NHWC already)."""
+        """x: [B,C,h,w] view with channels-last strides (tokens are NHWC already): channel counts / dtypes the implicit-GEMM conv kernels do
+        not cover -- outside the envelope (conv_head.py:32-41 as a reference operator of the test-suite)"""
         c = nn_ops.cast_param
-        x = F.relu(F.conv2d(x, c(self.conv6.weight, dt).contiguous(memory_format=torch.channels_last), padding=self.dilation,
-                            dilation=self.dilation))
-        x = F.relu(F.conv2d(x, c(self.conv7.weight, dt).contiguous(memory_format=torch.channels_last), padding=self.dilation,
-                            dilation=self.dilation))
-        return F.conv2d(x, c(self.conv8.weight, dt))
+        return nn_ops.reference_op("largefov", f"LargeFOV decoder ({dt}, {self.conv6.weight.shape[1]} channels, grad {torch.is_grad_enabled()})",
+                                   x, c(self.conv6.weight, dt), c(self.conv7.weight, dt), c(self.conv8.weight, dt), self.dilation)
 
 
 class VITNetwork(nn.Module):
@@ -131,7 +127,7 @@ class VITNetwork(nn.Module):
     def _cam(self, tok, weight, B, h, w, detach_feat, detach_w):
         """1x1 conv over tokens == tokens @ W^T; returned as fp32 NCHW [B,C,h,w] (models/__init__.py:190-192).  Own kernels: the
         exact-fp32 MFMA narrow-head kernel (no-grad paths; fp32 tokens of the fused teacher keep the head in fp32) and, with autograd,
-        nn_ops.NarrowLinearFn; torch only for shapes outside their envelope / on the host."""
+        nn_ops.NarrowLinearFn; other shapes are outside the envelope (nn_ops.reference_op)."""
         dt = tok.dtype
         if detach_feat:
             tok = tok.detach()
@@ -142,10 +138,8 @@ class VITNetwork(nn.Module):
         elif tok.is_cuda and dt == torch.bfloat16:
             cam = nn_ops.narrow_linear(tok.reshape(-1, tok.shape[-1]).contiguous(), weight.detach() if detach_w else weight)
         if cam is None:
-            if tok.is_cuda:
-                nn_ops.torch_fallback(f"CAM head ({tuple(weight.shape)}, tokens {dt})")
             wgt = nn_ops.cast_param(weight, dt).reshape(weight.shape[0], -1)
-            cam = F.linear(tok, wgt.detach() if detach_w else wgt).float()
+            cam = nn_ops.reference_op("linear", f"CAM head ({tuple(weight.shape)}, tokens {dt})", tok, wgt.detach() if detach_w else wgt, None).float()
         return cam.reshape(B, h, w, -1).permute(0, 3, 1, 2).contiguous()
 
     def _cls_head(self, pooled, weight, dt):
@@ -157,9 +151,8 @@ class VITNetwork(nn.Module):
         elif pooled.is_cuda and dt == torch.bfloat16:
             y = nn_ops.narrow_linear(pooled.to(dt).contiguous(), weight)
         if y is None:
-            if pooled.is_cuda:
-                nn_ops.torch_fallback(f"classification head ({tuple(weight.shape)}, {dt})")
-            y = F.linear(pooled.to(dt), nn_ops.cast_param(weight, dt).reshape(weight.shape[0], -1)).float()
+            y = nn_ops.reference_op("linear", f"classification head ({tuple(weight.shape)}, {dt})", pooled.to(dt),
+                                    nn_ops.cast_param(weight, dt).reshape(weight.shape[0], -1), None).float()
         return y
 
     def refresh_shadows(self):
@@ -194,13 +187,16 @@ class VITNetwork(nn.Module):
     def _heads_train_f32(self, x, feats, cam_only, seg_only, detach):
         """the heads of the training path on the fp32 residual stream (models/__init__.py:163-206): every consumer of the final tokens
         (decoder, CAM head, pooled classification head) and of the auxiliary tokens (aux CAM head, aux classification head) takes its own
-        bf16 view of ONE cast (nn_ops.fanout_bf16), whose backward adds the consumers' gradients in fp32"""
+        bf16 view of ONE cast (nn_ops.patch_fanout_bf16), whose backward adds the consumers' gradients in fp32"""
         B = x.shape[0]
         p = self.encoder.patch_size
         h, w = x.shape[-2] // p, x.shape[-1] // p
-        t_dec, t_cam, t_cls = nn_ops.patch_fanout_bf16(feats.final, 3)          # (patch tokens only: the class token feeds no head)
+        # (patch tokens only: the class token feeds no head.  The returned feature map x4 gets a view of its own: as a view of the decoder's
+        # input its gradient would meet the decoder's in bf16 before the fp32 junction -- ADVICE r4; no loss of the reference differentiates
+        # through it, and the junction kernel adds at most three live gradients: a fourth raises instead of rounding silently)
+        t_dec, t_cam, t_cls, t_x4 = nn_ops.patch_fanout_bf16(feats.final, 4)
         a_cam, a_cls = nn_ops.patch_fanout_bf16(feats.aux, 2)
-        x4 = t_dec.reshape(B, h, w, -1).permute(0, 3, 1, 2)
+        x4 = t_x4.reshape(B, h, w, -1).permute(0, 3, 1, 2)
         seg = self.decoder.forward_tokens_train(t_dec, B, h, w)
         if seg_only:
             return seg
@@ -230,8 +226,6 @@ class VITNetwork(nn.Module):
                 and torch.is_grad_enabled():
             seg = self.decoder.forward_tokens_train(tok, B, h, w)      # training: forward + both gradients on own kernels
         else:
-            if tok.is_cuda:
-                nn_ops.torch_fallback(f"LargeFOV decoder ({dt}, {self.decoder.conv6.weight.shape[1]} channels, grad {torch.is_grad_enabled()})")
             seg = self.decoder.forward_nhwc(x4, dt).float().contiguous()
         if seg_only:
             return seg

@@ -171,9 +171,7 @@ class VisionTransformer(nn.Module):
             # training: the same GEMM kernels with autograd (LinearShadowFn on the [768, 3*16*16] view of the conv weight)
             tok = nn_ops.linear_view2d(cols, self.patch_embed.proj.weight, self.patch_embed.proj.bias, dt)
         else:
-            if x.is_cuda:
-                nn_ops.torch_fallback(f"patch projection ({dt}, embed {self.embed_dim})")
-            tok = F.linear(cols, wgt, bias)
+            tok = nn_ops.reference_op("linear", f"patch projection ({dt}, embed {self.embed_dim})", cols, wgt, bias)
         if stream_f32:
             tok = torch.cat((self.cls_token.float().expand(B, -1, -1), tok.float()), dim=1)
             return tok + self._pos_for_grid(h, w, torch.float32), h, w
@@ -184,11 +182,12 @@ class VisionTransformer(nn.Module):
     def _block(self, blk, x):
         dt = self.compute_dtype
         c = nn_ops.cast_param
-        y = F.layer_norm(x, (self.embed_dim,), c(blk.norm1.weight, dt), c(blk.norm1.bias, dt), blk.norm1.eps)
+        ln = lambda t, n: nn_ops.reference_op("layer_norm", f"LayerNorm({self.embed_dim}) on {dt}", t, c(n.weight, dt), c(n.bias, dt), n.eps)
+        y = ln(x, blk.norm1)
         qkv = nn_ops.linear(y, blk.attn.qkv.weight, blk.attn.qkv.bias, dt)
         y = nn_ops.attention(qkv, self.num_heads)
         x = x + nn_ops.linear(y, blk.attn.proj.weight, blk.attn.proj.bias, dt)
-        y = F.layer_norm(x, (self.embed_dim,), c(blk.norm2.weight, dt), c(blk.norm2.bias, dt), blk.norm2.eps)
+        y = ln(x, blk.norm2)
         y = nn_ops.linear(y, blk.mlp.fc1.weight, blk.mlp.fc1.bias, dt, act=True)
         return x + nn_ops.linear(y, blk.mlp.fc2.weight, blk.mlp.fc2.bias, dt)
 
@@ -688,15 +687,15 @@ class VisionTransformer(nn.Module):
             if aux_idx == depth - 1:
                 aux = xn
             return xn[:, 0], xn[:, 1:], aux[:, 1:], None
-        if x.is_cuda:        # not ViT-B on 16-bit operands: only torch's operators could run this (a test-only mode, nn_ops.torch_reference_ops)
-            nn_ops.torch_fallback(f"VisionTransformer (embed {self.embed_dim}, {self.compute_dtype}) outside the HIP path's envelope")
+        # not ViT-B on 16-bit operands: outside the HIP path's envelope -- the block below is module wiring only, every operator of it is
+        # nn_ops.reference_op (raises in the product; the host-logic tests install torch's operators: tests/torch_reference.py)
         for i, blk in enumerate(self.blocks):
             x = self._block(blk, x)
             if i == aux_idx:
                 aux = x
         dt = self.compute_dtype
-        x = F.layer_norm(x, (self.embed_dim,), nn_ops.cast_param(self.norm.weight, dt), nn_ops.cast_param(self.norm.bias, dt),
-                         self.norm.eps)
+        x = nn_ops.reference_op("layer_norm", f"LayerNorm({self.embed_dim}) on {dt}", x, nn_ops.cast_param(self.norm.weight, dt),
+                                nn_ops.cast_param(self.norm.bias, dt), self.norm.eps)
         if aux_idx == depth - 1:
             aux = x
         return x[:, 0], x[:, 1:], aux[:, 1:], None

@@ -159,7 +159,8 @@ def test_launcher_rejects_flags_it_does_not_honour():
 
 def test_teacher_precision_mode_strings():
     """`set_nograd_precision`: "base", "base-n" (blocks from n on plain fp16) and "base-nmk" (their MLP halves from block k on); the launcher's
-    and the trainer's default is the measured 2x-margin map (profiles/r04_accuracy_teacher.txt)"""
+    and the trainer's default is the cheapest map with no failing draw on record (profiles/r05_accuracy_teacher.txt); "base-xn[mk]": the
+    blocks below n (their MLP halves below k) on bf16x3 operands"""
     import torch
     from cosa_amd.models import build_model
     from cosa_amd.train_step import default_args
@@ -167,15 +168,19 @@ def test_teacher_precision_mode_strings():
     from cosa_amd.train_step import resolve_teacher_precision
     a = default_args("VOC12", crop_size=64)
     assert a.teacher_precision == "auto"
-    assert [resolve_teacher_precision("auto", c) for c in (224, 448, 512, 640)] == ["fp16c4-12m9", "fp16c4-12m9", "fp16c8", "fp16c8"]
-    assert resolve_teacher_precision("bf16", 640) == "bf16" and resolve_teacher_precision("auto", 448, usepar=True) == "fp16c8"
+    assert [resolve_teacher_precision("auto", c) for c in (224, 448, 512, 640)] == ["fp16c8-x2"] * 4
+    assert resolve_teacher_precision("bf16", 640) == "bf16" and resolve_teacher_precision("auto", 448, usepar=True) == "fp16c8-x2"
     net = build_model(a)
     for mode, prec, dt, plain in (("bf16", None, torch.bfloat16, (12, 12)), ("fp16c8", "fp16c8", torch.float16, (12, 12)),
                                   ("fp16c8-9", "fp16c8", torch.float16, (9, 9)), ("fp16c4-8", "fp16c4", torch.float16, (8, 8)),
                                   ("fp16c4-12m8", "fp16c4", torch.float16, (12, 8)), ("fp16c4-9m7", "fp16c4", torch.float16, (9, 7))):
         net.set_nograd_precision(mode)
         assert net.encoder.precision == prec and net.encoder.compute_dtype == dt and net.encoder._plain_from() == plain, mode
-    for bad in ("fp16c4-", "fp16c4-m8", "bf16-3", "fp8", "fp16c4-9m"):
+        assert net.encoder._x3_until() == (0, 0)
+    for mode, prec, x3 in (("fp16c8-x2", "fp16c8", (2, 2)), ("fp16c8-x6m4", "fp16c8", (6, 4)), ("fp16c4-x0m3", "fp16c4", (0, 3))):      # round 5: early blocks on bf16x3
+        net.set_nograd_precision(mode)
+        assert net.encoder.precision == prec and net.encoder._x3_until() == x3 and net.encoder._plain_from() == (12, 12), mode
+    for bad in ("fp16c4-", "fp16c4-m8", "bf16-3", "fp8", "fp16c4-9m", "fp16c8-x", "bf16x3-x2"):
         with pytest.raises(AssertionError):
             net.set_nograd_precision(bad)
 

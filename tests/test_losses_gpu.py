@@ -367,3 +367,28 @@ def test_seg_loss_non_finite_input_gives_nan_not_garbage():
     l_seg, l_reg = seg_helper.fused_seg_and_energy_loss(seg, mk(), mk(), simg, box, layer)
     (l_seg + l_reg).backward()
     assert math.isfinite(float(l_seg)) and torch.isfinite(seg.grad).all()
+
+
+@pytest.mark.gpu
+def test_seg_loss_large_weight_with_few_foreground_pixels_is_not_an_overflow():
+    """one foreground pixel per image and a loss weight of 8 give per-add gradient contributions of 0.25 * 8 / 2 = 1.0 -- a
+    legitimate value that round 4's |v| < 1 bound of the fixed-point cells turned into NaN.  The gradient must be finite and 8 x the
+    weight-1 gradient (the backward is linear in the upstream gradient)."""
+    from cosa_amd.utils import seg_helper
+    from cosa_amd.train_step import synthetic_batch
+    dev = torch.device("cuda", 0)
+    B, K, S = 2, 21, 224
+    wimg, simg, lab, box = synthetic_batch(B, S, 20, dev, seed=3)
+    g = torch.Generator().manual_seed(1)
+    few = torch.zeros(B, S, S, device=dev)
+    few[:, 100, 120] = 3.0
+    layer = seg_helper.DenseEnergyLoss(weight=1e-7, sigma_rgb=15, sigma_xy=100, scale_factor=0.5)
+    seg0 = torch.randn(B, K, S // 16, S // 16, generator=g).to(dev)
+    grads = []
+    for wgt in (1.0, 8.0):
+        seg = seg0.clone().requires_grad_(True)
+        l_seg, _ = seg_helper.fused_seg_and_energy_loss(seg, few, few.clone(), simg, box, layer)
+        (l_seg * wgt).backward()
+        assert math.isfinite(float(l_seg)) and torch.isfinite(seg.grad).all(), wgt
+        grads.append(seg.grad.clone())
+    assert torch.allclose(grads[1], 8.0 * grads[0], rtol=1e-5, atol=1e-12)

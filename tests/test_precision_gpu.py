@@ -450,9 +450,11 @@ TEACHER_BARS = {
     "bf16": (3e-2, 0.99, 0.97),
     "fp16": (4e-3, 0.9990, 0.995),
     "bf16x3": NORTH_STAR,
-    "fp16c8": NORTH_STAR,          # fp16 + two e5m2 correction terms (round 3): >= 2.3x inside the bar on every seed and crop tried
+    "fp16c8": NORTH_STAR,          # fp16 + two e5m2 correction terms (round 3): inside the bar on these seeds; 1.12e-3 on ONE of 40 held-out draws
     "fp16c4": NORTH_STAR,          # round 4: FP4 (e2m1, MX blocks) correction terms in qkv / fc1 / fc2 of every block
-    "fp16c4-12m9": NORTH_STAR,     # ... attention halves corrected in every block, MLP halves in blocks 0-8: the trainer's default up to 448^2
+    "fp16c8-x2": NORTH_STAR,       # round 5: fp16c8 with blocks 0-1 on bf16x3 operands: the cheapest map that held the bars on all 40 held-out
+    #                                draws of the sweep below (worst 6.3e-4) -- the trainer's default
+    "fp16c4-12m9": ON_RECORD,      # round 4's default: holds the bars on the seven seeds it was chosen on, fails 12 of 40 held-out draws
     "fp16c8-9": ON_RECORD,         # round 3's benchmarked mode (last three blocks plain fp16): 1.06e-3 at 640^2 on one seed
     "fp16c4-10": ON_RECORD, "fp16c4-9": ON_RECORD,
     "fp16c4-8": ON_RECORD,         # last four blocks plain fp16: 2.0x inside the bar on seeds 3 / 11 / 29, mask IoU 0.9988 on seed 17
@@ -463,7 +465,7 @@ TEACHER_BARS = {
 # plain-fp16 attention in the last blocks pass seeds 3 / 11 / 29 with a 2x margin and fail seed 17); bench.py reports the WORST of these lines
 # (profiles/r04_accuracy_teacher.txt, copied from gpurun_out/ after the GPU run) and derives `tolerance_met` from them
 CONFORMING_SEEDS = (3, 11, 29, 5, 17, 23, 41)
-_MULTI = {448: ("fp16c4-12m9", "fp16c4", "fp16c8", "fp16c8-9", "fp16c4-8"), 224: ("fp16c4-12m9", "fp16c8")}
+_MULTI = {448: ("fp16c8-x2", "fp16c4-12m9", "fp16c4", "fp16c8", "fp16c8-9", "fp16c4-8"), 224: ("fp16c8-x2", "fp16c4-12m9", "fp16c8")}
 _CASES = [(m, 3, S) for m in TEACHER_BARS for S in (224, 448)] + [(m, sd_, S) for S, ms in _MULTI.items() for m in ms for sd_ in CONFORMING_SEEDS[1:]]
 
 
@@ -474,7 +476,7 @@ def test_fused_teacher_vs_fp32_cpu_oracle(mode, seed, S):
 
 # at 640^2 (3601 tokens at scale 1.5) the maps with plain-fp16 blocks lose most: fp16c4-8 9.8e-4, fp16c8-9 1.06e-3 on seed 11 -- on record only;
 # the trainer's "auto" default takes fp16c8 above 448^2
-MODES_640 = (("fp16c4-8", False), ("fp16c8-9", False), ("fp16c4-12m9", True), ("fp16c8", True))
+MODES_640 = (("fp16c4-8", False), ("fp16c8-9", False), ("fp16c4-12m9", False), ("fp16c8", True), ("fp16c8-x2", True))
 
 
 @pytest.mark.parametrize("seed", (3, 11, 29, 17))
@@ -516,10 +518,13 @@ def _check_teacher(mode, seed, S, bars=None, b=2):
 
 # ---- the wide sweep behind the headline: >= 32 further weight / batch draws at 448^2 and ONE batch of the bench's own size
 # (b = 16).  In the suite by default: SWEEP_DEFAULT draws (suite time); `COSA_ACCURACY_SWEEP_SEEDS=40 pytest -k sweep` writes the committed record
-# (profiles/r05_accuracy_teacher.txt).  Seeds 100 + i are disjoint from CONFORMING_SEEDS, on which the block maps were chosen: held-out evidence.
+# (profiles/r05_accuracy_teacher.txt).  Seeds 100-139 are disjoint from CONFORMING_SEEDS, on which round 4's block maps were chosen -- they are
+# what showed that fp16c4-12m9 and uniform fp16c8 do not hold, and the set the round-5 default (fp16c8-x2) was picked on; seeds 200-231
+# (COSA_ACCURACY_SWEEP_BASE=200) were drawn after that choice: held-out evidence for it.
 SWEEP_DEFAULT = 3
 SWEEP_SEEDS = int(os.environ.get("COSA_ACCURACY_SWEEP_SEEDS", str(SWEEP_DEFAULT)))
-SWEEP_MODES = tuple(os.environ.get("COSA_ACCURACY_SWEEP_MODES", "fp16c4-12m9,fp16c4,fp16c8").split(","))
+SWEEP_BASE = int(os.environ.get("COSA_ACCURACY_SWEEP_BASE", "100"))        # 100-139: the draws the round-5 map was chosen on; 200-231: drawn after the choice
+SWEEP_MODES = tuple(os.environ.get("COSA_ACCURACY_SWEEP_MODES", "fp16c8-x2,fp16c8").split(","))
 
 
 def _auto_mode(S):
@@ -527,7 +532,7 @@ def _auto_mode(S):
     return resolve_teacher_precision("auto", S)
 
 
-@pytest.mark.parametrize("seed", [100 + i for i in range(SWEEP_SEEDS)])
+@pytest.mark.parametrize("seed", [SWEEP_BASE + i for i in range(SWEEP_SEEDS)])
 def test_headline_modes_on_held_out_seeds_sweep(seed):
     """every mode of the sweep is put on record; the trainer's `auto` choice at 448^2 must hold the north-star bars on every draw"""
     auto = _auto_mode(448)

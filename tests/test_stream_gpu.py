@@ -8,6 +8,8 @@ import math
 import pytest
 import torch
 
+from torch_reference import torch_reference_ops
+
 pytestmark = pytest.mark.gpu
 
 
@@ -168,7 +170,7 @@ def test_grouped_deferred_wgrad_is_bit_identical_and_streams_agree():
 
 def test_shapes_outside_the_hip_path_raise_instead_of_falling_back():
     """north_star: "no dual backend" -- a CUDA tensor that no kernel of this repository covers raises CosaError; torch's own operators run
-    only inside nn_ops.torch_reference_ops() (tests)"""
+    only inside torch_reference_ops() (tests)"""
     from cosa_amd import nn_ops, _C
     dev = torch.device("cuda", 0)
     qkv32 = torch.randn(1, 65, 3 * 2 * 64, device=dev)
@@ -178,7 +180,7 @@ def test_shapes_outside_the_hip_path_raise_instead_of_falling_back():
     x = torch.randn(7, 96, device=dev, dtype=torch.bfloat16)
     with pytest.raises(_C.CosaError):
         nn_ops.linear(x, lin.weight, lin.bias, torch.bfloat16)
-    with nn_ops.torch_reference_ops():
+    with torch_reference_ops():
         y = nn_ops.linear(x, lin.weight, lin.bias, torch.bfloat16)
         o = nn_ops.attention(qkv32, 2)
     assert y.shape == (7, 40) and o.shape == (1, 65, 128) and math.isfinite(float(o.sum()))

@@ -24,6 +24,9 @@ def main():
     ap.add_argument("--n-iter", type=int, default=1, help="iteration number passed to the step (<= warmup_iters: classification losses only)")
     ap.add_argument("--single", action="store_true")
     ap.add_argument("--ranks", type=int, default=2, help="--single: how many ranks' shards to concatenate")
+    ap.add_argument("--defer-groups", type=int, default=0, help="batched weight-gradient launches per backward pass (0: the trainer's choice)")
+    ap.add_argument("--grid-policy", type=int, default=-1, help="persistent-GEMM grid policy (-1: the trainer's choice)")
+    ap.add_argument("--log-hooks", action="store_true", help="record when the DeferredWgrad nodes run and when DDP's bucket hooks fire")
     opt = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1")) if not opt.single else 1
     rank = int(os.environ.get("RANK", "0")) if not opt.single else 0
@@ -40,13 +43,31 @@ def main():
     box = torch.cat([s[3] for s in shards])
     args = default_args("VOC12", crop_size=opt.crop, batch_size=wimg.shape[0], teacher_graph=False, lr=1e-3)
     tr = CoSATrainer(args, dev, ddp=world > 1, seed=0)
-    for _ in range(opt.steps):
+    from cosa_amd import _C, nn_ops
+    if opt.defer_groups > 0:
+        tr.student.encoder.defer_groups = opt.defer_groups
+    if opt.grid_policy >= 0:
+        _C.lib().cosa_gemm_set_grid_policy(opt.grid_policy)
+        _C.lib().cosa_gemm_set_grid_policy_f16(opt.grid_policy)
+    events = []
+    if opt.log_hooks and world > 1:
+        import time
+        from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
+        nn_ops.event_log = events
+
+        def hook(state, bucket):          # DDP calls this when a gradient bucket is complete: the point where its all-reduce starts
+            events.append(("bucket", bucket.index(), time.perf_counter()))
+            return default_hooks.allreduce_hook(state, bucket)
+        tr.model_ON.register_comm_hook(None, hook)
+    for st in range(opt.steps):
+        events.append(("step", st, 0.0))
         logs = tr.step(wimg, simg, lab, box, n_iter=opt.n_iter)
     torch.cuda.synchronize()
     os.makedirs(opt.out, exist_ok=True)
     state = {"student": {k: v.detach().cpu() for k, v in tr.student.named_parameters()},
              "teacher": {k: v.detach().cpu() for k, v in tr.model_AN.named_parameters()},
-             "loss": float(logs["overall_loss"]), "world": dist.get_world_size() if world > 1 else 1}
+             "loss": float(logs["overall_loss"]), "world": dist.get_world_size() if world > 1 else 1, "events": events,
+             "defer_groups": tr.student.encoder._n_defer_groups()}
     torch.save(state, os.path.join(opt.out, "single.pt" if opt.single else f"rank{rank}.pt"))
     if world > 1:
         dist.barrier()
