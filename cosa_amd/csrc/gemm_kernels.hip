@@ -507,12 +507,10 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
     // ... and the store offset inside the tile's Y window for each 16-token row group (b, jj); after the lane swap a lane
     // owns features  wr*64 + pair*32 + (fq&1)*16 + 4*(fq&2) .. +7  of its token
     // (fp32 output: no swap, a lane owns features wr*64 + ii*16 + 4fq .. +3)
-    unsigned voY[4];
-#pragma unroll
-    for (int g4 = 0; g4 < 4; g4++) {
-        const int row = (g4 >> 1) * 128 + wc * 32 + (g4 & 1) * 16 + frow;
-        voY[g4] = RES ? (unsigned)((row * ldy + wr * WN + 4 * fq) * 4) : (unsigned)((row * ldy + wr * WN + (fq & 1) * 16 + 4 * (fq & 2)) * 2);
-    }
+    // (one register: the offsets of the other three row groups are formed at their use by a volatile add of a scalar -- V6_VOY below; kept as four
+    // loop-invariant registers they were what the GELU / bf16x3 instantiations spilled)
+    const unsigned voY0 = RES ? (unsigned)(((wc * 32 + frow) * ldy + wr * WN + 4 * fq) * 4)
+                              : (unsigned)(((wc * 32 + frow) * ldy + wr * WN + (fq & 1) * 16 + 4 * (fq & 2)) * 2);
     // FR == 3, 16-bit output: the third fragment of a wave has no partner to swap with; its lane keeps features 4fq .. 4fq + 3 (8-byte stores)
     const unsigned voY3 = (unsigned)((32 + 4 * fq - (fq & 1) * 16 - 4 * (fq & 2)) * 2);
     // c8 rows out: the lane's feature offset inside the tile in BYTES of an 8-bit plane (voY holds it doubled, for the fp16 plane)
@@ -545,6 +543,13 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
     // volatile asm on a scalar product: left to the compiler, the eight loop-invariant sums are hoisted out of the job loop, spilled, and
     // re-loaded from scratch behind `s_waitcnt vmcnt(0)` -- in the middle of the counted LDS-DMA stream.
     const int ldy_es = __builtin_amdgcn_readfirstlane(ldy * ES);
+#define V6_VOY(g4)                                                                                                   \
+    ({                                                                                                               \
+        unsigned r_ = voY0;                                                                                          \
+        if ((g4) != 0)                                                                                               \
+            asm volatile("v_add_u32 %0, %1, %2" : "=v"(r_) : "s"((((g4) >> 1) * 128 + ((g4) & 1) * 16) * ldy_es), "v"(voY0));  \
+        r_;                                                                                                          \
+    })
 #define V6_STG_OFF(qb, jj, it)                                                                                       \
     ({                                                                                                               \
         unsigned r_ = voS;                                                                                           \
@@ -598,7 +603,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
 #define V6_RLOAD(qa, qb, rsR)                                                                                        \
     _Pragma("unroll") for (int ii = 0; ii < FR; ii++) _Pragma("unroll") for (int jj = 0; jj < 2; jj++)               \
         asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(acc[(qa) * 4 + ii][(qb) * 2 + jj])           \
-                     : "v"(voY[(qb) * 2 + jj]), "s"(rsR), "s"(((qa) * HN + ii * 16) * 4) : "memory");
+                     : "v"(V6_VOY((qb) * 2 + jj)), "s"(rsR), "s"(((qa) * HN + ii * 16) * 4) : "memory");
 
     // pipeline fill (first job only): bias, [residual tile,] K-tile 0 complete, X0 W0 X1 of K-tile 1
     V6_LOAD_BIAS(n0);
@@ -658,7 +663,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
             _Pragma("unroll") for (int jj = 0; jj < 2; jj++) {                                                      \
                 const f32x4 o4_ = acc[(qa) * 4 + ii][(qb) * 2 + jj] + bv_;                                          \
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o4_), rsY,                         \
-                                                       voY[(qb) * 2 + jj] + ((qa) * HN + ii * 16) * 4, 0, 0);     \
+                                                       V6_VOY((qb) * 2 + jj) + ((qa) * HN + ii * 16) * 4, 0, 0);     \
             }                                                                                                       \
         }                                                                                                           \
     } else {                                                                                                        \
@@ -670,7 +675,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
             if (EPI == EPI_GELU) { _Pragma("unroll") for (int r = 0; r < 4; r++) v2_[r] = gelu_erf(v2_[r]); }       \
             const op16x2 s0_ = {(op16)v2_[0], (op16)v2_[1]}, s1_ = {(op16)v2_[2], (op16)v2_[3]};                    \
             const u32x2 o2_ = {__builtin_bit_cast(unsigned, s0_), __builtin_bit_cast(unsigned, s1_)};               \
-            __builtin_amdgcn_raw_buffer_store_b64(o2_, rsY, voY[(qb) * 2 + jj] + voY3 + (qa) * HN * 2, 0, 0);     \
+            __builtin_amdgcn_raw_buffer_store_b64(o2_, rsY, V6_VOY((qb) * 2 + jj) + voY3 + (qa) * HN * 2, 0, 0);     \
             continue;                                                                                               \
         }                                                                                                           \
         f32x4 v0_ = acc[(qa) * 4 + 2 * pr][(qb) * 2 + jj], v1_ = acc[(qa) * 4 + 2 * pr + 1][(qb) * 2 + jj];        \
@@ -681,7 +686,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
             const auto u1_ = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, r1_), __builtin_bit_cast(unsigned, r3_), false, false); \
             const u32x4 raw_ = {u0_[0], u1_[0], u0_[1], u1_[1]};                                                    \
             if (STG) V6_STG_WR(raw_, pr, 1);                                                                        \
-            else __builtin_amdgcn_raw_buffer_store_b128(raw_, rsY, voY[(qb) * 2 + jj] + ((qa) * HN + pr * 32) * 2, 0, 0); \
+            else __builtin_amdgcn_raw_buffer_store_b128(raw_, rsY, V6_VOY((qb) * 2 + jj) + ((qa) * HN + pr * 32) * 2, 0, 0); \
         }                                                                                                           \
         if (EPI == EPI_GELU) {                                                                                      \
             _Pragma("unroll") for (int r = 0; r < 4; r++) {                                                         \
@@ -695,8 +700,8 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
         const auto s1_ = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, p1_), __builtin_bit_cast(unsigned, p3_), false, false); \
         const u32x4 out_ = {s0_[0], s1_[0], s0_[1], s1_[1]};                                                        \
         if (STG) V6_STG_WR(out_, pr, 0);                                                                            \
-        else if (SPLIT == 2) __builtin_amdgcn_raw_buffer_store_b128(out_, (&rsY == &pY) ? pY2 : cY2, voY[(qb) * 2 + jj] + ((qa) * HN + pr * 32) * 2, 0, 0); \
-        else __builtin_amdgcn_raw_buffer_store_b128(out_, rsY, voY[(qb) * 2 + jj] + ((qa) * HN + pr * 32) * 2, 0, 0); \
+        else if (SPLIT == 2) __builtin_amdgcn_raw_buffer_store_b128(out_, (&rsY == &pY) ? pY2 : cY2, V6_VOY((qb) * 2 + jj) + ((qa) * HN + pr * 32) * 2, 0, 0); \
+        else __builtin_amdgcn_raw_buffer_store_b128(out_, rsY, V6_VOY((qb) * 2 + jj) + ((qa) * HN + pr * 32) * 2, 0, 0); \
         if (SPLIT == 1) {          /* the lo halves: what the 16-bit rounding above dropped, at column N + n */              \
             const op16x2 q0_ = {(op16)(v0_[0] - (float)p0_[0]), (op16)(v0_[1] - (float)p0_[1])};                    \
             const op16x2 q1_ = {(op16)(v0_[2] - (float)p1_[0]), (op16)(v0_[3] - (float)p1_[1])};                    \
@@ -706,7 +711,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
             const auto t1_ = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, q1_), __builtin_bit_cast(unsigned, q3_), false, false); \
             const u32x4 lo4_ = {t0_[0], t1_[0], t0_[1], t1_[1]};                                                    \
             if (STG) V6_STG_WR(lo4_, pr, 1);                                                                        \
-            else __builtin_amdgcn_raw_buffer_store_b128(lo4_, rsY, voY[(qb) * 2 + jj] + (N + (qa) * HN + pr * 32) * 2, 0, 0); \
+            else __builtin_amdgcn_raw_buffer_store_b128(lo4_, rsY, V6_VOY((qb) * 2 + jj) + (N + (qa) * HN + pr * 32) * 2, 0, 0); \
         }                                                                                                           \
         if (C8OUT) {       /* c8 rows: lo8 at byte 2N + n, hi8 at byte 3N + n of the row (the window starts at byte 2 n0 of it) */   \
             const float h0_ = (float)p0_[0], h1_ = (float)p0_[1], h2_ = (float)p1_[0], h3_ = (float)p1_[1];        \
@@ -724,7 +729,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
                 const auto g0_ = __builtin_amdgcn_permlane32_swap(c8h_[0][0], c8h_[1][0], false, false);            \
                 const auto g1_ = __builtin_amdgcn_permlane32_swap(c8h_[0][1], c8h_[1][1], false, false);            \
                 const int jn0_ = (&rsY == &pY) ? pn0 : n0;                                                          \
-                const unsigned v16_ = voY[(qb) * 2 + jj] + fo16m;                                                   \
+                const unsigned v16_ = V6_VOY((qb) * 2 + jj) + fo16m;                                                   \
                 __builtin_amdgcn_raw_buffer_store_b128((u32x4){l0_[0], l1_[0], l0_[1], l1_[1]}, rsY, v16_, 2 * N - jn0_ + (qa) * HN, 0); \
                 __builtin_amdgcn_raw_buffer_store_b128((u32x4){g0_[0], g1_[0], g0_[1], g1_[1]}, rsY, v16_, 3 * N - jn0_ + (qa) * HN, 0); \
             }                                                                                                       \
@@ -761,7 +766,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
                 const u32x4 blk_ = {(g0_ & 0xffffu) | (g1_ << 16), (g2_ & 0xffffu) | (g3_ << 16),                    \
                                     (g0_ >> 16) | (g1_ & 0xffff0000u), (g2_ >> 16) | (g3_ & 0xffff0000u)};          \
                 const int jn0_ = (&rsY == &pY) ? pn0 : n0, jm0_ = (&rsY == &pY) ? pm0 : m0;                         \
-                __builtin_amdgcn_raw_buffer_store_b128(blk_, rsY, voY[(qb) * 2 + jj] + fo16m, 2 * N - jn0_ + (qa) * HN, 0); \
+                __builtin_amdgcn_raw_buffer_store_b128(blk_, rsY, V6_VOY((qb) * 2 + jj) + fo16m, 2 * N - jn0_ + (qa) * HN, 0); \
                 const int el_ = fq == 0 ? c4e_[0][0] : (fq == 1 ? c4e_[0][1] : (fq == 2 ? c4e_[1][0] : c4e_[1][1])); \
                 __builtin_amdgcn_raw_buffer_store_b8((unsigned char)c4_scale_byte(el_, 0), sYr, sc_wr_y + ((qb) * 2 + jj) * 2, \
                                                      (((jm0_ >> 8) * (N >> 7) + (jn0_ >> 7) + (qa)) << 11), 0);   \
@@ -958,6 +963,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
 #undef V6_STG_WR
 #undef V6_STG_RD
 #undef V6_STG_OFF
+#undef V6_VOY
 #undef V6_MSECTION_BEGIN
 #undef V6_MSECTION_END
 #undef V6_TILE

@@ -205,7 +205,7 @@ def test_student_gradient_cosines_over_seeds_vs_cpu_oracle():
             f.write(f"{n}: mean {np.mean(cos[n]):.5f} min {np.min(cos[n]):.5f}  " + " ".join(f"{c:.5f}" for c in cos[n]) + "\n")
     for n in names:
         enc = "encoder" in n
-        assert np.mean(cos[n]) >= (0.994 if enc else 0.999) and np.min(cos[n]) >= (0.988 if enc else 0.998), (n, cos[n])
+        assert np.mean(cos[n]) >= (0.996 if enc else 0.999) and np.min(cos[n]) >= (0.993 if enc else 0.9985), (n, cos[n])          # measured: encoder mean >= 0.9974, min >= 0.9963 (profiles/r05_student_cosines_over_seeds.txt)
 
 
 def test_ten_step_trajectory_vs_cpu_oracle():

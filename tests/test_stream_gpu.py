@@ -98,21 +98,28 @@ def test_residual_linear_ln_vs_fp32_torch(M, K, y_f32):
     assert float((got["x"] - ref["x"]).abs().max()) <= 1e-5 * float(ref["x"].abs().max())      # the stream gradient stays fp32-exact
 
 
-def test_fanout_bf16_sums_gradients_in_fp32():
-    from cosa_amd import nn_ops
-    dev = torch.device("cuda", 0)
-    x = torch.randn(257, 768, device=dev, requires_grad=True)
-    a, b, c = nn_ops.fanout_bf16(x, 3)
-    assert a.dtype == torch.bfloat16 and torch.equal(a, x.detach().to(torch.bfloat16)) and a.data_ptr() == b.data_ptr() == c.data_ptr()
-    ga, gb, gc = (torch.randn(257, 768, device=dev).to(torch.bfloat16) for _ in range(3))
-    torch.autograd.backward([a, b, c], [ga, gb, gc])
-    assert x.grad.dtype == torch.float32 and torch.equal(x.grad, (ga.float() + gb.float()) + gc.float())
+class _FanoutRef(torch.autograd.Function):
+    """what nn_ops.patch_fanout_bf16 replaced (round 4's nn_ops.FanoutBf16Fn, kept here as the reference): fp32 x -> n views of one bf16 cast;
+    backward: the consumers' bf16 gradients added up in fp32, in consumer order"""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        x16 = x.to(torch.bfloat16)
+        return tuple(x16.view_as(x16) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        acc = None
+        for g in gs:
+            if g is not None:
+                acc = g.float() if acc is None else acc.add_(g)
+        return acc, None
 
 
 @pytest.mark.parametrize("live", [(0, 1, 2), (0, 2), (1,)])
 def test_patch_fanout_equals_the_sliced_fanout(live):
     """nn_ops.patch_fanout_bf16 (one bf16 copy of the patch tokens, the consumers' gradients summed by cosa_token_junction_bwd) against what it
-    replaced: fanout_bf16 of the whole token tensor + a [:, 1:] slice per consumer -- same forward bits, same gradient bits (fp32 adds in
+    replaced: a fan-out of the whole token tensor (_FanoutRef above) + a [:, 1:] slice per consumer -- same forward bits, same gradient bits (fp32 adds in
     consumer order, zero class-token row), also when some consumers take no part in the backward pass (ragged N)"""
     from cosa_amd import nn_ops
     dev = torch.device("cuda", 0)
@@ -120,7 +127,7 @@ def test_patch_fanout_equals_the_sliced_fanout(live):
     x = torch.randn(B, N, 768, device=dev, requires_grad=True)
     x2 = x.detach().clone().requires_grad_(True)
     outs = nn_ops.patch_fanout_bf16(x, 3)
-    refs = [t[:, 1:] for t in nn_ops.fanout_bf16(x2, 3)]
+    refs = [t[:, 1:] for t in _FanoutRef.apply(x2, 3)]
     assert all(o.shape == (B, N - 1, 768) and o.is_contiguous() and torch.equal(o, r) for o, r in zip(outs, refs))
     assert outs[0].data_ptr() == outs[1].data_ptr() == outs[2].data_ptr()
     gs = [torch.randn(B, N - 1, 768, device=dev).to(torch.bfloat16) for _ in range(3)]

@@ -16,6 +16,7 @@ for L in (old,):
     L.cosa_gemm_f16c4.argtypes = [P, P, P, P, P, P, P, P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, P]
     L.cosa_gemm_f16c8.argtypes = [P, P, P, P, P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, P]
     L.cosa_gemm_bf16_dual_gelu.argtypes = [P, P, P, P, P, ctypes.c_int, ctypes.c_int, ctypes.c_int, P]
+    L.cosa_gemm_bf16x3.argtypes = [P, P, P, P, P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, P]
 dev = torch.device("cuda", 0)
 ptr = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
@@ -104,3 +105,18 @@ yo, yn = torch.zeros(M, 768, device=dev), torch.zeros(M, 768, device=dev)
 report("fp16c8 proj res", M, 768, 768,
        lambda: old.cosa_gemm_f16c8(ptr(xs), ptr(ws), ptr(z), ptr(r), ptr(yo), M, 768, 768, 2, 768, st()),
        lambda: new.cosa_gemm_f16c8(ptr(xs), ptr(ws), ptr(z), ptr(r), ptr(yn), M, 768, 768, 2, 768, st()), [yo], [yn])
+
+# bf16x3 (the first two blocks of the default teacher since round 5): qkv (split rows out), fc1 + GELU (split rows out), fc2 + fp32 residual
+zb = torch.zeros(8192, device=dev, dtype=torch.bfloat16)
+for name, N, K, epi in (("qkv", 2304, 768, 0), ("fc1", 3072, 768, 1), ("fc2", 768, 3072, 2)):
+    x = torch.randn(M, K, device=dev); w = torch.randn(N, K, device=dev) * 0.03; b = torch.randn(N, device=dev)
+    xs, ws = nn_ops.split_rows(x, ones=True), nn_ops.split_rows(w, bias=b)
+    if epi == 2:
+        r, ldy = torch.randn(M, N, device=dev), N
+        yo, yn = torch.zeros(M, N, device=dev), torch.zeros(M, N, device=dev)
+    else:
+        r, ldy = None, 2 * N + (64 if epi == 1 else 0)
+        yo, yn = (torch.zeros((M, ldy), device=dev, dtype=torch.bfloat16) for _ in range(2))
+    report(f"bf16x3 {name}", M, N, K,
+           lambda: old.cosa_gemm_bf16x3(ptr(xs), ptr(ws), ptr(zb), ptr(r), ptr(yo), M, N, K, epi, ldy, st()),
+           lambda: new.cosa_gemm_bf16x3(ptr(xs), ptr(ws), ptr(zb), ptr(r), ptr(yn), M, N, K, epi, ldy, st()), [yo], [yn])

@@ -1,4 +1,5 @@
-"""which Python lines of the training step's FORWARD launch torch's copy / cat / cast kernels on large tensors (TorchDispatchMode + traceback)"""
+"""which Python lines of a whole training step (teacher pass, student forward, backward, optimizer) launch torch's (ATen) kernels, with the bytes
+they touch (TorchDispatchMode + traceback; autograd's engine-side adds show up as "?")"""
 import os, sys, collections, traceback
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
@@ -11,22 +12,28 @@ wimg, simg, lab, box = synthetic_batch(16, 448, 20, dev, seed=1234)
 n_iter = args.warmup_iters + 1
 for _ in range(2):
     tr.step(wimg, simg, lab, box, n_iter)
-agg = collections.Counter()
+agg, byt = collections.Counter(), collections.Counter()
 
 
 class Spy(TorchDispatchMode):
     def __torch_dispatch__(self, func, types, args=(), kwargs=None):
         out = func(*args, **(kwargs or {}))
         name = str(func)
-        big = [a for a in list(args) + ([out] if isinstance(out, torch.Tensor) else []) if isinstance(a, torch.Tensor) and a.numel() >= 1 << 20]
-        if big and any(k in name for k in ("copy", "cat", "clone", "_to_copy", "add", "mul", "fill", "zero", "where", "amax", "eq", "div", "contiguous")):
+        ts = [a for a in list(args) + ([out] if isinstance(out, torch.Tensor) else []) if isinstance(a, torch.Tensor) and a.is_cuda]
+        view = any(k in name for k in ("view", "reshape", "permute", "transpose", "slice", "select", "expand", "detach", "alias", "unsqueeze", "squeeze", "as_strided", "t.default", "unbind", "split", "_unsafe_view", "empty", "stride", "size", "is_", "_local_scalar", "lift"))
+        if ts and not view:
+            nbytes = sum(a.numel() * a.element_size() for a in ts)
             fr = [f for f in traceback.extract_stack() if "cosa_amd" in f.filename and "who_copies" not in f.filename]
             where = f"{os.path.basename(fr[-1].filename)}:{fr[-1].lineno}" if fr else "?"
-            agg[(name, tuple(big[0].shape), str(big[0].dtype), where)] += 1
+            key = (name, tuple(ts[0].shape), str(ts[0].dtype).replace("torch.", ""), where)
+            agg[key] += 1
+            byt[key] += nbytes
         return out
 
 
 with Spy():
-    loss, logs = tr.forward_losses(wimg, simg, lab, box, n_iter)
-for k, n in sorted(agg.items(), key=lambda kv: -kv[1]):
-    print(n, k)
+    tr.step(wimg, simg, lab, box, n_iter)
+tot = sum(byt.values())
+print(f"# {sum(agg.values())} ATen calls, {tot / 1e6:.0f} MB touched (at 5 TB/s: {tot / 5e12 * 1e3:.2f} ms)")
+for k, n in sorted(agg.items(), key=lambda kv: -byt[kv[0]])[:70]:
+    print(f"{byt[k] / 1e6:9.1f} MB  x{n:<3d} {k}")
