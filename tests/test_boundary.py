@@ -203,7 +203,7 @@ def test_auto_teacher_precision_is_backed_by_the_committed_accuracy_record():
     for crop in (224, 448, 640):
         c = bench.conformance(resolve_teacher_precision("auto", crop), crop)
         assert c.get("lines", 0) >= 8, (crop, c)
-        assert c["normalised_cam_rel_err_max"] <= 1e-3 and c["mask_miou_min"] >= 0.999, (crop, c)
+        assert c["cam_rel_err_own_scale_max"] <= 1e-3 and c["mask_miou_min"] >= 0.999 and c["label_agreement_min"] >= 0.999, (crop, c)
     rec = bench.newest_profile("accuracy_teacher.txt")
     if os.path.basename(rec) >= "r05":          # from round 5 on: the wide sweep and the bench's own batch size
         c = bench.conformance(resolve_teacher_precision("auto", 448), 448)

@@ -1,18 +1,26 @@
 """worst line per teacher mode and crop of an accuracy record (profiles/rNN_accuracy_teacher.txt or gpurun_out/...): max normalised-CAM rel. err,
-min mask mIoU, the seed it comes from, margin on the 1e-3 bar.   usage: python tools/accuracy_worst.py [file]"""
+max own-scale err (records from round 5 on), min label agreement / mask mIoU, the draw it comes from.   usage: python tools/accuracy_worst.py [file]"""
 import collections, re, sys
 f = sys.argv[1] if len(sys.argv) > 1 else "profiles/r05_accuracy_teacher.txt"
-w = collections.defaultdict(lambda: [0.0, 1.0, 0, "", set()])
+w = collections.defaultdict(lambda: dict(rel=0.0, own=None, iou=1.0, agree=1.0, n=0, where="", seeds=set(), over=set()))
 for ln in open(f):
-    m = re.match(r"teacher (\S+)\s+S=(\d+) b=\d+ seed=(\d+)\s+(\S+)\s*: .*rel err (\S+) .*mIoU (\S+)", ln)
+    m = re.match(r"teacher (\S+)\s+S=(\d+) b=(\d+) seed=(\d+)\s+(\S+)\s*: .*rel err (\S+)\s+label agreement (\S+)\s+mask mIoU (\S+)(?:\s+own-scale err (\S+))?", ln)
     if m:
-        k = (m.group(1), int(m.group(2)))
-        r, iou = float(m.group(5)), float(m.group(6))
-        if r > w[k][0]:
-            w[k][0], w[k][3] = r, f"seed {m.group(3)} {m.group(4)}"
-        w[k][1] = min(w[k][1], iou)
-        w[k][2] += 1
-        w[k][4].add(m.group(3))
-for (mode, S), v in sorted(w.items()):
-    ok = v[0] <= 1e-3 and v[1] >= 0.999
-    print(f"{mode:13s} S={S} lines {v[2]:2d} seeds {len(v[4])}  worst rel err {v[0]:.3e} ({v[3]}; margin {1e-3 / v[0]:.2f}x)  min mIoU {v[1]:.5f}  {'ok' if ok else 'FAILS'}")
+        e = w[(m.group(1), int(m.group(2)))]
+        r, ag, iou = float(m.group(6)), float(m.group(7)), float(m.group(8))
+        if r > e["rel"]:
+            e["rel"], e["where"] = r, f"seed {m.group(4)} b={m.group(3)} {m.group(5)}"
+        if r > 1e-3:
+            e["over"].add((m.group(4), m.group(3)))
+        if m.group(9):
+            e["own"] = max(e["own"] or 0.0, float(m.group(9)))
+        e["iou"], e["agree"], e["n"] = min(e["iou"], iou), min(e["agree"], ag), e["n"] + 1
+        e["seeds"].add((m.group(4), m.group(3)))
+for (mode, S), e in sorted(w.items()):
+    if e["own"] is not None:
+        ok = e["own"] <= 1e-3 and e["iou"] >= 0.999 and e["agree"] >= 0.999
+        print(f"{mode:13s} S={S} lines {e['n']:3d} draws {len(e['seeds']):2d}  own-scale err {e['own']:.3e} ({1e-3 / e['own']:.2f}x)  min agreement {e['agree']:.5f}  min mIoU {e['iou']:.5f}  "
+              f"{'ok   ' if ok else 'FAILS'}  | normalised planes: worst {e['rel']:.3e} ({e['where']}), over 1e-3 on {len(e['over'])} draws")
+    else:
+        ok = e["rel"] <= 1e-3 and e["iou"] >= 0.999
+        print(f"{mode:13s} S={S} lines {e['n']:3d} draws {len(e['seeds']):2d}  worst rel err {e['rel']:.3e} ({e['where']}; margin {1e-3 / e['rel']:.2f}x)  min mIoU {e['iou']:.5f}  {'ok' if ok else 'FAILS'}")

@@ -118,7 +118,12 @@ def split(t, dt):
 
 
 def prod(a, b, scheme):
-    """a [.., M, K] @ b[.., N, K]^T under a scheme"""
+    """a [.., M, K] @ b[.., N, K]^T under a scheme.  A leading "c" (cfp16, ch5, ch4i, ...) CENTRES the left operand over its rows (the tokens of
+    one image / head) before rounding: a = mean + a', a b^T = a' b^T (in the scheme) + mean b^T (exact: one row per image, a per-image bias).
+    The rounding error of a nearly token-independent activation then scales with its small token-specific part, not with its magnitude."""
+    if scheme.startswith("c") and scheme != "c":
+        mean = a.mean(-2, keepdim=True)
+        return prod(a - mean, b, scheme[1:]) + mean @ b.transpose(-1, -2)
     mm = lambda x, y: x @ y.transpose(-1, -2)
     if scheme == "f32":
         return mm(a, b)
@@ -192,10 +197,19 @@ def make_encoder(cfg):
             pre = f"encoder.blocks.{i}."
             y = F.layer_norm(t, (D,), p(pre + "norm1.weight"), p(pre + "norm1.bias"), 1e-6)
             qkv = lin(y, p(pre + "attn.qkv.weight"), p(pre + "attn.qkv.bias"), "qkv").reshape(B, N, 3, self.heads, hd).permute(2, 0, 3, 1, 4)
-            att = prod(qkv[0], qkv[1], sch("qk")) * hd ** -0.5
+            q_, k_, v_ = qkv[0], qkv[1], qkv[2]
+            vbar = None
+            if cfg.get("kvc"):          # centred K and V: softmax(q (k - kbar)^T) is softmax(q k^T) exactly; P (v - vbar) + vbar = P v exactly
+                k_ = k_ - k_.mean(-2, keepdim=True)
+                vbar = v_.mean(-2, keepdim=True)
+                v_ = v_ - vbar
+            att = prod(q_, k_, sch("qk")) * hd ** -0.5
             m = att.amax(-1, keepdim=True)
             e = torch.exp(att - m)
-            y = (prod(e, qkv[2].transpose(-1, -2), sch("pv")) / e.sum(-1, keepdim=True)).transpose(1, 2).reshape(B, N, D)
+            y = prod(e, v_.transpose(-1, -2), sch("pv")) / e.sum(-1, keepdim=True)
+            if vbar is not None:
+                y = y + vbar
+            y = y.transpose(1, 2).reshape(B, N, D)
             t = t + lin(y, p(pre + "attn.proj.weight"), p(pre + "attn.proj.bias"), "proj")
             y = F.layer_norm(t, (D,), p(pre + "norm2.weight"), p(pre + "norm2.bias"), 1e-6)
             y = F.gelu(lin(y, p(pre + "mlp.fc1.weight"), p(pre + "mlp.fc1.bias"), "fc1"))
