@@ -588,7 +588,7 @@ def main():
             return {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
                     "frac": round(ach * 1e12 / PEAK_BF16, 4), "issued_mfma_frac": round(issued / secs / PEAK_BF16, 4),
                     "note": "achieved / frac: ALGORITHMIC FLOPs (2 M N K per launch) over the launches' device time; issued_mfma_frac: the bf16-"
-                            "equivalent MFMA work the launches issue (fp16c4: 19 K-tiles per 12, fp16c8: 25 per 12) over the same time",
+                            "equivalent MFMA work the launches issue (fp16c4: 19 K-tiles per 12, fp16c8: 25 per 12, bf16x3: 37 per 12) over the same time",
                     "traffic": traffic, "launches": n_launch,
                     "avg_launch_ms": round(secs * 1e3 / n_launch, 4), "share_of_step": round(secs / (dt / opt.steps), 4),
                     "timer": "device s_memrealtime spans, last timed step" + ("" if opt.teacher_sync else
@@ -597,7 +597,7 @@ def main():
         c4mode = opt.teacher_precision.startswith("fp16c4")
         fams = [family(nn_ops.gemm_stamps, "gemm_bf16_v6_kernel (persistent 256x256 MFMA GEMM: qkv / proj+residual / fc1+GELU / fc2+residual; teacher "
                        "launches on " + ("fp16c4" if c4mode else opt.teacher_precision.split("-")[0]) + " operands, student launches on bf16)",
-                       "gemm_c4_pmc.json" if c4mode else "gemm_v6_pmc.json", "gemm_bf16"),
+                       "gemm_c4_pmc.json" if c4mode else ("gemm_c8_pmc.json" if opt.teacher_precision.startswith("fp16c8") else "gemm_v6_pmc.json"), "gemm_bf16"),
                 family(nn_ops.stamps, "attn_fwd2_kernel (fused attention forward)", "attn_fwd_pmc.json", "attn_fwd")]
         fams = sorted([f for f in fams if f], key=lambda f: -f["share_of_step"])
         roof = fams[0] if fams else None
