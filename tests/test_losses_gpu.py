@@ -100,7 +100,7 @@ def _cos(a, b):
 STUDENT_BARS = {"fp32": dict(enc=0.995, enc224=0.992, qk=0.99, dec=0.999, loss=1e-3), "bf16": dict(enc=0.98, enc224=0.98, qk=0.97, dec=0.99, loss=3e-3)}
 
 
-@pytest.mark.parametrize("S,stream", [(224, "fp32"), (448, "fp32"), (224, "bf16")])
+@pytest.mark.parametrize("S,stream", [(448, "fp32"), (224, "bf16")])          # (224 / fp32: five seeds of it in test_student_gradient_cosines_over_seeds_vs_cpu_oracle)
 def test_bf16_student_step_vs_cpu_oracle_vitb(S, stream):
     """The student's forward / backward through this repository's own kernels (bf16-operand GEMMs with fused epilogues -- the projections
     that close a residual branch add into the FP32 stream in their epilogue --, fused attention forward / backward, LayerNorm forward /

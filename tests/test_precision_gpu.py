@@ -467,8 +467,9 @@ TEACHER_BARS = {
 # plain-fp16 attention in the last blocks pass seeds 3 / 11 / 29 with a 2x margin and fail seed 17); bench.py reports the WORST of these lines
 # (profiles/r04_accuracy_teacher.txt, copied from gpurun_out/ after the GPU run) and derives `tolerance_met` from them
 CONFORMING_SEEDS = (3, 11, 29, 5, 17, 23, 41)
-_MULTI = {448: ("fp16c8-x2", "fp16c4-12m9", "fp16c4", "fp16c8", "fp16c8-9", "fp16c4-8"), 224: ("fp16c8-x2", "fp16c4-12m9", "fp16c8")}
-_CASES = [(m, 3, S) for m in TEACHER_BARS for S in (224, 448)] + [(m, sd_, S) for S, ms in _MULTI.items() for m in ms for sd_ in CONFORMING_SEEDS[1:]]
+_MULTI = {448: ("fp16c8-x2", "fp16c4-12m9", "fp16c8"), 224: ("fp16c8-x2", "fp16c4-12m9", "fp16c8")}      # (round 4 also ran fp16c4 / fp16c8-9 / fp16c4-8 on all seven: profiles/r04_accuracy_teacher.txt)
+_HISTORIC = ("fp16c4-10", "fp16c4-9", "fp16c4-12m8", "fp16c4-10q")          # round 4's margin table: on record in profiles/r04_accuracy_teacher.txt, not re-run
+_CASES = [(m, 3, S) for m in TEACHER_BARS if m not in _HISTORIC for S in (224, 448)] + [(m, sd_, S) for S, ms in _MULTI.items() for m in ms for sd_ in CONFORMING_SEEDS[1:]]
 
 
 @pytest.mark.parametrize("mode,seed,S", sorted(_CASES, key=lambda c: (c[2], c[1])))       # (grouped by oracle pass)
@@ -481,7 +482,7 @@ def test_fused_teacher_vs_fp32_cpu_oracle(mode, seed, S):
 MODES_640 = (("fp16c4-8", False), ("fp16c8-9", False), ("fp16c4-12m9", False), ("fp16c8", True), ("fp16c8-x2", True))
 
 
-@pytest.mark.parametrize("seed", (3, 11, 29, 17))
+@pytest.mark.parametrize("seed", (11, 17))          # (the committed record also holds seeds 3 and 29: round 5's evidence run)
 def test_fused_teacher_vs_fp32_cpu_oracle_640(seed):
     """the crop of BASELINE configs[4] (COCO, 640^2: 1601 / 401 / 3601 tokens per image and scale), so that a bench line at --crop 640 has its
     accuracy evidence too"""
@@ -538,7 +539,7 @@ def _check_teacher(mode, seed, S, bars=None, b=2):
 # (profiles/r05_accuracy_teacher.txt).  Seeds 100-139 are disjoint from CONFORMING_SEEDS, on which round 4's block maps were chosen -- they are
 # what showed that fp16c4-12m9 and uniform fp16c8 do not hold, and the set the round-5 default (fp16c8-x2) was picked on; seeds 200-231
 # (COSA_ACCURACY_SWEEP_BASE=200) were drawn after that choice: held-out evidence for it.
-SWEEP_DEFAULT = 3
+SWEEP_DEFAULT = 2
 SWEEP_SEEDS = int(os.environ.get("COSA_ACCURACY_SWEEP_SEEDS", str(SWEEP_DEFAULT)))
 SWEEP_BASE = int(os.environ.get("COSA_ACCURACY_SWEEP_BASE", "100"))        # 100-139: the draws the round-5 map was chosen on; 200-231: drawn after the choice
 SWEEP_MODES = tuple(os.environ.get("COSA_ACCURACY_SWEEP_MODES", "fp16c8-x2,fp16c8").split(","))
