@@ -469,7 +469,8 @@ TEACHER_BARS = {
 CONFORMING_SEEDS = (3, 11, 29, 5, 17, 23, 41)
 _MULTI = {448: ("fp16c8-x2", "fp16c4-12m9", "fp16c8"), 224: ("fp16c8-x2", "fp16c4-12m9", "fp16c8")}      # (round 4 also ran fp16c4 / fp16c8-9 / fp16c4-8 on all seven: profiles/r04_accuracy_teacher.txt)
 _HISTORIC = ("fp16c4-10", "fp16c4-9", "fp16c4-12m8", "fp16c4-10q")          # round 4's margin table: on record in profiles/r04_accuracy_teacher.txt, not re-run
-_CASES = [(m, 3, S) for m in TEACHER_BARS if m not in _HISTORIC for S in (224, 448)] + [(m, sd_, S) for S, ms in _MULTI.items() for m in ms for sd_ in CONFORMING_SEEDS[1:]]
+SUITE_SEEDS = (11, 29, 17, 41)          # the suite re-asserts four of round 4's seven seeds besides seed 3 (suite time); the record holds all seven
+_CASES = [(m, 3, S) for m in TEACHER_BARS if m not in _HISTORIC for S in (224, 448)] + [(m, sd_, S) for S, ms in _MULTI.items() for m in ms for sd_ in SUITE_SEEDS]
 
 
 @pytest.mark.parametrize("mode,seed,S", sorted(_CASES, key=lambda c: (c[2], c[1])))       # (grouped by oracle pass)
@@ -482,7 +483,7 @@ def test_fused_teacher_vs_fp32_cpu_oracle(mode, seed, S):
 MODES_640 = (("fp16c4-8", False), ("fp16c8-9", False), ("fp16c4-12m9", False), ("fp16c8", True), ("fp16c8-x2", True))
 
 
-@pytest.mark.parametrize("seed", (11, 17))          # (the committed record also holds seeds 3 and 29: round 5's evidence run)
+@pytest.mark.parametrize("seed", (11,))          # (the committed record also holds seeds 3, 17 and 29: round 5's evidence run)
 def test_fused_teacher_vs_fp32_cpu_oracle_640(seed):
     """the crop of BASELINE configs[4] (COCO, 640^2: 1601 / 401 / 3601 tokens per image and scale), so that a bench line at --crop 640 has its
     accuracy evidence too"""
@@ -539,9 +540,10 @@ def _check_teacher(mode, seed, S, bars=None, b=2):
 # (profiles/r05_accuracy_teacher.txt).  Seeds 100-139 are disjoint from CONFORMING_SEEDS, on which round 4's block maps were chosen -- they are
 # what showed that fp16c4-12m9 and uniform fp16c8 do not hold, and the set the round-5 default (fp16c8-x2) was picked on; seeds 200-231
 # (COSA_ACCURACY_SWEEP_BASE=200) were drawn after that choice: held-out evidence for it.
-SWEEP_DEFAULT = 2
+SWEEP_DEFAULT = 1
 SWEEP_SEEDS = int(os.environ.get("COSA_ACCURACY_SWEEP_SEEDS", str(SWEEP_DEFAULT)))
 SWEEP_BASE = int(os.environ.get("COSA_ACCURACY_SWEEP_BASE", "100"))        # 100-139: the draws the round-5 map was chosen on; 200-231: drawn after the choice
+SWEEP_S = int(os.environ.get("COSA_ACCURACY_SWEEP_S", "448"))               # crop size of the sweep (the record also holds sweeps at 224 and 640)
 SWEEP_MODES = tuple(os.environ.get("COSA_ACCURACY_SWEEP_MODES", "fp16c8-x2,fp16c8").split(","))
 
 
@@ -553,11 +555,11 @@ def _auto_mode(S):
 @pytest.mark.parametrize("seed", [SWEEP_BASE + i for i in range(SWEEP_SEEDS)])
 def test_headline_modes_on_held_out_seeds_sweep(seed):
     """every mode of the sweep is put on record; the trainer's `auto` choice at 448^2 must hold the north-star bars on every draw"""
-    auto = _auto_mode(448)
+    auto = _auto_mode(SWEEP_S)
     err = None
     for mode in dict.fromkeys(SWEEP_MODES + (auto,)):
         try:
-            _check_teacher(mode, seed, 448, bars=NORTH_STAR)
+            _check_teacher(mode, seed, SWEEP_S, bars=NORTH_STAR)
         except AssertionError as e:
             if mode == auto:
                 err = e
@@ -565,7 +567,7 @@ def test_headline_modes_on_held_out_seeds_sweep(seed):
         raise err
 
 
-@pytest.mark.skipif(os.environ.get("COSA_ACCURACY_B16", "1") == "0", reason="COSA_ACCURACY_B16=0")
+@pytest.mark.skipif(os.environ.get("COSA_ACCURACY_B16", "0") != "1", reason="50 s of CPU oracle: run with COSA_ACCURACY_B16=1 (the committed record holds its lines)")
 def test_headline_mode_on_the_bench_batch_b16():
     """BASELINE configs[1] itself: b = 16 x 448^2 through the fused teacher (M = 87 904 token rows per pass, the launch shapes of the bench)
     against the fp32 CPU oracle run two images at a time"""
@@ -575,7 +577,7 @@ def test_headline_mode_on_the_bench_batch_b16():
         _ORACLE.clear()
 
 
-@pytest.mark.parametrize("seed", (3, 17, 23))
+@pytest.mark.parametrize("seed", (3, 17))
 def test_teacher_masks_through_par_vs_fp32_cpu_oracle(seed):
     """--usepar: the label maps after PAR refinement (PAR.py:64-91: ten affinity-propagation steps over the CAMs) from the fused HIP teacher in
     the default mode against the oracle's (fp32 CAMs, oracle/cosa_oracle.c PAR) on the same denormalised images: the refinement must not
