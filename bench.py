@@ -359,6 +359,10 @@ def vit_forward_roofline(trainer, wimg, dev, crop):
         pa, pm = trainer.model_AN.encoder._plain_from()
         frac8 = (pa + 2 * pm) / 36.0              # (an MLP half is two thirds of a block's projection work)
         mult = frac8 * mult + (1.0 - frac8)
+    enc_ = trainer.model_AN.encoder
+    if enc_.precision == "fp16c8" and enc_.c4_from is not None:          # mixed maps: the late blocks' qkv / fc1 / fc2 on fp16c4 operands
+        fc = max(0, len(enc_.blocks) - enc_.c4_from) / len(enc_.blocks)
+        mult = (1.0 - fc) * mult + fc * (0.854 * 693 / 432 + 0.146)
     xa, xm = trainer.model_AN.encoder._x3_until() if trainer.model_AN.encoder.precision in ("fp16c8", "fp16c4") else (0, 0)
     if xa or xm:                                  # mixed maps: the early blocks' halves on bf16x3 operands (3 MFMA terms)
         fx = (xa + 2 * xm) / 36.0
@@ -387,13 +391,15 @@ def mode_text(mode):
     base, _, tail = mode.partition("-")
     t = _BASE_TEXT[base]
     m = re.fullmatch(r"(\d+)(?:m(\d+))?(q?)", tail) if tail else None
-    mx = re.fullmatch(r"x(\d+)(?:m(\d+))?", tail) if tail else None
+    mx = re.fullmatch(r"(?:x(\d+)(?:m(\d+))?)?(?:c(\d+))?", tail) if tail and not m else None
     if m:
         a, k = int(m.group(1)), int(m.group(2)) if m.group(2) else int(m.group(1))
         t += f"; attention halves from block {a} on and MLP halves from block {k} on: plain fp16 operands" + ("; qkv projections plain fp16" if m.group(3) else "")
-    if mx:
+    if mx and mx.group(1):
         a, k = int(mx.group(1)), int(mx.group(2)) if mx.group(2) else int(mx.group(1))
         t += f"; attention halves of blocks 0-{a - 1} and MLP halves of blocks 0-{k - 1}: bf16x3 operands (hi + lo bf16 halves, 3 MFMA terms)"
+    if mx and mx.group(3):
+        t += f"; qkv / fc1 / fc2 of the blocks from {int(mx.group(3))} on: fp16c4 operands (FP4 MX-block correction terms)"
     return t
 
 
@@ -407,7 +413,7 @@ MODE_TEXT = _ModeText()
 
 def _mode_arg(v):
     import re
-    if v == "auto" or v in _BASE_TEXT or re.fullmatch(r"fp16c[48]-(\d+(m\d+)?q?|x\d+(m\d+)?)", v):
+    if v == "auto" or v in _BASE_TEXT or re.fullmatch(r"fp16c[48]-(\d+(m\d+)?q?|x\d+(m\d+)?(c\d+)?|c\d+)", v):
         return v
     raise argparse.ArgumentTypeError(f"unknown teacher precision {v!r}")
 

@@ -98,8 +98,9 @@ class VITNetwork(nn.Module):
         base, sep, tail = mode.partition("-")            # "fp16c8-9": fp16c8 with the blocks from index 9 on plain fp16 operands;
         m = re.fullmatch(r"(\d+)(?:m(\d+))?(q?)", tail) if tail else None    # "fp16c4-9m7": ... and the MLP halves already from block 7 on;
         #                                                                         trailing "q": the qkv projections of the corrected blocks on plain fp16 too
-        mx = re.fullmatch(r"x(\d+)(?:m(\d+))?", tail) if tail else None     # "fp16c8-x6": the blocks BELOW index 6 on bf16x3 operands (round 5);
-        #                                                                         "fp16c8-x6m4": their attention halves below 6, their MLP halves below 4
+        mx = re.fullmatch(r"(?:x(\d+)(?:m(\d+))?)?(?:c(\d+))?", tail) if tail and not m else None     # "fp16c8-x6": the blocks BELOW index 6 on bf16x3
+        #                       operands (round 5); "fp16c8-x6m4": their attention halves below 6, their MLP halves below 4; "fp16c8-x2c6" / "fp16c8-c6":
+        #                       the blocks from index 6 on take qkv / fc1 / fc2 on fp16c4 operands (fp16c8 base only)
         assert base in ("bf16", "fp16", "bf16x3", "fp16c8", "fp16c4") and (bool(tail) == bool(sep)) and \
             (not tail or (base in ("fp16c8", "fp16c4") and (m or mx))), mode
         self.set_compute_dtype(torch.float16 if base in ("fp16", "fp16c8", "fp16c4") else torch.bfloat16)
@@ -107,8 +108,10 @@ class VITNetwork(nn.Module):
         self.encoder.c8_plain_from = int(m.group(1)) if m else None
         self.encoder.c8_plain_mlp_from = int(m.group(2)) if m and m.group(2) else None
         self.encoder.c8_plain_qkv = bool(m and m.group(3))
-        self.encoder.x3_until = int(mx.group(1)) if mx else None
+        assert not mx or not mx.group(3) or base == "fp16c8", mode
+        self.encoder.x3_until = int(mx.group(1)) if mx and mx.group(1) else None
         self.encoder.x3_mlp_until = int(mx.group(2)) if mx and mx.group(2) else None
+        self.encoder.c4_from = int(mx.group(3)) if mx and mx.group(3) else None
         return self
 
     def get_param_groups(self):

@@ -101,6 +101,7 @@ class VisionTransformer(nn.Module):
         self.c8_plain_mlp_from = None  # ... their MLP halves (norm2, fc1, fc2) already from this block on (None: as c8_plain_from)
         self.x3_until = None           # fp16c8 / fp16c4: blocks with index < this run on bf16x3 operands ("fp16c8-x6"); x3_mlp_until: their MLP halves
         self.x3_mlp_until = None
+        self.c4_from = None            # fp16c8: blocks with index >= this take their qkv / fc1 / fc2 on fp16c4 operands ("fp16c8-x2c6": mixed maps, round 5)
         self.c8_plain_qkv = False      # ... the qkv projections of the corrected blocks on plain fp16 operands too (the output projection keeps its terms)
         # fp16c4: the output projection too on fp16c4 operands (the attention kernel then writes c4 rows)?  Measured (round 4, three seeds, 448^2):
         # the auxiliary CAM's worst error goes from 4.5e-4 to 5.1e-4 (margin on the 1e-3 bar 2.2x -> 1.95x) for 0.15 ms per step, so it is off:
@@ -379,6 +380,14 @@ class VisionTransformer(nn.Module):
         xm = self.x3_mlp_until if getattr(self, "x3_mlp_until", None) is not None else xa
         return xa, xm
 
+    def _is_c4(self, i):
+        """does block i take its qkv / fc1 / fc2 projections on fp16c4 operands?  (every block in the fp16c4 modes; blocks >= c4_from in the mixed
+        fp16c8 maps: the late blocks, whose rounding passes through the fewest layers)"""
+        return self.precision == "fp16c4" or (self.precision == "fp16c8" and self.c4_from is not None and i >= self.c4_from)
+
+    def _any_c4(self):
+        return any(self._is_c4(i) for i in range(len(self.blocks)))
+
     def _c8_weights(self):
         """c8 rows [N, 2K+64 fp16 units] (bias in the augmentation block) of the patch projection and the block projections, rebuilt from the
         fp32 masters on every pass (the teacher's masters move every step; part of the captured graph) by ONE batched launch"""
@@ -388,7 +397,7 @@ class VisionTransformer(nn.Module):
         pa, pm = self._plain_from()
         xa, xm = self._x3_until()
         for i, blk in enumerate(self.blocks):
-            if self.precision == "fp16c4":          # qkv / fc1 / fc2 (and proj with c4_proj) run on fp16c4 operands (_c4_weights)
+            if self._is_c4(i):                      # qkv / fc1 / fc2 (and proj with c4_proj) run on fp16c4 operands (_c4_weights)
                 if not self.c4_proj and xa <= i < pa:
                     items += [(f"{i}.proj", blk.attn.proj.weight, blk.attn.proj.bias)]
                 continue
@@ -425,6 +434,8 @@ class VisionTransformer(nn.Module):
         pa, pm = self._plain_from()
         xa, xm = self._x3_until()
         for i, blk in enumerate(self.blocks):
+            if not self._is_c4(i):
+                continue
             if xa <= i < pa:
                 if not self.c8_plain_qkv:
                     items.append((f"{i}.qkv", blk.attn.qkv.weight, blk.attn.qkv.bias))
@@ -467,7 +478,7 @@ class VisionTransformer(nn.Module):
             mk = lambda cols: torch.zeros((M, cols), device=dev, dtype=torch.float16)
             ent = {"y": mk(nn_ops.split_ld(D)), "qkv": mk(3 * D), "o": mk(nn_ops.split_ld(D)), "h": mk(nn_ops.split_ld(Hd))}
             ent["h"][:, 2 * Hd:2 * Hd + 2] = 1
-            if self.precision == "fp16c4":          # the scale tensors of the c4 activation operands (LayerNorm, attention and GELU outputs)
+            if self._any_c4():                      # the scale tensors of the c4 activation operands (LayerNorm, attention and GELU outputs)
                 ent["y_sc"], ent["o_sc"], ent["h_sc"] = nn_ops.c4_scales(M, D, dev), nn_ops.c4_scales(M, D, dev), nn_ops.c4_scales(M, Hd, dev)
         bufs[key] = ent                             # (re-inserted last: the dict is the LRU order)
         if torch.cuda.is_current_stream_capturing():
@@ -482,8 +493,8 @@ class VisionTransformer(nn.Module):
         D, H = self.embed_dim, self.num_heads
         p = self.patch_size
         W = self._c8_weights()
-        c4 = self.precision == "fp16c4"
-        W4 = self._c4_weights() if c4 else None
+        any_c4 = self._any_c4()
+        W4 = self._c4_weights() if any_c4 else None
         nf = 2 if flip_pairs else 1                                                     # flip_pairs: every batch stands for cat(x, x.flip(-1))
         # token assembly without concatenations: the residual stream xr [sum_i B_i (n_i + 1), D] starts as (cls + pos_0 | pos rows) per image, the
         # im2col kernel writes the c8 rows of the patches (images and their mirror images) into a token-shaped operand whose class-token rows
@@ -512,7 +523,7 @@ class VisionTransformer(nn.Module):
                                                          _C.stream_ptr()), "cosa_im2col_flip_c8_tokens")
         nn_ops.gemm_c8(cols, W["patch"], M, D, Kp, nn_ops.EPI_RESIDUAL, residual=xr, out=xr)
         Hd = self.blocks[0].mlp.fc1.weight.shape[0]
-        if c4 and "y_sc" not in bf:                  # (the buffers were created under another precision setting)
+        if any_c4 and "y_sc" not in bf:              # (the buffers were created under another precision setting)
             bf["y_sc"], bf["o_sc"], bf["h_sc"] = nn_ops.c4_scales(M, D, dev), nn_ops.c4_scales(M, D, dev), nn_ops.c4_scales(M, Hd, dev)
         depth = len(self.blocks)
         aux_idx = self.aux_layer % depth
@@ -526,6 +537,7 @@ class VisionTransformer(nn.Module):
         b3 = self._x3_buffers(M, dev) if W3 is not None else None
         o16 = torch.empty((M, D), device=xr.device, dtype=torch.float16) if pa < depth else None
         for i, blk in enumerate(self.blocks):
+            c4 = self._is_c4(i)
             # ---- attention half ----
             xn = torch.empty_like(xr) if aux is xr else xr              # right after the auxiliary layer: keep its output, no clone
             if i < xa:

@@ -180,7 +180,12 @@ def test_teacher_precision_mode_strings():
     for mode, prec, x3 in (("fp16c8-x2", "fp16c8", (2, 2)), ("fp16c8-x6m4", "fp16c8", (6, 4)), ("fp16c4-x0m3", "fp16c4", (0, 3))):      # round 5: early blocks on bf16x3
         net.set_nograd_precision(mode)
         assert net.encoder.precision == prec and net.encoder._x3_until() == x3 and net.encoder._plain_from() == (12, 12), mode
-    for bad in ("fp16c4-", "fp16c4-m8", "bf16-3", "fp8", "fp16c4-9m", "fp16c8-x", "bf16x3-x2"):
+        assert net.encoder.c4_from is None and [net.encoder._is_c4(i) for i in (0, 11)] == [prec == "fp16c4"] * 2
+    for mode, x3, c4 in (("fp16c8-x2c6", (2, 2), 6), ("fp16c8-c8", (0, 0), 8)):      # ... and the late blocks' qkv / fc1 / fc2 on fp16c4 operands (mixed maps)
+        net.set_nograd_precision(mode)
+        assert net.encoder.precision == "fp16c8" and net.encoder._x3_until() == x3 and net.encoder.c4_from == c4
+        assert [net.encoder._is_c4(i) for i in range(12)] == [i >= c4 for i in range(12)]
+    for bad in ("fp16c4-", "fp16c4-m8", "bf16-3", "fp8", "fp16c4-9m", "fp16c8-x", "bf16x3-x2", "fp16c4-c6", "fp16c8-c", "fp16c8-9c6"):
         with pytest.raises(AssertionError):
             net.set_nograd_precision(bad)
 
