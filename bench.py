@@ -246,6 +246,7 @@ def par_refine_ms_per_img(trainer, simg, lab, box, dev, opt, C):
         logit = torch.randn(b, C + 1, S, S, generator=g).to(dev).requires_grad_(True)
 
         def f():
+            logit.grad = None                 # (as zero_grad(set_to_none=True) leaves it: the backward stores d logits, it does not add to an old one)
             loss = seg_helper.get_energy_loss(img, logit, mask, box, layer)
             loss.backward()
         for _ in range(3):                    # (allocator growth and the lattice workspace settle in the first calls)

@@ -519,6 +519,93 @@ __global__ __launch_bounds__(256) void softmax_half_bwd_kernel(const float *__re
     }
 }
 
+// K <= KMAX (VOC: 21): the quad's K x 4 logits stay in registers -- ONE pass over the logits, where the loops above read them three (forward) and
+// four times (backward); at b = 16, K = 21, 448^2 the logits are 270 MB, more than the Infinity Cache holds, so every further pass was an HBM
+// pass (round 5).  The same operations on the same values in the same class order: the results are bit-identical to the kernels above.
+template <int KMAX>
+__global__ __launch_bounds__(256) void softmax_half_fwd_reg_kernel(const float *__restrict__ logit, float *__restrict__ out, int K, int H, int W)
+{
+    const int Wq = W >> 1, Hq = H >> 1;
+    const int xq = blockIdx.x * 64 + (threadIdx.x & 63), yq = blockIdx.y * 4 + (threadIdx.x >> 6), b = blockIdx.z;
+    if (xq >= Wq || yq >= Hq) return;
+    const size_t plane = (size_t)H * W;
+    const float *base = logit + (size_t)b * K * plane + (size_t)(2 * yq) * W + 2 * xq;
+    float z[KMAX][4];
+#pragma unroll
+    for (int k = 0; k < KMAX; k++)
+        if (k < K) {
+            const float2 r0 = *reinterpret_cast<const float2 *>(base + k * plane), r1 = *reinterpret_cast<const float2 *>(base + k * plane + W);
+            z[k][0] = r0.x; z[k][1] = r0.y; z[k][2] = r1.x; z[k][3] = r1.y;
+        }
+    float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+    for (int k = 0; k < KMAX; k++)
+        if (k < K) { m[0] = fmaxf(m[0], z[k][0]); m[1] = fmaxf(m[1], z[k][1]); m[2] = fmaxf(m[2], z[k][2]); m[3] = fmaxf(m[3], z[k][3]); }
+    float sum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < KMAX; k++)
+        if (k < K) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) { z[k][j] = expf(z[k][j] - m[j]); sum[j] += z[k][j]; }
+        }
+    float *o = out + ((size_t)b * K * Hq + yq) * Wq + xq;
+#pragma unroll
+    for (int k = 0; k < KMAX; k++)
+        if (k < K) {
+            const float p00 = z[k][0] / sum[0], p01 = z[k][1] / sum[1], p10 = z[k][2] / sum[2], p11 = z[k][3] / sum[3];
+            o[(size_t)k * Hq * Wq] = 0.5f * (0.5f * p00 + 0.5f * p01) + 0.5f * (0.5f * p10 + 0.5f * p11);
+        }
+}
+
+template <int KMAX>
+__global__ __launch_bounds__(256) void softmax_half_bwd_reg_kernel(const float *__restrict__ logit, const float *__restrict__ g, float *__restrict__ dlogit,
+                                                                 int K, int H, int W)
+{
+    const int Wq = W >> 1, Hq = H >> 1;
+    const int xq = blockIdx.x * 64 + (threadIdx.x & 63), yq = blockIdx.y * 4 + (threadIdx.x >> 6), b = blockIdx.z;
+    if (xq >= Wq || yq >= Hq) return;
+    const size_t plane = (size_t)H * W, qplane = (size_t)Hq * Wq;
+    const size_t off = (size_t)b * K * plane + (size_t)(2 * yq) * W + 2 * xq;
+    const float *base = logit + off;
+    const float *gq = g + ((size_t)b * K * Hq + yq) * Wq + xq;
+    float z[KMAX][4], dp[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; k++)
+        if (k < K) {
+            const float2 r0 = *reinterpret_cast<const float2 *>(base + k * plane), r1 = *reinterpret_cast<const float2 *>(base + k * plane + W);
+            z[k][0] = r0.x; z[k][1] = r0.y; z[k][2] = r1.x; z[k][3] = r1.y;
+            dp[k] = 0.25f * gq[k * qplane];
+        }
+    float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+    for (int k = 0; k < KMAX; k++)
+        if (k < K) { m[0] = fmaxf(m[0], z[k][0]); m[1] = fmaxf(m[1], z[k][1]); m[2] = fmaxf(m[2], z[k][2]); m[3] = fmaxf(m[3], z[k][3]); }
+    float sum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < KMAX; k++)
+        if (k < K) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) { z[k][j] = expf(z[k][j] - m[j]); sum[j] += z[k][j]; }
+        }
+    float dot[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < KMAX; k++)
+        if (k < K) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) dot[j] += dp[k] * (z[k][j] / sum[j]);
+        }
+    float *d = dlogit + off;
+#pragma unroll
+    for (int k = 0; k < KMAX; k++)
+        if (k < K) {
+            float2 o0, o1;
+            o0.x = (dp[k] - dot[0]) * (z[k][0] / sum[0]); o0.y = (dp[k] - dot[1]) * (z[k][1] / sum[1]);
+            o1.x = (dp[k] - dot[2]) * (z[k][2] / sum[2]); o1.y = (dp[k] - dot[3]) * (z[k][3] / sum[3]);
+            *reinterpret_cast<float2 *>(d + k * plane) = o0;
+            *reinterpret_cast<float2 *>(d + k * plane + W) = o1;
+        }
+}
+
 }  // namespace
 }  // namespace cosa
 
@@ -637,7 +724,9 @@ extern "C" int cosa_softmax_halfres_forward(const float *logit, float *out, int 
 {
     COSA_REQUIRE(logit && out && B > 0 && K > 0 && H > 0 && W > 0 && B <= 65535, "cosa_softmax_halfres_forward: bad arguments");
     COSA_REQUIRE(H % 2 == 0 && W % 2 == 0, "cosa_softmax_halfres_forward: H and W must be even");
-    hipLaunchKernelGGL(softmax_half_fwd_kernel, dim3((W / 2 + 63) / 64, (H / 2 + 3) / 4, B), dim3(256), 0, as_stream(stream), logit, out, K, H, W);
+    const dim3 grid((W / 2 + 63) / 64, (H / 2 + 3) / 4, B);
+    if (K <= 24) hipLaunchKernelGGL(softmax_half_fwd_reg_kernel<24>, grid, dim3(256), 0, as_stream(stream), logit, out, K, H, W);
+    else hipLaunchKernelGGL(softmax_half_fwd_kernel, grid, dim3(256), 0, as_stream(stream), logit, out, K, H, W);
     COSA_LAUNCH_CHECK();
     return COSA_OK;
 }
@@ -646,8 +735,9 @@ extern "C" int cosa_softmax_halfres_backward(const float *logit, const float *gr
 {
     COSA_REQUIRE(logit && grad_out && grad_logit && B > 0 && K > 0 && H > 0 && W > 0 && B <= 65535, "cosa_softmax_halfres_backward: bad arguments");
     COSA_REQUIRE(H % 2 == 0 && W % 2 == 0, "cosa_softmax_halfres_backward: H and W must be even");
-    hipLaunchKernelGGL(softmax_half_bwd_kernel, dim3((W / 2 + 63) / 64, (H / 2 + 3) / 4, B), dim3(256), 0, as_stream(stream), logit, grad_out, grad_logit,
-                       K, H, W);
+    const dim3 grid((W / 2 + 63) / 64, (H / 2 + 3) / 4, B);
+    if (K <= 24) hipLaunchKernelGGL(softmax_half_bwd_reg_kernel<24>, grid, dim3(256), 0, as_stream(stream), logit, grad_out, grad_logit, K, H, W);
+    else hipLaunchKernelGGL(softmax_half_bwd_kernel, grid, dim3(256), 0, as_stream(stream), logit, grad_out, grad_logit, K, H, W);
     COSA_LAUNCH_CHECK();
     return COSA_OK;
 }

@@ -14,6 +14,11 @@
 //   * all K channels ride through the lattice together: values[M+1][KP] rows (channel fastest),
 //     so splat / blur / slice touch whole rows instead of re-streaming the lattice K times.
 //   * planar [K][H*W] <-> row [pixel][KP] transposes go through LDS tiles.
+//   * every kernel gathers rows of ONE image's tables in an order no cache line survives for long, and workgroup ids are dealt round-robin
+//     to the 8 XCDs (private 4-MB L2 each): with an image's workgroups on all XCDs every table is fetched into eight L2s.  image_wg()
+//     maps a 1-D grid to (image, workgroup of the image) so that an image lives on ONE XCD (batch >= 8; smaller batches split an image
+//     over 8 / N XCDs) -- the same work, the same bits, an eighth of the fabric traffic (round 5).
+//   * a hash-table entry is 16 bytes {packed key, dense id}: a probe that finds its key has the id in the same cache line.
 //   * splat without float atomics: the (pixel, vertex) pairs of an image are sorted by vertex once per lattice (stable LSD radix sort,
 //     radix_sort.hpp; the pairs are generated in pixel order, so a vertex's list is in ascending pixel order), and a
 //     half-wave per vertex adds its list up in that order -- the order of the reference's serial splat loop (permutohedral.cpp:507-530),
@@ -23,6 +28,7 @@
 #include <cmath>
 #include <cstring>
 #include <vector>
+#include <type_traits>
 #include "radix_sort.hpp"
 
 namespace cosa {
@@ -38,6 +44,8 @@ constexpr int PD = COSA_PD;
 constexpr int PD1 = COSA_PD + 1;
 constexpr unsigned long long kEmpty = 0xFFFFFFFFFFFFFFFFull;
 constexpr int TP = 64;  // pixels per LDS transpose tile
+constexpr int kAllXcds = 8;        // image_wg(): `parts` of a kernel whose images are shared by all XCDs
+constexpr int kWgPerImage = 1024;  // workgroups per image of the grid-stride kernels (they read M on the device; an image's XCD holds 256 at a time)
 
 struct LatticeParams {
     float scale[PD];   // diag of E: 1/sqrt((i+1)(i+2)) * sqrt(2/3)*(d+1)
@@ -47,11 +55,18 @@ struct LatticeParams {
     unsigned cap_mask;  // table capacity - 1 (power of two)
     int Mmax;           // rows reserved per image (excluding sink row 0)
     int KP;             // padded channel count
+    int nimg;           // images in the batch
+    int parts;          // XCDs that share one image (1 when the batch has >= 8 images): image_wg()
+};
+
+struct TableEntry {     // one slot of an image's open-addressing table (kEmpty key: free)
+    unsigned long long key;
+    int id;             // dense lattice id of the key (valid after lattice_build_kernel)
+    int pad;
 };
 
 struct ImageBuffers {   // per-image strides (in elements) into the workspace arrays
-    unsigned long long *keys;   // [N][cap]
-    int *slot_id;               // [N][cap]
+    TableEntry *table;          // [N][cap]
     unsigned long long *pkey;   // [N][Mmax]
     int *offset;                // [N][Npad*6]
     float *bary;                // [N][Npad*6]
@@ -93,23 +108,39 @@ __device__ __forceinline__ bool pack_key(const int *key, unsigned long long &pk)
     return ok;
 }
 
-__device__ __forceinline__ int find_slot(const unsigned long long *keys, unsigned mask, unsigned long long pk)
+// dense id of a packed key (-1: not a lattice point)
+__device__ __forceinline__ int find_id(const TableEntry *table, unsigned mask, unsigned long long pk)
 {
     unsigned s = (unsigned)hmix(pk) & mask;
     for (;;) {
-        const unsigned long long k = keys[s];
-        if (k == pk) return (int)s;
-        if (k == kEmpty) return -1;
+        const TableEntry t = table[s];          // (one 16-byte load)
+        if (t.key == pk) return t.id;
+        if (t.key == kEmpty) return -1;
         s = (s + 1) & mask;
     }
+}
+
+// 1-D grid -> (image n, workgroup l of the image's per_image workgroups), all workgroups of a unit (an image, or one of `parts` interleaved
+// slices of its workgroups) on one XCD: workgroup id i runs on XCD i % 8.  Unit u = n * parts + slice lives on XCD u % 8; the units of an
+// XCD run one after the other.  Grid size: image_grid().
+__device__ __forceinline__ bool image_wg(int N, int parts, int per_image, int &n, int &l)
+{
+    const int lp = (per_image + parts - 1) / parts;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int u = xcd + 8 * (j / lp);
+    if (u >= N * parts) return false;
+    n = u / parts;
+    l = (j % lp) * parts + (u - n * parts);
+    return l < per_image;
 }
 
 // ---- 1. per-pixel simplex + hash insertion ----------------------------------------------------
 __global__ __launch_bounds__(256) void lattice_build_kernel(const float *__restrict__ images, LatticeParams P, ImageBuffers B)
 {
-    const int p = blockIdx.x * 256 + threadIdx.x;
+    int n, wg;
+    if (!image_wg(P.nimg, P.parts, (P.Npad + 255) / 256, n, wg)) return;
+    const int p = wg * 256 + threadIdx.x;
     if (p >= P.Npad) return;
-    const int n = blockIdx.y;
     const size_t hw = (size_t)P.H * P.W;
     const float *img = images + (size_t)n * 3 * hw;
     float f[PD];
@@ -176,14 +207,25 @@ __global__ __launch_bounds__(256) void lattice_build_kernel(const float *__restr
     }
     bc[0] = bc[0] + (1.0f + bc[PD + 1]);
 
-    unsigned long long *keys = B.keys + (size_t)n * ((size_t)P.cap_mask + 1);
-    int *slot_id = B.slot_id + (size_t)n * ((size_t)P.cap_mask + 1);
+    TableEntry *table = B.table + (size_t)n * ((size_t)P.cap_mask + 1);
     unsigned long long *pkey = B.pkey + (size_t)n * P.Mmax;
     int *Mp = B.M + n;
     bool bad = false;
-    // slots this lane claimed (a new lattice point), their keys, one flag per r: the dense ids are handed out after the loop
+    // Three stages, each over the six vertices r, so that a wave's six table probes are in flight TOGETHER (round 5: one after the other they
+    // were six load latencies -- plus a CAS latency for every new point -- per wave):
+    //   1. keys, and wave-level de-duplication: on smooth images the 64 consecutive pixels of a wave share a handful of lattice points per r,
+    //      so one lane per distinct key (the first that holds it) probes / inserts and the others take its slot by a cross-lane read: an
+    //      order of magnitude fewer random accesses into the table.  The grouping loop is ballots and scalar compares only.
+    //   2. the leaders' first probes (plain loads), all six issued back to back;
+    //   3. test before test-and-set: a slot only ever goes kEmpty -> key, so a plain (possibly stale) load can at worst still show kEmpty, in
+    //      which case the CAS decides: most attempts end with the load of stage 2 instead of a memory-side 64-bit atomic on a contended
+    //      address.  Tried and dropped: de-duplicating a workgroup's 1536 keys in an LDS hash first (1.20 ms) and pre-aggregating the splat
+    //      contributions of a workgroup in LDS rows (0.75 vs 0.71 ms) -- the occupancy lost to the LDS tables cost more than they saved.
+    // new_slot / new_key / won: slots this lane claimed (a new lattice point): the dense ids are handed out after the loops.
+    const int lane = threadIdx.x & 63;
     unsigned new_slot[PD1];
-    unsigned long long new_key[PD1];
+    unsigned long long new_key[PD1], seen[PD1];
+    int leader[PD1];
     bool won[PD1];
 #pragma unroll
     for (int r = 0; r <= PD; r++) {
@@ -197,48 +239,65 @@ __global__ __launch_bounds__(256) void lattice_build_kernel(const float *__restr
         }
         unsigned long long pk;
         if (!pack_key(key, pk)) bad = true;
-        // Wave-level de-duplication first: on smooth images the 64 consecutive pixels of a wave share a handful of lattice points per r
-        // (M / N = 0.08), so one lane per distinct key (the first that holds it) probes / inserts and the others take its slot by a
-        // cross-lane read: an order of magnitude fewer random accesses into the table.  The grouping loop is ballots and scalar
-        // compares only (one round per distinct key); the probes of all leaders then run concurrently.
-        const int lane = threadIdx.x & 63;
         const unsigned pk_lo = (unsigned)pk, pk_hi = (unsigned)(pk >> 32);
-        int leader = lane;
+        int ld = lane;
         for (unsigned long long rem = __ballot(1); rem != 0;) {
             const int l = __ffsll((long long)rem) - 1;                                 // (wave-uniform)
             const unsigned llo = __builtin_amdgcn_readlane(pk_lo, l), lhi = __builtin_amdgcn_readlane(pk_hi, l);
             const bool mine = pk_lo == llo && pk_hi == lhi;
-            if (mine) leader = l;                                                      // (a later round cannot match again: the key is gone from rem)
+            if (mine) ld = l;                                                          // (a later round cannot match again: the key is gone from rem)
             rem &= ~__ballot(mine);
         }
-        unsigned s = (unsigned)hmix(pk) & P.cap_mask;
-        won[r] = false;
-        if (leader == lane)
-        for (;;) {
-            // test before test-and-set: a slot only ever goes kEmpty -> key, so a plain (possibly stale) load can at worst still show
-            // kEmpty, in which case the CAS below decides: most attempts end here with an L2 hit instead of a memory-side 64-bit atomic
-            // on a contended address.  Tried and dropped: de-duplicating a workgroup's 1536 keys in an LDS hash first (1.20 ms) and
-            // pre-aggregating the splat contributions of a workgroup in LDS rows (0.75 vs 0.71 ms) -- the occupancy lost to the LDS tables
-            // (8 -> 3 workgroups per CU) cost more than they saved.
-            const unsigned long long seen = __builtin_nontemporal_load(&keys[s]);
-            if (seen == pk) break;
-            if (seen != kEmpty) { s = (s + 1) & P.cap_mask; continue; }
-            const unsigned long long prev = atomicCAS(&keys[s], kEmpty, pk);
-            if (prev == kEmpty) { won[r] = true; break; }
-            if (prev == pk) break;
-            s = (s + 1) & P.cap_mask;
-        }
-        new_slot[r] = s;
+        leader[r] = ld;
         new_key[r] = pk;
-        s = (unsigned)__shfl((int)s, leader, 64);
-        B.offset[((size_t)n * P.Npad + p) * PD1 + r] = (int)s;   // slot for now; remapped to the dense id next
-        B.bary[((size_t)n * P.Npad + p) * PD1 + r] = bc[r];
+        new_slot[r] = (unsigned)hmix(pk) & P.cap_mask;
+    }
+#pragma unroll
+    for (int r = 0; r <= PD; r++) {
+        seen[r] = kEmpty;
+        if (leader[r] == lane) seen[r] = __builtin_nontemporal_load(&table[new_slot[r]].key);
+    }
+#pragma unroll
+    for (int r = 0; r <= PD; r++) {
+        won[r] = false;
+        if (leader[r] == lane) {
+            const unsigned long long pk = new_key[r];
+            unsigned s = new_slot[r];
+            unsigned long long sn = seen[r];
+            for (;;) {
+                if (sn == pk) break;
+                if (sn == kEmpty) {
+                    const unsigned long long prev = atomicCAS(&table[s].key, kEmpty, pk);
+                    if (prev == kEmpty) { won[r] = true; break; }
+                    if (prev == pk) break;
+                }
+                s = (s + 1) & P.cap_mask;
+                sn = __builtin_nontemporal_load(&table[s].key);
+            }
+            new_slot[r] = s;
+        }
+    }
+    {       // slot for now (remapped to the dense id next) and barycentric weights: 24 + 24 bytes per pixel, 8-byte stores
+        int so[PD1];
+#pragma unroll
+        for (int r = 0; r <= PD; r++) so[r] = __shfl((int)new_slot[r], leader[r], 64);
+        int *op = B.offset + ((size_t)n * P.Npad + p) * PD1;
+        float *bp = B.bary + ((size_t)n * P.Npad + p) * PD1;
+#if COSA_PD == 5
+#pragma unroll
+        for (int r = 0; r < PD1; r += 2) {
+            *reinterpret_cast<int2 *>(op + r) = make_int2(so[r], so[r + 1]);
+            *reinterpret_cast<float2 *>(bp + r) = make_float2(bc[r], bc[r + 1]);
+        }
+#else
+#pragma unroll
+        for (int r = 0; r <= PD; r++) { op[r] = so[r]; bp[r] = bc[r]; }
+#endif
     }
     // Dense ids: ONE add to the image's counter per wave for all the points its lanes created (ranked by ballot), not one per point:
     // the per-image counter is a single address, and same-address atomics serialise at ~20 ns each -- with one add per new point they
     // were 430 of this kernel's 630 us (b = 16, 224^2, ~25 k points per image).
     {
-        const int lane = threadIdx.x & 63;
         unsigned long long wm[PD1];
         int total = 0;
 #pragma unroll
@@ -252,7 +311,7 @@ __global__ __launch_bounds__(256) void lattice_build_kernel(const float *__restr
             for (int r = 0; r <= PD; r++) {
                 if (won[r]) {
                     const int id = base + __popcll(wm[r] & ((1ull << lane) - 1ull));
-                    slot_id[new_slot[r]] = id;
+                    table[new_slot[r]].id = id;
                     pkey[id] = new_key[r];
                 }
                 base += __popcll(wm[r]);
@@ -265,12 +324,13 @@ __global__ __launch_bounds__(256) void lattice_build_kernel(const float *__restr
 // ---- 2a. slot -> dense id ------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void lattice_remap_kernel(LatticeParams P, ImageBuffers B)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    int n, wg;
+    if (!image_wg(P.nimg, P.parts, (P.Npad * PD1 + 255) / 256, n, wg)) return;
+    const int i = wg * 256 + threadIdx.x;
     if (i >= P.Npad * PD1) return;
-    const int n = blockIdx.y;
     int *off = B.offset + (size_t)n * P.Npad * PD1;
-    const int *slot_id = B.slot_id + (size_t)n * ((size_t)P.cap_mask + 1);
-    const int id = slot_id[off[i]];
+    const TableEntry *table = B.table + (size_t)n * ((size_t)P.cap_mask + 1);
+    const int id = table[off[i]].id;
     off[i] = id;
     const size_t g = (size_t)n * P.Npad * PD1 + i;
     B.ckey0[g] = ((unsigned)n << B.id_bits) | (unsigned)(i / PD1 < P.N ? id : P.Mmax);
@@ -297,15 +357,15 @@ __device__ __forceinline__ void unpack_key(unsigned long long pk, int *key)
     for (int i = 0; i < PD; i++) key[i] = ((int)((pk >> (3 + 12 * i)) & 0xFFFull) - 2048) * PD1 + r;
 }
 
-__global__ __launch_bounds__(256) void lattice_neighbors_kernel(LatticeParams P, ImageBuffers B)
+__global__ __launch_bounds__(256) void lattice_neighbors_kernel(int per_image, LatticeParams P, ImageBuffers B)
 {
-    const int n = blockIdx.y;
+    int n, wg;
+    if (!image_wg(P.nimg, P.parts, per_image, n, wg)) return;
     const int M = B.M[n];
-    const unsigned long long *keys = B.keys + (size_t)n * ((size_t)P.cap_mask + 1);
-    const int *slot_id = B.slot_id + (size_t)n * ((size_t)P.cap_mask + 1);
+    const TableEntry *table = B.table + (size_t)n * ((size_t)P.cap_mask + 1);
     const unsigned long long *pkey = B.pkey + (size_t)n * P.Mmax;
     int2 *nb = B.nb + (size_t)n * PD1 * P.Mmax;
-    for (int e = blockIdx.x * 256 + threadIdx.x; e < M * PD1; e += gridDim.x * 256) {
+    for (int e = wg * 256 + threadIdx.x; e < M * PD1; e += per_image * 256) {
         const int j = e / M, i = e - j * M;
         int key[PD], k1[PD], k2[PD];
         unpack_key(pkey[i], key);
@@ -316,8 +376,8 @@ __global__ __launch_bounds__(256) void lattice_neighbors_kernel(LatticeParams P,
             if (k == j) { k1[k] = key[k] + PD; k2[k] = key[k] - PD; }
         unsigned long long p1, p2;
         int r1 = -1, r2 = -1;
-        if (pack_key(k1, p1)) { const int s = find_slot(keys, P.cap_mask, p1); if (s >= 0) r1 = slot_id[s]; }
-        if (pack_key(k2, p2)) { const int s = find_slot(keys, P.cap_mask, p2); if (s >= 0) r2 = slot_id[s]; }
+        if (pack_key(k1, p1)) r1 = find_id(table, P.cap_mask, p1);
+        if (pack_key(k2, p2)) r2 = find_id(table, P.cap_mask, p2);
         nb[(size_t)j * P.Mmax + i] = make_int2(r1, r2);
     }
 }
@@ -328,8 +388,9 @@ __global__ __launch_bounds__(256) void lattice_rows_kernel(const float *__restri
                                                           int K, LatticeParams P, ImageBuffers B)
 {
     extern __shared__ __attribute__((aligned(16))) float tile[];   // [TP][KP+1]
-    const int n = blockIdx.y;
-    const int p0 = blockIdx.x * TP;
+    int n, wg;
+    if (!image_wg(P.nimg, kAllXcds, (P.N + TP - 1) / TP, n, wg)) return;          // (a streaming kernel: nothing to keep in one L2)
+    const int p0 = wg * TP;
     const int KP = P.KP, ld = KP + 1;
     const size_t hw = (size_t)P.N;
     const float *in = ins + (size_t)n * K * hw;
@@ -350,18 +411,22 @@ __global__ __launch_bounds__(256) void lattice_rows_kernel(const float *__restri
     }
 }
 
-// values[id+1][k] = sum over the vertex's pairs, in ascending pixel order, of bary * rows[pixel][k]: 32 lanes per vertex (lane = channel),
-// four pairs' loads in flight.  Also zeroes the sink rows (row 0 of both value buffers).
+// values[id+1][k] = sum over the vertex's pairs, in ascending pixel order, of bary * rows[pixel][k]: 32 lanes per vertex (lane = channel).
+// The half-wave first fetches up to 32 of the vertex's pairs TOGETHER (lane u: pair number and barycentric weight of pair u -- two dependent
+// loads for 32 pairs instead of two per pair), then walks them in order with the pair broadcast by a lane shuffle, so the row loads have no
+// load in front of them and several are in flight (round 5: lists average 12 pairs, the kernel was a chain of load latencies).
+// Also zeroes the sink rows (row 0 of both value buffers).
 template <int NT>       // NT 32-channel groups per lane: KP <= 32 NT (VOC 21 planes: 1; COCO 81: 3) -- a vertex's pair list is walked once
-__global__ __launch_bounds__(256) void lattice_splat_sorted_kernel(LatticeParams P, ImageBuffers B)
+__global__ __launch_bounds__(256) void lattice_splat_sorted_kernel(int per_image, LatticeParams P, ImageBuffers B)
 {
-    const int n = blockIdx.y;
+    int n, wg;
+    if (!image_wg(P.nimg, P.parts, per_image, n, wg)) return;
     const int M = B.M[n];
     const int KP = P.KP;
     const int k = threadIdx.x & 31;
     const size_t vstride = ((size_t)P.Mmax + 1) * KP;
     float *val = B.val0 + (size_t)n * vstride;
-    if (blockIdx.x == 0) {
+    if (wg == 0) {
         for (int c = threadIdx.x; c < KP; c += 256) {
             val[c] = 0.0f;
             B.val1[(size_t)n * vstride + c] = 0.0f;
@@ -373,36 +438,49 @@ __global__ __launch_bounds__(256) void lattice_splat_sorted_kernel(LatticeParams
     bool on[NT];
 #pragma unroll
     for (int t = 0; t < NT; t++) on[t] = k + 32 * t < KP;
-    for (int id = blockIdx.x * 8 + (threadIdx.x >> 5); id < M; id += gridDim.x * 8) {
+    for (int id = wg * 8 + (threadIdx.x >> 5); id < M; id += per_image * 8) {
         const int beg = lo[id], end = hi[id];
         for (int kc0 = 0; kc0 < KP; kc0 += 32 * NT) {     // (one trip unless KP > 32 NT)
-            int i = beg;
             float acc[NT];
 #pragma unroll
             for (int t = 0; t < NT; t++) acc[t] = 0.0f;
-            for (; i + 4 <= end; i += 4) {
-                unsigned e[4];
-                float w[4], v[4][NT];
+            // a group of U pairs: U row loads in flight, then the U multiply-adds in pair order.  Long lists (a lattice point of a flat image
+            // region collects thousands of pixels) are one latency per GROUP, and the kernel ends with its longest list: groups of 16
+            auto group = [&](const unsigned e_l, const float w_l, const int i0, auto utag) {
+                constexpr int U = decltype(utag)::value;
+                float w[U], v[U][NT];
 #pragma unroll
-                for (int u = 0; u < 4; u++) e[u] = B.cent1[i + u];
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    w[u] = bary[e[u]];
-                    const float *rp = rows + (size_t)(e[u] / PD1) * KP + kc0 + k;
+                for (int u = 0; u < U; u++) {
+                    const unsigned e = (unsigned)__shfl((int)e_l, i0 + u, 32);
+                    w[u] = __shfl(w_l, i0 + u, 32);
+                    const float *rp = rows + (size_t)(e / PD1) * KP + kc0 + k;
 #pragma unroll
                     for (int t = 0; t < NT; t++) v[u][t] = (on[t] && kc0 + k + 32 * t < KP) ? rp[32 * t] : 0.0f;
                 }
 #pragma unroll
-                for (int u = 0; u < 4; u++)
+                for (int u = 0; u < U; u++)
 #pragma unroll
                     for (int t = 0; t < NT; t++) acc[t] = acc[t] + w[u] * v[u][t];
+            };
+            constexpr int UB = NT == 1 ? 16 : 8;
+            unsigned e_n = 0u;
+            float w_n = 0.0f;
+            if (beg + k < end) {
+                e_n = B.cent1[beg + k];
+                w_n = bary[e_n];
             }
-            for (; i < end; i++) {
-                const unsigned e = B.cent1[i];
-                const float w = bary[e];
-                const float *rp = rows + (size_t)(e / PD1) * KP + kc0 + k;
-#pragma unroll
-                for (int t = 0; t < NT; t++) acc[t] = acc[t] + w * ((on[t] && kc0 + k + 32 * t < KP) ? rp[32 * t] : 0.0f);
+            for (int base = beg; base < end; base += 32) {
+                const int cnt = end - base < 32 ? end - base : 32;          // (the same for the 32 lanes of the vertex)
+                const unsigned e_l = e_n;
+                const float w_l = w_n;
+                if (base + 32 + k < end) {                                  // the next 32 pairs: in flight under this chunk's rows
+                    e_n = B.cent1[base + 32 + k];
+                    w_n = bary[e_n];
+                }
+                int i = 0;
+                for (; i + UB <= cnt; i += UB) group(e_l, w_l, i, std::integral_constant<int, UB>{});
+                for (; i + 4 <= cnt; i += 4) group(e_l, w_l, i, std::integral_constant<int, 4>{});
+                for (; i < cnt; i++) group(e_l, w_l, i, std::integral_constant<int, 1>{});
             }
 #pragma unroll
             for (int t = 0; t < NT; t++)
@@ -412,9 +490,12 @@ __global__ __launch_bounds__(256) void lattice_splat_sorted_kernel(LatticeParams
 }
 
 // ---- 4. blur along axis j: new = old + 0.5*(old[n1] + old[n2]) ----------------------------------------
-__global__ __launch_bounds__(256) void lattice_blur_kernel(int axis, int parity, LatticeParams P, ImageBuffers B)
+__global__ __launch_bounds__(256) void lattice_blur_kernel(int axis, int parity, int per_image, LatticeParams P, ImageBuffers B)
 {
-    const int n = blockIdx.y;
+    // all XCDs share every image: the value rows of an image (2 x 2.4 MB at M = 25 k, K = 21) fit any L2, and the images' lattice sizes differ --
+    // with an image per XCD the pass waits for the XCD that drew the largest ones (measured: 17.6 us shared, 18.9-20.4 us per XCD)
+    int n, wg;
+    if (!image_wg(P.nimg, kAllXcds, per_image, n, wg)) return;
     const int M = B.M[n];
     const int KP = P.KP, q4 = KP / 4;
     const size_t vstride = ((size_t)P.Mmax + 1) * KP;
@@ -422,7 +503,7 @@ __global__ __launch_bounds__(256) void lattice_blur_kernel(int axis, int parity,
     float *newv = (parity ? B.val0 : B.val1) + (size_t)n * vstride;
     const int2 *nb = B.nb + ((size_t)n * PD1 + axis) * P.Mmax;
     const int tot = M * q4;
-    for (int e = blockIdx.x * 256 + threadIdx.x; e < tot; e += gridDim.x * 256) {
+    for (int e = wg * 256 + threadIdx.x; e < tot; e += per_image * 256) {
         const int i = e / q4, q = e - i * q4;
         const int2 nn = nb[i];
         const float4 o = *reinterpret_cast<const float4 *>(oldv + (size_t)(i + 1) * KP + 4 * q);
@@ -447,24 +528,30 @@ __global__ __launch_bounds__(256) void lattice_slice_kernel(float *__restrict__ 
 {
     extern __shared__ __attribute__((aligned(16))) float tile[];   // [TP][KP+1]
     __shared__ double red[4];
-    const int n = blockIdx.y;
-    const int p0 = blockIdx.x * TP;
+    int n, wg;
+    if (!image_wg(P.nimg, P.parts, (P.N + TP - 1) / TP, n, wg)) return;
+    const int p0 = wg * TP;
     const int KP = P.KP, ld = KP + 1;
     const size_t hw = (size_t)P.N;
     const float *val = (final_parity ? B.val1 : B.val0) + (size_t)n * ((size_t)P.Mmax + 1) * KP;
     const int *off = B.offset + ((size_t)n * P.Npad + p0) * PD1;
     const float *bar = B.bary + ((size_t)n * P.Npad + p0) * PD1;
     const float alpha = 1.0f / (1.0f + 1.0f / (float)(1 << PD));   // 1/(1+2^-d)
+    // the tile's vertex rows and weights, once, through LDS: the KP threads of a pixel would each load the same 2 (d + 1) words
+    __shared__ int off_s[TP * PD1];
+    __shared__ float bar_s[TP * PD1];
+    for (int e = threadIdx.x; e < TP * PD1; e += 256) {
+        const bool in = p0 + e / PD1 < P.N;
+        off_s[e] = in ? off[e] + 1 : 0;
+        bar_s[e] = in ? bar[e] * alpha : 0.0f;
+    }
+    __syncthreads();
     for (int e = threadIdx.x; e < TP * KP; e += 256) {
         const int pl = e / KP, k = e - pl * KP;
         float acc = 0.0f;
         if (p0 + pl < P.N && k < K) {
 #pragma unroll
-            for (int r = 0; r < PD1; r++) {
-                const int o = off[pl * PD1 + r] + 1;
-                const float w = bar[pl * PD1 + r] * alpha;
-                acc = acc + w * val[(size_t)o * KP + k];
-            }
+            for (int r = 0; r < PD1; r++) acc = acc + bar_s[pl * PD1 + r] * val[(size_t)off_s[pl * PD1 + r] * KP + k];
         }
         tile[pl * ld + k] = acc;
     }
@@ -515,7 +602,7 @@ __global__ __launch_bounds__(256) void lattice_slice_kernel(float *__restrict__ 
         for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
         __syncthreads();
-        if (threadIdx.x == 0) B.loss_part[(size_t)n * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+        if (threadIdx.x == 0) B.loss_part[(size_t)n * ((P.N + TP - 1) / TP) + wg] = red[0] + red[1] + red[2] + red[3];
     }
 }
 
@@ -559,12 +646,31 @@ struct Plan {
 
 inline int round_kp(int K) { return (K + 3) & ~3; }
 
+// XCDs per image: the smallest of 1 / 2 / 4 / 8 that keeps >= 80 % of the XCDs busy over the rounds of units (8 always does)
+inline int image_parts(int N)
+{
+    for (int parts = 1; parts < 8; parts *= 2) {
+        const int units = N * parts, rounds = (units + 7) / 8;
+        if (units * 5 >= rounds * 8 * 4) return parts;
+    }
+    return 8;
+}
+
+inline unsigned image_grid(const LatticeParams &P, int per_image, int parts = 0)
+{
+    if (parts == 0) parts = P.parts;
+    const int lp = (per_image + parts - 1) / parts, units = P.nimg * parts;
+    return (unsigned)(8 * ((units + 7) / 8) * lp);
+}
+
 size_t plan_layout(int N, int K, int H, int W, void *ws, Plan *pl)
 {
     LatticeParams &P = pl->P;
     P.H = H; P.W = W; P.N = H * W; P.Npad = (P.N + 3) & ~3;
+    P.nimg = N; P.parts = image_parts(N);
+    // worst case (every pixel six points of its own) loads the table to 2/3; the training images fill a few per cent of it
     size_t cap = 1;
-    while (cap < (size_t)P.Npad * PD1 * 2) cap <<= 1;
+    while (cap * 2 < (size_t)P.Npad * PD1 * 3) cap <<= 1;
     P.cap_mask = (unsigned)(cap - 1);
     P.Mmax = P.Npad * PD1;
     P.KP = round_kp(K);
@@ -574,9 +680,7 @@ size_t plan_layout(int N, int K, int H, int W, void *ws, Plan *pl)
     B.M = cv.take<int>((size_t)N);
     B.loss_acc = cv.take<double>(8);
     const size_t head = cv.off;       // [err | M | loss_acc] zeroed every call
-    B.keys = cv.take<unsigned long long>((size_t)N * cap);
-    const size_t keys_end = cv.off;
-    B.slot_id = cv.take<int>((size_t)N * cap);
+    B.table = cv.take<TableEntry>((size_t)N * cap);
     B.pkey = cv.take<unsigned long long>((size_t)N * P.Mmax);
     B.offset = cv.take<int>((size_t)N * P.Npad * PD1);
     B.bary = cv.take<float>((size_t)N * P.Npad * PD1);
@@ -596,7 +700,7 @@ size_t plan_layout(int N, int K, int H, int W, void *ws, Plan *pl)
     while ((1u << B.id_bits) <= (unsigned)P.Mmax) B.id_bits++;          // ids 0 .. Mmax (Mmax = "padding pixel")
     B.sort_tmp_bytes = rs_scratch_bytes(pairs);
     B.sort_tmp = cv.take<char>(B.sort_tmp_bytes);
-    (void)head; (void)keys_end;
+    (void)head;
     pl->bytes = cv.off;
     return cv.off;
 }
@@ -634,16 +738,16 @@ int lattice_phase(const float *images, int N, Plan &pl, hipStream_t st)
     LatticeParams &P = pl.P;
     ImageBuffers &B = pl.B;
     const size_t cap = (size_t)P.cap_mask + 1;
-    // zero [err | M | loss_acc] (one block at the start of the workspace), fill the key table with EMPTY
-    COSA_HIP_CHECK(hipMemsetAsync(B.err, 0, (char *)B.keys - (char *)B.err, st));
-    COSA_HIP_CHECK(hipMemsetAsync(B.keys, 0xFF, (size_t)N * cap * sizeof(unsigned long long), st));
+    // zero [err | M | loss_acc] (one block at the start of the workspace), fill the table with EMPTY keys (ids: don't care)
+    COSA_HIP_CHECK(hipMemsetAsync(B.err, 0, (char *)B.table - (char *)B.err, st));
+    COSA_HIP_CHECK(hipMemsetAsync(B.table, 0xFF, (size_t)N * cap * sizeof(TableEntry), st));
     const dim3 blk(256);
-    hipLaunchKernelGGL(lattice_build_kernel, dim3((P.Npad + 255) / 256, N), blk, 0, st, images, P, B);
+    hipLaunchKernelGGL(lattice_build_kernel, dim3(image_grid(P, (P.Npad + 255) / 256)), blk, 0, st, images, P, B);
     COSA_LAUNCH_CHECK();
-    hipLaunchKernelGGL(lattice_remap_kernel, dim3((P.Npad * PD1 + 255) / 256, N), blk, 0, st, P, B);
+    hipLaunchKernelGGL(lattice_remap_kernel, dim3(image_grid(P, (P.Npad * PD1 + 255) / 256)), blk, 0, st, P, B);
     COSA_LAUNCH_CHECK();
-    const int gs = 1024;   // grid-stride launches read M on the device
-    hipLaunchKernelGGL(lattice_neighbors_kernel, dim3(gs, N), blk, 0, st, P, B);
+    const int gs = kWgPerImage;   // grid-stride launches read M on the device
+    hipLaunchKernelGGL(lattice_neighbors_kernel, dim3(image_grid(P, gs)), blk, 0, st, gs, P, B);
     COSA_LAUNCH_CHECK();
     // the splat lists: pairs sorted by (image, vertex); stable, so a vertex keeps its pairs in pixel order
     const size_t pairs = (size_t)N * P.Npad * PD1;
@@ -668,20 +772,21 @@ int filter_phase(const float *ins, float *outs, int N, int K, const float *roi, 
     LatticeParams &P = pl.P;
     ImageBuffers &B = pl.B;
     const dim3 blk(256);
-    const int gs = 1024;
+    const int gs = kWgPerImage;
+    const int tiles = (P.N + TP - 1) / TP;
     const size_t lds = (size_t)TP * (P.KP + 1) * sizeof(float);
-    hipLaunchKernelGGL(lattice_rows_kernel, dim3((P.N + TP - 1) / TP, N), blk, lds, st, ins, roi, K, P, B);
+    hipLaunchKernelGGL(lattice_rows_kernel, dim3(image_grid(P, tiles, kAllXcds)), blk, lds, st, ins, roi, K, P, B);
     COSA_LAUNCH_CHECK();
-    if (P.KP <= 32) hipLaunchKernelGGL(lattice_splat_sorted_kernel<1>, dim3(gs, N), blk, 0, st, P, B);
-    else if (P.KP <= 64) hipLaunchKernelGGL(lattice_splat_sorted_kernel<2>, dim3(gs, N), blk, 0, st, P, B);
-    else hipLaunchKernelGGL(lattice_splat_sorted_kernel<3>, dim3(gs, N), blk, 0, st, P, B);
+    if (P.KP <= 32) hipLaunchKernelGGL(lattice_splat_sorted_kernel<1>, dim3(image_grid(P, gs)), blk, 0, st, gs, P, B);
+    else if (P.KP <= 64) hipLaunchKernelGGL(lattice_splat_sorted_kernel<2>, dim3(image_grid(P, gs)), blk, 0, st, gs, P, B);
+    else hipLaunchKernelGGL(lattice_splat_sorted_kernel<3>, dim3(image_grid(P, gs)), blk, 0, st, gs, P, B);
     COSA_LAUNCH_CHECK();
     for (int j = 0; j <= PD; j++) {
-        hipLaunchKernelGGL(lattice_blur_kernel, dim3(gs, N), blk, 0, st, j, j & 1, P, B);
+        hipLaunchKernelGGL(lattice_blur_kernel, dim3(image_grid(P, gs, kAllXcds)), blk, 0, st, j, j & 1, gs, P, B);
         COSA_LAUNCH_CHECK();
     }
     // d + 1 ping-pong passes: 6 (5-D lattice) leave the result in val0, 3 (2-D lattice) in val1
-    hipLaunchKernelGGL(lattice_slice_kernel, dim3((P.N + TP - 1) / TP, N), blk, lds, st, outs, K, PD1 & 1, seg_for_energy, roi,
+    hipLaunchKernelGGL(lattice_slice_kernel, dim3(image_grid(P, tiles)), blk, lds, st, outs, K, PD1 & 1, seg_for_energy, roi,
                        unlabel, P, B);
     COSA_LAUNCH_CHECK();
     if (seg_for_energy) {

@@ -15,6 +15,7 @@ mask = torch.randint(0, C + 1, (b, S, S), generator=g).to(dev).float()
 logit = torch.randn(b, C + 1, S, S, generator=g).to(dev).requires_grad_(True)
 
 def f():
+    logit.grad = None                 # (as zero_grad(set_to_none=True) leaves it)
     seg_helper.get_energy_loss(simg, logit, mask, box, layer).backward()
 
 for _ in range(3):
