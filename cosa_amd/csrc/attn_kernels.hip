@@ -50,13 +50,12 @@ __device__ __forceinline__ op16x8 v_frag(const unsigned char *Vs, int keyb, int 
 }
 
 constexpr float kDeferLog2 = 6.0f;
-// max of three floats in one instruction (fmaxf chains compile to v_max_f32 plus a canonicalising v_max x, x per input)
-__device__ __forceinline__ float max3f(float a, float b, float c)
-{
-    float r;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
+// max of three floats: one v_max3_f32 (this file is built with -fno-honor-nans: no canonicalising v_max x, x per input in front of fmaxf).
+// NOT inline asm: its operands are MFMA accumulators, and the wait states between an MFMA and a VALU read of its result are inserted by the
+// compiler's hazard recognizer, which does not look into asm statements.  Rounds 2-4 had `asm("v_max3_f32 ...")` here: correct only as long as
+// the schedule kept the statement >= 64 cycles behind the producing MFMA (it did: the builds are bit-identical to this one), and run-to-run
+// NON-deterministic as soon as the surrounding s_setprio fences were removed (round 5: tools/ab_attn_libs.py, profiles/r05_attn_variants.txt).
+__device__ __forceinline__ float max3f(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
 // c + p[0] + p[1] of a packed pair of probabilities, fp32 accumulation (v_dot2c_f32_f16 / _bf16 with the constant (1, 1))
 __device__ __forceinline__ float pair_sum(op16x2 p, float c)
 {
@@ -411,7 +410,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const op16 *__restric
             for (int kb = 0; kb < 2; kb++)
 #pragma unroll
                 for (int i = 0; i < 16; i++) sc[u][kb][i] = 0.f;
-        __builtin_amdgcn_s_setprio(1);
         if (AUGM) {
 #pragma unroll
             for (int u = 0; u < 2; u++) {
@@ -430,7 +428,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const op16 *__restric
                 sc[u][1] = COSA_MFMA_32x32x16(a1, qf[u][s], sc[u][1], 0, 0, 0);
             }
         }
-        __builtin_amdgcn_s_setprio(0);
 #pragma unroll
         for (int u = 0; u < 2; u++) {
             if constexpr (tail) {
@@ -515,7 +512,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const op16 *__restric
                     for (int t = 0; t < 8; t++) pk[u][kb][t] = (op16x2){(op16)sc[u][kb][2 * t], (op16)sc[u][kb][2 * t + 1]};
             }
         }
-        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kb = 0; kb < 2; kb++)
 #pragma unroll
@@ -531,7 +527,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const op16 *__restric
                     o[u][1] = COSA_MFMA_32x32x16(v1, pf, o[u][1], 0, 0, 0);
                 }
             }
-        __builtin_amdgcn_s_setprio(0);
         }
         if (DMA) {                                     // the next tile has landed and nobody still reads this one
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

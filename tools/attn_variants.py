@@ -1,0 +1,199 @@
+"""Experiment builds of the attention kernels WITHOUT touching cosa_amd/csrc (the teacher kernels' source hash is part of the accuracy record):
+a patched copy of attn_kernels.hip is compiled (both operand builds) and linked with the tree's other objects into
+cosa_amd/lib/variants/libcosa_hip_<name>.so.  usage: python tools/attn_variants.py <name> [<name> ...]; A/B: tools/ab_attn_libs.py"""
+import os, re, shutil, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from cosa_amd import build as B
+
+SRC = open(os.path.join(B.CSRC, "attn_kernels.hip")).read()
+a0, a1 = SRC.index("template <bool DMA, int OUTM = 0, int NW = 2, bool AUGM = false>"), SRC.index("// backward (student pass)")
+FWD2 = SRC[a0:a1]
+
+
+CMAX = False          # replace the inline-asm v_max3_f32 helper by fmaxf chains the compiler sees (its hazard recognizer covers them)
+
+
+def fwd2(f):
+    out = SRC[:a0] + f(FWD2) + SRC[a1:]
+    if CMAX:
+        i = out.index('    float r;\n    asm("v_max3_f32 %0, %1, %2, %3"')
+        j = out.index("    return r;\n", i) + len("    return r;\n")
+        out = out[:i] + "    return __builtin_fmaxf(__builtin_fmaxf(a, b), c);\n" + out[j:]
+    return out
+
+
+def noprio(t):
+    return re.sub(r"^\s*__builtin_amdgcn_s_setprio\(\d\);\n", "", t, flags=re.M)
+
+
+def prio_pv_only(t):          # priority only around the PV MFMAs
+    i = t.index("__builtin_amdgcn_s_setprio(1);")
+    j = t.index("__builtin_amdgcn_s_setprio(0);", i)
+    t = t[:i] + t[i:j + 40].replace("__builtin_amdgcn_s_setprio(1);", "").replace("__builtin_amdgcn_s_setprio(0);", "") + t[j + 40:]
+    return t
+
+
+def prio_qk_only(t):
+    i = t.rindex("__builtin_amdgcn_s_setprio(1);")
+    j = t.index("__builtin_amdgcn_s_setprio(0);", i)
+    return t[:i] + t[i:j + 40].replace("__builtin_amdgcn_s_setprio(1);", "").replace("__builtin_amdgcn_s_setprio(0);", "") + t[j + 40:]
+
+
+def occ3(t):                  # three workgroups of 256 per CU (<= 168 VGPRs)
+    return t.replace("__launch_bounds__(256, 2) void attn_fwd2_kernel", "__launch_bounds__(256, 3) void attn_fwd2_kernel")
+
+
+
+def _pipe(t, sgb):
+    """two query blocks of a wave software-pipelined: QK(u1) issues inside softmax(u0)'s exponentials, PV(u0) inside softmax(u1)'s; the same
+    operations in the same order per accumulator chain -> bit-identical"""
+    a = t.index("        op16x2 pk[2][2][8];")
+    b = t.index("        if (DMA) {                                     // the next tile has landed")
+    old = t[a:b]
+    # the softmax of one query block = body of `for (int u = 0; u < 2; u++) {` ... up to the PV section
+    i0 = old.index("        for (int u = 0; u < 2; u++) {\n            if constexpr (tail) {")
+    i1 = old.index("        __builtin_amdgcn_s_setprio(1);\n#pragma unroll\n        for (int kb = 0; kb < 2; kb++)\n#pragma unroll\n            for (int sp = 0; sp < 2; sp++) {")
+    body = old[i0:i1]
+    body = body[body.index("{\n") + 2:]
+    body = body[:body.rindex("        }\n")]            # drop the loop's closing brace
+    # split at the probabilities: [mask + max + rescale branch] | [exp + row sums + packing]
+    k = body.index("            // probabilities: exp2, rounded to the operand type in pairs")
+    part_a, part_b = body[:k], body[k:]
+    M = "COSA_MFMA_32x32x16"
+    new = f"""        op16x2 pk[2][2][8];
+        f32x16 sc[2][2];
+        op16x8 ka[4][2];
+#pragma unroll
+        for (int s = 0; s < 4; s++) {{
+            const int slot = ((2 * s + hh) ^ swz) << 4;
+            ka[s][0] = *reinterpret_cast<const op16x8 *>(Ks + r * 128 + slot);
+            ka[s][1] = *reinterpret_cast<const op16x8 *>(Ks + (r + 32) * 128 + slot);
+        }}
+        auto qk = [&](const int u) {{
+#pragma unroll
+            for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+                for (int i = 0; i < 16; i++) sc[u][kb][i] = 0.f;
+            if (AUGM) {{
+                sc[u][0] = {M}(a_aug, qaug[u], sc[u][0], 0, 0, 0);
+                sc[u][1] = {M}(a_aug, qaug[u], sc[u][1], 0, 0, 0);
+            }}
+#pragma unroll
+            for (int s = 0; s < 4; s++) {{
+                sc[u][0] = {M}(ka[s][0], qf[u][s], sc[u][0], 0, 0, 0);
+                sc[u][1] = {M}(ka[s][1], qf[u][s], sc[u][1], 0, 0, 0);
+            }}
+        }};
+        auto smax_a = [&](const int u) {{
+{part_a}        }};
+        auto smax_b = [&](const int u) {{
+{part_b}        }};
+        auto pv = [&](const int u) {{
+#pragma unroll
+            for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+                for (int sp = 0; sp < 2; sp++) {{
+                    const int keyb = kb * 32 + 16 * sp + 4 * hh;
+                    const op16x8 v0 = v_frag(Vs, keyb, 0, lane), v1 = v_frag(Vs, keyb, 1, lane);
+                    const op16x8 pf = __builtin_shufflevector(__builtin_shufflevector(pk[u][kb][4 * sp], pk[u][kb][4 * sp + 1], 0, 1, 2, 3),
+                                                              __builtin_shufflevector(pk[u][kb][4 * sp + 2], pk[u][kb][4 * sp + 3], 0, 1, 2, 3),
+                                                              0, 1, 2, 3, 4, 5, 6, 7);
+                    o[u][0] = {M}(v0, pf, o[u][0], 0, 0, 0);
+                    o[u][1] = {M}(v1, pf, o[u][1], 0, 0, 0);
+                }}
+        }};
+        qk(0);
+        smax_a(0);
+        smax_b(0);
+        qk(1);
+{sgb[0]}        smax_a(1);
+        smax_b(1);
+        pv(0);
+{sgb[1]}        pv(1);
+        }}
+"""
+    return t[:a] + new + t[b:]
+
+
+def v_pipe(t):
+    return noprio(_pipe(t, ("", "")))
+
+
+def _sgb(n_mfma, n_valu):
+    return "".join(f"        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);\n        __builtin_amdgcn_sched_group_barrier(0x002, {n_valu}, 0);\n" for _ in range(n_mfma))
+
+
+def v_pipe_sgb(t):
+    return noprio(_pipe(t, (_sgb(10, 8), _sgb(8, 10))))
+
+
+
+def bk2(t):
+    """NW = 4 (long sequences): K / V staged two 64-key tiles at a time (ring of 2 x 32 KB): one barrier + vmcnt(0) per 128 keys instead of per
+    64; the compute walks the same 64-key tiles in the same order -> bit-identical.  NW = 2 keeps the 32-KB ring (four workgroups per CU)."""
+    def rep(a, b):
+        nonlocal t
+        assert t.count(a) == 1, (t.count(a), a)
+        t = t.replace(a, b)
+    rep("    __shared__ __attribute__((aligned(16))) unsigned char smem[(DMA ? 4 : 2) * BK * 128];",
+        "    constexpr bool SUP = DMA && NW == 4;\n    __shared__ __attribute__((aligned(16))) unsigned char smem[(SUP ? 8 : (DMA ? 4 : 2)) * BK * 128];")
+    rep("""        dma_tile(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");""", """        dma_tile(0, 0);
+        if (SUP && BK < N) dma_tile(BK, 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");""")
+    rep("    auto tile = [&](int k0, auto tail_tag) {", "    auto tile = [&](int k0, auto tail_tag, const int sub, const bool sync_after) {")
+    rep("""            Ks = smem + ring * 2 * BK * 128;
+            Vs = Ks + BK * 128;
+            if (k0 + BK < N) dma_tile(k0 + BK, ring ^ 1);""", """            if (SUP) {
+                Ks = smem + (ring * 2 + sub) * 2 * BK * 128;
+                if (sub == 0) {
+                    if (k0 + 2 * BK < N) dma_tile(k0 + 2 * BK, (ring ^ 1) * 2);
+                    if (k0 + 3 * BK < N) dma_tile(k0 + 3 * BK, (ring ^ 1) * 2 + 1);
+                }
+            } else {
+                Ks = smem + ring * 2 * BK * 128;
+                if (k0 + BK < N) dma_tile(k0 + BK, ring ^ 1);
+            }
+            Vs = Ks + BK * 128;""")
+    rep("        if (DMA) {                                     // the next tile has landed and nobody still reads this one", "        if (DMA && sync_after) {                       // the next tile(s) landed and nobody still reads this one")
+    rep("""    for (int k0 = 0; k0 < nfull; k0 += BK) tile(k0, std::false_type{});
+    if (nfull < N) tile(nfull, std::true_type{});""", """    int tcount = 0;
+    for (int k0 = 0; k0 < nfull; k0 += BK, tcount++) tile(k0, std::false_type{}, SUP ? (tcount & 1) : 0, !SUP || (tcount & 1) || k0 + BK >= N);
+    if (nfull < N) tile(nfull, std::true_type{}, SUP ? (tcount & 1) : 0, true);""")
+    return t
+
+
+VARIANTS = {"base": lambda t: t, "noprio": noprio, "prio_pv": prio_pv_only, "prio_qk": prio_qk_only, "occ3": occ3,
+            "occ3_noprio": lambda t: occ3(noprio(t)), "bk2": lambda t: bk2(noprio(t)), "bk2_pipe": lambda t: bk2(v_pipe(t))}
+VARIANTS.update({k: v for k, v in globals().items() if k.startswith("v_") and callable(v)})
+
+
+def build(name):
+    global CMAX
+    CMAX = name.endswith("_cmax")
+    top = os.path.join("/tmp/attnv", name)
+    shutil.rmtree(top, ignore_errors=True)
+    d = os.path.join(top, "cosa_amd", "csrc")
+    shutil.copytree(B.CSRC, d)
+    os.symlink(os.path.join(ROOT, "include"), os.path.join(top, "include"))          # (common.hpp includes ../../include/cosa_hip.h)
+    open(os.path.join(d, "attn_kernels.hip"), "w").write(fwd2(VARIANTS[name[:-5] if CMAX else name]))
+    hipcc = B._hipcc()
+    objs = []
+    for key, extra in B.SOURCES.items():
+        src, _, tag = key.partition("@")
+        op = os.path.join(B.OBJDIR, src.replace(".hip", ("_" + tag if tag else "") + ".o"))
+        if src == "attn_kernels.hip":
+            op = os.path.join(d, "attn" + ("_" + tag if tag else "") + ".o")
+            subprocess.check_call([hipcc, "-c", os.path.join(d, src), "-o", op] + B.COMMON + extra)
+        objs.append(op)
+    out = os.path.join(ROOT, "cosa_amd", "lib", "variants")
+    os.makedirs(out, exist_ok=True)
+    lib = os.path.join(out, f"libcosa_hip_{name}.so")
+    subprocess.check_call([hipcc, "-shared", "-fPIC", "--offload-arch=" + B.ARCH, "-o", lib] + objs)
+    print(lib)
+
+
+if __name__ == "__main__":
+    for n in sys.argv[1:]:
+        build(n)
