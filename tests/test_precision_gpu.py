@@ -610,7 +610,7 @@ def test_teacher_masks_through_par_vs_fp32_cpu_oracle(seed):
     for name, mg, mo in (("cam", got[0], ref[0]), ("cam_aux", got[1], ref[1])):
         agree, iou = float(np.mean(mg == mo)), _miou(mg, mo)
         lines.append(f"teacher+PAR {mode:8s} S={S} b=2 seed={seed:<2d} {name:8s}: label agreement {agree:.5f}  mask mIoU {iou:.5f}")
-    with open(os.path.join(ROOT, "gpurun_out", "r04_accuracy_teacher_par.txt"), "a") as f:
+    with open(os.path.join(ROOT, "gpurun_out", "r05_accuracy_teacher_par.txt"), "a") as f:
         f.write("\n".join(lines) + "\n")
     for ln in lines:
         agree, iou = (float(ln.split(k)[1].split()[0]) for k in ("label agreement", "mask mIoU"))

@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT (the
 R=gpurun_out/r05_accuracy_teacher.txt
 W=${1:-all}          # all | 1 | 23 (a gpurun call is limited to 20 minutes: part 1 and parts 2-3 fit one call each)
 if [ "$W" != 23 ]; then
-rm -f $R gpurun_out/r04_accuracy_teacher_par.txt
+rm -f $R gpurun_out/r05_accuracy_teacher_par.txt
 COSA_ACCURACY_ALL_SEEDS=1 COSA_ACCURACY_B16=1 COSA_ACCURACY_SWEEP_SEEDS=3 python -m pytest tests/test_precision_gpu.py -q -m gpu -x > gpurun_out/evidence_part1.log 2>&1 || { tail -20 gpurun_out/evidence_part1.log; exit 1; }
 tail -1 gpurun_out/evidence_part1.log
 sed -i "1a # part 1: tests/test_precision_gpu.py with COSA_ACCURACY_ALL_SEEDS=1 COSA_ACCURACY_B16=1: seven seeds at 224^2 / 448^2, four at 640^2, three sweep draws, the b = 16 batch" $R
