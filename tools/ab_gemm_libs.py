@@ -106,6 +106,20 @@ report("fp16c8 proj res", M, 768, 768,
        lambda: old.cosa_gemm_f16c8(ptr(xs), ptr(ws), ptr(z), ptr(r), ptr(yo), M, 768, 768, 2, 768, st()),
        lambda: new.cosa_gemm_f16c8(ptr(xs), ptr(ws), ptr(z), ptr(r), ptr(yn), M, 768, 768, 2, 768, st()), [yo], [yn])
 
+# fp16c8 (blocks 2-11 of the default teacher): qkv (fp16 out), fc1 + GELU (c8 rows out), fc2 + fp32 residual
+for name, N, K, epi in (("qkv", 2304, 768, 0), ("fc1", 3072, 768, 1), ("fc2", 768, 3072, 2)):
+    x = torch.randn(M, K, device=dev); w = torch.randn(N, K, device=dev) * 0.03; b = torch.randn(N, device=dev)
+    xs, ws = nn_ops.c8_rows(x, ones=True), nn_ops.c8_rows(w, bias=b)
+    if epi == 2:
+        r, ldy = torch.randn(M, N, device=dev), N
+        yo, yn = torch.zeros(M, N, device=dev), torch.zeros(M, N, device=dev)
+    else:
+        r, ldy = None, (nn_ops.split_ld(N) if epi == 1 else N)
+        yo, yn = (torch.zeros((M, ldy), device=dev, dtype=torch.float16) for _ in range(2))
+    report(f"fp16c8 {name}", M, N, K,
+           lambda: old.cosa_gemm_f16c8(ptr(xs), ptr(ws), ptr(z), ptr(r), ptr(yo), M, N, K, epi, ldy, st()),
+           lambda: new.cosa_gemm_f16c8(ptr(xs), ptr(ws), ptr(z), ptr(r), ptr(yn), M, N, K, epi, ldy, st()), [yo], [yn])
+
 # bf16x3 (the first two blocks of the default teacher since round 5): qkv (split rows out), fc1 + GELU (split rows out), fc2 + fp32 residual
 zb = torch.zeros(8192, device=dev, dtype=torch.bfloat16)
 for name, N, K, epi in (("qkv", 2304, 768, 0), ("fc1", 3072, 768, 1), ("fc2", 768, 3072, 2)):
