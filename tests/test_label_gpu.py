@@ -199,6 +199,31 @@ def test_bilateral_vs_golden(oracle_c, golden):
         assert np.array_equal(out.cpu().numpy(), ref)
 
 
+@pytest.mark.parametrize("N", [1, 2, 3, 5, 6, 7, 8, 9, 16, 17])
+def test_bilateral_every_batch_size_places_its_images_on_xcds(oracle_c, N):
+    """round 5: the lattice kernels map a 1-D grid to (image, workgroup) so that an image's workgroups sit on one XCD (N >= 8) or on 8 / N of them
+    (permuto_kernels.hip: image_wg, image_parts -- 8, 4, 8, 4, 4, 1, 1, ... XCDs per image for these N; idle XCDs and a second round of images
+    for N = 9, 17): the same bits as the serial reference for every split, lattice sizes included"""
+    from cosa_amd import _C
+    from oracle.gen_golden import synth_image255
+    rng = np.random.default_rng(100 + N)
+    K, H, W = 5, 36, 44
+    img = synth_image255(rng, N, H, W)
+    if N > 1:
+        img[1] = rng.uniform(0, 255, img[1].shape).astype(np.float32)          # one noise image: a lattice several times the others' size
+    seg = rng.standard_normal((N, K, H, W)).astype(np.float32)
+    L = _C.lib()
+    out = torch.empty((N, K, H, W), device="cuda")
+    Ms = torch.zeros(N, dtype=torch.int32, device="cuda")
+    ws = _C.workspace(L.cosa_bilateral_workspace_bytes(N, K, H, W), "cuda", "t")
+    d_img, d_seg = dev(img), dev(seg)
+    _C.check(L.cosa_bilateralfilter_batch_dev(_C.ptr(d_img), _C.ptr(d_seg), _C.ptr(out), N, K, H, W, 15.0, 50.0, _C.ptr(Ms), _C.ptr(ws), ws.numel(),
+                                              _C.stream_ptr()))
+    ref, M_ref = oracle_c.bilateralfilter_batch(img, seg, N, K, H, W, 15.0, 50.0)
+    assert np.array_equal(Ms.cpu().numpy(), M_ref)
+    assert np.array_equal(out.cpu().numpy(), ref.reshape(N, K, H, W))
+
+
 def test_bilateralfilter_module_numpy_signature(golden):
     from cosa_amd import bilateralfilter as bf
     g = golden("bilateral")
