@@ -164,8 +164,48 @@ def bk2(t):
     return t
 
 
+
+def regstage(t):
+    """K / V tiles through registers instead of LDS-DMA (guide T14): the next tile's 16-byte pieces are fetched with plain buffer loads at the
+    top of a tile (16 VGPRs at NW = 4) and written to the other ring buffer after the PV MFMAs; the LDS image is the same -> bit-identical"""
+    def rep(a, b):
+        nonlocal t
+        assert t.count(a) == 1, (t.count(a), a)
+        t = t.replace(a, b)
+    rep("""    auto dma_tile = [&](int k0, int buf) {""", """    u32x4v stK[4], stV[4];
+    auto fetch_tile = [&](int k0) {
+        const unsigned ko = (unsigned)((size_t)k0 * rs * 2);
+#pragma unroll
+        for (int i = 0; i < PW; i++) {
+            stK[i] = __builtin_amdgcn_raw_buffer_load_b128(rsK, voK[i] + ko, 0, 0);
+            stV[i] = __builtin_amdgcn_raw_buffer_load_b128(rsV, voV[i] + ko, 0, 0);
+        }
+    };
+    auto commit_tile = [&](int buf) {
+        unsigned char *kd = smem + buf * 2 * BK * 128 + (PW * wave) * 1024 + lane * 16;
+#pragma unroll
+        for (int i = 0; i < PW; i++) {
+            *reinterpret_cast<u32x4v *>(kd + i * 1024) = stK[i];
+            *reinterpret_cast<u32x4v *>(kd + BK * 128 + i * 1024) = stV[i];
+        }
+    };
+    auto dma_tile = [&](int k0, int buf) {""")
+    rep("""        dma_tile(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();""", """        fetch_tile(0);
+        commit_tile(0);
+        __syncthreads();""")
+    rep("""            if (k0 + BK < N) dma_tile(k0 + BK, ring ^ 1);""", """            if (k0 + BK < N) fetch_tile(k0 + BK);""")
+    rep("""        if (DMA) {                                     // the next tile has landed and nobody still reads this one
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();""", """        if (DMA) {                                     // the next tile: registers -> the other buffer (nobody reads it during this tile)
+            if (k0 + BK < N) commit_tile(ring ^ 1);
+            __syncthreads();""")
+    return "typedef unsigned u32x4v __attribute__((ext_vector_type(4)));\n" + t
+
+
 VARIANTS = {"base": lambda t: t, "noprio": noprio, "prio_pv": prio_pv_only, "prio_qk": prio_qk_only, "occ3": occ3,
-            "occ3_noprio": lambda t: occ3(noprio(t)), "bk2": lambda t: bk2(noprio(t)), "bk2_pipe": lambda t: bk2(v_pipe(t))}
+            "occ3_noprio": lambda t: occ3(noprio(t)), "regstage": regstage, "bk2": lambda t: bk2(noprio(t)), "bk2_pipe": lambda t: bk2(v_pipe(t))}
 VARIANTS.update({k: v for k, v in globals().items() if k.startswith("v_") and callable(v)})
 
 
