@@ -375,6 +375,48 @@ def vit_forward_roofline(trainer, wimg, dev, crop):
             "note": "algorithmic FLOPs of the fp32 reference / time; bf16x3 issues 3 MFMA terms per product, fp16c8 ~2.08 in the projections"}
 
 
+def live_accuracy_check(trainer, wimg, lab, box, n=4):
+    """`tolerance_met` is read from the committed record (which must name this tree's kernel sources).  This is the same comparison made
+    IN THE RUN: the teacher pass in the benchmarked mode against the bf16x3 pass (16 significant bits, on other kernels -- split-row GEMMs,
+    attn_fwd_x3; 2.7e-5 from the fp32 CPU oracle on record) on the first n images of the bench batch -- CAM planes, label maps, masks.  A kernel
+    regression, another ROCm or another GPU shows here.  Gate: label agreement and mask mIoU >= 0.999; the normalised-plane figure is reported
+    (it carries the conditioning of the planes: DESIGN.md section 3)."""
+    import numpy as np
+    from cosa_amd.utils import seg_helper
+    from cosa_amd.models import build_model
+    args = trainer.args
+    mode = args.teacher_precision
+    # (a copy of the teacher: the trainer owns the 16-bit shadows and the captured graph of its own module, whose precision is fixed)
+    net = build_model(args).to(wimg.device).eval()
+    net.load_state_dict(trainer.model_AN.state_dict())
+    x, lb, bx = wimg[:n], lab[:n], box[:n]
+    res = {}
+    with torch.no_grad():
+        for m in (mode, "bf16x3"):
+            net.set_nograd_precision(m)
+            cam, cam_aux, _ = seg_helper.multi_scale_camseg(net, x, args.pseudo_scales)
+            masks = [seg_helper.cam2mask(x, bx, c * lb[:, :, None, None], lb, 0.7, 0.25).cpu().numpy() for c in (cam, cam_aux)]
+            res[m] = (cam.float().cpu(), cam_aux.float().cpu(), masks)
+    del net
+    act = lb.bool().cpu()
+    out = {"vs": f"bf16x3 teacher pass, first {n} images of the bench batch", "mode": mode}
+    rel, agree, iou = 0.0, 1.0, 1.0
+    for k in (0, 1):
+        g, o = res[mode][k], res["bf16x3"][k]
+        d = (g - o).abs().amax(dim=(2, 3))
+        rel = max(rel, float((d / o.abs().amax(dim=(2, 3)).clamp_min(1e-6))[act].max()))
+        mg, mo = res[mode][2][k], res["bf16x3"][2][k]
+        agree = min(agree, float(np.mean(mg == mo)))
+        ious = []
+        for c in np.union1d(np.unique(mg), np.unique(mo)):
+            a_, b_ = mg == c, mo == c
+            ious.append(float((a_ & b_).sum()) / float(max(1, (a_ | b_).sum())))
+        iou = min(iou, float(np.mean(ious)))
+    out.update({"normalised_cam_rel_err": float(f"{rel:.3e}"), "label_agreement": round(agree, 5), "mask_miou": round(iou, 5),
+                "ok": bool(agree >= 0.999 and iou >= 0.999)})
+    return out
+
+
 _BASE_TEXT = {
     "bf16": "bf16 operands (BASELINE configs[1] read literally; 8 significant bits)",
     "fp16": "fp16 operands (11 significant bits)",
@@ -619,7 +661,7 @@ def main():
             # fp32 CPU oracle)?  Read from the committed accuracy record of that mode (worst over every draw on record; the GPU tests that write
             # it assert the same bars, and the record must name the kernel sources of this tree: conformance()).  The default headline mode
             # does; the bf16-operand teacher (`fast_mode`) does not.
-            "tolerance_met": conformance(opt.teacher_precision, opt.crop)["tolerance_met"],
+            "tolerance_met": conformance(opt.teacher_precision, opt.crop)["tolerance_met"],          # (and the live check below: set after it ran)
             "accuracy_vs_fp32_cpu_oracle": conformance(opt.teacher_precision, opt.crop),
             "config": {"workload": f"{opt.dataset} {C + 1}-class, ViT-B/16 bf16, batch {opt.batch}/GPU x {opt.crop}x{opt.crop}, "
                                    f"teacher 3 scales x 2 flips + student fwd/bwd + cam2mask x2 + 5 losses + AdamW + EMA"
@@ -634,6 +676,11 @@ def main():
         if flop_img:
             out["step_mfma"] = {"achieved_TFLOPs": round(ips * flop_img / 1e12, 2), "peak_TFLOPs": PEAK_BF16 / 1e12 * world,
                                 "frac": round(ips * flop_img / (PEAK_BF16 * world), 4), "flop_per_img": flop_img}
+        try:
+            out["accuracy_live"] = live_accuracy_check(trainer, wimg, lab, box)
+            out["tolerance_met"] = bool(out["tolerance_met"] and (out["accuracy_live"]["ok"] or opt.teacher_precision == "bf16x3"))
+        except Exception as e:          # (never lose the bench line to the side check; an absent key reads as "not checked")
+            out["accuracy_live"] = {"error": repr(e)[:200]}
         vf = vit_forward_roofline(trainer, wimg, dev, opt.crop)
         if vf:
             out["vit_forward"] = vf
