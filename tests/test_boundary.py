@@ -213,3 +213,20 @@ def test_auto_teacher_precision_is_backed_by_the_committed_accuracy_record():
     if os.path.basename(rec) >= "r05":          # from round 5 on: the wide sweep and the bench's own batch size
         c = bench.conformance(resolve_teacher_precision("auto", 448), 448)
         assert c["lines"] >= 64 and c["seeds"] >= 32 and 16 in c["batch_sizes"], c
+
+
+def test_no_inline_asm_valu_on_mfma_accumulators():
+    """round 5: on gfx950 the wait states between an MFMA and a VALU read of its result are inserted by the compiler's hazard recognizer, which
+    does not look into asm statements.  `max3f` of the attention forward was `asm("v_max3_f32 ...")` on score accumulators: correct only while
+    the schedule happened to keep it far behind the MFMAs, run-to-run non-deterministic in every build that moved it
+    (profiles/r05_attn_variants.txt).  Rule since: no VALU instruction in inline asm in the files whose VALU code reads MFMA results, except
+    the listed address adds / loads / waits that touch no accumulator."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    allowed = {"attn_kernels.hip": (), "gemm_kernels.hip": ("v_add_u32",), "vit_kernels.hip": (), "split_kernels.hip": ("v_mul_f32",)}   # (split_kernels.hip has no MFMA)
+    for f, ok in allowed.items():
+        src = open(os.path.join(root, "cosa_amd", "csrc", f)).read()
+        src = re.sub(r"//[^\n]*", "", src)          # (comments may quote the old statement)
+        ops = set(re.findall(r'asm(?:\s+volatile)?\s*\(\s*"\s*(v_[a-z0-9_]+)', src))
+        assert ops <= set(ok), (f, ops - set(ok))
