@@ -598,3 +598,20 @@ def test_attention_backward_is_deterministic(B, N, H):
         nn_ops.attention(qkv, H).backward(go)
         grads.append(qkv.grad)
     assert torch.equal(grads[0], grads[1]) and torch.equal(grads[0], grads[2]) and torch.isfinite(grads[0].float()).all()
+
+
+@pytest.mark.parametrize("B,N,H", [(8, 1765, 12), (16, 785, 12)])
+def test_attention_fwd_nograd_c8_variant_is_deterministic_on_a_full_chip(B, N, H):
+    """the teacher's attention launch (fp16 q / k / v, c8 rows out) with every CU busy, twice: the same bytes.  Round 5 found the softmax's
+    `v_max3_f32` as inline asm on MFMA accumulators -- outside the compiler's MFMA -> VALU hazard handling: scheduling variants of the kernel
+    were run-to-run NON-deterministic at exactly these launch sizes while small launches stayed clean (profiles/r05_attn_variants.txt)."""
+    import ctypes
+    from cosa_amd import _C
+    L = _C.lib()
+    g = torch.Generator().manual_seed(7 + N)
+    qkv = (torch.randn(B, N, 3 * H * 64, generator=g) * 1.5).half().cuda()
+    outs = [torch.zeros(B * N, 4 * H * 64 + 128, device="cuda", dtype=torch.uint8) for _ in range(3)]
+    for o in outs:
+        _C.check(L.cosa_attn_fwd_f16c8(_C.ptr(qkv), _C.ptr(o), None, B, N, H, 64, ctypes.c_float(0.125), None, _C.stream_ptr()), "cosa_attn_fwd_f16c8")
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
