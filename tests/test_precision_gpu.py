@@ -572,12 +572,13 @@ def test_headline_modes_on_held_out_seeds_sweep(seed):
         raise err
 
 
-@pytest.mark.skipif(os.environ.get("COSA_ACCURACY_B16", "0") != "1", reason="50 s of CPU oracle: run with COSA_ACCURACY_B16=1 (the committed record holds its lines)")
-def test_headline_mode_on_the_bench_batch_b16():
+@pytest.mark.skipif(os.environ.get("COSA_ACCURACY_B16", "0") != "1", reason="50 s of CPU oracle per draw: run with COSA_ACCURACY_B16=1 (the committed record holds its lines)")
+@pytest.mark.parametrize("seed", [int(x) for x in os.environ.get("COSA_ACCURACY_B16_SEEDS", "7").split(",")])
+def test_headline_mode_on_the_bench_batch_b16(seed):
     """BASELINE configs[1] itself: b = 16 x 448^2 through the fused teacher (M = 87 904 token rows per pass, the launch shapes of the bench)
     against the fp32 CPU oracle run two images at a time"""
     try:
-        _check_teacher(_auto_mode(448), 7, 448, bars=NORTH_STAR, b=16)
+        _check_teacher(_auto_mode(448), seed, 448, bars=NORTH_STAR, b=16)
     finally:
         _ORACLE.clear()
 
