@@ -204,8 +204,16 @@ def regstage(t):
     return "typedef unsigned u32x4v __attribute__((ext_vector_type(4)));\n" + t
 
 
+
+def occ1(t):
+    """one workgroup per CU (LDS padded to 96 KB): how much do the two co-resident waves of a SIMD hide of each other?"""
+    a = "    __shared__ __attribute__((aligned(16))) unsigned char smem[(DMA ? 4 : 2) * BK * 128];"
+    assert t.count(a) == 1
+    return t.replace(a, "    __shared__ __attribute__((aligned(16))) unsigned char smem[(DMA ? 4 : 2) * BK * 128 + (NW == 4 ? 64 * 1024 : 0)];")
+
+
 VARIANTS = {"base": lambda t: t, "noprio": noprio, "prio_pv": prio_pv_only, "prio_qk": prio_qk_only, "occ3": occ3,
-            "occ3_noprio": lambda t: occ3(noprio(t)), "regstage": regstage, "bk2": lambda t: bk2(noprio(t)), "bk2_pipe": lambda t: bk2(v_pipe(t))}
+            "occ3_noprio": lambda t: occ3(noprio(t)), "regstage": regstage, "occ1": occ1, "bk2": lambda t: bk2(noprio(t)), "bk2_pipe": lambda t: bk2(v_pipe(t))}
 VARIANTS.update({k: v for k, v in globals().items() if k.startswith("v_") and callable(v)})
 
 
