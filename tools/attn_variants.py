@@ -53,7 +53,10 @@ def _pipe(t, sgb):
     old = t[a:b]
     # the softmax of one query block = body of `for (int u = 0; u < 2; u++) {` ... up to the PV section
     i0 = old.index("        for (int u = 0; u < 2; u++) {\n            if constexpr (tail) {")
-    i1 = old.index("        __builtin_amdgcn_s_setprio(1);\n#pragma unroll\n        for (int kb = 0; kb < 2; kb++)\n#pragma unroll\n            for (int sp = 0; sp < 2; sp++) {")
+    pv = "#pragma unroll\n        for (int kb = 0; kb < 2; kb++)\n#pragma unroll\n            for (int sp = 0; sp < 2; sp++) {"
+    i1 = old.index(pv)
+    if old[:i1].endswith("        __builtin_amdgcn_s_setprio(1);\n"):
+        i1 -= len("        __builtin_amdgcn_s_setprio(1);\n")
     body = old[i0:i1]
     body = body[body.index("{\n") + 2:]
     body = body[:body.rindex("        }\n")]            # drop the loop's closing brace
@@ -213,7 +216,7 @@ def occ1(t):
 
 
 VARIANTS = {"base": lambda t: t, "noprio": noprio, "prio_pv": prio_pv_only, "prio_qk": prio_qk_only, "occ3": occ3,
-            "occ3_noprio": lambda t: occ3(noprio(t)), "regstage": regstage, "occ1": occ1, "bk2": lambda t: bk2(noprio(t)), "bk2_pipe": lambda t: bk2(v_pipe(t))}
+            "occ3_noprio": lambda t: occ3(noprio(t)), "regstage": regstage, "occ1": occ1, "occ1_pipe": lambda t: occ1(v_pipe(t)), "occ1_regstage": lambda t: occ1(regstage(t)), "bk2": lambda t: bk2(noprio(t)), "bk2_pipe": lambda t: bk2(v_pipe(t))}
 VARIANTS.update({k: v for k, v in globals().items() if k.startswith("v_") and callable(v)})
 
 
