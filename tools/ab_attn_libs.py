@@ -18,7 +18,9 @@ for N in (1765, 785, 197):
     g = torch.Generator(device="cpu").manual_seed(N)
     qkv = (torch.randn(B, N, 3 * H * 64, generator=g) * 1.5).to(dev).half()
     outs = [torch.zeros(B * N, 4 * H * 64 + 128, device=dev, dtype=torch.uint8) for _ in libs]
-    fs = [(lambda L=L, o=o: L.cosa_attn_fwd_f16c8(ptr(qkv), ptr(o), None, B, N, H, 64, 0.125, None, st())) for (_, L), o in zip(libs, outs)]
+    timing = os.environ.get("ATTN_TIMING") == "1"          # builds of tools/attn_variants.py `timing`: per-section cycle sums in stamps[128 ..]
+    stamp = [torch.zeros(256, device=dev, dtype=torch.int64) for _ in libs]
+    fs = [(lambda L=L, o=o, sp=sp: L.cosa_attn_fwd_f16c8(ptr(qkv), ptr(o), None, B, N, H, 64, 0.125, ptr(sp) if timing else None, st())) for (_, L), o, sp in zip(libs, outs, stamp)]
     for f in fs:
         for _ in range(3):
             assert f() == 0
@@ -47,6 +49,15 @@ for N in (1765, 785, 197):
             e.record()
             torch.cuda.synchronize()
             acc.append(a.elapsed_time(e) / 10 * 1e3)
+    if timing:
+        for (name, _), f, sp in zip(libs, fs, stamp):
+            sp.zero_()
+            sp[:128:2] = torch.iinfo(torch.int64).max          # (the launch-span slots: min start / max end)
+            f()
+            torch.cuda.synchronize()
+            v = sp[128:134].cpu().tolist()
+            if v[5]:
+                print(f"N={N:5d} {name}: cycles per wave and tile: dma issue {v[0] / v[5]:.0f} | K reads + QK MFMAs {v[1] / v[5]:.0f} | softmax (incl. waiting for the scores) {v[2] / v[5]:.0f} | V reads + PV MFMAs {v[3] / v[5]:.0f} | vmcnt + barrier {v[4] / v[5]:.0f} | total {sum(v[:5]) / v[5]:.0f}  ({v[5]} wave-tiles)")
     fl = 4.0 * N * N * 64 * B * H
     base = sorted(ts[0])[3]
     for (name, _), t, s in zip(libs, ts, same):

@@ -215,8 +215,68 @@ def occ1(t):
     return t.replace(a, "    __shared__ __attribute__((aligned(16))) unsigned char smem[(DMA ? 4 : 2) * BK * 128 + (NW == 4 ? 64 * 1024 : 0)];")
 
 
+
+def timing(t):
+    """s_memtime stamps at the section boundaries of a tile, summed per wave and added up in stamps[128 ..] (tools/ab_attn_libs.py prints them with
+    ATTN_TIMING=1): where do a wave's cycles go?  (the stamps wait for outstanding LDS reads: the sections are slightly serialised)"""
+    def rep(a, b, cnt=1):
+        nonlocal t
+        assert t.count(a) == cnt, (t.count(a), a)
+        t = t.replace(a, b)
+    rep("    int ring = 0;\n", "    int ring = 0;\n    unsigned long long tsum[6] = {0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();\n"
+        "#define TS(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); tsum[i] += t_ - tprev; tprev = t_; } while (0)\n")
+    rep("        if (!DMA) __syncthreads();\n#pragma unroll\n        for (int i = 0; i < (DMA ? 0 : PW); i++) {", "        TS(0);\n        if (!DMA) __syncthreads();\n#pragma unroll\n        for (int i = 0; i < (DMA ? 0 : PW); i++) {")
+    # after the QK MFMAs: right before the softmax loop over u
+    rep("#pragma unroll\n        for (int u = 0; u < 2; u++) {\n            if constexpr (tail) {", "        TS(1);\n#pragma unroll\n        for (int u = 0; u < 2; u++) {\n            if constexpr (tail) {")
+    # before the PV section
+    rep("#pragma unroll\n        for (int kb = 0; kb < 2; kb++)\n#pragma unroll\n            for (int sp = 0; sp < 2; sp++) {", "        TS(2);\n#pragma unroll\n        for (int kb = 0; kb < 2; kb++)\n#pragma unroll\n            for (int sp = 0; sp < 2; sp++) {")
+    rep("        if (DMA) {                                     // the next tile has landed and nobody still reads this one\n", "        TS(3);\n        if (DMA) {                                     // the next tile has landed and nobody still reads this one\n")
+    rep("            ring ^= 1;\n        }\n    };\n", "            ring ^= 1;\n        }\n        TS(4);\n        tsum[5] += 1;\n    };\n")
+    rep("    if (stamps) {\n        __syncthreads();", "    if (stamps && lane == 0 && busy) {\n        for (int i = 0; i < 6; i++) atomicAdd(&stamps[128 + i], tsum[i]);\n    }\n    if (stamps) {\n        __syncthreads();")
+    return t
+
+
+
+def vprefetch(t, early=True):
+    """PV section with the V^T fragments of key group g + 1 requested BEFORE the four MFMAs of group g are issued (the compiler's own schedule
+    waits for each group's transposing reads right in front of its MFMAs: ~10 exposed LDS latencies per tile), the first group's reads above the
+    softmax; the same MFMAs in the same order -> bit-identical"""
+    a = t.index("#pragma unroll\n        for (int kb = 0; kb < 2; kb++)\n#pragma unroll\n            for (int sp = 0; sp < 2; sp++) {\n                const int keyb = kb * 32 + 16 * sp + 4 * hh;")
+    b = t.index("        if (DMA) {                                     // the next tile has landed", a)
+    new_pv = """        {
+            op16x8 vc0 = vpre0, vc1 = vpre1;
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int kb = g >> 1, sp = g & 1;
+                op16x8 vn0 = vc0, vn1 = vc1;
+                if (g < 3) {
+                    const int keyn = ((g + 1) >> 1) * 32 + 16 * ((g + 1) & 1) + 4 * hh;
+                    vn0 = v_frag(Vs, keyn, 0, lane);
+                    vn1 = v_frag(Vs, keyn, 1, lane);
+                }
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const op16x8 pf = __builtin_shufflevector(__builtin_shufflevector(pk[u][kb][4 * sp], pk[u][kb][4 * sp + 1], 0, 1, 2, 3),
+                                                              __builtin_shufflevector(pk[u][kb][4 * sp + 2], pk[u][kb][4 * sp + 3], 0, 1, 2, 3),
+                                                              0, 1, 2, 3, 4, 5, 6, 7);
+                    o[u][0] = COSA_MFMA_32x32x16(vc0, pf, o[u][0], 0, 0, 0);
+                    o[u][1] = COSA_MFMA_32x32x16(vc1, pf, o[u][1], 0, 0, 0);
+                }
+                vc0 = vn0; vc1 = vn1;
+            }
+        }
+        }
+"""
+    t = t[:a] + new_pv + t[b:]
+    # the first group's fragments: requested before the softmax (V does not depend on it)
+    anchor = "#pragma unroll\n        for (int u = 0; u < 2; u++) {\n            if constexpr (tail) {"
+    assert t.count(anchor) == 1
+    t = t.replace(anchor, "        const op16x8 vpre0 = v_frag(Vs, 4 * hh, 0, lane), vpre1 = v_frag(Vs, 4 * hh, 1, lane);\n" + anchor)
+    return t
+
+
 VARIANTS = {"base": lambda t: t, "noprio": noprio, "prio_pv": prio_pv_only, "prio_qk": prio_qk_only, "occ3": occ3,
-            "occ3_noprio": lambda t: occ3(noprio(t)), "regstage": regstage, "occ1": occ1, "occ1_pipe": lambda t: occ1(v_pipe(t)), "occ1_regstage": lambda t: occ1(regstage(t)), "bk2": lambda t: bk2(noprio(t)), "bk2_pipe": lambda t: bk2(v_pipe(t))}
+            "occ3_noprio": lambda t: occ3(noprio(t)), "regstage": regstage, "occ1": occ1, "vprefetch": vprefetch, "occ1_vprefetch": lambda t: occ1(vprefetch(t)), "timing": timing, "occ1_timing": lambda t: occ1(timing(t)), "occ1_pipe": lambda t: occ1(v_pipe(t)), "occ1_regstage": lambda t: occ1(regstage(t)), "bk2": lambda t: bk2(noprio(t)), "bk2_pipe": lambda t: bk2(v_pipe(t))}
 VARIANTS.update({k: v for k, v in globals().items() if k.startswith("v_") and callable(v)})
 
 
