@@ -280,6 +280,12 @@ VARIANTS = {"base": lambda t: t, "noprio": noprio, "prio_pv": prio_pv_only, "pri
 VARIANTS.update({k: v for k, v in globals().items() if k.startswith("v_") and callable(v)})
 
 
+FLAG_VARIANTS = {"bias0": ["-mllvm", "-amdgpu-schedule-metric-bias=0"],
+                 "iter_ilp": ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"],
+                 "iter_minreg": ["-mllvm", "-amdgpu-sched-strategy=iterative-minreg"],
+                 "max_ilp": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}          # compiler-flag variants of the unpatched source
+
+
 def build(name):
     global CMAX
     CMAX = name.endswith("_cmax")
@@ -288,7 +294,8 @@ def build(name):
     d = os.path.join(top, "cosa_amd", "csrc")
     shutil.copytree(B.CSRC, d)
     os.symlink(os.path.join(ROOT, "include"), os.path.join(top, "include"))          # (common.hpp includes ../../include/cosa_hip.h)
-    open(os.path.join(d, "attn_kernels.hip"), "w").write(fwd2(VARIANTS[name[:-5] if CMAX else name]))
+    flags = FLAG_VARIANTS.get(name, [])
+    open(os.path.join(d, "attn_kernels.hip"), "w").write(fwd2(VARIANTS["base" if name in FLAG_VARIANTS else (name[:-5] if CMAX else name)]))
     hipcc = B._hipcc()
     objs = []
     for key, extra in B.SOURCES.items():
@@ -296,7 +303,7 @@ def build(name):
         op = os.path.join(B.OBJDIR, src.replace(".hip", ("_" + tag if tag else "") + ".o"))
         if src == "attn_kernels.hip":
             op = os.path.join(d, "attn" + ("_" + tag if tag else "") + ".o")
-            subprocess.check_call([hipcc, "-c", os.path.join(d, src), "-o", op] + B.COMMON + extra)
+            subprocess.check_call([hipcc, "-c", os.path.join(d, src), "-o", op] + B.COMMON + extra + flags)
         objs.append(op)
     out = os.path.join(ROOT, "cosa_amd", "lib", "variants")
     os.makedirs(out, exist_ok=True)
