@@ -375,12 +375,13 @@ def vit_forward_roofline(trainer, wimg, dev, crop):
             "note": "algorithmic FLOPs of the fp32 reference / time; bf16x3 issues 3 MFMA terms per product, fp16c8 ~2.08 in the projections"}
 
 
-def live_accuracy_check(trainer, wimg, lab, box, n=4):
+def live_accuracy_check(trainer, wimg, lab, box, n=16):
     """`tolerance_met` is read from the committed record (which must name this tree's kernel sources).  This is the same comparison made
     IN THE RUN: the teacher pass in the benchmarked mode against the bf16x3 pass (16 significant bits, on other kernels -- split-row GEMMs,
     attn_fwd_x3; 2.7e-5 from the fp32 CPU oracle on record) on the first n images of the bench batch -- CAM planes, label maps, masks.  A kernel
-    regression, another ROCm or another GPU shows here.  Gate: label agreement and mask mIoU >= 0.999; the normalised-plane figure is reported
-    (it carries the conditioning of the planes: DESIGN.md section 3)."""
+    regression, another ROCm or another GPU shows here.  It is a gross-error gate, not a second lottery on one batch: label agreement >= 0.999 and
+    mask mIoU >= 0.998 (BASELINE's own bars on every draw are what the record holds: a class region of a few pixels moves one batch's mIoU by
+    1e-3 at a label agreement of 0.99999); the normalised-plane figure is reported (it carries the conditioning of the planes)."""
     import numpy as np
     from cosa_amd.utils import seg_helper
     from cosa_amd.models import build_model
@@ -399,7 +400,7 @@ def live_accuracy_check(trainer, wimg, lab, box, n=4):
             res[m] = (cam.float().cpu(), cam_aux.float().cpu(), masks)
     del net
     act = lb.bool().cpu()
-    out = {"vs": f"bf16x3 teacher pass, first {n} images of the bench batch", "mode": mode}
+    out = {"vs": f"bf16x3 teacher pass, first {int(x.shape[0])} images of the bench batch", "mode": mode, "gate": "label agreement >= 0.999, mask mIoU >= 0.998"}
     rel, agree, iou = 0.0, 1.0, 1.0
     for k in (0, 1):
         g, o = res[mode][k], res["bf16x3"][k]
@@ -413,7 +414,7 @@ def live_accuracy_check(trainer, wimg, lab, box, n=4):
             ious.append(float((a_ & b_).sum()) / float(max(1, (a_ | b_).sum())))
         iou = min(iou, float(np.mean(ious)))
     out.update({"normalised_cam_rel_err": float(f"{rel:.3e}"), "label_agreement": round(agree, 5), "mask_miou": round(iou, 5),
-                "ok": bool(agree >= 0.999 and iou >= 0.999)})
+                "ok": bool(agree >= 0.999 and iou >= 0.998)})
     return out
 
 
