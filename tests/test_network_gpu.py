@@ -415,6 +415,9 @@ def test_bench_contract_small(flags):
               "data", "config", "roofline"):
         assert k in d, k
     assert d["value"] > 0 and d["n_gpus"] == 1 and d["steps"] == int(flags[1]) and d["roofline"]["bound"] in ("mfma", "hbm")
+    # the in-run accuracy check (benchmarked teacher mode against the bf16x3 pass on the bench batch) ran and found no gross error
+    live = d["accuracy_live"]
+    assert "error" not in live and live["label_agreement"] >= 0.999 and live["mask_miou"] >= 0.998 and live["ok"] is True, live
 
 
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
