@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--usegmm", action="store_true", help="adaptive thresholds: 3-component mixture fitted to the CAM queue every step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--teacher-precision", default="auto", type=_mode_arg,
-                    metavar="{auto,bf16,fp16,bf16x3,fp16c8[-N[mK]|-xN[mK]],fp16c4[...]}",
+                    metavar="{auto,bf16,fp16,bf16x3,fp16x3,fp16c8[-N[mK]|-xN[mK]],fp16c4[...]}",
                     help="MFMA operand precision of the teacher's no-grad passes in the HEADLINE run (DESIGN.md section 3).  The default (`auto`) is the "
                          "cheapest mode that met BASELINE.json's tolerance (1e-3 relative on fp32 CAMs, mask IoU >= 0.999) on EVERY draw of the committed "
                          "accuracy record (train_step.resolve_teacher_precision; margins: DESIGN.md section 3); "
@@ -87,6 +87,7 @@ def newest_profile(name):
 
 TEACHER_CSRC = ("gemm_kernels.hip", "attn_kernels.hip", "split_kernels.hip", "vit_kernels.hip", "label_kernels.hip", "c4.hpp", "c8.hpp",
                 "op16.hpp", "common.hpp", "kernels.hpp")          # (= tests/test_precision_gpu.py:TEACHER_CSRC; tests/test_boundary.py checks)
+TEACHER_HOST = ("build.py", "models/vit.py")          # compiler flags and the block -> operand-format map are part of "the kernels the record was taken with"
 
 
 def teacher_csrc_hash():
@@ -94,60 +95,97 @@ def teacher_csrc_hash():
     h = hashlib.sha256()
     for f in TEACHER_CSRC:
         h.update(open(os.path.join(ROOT, "cosa_amd", "csrc", f), "rb").read())
+    for f in TEACHER_HOST:
+        h.update(open(os.path.join(ROOT, "cosa_amd", f), "rb").read())
     return h.hexdigest()[:16]
 
 
+# the pre-registered conformance criterion (= the constants at the top of tests/test_precision_gpu.py; tests/test_boundary.py checks they agree)
+CAM_BAR, COND_MAX, FP64_FACTOR, AGREE_BAR, MIOU_BAR, MIN_DRAWS = 1e-3, 50.0, 4.0, 0.999, 0.999, 64
+
+
+def parse_accuracy_record(path):
+    """lines of an accuracy record (tests/test_precision_gpu.py:_check_teacher) -> (rows, csrc hash).  Round-6 lines carry the per-plane
+    bookkeeping (`| planes N literal-ok L exempt E fail F [...]`) and the confusion counts (`| conf class:tp/fp/fn,...`)."""
+    import re
+    rows, rec_hash = [], None
+    pat = re.compile(r"teacher (\S+)\s+S=(\d+) b=(\d+) seed=(\d+)\s+(\S+)\s*: normalised-CAM rel err (\S+)\s+label agreement (\S+)\s+mask mIoU (\S+)"
+                     r"(?:\s+own-scale err (\S+)\s+worst conditioning (\S+))?(?:\s+\| planes (\d+) literal-ok (\d+) exempt (\d+) fail (\d+)([^|]*)\| conf (\S*))?")
+    for ln in open(path):
+        if ln.startswith("#") and "csrc_sha256_16=" in ln:
+            rec_hash = ln.split("csrc_sha256_16=")[1].split()[0]
+        m = pat.match(ln)
+        if not m:
+            continue
+        r = dict(mode=m.group(1), S=int(m.group(2)), b=int(m.group(3)), seed=int(m.group(4)), set=m.group(5), rel=float(m.group(6)),
+                 agree=float(m.group(7)), iou=float(m.group(8)), own=float(m.group(9)) if m.group(9) else None,
+                 cond=float(m.group(10)) if m.group(10) else None, planes=None)
+        if m.group(11) is not None:
+            r.update(planes=int(m.group(11)), literal_ok=int(m.group(12)), exempt=int(m.group(13)), fail=int(m.group(14)), notes=m.group(15).strip(),
+                     conf={int(c): [int(x) for x in v.split("/")] for c, v in (e.split(":") for e in m.group(16).split(",") if e)})
+        rows.append(r)
+    return rows, rec_hash
+
+
+def pooled_miou(conf):
+    """{class: [tp, fp, fn]} summed over draws -> (mean IoU over the classes the oracle's masks contain, min class IoU) -- the reference's
+    scoring (utils/evaluation.py:17-35: one confusion matrix over the set, iu = diag / (row + col - diag), mean over the rows that are present)"""
+    ious = [v[0] / (v[0] + v[1] + v[2]) for v in conf.values() if v[0] + v[2] > 0]
+    return (sum(ious) / len(ious), min(ious)) if ious else (1.0, 1.0)
+
+
 def conformance(mode, crop):
-    """Does teacher-operand mode `mode` meet BASELINE.json's tolerance ("1e-3 relative on fp32 CAMs ... mask IoU >= 0.999")?  Not a table of
-    names: the worst line of the mode in the newest committed profiles/rNN_accuracy_teacher.txt -- written by tests/test_precision_gpu.py on
-    the GPU (fused HIP teacher vs the fp32 CPU oracle: round 4's seven weight / batch seeds, 40 held-out draws, 32 more drawn after the default
-    was chosen, one batch of the bench's own b = 16), which asserts the same bars.  Criterion (records from round 5 on): the CAM error in the
-    CAM's own units (`own-scale err`: the difference of the normalised planes x what the normalisation divides by / the magnitude of the class
-    logits) <= 1e-3, label agreement >= 0.999, mask mIoU >= 0.999 on EVERY draw.  The difference of the normalised planes themselves is
-    reported beside it (`normalised_cam_rel_err_max`, `normalised_draws_over_bar`): on planes of barely activated classes it measures the
-    plane, not the operands -- the reference's own fp32 arithmetic is 2.5e-4 from float64 on the worst one (profiles/r05_oracle_conditioning.txt,
-    DESIGN.md section 3).  The record names the kernel sources it was taken with (sha256 of the teacher's files): a record of other kernels
-    does not count (`tolerance_met` false, with the reason)."""
+    """Does teacher-operand mode `mode` meet BASELINE.json's tolerance ("1e-3 relative on fp32 CAMs ... mask IoU >= 0.999") at this crop?  Read
+    from the newest committed profiles/rNN_accuracy_teacher.txt (written on the GPU by tests/test_precision_gpu.py: fused HIP teacher vs the fp32
+    CPU oracle, which asserts the same rule per draw), by the criterion PRE-REGISTERED at the top of that test file:
+      (a) every active (image, class) plane: max |delta| of the min-max NORMALISED plane <= 1e-3 (the literal bar), or
+      (b) -- only for a plane whose conditioning (class-logit magnitude / what the normalisation divides by, from the oracle) is > 50 -- the
+          exemption: own-scale err <= 1e-3 AND |HIP - float64 oracle| <= 1e-3 + 4 x |fp32 oracle - float64 oracle| on that plane;
+      (c) label agreement >= 0.999 on every draw, and mask mIoU >= 0.999 from ONE confusion matrix pooled over all draws (per CAM set), the way
+          the reference scores IoU (utils/evaluation.py:17-35); the per-draw minimum is reported as a diagnostic;
+      (d) at least 64 draws of the mode on record (8 at this crop).
+    `planes_exempt` / `planes_failed` count the planes that took (b) / failed it.  The record names the sources it was taken with (sha256 over the
+    teacher's kernel files, the build flags and the block -> format map): a record of another tree does not count."""
     f = newest_profile("accuracy_teacher.txt")
     if f is None:
         return {"tolerance_met": False, "note": "no committed accuracy file"}
-    rows, rec_hash = [], None
-    num = lambda ln, key: float(ln.split(key)[1].split()[0])
-    for ln in open(f):
-        if ln.startswith("#") and "csrc_sha256_16=" in ln:
-            rec_hash = ln.split("csrc_sha256_16=")[1].split()[0]
-        if ("teacher %-8s " % mode) in ln and f"S={crop} " in ln:
-            try:
-                rows.append(dict(rel=num(ln, "rel err"), agree=num(ln, "label agreement"), iou=num(ln, "mask mIoU"),
-                                 own=num(ln, "own-scale err") if "own-scale err" in ln else None,
-                                 seed=ln.split("seed=")[1].split()[0] if "seed=" in ln else "3", b=ln.split(" b=")[1].split()[0] if " b=" in ln else "2"))
-            except (IndexError, ValueError):
-                pass
+    rows_all, rec_hash = parse_accuracy_record(f)
+    rows_mode = [r for r in rows_all if r["mode"] == mode]
+    rows = [r for r in rows_mode if r["S"] == crop]
     if not rows:
         return {"tolerance_met": False, "note": f"no line for mode {mode} at S={crop} in {os.path.basename(f)}"}
-    has_own = all(r["own"] is not None for r in rows)
-    worst = {"normalised_cam_rel_err_max": max(r["rel"] for r in rows), "label_agreement_min": min(r["agree"] for r in rows),
-             "mask_miou_min": min(r["iou"] for r in rows)}
-    draws = {(r["seed"], r["b"]) for r in rows}
-    if has_own:
-        worst = {"cam_rel_err_own_scale_max": max(r["own"] for r in rows), **worst}
-        over = {(r["seed"], r["b"]) for r in rows if r["rel"] > 1e-3}
-        worst["normalised_draws_over_bar"] = f"{len(over)} of {len(draws)}"
-        ok = worst["cam_rel_err_own_scale_max"] <= 1e-3 and worst["label_agreement_min"] >= 0.999 and worst["mask_miou_min"] >= 0.999
-        lead = worst["cam_rel_err_own_scale_max"]
-        bars = "CAM rel err in the CAM's own units <= 1e-3, label agreement >= 0.999, mask mIoU >= 0.999 on every draw (BASELINE.json north_star); normalised-plane figure reported beside"
-    else:          # records of rounds 2-4: the normalised figure was the criterion
-        ok = worst["normalised_cam_rel_err_max"] <= 1e-3 and worst["mask_miou_min"] >= 0.999
-        lead = worst["normalised_cam_rel_err_max"]
-        bars = "rel err <= 1e-3, mask mIoU >= 0.999 (BASELINE.json north_star)"
-    out = {"tolerance_met": bool(ok), **worst, "margin_on_rel_err": round(1e-3 / max(lead, 1e-12), 2),
-           "seeds": len({r["seed"] for r in rows}), "lines": len(rows), "batch_sizes": sorted({int(r["b"]) for r in rows}), "bars": bars,
-           "source": "profiles/" + os.path.basename(f) + " (tests/test_precision_gpu.py, fused HIP teacher vs fp32 CPU oracle)"}
-    if rec_hash is not None:          # (records of rounds 1-4 carry no hash)
-        out["kernels_match_record"] = rec_hash == teacher_csrc_hash()
-        if not out["kernels_match_record"]:
-            out["tolerance_met"] = False
-            out["note"] = f"the accuracy record was taken with other teacher kernels (csrc hash {rec_hash}, tree {teacher_csrc_hash()}): re-run the sweep"
+    if any(r["planes"] is None for r in rows):
+        return {"tolerance_met": False, "note": f"{os.path.basename(f)} predates the pre-registered criterion (no per-plane bookkeeping): re-take the record"}
+    draws, draws_mode = {(r["seed"], r["b"]) for r in rows}, {(r["S"], r["seed"], r["b"]) for r in rows_mode}
+    pooled = {}
+    for r in rows:
+        acc = pooled.setdefault(r["set"], {})
+        for c, v in r["conf"].items():
+            acc[c] = [x + y for x, y in zip(acc.get(c, [0, 0, 0]), v)]
+    pm = {k: pooled_miou(v) for k, v in pooled.items()}
+    failed = [f"seed {r['seed']} b={r['b']} {r['set']}: {r['notes']}" for r in rows if r["fail"]]
+    out = {"planes": sum(r["planes"] for r in rows), "planes_exempt": sum(r["exempt"] for r in rows), "planes_failed": sum(r["fail"] for r in rows),
+           "normalised_cam_rel_err_max": max(r["rel"] for r in rows),
+           "normalised_cam_rel_err_max_non_exempt": max([r["rel"] for r in rows if not r["exempt"] and not r["fail"]] or [0.0]),
+           "cam_rel_err_own_scale_max": max(r["own"] for r in rows), "worst_conditioning": max(r["cond"] for r in rows),
+           "label_agreement_min": min(r["agree"] for r in rows),
+           "mask_miou_pooled": {k: round(v[0], 6) for k, v in pm.items()}, "mask_iou_pooled_min_class": {k: round(v[1], 6) for k, v in pm.items()},
+           "mask_miou_per_draw_min": min(r["iou"] for r in rows),
+           "draws": len(draws), "draws_all_crops": len(draws_mode), "lines": len(rows), "seeds": len({r["seed"] for r in rows}),
+           "batch_sizes": sorted({r["b"] for r in rows})}
+    ok = (out["planes_failed"] == 0 and out["label_agreement_min"] >= AGREE_BAR and min(v[0] for v in pm.values()) >= MIOU_BAR
+          and len(draws_mode) >= MIN_DRAWS and len(draws) >= 8)
+    out = {"tolerance_met": bool(ok), **out,
+           "bars": f"per plane: normalised-CAM |delta| <= {CAM_BAR:g}, or (conditioning > {COND_MAX:g}: own-scale err <= {CAM_BAR:g} and |HIP - fp64| <= {CAM_BAR:g} + "
+                   f"{FP64_FACTOR:g} x |fp32 - fp64|); label agreement >= {AGREE_BAR} per draw; pooled-confusion mask mIoU >= {MIOU_BAR}; >= {MIN_DRAWS} draws "
+                   "(pre-registered: tests/test_precision_gpu.py)",
+           "source": "profiles/" + os.path.basename(f) + " (tests/test_precision_gpu.py, fused HIP teacher vs fp32 / float64 CPU oracle)"}
+    if failed:
+        out["failed_planes"] = failed[:8]
+    out["kernels_match_record"] = rec_hash == teacher_csrc_hash()
+    if not out["kernels_match_record"]:
+        out["tolerance_met"] = False
+        out["note"] = f"the accuracy record was taken with another tree (source hash {rec_hash}, tree {teacher_csrc_hash()}): re-run tools/accuracy_evidence.sh"
     return out
 
 
@@ -379,9 +417,9 @@ def live_accuracy_check(trainer, wimg, lab, box, n=16):
     """`tolerance_met` is read from the committed record (which must name this tree's kernel sources).  This is the same comparison made
     IN THE RUN: the teacher pass in the benchmarked mode against the bf16x3 pass (16 significant bits, on other kernels -- split-row GEMMs,
     attn_fwd_x3; 2.7e-5 from the fp32 CPU oracle on record) on the first n images of the bench batch -- CAM planes, label maps, masks.  A kernel
-    regression, another ROCm or another GPU shows here.  It is a gross-error gate, not a second lottery on one batch: label agreement >= 0.999 and
-    mask mIoU >= 0.998 (BASELINE's own bars on every draw are what the record holds: a class region of a few pixels moves one batch's mIoU by
-    1e-3 at a label agreement of 0.99999); the normalised-plane figure is reported (it carries the conditioning of the planes)."""
+    regression, another ROCm or another GPU shows here.  It is a gross-error gate (`gross_error_ok`), not the tolerance: label agreement >= 0.999
+    and mask mIoU over the masks of the whole batch >= 0.999; the normalised-plane figure is reported (it carries the conditioning of the planes).
+    bench.py sets `tolerance_met` false when this check fails OR cannot run."""
     import numpy as np
     from cosa_amd.utils import seg_helper
     from cosa_amd.models import build_model
@@ -400,7 +438,8 @@ def live_accuracy_check(trainer, wimg, lab, box, n=16):
             res[m] = (cam.float().cpu(), cam_aux.float().cpu(), masks)
     del net
     act = lb.bool().cpu()
-    out = {"vs": f"bf16x3 teacher pass, first {int(x.shape[0])} images of the bench batch", "mode": mode, "gate": "label agreement >= 0.999, mask mIoU >= 0.998"}
+    out = {"vs": f"bf16x3 teacher pass, first {int(x.shape[0])} images of the bench batch", "mode": mode,
+           "gate": "gross-error gate (NOT the tolerance: that is accuracy_vs_fp32_cpu_oracle): label agreement >= 0.999, mask mIoU over the batch's pooled masks >= 0.999"}
     rel, agree, iou = 0.0, 1.0, 1.0
     for k in (0, 1):
         g, o = res[mode][k], res["bf16x3"][k]
@@ -414,7 +453,7 @@ def live_accuracy_check(trainer, wimg, lab, box, n=16):
             ious.append(float((a_ & b_).sum()) / float(max(1, (a_ | b_).sum())))
         iou = min(iou, float(np.mean(ious)))
     out.update({"normalised_cam_rel_err": float(f"{rel:.3e}"), "label_agreement": round(agree, 5), "mask_miou": round(iou, 5),
-                "ok": bool(agree >= 0.999 and iou >= 0.998)})
+                "gross_error_ok": bool(agree >= 0.999 and iou >= 0.999)})
     return out
 
 
@@ -422,6 +461,7 @@ _BASE_TEXT = {
     "bf16": "bf16 operands (BASELINE configs[1] read literally; 8 significant bits)",
     "fp16": "fp16 operands (11 significant bits)",
     "bf16x3": "bf16x3 (hi + lo bf16 halves, 3 MFMA terms, fp32 accumulation: 16 significant bits)",
+    "fp16x3": "fp16x3 (hi + lo fp16 halves, 3 MFMA terms, fp32 accumulation: 22 significant bits; attention included)",
     "fp16c8": "fp16c8 (fp16 x fp16 + two e5m2 correction terms on the block-scaled MFMA, fp32 accumulation; attention operands fp16, "
               "attention output fp16 + e5m2)",
     "fp16c4": "fp16c4 (fp16 x fp16 + both correction terms as FP4 (e2m1) MX blocks on the block-scaled MFMA at 4x the fp16 rate in qkv / fc1 / "
@@ -508,7 +548,7 @@ def secondary_modes(opt, dev, C, wimg, simg, lab, box, n_iter):
         else:
             from cosa_amd.train_step import resolve_teacher_precision
             out["conforming_mode"] = secondary_run(opt, dev, C, wimg, simg, lab, box, n_iter, resolve_teacher_precision("auto", opt.crop, opt.usepar))
-        others = [m for m in ("fp16c4-12m9", "fp16c8", "bf16x3") if m != opt.teacher_precision]
+        others = [m for m in ("fp16c8-x2", "fp16c4-12m9", "fp16c8", "fp16x3", "bf16x3") if m != opt.teacher_precision]
         out["other_modes"] = {m: {k: v for k, v in secondary_run(opt, dev, C, wimg, simg, lab, box, n_iter, m).items() if k != "vit_forward"}
                                          for m in others}
     finally:
@@ -566,6 +606,12 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+        # fail loudly, before any timing, when the collective library does not see the world the driver asked for (a failed rank exits non-zero;
+        # nothing is ever re-exec'ed from a process that has touched the GPU)
+        if dist.get_world_size() != opt.gpus or world != opt.gpus:
+            raise SystemExit(f"bench.py --gpus {opt.gpus}: launched with WORLD_SIZE={world}, the {backend} process group reports {dist.get_world_size()} ranks")
+    elif opt.gpus != 1:
+        raise SystemExit(f"bench.py --gpus {opt.gpus} needs one process per GPU: launch it with torch.distributed.run --nproc-per-node {opt.gpus} (WORLD_SIZE is {world})")
 
     from cosa_amd import _C, nn_ops
     from cosa_amd.train_step import CoSATrainer, default_args, rank_seed, synthetic_batch
@@ -575,7 +621,8 @@ def main():
     # ping-pong across time slices (measured: 7 s/step), so the side-stream teacher is only used with a card per rank
     shared_card = world > ndev
     args = default_args(opt.dataset, crop_size=opt.crop, batch_size=opt.batch, usepar=opt.usepar, usegmm=opt.usegmm,
-                        teacher_precision=opt.teacher_precision, teacher_async=not (opt.teacher_sync or shared_card or os.environ.get("COSA_TEACHER_SYNC")))
+                        teacher_precision=opt.teacher_precision,
+                        teacher_async=not (opt.teacher_sync or shared_card or os.environ.get("COSA_TEACHER_SYNC", "0") not in ("0", "")))
     nn_ops.stamps = nn_ops.KernelStamps(dev)          # device-side launch spans of the two dominant kernels (work inside hipGraphs)
     nn_ops.gemm_stamps = nn_ops.KernelStamps(dev)
     trainer = CoSATrainer(args, dev, ddp=world > 1, seed=0)
@@ -677,15 +724,21 @@ def main():
         if flop_img:
             out["step_mfma"] = {"achieved_TFLOPs": round(ips * flop_img / 1e12, 2), "peak_TFLOPs": PEAK_BF16 / 1e12 * world,
                                 "frac": round(ips * flop_img / (PEAK_BF16 * world), 4), "flop_per_img": flop_img}
+        acc = out["accuracy_vs_fp32_cpu_oracle"]
+        out["tolerance_planes"] = {k: acc.get(k) for k in ("planes", "planes_exempt", "planes_failed", "draws")}          # how many planes took the conditioning exemption
         try:
             out["accuracy_live"] = live_accuracy_check(trainer, wimg, lab, box)
-            out["tolerance_met"] = bool(out["tolerance_met"] and (out["accuracy_live"]["ok"] or opt.teacher_precision == "bf16x3"))
-        except Exception as e:          # (never lose the bench line to the side check; an absent key reads as "not checked")
+            out["tolerance_met"] = bool(out["tolerance_met"] and (out["accuracy_live"]["gross_error_ok"] or opt.teacher_precision == "bf16x3"))
+        except Exception as e:          # (never lose the bench line to the side check -- but a check that could not run is not a pass: ADVICE r5)
             out["accuracy_live"] = {"error": repr(e)[:200]}
+            out["tolerance_met"] = False
+            out["tolerance_note"] = "the in-run accuracy check raised: tolerance not confirmed in this run"
         vf = vit_forward_roofline(trainer, wimg, dev, opt.crop)
         if vf:
             out["vit_forward"] = vf
         out["config"]["teacher_operands"] = opt.teacher_precision + ": " + MODE_TEXT[opt.teacher_precision]
+        out["config"]["teacher_graph"] = {"captured": trainer._graph is not None, "side_stream": bool(trainer.teacher_async), "error": trainer.graph_error,
+                                          "fallbacks": "COSA_TEACHER_SYNC=1 (replay on the main stream), COSA_TEACHER_GRAPH=0 (eager teacher)"}
         enc = trainer.student.encoder
         out["config"]["student"] = f"bf16 MFMA operands, {enc.residual_stream} residual stream and gradient sums, fp32 master weights / AdamW / EMA"
         out["config"]["defer_groups"] = enc._n_defer_groups() if enc.defer_wgrad else 0

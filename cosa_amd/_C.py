@@ -146,7 +146,10 @@ for _bf, _f in (("cosa_gemm_bf16", "cosa_gemm_f16"), ("cosa_gemm_wgrad_bf16", "c
                 ("cosa_gemm_set_variant", "cosa_gemm_set_variant_f16"), ("cosa_gemm_set_stamp_slot", "cosa_gemm_set_stamp_slot_f16"),
                 ("cosa_attn_workspace_bytes", "cosa_attn_workspace_bytes_f16"), ("cosa_attn_prepare_vt", "cosa_attn_prepare_vt_f16"),
                 ("cosa_attn_fwd", "cosa_attn_fwd_f16"), ("cosa_attn_bwd_workspace_bytes", "cosa_attn_bwd_workspace_bytes_f16"),
-                ("cosa_attn_bwd", "cosa_attn_bwd_f16")):
+                ("cosa_attn_bwd", "cosa_attn_bwd_f16"),
+                # fp16x3 (round 6): the split-row producers and the three-term GEMM / attention with fp16 halves
+                ("cosa_split_rows", "cosa_split_rows_f16"), ("cosa_layernorm_split", "cosa_layernorm_split_f16"),
+                ("cosa_gemm_bf16x3", "cosa_gemm_f16x3"), ("cosa_attn_fwd_bf16x3", "cosa_attn_fwd_f16x3")):
     _SIGS[_f] = _SIGS[_bf]
 
 # entry points added by later translation units register themselves here (vit / gemm / attention)

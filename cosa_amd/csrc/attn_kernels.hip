@@ -95,8 +95,10 @@ __device__ __forceinline__ bool attn_block_map(int nblk, int ngroups, int H, int
 // stamps: optional device-side span of the launch (100 MHz wall clock; min start / max end over workgroups) -- HIP events cannot be
 // recorded inside a captured hipGraph on ROCm, so bench.py reads these instead.
 
-#if !COSA_OP_F16
 // ---- forward with bf16x3 ("split") operands: the parity-grade no-grad passes ------------------------------------------------------
+// (both builds since round 6: with fp16 operands this is the attention of the "fp16x3" mode -- hi + lo fp16 halves.  There the probabilities
+// carry a factor 2^kX3Shift: exp2 arguments are s - m + kX3Shift, so that the lo half of a probability of ~1/N, 2^-12 of it, stays an fp16
+// NORMAL number (2^-12 2^10 / 1765 > 2^-14); the row sum carries the same factor and it cancels in O / l; LSE subtracts it again)
 // The algorithm above, 4 waves x 32 queries per workgroup; q, k, v and the probabilities are carried as hi + lo bf16 halves (16 significant
 // bits) and every product is the three MFMA terms hi*hi + hi*lo + lo*hi with fp32 accumulation:
 //     S^T  = K_h Q_h^T + K_h Q_l^T + K_l Q_h^T          O^T += V_h^T P_h^T + V_h^T P_l^T + V_l^T P_h^T
@@ -106,6 +108,11 @@ __device__ __forceinline__ bool attn_block_map(int nblk, int ngroups, int H, int
 // one is computed, one barrier per tile, no staging registers.  (The first version staged them through 32 registers that the compiler
 // kept in scratch: every tile waited for its global loads to store them, 1.02 ms per launch of the teacher's mix against 0.14 ms for
 // the bf16 kernel.)
+#if COSA_OP_F16
+constexpr float kX3Shift = 10.0f;
+#else
+constexpr float kX3Shift = 0.0f;
+#endif
 __global__ __launch_bounds__(256) void attn_fwd_x3_kernel(const op16 *__restrict__ qkv, op16 *__restrict__ out, float *__restrict__ lse,
                                                          int N, int H, int nblk, int ngroups, float scale_log2e, int ldq, int ldo)
 {
@@ -207,8 +214,8 @@ __global__ __launch_bounds__(256) void attn_fwd_x3_kernel(const op16 *__restrict
         float ls = 0.f;
 #pragma unroll
         for (int i = 0; i < 16; i++) {
-            s0[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[i], scale_log2e, -m));
-            s1[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[i], scale_log2e, -m));
+            s0[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[i], scale_log2e, kX3Shift - m));
+            s1[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[i], scale_log2e, kX3Shift - m));
             ls += s0[i] + s1[i];
         }
         l += ls;
@@ -272,10 +279,9 @@ __global__ __launch_bounds__(256) void attn_fwd_x3_kernel(const op16 *__restrict
                 *reinterpret_cast<op16x8 *>(ap + 8 * c) = a;
             }
         }
-        if (hh == 0 && lse) lse[((size_t)b * H + h) * N + q] = (m + __builtin_amdgcn_logf(l)) * 0.6931471805599453f;
+        if (hh == 0 && lse) lse[((size_t)b * H + h) * N + q] = (m - kX3Shift + __builtin_amdgcn_logf(l)) * 0.6931471805599453f;
     }
 }
-#endif
 
 // ---- forward, 64 queries per wave ---------------------------------------------------------------------------------
 // The algorithm above; a workgroup is 2 waves, each wave owns TWO 32-query
@@ -947,6 +953,7 @@ using namespace cosa;
 #define cosa_attn_workspace_bytes cosa_attn_workspace_bytes_f16
 #define cosa_attn_prepare_vt cosa_attn_prepare_vt_f16
 #define cosa_attn_fwd cosa_attn_fwd_f16
+#define cosa_attn_fwd_bf16x3 cosa_attn_fwd_f16x3
 #define cosa_attn_bwd_workspace_bytes cosa_attn_bwd_workspace_bytes_f16
 #define cosa_attn_bwd cosa_attn_bwd_f16
 #endif
@@ -1075,7 +1082,6 @@ extern "C" int cosa_attn_fwd_f16c4(const void *qkv, void *out_c4, void *out_scal
 #endif
 
 /* backward workspace: delta [B,H,N] f32 (the transposed operands come from transposing LDS reads now) */
-#if !COSA_OP_F16
 extern "C" int cosa_attn_fwd_bf16x3(const void *qkv_split, void *out_split, float *lse, int B, int N, int H, int head_dim, float scale,
                                     int ldq, int ldo, void *stream)
 {
@@ -1096,7 +1102,6 @@ extern "C" int cosa_attn_fwd_bf16x3(const void *qkv_split, void *out_split, floa
     COSA_LAUNCH_CHECK();
     return COSA_OK;
 }
-#endif
 
 extern "C" size_t cosa_attn_bwd_workspace_bytes(int B, int N, int H)
 {

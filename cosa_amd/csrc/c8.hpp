@@ -20,13 +20,17 @@ namespace cosa {
 constexpr float kC8LoScale = 2048.0f;          // 2^11
 constexpr float kC8Max = 57344.0f;             // largest finite e5m2
 
-__device__ __forceinline__ float c8_clamp(float v) { return __builtin_fminf(__builtin_fmaxf(v, -kC8Max), kC8Max); }
+// Saturation (round 6: ONE v_med3_f32 on the value instead of a min / max pair on each of its two 8-bit terms).  With |v| <= 57344 (which is an
+// fp16 value) hi = fp16(v) is finite and <= 57344 in magnitude, and |v - hi| <= half an fp16 ulp = 2^-11 2^15 at most, so lo = (v - hi) 2^11 <=
+// 2^15 < 57344: neither term can leave e5m2's range and the conversions need no clamp of their own.  For every |v| <= 57344 the bytes are the
+// ones the clamped form produced (its clamps were identities there); beyond, v saturates as a whole instead of going through fp16 infinity.
+__device__ __forceinline__ float c8_sat(float v) { return __builtin_amdgcn_fmed3f(v, -kC8Max, kC8Max); }
 
-// four floats -> four e5m2 bytes (little end first), round to nearest even, saturating
+// four floats (each within +-57344) -> four e5m2 bytes (little end first), round to nearest even
 __device__ __forceinline__ unsigned c8_pack4(float a, float b, float c, float d)
 {
-    int r = __builtin_amdgcn_cvt_pk_bf8_f32(c8_clamp(a), c8_clamp(b), 0, false);
-    r = __builtin_amdgcn_cvt_pk_bf8_f32(c8_clamp(c), c8_clamp(d), r, true);
+    int r = __builtin_amdgcn_cvt_pk_bf8_f32(a, b, 0, false);
+    r = __builtin_amdgcn_cvt_pk_bf8_f32(c, d, r, true);
     return (unsigned)r;
 }
 
@@ -36,9 +40,10 @@ __device__ __forceinline__ void c8_split4(const float (&v)[4], _Float16 (&hi)[4]
     float h[4], l[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        hi[j] = (_Float16)v[j];
+        const float vs = c8_sat(v[j]);
+        hi[j] = (_Float16)vs;
         h[j] = (float)hi[j];
-        l[j] = (v[j] - h[j]) * kC8LoScale;
+        l[j] = (vs - h[j]) * kC8LoScale;
     }
     lo8 = c8_pack4(l[0], l[1], l[2], l[3]);
     hi8 = c8_pack4(h[0], h[1], h[2], h[3]);

@@ -692,6 +692,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
             _Pragma("unroll") for (int r = 0; r < 4; r++) {                                                         \
                 v0_[r] = gelu_erf(v0_[r]);                                                                          \
                 v1_[r] = gelu_erf(v1_[r]);                                                                          \
+                if (C8OUT) { v0_[r] = c8_sat(v0_[r]); v1_[r] = c8_sat(v1_[r]); }   /* saturate the VALUE once: its two 8-bit terms then need no clamp (c8.hpp) */ \
             }                                                                                                       \
         }                                                                                                           \
         const op16x2 p0_ = {(op16)v0_[0], (op16)v0_[1]}, p1_ = {(op16)v0_[2], (op16)v0_[3]};                        \
@@ -1562,6 +1563,7 @@ using namespace cosa;
 #define cosa_gemm_set_variant cosa_gemm_set_variant_f16
 #define cosa_gemm_set_grid_policy cosa_gemm_set_grid_policy_f16
 #define cosa_gemm_bf16 cosa_gemm_f16
+#define cosa_gemm_bf16x3 cosa_gemm_f16x3
 #define cosa_layernorm cosa_layernorm_f16
 #define cosa_gemm_wgrad_bf16 cosa_gemm_wgrad_f16
 #define cosa_conv3x3_dilated_wgrad cosa_conv3x3_dilated_wgrad_f16
@@ -1695,7 +1697,8 @@ extern "C" int cosa_gemm_bf16(const void *X, const void *W, const void *bias, co
     return COSA_OK;
 }
 
-#if !COSA_OP_F16
+// (both builds since round 6: the fp16 build exports it as cosa_gemm_f16x3 -- "fp16x3": hi + lo fp16 halves, 11 + 11 significant bits, the
+// same three terms at the same cost; tools/sim_precision_map.py scheme `hh`)
 // Y = X W^T (+ bias, carried by the augmentation block) with bf16x3 operands -- see split_tile_x / split_tile_w.
 //   Xs [M, 2K + 64] = [x_hi | x_lo | 1 1 0 ...],  Ws [N, 2K + 64] = [w_hi | w_lo | b_hi b_lo 0 ...]  (bf16),  zeros: N bf16 zeros
 //   epilogue 0 / 1: Y bf16 [M, ldy], columns [0, N) = hi, [N, 2N) = lo of the (GELU'd) result;  epilogue 2: Y fp32 [M, N] = residual + .
@@ -1740,7 +1743,6 @@ extern "C" int cosa_gemm_bf16x3(const void *Xs, const void *Ws, const void *zero
     COSA_LAUNCH_CHECK();
     return COSA_OK;
 }
-#endif
 
 #if COSA_OP_F16
 // Y = X W^T (+ bias, carried by the augmentation block) with fp16c8 operands (c8.hpp; c8_tile_x / c8_tile_w above).

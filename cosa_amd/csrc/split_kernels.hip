@@ -20,47 +20,54 @@ typedef __bf16 bf16;
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-__device__ __forceinline__ void split4(const float (&v)[4], bf16x4 &hi, bf16x4 &lo)
+// T: the 16-bit type of the halves -- __bf16 (bf16x3: 8 + 8 significant bits, fp32's exponent range) or _Float16 (fp16x3, round 6: 11 + 11 bits;
+// a lo half below 2^-14 is an fp16 subnormal, i.e. carries an absolute 2^-24: still >= 18 significant bits for |v| >= 2^-6)
+template <typename T> using vec4 = T __attribute__((ext_vector_type(4)));
+template <typename T> using vec8 = T __attribute__((ext_vector_type(8)));
+
+template <typename T>
+__device__ __forceinline__ void split4(const float (&v)[4], vec4<T> &hi, vec4<T> &lo)
 {
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        hi[j] = (bf16)v[j];
-        lo[j] = (bf16)(v[j] - (float)hi[j]);
+        hi[j] = (T)v[j];
+        lo[j] = (T)(v[j] - (float)hi[j]);
     }
 }
 
 // one wave per row; K % 4 == 0
-__global__ __launch_bounds__(256) void split_rows_kernel(const float *__restrict__ src, const float *__restrict__ bias, bf16 *__restrict__ dst,
+template <typename T>
+__global__ __launch_bounds__(256) void split_rows_kernel(const float *__restrict__ src, const float *__restrict__ bias, T *__restrict__ dst,
                                                         int R, int K, long long src_ld, int ones)
 {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= R) return;
     const int lane = threadIdx.x & 63;
     const float *s = src + (size_t)row * src_ld;
-    bf16 *d = dst + (size_t)row * (2 * K + 64);
+    T *d = dst + (size_t)row * (2 * K + 64);
     for (int c = lane * 4; c < K; c += 256) {
         const float4 f = *reinterpret_cast<const float4 *>(s + c);
         const float v[4] = {f.x, f.y, f.z, f.w};
-        bf16x4 hi, lo;
-        split4(v, hi, lo);
-        *reinterpret_cast<bf16x4 *>(d + c) = hi;
-        *reinterpret_cast<bf16x4 *>(d + K + c) = lo;
+        vec4<T> hi, lo;
+        split4<T>(v, hi, lo);
+        *reinterpret_cast<vec4<T> *>(d + c) = hi;
+        *reinterpret_cast<vec4<T> *>(d + K + c) = lo;
     }
-    if (lane < 8) {                                   // augmentation block: 8 lanes x 8 bf16
-        bf16x8 a;
+    if (lane < 8) {                                   // augmentation block: 8 lanes x 8 halves
+        vec8<T> a;
 #pragma unroll
-        for (int j = 0; j < 8; j++) a[j] = (bf16)0.f;
+        for (int j = 0; j < 8; j++) a[j] = (T)0.f;
         if (lane == 0) {
-            if (ones) { a[0] = (bf16)1.f; a[1] = (bf16)1.f; }
-            else if (bias) { const float b = bias[row]; a[0] = (bf16)b; a[1] = (bf16)(b - (float)a[0]); }
+            if (ones) { a[0] = (T)1.f; a[1] = (T)1.f; }
+            else if (bias) { const float b = bias[row]; a[0] = (T)b; a[1] = (T)(b - (float)a[0]); }
         }
-        *reinterpret_cast<bf16x8 *>(d + 2 * K + lane * 8) = a;
+        *reinterpret_cast<vec8<T> *>(d + 2 * K + lane * 8) = a;
     }
 }
 
-template <int D>
+template <int D, typename T>
 __global__ __launch_bounds__(256) void layernorm_split_kernel(const float *__restrict__ x, const float *__restrict__ g, const float *__restrict__ b,
-                                                             bf16 *__restrict__ y, float *__restrict__ y32, int rows, float eps)
+                                                             T *__restrict__ y, float *__restrict__ y32, int rows, float eps)
 {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -83,7 +90,7 @@ __global__ __launch_bounds__(256) void layernorm_split_kernel(const float *__res
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
     const float rstd = rsqrtf(q * (1.0f / D) + eps);
-    bf16 *yr = y ? y + (size_t)row * (2 * D + 64) : nullptr;
+    T *yr = y ? y + (size_t)row * (2 * D + 64) : nullptr;
 #pragma unroll
     for (int i = 0; i < PER; i++) {
         const int c0 = (lane + 64 * i) * 4;
@@ -91,19 +98,19 @@ __global__ __launch_bounds__(256) void layernorm_split_kernel(const float *__res
         const float o[4] = {(v[i].x - mean) * rstd * gg.x + bb.x, (v[i].y - mean) * rstd * gg.y + bb.y,
                             (v[i].z - mean) * rstd * gg.z + bb.z, (v[i].w - mean) * rstd * gg.w + bb.w};
         if (yr) {
-            bf16x4 hi, lo;
-            split4(o, hi, lo);
-            *reinterpret_cast<bf16x4 *>(yr + c0) = hi;
-            *reinterpret_cast<bf16x4 *>(yr + D + c0) = lo;
+            vec4<T> hi, lo;
+            split4<T>(o, hi, lo);
+            *reinterpret_cast<vec4<T> *>(yr + c0) = hi;
+            *reinterpret_cast<vec4<T> *>(yr + D + c0) = lo;
         }
         if (y32) *reinterpret_cast<float4 *>(y32 + (size_t)row * D + c0) = make_float4(o[0], o[1], o[2], o[3]);
     }
     if (yr && lane < 8) {
-        bf16x8 a;
+        vec8<T> a;
 #pragma unroll
-        for (int j = 0; j < 8; j++) a[j] = (bf16)0.f;
-        if (lane == 0) { a[0] = (bf16)1.f; a[1] = (bf16)1.f; }
-        *reinterpret_cast<bf16x8 *>(yr + 2 * D + lane * 8) = a;
+        for (int j = 0; j < 8; j++) a[j] = (T)0.f;
+        if (lane == 0) { a[0] = (T)1.f; a[1] = (T)1.f; }
+        *reinterpret_cast<vec8<T> *>(yr + 2 * D + lane * 8) = a;
     }
 }
 
@@ -415,24 +422,45 @@ extern "C" int cosa_layernorm_c4(const float *x, const float *gamma, const float
     return COSA_OK;
 }
 
-extern "C" int cosa_split_rows(const float *src, const float *bias, void *dst, int R, int K, long long src_ld, int ones, void *stream)
+template <typename T>
+static int split_rows_launch(const float *src, const float *bias, void *dst, int R, int K, long long src_ld, int ones, void *stream)
 {
     COSA_REQUIRE(src && dst && R > 0 && K > 0 && K % 4 == 0 && src_ld >= K && src_ld % 4 == 0, "cosa_split_rows: bad arguments (K %% 4 == 0)");
-    hipLaunchKernelGGL(split_rows_kernel, dim3((R + 3) / 4), dim3(256), 0, as_stream(stream), src, bias, static_cast<bf16 *>(dst), R, K,
-                       src_ld, ones);
+    hipLaunchKernelGGL(split_rows_kernel<T>, dim3((R + 3) / 4), dim3(256), 0, as_stream(stream), src, bias, static_cast<T *>(dst), R, K, src_ld, ones);
     COSA_LAUNCH_CHECK();
     return COSA_OK;
+}
+
+template <typename T>
+static int layernorm_split_launch(const float *x, const float *gamma, const float *beta, void *y_split, float *y_f32, int rows, int dim, float eps,
+                                  void *stream)
+{
+    COSA_REQUIRE(x && gamma && beta && (y_split || y_f32) && rows > 0, "cosa_layernorm_split: bad arguments");
+    COSA_REQUIRE(dim == 768, "cosa_layernorm_split: dim must be 768 (ViT-B)");
+    hipLaunchKernelGGL((layernorm_split_kernel<768, T>), dim3((rows + 3) / 4), dim3(256), 0, as_stream(stream), x, gamma, beta,
+                       static_cast<T *>(y_split), y_f32, rows, eps);
+    COSA_LAUNCH_CHECK();
+    return COSA_OK;
+}
+
+extern "C" int cosa_split_rows(const float *src, const float *bias, void *dst, int R, int K, long long src_ld, int ones, void *stream)
+{
+    return split_rows_launch<bf16>(src, bias, dst, R, K, src_ld, ones, stream);
+}
+extern "C" int cosa_split_rows_f16(const float *src, const float *bias, void *dst, int R, int K, long long src_ld, int ones, void *stream)
+{
+    return split_rows_launch<_Float16>(src, bias, dst, R, K, src_ld, ones, stream);
 }
 
 extern "C" int cosa_layernorm_split(const float *x, const float *gamma, const float *beta, void *y_split, float *y_f32, int rows, int dim,
                                     float eps, void *stream)
 {
-    COSA_REQUIRE(x && gamma && beta && (y_split || y_f32) && rows > 0, "cosa_layernorm_split: bad arguments");
-    COSA_REQUIRE(dim == 768, "cosa_layernorm_split: dim must be 768 (ViT-B)");
-    hipLaunchKernelGGL(layernorm_split_kernel<768>, dim3((rows + 3) / 4), dim3(256), 0, as_stream(stream), x, gamma, beta,
-                       static_cast<bf16 *>(y_split), y_f32, rows, eps);
-    COSA_LAUNCH_CHECK();
-    return COSA_OK;
+    return layernorm_split_launch<bf16>(x, gamma, beta, y_split, y_f32, rows, dim, eps, stream);
+}
+extern "C" int cosa_layernorm_split_f16(const float *x, const float *gamma, const float *beta, void *y_split, float *y_f32, int rows, int dim,
+                                        float eps, void *stream)
+{
+    return layernorm_split_launch<_Float16>(x, gamma, beta, y_split, y_f32, rows, dim, eps, stream);
 }
 
 // ---- fp16c8 producers (c8.hpp; include/cosa_hip.h) ---------------------------------------------------------------------------------

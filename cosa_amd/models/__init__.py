@@ -91,7 +91,8 @@ class VITNetwork(nn.Module):
 
     def set_nograd_precision(self, mode):
         """operand precision of the no-grad passes (teacher pseudo-labels, evaluation): "bf16" (8 significant bits), "fp16" (11; the
-        same kernels built for fp16 operands), "bf16x3" (16; hi + lo bf16 halves, three MFMA terms), "fp16c8" (fp16 + 8-bit correction
+        same kernels built for fp16 operands), "bf16x3" (16; hi + lo bf16 halves, three MFMA terms), "fp16x3" (22: hi + lo fp16 halves, the same three
+        terms at the same cost), "fp16c8" (fp16 + 8-bit correction
         terms on the block-scaled MFMA, ~14 bits at twice the 16-bit work; attention operands plain fp16) or "fp16c4" (the same with FP4 MX-block
         correction terms at 4x the fp16 rate: ~1.6x the 16-bit work); "-n" suffix: blocks from index n on plain fp16, "-nmk": their MLP halves (fc1, fc2) from
         block k <= n on: DESIGN.md section 3"""
@@ -101,10 +102,12 @@ class VITNetwork(nn.Module):
         mx = re.fullmatch(r"(?:x(\d+)(?:m(\d+))?)?(?:c(\d+))?", tail) if tail and not m else None     # "fp16c8-x6": the blocks BELOW index 6 on bf16x3
         #                       operands (round 5); "fp16c8-x6m4": their attention halves below 6, their MLP halves below 4; "fp16c8-x2c6" / "fp16c8-c6":
         #                       the blocks from index 6 on take qkv / fc1 / fc2 on fp16c4 operands (fp16c8 base only)
-        assert base in ("bf16", "fp16", "bf16x3", "fp16c8", "fp16c4") and (bool(tail) == bool(sep)) and \
+        assert base in ("bf16", "fp16", "bf16x3", "fp16x3", "fp16c8", "fp16c4") and (bool(tail) == bool(sep)) and \
             (not tail or (base in ("fp16c8", "fp16c4") and (m or mx))), mode
-        self.set_compute_dtype(torch.float16 if base in ("fp16", "fp16c8", "fp16c4") else torch.bfloat16)
-        self.encoder.precision = base if base in ("bf16x3", "fp16c8", "fp16c4") else None
+        self.set_compute_dtype(torch.float16 if base in ("fp16", "fp16x3", "fp16c8", "fp16c4") else torch.bfloat16)
+        # "fp16x3" (round 6): the three-term path with fp16 halves (hi + lo: 11 + 11 significant bits; bf16x3: 8 + 8) -- same kernels, same cost
+        self.encoder.precision = "bf16x3" if base == "fp16x3" else (base if base in ("bf16x3", "fp16c8", "fp16c4") else None)
+        self.encoder.x3_dtype = torch.float16 if base == "fp16x3" else torch.bfloat16
         self.encoder.c8_plain_from = int(m.group(1)) if m else None
         self.encoder.c8_plain_mlp_from = int(m.group(2)) if m and m.group(2) else None
         self.encoder.c8_plain_qkv = bool(m and m.group(3))
@@ -240,8 +243,12 @@ class VITNetwork(nn.Module):
             return cam, cam_aux
         if not need_cls:        # the training loop's teacher passes never read the classification logits (seg_helper.py:247-249 drops them)
             return None, None, x4, seg, cam, cam_aux
-        cls_x4 = self._cls_head(self._pool(tok), self.classifier.weight, dt)
-        cls_aux = self._cls_head(self._pool(tok_aux), self.aux_classifier.weight, dt)
+        # the classification logits read the SAME tokens as the CAM heads (round 6: the fused no-grad path pooled its 16-bit copy of the final
+        # tokens while the CAMs came from the fp32 ones -- 2e-3 of the logits' range against the reference at ViT-B width,
+        # tests/test_network_gpu.py::test_hip_network_at_vit_b_width_vs_reference_golden; evaluation's mAP reads them)
+        p_fin = tok if tok32 is None else tok32
+        cls_x4 = self._cls_head(self._pool(p_fin), self.classifier.weight, dt if p_fin.dtype != torch.float32 else torch.float32)
+        cls_aux = self._cls_head(self._pool(tok_aux), self.aux_classifier.weight, dt if tok_aux.dtype != torch.float32 else torch.float32)
         return cls_x4, cls_aux, x4, seg, cam, cam_aux
 
 

@@ -101,6 +101,7 @@ class VisionTransformer(nn.Module):
         self.c8_plain_mlp_from = None  # ... their MLP halves (norm2, fc1, fc2) already from this block on (None: as c8_plain_from)
         self.x3_until = None           # fp16c8 / fp16c4: blocks with index < this run on bf16x3 operands ("fp16c8-x6"); x3_mlp_until: their MLP halves
         self.x3_mlp_until = None
+        self.x3_dtype = torch.bfloat16   # type of the hi / lo halves of the three-term path: bf16 ("bf16x3") or fp16 ("fp16x3")
         self.c4_from = None            # fp16c8: blocks with index >= this take their qkv / fc1 / fc2 on fp16c4 operands ("fp16c8-x2c6": mixed maps, round 5)
         self.c8_plain_qkv = False      # ... the qkv projections of the corrected blocks on plain fp16 operands too (the output projection keeps its terms)
         # fp16c4: the output projection too on fp16c4 operands (the attention kernel then writes c4 rows)?  Measured (round 4, three seeds, 448^2):
@@ -281,12 +282,12 @@ class VisionTransformer(nn.Module):
         return outs
 
     # -- parity-grade no-grad path: every MFMA operand as hi + lo bf16 halves (bf16x3), fp32 residual / LayerNorm / CAM heads ----------
-    def _split_weights(self, until=None):
+    def _split_weights(self, until=None, dtype=torch.bfloat16):
         """split rows [N, 2K+64] (bias in the augmentation block) of the patch projection and the 48 block projections, rebuilt from
         the fp32 masters on every pass (the teacher's masters move every step; ~0.5 GB of traffic, part of the captured graph).
         until = (xa, xm): only the attention projections of blocks < xa and the MLP projections of blocks < xm (the mixed fp16c8-xN maps;
         the patch projection then stays with the fp16c8 path)"""
-        ws = self.__dict__.setdefault("_x3_w", {})
+        ws = self.__dict__.setdefault("_x3_w", {}).setdefault(dtype, {})          # (bf16 halves: bf16x3 and the early blocks of fp16c8-xN; fp16: fp16x3)
         depth = len(self.blocks)
         xa, xm = until if until is not None else (depth, depth)
         items = [("patch", self.patch_embed.proj.weight.reshape(self.embed_dim, -1), self.patch_embed.proj.bias)] if until is None else []
@@ -298,27 +299,28 @@ class VisionTransformer(nn.Module):
         for name, w, b in items:
             buf = ws.get(name)
             if buf is None or buf.device != w.device:
-                buf = ws[name] = torch.empty((w.shape[0], nn_ops.split_ld(w.shape[1])), device=w.device, dtype=torch.bfloat16)
+                buf = ws[name] = torch.empty((w.shape[0], nn_ops.split_ld(w.shape[1])), device=w.device, dtype=dtype)
             nn_ops.split_rows(w.detach(), bias=b.detach(), out=buf)
         return ws
 
-    def _x3_buffers(self, M, dev):
+    def _x3_buffers(self, M, dev, dtype=torch.bfloat16):
         """persistent split-row activations for M token rows; the (1, 1, 0, ...) augmentation block of the fc1 output is set once here
         (the GEMM epilogue writes the hi | lo halves only), the other buffers get theirs from their producing kernels"""
         bufs = self.__dict__.setdefault("_x3_bufs", {})
-        ent = bufs.get((M, dev))
+        ent = bufs.get((M, dev, dtype))
         if ent is None:
             D, Hd = self.embed_dim, self.blocks[0].mlp.fc1.weight.shape[0]
-            mk = lambda cols: torch.zeros((M, cols), device=dev, dtype=torch.bfloat16)
+            mk = lambda cols: torch.zeros((M, cols), device=dev, dtype=dtype)
             ent = {"y": mk(nn_ops.split_ld(D)), "qkv": mk(2 * 3 * D), "o": mk(nn_ops.split_ld(D)), "h": mk(nn_ops.split_ld(Hd))}
             ent["h"][:, 2 * Hd:2 * Hd + 2] = 1
-            bufs[(M, dev)] = ent
+            bufs[(M, dev, dtype)] = ent
         return ent
 
     def _forward_features_x3_multi(self, xs):
         D, H = self.embed_dim, self.num_heads
         p = self.patch_size
-        W = self._split_weights()
+        hdt = self.x3_dtype                      # bf16 halves ("bf16x3") or fp16 halves ("fp16x3", round 6: 11 + 11 significant bits at the same cost)
+        W = self._split_weights(dtype=hdt)
         toks, shapes = [], []
         for x in xs:
             B, nc, Hh, Ww = x.shape
@@ -326,7 +328,7 @@ class VisionTransformer(nn.Module):
             cols = x.float().reshape(B, nc, h, p, w, p).permute(0, 2, 4, 1, 3, 5).reshape(B * h * w, nc * p * p)
             pos = self._pos_for_grid(h, w, torch.float32)                              # [1, n+1, D]
             tok = pos[:, 1:].expand(B, -1, -1).contiguous().view(B * h * w, D)          # residual operand: the position rows
-            nn_ops.gemm_x3(nn_ops.split_rows(cols, ones=True), W["patch"], B * h * w, D, nc * p * p, nn_ops.EPI_RESIDUAL, residual=tok, out=tok)
+            nn_ops.gemm_x3(nn_ops.split_rows(cols, ones=True, dtype=hdt), W["patch"], B * h * w, D, nc * p * p, nn_ops.EPI_RESIDUAL, residual=tok, out=tok)
             cls = (self.cls_token.detach().float() + pos[:, :1]).expand(B, -1, -1)
             toks.append(torch.cat((cls, tok.view(B, h * w, D)), dim=1).reshape(-1, D))
             shapes.append((B, h * w + 1))
@@ -335,7 +337,7 @@ class VisionTransformer(nn.Module):
         for B, N in shapes:
             offs.append(offs[-1] + B * N)
         M = offs[-1]
-        bf = self._x3_buffers(M, xr.device)
+        bf = self._x3_buffers(M, xr.device, dtype=hdt)
         depth = len(self.blocks)
         aux_idx = self.aux_layer % depth
         aux = None

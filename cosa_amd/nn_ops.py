@@ -353,34 +353,44 @@ def split_ld(K):
     return 2 * K + 64
 
 
-def split_rows(src, bias=None, ones=False, out=None):
-    """fp32 [R, K] (unit column stride; any row stride) -> split rows [R, 2K + 64]; aug block = (bias_hi, bias_lo, 0..) per row,
-    (1, 1, 0..) with ones=True, zeros otherwise"""
+def _x3_fn(name, dtype):
+    """entry point of the three-term ("x3") path for halves of `dtype`: bf16 -> bf16x3, fp16 -> fp16x3 (round 6)"""
+    if dtype == torch.bfloat16:
+        return getattr(_C.lib(), name)
+    if dtype == torch.float16:
+        return getattr(_C.lib(), {"cosa_gemm_bf16x3": "cosa_gemm_f16x3", "cosa_attn_fwd_bf16x3": "cosa_attn_fwd_f16x3"}.get(name, name + "_f16"))
+    raise _C.CosaError(f"{name}: split halves must be bfloat16 or float16, got {dtype}")
+
+
+def split_rows(src, bias=None, ones=False, out=None, dtype=torch.bfloat16):
+    """fp32 [R, K] (unit column stride; any row stride) -> split rows [R, 2K + 64] of `dtype` halves (out.dtype when `out` is given); aug
+    block = (bias_hi, bias_lo, 0..) per row, (1, 1, 0..) with ones=True, zeros otherwise"""
     R, K = src.shape
     assert src.dtype == torch.float32 and src.stride(1) == 1
     if out is None:
-        out = torch.empty((R, split_ld(K)), device=src.device, dtype=torch.bfloat16)
-    _C.check(_C.lib().cosa_split_rows(_C.ptr(src), _C.ptr(bias), _C.ptr(out), R, K, src.stride(0), int(ones), _C.stream_ptr()),
+        out = torch.empty((R, split_ld(K)), device=src.device, dtype=dtype)
+    _C.check(_x3_fn("cosa_split_rows", out.dtype)(_C.ptr(src), _C.ptr(bias), _C.ptr(out), R, K, src.stride(0), int(ones), _C.stream_ptr()),
              "cosa_split_rows")
     return out
 
 
-def layernorm_split(x, g, b, eps, out=None, want_f32=False):
+def layernorm_split(x, g, b, eps, out=None, want_f32=False, dtype=torch.bfloat16):
     """LayerNorm(768) over the fp32 stream with fp32 gamma / beta -> (split rows [rows, 1600] | None, fp32 | None)"""
     rows, D = x.shape
     y32 = torch.empty((rows, D), device=x.device, dtype=torch.float32) if want_f32 else None
-    _C.check(_C.lib().cosa_layernorm_split(_C.ptr(x), _C.ptr(g), _C.ptr(b), _C.ptr(out), _C.ptr(y32), rows, D, float(eps),
-                                           _C.stream_ptr()), "cosa_layernorm_split")
+    _C.check(_x3_fn("cosa_layernorm_split", out.dtype if out is not None else dtype)(_C.ptr(x), _C.ptr(g), _C.ptr(b), _C.ptr(out), _C.ptr(y32), rows, D,
+                                                                                     float(eps), _C.stream_ptr()), "cosa_layernorm_split")
     return out, y32
 
 
 def gemm_x3(xs, ws, M, N, K, epilogue=EPI_BIAS, residual=None, out=None, ldy=None):
-    """xs [M, 2K+64], ws [N, 2K+64] split rows (bias inside ws) -> epilogue 0/1: bf16 [M, ldy >= 2N] = [hi | lo | ...];
+    """xs [M, 2K+64], ws [N, 2K+64] split rows of the same 16-bit type (bias inside ws) -> epilogue 0/1: that type [M, ldy >= 2N] = [hi | lo | ...];
     epilogue 2: fp32 [M, N] = residual + . (in place allowed)"""
-    dev = xs.device
-    z = _zero_bias.get(dev)
+    dev, dt = xs.device, xs.dtype
+    assert ws.dtype == dt
+    z = _zero_bias.get((dev, dt))
     if z is None:
-        z = _zero_bias[dev] = torch.zeros(8192, device=dev, dtype=torch.bfloat16)
+        z = _zero_bias[(dev, dt)] = torch.zeros(8192, device=dev, dtype=dt)
     if epilogue == EPI_RESIDUAL:
         ldy = N
         if out is None:
@@ -388,20 +398,21 @@ def gemm_x3(xs, ws, M, N, K, epilogue=EPI_BIAS, residual=None, out=None, ldy=Non
     else:
         ldy = ldy or 2 * N
         if out is None:
-            out = torch.empty((M, ldy), device=dev, dtype=torch.bfloat16)
+            out = torch.empty((M, ldy), device=dev, dtype=dt)
     if gemm_stamps is not None and M >= 4096:
-        _C.lib().cosa_gemm_set_stamp_slot(gemm_stamps.next_slot(2.0 * M * N * K, 2.0 * M * N * K * (3 * (K // 64) + 1) / (K // 64)))
+        _C.fn16("cosa_gemm_set_stamp_slot", dt)(gemm_stamps.next_slot(2.0 * M * N * K, 2.0 * M * N * K * (3 * (K // 64) + 1) / (K // 64)))
     with _C.profiled("gemm_x3"):
-        _C.check(_C.lib().cosa_gemm_bf16x3(_C.ptr(xs), _C.ptr(ws), _C.ptr(z), _C.ptr(residual), _C.ptr(out), M, N, K, epilogue, ldy,
-                                           _C.stream_ptr()), "cosa_gemm_bf16x3")
+        _C.check(_x3_fn("cosa_gemm_bf16x3", dt)(_C.ptr(xs), _C.ptr(ws), _C.ptr(z), _C.ptr(residual), _C.ptr(out), M, N, K, epilogue, ldy,
+                                                _C.stream_ptr()), "cosa_gemm_x3")
     _flops["gemm_x3"] = _flops.get("gemm_x3", 0) + 6.0 * M * N * K
     return out
 
 
 def attn_fwd_x3(qkv_s, B, N, H, out_s, lse=None):
     """attention on split qkv rows [B*N, ldq] -> split rows out_s [B*N, ldo] (hi | lo | aug) for the output projection"""
-    _C.check(_C.lib().cosa_attn_fwd_bf16x3(_C.ptr(qkv_s), _C.ptr(out_s), _C.ptr(lse), B, N, H, 64, 0.125, qkv_s.stride(0), out_s.stride(0),
-                                           _C.stream_ptr()), "cosa_attn_fwd_bf16x3")
+    assert out_s.dtype == qkv_s.dtype
+    _C.check(_x3_fn("cosa_attn_fwd_bf16x3", qkv_s.dtype)(_C.ptr(qkv_s), _C.ptr(out_s), _C.ptr(lse), B, N, H, 64, 0.125, qkv_s.stride(0),
+                                                         out_s.stride(0), _C.stream_ptr()), "cosa_attn_fwd_x3")
     _flops["attn_x3"] = _flops.get("attn_x3", 0) + 12.0 * B * H * N * N * 64
     return out_s
 
@@ -1159,7 +1170,8 @@ class PatchFanoutFn(Function):
         B, N, D = ctx.shape
         gs = [g.contiguous() if g is not None else None for g in gs]
         live = [g for g in gs if g is not None]
-        assert 1 <= len(live) <= 3 and all(g.dtype == torch.bfloat16 and g.shape == (B, N - 1, D) for g in live)
+        if not (1 <= len(live) <= 3 and all(g.dtype == torch.bfloat16 and g.shape == (B, N - 1, D) for g in live)):      # (not an assert: python -O must not strip it)
+            raise _C.CosaError(f"PatchFanoutFn.backward: {len(live)} live gradients (the junction kernel sums at most three bf16 [B, N-1, 768] maps)")
         live += [None] * (3 - len(live))
         dx = torch.empty((B, N, D), device=live[0].device, dtype=torch.float32)
         _C.check(_C.lib().cosa_token_junction_bwd(_C.ptr(live[0]), _C.ptr(live[1]), _C.ptr(live[2]), _C.ptr(dx), B, N, D, _C.stream_ptr()),

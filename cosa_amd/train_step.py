@@ -90,11 +90,17 @@ class CoSATrainer:
             p.requires_grad = False
         groups = self.model_ON.get_param_groups()
         self.student = self.model_ON
+        # Data parallelism (main.py:49-50).  On the GPU the teacher's hipGraph is captured BEFORE DistributedDataParallel exists (first step:
+        # prepare_ddp): at that point the process group has no collective in flight, so RCCL's watchdog has no event to poll while the
+        # capture is open and DDP's reducer / comm stream do not exist yet; the wrap's own parameter broadcast follows the capture.
+        self._ddp_pending = False
         if ddp:
-            self.model_ON = wrap_ddp(self.model_ON, device)
             if device.type == "cuda":        # leave CUs to RCCL's channels: persistent GEMM grids balanced over their rounds (include/cosa_hip.h)
-                _C.lib().cosa_gemm_set_grid_policy(1)
+                _C.lib().cosa_gemm_set_grid_policy(1)            # (before the capture: a captured launch keeps the grid it was recorded with)
                 _C.lib().cosa_gemm_set_grid_policy_f16(1)
+                self._ddp_pending = True
+            else:
+                self.model_ON = wrap_ddp(self.model_ON, device)
         self.optimizer = torch_helper.PolyWarmupAdamW(
             params=[
                 {'params': [p for p in groups[0] if p.requires_grad], 'lr': args.lr, 'weight_decay': args.wt_dec},
@@ -149,13 +155,15 @@ class CoSATrainer:
             for blk in self.student.encoder.blocks:
                 ws += [blk.attn.qkv.weight, blk.attn.proj.weight, blk.mlp.fc1.weight, blk.mlp.fc2.weight]
             self._student_wT = nn_ops.TransposedShadows(ws)
-        self.use_graph = bool(getattr(args, "teacher_graph", True)) and self._shadows is not None
+        # COSA_TEACHER_GRAPH=0 / COSA_TEACHER_SYNC=1: fallbacks reachable from any launcher's command line (first multi-GPU runs)
+        self.use_graph = bool(getattr(args, "teacher_graph", True)) and self._shadows is not None and os.environ.get("COSA_TEACHER_GRAPH", "1") != "0"
+        self.graph_error = None              # why the capture was abandoned, if it was (the teacher then runs eagerly)
         self.fused_losses = bool(getattr(args, "fused_losses", True)) and device.type == "cuda" and not args.after_softmax
         self._graph = None
         self._loss_weights = {}
         self._graph_calls = 0
         self._cam_buffers = {}               # this trainer's CAM buffers of the teacher passes (seg_helper.multi_scale_camseg, `_buffers`)
-        self.teacher_async = bool(getattr(args, "teacher_async", True)) and self.use_graph
+        self.teacher_async = bool(getattr(args, "teacher_async", True)) and self.use_graph and os.environ.get("COSA_TEACHER_SYNC", "0") in ("0", "")
         self._side = None
         self._teacher_pending = False
 
@@ -180,12 +188,21 @@ class CoSATrainer:
             self._s_lab = cls_label.clone()
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):   # RCCL's watchdog thread may poll events meanwhile
-                for st in sts:
-                    st.reset()
-                self._s_out = seg_helper.multi_scale_camseg(self.model_AN, self._s_wimg, args.pseudo_scales,
-                                                            _active_labels=None if args.use_cammix else self._s_lab,
-                                                            _seg_scales=self.fused_losses, _buffers=self._cam_buffers)
+            try:
+                # thread_local: a call another thread makes meanwhile (RCCL's watchdog polling an event) does not invalidate this capture
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    for st in sts:
+                        st.reset()
+                    self._s_out = seg_helper.multi_scale_camseg(self.model_AN, self._s_wimg, args.pseudo_scales,
+                                                                _active_labels=None if args.use_cammix else self._s_lab,
+                                                                _seg_scales=self.fused_losses, _buffers=self._cam_buffers)
+            except Exception as e:          # a failed capture must not cost the run: eager teacher from here on, and the reason on record
+                import sys
+                self.graph_error = repr(e)[:300]
+                self.use_graph = self.teacher_async = False
+                print(f"[cosa_amd] teacher hipGraph capture failed ({self.graph_error}); the teacher runs eagerly", file=sys.stderr, flush=True)
+                torch.cuda.synchronize()
+                return self._teacher(wimg, cls_label)
             self._graph = g
             self._g_stamps = [(st.n, list(st.flops)) for st in sts]
         if self.teacher_async:
@@ -233,6 +250,8 @@ class CoSATrainer:
         fused = self.fused_losses and args.aux_cam2seg and args.segfg_alpha == 0.5 and args.aux_cam2seg_alpha == 0.5
         if fused and self._lattice is not None:
             self._lattice.start(simg, args.num_classes)
+        if self._ddp_pending:
+            self.prepare_ddp(wimg, cls_label)
         cam_ps, cam_aux_ps, seg_ps = self._teacher(wimg, cls_label)
         cls_final, cls_aux, _feat, seg_pred, cam_pred, cam_aux_pred = self.model_ON(simg, cam_only=False, detach=args.detach)
         self._join_teacher()
@@ -298,6 +317,17 @@ class CoSATrainer:
         return loss, dict(overall_loss=loss.detach(), cls_loss=cls_loss.detach(), cls_aux_loss=cls_loss_aux.detach(),
                           seg_loss=seg_loss.detach(), cam_loss=cam_loss.detach(), reg_loss=reg_loss.detach(),
                           mask=refine_mask_label, cls_logits=cls_final.detach(), cls_aux_logits=cls_aux.detach())
+
+    def prepare_ddp(self, wimg, cls_label):
+        """first step under data parallelism on the GPU: warm up and CAPTURE the teacher pass, then wrap the student (see __init__)"""
+        if self.use_graph:
+            with torch.no_grad():
+                while self._graph is None and self.use_graph:
+                    self._teacher(wimg, cls_label)
+                    self._join_teacher()
+            torch.cuda.synchronize()
+        self.model_ON = wrap_ddp(self.student, self.device)
+        self._ddp_pending = False
 
     def step(self, wimg, simg, cls_label, img_box, n_iter):
         loss, logs = self.forward_losses(wimg, simg, cls_label, img_box, n_iter)

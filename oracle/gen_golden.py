@@ -237,6 +237,72 @@ def gen_vit(rng):
     np.savez_compressed(os.path.join(OUT, "vit_tiny.npz"), **out)
 
 
+def recipe_state(shapes, seed0=5000):
+    """weights by a recipe a test can replay without the reference: per SORTED key, `torch.randn(shape, generator=manual_seed(seed0 + index)) *
+    s(key)` (+ 1 for LayerNorm weights), s = 0.1 for one-dimensional parameters (biases, norms: so that every term is exercised), 0.05 for the two
+    CAM classifiers, 0.02 otherwise (the reference's trunc_normal std).  shapes: {key: shape}.  Returns ({key: tensor}, sha256 hex of the bytes)."""
+    import hashlib
+    sd, h = {}, hashlib.sha256()
+    for i, k in enumerate(sorted(shapes)):
+        g = torch.Generator().manual_seed(seed0 + i)
+        shp = tuple(shapes[k])
+        s = 0.1 if len(shp) == 1 else (0.05 if k.endswith("classifier.weight") else 0.02)
+        t = torch.randn(shp, generator=g) * s
+        if len(shp) == 1 and ".norm" in "." + k and k.endswith(".weight"):
+            t = t + 1.0
+        sd[k] = t
+        h.update(k.encode())
+        h.update(t.numpy().tobytes())
+    return sd, h.hexdigest()
+
+
+VIT_BASE_CFG = dict(embed_dim=768, depth=2, num_heads=12, aux_layer=-2, num_classes=21, img=(96, 64), batch=2)
+
+
+def gen_vit_base(rng):
+    """a reference-produced vector INSIDE the HIP kernels' envelope -- the reference's own VisionTransformer at ViT-B WIDTH
+    (embed 768, 12 heads x 64, depth 2: vit.py:219-330) + LargeFOV (conv_head.py:11-41) + the two CAM classifiers, composed the way
+    models/__init__.py:163-206 composes them, on a 2 x 3 x 96 x 64 batch (6 x 4 patches: the bicubic pos-embed resize 14^2 -> 6 x 4 is live).
+    Weights come from `recipe_state` (replayed by the test); stored: input, the six outputs of VITNetwork.forward, sha256 of the weights."""
+    vit = ref_loader.vit_module()
+    head = ref_loader.conv_head_module()
+    from functools import partial
+    cfg = VIT_BASE_CFG
+    E, C1 = cfg["embed_dim"], cfg["num_classes"]
+    enc = vit.VisionTransformer(patch_size=16, embed_dim=E, depth=cfg["depth"], num_heads=cfg["num_heads"], mlp_ratio=4, qkv_bias=True,
+                                norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), aux_layer=cfg["aux_layer"], num_classes=1000)
+    dec = head.LargeFOV(in_planes=E, out_planes=C1)
+    cls_w = torch.nn.Conv2d(E, C1 - 1, 1, bias=False)
+    aux_w = torch.nn.Conv2d(E, C1 - 1, 1, bias=False)
+    shapes = {"encoder." + k: v.shape for k, v in enc.state_dict().items()}
+    shapes.update({"decoder." + k: v.shape for k, v in dec.state_dict().items()})
+    shapes["classifier.weight"], shapes["aux_classifier.weight"] = cls_w.weight.shape, aux_w.weight.shape
+    sd, digest = recipe_state(shapes)
+    enc.load_state_dict({k[len("encoder."):]: v for k, v in sd.items() if k.startswith("encoder.")}, strict=True)
+    dec.load_state_dict({k[len("decoder."):]: v for k, v in sd.items() if k.startswith("decoder.")}, strict=True)
+    with torch.no_grad():
+        cls_w.weight.copy_(sd["classifier.weight"])
+        aux_w.weight.copy_(sd["aux_classifier.weight"])
+    enc.eval(); dec.eval()
+    H, W = cfg["img"]
+    x = torch.from_numpy(rng.normal(0, 1, (cfg["batch"], 3, H, W)).astype(np.float32))
+    with torch.no_grad():
+        cls_tok, tok, tok_aux = enc.forward_features(x)
+        h, w = H // 16, W // 16
+        to2d = lambda t: t.transpose(1, 2).reshape(t.shape[0], E, h, w)
+        x4, xa = to2d(tok), to2d(tok_aux)
+        seg = dec(x4)
+        cam = F.conv2d(x4, cls_w.weight)
+        cam_aux = F.conv2d(xa, aux_w.weight)
+        cls = cls_w(F.adaptive_max_pool2d(x4, (1, 1))).view(-1, C1 - 1)
+        cls_aux = aux_w(F.adaptive_max_pool2d(xa, (1, 1))).view(-1, C1 - 1)
+    out = {"x": x.numpy(), "cls": cls.numpy(), "cls_aux": cls_aux.numpy(), "x4": x4.numpy(), "seg": seg.numpy(),
+           "cam": cam.numpy(), "cam_aux": cam_aux.numpy(), "weights_sha256": np.array(digest),
+           "shape_keys": np.array(sorted(shapes)), "shape_dims": np.array([",".join(str(d) for d in shapes[k]) for k in sorted(shapes)])}
+    np.savez_compressed(os.path.join(OUT, "vit_base_d2.npz"), **out)
+    print("vit_base_d2: weights sha256", digest[:16], "cam range", float(cam.abs().max()), "seg range", float(seg.abs().max()))
+
+
 EVAL_SIZES = [(333, 500), (375, 500), (500, 281)]
 
 
@@ -435,11 +501,15 @@ def gen_signatures():
 
 
 def main():
+    import sys
     assert ref_loader.available(), "reference tree not present"
     os.makedirs(OUT, exist_ok=True)
     c_oracle.build()
     torch.manual_seed(0)
     torch.set_num_threads(8)
+    if "--only-vit-base" in sys.argv:          # (round 6: one new fixture; the others stay as committed)
+        gen_vit_base(np.random.default_rng(20))
+        return
     gen_par(np.random.default_rng(11))
     gen_cam2mask(np.random.default_rng(12))
     gen_camseg(np.random.default_rng(13))
@@ -449,6 +519,7 @@ def main():
     gen_eval(np.random.default_rng(17))
     gen_gmm(np.random.default_rng(18))
     gen_augment(np.random.default_rng(19))
+    gen_vit_base(np.random.default_rng(20))
     gen_signatures()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")

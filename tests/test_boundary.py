@@ -171,6 +171,9 @@ def test_teacher_precision_mode_strings():
     assert [resolve_teacher_precision("auto", c) for c in (224, 448, 512, 640)] == ["fp16c8-x2"] * 4
     assert resolve_teacher_precision("bf16", 640) == "bf16" and resolve_teacher_precision("auto", 448, usepar=True) == "fp16c8-x2"
     net = build_model(a)
+    for mode, hdt in (("bf16x3", torch.bfloat16), ("fp16x3", torch.float16)):          # the three-term path: bf16 halves / fp16 halves (round 6)
+        net.set_nograd_precision(mode)
+        assert net.encoder.precision == "bf16x3" and net.encoder.x3_dtype == hdt and net.encoder.compute_dtype == hdt, mode
     for mode, prec, dt, plain in (("bf16", None, torch.bfloat16, (12, 12)), ("fp16c8", "fp16c8", torch.float16, (12, 12)),
                                   ("fp16c8-9", "fp16c8", torch.float16, (9, 9)), ("fp16c4-8", "fp16c4", torch.float16, (8, 8)),
                                   ("fp16c4-12m8", "fp16c4", torch.float16, (12, 8)), ("fp16c4-9m7", "fp16c4", torch.float16, (9, 7))):
@@ -185,7 +188,7 @@ def test_teacher_precision_mode_strings():
         net.set_nograd_precision(mode)
         assert net.encoder.precision == "fp16c8" and net.encoder._x3_until() == x3 and net.encoder.c4_from == c4
         assert [net.encoder._is_c4(i) for i in range(12)] == [i >= c4 for i in range(12)]
-    for bad in ("fp16c4-", "fp16c4-m8", "bf16-3", "fp8", "fp16c4-9m", "fp16c8-x", "bf16x3-x2", "fp16c4-c6", "fp16c8-c", "fp16c8-9c6"):
+    for bad in ("fp16c4-", "fp16c4-m8", "bf16-3", "fp8", "fp16c4-9m", "fp16c8-x", "bf16x3-x2", "fp16x3-2", "fp16c4-c6", "fp16c8-c", "fp16c8-9c6"):
         with pytest.raises(AssertionError):
             net.set_nograd_precision(bad)
 
@@ -205,14 +208,17 @@ def test_auto_teacher_precision_is_backed_by_the_committed_accuracy_record():
     src = open(os.path.join(root, "tests", "test_precision_gpu.py")).read()
     names = re.search(r"TEACHER_CSRC = \(([^)]*)\)", src).group(1)
     assert tuple(re.findall(r'"([^"]+)"', names)) == bench.TEACHER_CSRC            # one definition of "the teacher's kernels" on both sides
+    assert tuple(re.findall(r'"([^"]+)"', re.search(r"TEACHER_HOST = \(([^)]*)\)", src).group(1))) == bench.TEACHER_HOST
+    # the pre-registered criterion: ONE set of constants (the test file's), bench.py reads the record by the same numbers
+    for name in ("CAM_BAR", "COND_MAX", "FP64_FACTOR", "AGREE_BAR", "MIOU_BAR", "MIN_DRAWS"):
+        assert float(re.search(rf"^{name} = (\S+)", src, re.M).group(1)) == float(getattr(bench, name)), name
     for crop in (224, 448, 640):
         c = bench.conformance(resolve_teacher_precision("auto", crop), crop)
-        assert c.get("lines", 0) >= 8, (crop, c)
-        assert c["cam_rel_err_own_scale_max"] <= 1e-3 and c["mask_miou_min"] >= 0.999 and c["label_agreement_min"] >= 0.999, (crop, c)
-    rec = bench.newest_profile("accuracy_teacher.txt")
-    if os.path.basename(rec) >= "r05":          # from round 5 on: the wide sweep and the bench's own batch size
-        c = bench.conformance(resolve_teacher_precision("auto", 448), 448)
-        assert c["lines"] >= 64 and c["seeds"] >= 32 and 16 in c["batch_sizes"], c
+        assert c.get("lines", 0) >= 8 and c["draws_all_crops"] >= bench.MIN_DRAWS, (crop, c)
+        assert c["planes_failed"] == 0 and c["label_agreement_min"] >= bench.AGREE_BAR and min(c["mask_miou_pooled"].values()) >= bench.MIOU_BAR, (crop, c)
+        assert c["tolerance_met"] or "another tree" in c.get("note", ""), (crop, c)      # (a source change after the record was taken is bench.py's business: it then reports false)
+    c = bench.conformance(resolve_teacher_precision("auto", 448), 448)
+    assert c["draws"] >= bench.MIN_DRAWS and c["seeds"] >= 32 and 16 in c["batch_sizes"], c          # the wide sweep and the bench's own batch size
 
 
 def test_no_inline_asm_valu_on_mfma_accumulators():

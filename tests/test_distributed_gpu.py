@@ -102,3 +102,38 @@ def test_two_rank_defer_groups_and_grid_policy_give_the_same_weights_and_overlap
     # completes after the single weight-gradient node, 0 early buckets; with six groups buckets 0-4 complete between the groups, 5 early)
     for a, b in zip(n_early[(6, 1)], n_early[(1, 0)]):
         assert a > b, (n_early, "six weight-gradient groups completed no more buckets before the end of the backward pass than one group")
+
+
+def test_teacher_graph_is_captured_before_ddp_and_changes_no_bit(tmp_path):
+    """under data parallelism the teacher's hipGraph is captured BEFORE DistributedDataParallel is constructed
+    (CoSATrainer.prepare_ddp), tools/ddp_check.py fails when the capture did not succeed, and the trained weights of a 2-rank run with the
+    captured side-stream teacher are the same bits as with the eager teacher (gloo, both ranks on card 0)."""
+    res = {}
+    for graph in (False, True):
+        out = str(tmp_path / f"graph{int(graph)}")
+        _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+              "--master-port", str(_free_port()), os.path.join(ROOT, "tools", "ddp_check.py"), "--out", out, "--steps", "4", "--crop", "64",
+              "--batch", "2", "--n-iter", str(10 ** 6)] + (["--teacher-graph"] if graph else []), env={"COSA_DIST_BACKEND": "gloo"})
+        res[graph] = [torch.load(os.path.join(out, f"rank{r}.pt")) for r in (0, 1)]
+        assert all(r["graph_captured"] == graph and r["world"] == 2 for r in res[graph])
+    for net in ("student", "teacher"):
+        for k in res[False][0][net]:
+            assert torch.equal(res[False][0][net][k], res[True][0][net][k]) and torch.equal(res[True][0][net][k], res[True][1][net][k]), f"{net}.{k}"
+
+
+def test_one_rank_over_rccl_with_the_captured_teacher(tmp_path):
+    """the part of the multi-GPU path a one-GPU box CAN run on the real backend: `init_process_group("nccl", device_id=...)` (RCCL, its watchdog
+    thread and comm stream), the teacher hipGraph captured under it and replayed on the side stream beside DDP's bucket all-reduces (a world
+    of one: the collectives are RCCL's own single-rank path), six weight-gradient groups.  Finite loss, capture asserted by the tool, and the
+    same weights as the run without a process group."""
+    out = str(tmp_path)
+    common = ["--out", out, "--steps", "4", "--crop", "64", "--batch", "2", "--n-iter", str(10 ** 6), "--teacher-graph", "--defer-groups", "6"]
+    _run([sys.executable, os.path.join(ROOT, "tools", "ddp_check.py"), "--force-dist"] + common,
+         env={"COSA_DIST_BACKEND": "nccl", "MASTER_PORT": str(_free_port()), "RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
+    r = torch.load(os.path.join(out, "rank0.pt"))
+    assert r["backend"] == "nccl" and r["graph_captured"] and r["teacher_async"] and r["world"] == 1 and r["loss"] == r["loss"]
+    _run([sys.executable, os.path.join(ROOT, "tools", "ddp_check.py"), "--single", "--ranks", "1"] + common)
+    s = torch.load(os.path.join(out, "single.pt"))
+    for net in ("student", "teacher"):
+        for k in r[net]:
+            assert torch.equal(r[net][k], s[net][k]), f"{net}.{k}: one rank over RCCL differs from the run without a process group"

@@ -51,3 +51,33 @@ def test_launcher_trains_evaluates_and_reloads(tmp_path, make_voc_tree, usepar):
     assert df["seg_loss"][1] > 0 and df["cam_loss"][1] > 0                       # post-warm-up iterations: every loss live
     log = open(os.path.join(out, "log_val.txt")).read()
     assert log.count("ON model") == 2 and log.count("AN model") == 2 and "Final Model Result" in log
+
+
+def test_reproduce_released_scores_a_checkpoint_in_the_reference_format(tmp_path, make_voc_tree):
+    """SURVEY f-3 readiness: tools/reproduce_released.py <ckpt> <voc_root> is finaleval (main.py:401-433) for a checkpoint file -- strict load of
+    `ckpt["model"]` by the reference's key names, evaluation with the dense-CRF row, the reference's score table.  The released voc_weights.pth
+    is not in this environment: the script runs here on a synthetic checkpoint written in the reference's dict format
+    (utils/torch_helper.py:101-117) over a tiny VOC-shaped tree; a bare state dict and a `module.`-prefixed one load too, a missing key fails."""
+    from PIL import Image
+    from cosa_amd.models import build_model
+    from cosa_amd.train_step import default_args
+    root, lists, names, labels = make_voc_tree(tmp_path, n=4)
+    os.makedirs(f"{root}/SegmentationClassAug")
+    for n in names:
+        im = np.asarray(Image.open(f"{root}/JPEGImages/{n}.jpg"))
+        Image.fromarray((im[..., 0] // 13).astype(np.uint8)).save(f"{root}/SegmentationClassAug/{n}.png")
+    shutil.copy(f"{lists}/train_aug.txt", f"{lists}/val.txt")
+    torch.manual_seed(0)
+    sd = build_model(default_args("VOC12", crop_size=64)).state_dict()
+    ck = str(tmp_path / "voc_weights.pth")
+    torch.save({"s_or_t": "t", "model": sd, "epoch": 32000, "args": None, "result": {"miou": 0.0}}, ck)
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "reproduce_released.py"), ck, root, "--name_list_dir", lists, "--work_dir", str(tmp_path / "w")]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "Final Model Result:" in r.stdout and "Seg_crf" in r.stdout and "CAM" in r.stdout, r.stdout[-2000:]
+    assert "Released checkpoint" in open(tmp_path / "w" / "REPRODUCE" / "log_val.txt").read()
+    bad = {k: v for k, v in sd.items() if k != "decoder.conv8.weight"}
+    torch.save({"module." + k: v for k, v in bad.items()}, ck)                   # bare, DDP-prefixed, one key short: strict load must refuse it
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode != 0 and "decoder.conv8.weight" in r.stderr, r.stderr[-2000:]

@@ -169,3 +169,30 @@ def test_oracle_vit_vs_reference_golden(golden):
         ref = g[name]
         assert o.shape == ref.shape, name
         assert np.abs(o.numpy() - ref).max() <= 1e-6 * max(1.0, np.abs(ref).max()), (name, np.abs(o.numpy() - ref).max())
+
+
+def _vit_base_state(g):
+    """the recipe weights of tests/golden/vit_base_d2.npz, replayed (oracle/gen_golden.py:recipe_state) and checked against the stored sha256"""
+    from oracle.gen_golden import recipe_state
+    shapes = {str(k): tuple(int(d) for d in str(s).split(",")) for k, s in zip(g["shape_keys"], g["shape_dims"])}
+    sd, digest = recipe_state(shapes)
+    assert digest == str(g["weights_sha256"]), "the replayed weights are not the ones the reference's forward was run with"
+    return sd
+
+
+def test_oracle_vit_at_vit_b_width_vs_reference_golden(golden):
+    """the same pin at the HIP kernels' own width: OracleViT(embed 768, 12 heads, depth 2) against the six outputs the
+    REFERENCE's VisionTransformer + LargeFOV + classifiers produced on tests/golden/vit_base_d2.npz (2 x 3 x 96 x 64; weights by recipe)"""
+    from oracle.torch_oracle import OracleViT
+    from oracle.gen_golden import VIT_BASE_CFG as cfg
+    g = golden("vit_base_d2")
+    sd = _vit_base_state(g)
+    m = OracleViT(num_classes=cfg["num_classes"], embed_dim=cfg["embed_dim"], depth=cfg["depth"], num_heads=cfg["num_heads"], aux_layer=cfg["aux_layer"])
+    assert set(sd) == set(m.named_state())
+    m.load_named(sd)
+    with torch.no_grad():
+        out = m(torch.from_numpy(g["x"]))
+    for name, o in zip(["cls", "cls_aux", "x4", "seg", "cam", "cam_aux"], out):
+        ref = g[name]
+        assert o.shape == ref.shape, name
+        assert np.abs(o.numpy() - ref).max() <= 2e-6 * max(1.0, np.abs(ref).max()), (name, np.abs(o.numpy() - ref).max())

@@ -3,6 +3,7 @@
   bf16    8 significant bits per MFMA operand  (the training path's type)
   fp16    11 significant bits, same kernels built with fp16 operands (csrc/op16.hpp)
   bf16x3  16 significant bits: every operand as hi + lo bf16 halves, three MFMA terms (hi*hi + lo*hi + hi*lo), fp32 accumulation
+  fp16x3  the same three terms with fp16 halves: 22 significant bits (round 6)
   fp16c8  fp16 hi (11 bits) + two e5m2 correction terms on the block-scaled 8-bit MFMA (~14 bits at 2x the 16-bit work; attention
           operands plain fp16, attention output as c8 rows): the benchmarked parity-grade mode since round 3
 
@@ -96,11 +97,18 @@ def _split_ref(v):
     return hi.float() + lo.float()
 
 
+# halves' dtype -> (GEMM tolerance, attention tolerance, LayerNorm re-composition tolerance) relative to the output scale
+_X3 = {torch.bfloat16: (2.0 ** -14, 2.0 ** -13, 2.0 ** -16), torch.float16: (2.0 ** -19, 2.0 ** -17, 2.0 ** -21)}
+
+
+@pytest.mark.parametrize("hdt", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("epi", [0, 1, 2])
-def test_gemm_bf16x3_vs_fp64(epi):
+def test_gemm_bf16x3_vs_fp64(epi, hdt):
     """hi + lo bf16 operands, three MFMA terms: the operands carry 16 significant bits (2^-17 relative rounding), the dropped lo*lo
     term is 2^-18; against an fp64 product of the fp32 inputs the error stays below 2^-14 of the output scale, ~100x below bf16.
-    Covers the persistent 256x256 kernel (M >= 4096, several jobs per workgroup, M tails) and the 128x128 kernel."""
+    Covers the persistent 256x256 kernel (M >= 4096, several jobs per workgroup, M tails) and the 128x128 kernel.
+    fp16 halves (round 6, "fp16x3"): 11 + 11 significant bits, lo halves below 2^-14 as fp16 subnormals (the MFMA must NOT flush them:
+    this tolerance -- 2^-19, 32x tighter -- is what shows it), the dropped lo*lo term 2^-24."""
     from cosa_amd import nn_ops
     torch.manual_seed(epi)
     for (M, N, K) in [(4099, 768, 768), (4608, 2304, 768), (5000, 768, 3072), (300, 768, 768), (70000, 256, 128), (131, 128, 64)]:
@@ -108,8 +116,8 @@ def test_gemm_bf16x3_vs_fp64(epi):
         w = torch.randn(N, K, device="cuda") * K ** -0.5
         b = torch.randn(N, device="cuda")
         r = torch.randn(M, N, device="cuda") if epi == 2 else None
-        xs, ws = nn_ops.split_rows(x, ones=True), nn_ops.split_rows(w, bias=b)
-        assert xs.shape == (M, 2 * K + 64) and torch.equal(xs[:, 2 * K:2 * K + 3].float().cpu(), torch.tensor([1., 1., 0.]).expand(M, 3))
+        xs, ws = nn_ops.split_rows(x, ones=True, dtype=hdt), nn_ops.split_rows(w, bias=b, dtype=hdt)
+        assert xs.dtype == hdt and xs.shape == (M, 2 * K + 64) and torch.equal(xs[:, 2 * K:2 * K + 3].float().cpu(), torch.tensor([1., 1., 0.]).expand(M, 3))
         y = nn_ops.gemm_x3(xs, ws, M, N, K, epi, residual=r.clone() if r is not None else None, ldy=2 * N + 64 if epi != 2 else None)
         ref = x.double() @ w.double().t() + b.double()
         if epi == 1:
@@ -118,43 +126,45 @@ def test_gemm_bf16x3_vs_fp64(epi):
             ref = ref + r.double()
             got = y.double()
         else:
-            assert y.shape == (M, 2 * N + 64) and y.dtype == torch.bfloat16
+            assert y.shape == (M, 2 * N + 64) and y.dtype == hdt
             got = y[:, :N].double() + y[:, N:2 * N].double()
         scale = max(ref.abs().max().item(), 1.0)
         err = (got - ref).abs().max().item()
-        assert err <= 2.0 ** -14 * scale, (epi, M, N, K, err / scale)
+        assert err <= _X3[hdt][0] * scale, (epi, M, N, K, err / scale)
 
 
+@pytest.mark.parametrize("hdt", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("B,N,H", [(2, 197, 12), (1, 785, 3), (2, 100, 3), (1, 1765, 2), (1, 1, 1), (1, 129, 1)])
-def test_attention_bf16x3_vs_fp64(B, N, H):
+def test_attention_bf16x3_vs_fp64(B, N, H, hdt):
     from cosa_amd import nn_ops
     torch.manual_seed(N)
     qkv = torch.randn(B * N, 3 * H * 64, device="cuda") * 1.5
-    qs = nn_ops.split_rows(qkv)[:, :6 * H * 64].contiguous()                 # [hi | lo] rows, as the split qkv projection writes them
-    out = torch.zeros(B * N, 2 * H * 64 + 64, device="cuda", dtype=torch.bfloat16)
+    qs = nn_ops.split_rows(qkv, dtype=hdt)[:, :6 * H * 64].contiguous()      # [hi | lo] rows, as the split qkv projection writes them
+    out = torch.zeros(B * N, 2 * H * 64 + 64, device="cuda", dtype=hdt)
     lse = torch.empty(B, H, N, device="cuda")
     nn_ops.attn_fwd_x3(qs, B, N, H, out, lse)
     q, k, v = qkv.double().view(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
     att = (q @ k.transpose(-1, -2)) * 0.125
     ref = (att.softmax(-1) @ v).transpose(1, 2).reshape(B * N, H * 64)
     got = out[:, :H * 64].double() + out[:, H * 64:2 * H * 64].double()
-    assert (got - ref).abs().max().item() <= 2.0 ** -13 * ref.abs().max().item() + 1e-6
-    assert torch.allclose(lse.double(), torch.logsumexp(att, -1), rtol=1e-5, atol=1e-4)
+    assert (got - ref).abs().max().item() <= _X3[hdt][1] * ref.abs().max().item() + 1e-6
+    assert torch.allclose(lse.double(), torch.logsumexp(att, -1), rtol=1e-5, atol=1e-4)          # (fp16 halves: the 2^10 carried by the probabilities is taken out again)
     aug = out[:, 2 * H * 64:].float().cpu()
     assert torch.equal(aug[:, :2], torch.ones(B * N, 2)) and aug[:, 2:].abs().max().item() == 0
 
 
-def test_layernorm_split_vs_torch():
+@pytest.mark.parametrize("hdt", [torch.bfloat16, torch.float16])
+def test_layernorm_split_vs_torch(hdt):
     from cosa_amd import nn_ops
     torch.manual_seed(0)
     x = torch.randn(1000, 768, device="cuda") * 3 + 1
     g, b = torch.rand(768, device="cuda") + 0.5, torch.randn(768, device="cuda")
-    out = torch.empty(1000, 1600, device="cuda", dtype=torch.bfloat16)
+    out = torch.empty(1000, 1600, device="cuda", dtype=hdt)
     _, y32 = nn_ops.layernorm_split(x, g, b, 1e-6, out=out, want_f32=True)
     ref = torch.nn.functional.layer_norm(x, (768,), g, b, 1e-6)
     assert (y32 - ref).abs().max().item() < 1e-4
     got = out[:, :768].float() + out[:, 768:1536].float()
-    assert (got - y32).abs().max().item() <= 2.0 ** -16 * y32.abs().max().item()
+    assert (got - y32).abs().max().item() <= _X3[hdt][2] * y32.abs().max().item()
     assert torch.equal(out[:, 1536:1538].float().cpu(), torch.ones(1000, 2)) and out[:, 1538:].float().abs().max().item() == 0
 
 
@@ -207,6 +217,15 @@ def test_c8_rows_and_layernorm_c8_fields():
     # saturation: values beyond the largest finite e5m2 (57344) keep a finite hi8
     big = torch.full((4, 128), 65000.0, device="cuda")
     assert torch.equal(_c8_fields(nn_ops.c8_rows(big), 128)[2], torch.full((4, 128), 57344.0, device="cuda"))
+    # round 6: the VALUE saturates once (c8.hpp:c8_sat) -- beyond +-57344, fp16's own range included, every field is the one of +-57344 (hi finite,
+    # lo8 = 0); up to it the fields are torch's conversions bit for bit (first part of this test: magnitudes up to ~4e3; here the top of the range)
+    huge = torch.tensor([1e6, -1e6, 65504.0, -70000.0, float("inf"), 57344.0, -57344.0, 3e38], device="cuda").repeat(16)[None].repeat(4, 1)
+    hh, hl, hh8, _ = _c8_fields(nn_ops.c8_rows(huge), 128)
+    assert torch.equal(hh, huge.clamp(-57344, 57344)) and hl.abs().max().item() == 0 and torch.equal(hh8, huge.clamp(-57344, 57344))
+    top = (torch.rand(4, 128, device="cuda") * 2 - 1) * 57344.0
+    th, tl, th8, _ = _c8_fields(nn_ops.c8_rows(top), 128)
+    rh, rl, rh8 = _c8_ref_fields(top)
+    assert torch.equal(th, rh) and torch.equal(tl, rl) and torch.equal(th8, rh8)
     x = torch.randn(1000, 768, device="cuda") * 3 + 1
     g, b = torch.rand(768, device="cuda") + 0.5, torch.randn(768, device="cuda")
     out = torch.empty(1000, 1600, device="cuda", dtype=torch.float16)
@@ -373,16 +392,38 @@ def teacher_csrc_hash():
     h = hashlib.sha256()
     for f in TEACHER_CSRC:
         h.update(open(os.path.join(ROOT, "cosa_amd", "csrc", f), "rb").read())
+    for f in TEACHER_HOST:          # (the compiler flags and the block -> operand-format map decide the arithmetic too)
+        h.update(open(os.path.join(ROOT, "cosa_amd", f), "rb").read())
     return h.hexdigest()[:16]
 
 
 TEACHER_CSRC = ("gemm_kernels.hip", "attn_kernels.hip", "split_kernels.hip", "vit_kernels.hip", "label_kernels.hip", "c4.hpp", "c8.hpp",
                 "op16.hpp", "common.hpp", "kernels.hpp")
+TEACHER_HOST = ("build.py", "models/vit.py")
 # COSA_ACCURACY_DATASET=COCO: the same checks with BASELINE configs[3] / [4]'s class count (81 CAM planes per set instead of 21; 80 labels in the
 # synthetic batch) -- on record in its own file, the VOC record keeps its format
 DATASET = os.environ.get("COSA_ACCURACY_DATASET", "VOC12")
 NCLS = {"VOC12": 21, "COCO": 81}[DATASET]
-RECORD = os.path.join(ROOT, "gpurun_out", "r05_accuracy_teacher.txt" if DATASET == "VOC12" else "r05_accuracy_teacher_coco.txt")
+RECORD = os.path.join(ROOT, "gpurun_out", "r06_accuracy_teacher.txt" if DATASET == "VOC12" else "r06_accuracy_teacher_coco.txt")
+
+# ---- the conformance criterion: PRE-REGISTERED -- these constants were committed before any round-6 draw was looked at --------
+# BASELINE.json: "within 1e-3 relative on fp32 CAMs ... mask IoU vs. CPU reference >= 0.999".  Per active (image, class) plane of a CAM set:
+#   (a) the LITERAL bar: max |delta| of the min-max normalised plane (what multi_scale_camseg returns, seg_helper.py:264-270) <= CAM_BAR.
+#   (b) a plane over that bar may take the EXEMPTION only if its conditioning (rawmax / peak from the ORACLE: the magnitude of the class logits
+#       over what the normalisation divides by) is > COND_MAX, and then it must keep BOTH own-scale err (|delta| x peak / rawmax) <= CAM_BAR AND
+#       |HIP - float64 oracle| <= CAM_BAR + FP64_FACTOR x |fp32 oracle - float64 oracle| on that plane: the exemption is bounded by how far the
+#       reference's own fp32 arithmetic is from exact arithmetic there, not by nothing.  Anything else is a FAILED plane.
+#   (c) masks: label agreement >= AGREE_BAR on every draw; mask IoU the way the reference scores it (utils/evaluation.py:17-35): ONE confusion matrix
+#       pooled over all draws of a (mode, crop, CAM set), per-class IoU = diag / (row + col - diag) over the classes the oracle's masks contain
+#       (255 = "ignore" counted as a category of its own), their mean >= MIOU_BAR.  The per-draw mIoU stays on record as a diagnostic.
+# A mode is CONFORMING at a crop only if no plane failed, (c) holds, and the record has >= MIN_DRAWS draws of it (bench.py: `tolerance_met`).
+CAM_BAR = 1e-3
+COND_MAX = 50.0
+FP64_FACTOR = 4.0
+AGREE_BAR = 0.999
+MIOU_BAR = 0.999
+MIN_DRAWS = 64
+_POOL = {}          # (mode, S, set name) -> {class: [tp, fp, fn]} over the draws of this pytest process (test_pooled_mask_iou_of_this_run)
 
 
 def _record(lines):
@@ -449,6 +490,50 @@ def _oracle_pass_b(S, seed, b):
     return _ORACLE[(S, seed, b)]
 
 
+_ORACLE64 = {}
+
+
+def _oracle_fp64_planes(S, seed, b, images):
+    """float64 leg of the oracle for the exempted planes: the SAME OracleViT weights / inputs in float64 (oracle/torch_oracle.py), for the image
+    pairs that hold `images`; returns {image: (cam64 [C, S, S], cam_aux64)} normalised planes.  Cached per (S, seed, b, pair)."""
+    from oracle import torch_oracle as to
+    from cosa_amd.train_step import default_args
+    sd, wimg = _oracle_pass(S, seed, b)[:2]
+    out = {}
+    for i in sorted({(im // 2) * 2 for im in images}):
+        key = (S, seed, b, i)
+        if key not in _ORACLE64:
+            for k in [k for k in _ORACLE64 if k[:3] != (S, seed, b)]:
+                _ORACLE64.pop(k)
+            m = to.OracleViT(num_classes=NCLS, aux_layer=default_args(DATASET).aux_layer)
+            m.load_named(sd)
+            m = m.double()
+            with torch.no_grad():
+                cam, cam_aux, _ = to.multi_scale_camseg(m, wimg[i:i + 2].double(), [1.0, 0.5, 1.5])
+            _ORACLE64[key] = (cam, cam_aux)
+        cam, cam_aux = _ORACLE64[key]
+        for j in range(cam.shape[0]):
+            out[i + j] = (cam[j], cam_aux[j])
+    return out
+
+
+def _confusion(pred, true, n):
+    """per class (0 .. n-1 and 255): [tp, fp, fn] of the HIP mask against the oracle's"""
+    out = {}
+    for c in list(range(n)) + [255]:
+        P, T = pred == c, true == c
+        tp, fp, fn = int((P & T).sum()), int((P & ~T).sum()), int((~P & T).sum())
+        if tp or fp or fn:
+            out[c] = [tp, fp, fn]
+    return out
+
+
+def pooled_miou(conf):
+    """conf: {class: [tp, fp, fn]} summed over draws -> (mean IoU over the classes present in the oracle's masks, min IoU, classes)"""
+    ious = [v[0] / (v[0] + v[1] + v[2]) for v in conf.values() if v[0] + v[2] > 0]
+    return (float(np.mean(ious)), float(np.min(ious)), len(ious)) if ious else (1.0, 1.0, 0)
+
+
 # mode -> (max normalised-CAM relative error, min label agreement, min mask IoU); the conforming modes carry the north-star bars
 NORTH_STAR = (1e-3, 0.999, 0.999)      # BASELINE.json north_star: 1e-3 relative on fp32 CAMs, mask IoU >= 0.999
 ON_RECORD = (2e-3, 0.999, 0.998)       # maps measured for the margin table: faster, but over the bar on at least one seed / crop
@@ -456,6 +541,7 @@ TEACHER_BARS = {
     "bf16": (3e-2, 0.99, 0.97),
     "fp16": (4e-3, 0.9990, 0.995),
     "bf16x3": NORTH_STAR,
+    "fp16x3": NORTH_STAR,          # round 6: the three-term path with fp16 halves (11 + 11 significant bits), same cost as bf16x3
     "fp16c8": NORTH_STAR,          # fp16 + two e5m2 correction terms (round 3): inside the bar on these seeds; 1.12e-3 on ONE of 40 held-out draws
     "fp16c4": NORTH_STAR,          # round 4: FP4 (e2m1, MX blocks) correction terms in qkv / fc1 / fc2 of every block
     "fp16c8-x2": NORTH_STAR,       # round 5: fp16c8 with blocks 0-1 on bf16x3 operands: the cheapest map that held the bars on all 40 held-out
@@ -500,17 +586,13 @@ def test_fused_teacher_vs_fp32_cpu_oracle_640(seed):
 
 
 def _check_teacher(mode, seed, S, bars=None, b=2):
-    """One draw: the fused HIP teacher in operand mode `mode` against the fp32 CPU oracle.  Per CAM set (main, aux) on record:
-      * normalised-CAM rel err -- max |delta| of the min-max normalised planes of the active classes (rounds 2-4's figure), and
-      * own-scale err -- the same difference expressed in the CAM's OWN units: |delta| x peak / rawmax per plane, peak = what the normalisation of
-        the oracle's plane divides by, rawmax = the magnitude of the class logits the plane was formed from (oracle/torch_oracle.py).  For a
-        well-activated class the two coincide.  For a class whose logits are negative nearly everywhere the ReLU leaves a sliver that the
-        normalisation stretches to [0, 1] together with every rounding error in it: on such a plane of seed 210 the reference's OWN fp32
-        arithmetic is 2.5e-4 away from float64 (profiles/r05_oracle_conditioning.txt) and bf16x3 operands (16 significant bits) read 2.3e-3
-        at a mask IoU of 0.99998 -- "1e-3 on the normalised plane" is not a property of the operand precision there but of the plane.
-    BASELINE.json's tolerance, "1e-3 relative on fp32 CAMs ... mask IoU >= 0.999", is asserted as: own-scale err <= bar, label agreement and
-    mask IoU (which see the stretched planes end to end through the thresholds) >= their bars; the normalised figure is recorded and reported
-    beside them (bench.py: `normalised_cam_rel_err_max`, `normalised_draws_over_bar`)."""
+    """One draw: the fused HIP teacher in operand mode `mode` against the fp32 CPU oracle, by the pre-registered criterion at the top of this
+    file (CAM_BAR / COND_MAX / FP64_FACTOR / AGREE_BAR / MIOU_BAR).  Per CAM set (main, aux) one record line: the worst literal figure
+    (normalised-CAM rel err), the worst own-scale err and conditioning, label agreement, the draw's own mIoU (diagnostic), then
+    `| planes N literal-ok L exempt E fail F` with one bracket per plane that is over the literal bar (conditioning, literal, own-scale, and --
+    where the exemption applies -- |HIP - fp64| against its bound CAM_BAR + FP64_FACTOR x |fp32 - fp64|), then the confusion counts
+    `conf class:tp/fp/fn,...` of the HIP mask against the oracle's that the pooled IoU is formed from.
+    Modes carrying NORTH_STAR are asserted by that criterion; the on-record / historic modes by their own looser per-draw bars (gross-error gates)."""
     from cosa_amd.models import build_model
     from cosa_amd.train_step import default_args
     from cosa_amd.utils import seg_helper
@@ -525,19 +607,55 @@ def _check_teacher(mode, seed, S, bars=None, b=2):
         masks = [seg_helper.cam2mask(wimg.cuda(), box, c * lab.cuda()[:, :, None, None], lab.cuda(), 0.7, 0.25).cpu().numpy() for c in (cam, cam_aux)]
     act = lab.bool()
     bar_rel, bar_agree, bar_iou = bars or TEACHER_BARS[mode]
-    lines = []
-    for name, g, o, mg, mo, (peak, rawmax) in (("cam", cam, cam_o, masks[0], masks_o[0], scales_o[0]), ("cam_aux", cam_aux, cam_aux_o, masks[1], masks_o[1], scales_o[1])):
-        d = (g.cpu() - o).abs().amax(dim=(2, 3))
-        rel = (d / o.abs().amax(dim=(2, 3)).clamp_min(1e-6))[act].max().item()
-        own = (d * peak / rawmax.clamp_min(1e-30))[act].max().item()
-        cond = (rawmax / peak)[act].max().item()
-        agree, iou = float(np.mean(mg == mo)), _miou(mg, mo)
-        lines.append(f"teacher {mode:8s} S={S} b={b} seed={seed:<2d} {name:8s}: normalised-CAM rel err {rel:.3e}  label agreement {agree:.5f}  mask mIoU {iou:.5f}"
-                     f"  own-scale err {own:.3e}  worst conditioning {cond:.1f}")
-    _record(lines)
-    for ln in lines:
-        own, agree, iou = (float(ln.split(k)[1].split()[0]) for k in ("own-scale err", "label agreement", "mask mIoU"))
-        assert own <= bar_rel and agree >= bar_agree and iou >= bar_iou, ln
+    strict = (bar_rel, bar_agree, bar_iou) == NORTH_STAR
+    lines, failed = [], []
+    sets = (("cam", cam.cpu(), cam_o, masks[0], masks_o[0], scales_o[0], 0), ("cam_aux", cam_aux.cpu(), cam_aux_o, masks[1], masks_o[1], scales_o[1], 1))
+    # planes over the literal bar whose conditioning admits the exemption: they need the float64 leg (strict modes only: the others are on record
+    # with the literal / own-scale figures alone)
+    over = {}
+    for name, g, o, _, _, (peak, rawmax), _ in sets:
+        d = (g - o).abs().amax(dim=(2, 3))
+        lit = d / o.abs().amax(dim=(2, 3)).clamp_min(1e-6)
+        cond = rawmax / peak
+        over[name] = [(int(i), int(c)) for i, c in zip(*torch.nonzero(act & (lit > CAM_BAR), as_tuple=True))]
+    need64 = sorted({i for name in over for (i, c) in over[name]
+                     if float((scales_o[0] if name == "cam" else scales_o[1])[1][i, c] / (scales_o[0] if name == "cam" else scales_o[1])[0][i, c]) > COND_MAX}) if strict else []
+    o64 = _oracle_fp64_planes(S, seed, b, need64) if need64 else {}
+    for name, g, o, mg, mo, (peak, rawmax), k in sets:
+        d = (g - o).abs().amax(dim=(2, 3))
+        lit = d / o.abs().amax(dim=(2, 3)).clamp_min(1e-6)
+        own = d * peak / rawmax.clamp_min(1e-30)
+        cond = rawmax / peak
+        n_planes, n_ok, n_ex, n_fail, notes = int(act.sum()), int((act & (lit <= CAM_BAR)).sum()), 0, 0, []
+        for (i, c) in over[name]:
+            cd, lt, ow = float(cond[i, c]), float(lit[i, c]), float(own[i, c])
+            if cd <= COND_MAX or not strict:
+                n_fail += 1
+                notes.append(f"[img {i} cls {c}: cond {cd:.1f} lit {lt:.3e} own {ow:.3e} FAIL]")
+                continue
+            p64 = o64[i][k][c]
+            e_ref = float((o[i, c].double() - p64).abs().max())
+            e_hip = float((g[i, c].double() - p64).abs().max())
+            bound = CAM_BAR + FP64_FACTOR * e_ref
+            ok = ow <= CAM_BAR and e_hip <= bound
+            n_ex, n_fail = n_ex + ok, n_fail + (not ok)
+            notes.append(f"[img {i} cls {c}: cond {cd:.1f} lit {lt:.3e} own {ow:.3e} fp64 {e_hip:.3e} bound {bound:.3e} {'ok' if ok else 'FAIL'}]")
+        agree, iou = float(np.mean(mg == mo)), _miou(mg, mo, NCLS)
+        conf = _confusion(mg, mo, NCLS)
+        pool = _POOL.setdefault((mode, S, name), {})
+        for c, v in conf.items():
+            pool[c] = [x + y for x, y in zip(pool.get(c, [0, 0, 0]), v)]
+        lines.append(f"teacher {mode:8s} S={S} b={b} seed={seed:<2d} {name:8s}: normalised-CAM rel err {float(lit[act].max()):.3e}  label agreement {agree:.5f}  mask mIoU {iou:.5f}"
+                     f"  own-scale err {float(own[act].max()):.3e}  worst conditioning {float(cond[act].max()):.1f}"
+                     f"  | planes {n_planes} literal-ok {n_ok} exempt {n_ex} fail {n_fail} {' '.join(notes)}"
+                     f" | conf {','.join(f'{c}:{v[0]}/{v[1]}/{v[2]}' for c, v in sorted(conf.items()))}")
+        if strict and (n_fail or agree < AGREE_BAR):
+            failed.append(lines[-1])
+        if not strict:
+            if not (float(own[act].max()) <= bar_rel and agree >= bar_agree and iou >= bar_iou):
+                failed.append(lines[-1])
+    _record(lines)          # (written before the asserts: a failing mode is on record too)
+    assert not failed, "\n".join(failed)
 
 
 # ---- the wide sweep behind the headline: >= 32 further weight / batch draws at 448^2 and ONE batch of the bench's own size
@@ -572,15 +690,38 @@ def test_headline_modes_on_held_out_seeds_sweep(seed):
         raise err
 
 
-@pytest.mark.skipif(os.environ.get("COSA_ACCURACY_B16", "0") != "1", reason="50 s of CPU oracle per draw: run with COSA_ACCURACY_B16=1 (the committed record holds its lines)")
+@pytest.mark.skipif(os.environ.get("COSA_ACCURACY_B16", "1") != "1", reason="COSA_ACCURACY_B16=0: the b = 16 draw (50 s of CPU oracle) switched off")
 @pytest.mark.parametrize("seed", [int(x) for x in os.environ.get("COSA_ACCURACY_B16_SEEDS", "7").split(",")])
 def test_headline_mode_on_the_bench_batch_b16(seed):
     """BASELINE configs[1] itself: b = 16 x 448^2 through the fused teacher (M = 87 904 token rows per pass, the launch shapes of the bench)
     against the fp32 CPU oracle run two images at a time"""
+    modes = [m for m in os.environ.get("COSA_ACCURACY_B16_MODES", "").split(",") if m] or [_auto_mode(448)]      # (the evidence run puts more modes on record)
+    err = None
     try:
-        _check_teacher(_auto_mode(448), seed, 448, bars=NORTH_STAR, b=16)
+        for mode in modes:
+            try:
+                _check_teacher(mode, seed, 448, bars=NORTH_STAR, b=16)
+            except AssertionError as e:
+                if mode == _auto_mode(448):
+                    err = e
     finally:
         _ORACLE.clear()
+    if err is not None:
+        raise err
+
+
+def test_pooled_mask_iou_of_this_run():
+    """criterion (c) on whatever this pytest process drew (runs after the per-draw tests above in file order; the committed record's pooled
+    figure over ALL draws is checked by bench.conformance / tests/test_boundary.py): per (mode, crop, CAM set) the confusion matrix pooled over
+    the draws, per-class IoU from it the way utils/evaluation.py:17-35 forms it, mean >= MIOU_BAR for the modes that carry NORTH_STAR"""
+    if not _POOL:
+        pytest.skip("no teacher draw ran in this process")
+    bad = []
+    for (mode, S, name), conf in sorted(_POOL.items()):
+        miou, lo, n = pooled_miou(conf)
+        if mode in (_auto_mode(S), "bf16x3") and miou < MIOU_BAR:          # (the other modes are on record; a sweep swallows their failures)
+            bad.append(f"{mode} S={S} {name}: pooled mIoU {miou:.5f} (min class IoU {lo:.5f}, {n} classes)")
+    assert not bad, bad
 
 
 @pytest.mark.parametrize("seed", (3, 17))
@@ -611,7 +752,7 @@ def test_teacher_masks_through_par_vs_fp32_cpu_oracle(seed):
     for name, mg, mo in (("cam", got[0], ref[0]), ("cam_aux", got[1], ref[1])):
         agree, iou = float(np.mean(mg == mo)), _miou(mg, mo)
         lines.append(f"teacher+PAR {mode:8s} S={S} b=2 seed={seed:<2d} {name:8s}: label agreement {agree:.5f}  mask mIoU {iou:.5f}")
-    with open(os.path.join(ROOT, "gpurun_out", "r05_accuracy_teacher_par.txt"), "a") as f:
+    with open(os.path.join(ROOT, "gpurun_out", "r06_accuracy_teacher_par.txt"), "a") as f:
         f.write("\n".join(lines) + "\n")
     for ln in lines:
         agree, iou = (float(ln.split(k)[1].split()[0]) for k in ("label agreement", "mask mIoU"))

@@ -1,7 +1,7 @@
 """which Python lines of a whole training step (teacher pass, student forward, backward, optimizer) launch torch's (ATen) kernels, with the bytes
 they touch (TorchDispatchMode + traceback; autograd's engine-side adds show up as "?")"""
 import os, sys, collections, traceback
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from torch.utils._python_dispatch import TorchDispatchMode
 from cosa_amd.train_step import CoSATrainer, default_args, synthetic_batch
@@ -23,7 +23,7 @@ class Spy(TorchDispatchMode):
         view = any(k in name for k in ("view", "reshape", "permute", "transpose", "slice", "select", "expand", "detach", "alias", "unsqueeze", "squeeze", "as_strided", "t.default", "unbind", "split", "_unsafe_view", "empty", "stride", "size", "is_", "_local_scalar", "lift"))
         if ts and not view:
             nbytes = sum(a.numel() * a.element_size() for a in ts)
-            fr = [f for f in traceback.extract_stack() if "cosa_amd" in f.filename and "who_copies" not in f.filename]
+            fr = [f for f in traceback.extract_stack() if "cosa_amd" in f.filename and "aten_calls_in_step" not in f.filename]
             where = f"{os.path.basename(fr[-1].filename)}:{fr[-1].lineno}" if fr else "?"
             key = (name, tuple(ts[0].shape), str(ts[0].dtype).replace("torch.", ""), where)
             agg[key] += 1

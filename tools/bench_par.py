@@ -1,5 +1,6 @@
 """PAR refine timing alone (the second half of the headline metric): cam2mask_multi on main+aux CAM sets, b=16 448^2.
-usage: python tools/bench_par.py"""
+usage: python tools/bench_par.py [chunk sizes ...]     (chunk sizes: also time the batch refined in slices of that many images -- does the
+48-weight affinity tensor of a slice stay in the Infinity Cache across the ten steps?)"""
 import os, sys, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -33,4 +34,12 @@ sep = lambda r: (lambda: (seg_helper.cam2mask(den, box, cams, lab, 0.7, 0.25, re
                           seg_helper.cam2mask(den, box, cams_aux, lab, 0.7, 0.25, refine_model=r, _fold_validation=True)))
 out = {
        "multi_ms": round(timed(multi(par)) - timed(multi(None)), 4), "separate_ms": round(timed(sep(par)) - timed(sep(None)), 4)}
+for ch in [int(a) for a in sys.argv[1:]]:
+    def chunked(r, ch=ch):
+        def f():
+            for i in range(0, b, ch):
+                seg_helper.cam2mask_multi(den[i:i + ch], box[i:i + ch], [cams[i:i + ch], cams_aux[i:i + ch]], lab[i:i + ch], [0.7, 0.7], [0.25, 0.25],
+                                          refine_model=r, _fold_validation=True)
+        return f
+    out[f"multi_chunks_of_{ch}_ms"] = round(timed(chunked(par)) - timed(chunked(None)), 4)
 print(json.dumps(out))

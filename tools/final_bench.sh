@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage (GPU box): tools/final_bench.sh -- the round's bench lines (default run + variants) and the rocprofv3 kernel stats of the default command
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT (the repository root on the GPU box)}" || exit 1
-R=${R:-r05}
+R=${R:-r06}
 python bench.py > gpurun_out/${R}_bench_final.json 2> gpurun_out/${R}_bench_final.err || { tail -5 gpurun_out/${R}_bench_final.err; exit 1; }
 tail -c 400 gpurun_out/${R}_bench_final.json; echo
 python bench.py --usepar --no-cpu-baseline --no-secondary > gpurun_out/${R}_bench_usepar.json 2>/dev/null || exit 1

@@ -242,7 +242,11 @@ def main():
     args = default_args("VOC12", crop_size=S, compute_dtype=torch.float32)
     net = build_model(args)
     sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
-    wimg, simg, lab, box = synthetic_batch(2, S, 20, torch.device('cpu'), seed=seed + 2)
+    nb = int(os.environ.get("SIM_B", "2"))               # batch size of the draw; SIM_SLICE=i0:i1 keeps images i0 .. i1-1 of it (a pair of a b = 16 draw)
+    wimg, simg, lab, box = synthetic_batch(nb, S, 20, torch.device('cpu'), seed=seed + 2)
+    if os.environ.get("SIM_SLICE"):
+        i0, i1 = (int(v) for v in os.environ["SIM_SLICE"].split(":"))
+        wimg, simg, lab, box = wimg[i0:i1], simg[i0:i1], lab[i0:i1], box[i0:i1]
 
     def run(cfg):
         m = to.OracleViT(num_classes=21, aux_layer=-4)

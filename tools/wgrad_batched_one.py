@@ -1,5 +1,5 @@
 import sys, os, torch, json
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cosa_amd import nn_ops
 torch.manual_seed(0)
 M = 12560
