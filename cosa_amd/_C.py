@@ -116,6 +116,8 @@ _SIGS.update({
     "cosa_gelu_backward": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_longlong, c_void_p]),
     "cosa_transpose_record_bytes": (c_size_t, []),
     "cosa_transpose_cast_batched": (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    "cosa_broadcast_rows": (c_int, [c_void_p, c_void_p, c_int, ctypes.c_longlong, c_void_p]),
+    "cosa_resize_bilinear": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "cosa_split_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, ctypes.c_longlong, c_int, c_void_p]),
     "cosa_layernorm_split": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     "cosa_gemm_bf16x3": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),

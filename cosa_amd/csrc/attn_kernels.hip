@@ -96,9 +96,9 @@ __device__ __forceinline__ bool attn_block_map(int nblk, int ngroups, int H, int
 // recorded inside a captured hipGraph on ROCm, so bench.py reads these instead.
 
 // ---- forward with bf16x3 ("split") operands: the parity-grade no-grad passes ------------------------------------------------------
-// (both builds since round 6: with fp16 operands this is the attention of the "fp16x3" mode -- hi + lo fp16 halves.  There the probabilities
-// carry a factor 2^kX3Shift: exp2 arguments are s - m + kX3Shift, so that the lo half of a probability of ~1/N, 2^-12 of it, stays an fp16
-// NORMAL number (2^-12 2^10 / 1765 > 2^-14); the row sum carries the same factor and it cancels in O / l; LSE subtracts it again)
+// (both builds since round 6: with fp16 operands this is the attention of the "fp16x3" mode -- hi + lo fp16 halves.  The un-normalised
+// probabilities are <= 1 with the row maximum at 1: a lo half that falls into fp16's subnormal range belongs to a probability below 2^-3 of
+// the maximum and carries an absolute 2^-25 of it -- nothing is scaled.  The fp16 MFMA takes subnormal operands as they are (measured).)
 // The algorithm above, 4 waves x 32 queries per workgroup; q, k, v and the probabilities are carried as hi + lo bf16 halves (16 significant
 // bits) and every product is the three MFMA terms hi*hi + hi*lo + lo*hi with fp32 accumulation:
 //     S^T  = K_h Q_h^T + K_h Q_l^T + K_l Q_h^T          O^T += V_h^T P_h^T + V_h^T P_l^T + V_l^T P_h^T
@@ -108,11 +108,6 @@ __device__ __forceinline__ bool attn_block_map(int nblk, int ngroups, int H, int
 // one is computed, one barrier per tile, no staging registers.  (The first version staged them through 32 registers that the compiler
 // kept in scratch: every tile waited for its global loads to store them, 1.02 ms per launch of the teacher's mix against 0.14 ms for
 // the bf16 kernel.)
-#if COSA_OP_F16
-constexpr float kX3Shift = 10.0f;
-#else
-constexpr float kX3Shift = 0.0f;
-#endif
 __global__ __launch_bounds__(256) void attn_fwd_x3_kernel(const op16 *__restrict__ qkv, op16 *__restrict__ out, float *__restrict__ lse,
                                                          int N, int H, int nblk, int ngroups, float scale_log2e, int ldq, int ldo)
 {
@@ -214,8 +209,8 @@ __global__ __launch_bounds__(256) void attn_fwd_x3_kernel(const op16 *__restrict
         float ls = 0.f;
 #pragma unroll
         for (int i = 0; i < 16; i++) {
-            s0[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[i], scale_log2e, kX3Shift - m));
-            s1[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[i], scale_log2e, kX3Shift - m));
+            s0[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[i], scale_log2e, -m));
+            s1[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[i], scale_log2e, -m));
             ls += s0[i] + s1[i];
         }
         l += ls;
@@ -259,7 +254,14 @@ __global__ __launch_bounds__(256) void attn_fwd_x3_kernel(const op16 *__restrict
             op16x4 h0, h1, l0, l1;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const float a = o0[4 * g + j] * inv, c = o1[4 * g + j] * inv;
+                // The products must be ROUNDED fp32 values before they are split: under -ffp-contract=fast the fp16 build fused the multiply
+                // into one of the two conversions (v_fma_mixlo_f16: one rounding of the exact product) and not into the other (v_mul_f32 +
+                // v_cvt: two roundings), so that on a double-rounding tie -- 2 to 4 elements in 150 000 -- the stored hi half and the hi half
+                // the lo half was formed from differed by one fp16 ulp (round 6, found by the fp16x3 kernel test).
+                // The empty asm makes each product an opaque fp32 register (no instruction is emitted; the backend's fusion is a global
+                // option under -ffp-contract=fast and ignores `#pragma clang fp contract(off)`).
+                float a = o0[4 * g + j] * inv, c = o1[4 * g + j] * inv;
+                asm volatile("" : "+v"(a), "+v"(c));
                 h0[j] = (op16)a; l0[j] = (op16)(a - (float)h0[j]);
                 h1[j] = (op16)c; l1[j] = (op16)(c - (float)h1[j]);
             }
@@ -279,7 +281,7 @@ __global__ __launch_bounds__(256) void attn_fwd_x3_kernel(const op16 *__restrict
                 *reinterpret_cast<op16x8 *>(ap + 8 * c) = a;
             }
         }
-        if (hh == 0 && lse) lse[((size_t)b * H + h) * N + q] = (m - kX3Shift + __builtin_amdgcn_logf(l)) * 0.6931471805599453f;
+        if (hh == 0 && lse) lse[((size_t)b * H + h) * N + q] = (m + __builtin_amdgcn_logf(l)) * 0.6931471805599453f;
     }
 }
 
@@ -565,7 +567,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const op16 *__restric
                         _Float16 hi[4];
 #pragma unroll
                         for (int j = 0; j < 4; j++) {
-                            const float v = o[u][d][4 * g + j] * inv;
+                            float v = o[u][d][4 * g + j] * inv;
+                            asm volatile("" : "+v"(v));          // one rounded fp32 value before the split (see attn_fwd_x3_kernel's output stage)
                             hi[j] = (_Float16)v;
                             hv[e][j] = (float)hi[j];
                             lv[e][j] = (v - hv[e][j]) * kC4LoScale;

@@ -48,6 +48,13 @@ __device__ __forceinline__ float gelu_erf(float x)
     return 0.5f * x * (1.0f + erfx);
 }
 
+// A value that is about to be split into hi = op16(v) and lo = op16(v - hi) must be ONE rounded fp32 number.  Under -ffp-contract=fast the fp16
+// build may fuse the multiply that produced v into a conversion (v_fma_mixlo_f16: one rounding of the exact product) at one use and not at
+// another (v_mul_f32 + v_cvt: two roundings); on a double-rounding tie the stored hi and the hi the lo half was formed from then differ by
+// one fp16 ulp (found in round 6 in the fp16x3 attention: 2 to 4 elements in 150 000).  The empty asm emits no instruction; it makes the
+// values opaque registers.  (Its operands are VALU results -- GELU of an accumulator -- never MFMA accumulators themselves.)
+#define COSA_SPLIT_OPAQUE(a, b) asm volatile("" : "+v"(a), "+v"(b))
+
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
 
@@ -288,6 +295,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const op16 *__restric
                         vlo[r] = (op16)gelu_erf(t);
                     } else {
                         if (EPI == EPI_GELU) t = gelu_erf(t);
+                        if (SPLIT) asm volatile("" : "+v"(t));      // a ROUNDED fp32 value before it is split (COSA_SPLIT_OPAQUE below)
                         v[r] = (op16)t;
                         if (SPLIT) vlo[r] = (op16)(t - (float)v[r]);
                     }
@@ -693,6 +701,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_v6_kernel(const op16 *__rest
                 v0_[r] = gelu_erf(v0_[r]);                                                                          \
                 v1_[r] = gelu_erf(v1_[r]);                                                                          \
                 if (C8OUT) { v0_[r] = c8_sat(v0_[r]); v1_[r] = c8_sat(v1_[r]); }   /* saturate the VALUE once: its two 8-bit terms then need no clamp (c8.hpp) */ \
+                if (SPLIT == 1 || C4OUT) COSA_SPLIT_OPAQUE(v0_[r], v1_[r]);                                         \
             }                                                                                                       \
         }                                                                                                           \
         const op16x2 p0_ = {(op16)v0_[0], (op16)v0_[1]}, p1_ = {(op16)v0_[2], (op16)v0_[3]};                        \

@@ -138,6 +138,12 @@ __global__ __launch_bounds__(1024) void minmax_norm_kernel(float *__restrict__ c
 __device__ __forceinline__ unsigned f2key(float f) { const unsigned u = __float_as_uint(f); return u ^ ((u >> 31) ? 0xffffffffu : 0x80000000u); }
 __device__ __forceinline__ float key2f(unsigned k) { return __uint_as_float(k ^ ((k >> 31) ? 0x80000000u : 0xffffffffu)); }
 
+__global__ __launch_bounds__(256) void minmax_init_kernel(unsigned *__restrict__ kmin, unsigned *__restrict__ kmax, int BC)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < BC) { kmin[i] = 0xFFFFFFFFu; kmax[i] = 0u; }
+}
+
 __global__ __launch_bounds__(256) void minmax_reduce_kernel(const float *__restrict__ cam, int HW, const float *__restrict__ active,
                                                            unsigned *__restrict__ kmin, unsigned *__restrict__ kmax)
 {
@@ -385,6 +391,46 @@ __global__ __launch_bounds__(256) void upsample_argmax_merge_kernel(const float 
 
 using namespace cosa;
 
+namespace {
+// F.interpolate(x, size=(OH, OW), mode="bilinear", align_corners=False) on NCHW fp32 planes -- the teacher's input rescale (utils/seg_helper.py:247-250).
+// ATen's formula (area_pixel_compute_source_index: src = scale (dst + 0.5) - 0.5 clamped at 0, scale = in / out; the blend
+// h0 (w0 a + w1 b) + h1 (w0 c + w1 d)).  The source index is ONE fused multiply-add, as in ATen's own CPU and GPU builds (both are compiled
+// with contraction; evaluated as a product and a difference the index is off by up to an ulp of the image size and the result by 3e-5 of
+// the image range); written as an explicit fmaf because this translation unit is built with -ffp-contract=off.  Against the CPU operator:
+// within 1 ulp of the image range (tests/test_label_gpu.py::test_resize_bilinear_is_atens_formula).
+__global__ __launch_bounds__(256) void resize_bilinear_kernel(const float *__restrict__ src, float *__restrict__ dst, int planes, int H, int W,
+                                                             int OH, int OW, float rh, float rw)
+{
+    const size_t n = (size_t)planes * OH * OW;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int ox = (int)(i % OW), oy = (int)((i / OW) % OH);
+        const size_t pl = i / ((size_t)OW * OH);
+        float h1r = __builtin_fmaf(rh, (float)oy + 0.5f, -0.5f);
+        h1r = h1r < 0.f ? 0.f : h1r;
+        float w1r = __builtin_fmaf(rw, (float)ox + 0.5f, -0.5f);
+        w1r = w1r < 0.f ? 0.f : w1r;
+        const int h1 = (int)h1r, w1 = (int)w1r;
+        const int h1p = h1 < H - 1 ? 1 : 0, w1p = w1 < W - 1 ? 1 : 0;
+        const float h1l = h1r - (float)h1, h0l = 1.0f - h1l, w1l = w1r - (float)w1, w0l = 1.0f - w1l;
+        const float *p = src + pl * (size_t)H * W + (size_t)h1 * W + w1;
+        const float top = __builtin_fmaf(w0l, p[0], w1l * p[w1p]);
+        const float bot = __builtin_fmaf(w0l, p[(size_t)h1p * W], w1l * p[(size_t)h1p * W + w1p]);
+        dst[i] = __builtin_fmaf(h0l, top, h1l * bot);
+    }
+}
+}  // namespace
+
+extern "C" int cosa_resize_bilinear(const float *src, float *dst, int planes, int H, int W, int OH, int OW, void *stream)
+{
+    COSA_REQUIRE(src && dst && planes > 0 && H > 0 && W > 0 && OH > 0 && OW > 0, "cosa_resize_bilinear: bad arguments");
+    const size_t n = (size_t)planes * OH * OW;
+    const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 256 * 32);
+    hipLaunchKernelGGL(resize_bilinear_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), src, dst, planes, H, W, OH, OW,
+                       (float)H / (float)OH, (float)W / (float)OW);
+    COSA_LAUNCH_CHECK();
+    return COSA_OK;
+}
+
 extern "C" int cosa_denormalize_img(const float *img, float *out, int B, int H, int W, void *stream)
 {
     COSA_REQUIRE(img && out && B > 0 && H > 0 && W > 0, "cosa_denormalize_img: bad arguments");
@@ -410,8 +456,12 @@ extern "C" int cosa_cam_minmax_norm_ws(float *cam, int BC, int HW, const float *
     COSA_REQUIRE(cam && workspace && BC > 0 && HW > 0 && BC <= 65535, "cosa_cam_minmax_norm_ws: bad arguments");
     hipStream_t st = as_stream(stream);
     unsigned *kmin = static_cast<unsigned *>(workspace), *kmax = kmin + BC;
-    COSA_HIP_CHECK(hipMemsetAsync(kmin, 0xFF, (size_t)BC * sizeof(unsigned), st));
-    COSA_HIP_CHECK(hipMemsetAsync(kmax, 0x00, (size_t)BC * sizeof(unsigned), st));
+    // The keys are initialised by a KERNEL, not by hipMemsetAsync: this call sits inside the teacher's captured hipGraph, and memset nodes of
+    // a captured graph are not ordered with the kernel nodes around them from the second replay on (ROCm 7.0: the second normalisation of a
+    // pass -- same workspace block, reused by the allocator -- saw its keys reset while the first one's apply kernel was still to read
+    // them, or its own reduce ran before the reset: NaN planes in every replay but the first.  Round 6; tests/test_label_gpu.py).
+    hipLaunchKernelGGL(minmax_init_kernel, dim3((BC + 255) / 256), dim3(256), 0, st, kmin, kmax, BC);
+    COSA_LAUNCH_CHECK();
     int chunks = (HW + 8191) / 8192;                 // >= 32 elements per thread
     chunks = chunks < 1 ? 1 : (chunks > 64 ? 64 : chunks);
     hipLaunchKernelGGL(minmax_reduce_kernel, dim3(chunks, BC), dim3(256), 0, st, cam, HW, active, kmin, kmax);

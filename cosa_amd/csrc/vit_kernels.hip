@@ -831,6 +831,25 @@ extern "C" int cosa_im2col_flip_c8_tokens(const float *x, void *rows, int B, int
     return COSA_OK;
 }
 
+// dst [B][n] fp32 = src [n] for every b: the fp32 residual stream of a no-grad pass starts as (cls + pos_0 | pos rows) per image before the patch
+// projection adds into it in place (models/vit/vit.py:283-300); n % 4 == 0
+__global__ __launch_bounds__(256) void broadcast_rows_kernel(const float4 *__restrict__ src, float4 *__restrict__ dst, int B, size_t n4)
+{
+    const size_t total = (size_t)B * n4;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) dst[e] = src[e % n4];
+}
+
+extern "C" int cosa_broadcast_rows(const float *src, float *dst, int B, long long n, void *stream)
+{
+    COSA_REQUIRE(src && dst && B > 0 && n > 0 && n % 4 == 0, "cosa_broadcast_rows: bad arguments (n %% 4 == 0)");
+    const size_t total = (size_t)B * (size_t)(n / 4);
+    const unsigned grid = (unsigned)std::min<size_t>((total + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(broadcast_rows_kernel, dim3(grid), dim3(256), 0, as_stream(stream), reinterpret_cast<const float4 *>(src),
+                       reinterpret_cast<float4 *>(dst), B, (size_t)(n / 4));
+    COSA_LAUNCH_CHECK();
+    return COSA_OK;
+}
+
 // out [B, n+1, D] fp32 = (cls | tok [B, n, D]) + pos [n+1, D]; tok / cls / pos in one 16-bit type (dtype 1 = bf16, 2 = fp16), D % 8 == 0
 extern "C" int cosa_embed_finish(const void *tok, const void *cls, const void *pos, float *out, int B, int n, int D, int dtype, void *stream)
 {

@@ -225,7 +225,9 @@ class VITNetwork(nn.Module):
         _, tok, tok_aux, tok32 = feats
         p = self.encoder.patch_size
         h, w = x.shape[-2] // p, x.shape[-1] // p
-        x4 = tok.reshape(B, h, w, -1).permute(0, 3, 1, 2)            # NCHW view, channels-last strides (no copy)
+        # NCHW view, channels-last strides (no copy).  The fused no-grad path returns the fp32 tokens as the feature map, like the reference (round 6:
+        # it returned its 16-bit copy -- 3e-3 of the range in the bf16 builds against the reference at ViT-B width; no loss reads it)
+        x4 = (tok if tok32 is None else tok32).reshape(B, h, w, -1).permute(0, 3, 1, 2)
         if tok32 is not None and tok.dtype in vitencoder._OP16 and self.decoder.conv6.weight.shape[1] % 64 == 0:
             seg = self.decoder.forward_tokens(tok, B, h, w)            # fused no-grad path: own implicit-GEMM convs
         elif tok.dtype == torch.bfloat16 and tok.is_cuda and self.decoder.conv6.weight.shape[1] % 128 == 0 \

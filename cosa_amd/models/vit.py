@@ -518,8 +518,8 @@ class VisionTransformer(nn.Module):
         for x, (B, N), o0, o1 in zip(xs, shapes, offs[:-1], offs[1:]):
             h, w = x.shape[2] // p, x.shape[3] // p
             pos = self._pos_for_grid(h, w, torch.float32)                              # [1, n+1, D]
-            first = torch.cat((pos[:, :1] + cls, pos[:, 1:]), dim=1)                    # (a [n+1, D] tensor: small)
-            xr[o0:o1].view(B, N, D).copy_(first.expand(B, N, D))
+            first = torch.cat((pos[:, :1] + cls, pos[:, 1:]), dim=1).contiguous()       # (a [n+1, D] tensor: small)
+            _C.check(_C.lib().cosa_broadcast_rows(_C.ptr(first), _C.ptr(xr[o0:o1]), B, N * D, _C.stream_ptr()), "cosa_broadcast_rows")
             xf = x.float().contiguous()
             _C.check(_C.lib().cosa_im2col_flip_c8_tokens(_C.ptr(xf), _C.ptr(cols[o0:o1]), x.shape[0], x.shape[1], x.shape[2], x.shape[3], p, nf, 1,
                                                          _C.stream_ptr()), "cosa_im2col_flip_c8_tokens")

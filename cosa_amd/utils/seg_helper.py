@@ -24,6 +24,16 @@ def _refresh_once(model):
 # --------------------------------------------------------------------------------------------
 # multi_scale_camseg  (utils/seg_helper.py:232-275)
 # --------------------------------------------------------------------------------------------
+def resize_bilinear(x, size):
+    """F.interpolate(x, size=size, mode='bilinear', align_corners=False) for NCHW fp32 on the GPU (own kernel: the teacher's input rescale,
+    utils/seg_helper.py:247-250, was the last ATen kernel inside the captured teacher pass)"""
+    x = x.contiguous().float()
+    b, c, h, w = x.shape
+    out = torch.empty((b, c, int(size[0]), int(size[1])), device=x.device, dtype=torch.float32)
+    _C.check(_C.lib().cosa_resize_bilinear(_C.ptr(x), _C.ptr(out), b * c, h, w, int(size[0]), int(size[1]), _C.stream_ptr()), "cosa_resize_bilinear")
+    return out
+
+
 def _flip_merge_upsample(src, dst, B, S, mode, accumulate, active=None, prev_active=None):
     src = src.contiguous().float()
     _, C, h, w = src.shape
@@ -80,7 +90,7 @@ def multi_scale_camseg(model, imgs, scales, _active_labels=None, _seg_scales=Fal
     seg_list = []
     act = _active_labels.contiguous().float() if _active_labels is not None else None
     with torch.no_grad():
-        scaled = [imgs if s == 1.0 else F.interpolate(imgs, size=(int(s * h), int(s * w)), mode='bilinear', align_corners=False) for s in scales]
+        scaled = [imgs if s == 1.0 else resize_bilinear(imgs, (int(s * h), int(s * w))) for s in scales]
         # cosa_amd networks can take all scales in one go (shared GEMM/LayerNorm launches across scales), the mirror images only as
         # im2col rows of the patch projection (flip_pairs)
         if getattr(model, "can_forward_multi", lambda _x: False)(scaled[0]):
@@ -129,7 +139,7 @@ def multi_scale_camsegv3(model, imgs, scales, getcls=False, _per_image_cls=False
     cam = cam_aux = seg = None
     cls_f_ = cls_a_ = None
     with torch.no_grad():
-        scaled = [imgs if s == 1.0 else F.interpolate(imgs, size=(int(s * h), int(s * w)), mode='bilinear', align_corners=False) for s in scales]
+        scaled = [imgs if s == 1.0 else resize_bilinear(imgs, (int(s * h), int(s * w))) for s in scales]
         if getattr(model, "can_forward_multi", lambda _x: False)(scaled[0]):
             multi, inputs = model.forward_multi(scaled, flip_pairs=True, need_cls=bool(getcls)), None
         else:

@@ -45,6 +45,9 @@ int cosa_cam_minmax_norm(float *cam, int BC, int HW, const float *active /* [BC]
 /* the same result bit for bit with a plane spread over several workgroups; workspace: 2 * BC unsigned ints of device memory */
 int cosa_cam_minmax_norm_ws(float *cam, int BC, int HW, const float *active /* [BC] or NULL */, void *workspace, void *stream);
 
+/* utils/seg_helper.py:247-250: F.interpolate(imgs, size, mode="bilinear", align_corners=False) of the teacher's input batch to the 0.5x / 1.5x
+ * scales; src [planes, H, W] fp32 -> dst [planes, OH, OW] (ATen's formula incl. its fused source-index multiply-add: within 1 ulp of the image range of the CPU operator) */
+int cosa_resize_bilinear(const float *src, float *dst, int planes, int H, int W, int OH, int OW, void *stream);
 /* ---------------------------------------------------------------------------------------
  * utils/seg_helper.py:252-270  fused tail of multi_scale_camseg for ONE scale:
  *   up   = bilinear(src[2b,C,h,w] -> (S,S), align_corners=False)
@@ -283,6 +286,9 @@ int cosa_layernorm(const float *x, const void *gamma, const void *beta, void *y_
  *   cosa_gelu_backward          dH = dA * gelu_erf'(H) (bf16, n % 8 == 0)
  *   cosa_transpose_cast_batched bf16 W^T shadows of the fp32 master weights (one launch for all tensors): the input gradient
  *                               dX = dY W is then cosa_gemm_bf16(dY, W^T, zeros) -- the forward kernel, no second GEMM family   */
+/* dst [B][n] fp32 = src [n] for every b (n % 4 == 0): the fp32 token stream of a no-grad pass starts as (cls + pos_0 | pos rows) per image,
+ * models/vit/vit.py:283-300; the patch projection then adds into it in place */
+int cosa_broadcast_rows(const float *src, float *dst, int B, long long n, void *stream);
 /* vit.py:288-291: bicubic resize of the frozen 14 x 14 position grid to the token grid as a 16-tap gather (idx / wgt [P,16]: the non-zero
  * entries of the interpolation matrix's rows): out[P, D] fp32 = sum_t wgt[p][t] * pe[idx[p][t]][:]                                 */
 int cosa_pos_resize(const float *pe, const int *idx, const float *wgt, float *out, int P, int D, void *stream);

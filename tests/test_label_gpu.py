@@ -415,3 +415,20 @@ def test_radix_sort_is_a_stable_sort(n, bits):
     order = np.argsort(keys, kind="stable")
     assert np.array_equal(ok.cpu().numpy().view(np.uint32), keys[order])
     assert np.array_equal(ov.cpu().numpy().view(np.uint32), vals[order])
+
+
+@pytest.mark.parametrize("size", [(224, 224), (672, 672), (37, 91), (448, 448), (960, 960)])
+def test_resize_bilinear_is_atens_formula(size):
+    """the teacher's input rescale (utils/seg_helper.py:247-250: F.interpolate(..., mode='bilinear', align_corners=False)) on the own kernel:
+    ATen's formula with its fused source-index multiply-add -- against the fp32 CPU operator (what the oracle runs) within 2 ulp of the image range
+    (an unfused index is 3e-5 off: the 1.5x pass of the teacher then starts from other pixels than the oracle's), and the same
+    sampling geometry (a constant image stays constant to the last bit or two)"""
+    from cosa_amd.utils import seg_helper
+    torch.manual_seed(size[0])
+    for b, c, h, w in ((2, 3, 448, 448), (1, 3, 50, 70)):
+        x = torch.randn(b, c, h, w) * 2
+        ref = torch.nn.functional.interpolate(x, size=size, mode="bilinear", align_corners=False)
+        got = seg_helper.resize_bilinear(x.cuda(), size).cpu()
+        assert got.shape == ref.shape and (got - ref).abs().max().item() <= 2 * 2.0 ** -23 * x.abs().max().item()
+        const = torch.full((1, 1, h, w), 0.37)
+        assert (seg_helper.resize_bilinear(const.cuda(), size).cpu() - 0.37).abs().max().item() <= 1e-7

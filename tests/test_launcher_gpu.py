@@ -75,7 +75,7 @@ def test_reproduce_released_scores_a_checkpoint_in_the_reference_format(tmp_path
     cmd = [sys.executable, os.path.join(ROOT, "tools", "reproduce_released.py"), ck, root, "--name_list_dir", lists, "--work_dir", str(tmp_path / "w")]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    assert "Final Model Result:" in r.stdout and "Seg_crf" in r.stdout and "CAM" in r.stdout, r.stdout[-2000:]
+    assert "Final Model Result:" in r.stdout and "Seg_vd" in r.stdout and "Seg_crf" in r.stdout and "mIoU" in r.stdout, r.stdout[-2000:]      # (finaleval's table: main.py:414-425)
     assert "Released checkpoint" in open(tmp_path / "w" / "REPRODUCE" / "log_val.txt").read()
     bad = {k: v for k, v in sd.items() if k != "decoder.conv8.weight"}
     torch.save({"module." + k: v for k, v in bad.items()}, ck)                   # bare, DDP-prefixed, one key short: strict load must refuse it

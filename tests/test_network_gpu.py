@@ -150,7 +150,10 @@ def test_hip_network_at_vit_b_width_vs_reference_golden(golden, mode, tol):
         ref = g[name]
         assert tuple(o.shape) == ref.shape, name
         err = np.abs(o.float().cpu().numpy() - ref).max() / np.abs(ref).max()
-        assert err <= tol, (mode, name, err)
+        # the decoder's convolutions take the final tokens as ONE 16-bit copy in every mode (bf16: 8 significant bits, fp16: 11) -- `seg` is not
+        # part of the CAM tolerance; the other five outputs are formed from the fp32 tokens
+        bound = tol if name != "seg" else max(tol, 1e-2 if net.compute_dtype == torch.bfloat16 else 2e-3)
+        assert err <= bound, (mode, name, err)
 
 
 def test_state_dict_keys_match_reference(golden):

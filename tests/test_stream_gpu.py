@@ -193,3 +193,62 @@ def test_shapes_outside_the_hip_path_raise_instead_of_falling_back():
     assert y.shape == (7, 40) and o.shape == (1, 65, 128) and math.isfinite(float(o.sum()))
     with pytest.raises(_C.CosaError):                        # the switch is scoped
         nn_ops.attention(qkv32, 2)
+
+
+@pytest.mark.parametrize("S,mode,use_act", [(64, "fp16c8-x2", True), (64, "bf16", False), (224, "fp16c8-x2", True)])
+def test_teacher_graph_every_replay_equals_the_eager_pass(S, mode, use_act):
+    """Round 6: the captured teacher pass must give the eager pass's bits on EVERY replay, not only on the first.  It did not: the min-max
+    normalisation initialised its per-plane keys with hipMemsetAsync, and inside a captured hipGraph those memset nodes were not ordered with the
+    kernels around them from the second replay on -- the auxiliary CAM came out NaN (and the main CAM altered at 224^2 / 448^2) in every step
+    of the benchmarked loop but the one that captured the graph; every test before this one looked at eager passes or at the first replay.
+    The keys are now set by a kernel (csrc/label_kernels.hip: minmax_init_kernel)."""
+    from cosa_amd import nn_ops
+    from cosa_amd.models import build_model
+    from cosa_amd.train_step import default_args, synthetic_batch
+    from cosa_amd.utils import seg_helper
+    dev = torch.device("cuda", 0)
+    wimg, _, lab, _ = synthetic_batch(2, S, 20, dev, seed=100)
+    args = default_args("VOC12", crop_size=S, batch_size=2)
+    torch.manual_seed(0)
+    net = build_model(args).to(dev).eval()
+    net.set_nograd_precision(mode)
+    nn_ops.ensure_shadows(net, net.compute_dtype)
+    bufs = {} if use_act else None
+    run = lambda: seg_helper.multi_scale_camseg(net, wimg, args.pseudo_scales, _active_labels=lab if use_act else None, _seg_scales=True, _buffers=bufs)
+    with torch.no_grad():
+        for _ in range(2):
+            e = run()
+        torch.cuda.synchronize()
+        ref = [e[0].clone(), e[1].clone()] + [t.clone() for t in e[2]]
+        assert all(torch.isfinite(t).all() for t in ref)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            out = run()
+        for rep in range(4):
+            g.replay()
+            torch.cuda.synchronize()
+            for name, c, r in zip(("cam", "cam_aux", "seg0", "seg1", "seg2"), [out[0], out[1]] + list(out[2]), ref):
+                assert torch.equal(c, r), (rep + 1, name, float((c - r).abs().max()))
+
+
+def test_trainer_with_the_captured_teacher_trains_the_same_weights_as_with_the_eager_one():
+    """the same at the level of the training loop: six steps with the teacher as a replayed hipGraph on the side stream (the benchmarked
+    configuration) and six with the eager teacher give bit-identical student and teacher weights and the same label maps in every step"""
+    from cosa_amd.train_step import CoSATrainer, default_args, synthetic_batch
+    dev = torch.device("cuda", 0)
+    wimg, simg, lab, box = synthetic_batch(2, 64, 20, dev, seed=100)
+    res = {}
+    for graph in (False, True):
+        tr = CoSATrainer(default_args("VOC12", crop_size=64, batch_size=2, teacher_graph=graph, lr=1e-3), dev, seed=0)
+        masks = []
+        for _ in range(6):
+            logs = tr.step(wimg, simg, lab, box, n_iter=10 ** 6)
+            masks.append(logs["mask"].clone())
+        torch.cuda.synchronize()
+        assert (tr._graph is not None) == graph
+        res[graph] = (masks, {k: v.detach().clone() for k, v in tr.student.named_parameters()}, {k: v.detach().clone() for k, v in tr.model_AN.named_parameters()})
+    for a, b in zip(res[False][0], res[True][0]):
+        assert torch.equal(a, b) and int(((a > 0) & (a < 255)).sum()) > 0
+    for i in (1, 2):
+        for k in res[False][i]:
+            assert torch.equal(res[False][i][k], res[True][i][k]), k

@@ -11,10 +11,10 @@ W=${1:?part: 1 | 2a | 2b | 3}
 R=gpurun_out/r06_accuracy_teacher.txt
 rm -f $R gpurun_out/r06_accuracy_teacher_par.txt
 run() { "$@" > gpurun_out/evidence_part$W.log 2>&1; tail -1 gpurun_out/evidence_part$W.log; }          # (a failing draw is on record: the run goes on)
-M4=fp16c8-x2,fp16c8,fp16c4-12m9,bf16x3
-M3=fp16c8-x2,fp16c8,fp16c4-12m9
+M4=fp16x3,fp16c8-x2,fp16c8,bf16x3
+M3=fp16x3,fp16c8-x2,fp16c8
 case $W in
-1)  COSA_ACCURACY_ALL_SEEDS=1 COSA_ACCURACY_B16_SEEDS=7,8,9,10 COSA_ACCURACY_SWEEP_SEEDS=1 run python -m pytest tests/test_precision_gpu.py -q -m gpu
+1)  COSA_ACCURACY_ALL_SEEDS=1 COSA_ACCURACY_B16_SEEDS=7,8,9,10 COSA_ACCURACY_B16_MODES=fp16x3,fp16c8-x2 COSA_ACCURACY_SWEEP_SEEDS=1 run python -m pytest tests/test_precision_gpu.py -q -m gpu
     sed -i "1a # part 1: tests/test_precision_gpu.py with COSA_ACCURACY_ALL_SEEDS=1 COSA_ACCURACY_B16_SEEDS=7,8,9,10: seven seeds at 224^2 / 448^2, four at 640^2, one sweep draw, four b = 16 batches" $R ;;
 2a) echo "# part 2a: COSA_ACCURACY_SWEEP_SEEDS=40 COSA_ACCURACY_SWEEP_BASE=100, modes $M4 (pytest -k sweep)" > $R.hdr
     COSA_ACCURACY_SWEEP_MODES=$M4 COSA_ACCURACY_SWEEP_SEEDS=40 COSA_ACCURACY_SWEEP_BASE=100 run python -m pytest tests/test_precision_gpu.py -q -m gpu -k "sweep or pooled" ;;
