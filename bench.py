@@ -11,9 +11,11 @@ regulariser, AdamW, EMA -- on one synthetic batch per rank, pos
 weights so every loss is live.  Workload = BASELINE.json configs[1]: VOC 21-class, ViT-B bf16,
 batch 16 x 448 x 448 per GPU (weak scaling).
 
-The headline `value` is measured in a TOLERANCE-CONFORMING mode (teacher operands fp16 + FP4 MX-block correction terms, student on an fp32 residual
-stream): top-level `tolerance_met` is read from the committed accuracy record of that mode.  `fast_mode` = the same step with the
-bf16-operand teacher of configs[1] read literally (faster, out of tolerance).
+The headline `value` is measured in the trainer's default mode -- the cheapest teacher-operand mode with no failed plane on the committed
+accuracy record under the pre-registered criterion (`conformance()` below; since round 6: fp16x3, hi + lo fp16 halves and three MFMA terms per
+product), student on an fp32 residual stream: top-level `tolerance_met` is read from that record and confirmed in the run.  `fast_mode` = the
+same step with the bf16-operand teacher of configs[1] read literally (faster, out of tolerance); `other_modes`: fp16c8-x2 (round 5's default:
+25 % faster, fails the float64-bounded exemption on planes of conditioning > 100), uniform fp16c8, bf16x3.
 
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
   roofline      the dominant hand-written kernel, timed with HIP events inside the timed steps
@@ -50,8 +52,9 @@ def parse():
     ap.add_argument("--teacher-precision", default="auto", type=_mode_arg,
                     metavar="{auto,bf16,fp16,bf16x3,fp16x3,fp16c8[-N[mK]|-xN[mK]],fp16c4[...]}",
                     help="MFMA operand precision of the teacher's no-grad passes in the HEADLINE run (DESIGN.md section 3).  The default (`auto`) is the "
-                         "cheapest mode that met BASELINE.json's tolerance (1e-3 relative on fp32 CAMs, mask IoU >= 0.999) on EVERY draw of the committed "
-                         "accuracy record (train_step.resolve_teacher_precision; margins: DESIGN.md section 3); "
+                         "cheapest mode with no failed plane on the committed accuracy record under the pre-registered criterion of "
+                         "tests/test_precision_gpu.py (literal normalised-CAM bar 1e-3; float64-bounded exemption above conditioning 50; pooled mask "
+                         "mIoU >= 0.999; >= 64 draws): train_step.resolve_teacher_precision; "
                          "`bf16` is BASELINE configs[1] read literally and does not meet it (measured beside the headline as `fast_mode`)")
     ap.add_argument("--no-secondary", "--no-parity-grade", dest="no_secondary", action="store_true",
                     help="skip the secondary measurements (`fast_mode`: bf16-operand teacher; `other_modes`)")
@@ -536,8 +539,8 @@ def configure_student(trainer, opt):
 
 def secondary_modes(opt, dev, C, wimg, simg, lab, box, n_iter):
     """`fast_mode`: the bf16-operand teacher (configs[1] literally; out of tolerance) -- or, when the headline itself is that mode, the
-    conforming default; `other_modes`: round 4's default fp16c4-12m9 (17 % faster; fails 12 of the 40 held-out draws of round 5's sweep --
-    its own `tolerance_met` says so), uniform fp16c8 (fails one of them) and bf16x3 in every block (holds everywhere with a 4.5x margin)"""
+    conforming default; `other_modes`: round 5's default fp16c8-x2 and uniform fp16c8 (~14-bit products: faster, each with failed planes on
+    record -- their own `tolerance_met` says so), fp16x3 / bf16x3 (three-term products with fp16 / bf16 halves)"""
     from cosa_amd import nn_ops
     st, gst = nn_ops.stamps, nn_ops.gemm_stamps
     nn_ops.stamps = nn_ops.gemm_stamps = None
@@ -548,7 +551,7 @@ def secondary_modes(opt, dev, C, wimg, simg, lab, box, n_iter):
         else:
             from cosa_amd.train_step import resolve_teacher_precision
             out["conforming_mode"] = secondary_run(opt, dev, C, wimg, simg, lab, box, n_iter, resolve_teacher_precision("auto", opt.crop, opt.usepar))
-        others = [m for m in ("fp16c8-x2", "fp16c4-12m9", "fp16c8", "fp16x3", "bf16x3") if m != opt.teacher_precision]
+        others = [m for m in ("fp16c8-x2", "fp16c8", "fp16x3", "bf16x3") if m != opt.teacher_precision]
         out["other_modes"] = {m: {k: v for k, v in secondary_run(opt, dev, C, wimg, simg, lab, box, n_iter, m).items() if k != "vit_forward"}
                                          for m in others}
     finally:
@@ -685,7 +688,7 @@ def main():
             return {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
                     "frac": round(ach * 1e12 / PEAK_BF16, 4), "issued_mfma_frac": round(issued / secs / PEAK_BF16, 4),
                     "note": "achieved / frac: ALGORITHMIC FLOPs (2 M N K per launch) over the launches' device time; issued_mfma_frac: the bf16-"
-                            "equivalent MFMA work the launches issue (fp16c4: 19 K-tiles per 12, fp16c8: 25 per 12, bf16x3: 37 per 12) over the same time",
+                            "equivalent MFMA work the launches issue (fp16c4: 19 K-tiles per 12, fp16c8: 25 per 12, fp16x3 / bf16x3: 37 per 12) over the same time",
                     "traffic": traffic, "launches": n_launch,
                     "avg_launch_ms": round(secs * 1e3 / n_launch, 4), "share_of_step": round(secs / (dt / opt.steps), 4),
                     "timer": "device s_memrealtime spans, last timed step" + ("" if opt.teacher_sync else
@@ -694,7 +697,8 @@ def main():
         c4mode = opt.teacher_precision.startswith("fp16c4")
         fams = [family(nn_ops.gemm_stamps, "gemm_bf16_v6_kernel (persistent 256x256 MFMA GEMM: qkv / proj+residual / fc1+GELU / fc2+residual; teacher "
                        "launches on " + ("fp16c4" if c4mode else opt.teacher_precision.split("-")[0]) + " operands, student launches on bf16)",
-                       "gemm_c4_pmc.json" if c4mode else ("gemm_c8_pmc.json" if opt.teacher_precision.startswith("fp16c8") else "gemm_v6_pmc.json"), "gemm_bf16"),
+                       "gemm_c4_pmc.json" if c4mode else ("gemm_c8_pmc.json" if opt.teacher_precision.startswith("fp16c8") else
+                                                          ("gemm_x3_pmc.json" if opt.teacher_precision.endswith("x3") else "gemm_v6_pmc.json")), "gemm_bf16"),
                 family(nn_ops.stamps, "attn_fwd2_kernel (fused attention forward)", "attn_fwd_pmc.json", "attn_fwd")]
         fams = sorted([f for f in fams if f], key=lambda f: -f["share_of_step"])
         roof = fams[0] if fams else None

@@ -60,18 +60,19 @@ def rank_seed(base, rank):
 
 
 def resolve_teacher_precision(mode, crop_size, usepar=False):
-    """"auto" -> the cheapest operand mode of the teacher's no-grad passes that kept BASELINE.json's tolerance (1e-3 on normalised CAMs, mask
-    IoU >= 0.999 against the fp32 CPU oracle) on EVERY weight / batch draw of the committed accuracy record (profiles/r05_accuracy_teacher.txt,
-    written by tests/test_precision_gpu.py: the seven seeds of round 4, a sweep of further draws at 448^2, one batch of b = 16, 224^2 and
-    640^2): "fp16c8-x2" -- fp16 operands + two e5m2 correction terms per product (fp16c8), the first two blocks on bf16x3 operands (16
-    significant bits: rounding injected there passes through the most layers).  Round 4's default fp16c4-12m9 held the bars on the seven seeds
-    it was chosen on and fails 12 of 40 held-out draws (worst 4.4e-3: random-init CAMs are nearly flat, and the min-max normalisation
-    amplifies the operand rounding by max|cam| / (max - min), which is heavy-tailed over weight draws); uniform fp16c8 fails one of them
-    (1.12e-3).  tests/test_boundary.py checks that the name returned here has no failing line on record.  "bf16" / "fp16c4-12m9" are faster
-    and out of tolerance."""
+    """"auto" -> the cheapest operand mode of the teacher's no-grad passes with NO failed plane on the committed accuracy record
+    (profiles/r06_accuracy_teacher.txt, written by tests/test_precision_gpu.py) under the criterion pre-registered there: per active CAM plane
+    the literal bar (normalised-CAM |delta| <= 1e-3), or -- only for planes of conditioning > 50 -- own-scale err <= 1e-3 AND |HIP - float64| <=
+    1e-3 + 4 x |fp32 - float64|; label agreement >= 0.999 per draw; mask mIoU >= 0.999 from a confusion matrix pooled over the draws; >= 64
+    draws.  Since round 6 that is "fp16x3": every MFMA operand as hi + lo fp16 halves (22 significant bits), three MFMA terms, attention
+    included.  Round 5's default "fp16c8-x2" (fp16 + two e5m2 correction terms, blocks 0-1 on bf16x3: ~14 bits, 25 % faster) keeps the
+    literal bar on every plane of conditioning <= 50 but fails the float64-bounded exemption on planes of conditioning > 100 (one of the
+    260 planes of the b = 16 record; on such a plane its literal figure moves by 1e-3 with the last bit of the inputs): selectable, reported by
+    bench.py as `other_modes`, not the default.  tests/test_boundary.py checks that the name returned here has no failed plane on record.
+    "bf16" (configs[1] literally) is 1.9x faster and an order of magnitude out of tolerance."""
     if mode != "auto":
         return mode
-    return "fp16c8-x2"
+    return "fp16x3"
 
 
 class CoSATrainer:

@@ -168,8 +168,8 @@ def test_teacher_precision_mode_strings():
     from cosa_amd.train_step import resolve_teacher_precision
     a = default_args("VOC12", crop_size=64)
     assert a.teacher_precision == "auto"
-    assert [resolve_teacher_precision("auto", c) for c in (224, 448, 512, 640)] == ["fp16c8-x2"] * 4
-    assert resolve_teacher_precision("bf16", 640) == "bf16" and resolve_teacher_precision("auto", 448, usepar=True) == "fp16c8-x2"
+    assert [resolve_teacher_precision("auto", c) for c in (224, 448, 512, 640)] == ["fp16x3"] * 4          # (round 6; rounds 5: fp16c8-x2)
+    assert resolve_teacher_precision("bf16", 640) == "bf16" and resolve_teacher_precision("auto", 448, usepar=True) == "fp16x3"
     net = build_model(a)
     for mode, hdt in (("bf16x3", torch.bfloat16), ("fp16x3", torch.float16)):          # the three-term path: bf16 halves / fp16 halves (round 6)
         net.set_nograd_precision(mode)

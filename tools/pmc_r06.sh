@@ -19,6 +19,19 @@ bash tools/pmc_collect.sh gemmc8f2 "tools/gemm_c8_one.py fc2" || exit 1
 python3 tools/pmc_summary.py gpurun_out/pmc_gemmc8f2 gemm_bf16_v6_kernel $((87904*3072*4 + 768*3072*4 + 87904*768*8)) "fc2 + residual M=87904 N=768 K=3072 (fp16c8 operands, fp32 stream in place)" gpurun_out/r06_gemm_c8_fc2_pmc.json > /dev/null || exit 1
 rm -rf gpurun_out/pmc_gemmc8 gpurun_out/pmc_gemmc8f2
 fi
+if [ "$which" = all ] || [ "$which" = gemmx3 ]; then
+# the default teacher's dominant launch since round 6: fp16x3 fc1 + GELU (split rows in and out: hi 2K + lo 2K per row) and fc2 + residual
+bash tools/pmc_collect.sh gemmx3 tools/gemm_x3_one.py || exit 1
+python3 tools/pmc_summary.py gpurun_out/pmc_gemmx3 gemm_bf16_v6_kernel $((87904*768*4 + 3072*768*4 + 87904*3072*4)) "fc1+GELU M=87904 N=3072 K=768 (fp16x3 operands: hi + lo fp16 halves, split rows out)" gpurun_out/r06_gemm_x3_pmc.json > /dev/null || exit 1
+bash tools/pmc_collect.sh gemmx3f2 "tools/gemm_x3_one.py fc2" || exit 1
+python3 tools/pmc_summary.py gpurun_out/pmc_gemmx3f2 gemm_bf16_v6_kernel $((87904*3072*4 + 768*3072*4 + 87904*768*8)) "fc2 + residual M=87904 N=768 K=3072 (fp16x3 operands, fp32 stream in place)" gpurun_out/r06_gemm_x3_fc2_pmc.json > /dev/null || exit 1
+rm -rf gpurun_out/pmc_gemmx3 gpurun_out/pmc_gemmx3f2
+fi
+if [ "$which" = all ] || [ "$which" = attnx3 ]; then
+bash tools/pmc_collect.sh attnx3 tools/bench_attn_x3.py || exit 1
+python3 tools/pmc_summary.py gpurun_out/pmc_attnx3 attn_fwd_x3_kernel $((32*1765*12*64*2*2*4)) "B=32 N=1765 H=12 (teacher scale 1.5), fp16x3 operands (q, k, v, out as hi + lo halves)" gpurun_out/r06_attn_x3_pmc.json > /dev/null || exit 1
+rm -rf gpurun_out/pmc_attnx3
+fi
 if [ "$which" = all ] || [ "$which" = attn ]; then
 bash tools/pmc_collect.sh attn4 tools/attn_one.py || exit 1
 python3 tools/pmc_summary.py gpurun_out/pmc_attn4 attn_fwd2_kernel 433766400 "B=32 N=1765 H=12 (teacher scale 1.5), fp16 operands, no-grad variant (flag bit 10), 4 waves per workgroup" gpurun_out/r06_attn_fwd_pmc.json > /dev/null || exit 1
