@@ -48,7 +48,7 @@ COCO_DEFAULTS = dict(eval_iters=6000, dataset='COCO', num_classes=81, batch_size
 EXTRA = [
     ("pretrained_path", str, None),          # local timm ViT-B/16 checkpoint for --pretrained true (no network here)
     ("name_list_dir", str, None),            # split lists / cls_labels_onehot.npy (default: ./dataloaders/<dataset>/ as the reference)
-    ("teacher_precision", str, "auto"), # auto (fp16c8-x2: train_step.resolve_teacher_precision) | bf16 | fp16 | bf16x3 | fp16c8[-n[mk]|-xn[mk]] | fp16c4[...]: operand precision of the teacher's no-grad passes;
+    ("teacher_precision", str, "auto"), # auto (fp16x3: train_step.resolve_teacher_precision) | bf16 | fp16 | bf16x3 | fp16x3 | fp16c8[-n[mk]|-xn[mk]] | fp16c4[...]: operand precision of the teacher's no-grad passes;
                                              # the default meets the 1e-3 / IoU 0.999 tolerance against the fp32 reference, bf16 (faster) does not
     ("log_iters", int, 20),
 ]

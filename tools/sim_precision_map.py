@@ -160,6 +160,10 @@ def prod(a, b, scheme):
         return y + (mm(al4, bh4) + mm(ah4, bl4)) / 2048.0
     if scheme == "hh":            # fp16 hi + fp16 lo on both sides, three fp16 terms (the fp16 analogue of x3: 22 significant bits)
         return y + mm(al.half().float(), bh) + mm(ah, bl.half().float())
+    if scheme == "hha":           # ... without the b-side lo half: two terms (a at 22 bits, b at 11)
+        return y + mm(al.half().float(), bh)
+    if scheme == "hhb":           # ... without the a-side lo half: two terms (a at 11 bits, b at 22)
+        return y + mm(ah, bl.half().float())
     raise ValueError(scheme)
 
 
