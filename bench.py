@@ -416,6 +416,40 @@ def vit_forward_roofline(trainer, wimg, dev, crop):
             "note": "algorithmic FLOPs of the fp32 reference / time; bf16x3 issues 3 MFMA terms per product, fp16c8 ~2.08 in the projections"}
 
 
+def teacher_attention_roofline(dev, batch, crop, mode):
+    """the attention kernel the teacher's default mode runs (attn_fwd_x3_kernel: hi + lo halves, three MFMA terms per product), stand-alone at
+    the three sequence lengths of a step (B = 2 x batch images), HIP events on the launch stream; `achieved` counts ALGORITHMIC flops
+    (4 N^2 64 per image and head), `issued_mfma_frac` the three terms.  (Inside the step these launches sit in the captured graph.)"""
+    from cosa_amd import nn_ops
+    if not mode.endswith("x3"):
+        return None
+    hdt = torch.float16 if mode == "fp16x3" else torch.bfloat16
+    B, H, p = 2 * batch, 12, 16
+    tot_fl = tot_s = 0.0
+    per = {}
+    for sc in (1.0, 0.5, 1.5):
+        N = (int(crop * sc) // p) ** 2 + 1
+        qkv = torch.randn(B * N, 3 * H * 64, device=dev) * 1.5
+        qs = nn_ops.split_rows(qkv, dtype=hdt)[:, :6 * H * 64].contiguous()
+        out = torch.zeros(B * N, 2 * H * 64 + 64, device=dev, dtype=hdt)
+        for _ in range(3):
+            nn_ops.attn_fwd_x3(qs, B, N, H, out)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(10):
+            nn_ops.attn_fwd_x3(qs, B, N, H, out)
+        b.record()
+        torch.cuda.synchronize()
+        sec = a.elapsed_time(b) * 1e-4
+        fl = 4.0 * B * H * N * N * 64
+        per[f"N={N}"] = {"us": round(sec * 1e6, 1), "algorithmic_TFLOPs": round(fl / sec / 1e12, 1)}
+        tot_fl, tot_s = tot_fl + fl, tot_s + sec
+    ach = tot_fl / tot_s / 1e12
+    return {"kernel": "attn_fwd_x3_kernel (" + mode + " operands)", "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
+            "frac": round(ach * 1e12 / PEAK_BF16, 4), "issued_mfma_frac": round(3 * ach * 1e12 / PEAK_BF16, 4), "launches": per,
+            "ms_per_block": round(tot_s * 1e3, 3), "timer": "HIP events, stand-alone launches at the step's three sequence lengths"}
+
+
 def live_accuracy_check(trainer, wimg, lab, box, n=16):
     """`tolerance_met` is read from the committed record (which must name this tree's kernel sources).  This is the same comparison made
     IN THE RUN: the teacher pass in the benchmarked mode against the bf16x3 pass (16 significant bits, on other kernels -- split-row GEMMs,
@@ -740,6 +774,9 @@ def main():
         vf = vit_forward_roofline(trainer, wimg, dev, opt.crop)
         if vf:
             out["vit_forward"] = vf
+        ta = teacher_attention_roofline(dev, opt.batch, opt.crop, opt.teacher_precision)
+        if ta:
+            out["teacher_attention"] = ta
         out["config"]["teacher_operands"] = opt.teacher_precision + ": " + MODE_TEXT[opt.teacher_precision]
         out["config"]["teacher_graph"] = {"captured": trainer._graph is not None, "side_stream": bool(trainer.teacher_async), "error": trainer.graph_error,
                                           "fallbacks": "COSA_TEACHER_SYNC=1 (replay on the main stream), COSA_TEACHER_GRAPH=0 (eager teacher)"}
