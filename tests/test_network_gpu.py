@@ -445,7 +445,7 @@ def test_teacher_pass_flip_equivariance_at_bench_size():
     assert (mf == m.flip(-1)).float().mean().item() > 0.99
 
 
-@pytest.mark.parametrize("flags", [["--steps", "1", "--warmup", "0"], ["--steps", "2", "--warmup", "1", "--usepar", "--usegmm"]])
+@pytest.mark.parametrize("flags", [["--steps", "1", "--warmup", "0"], ["--steps", "2", "--warmup", "1", "--usepar", "--usegmm", "--no-secondary"]])
 def test_bench_contract_small(flags):
     """bench.py as the driver calls it (own process), tiny configuration, warm-up counts below the graph-capture threshold: prints ONE JSON
     line with the contract's keys (profiling events must not be taken inside the teacher's graph capture)."""
