@@ -542,10 +542,10 @@ TEACHER_BARS = {
     "fp16": (4e-3, 0.9990, 0.995),
     "bf16x3": NORTH_STAR,
     "fp16x3": NORTH_STAR,          # round 6: the three-term path with fp16 halves (11 + 11 significant bits), same cost as bf16x3
-    "fp16c8": NORTH_STAR,          # fp16 + two e5m2 correction terms (round 3): inside the bar on these seeds; 1.12e-3 on ONE of 40 held-out draws
+    "fp16c8": NORTH_STAR,          # fp16 + two e5m2 correction terms (round 3): 3 failed planes on the round-6 record (conditioning 43 / 66 / 2199)
     "fp16c4": NORTH_STAR,          # round 4: FP4 (e2m1, MX blocks) correction terms in qkv / fc1 / fc2 of every block
-    "fp16c8-x2": NORTH_STAR,       # round 5: fp16c8 with blocks 0-1 on bf16x3 operands: the cheapest map that held the bars on all 40 held-out
-    #                                draws of the sweep below (worst 6.3e-4) -- the trainer's default
+    "fp16c8-x2": NORTH_STAR,       # round 5's default (fp16c8 with blocks 0-1 on bf16x3 operands): literal worst 7.3e-4 on seeds 100-139, but 3 failed
+    #                                planes on the round-6 record (224^2 seed 112: 1.75e-3 at conditioning 43; b = 16 seed 8; seed 210): not the default any more
     "fp16c4-12m9": ON_RECORD,      # round 4's default: holds the bars on the seven seeds it was chosen on, fails 12 of 40 held-out draws
     "fp16c8-9": ON_RECORD,         # round 3's benchmarked mode (last three blocks plain fp16): 1.06e-3 at 640^2 on one seed
     "fp16c4-10": ON_RECORD, "fp16c4-9": ON_RECORD,
@@ -671,9 +671,10 @@ def _check_teacher(mode, seed, S, bars=None, b=2):
 
 # ---- the wide sweep behind the headline: >= 32 further weight / batch draws at 448^2 and ONE batch of the bench's own size
 # (b = 16).  In the suite by default: SWEEP_DEFAULT draws (suite time); `COSA_ACCURACY_SWEEP_SEEDS=40 pytest -k sweep` writes the committed record
-# (profiles/r05_accuracy_teacher.txt).  Seeds 100-139 are disjoint from CONFORMING_SEEDS, on which round 4's block maps were chosen -- they are
-# what showed that fp16c4-12m9 and uniform fp16c8 do not hold, and the set the round-5 default (fp16c8-x2) was picked on; seeds 200-231
-# (COSA_ACCURACY_SWEEP_BASE=200) were drawn after that choice: held-out evidence for it.
+# (profiles/r06_accuracy_teacher.txt, tools/accuracy_evidence.sh).  Seeds 100-139 are disjoint from CONFORMING_SEEDS, on which round 4's block maps
+# were chosen -- they are what showed that fp16c4-12m9 and uniform fp16c8 do not hold, and the set the round-5 default (fp16c8-x2) was picked on;
+# seeds 200-231 (COSA_ACCURACY_SWEEP_BASE=200) were drawn after that choice; seeds 300-323 are round 6's, drawn after the criterion at the top
+# of this file was fixed and before fp16x3 existed: held-out for both.
 SWEEP_DEFAULT = 1
 SWEEP_SEEDS = int(os.environ.get("COSA_ACCURACY_SWEEP_SEEDS", str(SWEEP_DEFAULT)))
 SWEEP_BASE = int(os.environ.get("COSA_ACCURACY_SWEEP_BASE", "100"))        # 100-139: the draws the round-5 map was chosen on; 200-231: drawn after the choice
