@@ -733,7 +733,9 @@ def main():
                        "launches on " + ("fp16c4" if c4mode else opt.teacher_precision.split("-")[0]) + " operands, student launches on bf16)",
                        "gemm_c4_pmc.json" if c4mode else ("gemm_c8_pmc.json" if opt.teacher_precision.startswith("fp16c8") else
                                                           ("gemm_x3_pmc.json" if opt.teacher_precision.endswith("x3") else "gemm_v6_pmc.json")), "gemm_bf16"),
-                family(nn_ops.stamps, "attn_fwd2_kernel (fused attention forward)", "attn_fwd_pmc.json", "attn_fwd")]
+                family(nn_ops.stamps, ("attn_fwd_x3_kernel (teacher, three-term operands) + attn_fwd2_kernel (student)" if opt.teacher_precision.endswith("x3")
+                                       else "attn_fwd2_kernel (fused attention forward)"),
+                       "attn_x3_pmc.json" if opt.teacher_precision.endswith("x3") else "attn_fwd_pmc.json", "attn_fwd")]
         fams = sorted([f for f in fams if f], key=lambda f: -f["share_of_step"])
         roof = fams[0] if fams else None
         # the remaining legs time their own launches: stamping off (the buffers stay alive: the teacher's captured launches still write to them)

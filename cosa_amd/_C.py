@@ -121,7 +121,7 @@ _SIGS.update({
     "cosa_split_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, ctypes.c_longlong, c_int, c_void_p]),
     "cosa_layernorm_split": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     "cosa_gemm_bf16x3": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
-    "cosa_attn_fwd_bf16x3": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_int, c_void_p]),
+    "cosa_attn_fwd_bf16x3": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_int, c_void_p, c_void_p]),
     "cosa_lattice_filter_d2_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "cosa_lattice_filter_d2": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_size_t, c_void_p]),
     "cosa_c8_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, ctypes.c_longlong, c_int, c_void_p]),

@@ -109,9 +109,11 @@ __device__ __forceinline__ bool attn_block_map(int nblk, int ngroups, int H, int
 // kept in scratch: every tile waited for its global loads to store them, 1.02 ms per launch of the teacher's mix against 0.14 ms for
 // the bf16 kernel.)
 __global__ __launch_bounds__(256) void attn_fwd_x3_kernel(const op16 *__restrict__ qkv, op16 *__restrict__ out, float *__restrict__ lse,
-                                                         int N, int H, int nblk, int ngroups, float scale_log2e, int ldq, int ldo)
+                                                         int N, int H, int nblk, int ngroups, float scale_log2e, int ldq, int ldo,
+                                                         unsigned long long *__restrict__ stamps)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];          // [2 stages][Kh | Kl | Vh | Vl][64 * 128]
+    if (stamps && threadIdx.x == 0) atomicMin(&stamps[2 * (blockIdx.x & 63)], __builtin_amdgcn_s_memrealtime());     // device-clock span of the launch, as attn_fwd2_kernel
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
     int blk, b, h;
     if (!attn_block_map(nblk, ngroups, H, blk, b, h)) return;
@@ -282,6 +284,10 @@ __global__ __launch_bounds__(256) void attn_fwd_x3_kernel(const op16 *__restrict
             }
         }
         if (hh == 0 && lse) lse[((size_t)b * H + h) * N + q] = (m + __builtin_amdgcn_logf(l)) * 0.6931471805599453f;
+    }
+    if (stamps) {
+        __syncthreads();
+        if (threadIdx.x == 0) atomicMax(&stamps[2 * (blockIdx.x & 63) + 1], __builtin_amdgcn_s_memrealtime());
     }
 }
 
@@ -1086,7 +1092,7 @@ extern "C" int cosa_attn_fwd_f16c4(const void *qkv, void *out_c4, void *out_scal
 
 /* backward workspace: delta [B,H,N] f32 (the transposed operands come from transposing LDS reads now) */
 extern "C" int cosa_attn_fwd_bf16x3(const void *qkv_split, void *out_split, float *lse, int B, int N, int H, int head_dim, float scale,
-                                    int ldq, int ldo, void *stream)
+                                    int ldq, int ldo, uint64_t *stamps, void *stream)
 {
     COSA_REQUIRE(qkv_split && out_split && B > 0 && N > 0 && H > 0, "cosa_attn_fwd_bf16x3: bad arguments");
     COSA_REQUIRE(head_dim == HD, "cosa_attn_fwd_bf16x3: head_dim must be 64");
@@ -1101,7 +1107,8 @@ extern "C" int cosa_attn_fwd_bf16x3(const void *qkv_split, void *out_split, floa
         attr_done = true;
     }
     hipLaunchKernelGGL(attn_fwd_x3_kernel, dim3(grid), dim3(256), kLdsX3, as_stream(stream), static_cast<const op16 *>(qkv_split),
-                       static_cast<op16 *>(out_split), lse, N, H, nblk, ngroups, scale * 1.4426950408889634f, ldq, ldo);
+                       static_cast<op16 *>(out_split), lse, N, H, nblk, ngroups, scale * 1.4426950408889634f, ldq, ldo,
+                       reinterpret_cast<unsigned long long *>(stamps));
     COSA_LAUNCH_CHECK();
     return COSA_OK;
 }

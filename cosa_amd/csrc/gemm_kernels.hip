@@ -1613,7 +1613,9 @@ static int launch_v6(const op16 *x, const op16 *w, const op16 *b, const float *r
     // 45.83 / 45.96 ms, for the 4.03-round launches only 45.66 / 45.65, none 46.05 / 46.22
     const int rem = ntiles % 256, rounds_up = (ntiles + 255) / 256;
     // (fp16c8 operands: the 128 x 128 kernel knows their tile sequence for the residual epilogue -- the output projection, N = 768)
-    constexpr bool can_tail = FR == 4 && (SPLIT == 0 || (SPLIT == 3 && EPI == EPI_RESIDUAL));
+    // (three-term operands, SPLIT == 1 -- the default teacher's projections since round 6: the 128 x 128 kernel walks the same 3 K / 64 + 1 tile
+    // sequence, so its quarters are interchangeable with the persistent jobs bit for bit; N = 768: 1032 jobs = 4 x 256 + 8)
+    constexpr bool can_tail = FR == 4 && (SPLIT == 0 || SPLIT == 1 || (SPLIT == 3 && EPI == EPI_RESIDUAL));
     if (can_tail && ntiles > 256 && rem != 0 && rem <= tail_max && (256 - rem) * 10 > 256 * rounds_up)
         run = ntiles - rem;
     // The persistent grid is balanced over the rounds it needs anyway: 600 jobs are three rounds on 256 workgroups and on 200, and 200
@@ -1634,12 +1636,14 @@ static int launch_v6(const op16 *x, const op16 *w, const op16 *b, const float *r
     COSA_LAUNCH_CHECK();
     if constexpr (can_tail) {
         if (run < ntiles) {
+            // (split 16-bit outputs stage TWO epilogue tiles, hi and lo: 2 x 128 x 272 B, as cosa_gemm_bf16x3 sizes it)
+            constexpr int tail_lds = (SPLIT == 1 && 2 * BM * CT_LD > (int)kLdsBytes) ? 2 * BM * CT_LD : (int)kLdsBytes;
             static bool tail_attr = false;
             if (!tail_attr) {
-                COSA_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_bf16_kernel<EPI, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes));
+                COSA_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_bf16_kernel<EPI, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, tail_lds));
                 tail_attr = true;
             }
-            hipLaunchKernelGGL((gemm_bf16_kernel<EPI, SPLIT>), dim3(4 * (ntiles - run)), dim3(256), kLdsBytes, st, x, w, b, residual, Y, M, N, K, tiles_m, tiles_n,
+            hipLaunchKernelGGL((gemm_bf16_kernel<EPI, SPLIT>), dim3(4 * (ntiles - run)), dim3(256), tail_lds, st, x, w, b, residual, Y, M, N, K, tiles_m, tiles_n,
                                ld ? ld : K, ldy ? ldy : N, static_cast<void *>(nullptr), run);
             COSA_LAUNCH_CHECK();
         }

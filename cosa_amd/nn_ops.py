@@ -411,8 +411,10 @@ def gemm_x3(xs, ws, M, N, K, epilogue=EPI_BIAS, residual=None, out=None, ldy=Non
 def attn_fwd_x3(qkv_s, B, N, H, out_s, lse=None):
     """attention on split qkv rows [B*N, ldq] -> split rows out_s [B*N, ldo] (hi | lo | aug) for the output projection"""
     assert out_s.dtype == qkv_s.dtype
+    fl = 4.0 * B * H * N * N * 64          # algorithmic; issued: three MFMA terms per product
+    st = stamps.next_slot(fl, 3.0 * fl) if stamps is not None else None
     _C.check(_x3_fn("cosa_attn_fwd_bf16x3", qkv_s.dtype)(_C.ptr(qkv_s), _C.ptr(out_s), _C.ptr(lse), B, N, H, 64, 0.125, qkv_s.stride(0),
-                                                         out_s.stride(0), _C.stream_ptr()), "cosa_attn_fwd_x3")
+                                                         out_s.stride(0), st, _C.stream_ptr()), "cosa_attn_fwd_x3")
     _flops["attn_x3"] = _flops.get("attn_x3", 0) + 12.0 * B * H * N * N * 64
     return out_s
 

@@ -343,7 +343,7 @@ int cosa_layernorm_split(const float *x, const float *gamma, const float *beta, 
 int cosa_gemm_bf16x3(const void *Xs, const void *Ws, const void *zeros, const float *residual, void *Y,
                      int M, int N, int K, int epilogue, int ldy, void *stream);
 int cosa_attn_fwd_bf16x3(const void *qkv_split, void *out_split, float *lse, int B, int N, int H, int head_dim, float scale,
-                         int ldq, int ldo, void *stream);
+                         int ldq, int ldo, uint64_t *stamps /* optional device-clock span of the launch, as cosa_attn_fwd */, void *stream);
 /* fp16x3 (round 6): the same four entry points with hi = fp16(v), lo = fp16(v - hi) halves -- 11 + 11 significant bits (a lo half below 2^-14
  * is an fp16 subnormal: an absolute 2^-24), three fp16 MFMA terms, same cost as bf16x3 and ~10x closer to the fp32 reference
  * (tools/sim_precision_map.py scheme `hh`).  Same layouts with fp16 halves; the attention carries its probabilities scaled by 2^10 so that
@@ -354,7 +354,7 @@ int cosa_layernorm_split_f16(const float *x, const float *gamma, const float *be
 int cosa_gemm_f16x3(const void *Xs, const void *Ws, const void *zeros, const float *residual, void *Y,
                     int M, int N, int K, int epilogue, int ldy, void *stream);
 int cosa_attn_fwd_f16x3(const void *qkv_split, void *out_split, float *lse, int B, int N, int H, int head_dim, float scale,
-                        int ldq, int ldo, void *stream);
+                        int ldq, int ldo, uint64_t *stamps, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * utils/seg_helper.py:961-996 (DenseCRF / crf_inference_infv2, final evaluation only): the position-only Gaussian kernel of the dense

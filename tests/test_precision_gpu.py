@@ -134,6 +134,36 @@ def test_gemm_bf16x3_vs_fp64(epi, hdt):
 
 
 @pytest.mark.parametrize("hdt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("epi", [0, 1, 2])
+def test_gemm_x3_tail_launch_is_interchangeable_with_persistent_jobs(epi, hdt):
+    """round 6: the three-term GEMM's leftover jobs (N = 768 at the teacher's M: 1032 = 4 x 256 + 8) run as 128 x 128 quarters on the two-stage
+    kernel instead of as a fifth round of the persistent one (launch_v6).  M = 66 000, N = 768: 774 jobs = 3 rounds + 6.  A token's result must
+    not depend on which kernel computed it: rolling the rows of X by half the matrix (every row changes tile, most change kernel) rolls the
+    output and nothing else, bit for bit -- split 16-bit outputs (two epilogue tiles in LDS) and the fp32 residual form."""
+    from cosa_amd import nn_ops
+    torch.manual_seed(epi)
+    M, N, K = 66000, 768, 768
+    x = torch.randn(M, K, device="cuda")
+    w = torch.randn(N, K, device="cuda") * K ** -0.5
+    b = torch.randn(N, device="cuda")
+    r = torch.randn(M, N, device="cuda") if epi == 2 else None
+    sh = 33000 + 128
+    ws = nn_ops.split_rows(w, bias=b, dtype=hdt)
+    run = lambda xx, rr: nn_ops.gemm_x3(nn_ops.split_rows(xx, ones=True, dtype=hdt), ws, M, N, K, epi, residual=rr.clone() if rr is not None else None,
+                                        ldy=2 * N + 64 if epi != 2 else None)
+    y = run(x, r)
+    y2 = run(x.roll(sh, 0).contiguous(), r.roll(sh, 0).contiguous() if r is not None else None)
+    assert torch.equal(y2[:, :2 * N] if epi != 2 else y2, (y[:, :2 * N] if epi != 2 else y).roll(sh, 0))
+    ref = x.double() @ w.double().t() + b.double()
+    if epi == 1:
+        ref = torch.nn.functional.gelu(ref)
+    got = y.double() if epi == 2 else y[:, :N].double() + y[:, N:2 * N].double()
+    if epi == 2:
+        ref = ref + r.double()
+    assert (got - ref).abs().max().item() <= _X3[hdt][0] * max(ref.abs().max().item(), 1.0)
+
+
+@pytest.mark.parametrize("hdt", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("B,N,H", [(2, 197, 12), (1, 785, 3), (2, 100, 3), (1, 1765, 2), (1, 1, 1), (1, 129, 1)])
 def test_attention_bf16x3_vs_fp64(B, N, H, hdt):
     from cosa_amd import nn_ops
