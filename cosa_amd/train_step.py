@@ -394,8 +394,11 @@ def smoke():
     args = default_args("VOC12", crop_size=128)
     tr = CoSATrainer(args, dev)
     wimg, simg, lab, box = synthetic_batch(2, 128, 20, dev, seed=1)
-    logs = tr.step(wimg, simg, lab, box, n_iter=args.warmup_iters + 1)
+    for _ in range(5):          # (the third call captures the teacher's hipGraph, the following ones replay it: the benchmarked configuration)
+        logs = tr.step(wimg, simg, lab, box, n_iter=args.warmup_iters + 1)
     torch.cuda.synchronize()
     vals = {k: float(v) for k, v in logs.items() if torch.is_tensor(v) and v.numel() == 1}
     assert all(math.isfinite(v) for v in vals.values()), vals
+    assert tr._graph is not None and all(bool(torch.isfinite(t).all()) for t in tr._s_out[:2]), "the replayed teacher pass must give finite CAMs"
+    assert int(((logs["mask"] > 0) & (logs["mask"] < 255)).sum()) > 0, "a replayed step produced a label map without foreground"
     print("train_step smoke:", {k: round(v, 5) for k, v in vals.items()})
