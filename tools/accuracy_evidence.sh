@@ -6,8 +6,9 @@
 #   part 2a: 40 held-out draws at 448^2 (seeds 100-139: the set round 5's default was chosen on), four modes
 #   part 2b: 32 more (seeds 200-231: drawn after that choice) + 24 new in round 6 (300-323: drawn after the criterion was pre-registered)
 #   part 3:  32 draws at 224^2, 12 at 640^2, three modes
+#   part 4:  40 draws at 448^2 with seeds 400-439, drawn AFTER the default mode was chosen (fp16x3, fp16c8-x2, bf16x3), + the four b = 16 batches for bf16x3
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT (the repository root on the GPU box)}" || exit 1
-W=${1:?part: 1 | 2a | 2b | 3}
+W=${1:?part: 1 | 2a | 2b | 3 | 4}
 R=gpurun_out/r06_accuracy_teacher.txt
 rm -f $R gpurun_out/r06_accuracy_teacher_par.txt
 run() { "$@" > gpurun_out/evidence_part$W.log 2>&1; tail -1 gpurun_out/evidence_part$W.log; }          # (a failing draw is on record: the run goes on)
@@ -24,6 +25,9 @@ case $W in
 3)  echo "# part 3: COSA_ACCURACY_SWEEP_S=224 COSA_ACCURACY_SWEEP_SEEDS=32 and COSA_ACCURACY_SWEEP_S=640 COSA_ACCURACY_SWEEP_SEEDS=12 (seeds 100 + i), modes $M3" > $R.hdr
     COSA_ACCURACY_SWEEP_MODES=$M3 COSA_ACCURACY_SWEEP_S=224 COSA_ACCURACY_SWEEP_SEEDS=32 run python -m pytest tests/test_precision_gpu.py -q -m gpu -k "sweep or pooled"
     COSA_ACCURACY_SWEEP_MODES=$M3 COSA_ACCURACY_SWEEP_S=640 COSA_ACCURACY_SWEEP_SEEDS=12 run python -m pytest tests/test_precision_gpu.py -q -m gpu -k "sweep or pooled" ;;
+4)  echo "# part 4: COSA_ACCURACY_SWEEP_SEEDS=40 COSA_ACCURACY_SWEEP_BASE=400 (drawn after the default was chosen), modes fp16x3,fp16c8-x2,bf16x3; COSA_ACCURACY_B16_SEEDS=7,8,9,10 for bf16x3" > $R.hdr
+    COSA_ACCURACY_SWEEP_MODES=fp16x3,fp16c8-x2,bf16x3 COSA_ACCURACY_SWEEP_SEEDS=40 COSA_ACCURACY_SWEEP_BASE=400 run python -m pytest tests/test_precision_gpu.py -q -m gpu -k "sweep or pooled"
+    COSA_ACCURACY_B16_SEEDS=7,8,9,10 COSA_ACCURACY_B16_MODES=bf16x3 run python -m pytest tests/test_precision_gpu.py -q -m gpu -k "b16 or pooled" ;;
 esac
 [ -f $R.hdr ] && { sed -i "1r $R.hdr" $R; rm -f $R.hdr; }
 cp $R gpurun_out/r06_accuracy_teacher_part$W.txt
