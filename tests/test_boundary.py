@@ -219,6 +219,11 @@ def test_auto_teacher_precision_is_backed_by_the_committed_accuracy_record():
         assert c["tolerance_met"] or "another tree" in c.get("note", ""), (crop, c)      # (a source change after the record was taken is bench.py's business: it then reports false)
     c = bench.conformance(resolve_teacher_precision("auto", 448), 448)
     assert c["draws"] >= bench.MIN_DRAWS and c["seeds"] >= 32 and 16 in c["batch_sizes"], c          # the wide sweep and the bench's own batch size
+    # held out in the strict sense: seeds 300-323 were drawn after the criterion was fixed, 400-439 after the default mode was chosen
+    rows, _ = bench.parse_accuracy_record(bench.newest_profile("accuracy_teacher.txt"))
+    mode = resolve_teacher_precision("auto", 448)
+    late = {r["seed"] for r in rows if r["mode"] == mode and r["S"] == 448 and r["seed"] >= 300}
+    assert len(late) >= bench.MIN_DRAWS and not any(r["fail"] for r in rows if r["mode"] == mode and r["seed"] >= 300), len(late)
 
 
 def test_no_inline_asm_valu_on_mfma_accumulators():
