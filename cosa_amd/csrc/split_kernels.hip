@@ -65,6 +65,59 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float *__restrict
     }
 }
 
+// ---- im2col of the stride-16 patch projection for an image batch and (flips = 2) its horizontal flip, written as SPLIT rows INTO a token
+// matrix (the x3 analogue of vit_kernels.hip: im2col_flip_c8_kernel): the row of patch (f, b, py, px) is
+//     cols[c*P*P + dy*P + dx] = x[b][c][P*py + dy][f ? W-1-(P*px+dx) : P*px+dx]          as  [hi | lo | aug = (1, 1, 0, ...)]
+// at token row (f*B + b) * (h*w + cls_rows) + cls_rows + py*w + px: every image's patch rows leave `cls_rows` rows in front of them untouched --
+// the class-token slots of the token matrix, zero for good (augmentation block included: no bias there) -- so that ONE patch projection over
+// the tokens of all scales adds into the fp32 residual stream in place.  Replaces flip + cat, the permuted .contiguous(), split_rows, the
+// position-row broadcast and two concatenations per scale of the x3 teacher (0.75 ms per step in ATen kernels, round 6).
+template <typename T>
+__global__ __launch_bounds__(256) void im2col_flip_split_kernel(const float *__restrict__ x, T *__restrict__ rows, int B, int C, int H, int W, int P,
+                                                               int flips, int cls_rows)
+{
+    const int h = H / P, w = W / P, KC = C * P * P, K8 = KC / 8;
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t total = (size_t)flips * B * h * w * K8;
+    if (e >= total) return;
+    const int k8 = (int)(e % K8), k = k8 * 8;
+    const size_t row_id = e / K8;
+    size_t row = row_id;
+    const int px = (int)(row % w);
+    row /= w;
+    const int py = (int)(row % h);
+    row /= h;
+    const int b = (int)(row % B), f = (int)(row / B);
+    const int c = k / (P * P), dy = (k - c * P * P) / P, dx = k % P;          // P % 8 == 0: the 8 elements share (c, dy)
+    const float *src = x + (((size_t)b * C + c) * H + (size_t)P * py + dy) * W;
+    const int x0 = P * px + dx;
+    float v0[4], v1[4];
+    if (!f) {
+        const float4 a = *reinterpret_cast<const float4 *>(src + x0), d = *reinterpret_cast<const float4 *>(src + x0 + 4);
+        v0[0] = a.x; v0[1] = a.y; v0[2] = a.z; v0[3] = a.w; v1[0] = d.x; v1[1] = d.y; v1[2] = d.z; v1[3] = d.w;
+    } else {
+        const int xe = W - 8 - x0;                                             // source columns xe .. xe + 7, reversed
+        const float4 a = *reinterpret_cast<const float4 *>(src + xe), d = *reinterpret_cast<const float4 *>(src + xe + 4);
+        v0[0] = d.w; v0[1] = d.z; v0[2] = d.y; v0[3] = d.x; v1[0] = a.w; v1[1] = a.z; v1[2] = a.y; v1[3] = a.x;
+    }
+    const size_t out_row = row_id + (size_t)cls_rows * ((size_t)(f * B + b) + 1);
+    T *r = rows + out_row * (size_t)(2 * KC + 64);
+    vec4<T> h0, l0, h1, l1;
+    split4<T>(v0, h0, l0);
+    split4<T>(v1, h1, l1);
+    *reinterpret_cast<vec4<T> *>(r + k) = h0;
+    *reinterpret_cast<vec4<T> *>(r + k + 4) = h1;
+    *reinterpret_cast<vec4<T> *>(r + KC + k) = l0;
+    *reinterpret_cast<vec4<T> *>(r + KC + k + 4) = l1;
+    if (k8 < 8) {                                     // augmentation block: 8 threads x 8 halves
+        vec8<T> a;
+#pragma unroll
+        for (int j = 0; j < 8; j++) a[j] = (T)0.f;
+        if (k8 == 0) { a[0] = (T)1.f; a[1] = (T)1.f; }
+        *reinterpret_cast<vec8<T> *>(r + 2 * KC + 8 * k8) = a;
+    }
+}
+
 template <int D, typename T>
 __global__ __launch_bounds__(256) void layernorm_split_kernel(const float *__restrict__ x, const float *__restrict__ g, const float *__restrict__ b,
                                                              T *__restrict__ y, float *__restrict__ y32, int rows, float eps)
@@ -441,6 +494,32 @@ static int layernorm_split_launch(const float *x, const float *gamma, const floa
                        static_cast<T *>(y_split), y_f32, rows, eps);
     COSA_LAUNCH_CHECK();
     return COSA_OK;
+}
+
+template <typename T>
+static int im2col_flip_split_launch(const float *x, void *rows, int B, int C, int H, int W, int P, int flips, int cls_rows, void *stream)
+{
+    COSA_REQUIRE(x && rows && B > 0 && C > 0 && H > 0 && W > 0 && P > 0 && cls_rows >= 0, "cosa_im2col_flip_split_tokens: bad arguments");
+    COSA_REQUIRE(P % 8 == 0 && H % P == 0 && W % P == 0 && W % 4 == 0, "cosa_im2col_flip_split_tokens: patch size must be a multiple of 8 and divide H and W (got P=%d H=%d W=%d)", P, H, W);
+    COSA_REQUIRE((flips == 1 || flips == 2) && (C * P * P) % 64 == 0, "cosa_im2col_flip_split_tokens: flips 1 | 2, C*P*P %% 64 == 0");
+    const size_t total = (size_t)flips * B * (H / P) * (W / P) * (C * P * P / 8);
+    COSA_REQUIRE(total / 256 < 0x7fffffffull, "cosa_im2col_flip_split_tokens: too many elements for one launch");
+    hipLaunchKernelGGL(im2col_flip_split_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), x, static_cast<T *>(rows), B, C, H, W, P,
+                       flips, cls_rows);
+    COSA_LAUNCH_CHECK();
+    return COSA_OK;
+}
+
+/* split rows (hi | lo | aug, bf16 halves; _f16: fp16 halves) of the im2col view of x [B,C,H,W] (flips = 1) or cat(x, x.flip(-1)) (flips = 2)
+ * written INTO a token matrix [flips * B * (h*w + cls_rows), 2 C P P + 64]: image (f, b)'s patch rows start at row (f*B + b) * (h*w + cls_rows) +
+ * cls_rows; the rows in between are not touched (vit.py:254-262 PatchEmbed as a GEMM over token rows; seg_helper.py:241-246 the flip pair) */
+extern "C" int cosa_im2col_flip_split_tokens(const float *x, void *rows, int B, int C, int H, int W, int P, int flips, int cls_rows, void *stream)
+{
+    return im2col_flip_split_launch<bf16>(x, rows, B, C, H, W, P, flips, cls_rows, stream);
+}
+extern "C" int cosa_im2col_flip_split_tokens_f16(const float *x, void *rows, int B, int C, int H, int W, int P, int flips, int cls_rows, void *stream)
+{
+    return im2col_flip_split_launch<_Float16>(x, rows, B, C, H, W, P, flips, cls_rows, stream);
 }
 
 extern "C" int cosa_split_rows(const float *src, const float *bias, void *dst, int R, int K, long long src_ld, int ones, void *stream)

@@ -217,7 +217,7 @@ class VisionTransformer(nn.Module):
         better tile quantisation on 256 CUs, a third of the launches); only attention runs per scale, on its slice of
         the packed qkv buffer."""
         if self.precision == "bf16x3":
-            return self._forward_features_x3_multi([torch.cat([x, x.flip(-1)], dim=0) for x in xs] if flip_pairs else xs)
+            return self._forward_features_x3_multi(xs, flip_pairs)
         if self.precision in ("fp16c8", "fp16c4"):
             return self._forward_features_c8_multi(xs, flip_pairs)
         dt16 = self.compute_dtype                                # bf16, or fp16 (no-grad passes only: same kernels, fp16 operands)
@@ -316,28 +316,44 @@ class VisionTransformer(nn.Module):
             bufs[(M, dev, dtype)] = ent
         return ent
 
-    def _forward_features_x3_multi(self, xs):
+    def _forward_features_x3_multi(self, xs, flip_pairs=False):
+        from .. import _C
         D, H = self.embed_dim, self.num_heads
         p = self.patch_size
         hdt = self.x3_dtype                      # bf16 halves ("bf16x3") or fp16 halves ("fp16x3", round 6: 11 + 11 significant bits at the same cost)
         W = self._split_weights(dtype=hdt)
-        toks, shapes = [], []
-        for x in xs:
-            B, nc, Hh, Ww = x.shape
-            h, w = Hh // p, Ww // p
-            cols = x.float().reshape(B, nc, h, p, w, p).permute(0, 2, 4, 1, 3, 5).reshape(B * h * w, nc * p * p)
-            pos = self._pos_for_grid(h, w, torch.float32)                              # [1, n+1, D]
-            tok = pos[:, 1:].expand(B, -1, -1).contiguous().view(B * h * w, D)          # residual operand: the position rows
-            nn_ops.gemm_x3(nn_ops.split_rows(cols, ones=True, dtype=hdt), W["patch"], B * h * w, D, nc * p * p, nn_ops.EPI_RESIDUAL, residual=tok, out=tok)
-            cls = (self.cls_token.detach().float() + pos[:, :1]).expand(B, -1, -1)
-            toks.append(torch.cat((cls, tok.view(B, h * w, D)), dim=1).reshape(-1, D))
-            shapes.append((B, h * w + 1))
-        xr = toks[0].contiguous() if len(toks) == 1 else torch.cat(toks, 0)
+        nf = 2 if flip_pairs else 1              # flip_pairs: every batch stands for cat(x, x.flip(-1)) (the teacher's passes)
+        # token assembly without ATen passes (as the fp16c8 path has it): the residual stream xr [sum_i B_i (n_i + 1), D] starts as
+        # (cls + pos_0 | pos rows) per image, the im2col kernel writes the split rows of the patches (images and their mirror images) into a
+        # token-shaped operand whose class-token rows stay zero (augmentation block included: no bias there), and the patch projection of
+        # a scale adds into xr in place through its fp32 residual epilogue.  One launch per scale, as before: cosa_gemm_bf16x3 picks its kernel by
+        # M (the 128 x 128 kernel below 4096 rows: another summation order than the persistent one), so per token row the same products are
+        # summed in the same order as with one projection per scale on materialised im2col rows (the form up to round 6): bit-identical CAMs.
+        shapes = [(nf * x.shape[0], (x.shape[2] // p) * (x.shape[3] // p) + 1) for x in xs]
         offs = [0]
         for B, N in shapes:
             offs.append(offs[-1] + B * N)
         M = offs[-1]
-        bf = self._x3_buffers(M, xr.device, dtype=hdt)
+        dev = xs[0].device
+        Kp = xs[0].shape[1] * p * p
+        bf = self._x3_buffers(M, dev, dtype=hdt)
+        ckey = ("cols", tuple(shapes), Kp)
+        cols = bf.get(ckey)
+        if cols is None:
+            for k in [k for k in bf if isinstance(k, tuple) and k[0] == "cols"]:
+                del bf[k]                                                                 # (another token geometry at the same M: its zero rows are elsewhere)
+            cols = bf[ckey] = torch.zeros((M, nn_ops.split_ld(Kp)), device=dev, dtype=hdt)      # (class-token rows: zero for good)
+        xr = torch.empty((M, D), device=dev, dtype=torch.float32)
+        cls = self.cls_token.detach().float().reshape(1, 1, D)
+        for x, (B, N), o0, o1 in zip(xs, shapes, offs[:-1], offs[1:]):
+            h, w = x.shape[2] // p, x.shape[3] // p
+            pos = self._pos_for_grid(h, w, torch.float32)                              # [1, n+1, D]
+            first = torch.cat((cls + pos[:, :1], pos[:, 1:]), dim=1).contiguous()       # (a [n+1, D] tensor: small)
+            _C.check(_C.lib().cosa_broadcast_rows(_C.ptr(first), _C.ptr(xr[o0:o1]), B, N * D, _C.stream_ptr()), "cosa_broadcast_rows")
+            xf = x.float().contiguous()
+            _C.check(nn_ops._x3_fn("cosa_im2col_flip_split_tokens", hdt)(_C.ptr(xf), _C.ptr(cols[o0:o1]), x.shape[0], x.shape[1], x.shape[2], x.shape[3],
+                                                                       p, nf, 1, _C.stream_ptr()), "cosa_im2col_flip_split_tokens")
+            nn_ops.gemm_x3(cols[o0:o1], W["patch"], B * N, D, Kp, nn_ops.EPI_RESIDUAL, residual=xr[o0:o1], out=xr[o0:o1])
         depth = len(self.blocks)
         aux_idx = self.aux_layer % depth
         aux = None

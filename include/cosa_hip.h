@@ -261,6 +261,10 @@ int cosa_im2col_flip(const float *x, void *cols, int B, int C, int H, int W, int
 /* the dtype-3 form writing into a token matrix with cls_rows free rows in front of every image's patch rows (kept zero by the caller): the
  * patch projection's fp32 residual epilogue then produces the residual stream [images, 1 + n, D] in place, without concatenations */
 int cosa_im2col_flip_c8_tokens(const float *x, void *rows, int B, int C, int H, int W, int P, int flips, int cls_rows, void *stream);
+/* the same token-shaped operand as split rows (hi | lo | aug = (1, 1, 0, ...); bf16 halves, `_f16`: fp16 halves) for the three-term (bf16x3 /
+ * fp16x3) patch projection: rows [flips * B * (h*w + cls_rows), 2 C P P + 64], class-token rows untouched (vit.py:254-262, seg_helper.py:241-246) */
+int cosa_im2col_flip_split_tokens(const float *x, void *rows, int B, int C, int H, int W, int P, int flips, int cls_rows, void *stream);
+int cosa_im2col_flip_split_tokens_f16(const float *x, void *rows, int B, int C, int H, int W, int P, int flips, int cls_rows, void *stream);
 /* vit.py:303-313 (prepare_tokens: cat(cls_token, patch tokens) + interpolated pos_embed) for the no-grad passes, written straight into
  * the fp32 residual stream: out [B, n+1, D] = (cls [D] | tok [B, n, D]) + pos [n+1, D]; tok / cls / pos share one 16-bit type
  * (dtype 1 = bf16, 2 = fp16), each sum is rounded to that type before it is widened (the 16-bit torch expression's value); D % 8 == 0. */

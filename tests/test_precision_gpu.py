@@ -268,6 +268,29 @@ def test_c8_rows_and_layernorm_c8_fields():
     assert torch.equal(aug[:, :2].cpu(), torch.ones(1000, 2)) and aug[:, 2:].abs().max().item() == 0
 
 
+@pytest.mark.parametrize("hdt", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+def test_im2col_split_tokens_equal_split_rows_of_the_im2col_view(hdt):
+    """cosa_im2col_flip_split_tokens[_f16] (round 6: the x3 teacher's patch rows written into a token-shaped operand) = split_rows(ones) of the
+    im2col view of cat(x, x.flip(-1)), bit for bit, at the rows behind every image's class-token slot; the slots and the canary row stay untouched"""
+    from cosa_amd import nn_ops, _C
+    torch.manual_seed(6)
+    p = 16
+    for B, H, W in ((3, 64, 96), (2, 224, 224), (1, 16, 16)):
+        x = torch.randn(B, 3, H, W, device="cuda") * 2
+        h, w = H // p, W // p
+        n = h * w
+        for flips in (1, 2):
+            for cls_rows in (1, 0):
+                rows = torch.full((flips * B * (n + cls_rows) + 1, nn_ops.split_ld(768)), 7.0, device="cuda", dtype=hdt)      # one canary row
+                _C.check(nn_ops._x3_fn("cosa_im2col_flip_split_tokens", hdt)(_C.ptr(x), _C.ptr(rows), B, 3, H, W, p, flips, cls_rows, _C.stream_ptr()), "im2col")
+                xx = torch.cat([x, x.flip(-1)], 0) if flips == 2 else x
+                cols = xx.reshape(flips * B, 3, h, p, w, p).permute(0, 2, 4, 1, 3, 5).reshape(flips * B * n, 768).contiguous()
+                want = nn_ops.split_rows(cols, ones=True, dtype=hdt).view(flips * B, n, -1)
+                got = rows[:-1].view(flips * B, n + cls_rows, -1)
+                assert torch.equal(got[:, cls_rows:].contiguous().view(torch.int16), want.contiguous().view(torch.int16))
+                assert torch.all(got[:, :cls_rows] == 7.0) and torch.all(rows[-1] == 7.0)
+
+
 def test_im2col_c8_and_batched_weight_rows_equal_the_row_producer():
     """cosa_im2col_flip(dtype 3) = c8_rows of the im2col view of cat(x, x.flip(-1)); cosa_c8_rows_batched (all weight matrices of a network in
     one launch) = c8_rows per matrix -- both bit for bit"""
